@@ -1,0 +1,201 @@
+// gemm.hip — LDS-tiled MFMA GEMM for every dense layer of the HULC++ low-level policy.
+//
+//   C[M,N] = epilogue( alpha * sum_k A[m,k] * B[n,k] )
+//
+// serves, with one kernel template:
+//   * forward Linear  y = x W^T + b              (A = x  k-major, B = W   k-major)
+//       reference: nn.Linear in hulc2/models/plan_encoders/plan_proposal_net.py:26-40,
+//       goal_encoders.py:21-27, vision_network.py:49-52, logistic_decoder_rnn.py:60-62
+//   * data gradient   dx = dy W                   (A = dy k-major, B = W   stored [K][N])
+//   * weight gradient dW = dy^T x                 (A = dy stored [K][M], B = x stored [K][N])
+//   * ReLU-RNN step   h_t = relu(pre_t + h_{t-1} W_hh^T)  (add + relu epilogue)
+//       reference: nn.RNN(nonlinearity="relu") hulc2/models/decoders/utils/rnn.py:5-14
+//
+// Tile: each wave owns TM x TN accumulators of 32x32 (v_mfma_f32_32x32x16_bf16 or the exact
+// v_mfma_f32_32x32x2_f32); WM x WN waves per workgroup; operands are converted to the compute type
+// while staged (global -> registers -> LDS, double-buffered, next tile's loads in flight during MFMA).
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+struct GemmP {
+    const void* A; const void* B; void* C;
+    const float* bias; const void* add; const void* mask;
+    int M, N, K;
+    long lda, ldb, ldc, ld_add, ld_mask;
+    int a_dtype, b_dtype, c_dtype, add_dtype, mask_dtype;
+    int relu, accumulate;
+    float alpha, mask_scale, drop_p;
+    unsigned long long drop_seed;
+};
+
+// Load the 8-element k-chunk (row r, k0..k0+7) of an operand.
+//   KMAJOR : operand stored [rows][K], k contiguous   -> one or two 16-byte loads
+//   !KMAJOR: operand stored [K][rows], row contiguous -> 8 strided loads (coalesced across lanes)
+template <bool KMAJOR>
+HULC_DEVICE void load_operand_chunk(Chunk8& c, const void* base, int dtype, long ld, int rows, int K, int r, int k0) {
+    if (k0 >= K) { chunk_zero(c); return; }
+    r = r < rows ? r : rows - 1;   // clamp: out-of-range rows are computed but never stored
+    if (KMAJOR) {
+        chunk_load_contig(c, base, dtype, (long)r * ld + k0);
+    } else {
+        int nvalid = K - k0; nvalid = nvalid > 8 ? 8 : nvalid;
+        chunk_load_strided(c, base, dtype, (long)k0 * ld + r, ld, nvalid);
+    }
+}
+
+template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
+    using T = MmaTraits<CT>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int KT = T::KT, NCH = T::NCH, CHB = T::CHB;
+    constexpr int A_CH = BM * NCH, B_CH = BN * NCH;           // chunks per tile
+    constexpr int A_PER = (A_CH + NT - 1) / NT, B_PER = (B_CH + NT - 1) / NT;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * HULC_ROWB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // blockIdx.x walks M fastest so that blocks sharing a weight (B) panel are co-resident
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Chunk8 ra[A_PER], rb[B_PER];
+    const int nkt = (p.K + KT - 1) / KT;
+
+    // chunk id -> (row, chunk-in-row).  k-major sources: consecutive threads walk k first (one row's
+    // 64..128 contiguous bytes per 2..4 threads); row-major sources: consecutive threads walk rows
+    // (each strided load instruction is a contiguous row segment across the wave).
+    auto a_map = [&](int id, int& r, int& ch) { if (AK) { r = id / NCH; ch = id % NCH; } else { r = id % BM; ch = id / BM; } };
+    auto b_map = [&](int id, int& r, int& ch) { if (BK) { r = id / NCH; ch = id % NCH; } else { r = id % BN; ch = id / BN; } };
+
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            int id = tid + q * NT;
+            if (A_CH % NT == 0 || id < A_CH) {
+                int r, ch; a_map(id, r, ch);
+                load_operand_chunk<AK>(ra[q], p.A, p.a_dtype, p.lda, p.M, p.K, m0 + r, kt * KT + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            int id = tid + q * NT;
+            if (B_CH % NT == 0 || id < B_CH) {
+                int r, ch; b_map(id, r, ch);
+                load_operand_chunk<BK>(rb[q], p.B, p.b_dtype, p.ldb, p.N, p.K, n0 + r, kt * KT + ch * 8);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        char* Bs = As + BM * HULC_ROWB;
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            int id = tid + q * NT;
+            if (A_CH % NT == 0 || id < A_CH) {
+                int r, ch; a_map(id, r, ch);
+                chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            int id = tid + q * NT;
+            if (B_CH % NT == 0 || id < B_CH) {
+                int r, ch; b_map(id, r, ch);
+                chunk_store_lds<CT>(Bs + r * HULC_ROWB + ch * CHB, rb[q]);
+            }
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        const char* Bs = As + BM * HULC_ROWB;
+        MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns column n = lane & 31 of each tile; each accumulator register is one row.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][e] + bv;
+                if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
+                if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
+                const long ci = (long)m * p.ldc + n;
+                if (p.accumulate) v += load_elem(p.C, p.c_dtype, ci);
+                store_elem(p.C, p.c_dtype, ci, v);
+            }
+        }
+    }
+}
+
+template <typename CT, int TM, int TN, int WM, int WN>
+void launch_cfg(const GemmP& p, int ak, int bk, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), block(WM * WN * 64);
+    if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p);
+    else if (ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, true, false><<<grid, block, 0, s>>>(p);
+    else if (!ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, false, false><<<grid, block, 0, s>>>(p);
+    else gemm_kernel<CT, TM, TN, WM, WN, false, true><<<grid, block, 0, s>>>(p);
+}
+
+template <typename CT>
+void launch_ct(const GemmP& p, int ak, int bk, hipStream_t s) {
+    // tile choice: keep >= ~256 workgroups when the problem allows it (256 CUs), shrink BM for the
+    // skinny per-sequence layers (M = batch = 32) so no MFMA rows are wasted.
+    const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.M <= 32) launch_cfg<CT, 1, 1, 1, 4>(p, ak, bk, s);          // 32 x 128
+    else if (p.M <= 64 || blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, s);   // 64 x 64
+    else launch_cfg<CT, 2, 2, 2, 2>(p, ak, bk, s);                    // 128 x 128
+}
+
+}  // namespace
+
+extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return hulc_fail(-1, "hulc_gemm: null operand");
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return hulc_fail(-2, "hulc_gemm: non-positive dimension");
+    if (d->K % 8 != 0 && (d->a_kmajor || d->b_kmajor)) return hulc_fail(-3, "hulc_gemm: K must be a multiple of 8 for k-major operands");
+    const int asz = d->a_dtype == HULC_F32 ? 4 : 2, bsz = d->b_dtype == HULC_F32 ? 4 : 2;
+    if (d->a_kmajor && (((uintptr_t)d->A % 16) || (d->lda * asz) % 16)) return hulc_fail(-4, "hulc_gemm: A not 16-byte aligned");
+    if (d->b_kmajor && (((uintptr_t)d->B % 16) || (d->ldb * bsz) % 16)) return hulc_fail(-4, "hulc_gemm: B not 16-byte aligned");
+    if (d->compute == HULC_F32 && (d->a_dtype != HULC_F32 || d->b_dtype != HULC_F32))
+        return hulc_fail(-5, "hulc_gemm: f32 compute requires f32 operands");
+    GemmP p;
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.add = d->add; p.mask = d->mask;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ld_add = d->ld_add; p.ld_mask = d->ld_mask;
+    p.a_dtype = d->a_dtype; p.b_dtype = d->b_dtype; p.c_dtype = d->c_dtype;
+    p.add_dtype = d->add_dtype; p.mask_dtype = d->mask_dtype;
+    p.relu = d->relu; p.accumulate = d->accumulate;
+    p.alpha = d->alpha; p.mask_scale = d->mask_scale; p.drop_p = d->drop_p; p.drop_seed = d->drop_seed;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->compute == HULC_F32) launch_ct<float>(p, d->a_kmajor, d->b_kmajor, s);
+    else launch_ct<bf16_t>(p, d->a_kmajor, d->b_kmajor, s);
+    return hulc_check_launch("hulc_gemm");
+}

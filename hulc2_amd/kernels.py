@@ -1,0 +1,75 @@
+"""Thin typed wrappers over the C ABI (include/hulc2_amd.h): tensors in, raw pointers out.
+
+Everything here takes device tensors, extracts `data_ptr()` / strides and calls libhulc2_amd.so on
+the current torch stream.  No arithmetic happens in Python.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib as _L
+
+F32, BF16 = 0, 1
+_COMPUTE = {"bf16": BF16, "fp32": F32, "f32": F32}
+_compute_mode = BF16
+
+
+def set_compute(mode: str) -> None:
+    """Select MFMA arithmetic: 'bf16' (v_mfma_f32_32x32x16_bf16, fp32 accumulate) or 'fp32' (exact)."""
+    global _compute_mode
+    _compute_mode = _COMPUTE[mode]
+
+
+def get_compute() -> str:
+    return "bf16" if _compute_mode == BF16 else "fp32"
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _L.HulcKernelError(
+                "hulc2_amd kernels run on MI355X device memory only; got a CPU tensor "
+                "(there is no CPU fallback — use oracle/ for CPU reference values in tests)"
+            )
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=None, add=None, ld_add=0,
+         mask=None, ld_mask=0, mask_scale=1.0, relu=False, accumulate=False, alpha=1.0, drop_p=0.0,
+         drop_seed=0, compute=None):
+    """C[M,N] = epi(alpha * A·B^T); see hulc_gemm in include/hulc2_amd.h."""
+    _require_cuda(A, B, C, bias, add, mask)
+    d = _L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.add = add.data_ptr() if add is not None else None
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ld_add, d.ld_mask = lda, ldb, ldc, ld_add, ld_mask
+    d.a_dtype, d.b_dtype, d.c_dtype = _dt(A), _dt(B), _dt(C)
+    d.add_dtype = _dt(add) if add is not None else F32
+    d.mask_dtype = _dt(mask) if mask is not None else F32
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.relu, d.accumulate = int(relu), int(accumulate)
+    d.alpha, d.mask_scale, d.drop_p, d.drop_seed = alpha, mask_scale, drop_p, drop_seed
+    d.compute = _compute_mode if compute is None else compute
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be float32")
+    _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
+    return C

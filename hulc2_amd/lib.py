@@ -1,0 +1,60 @@
+"""ctypes loader for libhulc2_amd.so — the only way compute enters the product path.
+
+There is no CPU or eager-PyTorch fallback: if the HIP library is missing or a kernel rejects a call,
+the caller gets an exception (the oracle under oracle/ is test infrastructure and is never imported
+from here).
+"""
+import ctypes
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libhulc2_amd.so"
+_lib = None
+
+
+class HulcKernelError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("add", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("lda", ctypes.c_long), ("ldb", ctypes.c_long), ("ldc", ctypes.c_long),
+        ("ld_add", ctypes.c_long), ("ld_mask", ctypes.c_long),
+        ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int), ("c_dtype", ctypes.c_int),
+        ("add_dtype", ctypes.c_int), ("mask_dtype", ctypes.c_int),
+        ("a_kmajor", ctypes.c_int), ("b_kmajor", ctypes.c_int),
+        ("relu", ctypes.c_int), ("accumulate", ctypes.c_int),
+        ("alpha", ctypes.c_float), ("mask_scale", ctypes.c_float), ("drop_p", ctypes.c_float),
+        ("drop_seed", ctypes.c_ulonglong),
+        ("compute", ctypes.c_int),
+    ]
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise HulcKernelError(
+            f"{_LIB_PATH} is missing: build it with `python -m hulc2_amd.build` "
+            "(hipcc --offload-arch=gfx950). hulc2_amd has no non-HIP fallback."
+        )
+    lib = ctypes.CDLL(os.fspath(_LIB_PATH))
+    lib.hulc_last_error.restype = ctypes.c_char_p
+    lib.hulc_abi_version.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().hulc_last_error().decode(errors="replace")
+        raise HulcKernelError(f"{what} failed with code {rc}: {msg}")
