@@ -1,0 +1,107 @@
+"""Deterministic synthetic parameters and CALVIN-shaped batches.
+
+Used by bench.py (device-resident synthetic play sequences), by the golden-fixture
+generator and by the tests: because values are a pure function of (name, shape, seed) the fixtures
+under tests/golden/ only need to carry seeds + checksums instead of 47 M parameters.
+"""
+import math
+import zlib
+from typing import Dict
+
+import torch
+
+
+def _gen(seed: int, name: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2**63 - 1))
+    return g
+
+
+@torch.no_grad()
+def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
+    """In-place, order-independent init of every floating tensor of a state_dict whose keys follow the
+    reference's names.  Weights/biases ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (the nn.Linear/Conv default
+    scale), LayerNorm gains 1 + 0.1 N(0,1), LayerNorm biases 0.1 N(0,1), embeddings N(0,1).
+    Registered buffers (maps, bounds, eye) are left untouched."""
+    skip = ("x_map", "y_map", "temperature", "one_hot_embedding_eye", ".ones", "gripper_bounds",
+            "action_max_bound", "action_min_bound")
+    for name, t in sd.items():
+        if not t.is_floating_point() or any(s in name for s in skip):
+            continue
+        g = _gen(seed, name)
+        leaf = name.rsplit(".", 1)[-1]
+        if name == "logit_scale":
+            t.fill_(math.log(1 / 0.07))
+        elif ".ln." in name or ".norm1." in name or ".norm2." in name or ".layernorm." in name:
+            r = torch.randn(t.shape, generator=g) * 0.1
+            t.copy_(r + 1.0 if leaf == "weight" else r)
+        elif "position_embeddings" in name:
+            t.copy_(torch.randn(t.shape, generator=g))
+        else:
+            if t.dim() >= 2:
+                bound = 1.0 / math.sqrt(t[0].numel())
+            elif "bias_ih" in name or "bias_hh" in name:
+                bound = 1.0 / math.sqrt(t.numel())
+            else:
+                bound = 0.05
+            t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
+
+
+def checksum(sd: Dict[str, torch.Tensor]) -> Dict[str, float]:
+    """Per-tensor (sum, abs-sum) in float64 — stored in fixtures to prove the recipe reproduced."""
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point():
+            d = v.detach().double()
+            out[k] = (float(d.sum()), float(d.abs().sum()))
+    return out
+
+
+def make_modality_batch(seed: int, name: str, B: int, S: int, lang: bool, static_hw=(200, 200),
+                        gripper_hw=(84, 84), device="cpu") -> Dict:
+    """One modality's batch in the reference's nested-dict contract (hulc2.py:336-361):
+    images ~ U(-1,1) (post Normalize(0.5,0.5) range), actions ~ U(-1,1) with a ±1 gripper command,
+    state_info.robot_obs (15) with euler angles in columns 3:6, lang ~ 0.05 N(0,1) (B,384)."""
+    g = _gen(seed, "batch." + name)
+
+    def u(*shape):
+        return torch.rand(shape, generator=g) * 2 - 1
+
+    rgb_static = u(B, S, 3, *static_hw)
+    rgb_gripper = u(B, S, 3, *gripper_hw)
+    robot_obs = torch.randn(B, S, 8, generator=g)
+    state_robot_obs = torch.randn(B, S, 15, generator=g)
+    state_robot_obs[..., 3:6] = u(B, S, 3) * (math.pi * 0.5)
+    actions = u(B, S, 7)
+    actions[..., 6] = (torch.rand(B, S, generator=g) < 0.5).float() * 2 - 1
+    plan_idx = torch.randint(0, 32, (B, 32), generator=g)
+    batch = {
+        "rgb_obs": {"rgb_static": rgb_static, "rgb_gripper": rgb_gripper},
+        "depth_obs": {},
+        "robot_obs": robot_obs,
+        "actions": actions,
+        "state_info": {"robot_obs": state_robot_obs},
+        "idx": torch.arange(B),
+        "lang": torch.empty(0),
+        "plan_idx": plan_idx,      # not part of the reference contract: injected categorical sample for parity
+    }
+    if lang:
+        batch["lang"] = torch.randn(B, 384, generator=g) * 0.05
+        batch["use_for_aux_lang_loss"] = torch.ones(B, dtype=torch.bool)
+    return _to(batch, device)
+
+
+def make_batch(seed: int, B: int, S: int, device="cpu", **kw) -> Dict[str, Dict]:
+    """{'vis': ..., 'lang': ...} as the reference's CombinedLoader yields (hulc2.py:379)."""
+    return {
+        "vis": make_modality_batch(seed, "vis", B, S, lang=False, device=device, **kw),
+        "lang": make_modality_batch(seed, "lang", B, S, lang=True, device=device, **kw),
+    }
+
+
+def _to(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if isinstance(x, dict):
+        return {k: _to(v, device) for k, v in x.items()}
+    return x

@@ -1,0 +1,411 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own leaf modules on CPU (fp32).
+
+Runs only in the build container (needs /root/reference); the GPU box receives the fixtures, never the
+reference.  Nothing is copied from the reference: its modules are imported in place through stub
+packages that bypass hulc2/models/__init__.py (which eagerly imports torchvision/r3m, absent here) and
+two name-only stubs for `omegaconf` / `pytorch3d.transforms` (imported by logistic_decoder_rnn.py:6,13
+but never called with gripper_control=False, load_action_bounds=False).
+
+hulc2/models/hulc2.py and concat_encoders.py need hydra + pytorch_lightning and cannot be imported;
+they hold no arithmetic beyond composition, so the whole-step fixtures compose the
+imported leaf modules in the order of hulc2.py:379-442 / :200-245 / :444-466 / :472-508.
+
+Parameters and inputs are a pure function of (name, seed) — hulc2_amd/synthetic.py — so fixtures carry
+seeds, checksums, outputs and selected gradients only.
+
+usage: python oracle/gen_golden.py
+"""
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributions as D
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+from hulc2_amd import synthetic as syn  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+
+def _stub_pkg(name: str, path: Path):
+    m = types.ModuleType(name)
+    m.__path__ = [str(path)]
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    for name, rel in [
+        ("hulc2", "hulc2"), ("hulc2.models", "hulc2/models"), ("hulc2.utils", "hulc2/utils"),
+        ("hulc2.models.decoders", "hulc2/models/decoders"), ("hulc2.models.decoders.utils", "hulc2/models/decoders/utils"),
+        ("hulc2.models.perceptual_encoders", "hulc2/models/perceptual_encoders"),
+        ("hulc2.models.plan_encoders", "hulc2/models/plan_encoders"), ("hulc2.models.encoders", "hulc2/models/encoders"),
+        ("hulc2.models.auxiliary_loss_networks", "hulc2/models/auxiliary_loss_networks"),
+    ]:
+        _stub_pkg(name, REF / rel)
+    oc = types.ModuleType("omegaconf")
+    oc.ListConfig = list
+    oc.OmegaConf = type("OmegaConf", (), {})
+    oc.DictConfig = dict
+    sys.modules["omegaconf"] = oc
+    p3 = types.ModuleType("pytorch3d")
+    p3t = types.ModuleType("pytorch3d.transforms")
+    for n in ("euler_angles_to_matrix", "matrix_to_euler_angles", "matrix_to_quaternion", "quaternion_to_matrix"):
+        setattr(p3t, n, None)
+    sys.modules["pytorch3d"], sys.modules["pytorch3d.transforms"] = p3, p3t
+    import importlib
+
+    mods = {}
+    for short, full in [
+        ("dist", "hulc2.utils.distributions"),
+        ("vn", "hulc2.models.perceptual_encoders.vision_network"),
+        ("vng", "hulc2.models.perceptual_encoders.vision_network_gripper"),
+        ("prn", "hulc2.models.plan_encoders.plan_recognition_net"),
+        ("ppn", "hulc2.models.plan_encoders.plan_proposal_net"),
+        ("goal", "hulc2.models.encoders.goal_encoders"),
+        ("dec", "hulc2.models.decoders.logistic_decoder_rnn"),
+        ("pvl", "hulc2.models.auxiliary_loss_networks.proj_vis_lang"),
+    ]:
+        mods[short] = importlib.import_module(full)
+    return mods
+
+
+def build_reference_modules(R, seed: int):
+    """Instantiate the reference leaf modules with the kwargs of conf/model/** (cfg_low_level with
+    model/perceptual_encoder/rgb_static=default input_height=200, language_encoder=none) and load the
+    synthetic parameters.  Returns (modules dict, flat state_dict under Hulc2's attribute names)."""
+    dist = R["dist"].Distribution(dist="discrete", category_size=32, class_size=32)
+    m = {
+        "perceptual_encoder.rgb_static_encoder": R["vn"].VisionNetwork(
+            input_width=200, input_height=200, activation_function="ReLU", dropout_vis_fc=0.0, l2_normalize_output=False,
+            visual_features=64, num_c=3, use_sinusoid=False, spatial_softmax_temp=1.0),
+        "perceptual_encoder.rgb_gripper_encoder": R["vng"].VisionNetwork(
+            input_width=84, input_height=84, conv_encoder="nature_cnn", activation_function="ReLU", dropout_vis_fc=0.0,
+            l2_normalize_output=False, visual_features=64, num_c=3),
+        "plan_proposal": R["ppn"].PlanProposalNetwork(
+            perceptual_features=128, latent_goal_features=32, plan_features=1024, activation_function="ReLU",
+            hidden_size=2048, dist=dist),
+        "plan_recognition": R["prn"].PlanRecognitionTransformersNetwork(
+            num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, plan_features=1024, in_features=128,
+            action_space=7, encoder_normalize=False, positional_normalize=False, position_embedding=True,
+            max_position_embeddings=32, dropout_p=0.0, dist=dist),
+        "visual_goal": R["goal"].VisualGoalEncoder(
+            hidden_size=2048, latent_goal_features=32, in_features=128, l2_normalize_goal_embeddings=False,
+            activation_function="ReLU"),
+        "language_goal": R["goal"].LanguageGoalEncoder(
+            lang_net=None, in_features=384, hidden_size=2048, latent_goal_features=32, l2_normalize_goal_embeddings=False,
+            word_dropout_p=0.0, activation_function="ReLU"),
+        "action_decoder": R["dec"].LogisticDecoderRNN(
+            perceptual_features=128, latent_goal_features=32, plan_features=1024, n_mixtures=10, hidden_size=2048,
+            out_features=7, log_scale_min=-7.0, act_max_bound=[1.0] * 7, act_min_bound=[-1.0] * 7, dataset_dir="",
+            load_action_bounds=False, num_classes=10, gripper_alpha=1.0, perceptual_emb_slice=[64, 128],
+            policy_rnn_dropout_p=0.0, num_layers=2, rnn_model="rnn_decoder", gripper_control=False, discrete_gripper=True),
+        "proj_vis_lang": R["pvl"].ProjVisLang(im_dim=4096, lang_dim=32, output_dim=32, proj_lang=True),
+    }
+    flat = {}
+    for prefix, mod in m.items():
+        mod.train()   # training_step semantics; every dropout on this config has p = 0
+        for k, v in mod.state_dict().items():
+            flat[f"{prefix}.{k}"] = v
+    flat["logit_scale"] = torch.nn.Parameter(torch.ones([]))
+    syn.fill_state_dict_(flat, seed)        # in place: state_dict tensors alias the parameters
+    return m, dist, flat
+
+
+def g(seed, name):
+    return syn._gen(seed, name)
+
+
+def randu(seed, name, *shape):
+    return torch.rand(shape, generator=g(seed, name)) * 2 - 1
+
+
+def randn(seed, name, *shape):
+    return torch.randn(shape, generator=g(seed, name))
+
+
+def save(name, **arrays):
+    OUT.mkdir(parents=True, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(OUT / f"{name}.npz", **conv)
+    print(f"  wrote {name}.npz  ({(OUT / (name + '.npz')).stat().st_size >> 10} KiB)")
+
+
+def params_of(mod):
+    return dict(mod.named_parameters())
+
+
+def zero_grads(mods):
+    for m in mods.values():
+        for p in m.parameters():
+            p.grad = None
+
+
+def checksum_arrays(flat, prefix):
+    cs = syn.checksum({k: v for k, v in flat.items() if k.startswith(prefix)})
+    keys = sorted(cs)
+    return np.array(keys), np.array([cs[k] for k in keys], dtype=np.float64)
+
+
+SEED = 7
+
+
+def gen_vision(m, flat):
+    for tag, key, hw, n in [("vision_static", "perceptual_encoder.rgb_static_encoder", 200, 2),
+                            ("vision_gripper", "perceptual_encoder.rgb_gripper_encoder", 84, 2)]:
+        net = m[key]
+        zero_grads(m)
+        x = randu(SEED, "x." + tag, n, 3, hw, hw)
+        conv = net.conv_model[:6](x) if tag == "vision_gripper" else net.conv_model(x)
+        out = net(x)
+        r = randn(SEED, "r." + tag, *out.shape)
+        (out * r).sum().backward()
+        P = params_of(net)
+        ck, cv = checksum_arrays(flat, key)
+        arrays = dict(seed=SEED, n=n, hw=hw, out=out, conv3_frame0=conv[0], ck=ck, cv=cv,
+                      g_conv0_w=P["conv_model.0.weight"].grad, g_conv0_b=P["conv_model.0.bias"].grad,
+                      g_conv2_w_s=P["conv_model.2.weight"].grad[::4, ::4], g_conv2_b=P["conv_model.2.bias"].grad,
+                      g_conv4_w_s=P["conv_model.4.weight"].grad[::4, ::4], g_conv4_b=P["conv_model.4.bias"].grad,
+                      g_fc1_w_s=P["fc1.0.weight"].grad[::8, ::4], g_fc1_b=P["fc1.0.bias"].grad,
+                      g_fc2_w=P["fc2.weight"].grad, g_ln_w=P["ln.weight"].grad, g_ln_b=P["ln.bias"].grad)
+        if tag == "vision_static":
+            arrays["ssm"] = net.spatial_softmax(net.conv_model(x))
+        else:
+            arrays["g_fc0_w_s"] = P["conv_model.7.weight"].grad[::4, ::16]
+            arrays["g_fc0_b"] = P["conv_model.7.bias"].grad
+        save(tag, **arrays)
+
+
+def gen_goal_and_proposal(m, flat):
+    zero_grads(m)
+    B = 4
+    xv = randn(SEED, "x.visual_goal", B, 128).requires_grad_()
+    xl = (randn(SEED, "x.language_goal", B, 384) * 0.05).requires_grad_()
+    ov, ol = m["visual_goal"](xv), m["language_goal"](xl)
+    rv, rl = randn(SEED, "r.visual_goal", B, 32), randn(SEED, "r.language_goal", B, 32)
+    ((ov * rv).sum() + (ol * rl).sum()).backward()
+    Pv, Pl = params_of(m["visual_goal"]), params_of(m["language_goal"])
+    ck, cv = checksum_arrays(flat, "visual_goal")
+    ck2, cv2 = checksum_arrays(flat, "language_goal")
+    save("goal_encoders", seed=SEED, B=B, out_vis=ov, out_lang=ol, gx_vis=xv.grad, gx_lang=xl.grad,
+         g_vis_mlp0_w_s=Pv["mlp.0.weight"].grad[::16], g_vis_mlp4_w=Pv["mlp.4.weight"].grad, g_vis_ln_w=Pv["ln.weight"].grad,
+         g_lang_mlp1_w_s=Pl["mlp.1.weight"].grad[::16], g_lang_mlp5_b=Pl["mlp.5.bias"].grad, g_lang_ln_b=Pl["ln.bias"].grad,
+         ck=np.concatenate([ck, ck2]), cv=np.concatenate([cv, cv2]))
+
+    zero_grads(m)
+    e0 = randn(SEED, "x.plan_proposal.emb", B, 128).requires_grad_()
+    gl = randn(SEED, "x.plan_proposal.goal", B, 32).requires_grad_()
+    st = m["plan_proposal"](e0, gl)
+    r = randn(SEED, "r.plan_proposal", B, 1024)
+    (st.logit * r).sum().backward()
+    P = params_of(m["plan_proposal"])
+    ck, cv = checksum_arrays(flat, "plan_proposal")
+    save("plan_proposal", seed=SEED, B=B, logits=st.logit, g_emb=e0.grad, g_goal=gl.grad,
+         g_fc0_w_s=P["fc_model.0.weight"].grad[::16], g_fc6_b=P["fc_model.6.bias"].grad,
+         g_state_w_s=P["fc_state.0.weight"].grad[::8, ::8], ck=ck, cv=cv)
+
+
+def gen_plan_recognition(m, flat):
+    net = m["plan_recognition"]
+    P = params_of(net)
+    for S in (16, 32):
+        zero_grads(m)
+        B = 2
+        x = randn(SEED, f"x.plan_recognition.{S}", B, S, 128).requires_grad_()
+        st, feat = net(x)
+        r1, r2 = randn(SEED, f"r1.plan_recognition.{S}", B, 1024), randn(SEED, f"r2.plan_recognition.{S}", B, 4096)
+        ((st.logit * r1).sum() + (feat * r2).sum()).backward()
+        ck, cv = checksum_arrays(flat, "plan_recognition")
+        save(f"plan_recognition_S{S}", seed=SEED, B=B, S=S, logits=st.logit, seq_feat=feat, gx=x.grad,
+             position_ids=np.arange(S, dtype=np.int64),
+             g_pos=P["position_embeddings.weight"].grad,
+             g_inproj_w=P["transformer_encoder.layers.0.self_attn.in_proj_weight"].grad,
+             g_inproj_b=P["transformer_encoder.layers.1.self_attn.in_proj_bias"].grad,
+             g_outproj_w=P["transformer_encoder.layers.1.self_attn.out_proj.weight"].grad,
+             g_lin1_w_s=P["transformer_encoder.layers.0.linear1.weight"].grad[::8],
+             g_lin2_b=P["transformer_encoder.layers.0.linear2.bias"].grad,
+             g_norm1_w=P["transformer_encoder.layers.0.norm1.weight"].grad,
+             g_norm2_b=P["transformer_encoder.layers.1.norm2.bias"].grad,
+             g_fc_w_s=P["fc.weight"].grad[::16], g_fc_b=P["fc.bias"].grad,
+             g_state_w_s=P["fc_state.0.weight"].grad[::8, ::16], ck=ck, cv=cv)
+
+
+def ref_kl(dist, pp_logit, pr_logit, kl_beta=0.01, mix=0.8):
+    """hulc2.py:444-466 restated with the reference's own Distribution + torch.distributions."""
+    DS = sys.modules["hulc2.utils.distributions"].DiscState
+    pp_state, pr_state = DS(pp_logit), DS(pr_logit)
+    pp_dist, pr_dist = dist.get_dist(pp_state), dist.get_dist(pr_state)
+    lhs = D.kl_divergence(dist.get_dist(dist.detach_state(pr_state)), pp_dist).mean()
+    rhs = D.kl_divergence(pr_dist, dist.get_dist(dist.detach_state(pp_state))).mean()
+    return (mix * lhs + (1 - mix) * rhs) * kl_beta
+
+
+def ref_rsample_with_idx(dist, logit, idx):
+    """OneHotCategoricalStraightThrough.rsample() = sample + (probs - probs.detach()) with the sample
+    replaced by one_hot(idx) (torch/distributions/one_hot_categorical.py), then flatten (hulc2.py:235-237)."""
+    DS = sys.modules["hulc2.utils.distributions"].DiscState
+    d = dist.get_dist(DS(logit))
+    probs = d.base_dist.probs
+    onehot = F.one_hot(idx, 32).to(probs.dtype)
+    return torch.flatten(onehot + (probs - probs.detach()), start_dim=-2, end_dim=-1)
+
+
+def gen_dist(dist):
+    B = 3
+    pp = (randn(SEED, "x.kl.pp", B, 1024) * 2).requires_grad_()
+    pr = (randn(SEED, "x.kl.pr", B, 1024) * 2).requires_grad_()
+    idx = torch.randint(0, 32, (B, 32), generator=g(SEED, "x.kl.idx"))
+    kl = ref_kl(dist, pp, pr)
+    plan = ref_rsample_with_idx(dist, pr, idx)
+    r = randn(SEED, "r.kl.plan", B, 1024)
+    (kl + (plan * r).sum() * 1e-3).backward()
+    save("distribution_kl", seed=SEED, B=B, pp=pp, pr=pr, idx=idx, kl=kl, plan=plan, r=r, g_pp=pp.grad, g_pr=pr.grad)
+
+
+def gen_decoder(m, flat):
+    dec = m["action_decoder"]
+    P = params_of(dec)
+    for S in (16, 32):
+        zero_grads(m)
+        B = 2
+        plan = F.one_hot(torch.randint(0, 32, (B, 32), generator=g(SEED, f"x.dec.idx.{S}")), 32).float().flatten(1).requires_grad_()
+        emb = randn(SEED, f"x.dec.emb.{S}", B, S, 128).requires_grad_()
+        goal = randn(SEED, f"x.dec.goal.{S}", B, 32).requires_grad_()
+        acts = randu(SEED, f"x.dec.act.{S}", B, S, 7)
+        acts[..., 6] = (torch.rand(B, S, generator=g(SEED, f"x.dec.grip.{S}")) < 0.5).float() * 2 - 1
+        acts[0, 0, 0], acts[0, 1, 1], acts[1, 2, 2], acts[1, 3, 3] = -1.0, 1.0, -0.9995, 0.9995   # bin-edge branches
+        robot_obs = randn(SEED, f"x.dec.robot.{S}", B, S, 15)
+        lp, ls, mu, grip, h_n = dec(plan, emb, goal)
+        loss = dec.loss(plan, emb, goal, acts, robot_obs)
+        loss.backward()
+        ck, cv = checksum_arrays(flat, "action_decoder")
+        save(f"decoder_S{S}", seed=SEED, B=B, S=S, acts=acts, logit_probs=lp, log_scales=ls, means=mu, grip=grip, h_n=h_n,
+             loss=loss, g_plan=plan.grad, g_emb=emb.grad, g_goal=goal.grad,
+             g_whh0_s=P["rnn.weight_hh_l0"].grad[::16, ::16], g_wih0_s=P["rnn.weight_ih_l0"].grad[::16, ::8],
+             g_whh1_s=P["rnn.weight_hh_l1"].grad[::16, ::16], g_wih1_s=P["rnn.weight_ih_l1"].grad[::16, ::16],
+             g_bih0=P["rnn.bias_ih_l0"].grad, g_bhh1=P["rnn.bias_hh_l1"].grad,
+             g_mean_w_s=P["mean_fc.weight"].grad[:, ::8], g_ls_b=P["log_scale_fc.bias"].grad,
+             g_prob_w_s=P["prob_fc.weight"].grad[:, ::8], g_grip_w=P["gripper_fc.weight"].grad, ck=ck, cv=cv)
+
+    # direct _logistic_loss / _loss on crafted inputs that force every branch of the torch.where ladder
+    T = 24
+    lp = randn(SEED, "x.mix.lp", 1, T, 6, 10).requires_grad_()
+    mu = (randn(SEED, "x.mix.mu", 1, T, 6, 10) * 0.5).requires_grad_()
+    ls = (randn(SEED, "x.mix.ls", 1, T, 6, 10) * 3 - 3).requires_grad_()          # many below -7 (clamp) and tiny scales
+    grip = randn(SEED, "x.mix.grip", 1, T, 2).requires_grad_()
+    acts = randu(SEED, "x.mix.act", 1, T, 7)
+    acts[0, :4, :6] = -1.0
+    acts[0, 4:8, :6] = 1.0
+    acts[0, 8:10, :6] = -0.9992     # inside the 1e-3 guard band
+    acts[0, 10:12, :6] = 0.9992
+    acts[..., 6] = torch.tensor([-1.0, 1.0] * (T // 2))
+    loss = dec._loss(lp, ls, mu, grip, acts)
+    loss.backward()
+    save("logistic_mixture_edges", acts=acts, logit_probs=lp, log_scales=ls, means=mu, grip=grip, loss=loss,
+         g_lp=lp.grad, g_ls=ls.grad, g_mu=mu.grad, g_grip=grip.grad,
+         gripper_labels=np.where(acts[..., 6].numpy() == -1, 0, acts[..., 6].numpy()).astype(np.int64))
+
+
+def ref_clip_loss(m, logit_scale, seq_feat, goal, use):
+    """hulc2.py:472-508 composed around the imported ProjVisLang."""
+    if use is not None:
+        if not torch.any(use):
+            return torch.tensor(0.0)
+        seq_feat, goal = seq_feat[use], goal[use]
+    im, tx = m["proj_vis_lang"](seq_feat, goal)
+    im = im / im.norm(dim=-1, keepdim=True)
+    tx = tx / tx.norm(dim=-1, keepdim=True)
+    logits = logit_scale.exp() * im @ tx.t()
+    labels = torch.arange(logits.shape[0])
+    return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+
+
+def gen_clip(m, flat):
+    zero_grads(m)
+    B = 6
+    feat = randn(SEED, "x.clip.feat", B, 4096).requires_grad_()
+    goal = randn(SEED, "x.clip.goal", B, 32).requires_grad_()
+    use = torch.tensor([True, True, False, True, True, False])
+    ls = flat["logit_scale"]
+    ls.grad = None
+    loss = ref_clip_loss(m, ls, feat, goal, use)
+    loss.backward()
+    P = params_of(m["proj_vis_lang"])
+    ck, cv = checksum_arrays(flat, "proj_vis_lang")
+    save("clip_loss", seed=SEED, B=B, use=use, loss=loss, g_feat=feat.grad, g_goal=goal.grad, g_logit_scale=ls.grad,
+         g_im0_w_s=P["mlp_im.0.weight"].grad[:, ::16], g_lang2_w=P["mlp_lang.2.weight"].grad, ck=ck, cv=cv)
+
+
+def gen_step(m, dist, flat, B, S):
+    """hulc2.py:379-442 composed from the imported leaf modules (gripper_control=False, language input =
+    (B,384) embeddings i.e. language_encoder=none, clip aux loss on, kl_beta 0.01, mix 0.8, clip beta 3)."""
+    zero_grads(m)
+    flat["logit_scale"].grad = None
+    batch = syn.make_batch(SEED, B, S)
+    res = {}
+    kl_t = act_t = tot_t = clip_t = torch.tensor(0.0)
+    for mod, db in batch.items():
+        st = db["rgb_obs"]["rgb_static"]
+        gr = db["rgb_obs"]["rgb_gripper"]
+        e1 = m["perceptual_encoder.rgb_static_encoder"](st.reshape(-1, *st.shape[2:])).reshape(B, S, -1)
+        e2 = m["perceptual_encoder.rgb_gripper_encoder"](gr.reshape(-1, *gr.shape[2:])).reshape(B, S, -1)
+        emb = torch.cat([e1, e2], dim=-1)                               # concat_encoders.py:68-107 (proprio none)
+        goal = m["language_goal"](db["lang"]) if "lang" in mod else m["visual_goal"](emb[:, -1])
+        pp_state = m["plan_proposal"](emb[:, 0], goal)                   # hulc2.py:228
+        pr_state, seq_feat = m["plan_recognition"](emb)                  # :232
+        plan = ref_rsample_with_idx(dist, pr_state.logit, db["plan_idx"])  # :235-237 with injected sample
+        act = m["action_decoder"].loss(plan, emb, goal, db["actions"], db["state_info"]["robot_obs"])  # :239
+        kl = ref_kl(dist, pp_state.logit, pr_state.logit)                # :242
+        if "lang" in mod:
+            clip_t = clip_t + ref_clip_loss(m, flat["logit_scale"], seq_feat, goal, db["use_for_aux_lang_loss"])
+        kl_t, act_t, tot_t = kl_t + kl, act_t + act, tot_t + (act + kl)
+        res.update({f"kl_{mod}": kl, f"act_{mod}": act, f"emb_{mod}": emb, f"goal_{mod}": goal,
+                    f"pp_{mod}": pp_state.logit, f"pr_{mod}": pr_state.logit, f"seq_feat_{mod}": seq_feat[:, ::8]})
+    total = tot_t / 2 + 3.0 * clip_t
+    total.backward()
+    names, norms = [], []
+    slices = {}
+    for prefix, mod in m.items():
+        for k, p in mod.named_parameters():
+            names.append(f"{prefix}.{k}")
+            norms.append(float(p.grad.double().norm()) if p.grad is not None else -1.0)
+    names.append("logit_scale")
+    norms.append(float(flat["logit_scale"].grad.abs()))
+    P = {f"{pf}.{k}": p for pf, mod in m.items() for k, p in mod.named_parameters()}
+    slices["g_conv0_w_static"] = P["perceptual_encoder.rgb_static_encoder.conv_model.0.weight"].grad
+    slices["g_conv0_w_gripper"] = P["perceptual_encoder.rgb_gripper_encoder.conv_model.0.weight"].grad
+    slices["g_pos"] = P["plan_recognition.position_embeddings.weight"].grad
+    slices["g_grip_w"] = P["action_decoder.gripper_fc.weight"].grad
+    slices["g_vis_ln_w"] = P["visual_goal.ln.weight"].grad
+    ck, cv = checksum_arrays(flat, "")
+    save(f"step_B{B}_S{S}", seed=SEED, B=B, S=S, kl_loss=kl_t / 2, action_loss=act_t / 2, clip_loss=clip_t, total_loss=total,
+         grad_names=np.array(names), grad_norms=np.array(norms), ck=ck, cv=cv, torch_version=torch.__version__, **res, **slices)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = import_reference()
+    m, dist, flat = build_reference_modules(R, SEED)
+    print("reference leaf modules imported from", REF)
+    gen_vision(m, flat)
+    gen_goal_and_proposal(m, flat)
+    gen_plan_recognition(m, flat)
+    gen_dist(dist)
+    gen_decoder(m, flat)
+    gen_clip(m, flat)
+    gen_step(m, dist, flat, 2, 16)
+    gen_step(m, dist, flat, 2, 32)
+
+
+if __name__ == "__main__":
+    main()

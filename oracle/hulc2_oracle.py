@@ -1,0 +1,363 @@
+"""CPU ORACLE (test infrastructure only) for the HULC++ low-level policy training_step.
+
+This file is NOT part of the product: only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import it.  It restates, in plain fp32 torch functional ops over a flat
+state_dict that uses the reference's parameter names, what the reference computes on the path
+`Hulc2.training_step` (/root/reference/hulc2/models/hulc2.py:336-442).  It never touches a GPU kernel.
+
+Pinning: every function below is checked in tests/test_oracle_golden.py against fixtures under
+tests/golden/ that were produced by importing the reference's own leaf modules in the build container
+(oracle/gen_golden.py).  Exceptions — `world_to_tcp_frame` follows pytorch3d (un-vendored, version
+unpinned in the reference's requirements.txt:23): PARITY UNPINNED, checked by properties only.
+SBERT (sentence-transformers, unpinned) and R3M (empty submodule) are outside the oracle: the path's
+language input is the (B,384) embedding.
+
+Each function cites the reference lines it follows.
+"""
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ------------------------------------------------------------------------------------------------
+# perceptual encoders
+# ------------------------------------------------------------------------------------------------
+def spatial_softmax(x: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+    """hulc2/models/perceptual_encoders/vision_network.py:74-108.
+
+    x_map varies along rows (meshgrid(linspace(num_cols), linspace(num_rows), indexing="ij") flattened
+    row-major), y_map along columns; output interleaves (ex, ey) per channel.
+    """
+    n, c, h, w = x.shape
+    # reference builds the maps from (num_cols=h_out?, num_rows) = the conv output size; both are
+    # square on this path.  grid_x[i, j] = lin_cols[i], grid_y[i, j] = lin_rows[j].
+    lin_a = torch.linspace(-1.0, 1.0, w, dtype=x.dtype)
+    lin_b = torch.linspace(-1.0, 1.0, h, dtype=x.dtype)
+    x_map = lin_a.reshape(-1, 1).expand(w, h).reshape(-1)
+    y_map = lin_b.reshape(1, -1).expand(w, h).reshape(-1)
+    flat = x.contiguous().view(-1, h * w)
+    att = F.softmax(flat / temperature, dim=1)
+    ex = torch.sum(x_map * att, dim=1, keepdim=True)
+    ey = torch.sum(y_map * att, dim=1, keepdim=True)
+    return torch.cat((ex, ey), 1).view(-1, c * 2)
+
+
+def _conv_stack(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """The three un-padded convs shared by both cameras: 8x8 s4 -> 4x4 s2 -> 3x3 s1, ReLU after each
+    (vision_network.py:36-47, vision_network_gripper.py:11-20)."""
+    x = F.relu(F.conv2d(x, sd[p + "conv_model.0.weight"], sd[p + "conv_model.0.bias"], stride=4))
+    x = F.relu(F.conv2d(x, sd[p + "conv_model.2.weight"], sd[p + "conv_model.2.bias"], stride=2))
+    x = F.relu(F.conv2d(x, sd[p + "conv_model.4.weight"], sd[p + "conv_model.4.bias"], stride=1))
+    return x
+
+
+def _fc_tail(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """fc1 (+ReLU, dropout p=0) -> fc2 -> LayerNorm (vision_network.py:49-53,60-64)."""
+    x = F.relu(F.linear(x, sd[p + "fc1.0.weight"], sd[p + "fc1.0.bias"]))
+    x = F.linear(x, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return F.layer_norm(x, (x.shape[-1],), sd[p + "ln.weight"], sd[p + "ln.bias"], 1e-5)
+
+
+def vision_network_static(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """VisionNetwork.forward, hulc2/models/perceptual_encoders/vision_network.py:55-65."""
+    x = _conv_stack(sd, p, x)
+    x = spatial_softmax(x, float(sd[p + "spatial_softmax.temperature"]) if p + "spatial_softmax.temperature" in sd else 1.0)
+    return _fc_tail(sd, p, x)
+
+
+def vision_network_gripper(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """nature_cnn + VisionNetwork.forward, vision_network_gripper.py:11-26,82-89."""
+    x = _conv_stack(sd, p, x)
+    x = torch.flatten(x, 1)
+    x = F.relu(F.linear(x, sd[p + "conv_model.7.weight"], sd[p + "conv_model.7.bias"]))
+    return _fc_tail(sd, p, x)
+
+
+def concat_encoders(sd: SD, p: str, rgb_static: torch.Tensor, rgb_gripper: torch.Tensor) -> torch.Tensor:
+    """ConcatEncoders.forward with proprio: none (concat_encoders.py:59-109)."""
+    b, s, c, h, w = rgb_static.shape
+    e1 = vision_network_static(sd, p + "rgb_static_encoder.", rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
+    b, s, c, h, w = rgb_gripper.shape
+    e2 = vision_network_gripper(sd, p + "rgb_gripper_encoder.", rgb_gripper.reshape(-1, c, h, w)).reshape(b, s, -1)
+    return torch.cat([e1, e2], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# goal encoders, plan proposal
+# ------------------------------------------------------------------------------------------------
+def _mlp3_ln(sd: SD, p: str, x: torch.Tensor, i0: int) -> torch.Tensor:
+    x = F.relu(F.linear(x, sd[f"{p}mlp.{i0}.weight"], sd[f"{p}mlp.{i0}.bias"]))
+    x = F.relu(F.linear(x, sd[f"{p}mlp.{i0 + 2}.weight"], sd[f"{p}mlp.{i0 + 2}.bias"]))
+    x = F.linear(x, sd[f"{p}mlp.{i0 + 4}.weight"], sd[f"{p}mlp.{i0 + 4}.bias"])
+    return F.layer_norm(x, (x.shape[-1],), sd[p + "ln.weight"], sd[p + "ln.bias"], 1e-5)
+
+
+def visual_goal_encoder(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """VisualGoalEncoder.forward, hulc2/models/encoders/goal_encoders.py:29-34 (mlp indices 0,2,4)."""
+    return _mlp3_ln(sd, p, x, 0)
+
+
+def language_goal_encoder(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """LanguageGoalEncoder.forward with lang_net=None and word dropout 0, goal_encoders.py:62-71
+    (the Dropout sits at index 0 so the Linear indices are 1,3,5)."""
+    return _mlp3_ln(sd, p, x, 1)
+
+
+def plan_proposal(sd: SD, p: str, emb0: torch.Tensor, goal: torch.Tensor) -> torch.Tensor:
+    """PlanProposalNetwork.forward -> prior logits, plan_proposal_net.py:42-47."""
+    x = torch.cat([emb0, goal], dim=-1)
+    for i in (0, 2, 4, 6):
+        x = F.relu(F.linear(x, sd[f"{p}fc_model.{i}.weight"], sd[f"{p}fc_model.{i}.bias"]))
+    return F.linear(x, sd[p + "fc_state.0.weight"], sd[p + "fc_state.0.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# plan recognition transformer (post-norm nn.TransformerEncoderLayer written out)
+# ------------------------------------------------------------------------------------------------
+def _encoder_layer(sd: SD, p: str, x: torch.Tensor, nhead: int) -> torch.Tensor:
+    """x: (S, B, E).  torch.nn.TransformerEncoderLayer defaults as the reference instantiates it
+    (plan_recognition_net.py:115-117): post-norm, ReLU, eps 1e-5, packed in_proj; dropout off."""
+    S, B, E = x.shape
+    dh = E // nhead
+    qkv = F.linear(x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+
+    def heads(t):  # (S, B, E) -> (B*h, S, dh), feature e = head*dh + d
+        return t.contiguous().view(S, B * nhead, dh).transpose(0, 1)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(dh), dim=-1)
+    o = torch.bmm(att, v).transpose(0, 1).contiguous().view(S, B, E)
+    o = F.linear(o, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + o, (E,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    ff = F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
+                  sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+    return F.layer_norm(x + ff, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+
+
+def plan_recognition(sd: SD, p: str, emb: torch.Tensor, nhead: int = 8, num_layers: int = 2) -> Tuple[torch.Tensor, torch.Tensor]:
+    """PlanRecognitionTransformersNetwork.forward (position_embedding=True, no normalisation flags,
+    dropout disabled), plan_recognition_net.py:125-148.  Returns (posterior logits, seq_feat)."""
+    B, S, E = emb.shape
+    pos_ids = torch.arange(S, dtype=torch.long)          # integer indexing: bit-exact by construction
+    x = emb + sd[p + "position_embeddings.weight"][pos_ids].unsqueeze(0)
+    x = x.permute(1, 0, 2)
+    for l in range(num_layers):
+        x = _encoder_layer(sd, f"{p}transformer_encoder.layers.{l}.", x, nhead)
+    x = F.linear(x.permute(1, 0, 2), sd[p + "fc.weight"], sd[p + "fc.bias"])
+    seq_feat = torch.mean(x, dim=1)
+    logits = F.linear(seq_feat, sd[p + "fc_state.0.weight"], sd[p + "fc_state.0.bias"])
+    return logits, seq_feat
+
+
+# ------------------------------------------------------------------------------------------------
+# discrete latent plan: straight-through sample and KL balancing
+# ------------------------------------------------------------------------------------------------
+def straight_through_sample(logits: torch.Tensor, idx: torch.Tensor, cat: int = 32, cls: int = 32) -> torch.Tensor:
+    """Independent(OneHotCategoricalStraightThrough).rsample() with the sampled class indices injected
+    (distributions.py:23-27, hulc2.py:235-237): onehot + probs - probs.detach(), flattened."""
+    lg = logits.reshape(*logits.shape[:-1], cat, cls)
+    probs = torch.softmax(lg, dim=-1)
+    onehot = F.one_hot(idx, cls).to(probs.dtype)
+    return (onehot + (probs - probs.detach())).flatten(-2, -1)
+
+
+def _cat_kl(post_logits: torch.Tensor, prior_logits: torch.Tensor, cat: int, cls: int) -> torch.Tensor:
+    """KL(Independent(OneHotCategorical(post), 1) || ...(prior)) per sample = sum over categories of
+    sum_c p_c (log p_c - log q_c)  (torch.distributions.kl._kl_categorical_categorical)."""
+    lp = torch.log_softmax(post_logits.reshape(-1, cat, cls), dim=-1)
+    lq = torch.log_softmax(prior_logits.reshape(-1, cat, cls), dim=-1)
+    return (lp.exp() * (lp - lq)).sum(-1).sum(-1)
+
+
+def kl_loss(pp_logits: torch.Tensor, pr_logits: torch.Tensor, kl_beta: float, kl_balancing_mix: float,
+            cat: int = 32, cls: int = 32) -> torch.Tensor:
+    """Hulc2.compute_kl_loss, hulc2.py:444-466 (KL balancing: alpha*KL(sg(post)||prior) + (1-alpha)*KL(post||sg(prior)))."""
+    lhs = _cat_kl(pr_logits.detach(), pp_logits, cat, cls).mean()
+    rhs = _cat_kl(pr_logits, pp_logits.detach(), cat, cls).mean()
+    return (kl_balancing_mix * lhs + (1 - kl_balancing_mix) * rhs) * kl_beta
+
+
+# ------------------------------------------------------------------------------------------------
+# action decoder: 2-layer ReLU RNN + discretised logistic mixture + gripper CE
+# ------------------------------------------------------------------------------------------------
+def relu_rnn(sd: SD, p: str, x: torch.Tensor, num_layers: int = 2) -> torch.Tensor:
+    """nn.RNN(nonlinearity='relu', batch_first=True), h0 = 0 (decoders/utils/rnn.py:5-14)."""
+    B, S, _ = x.shape
+    inp = x
+    for l in range(num_layers):
+        w_ih, w_hh = sd[f"{p}weight_ih_l{l}"], sd[f"{p}weight_hh_l{l}"]
+        b = sd[f"{p}bias_ih_l{l}"] + sd[f"{p}bias_hh_l{l}"]
+        h = torch.zeros(B, w_hh.shape[0], dtype=x.dtype)
+        outs = []
+        for t in range(S):
+            h = F.relu(F.linear(inp[:, t], w_ih) + F.linear(h, w_hh) + b)
+            outs.append(h)
+        inp = torch.stack(outs, dim=1)
+    return inp
+
+
+def decoder_forward(sd: SD, p: str, plan: torch.Tensor, emb: torch.Tensor, goal: torch.Tensor,
+                    emb_slice=(64, 128), n_mix: int = 10, log_scale_min: float = -7.0):
+    """LogisticDecoderRNN.forward, logistic_decoder_rnn.py:257-284."""
+    pe = emb[..., emb_slice[0]:emb_slice[1]]
+    B, S = pe.shape[0], pe.shape[1]
+    x = torch.cat([plan.unsqueeze(1).expand(-1, S, -1), pe, goal.unsqueeze(1).expand(-1, S, -1)], dim=-1)
+    h = relu_rnn(sd, p + "rnn.", x)
+    probs = F.linear(h, sd[p + "prob_fc.weight"], sd[p + "prob_fc.bias"])
+    means = F.linear(h, sd[p + "mean_fc.weight"], sd[p + "mean_fc.bias"])
+    log_scales = torch.clamp(F.linear(h, sd[p + "log_scale_fc.weight"], sd[p + "log_scale_fc.bias"]), min=log_scale_min)
+    grip = F.linear(h, sd[p + "gripper_fc.weight"], sd[p + "gripper_fc.bias"])
+    A = probs.shape[-1] // n_mix
+    return probs.view(B, S, A, n_mix), log_scales.view(B, S, A, n_mix), means.view(B, S, A, n_mix), grip
+
+
+def logistic_loss(logit_probs, log_scales, means, actions, act_min=-1.0, act_max=1.0, num_classes=10,
+                  log_scale_min=-7.0) -> torch.Tensor:
+    """LogisticDecoderRNN._logistic_loss, logistic_decoder_rnn.py:181-228 (+ log_sum_exp :19-24)."""
+    log_scales = torch.clamp(log_scales, min=log_scale_min)
+    a = actions.unsqueeze(-1) * torch.ones_like(means)
+    centered = a - means
+    inv_stdv = torch.exp(-log_scales)
+    half = (act_max - act_min) / 2.0 / (num_classes - 1)
+    plus_in = inv_stdv * (centered + half)
+    cdf_plus = torch.sigmoid(plus_in)
+    min_in = inv_stdv * (centered - half)
+    cdf_min = torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    mid_in = inv_stdv * centered
+    log_pdf_mid = mid_in - log_scales - 2.0 * F.softplus(mid_in)
+    cdf_delta = cdf_plus - cdf_min
+    log_probs = torch.where(
+        a < act_min + 1e-3, log_cdf_plus,
+        torch.where(a > act_max - 1e-3, log_one_minus_cdf_min,
+                    torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-12)),
+                                log_pdf_mid - math.log((num_classes - 1) / 2))))
+    log_probs = log_probs + F.log_softmax(logit_probs, dim=-1)
+    m = log_probs.max(dim=-1).values
+    lse = m + torch.log(torch.sum(torch.exp(log_probs - m.unsqueeze(-1)), dim=-1))
+    return -torch.sum(lse, dim=-1).mean()
+
+
+def decoder_loss(logit_probs, log_scales, means, grip, actions, gripper_alpha: float = 1.0) -> torch.Tensor:
+    """LogisticDecoderRNN._loss with discrete_gripper, logistic_decoder_rnn.py:133-152."""
+    l_mix = logistic_loss(logit_probs, log_scales, means, actions[:, :, :-1])
+    g = actions[:, :, -1].clone()
+    g[g == -1] = 0                                        # integer label remap: bit-exact by construction
+    l_grip = F.cross_entropy(grip.reshape(-1, 2), g.reshape(-1).long())
+    return l_mix + gripper_alpha * l_grip
+
+
+# ---- pytorch3d restatement (PARITY UNPINNED: un-vendored dependency, requirements.txt:23) ----------
+def euler_xyz_to_matrix(e: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.euler_angles_to_matrix(e, 'XYZ') = Rx(e0) @ Ry(e1) @ Rz(e2)."""
+    a, b, c = e.unbind(-1)
+    ca, sa, cb, sb, cc, sc = a.cos(), a.sin(), b.cos(), b.sin(), c.cos(), c.sin()
+    one, zero = torch.ones_like(a), torch.zeros_like(a)
+    rx = torch.stack([one, zero, zero, zero, ca, -sa, zero, sa, ca], -1).reshape(*a.shape, 3, 3)
+    ry = torch.stack([cb, zero, sb, zero, one, zero, -sb, zero, cb], -1).reshape(*a.shape, 3, 3)
+    rz = torch.stack([cc, -sc, zero, sc, cc, zero, zero, zero, one], -1).reshape(*a.shape, 3, 3)
+    return rx @ ry @ rz
+
+
+def matrix_to_euler_xyz(m: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.matrix_to_euler_angles(m, 'XYZ')."""
+    return torch.stack([torch.atan2(-m[..., 1, 2], m[..., 2, 2]), torch.asin(m[..., 0, 2]),
+                        torch.atan2(-m[..., 0, 1], m[..., 0, 0])], -1)
+
+
+def world_to_tcp_frame(action: torch.Tensor, robot_obs: torch.Tensor) -> torch.Tensor:
+    """hulc2/models/decoders/utils/gripper_control.py:16-36."""
+    b, s, _ = action.shape
+    w_T_tcp = euler_xyz_to_matrix(robot_obs[..., 3:6]).float().view(-1, 3, 3)
+    tcp_T_w = torch.inverse(w_T_tcp)
+    pos = tcp_T_w @ action[..., :3].reshape(-1, 3, 1)
+    orn = action[..., 3:6] * 0.01
+    w_T_tcp_new = euler_xyz_to_matrix(robot_obs[..., 3:6] + orn).float().view(-1, 3, 3)
+    rel = torch.inverse(w_T_tcp_new) @ w_T_tcp
+    e = matrix_to_euler_xyz(rel).float()
+    e = torch.where(e < -math.pi, e + 2 * math.pi, e)
+    e = torch.where(e > math.pi, e - 2 * math.pi, e)
+    e = e * 100
+    return torch.cat([pos.view(b, s, -1), e.view(b, s, -1), action[..., -1:]], dim=-1)
+
+
+def tcp_to_world_frame(action: torch.Tensor, robot_obs: torch.Tensor) -> torch.Tensor:
+    """gripper_control.py:39-63 (without the NaN quaternion fallback)."""
+    b, s, _ = action.shape
+    w_T_tcp = euler_xyz_to_matrix(robot_obs[..., 3:6]).float().view(-1, 3, 3)
+    pos = w_T_tcp @ action[..., :3].reshape(-1, 3, 1)
+    rel = euler_xyz_to_matrix(action[..., 3:6] * 0.01).float().view(-1, 3, 3)
+    w_T_new = w_T_tcp @ torch.inverse(rel)
+    e = matrix_to_euler_xyz(w_T_new).float() - robot_obs[..., 3:6].reshape(-1, 3)
+    e = torch.where(e < -math.pi, e + 2 * math.pi, e)
+    e = torch.where(e > math.pi, e - 2 * math.pi, e)
+    e = e * 100
+    return torch.cat([pos.view(b, s, -1), e.view(b, s, -1), action[..., -1:]], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP-style auxiliary loss
+# ------------------------------------------------------------------------------------------------
+def clip_auxiliary_loss(sd: SD, seq_feat: torch.Tensor, goal: torch.Tensor, use: Optional[torch.Tensor]) -> torch.Tensor:
+    """Hulc2.clip_auxiliary_loss + ProjVisLang.forward, hulc2.py:472-508, proj_vis_lang.py:23-27."""
+    if use is not None:
+        if not torch.any(use):
+            return torch.tensor(0.0)
+        seq_feat, goal = seq_feat[use], goal[use]
+    im = F.linear(F.relu(F.linear(seq_feat, sd["proj_vis_lang.mlp_im.0.weight"], sd["proj_vis_lang.mlp_im.0.bias"])),
+                  sd["proj_vis_lang.mlp_im.2.weight"], sd["proj_vis_lang.mlp_im.2.bias"])
+    tx = F.linear(F.relu(F.linear(goal, sd["proj_vis_lang.mlp_lang.0.weight"], sd["proj_vis_lang.mlp_lang.0.bias"])),
+                  sd["proj_vis_lang.mlp_lang.2.weight"], sd["proj_vis_lang.mlp_lang.2.bias"])
+    im = im / im.norm(dim=-1, keepdim=True)
+    tx = tx / tx.norm(dim=-1, keepdim=True)
+    logits = sd["logit_scale"].exp() * im @ tx.t()
+    labels = torch.arange(logits.shape[0])
+    return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+
+
+# ------------------------------------------------------------------------------------------------
+# whole step
+# ------------------------------------------------------------------------------------------------
+def lmp_train(sd: SD, emb, goal, actions, robot_obs, plan_idx, cfg) -> Dict[str, torch.Tensor]:
+    """Hulc2.lmp_train, hulc2.py:200-245, with the categorical sample injected as `plan_idx` (B,32)."""
+    pp = plan_proposal(sd, "plan_proposal.", emb[:, 0], goal)
+    pr, seq_feat = plan_recognition(sd, "plan_recognition.", emb)
+    plan = straight_through_sample(pr, plan_idx)
+    lp, ls, mu, grip = decoder_forward(sd, "action_decoder.", plan, emb, goal, emb_slice=cfg.get("emb_slice", (64, 128)))
+    acts = world_to_tcp_frame(actions, robot_obs) if cfg.get("gripper_control", False) else actions
+    act_loss = decoder_loss(lp, ls, mu, grip, acts)
+    kl = kl_loss(pp, pr, cfg.get("kl_beta", 0.01), cfg.get("kl_balancing_mix", 0.8))
+    return dict(kl=kl, act=act_loss, total=act_loss + kl, pp=pp, pr=pr, seq_feat=seq_feat, plan=plan)
+
+
+def training_step(sd: SD, batch: Dict[str, Dict], cfg: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """Hulc2.training_step, hulc2.py:379-442.  `batch[m]` carries rgb_static, rgb_gripper, actions,
+    robot_obs (state_info), plan_idx (injected sample) and, for 'lang', lang (B,384) + use_for_aux_lang_loss."""
+    cfg = cfg or {}
+    out: Dict[str, torch.Tensor] = {}
+    kl = act = total = clip = torch.tensor(0.0)
+    for m, db in batch.items():
+        emb = concat_encoders(sd, "perceptual_encoder.", db["rgb_static"], db["rgb_gripper"])
+        if "lang" in m:
+            goal = language_goal_encoder(sd, "language_goal.", db["lang"])
+        else:
+            goal = visual_goal_encoder(sd, "visual_goal.", emb[:, -1])
+        r = lmp_train(sd, emb, goal, db["actions"], db["robot_obs"], db["plan_idx"], cfg)
+        if "lang" in m and cfg.get("use_clip_auxiliary_loss", True) and torch.any(db["use_for_aux_lang_loss"]):
+            clip = clip + clip_auxiliary_loss(sd, r["seq_feat"], goal, db["use_for_aux_lang_loss"])
+        kl, act, total = kl + r["kl"], act + r["act"], total + r["total"]
+        for k in ("kl", "act", "total", "pp", "pr", "seq_feat"):
+            out[f"{k}_{m}"] = r[k]
+        out[f"emb_{m}"], out[f"goal_{m}"] = emb, goal
+    n = len(batch)
+    total = total / n
+    if cfg.get("use_clip_auxiliary_loss", True):
+        total = total + cfg.get("clip_auxiliary_loss_beta", 3.0) * clip
+    out.update(kl_loss=kl / n, action_loss=act / n, clip_loss=clip, total_loss=total)
+    return out

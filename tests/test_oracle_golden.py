@@ -1,0 +1,270 @@
+"""Pin the CPU oracle (oracle/hulc2_oracle.py) against fixtures produced by the reference's own leaf
+modules (oracle/gen_golden.py, run in the build container).  CPU only, fp32, tolerance 2e-5 rel
+(different op order only: explicit transformer / RNN loops vs torch's fused modules)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from hulc2_amd import param_spec, synthetic as syn  # noqa: E402
+from oracle import hulc2_oracle as O  # noqa: E402
+
+G = ROOT / "tests" / "golden"
+RTOL = 2e-5
+
+
+def load(name):
+    return dict(np.load(G / f"{name}.npz", allow_pickle=False))
+
+
+def close(a, b, rtol=RTOL, what=""):
+    a = torch.as_tensor(np.asarray(a)).double() if not isinstance(a, torch.Tensor) else a.detach().double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale + 1e-7, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def sd():
+    seed = int(load("vision_static")["seed"])
+    d = {k: torch.empty(s) for k, s in param_spec.trainable_shapes().items()}
+    syn.fill_state_dict_(d, seed)
+    for v in d.values():
+        v.requires_grad_(True)
+    return d
+
+
+def check_recipe(sd, fx):
+    """the (name, seed) recipe must regenerate exactly the parameters the reference ran with"""
+    cs = syn.checksum(sd)
+    for k, (s, a) in zip(fx["ck"], fx["cv"]):
+        k = str(k)
+        if k in cs:
+            assert abs(cs[k][0] - s) <= 1e-9 * max(1, abs(s)) and abs(cs[k][1] - a) <= 1e-9 * max(1, a), f"recipe drift in {k}"
+
+
+def zero(sd):
+    for v in sd.values():
+        v.grad = None
+
+
+def test_param_count():
+    assert param_spec.num_trainable() == 47_050_727 or abs(param_spec.num_trainable() - 47.05e6) < 0.02e6
+
+
+@pytest.mark.parametrize("tag,hw", [("vision_static", 200), ("vision_gripper", 84)])
+def test_vision(sd, tag, hw):
+    fx = load(tag)
+    check_recipe(sd, fx)
+    zero(sd)
+    seed, n = int(fx["seed"]), int(fx["n"])
+    x = torch.rand(n, 3, hw, hw, generator=syn._gen(seed, "x." + tag)) * 2 - 1
+    p = "perceptual_encoder.rgb_static_encoder." if tag == "vision_static" else "perceptual_encoder.rgb_gripper_encoder."
+    out = (O.vision_network_static if tag == "vision_static" else O.vision_network_gripper)(sd, p, x)
+    close(out, fx["out"], what="out")
+    close(O._conv_stack(sd, p, x)[0], fx["conv3_frame0"], what="conv3")
+    if tag == "vision_static":
+        close(O.spatial_softmax(O._conv_stack(sd, p, x)), fx["ssm"], what="spatial softmax")
+    r = torch.randn(out.shape, generator=syn._gen(seed, "r." + tag))
+    (out * r).sum().backward()
+    close(sd[p + "conv_model.0.weight"].grad, fx["g_conv0_w"], 1e-4, "g conv0 w")
+    close(sd[p + "conv_model.0.bias"].grad, fx["g_conv0_b"], 1e-4, "g conv0 b")
+    close(sd[p + "conv_model.2.weight"].grad[::4, ::4], fx["g_conv2_w_s"], 1e-4, "g conv2 w")
+    close(sd[p + "conv_model.4.weight"].grad[::4, ::4], fx["g_conv4_w_s"], 1e-4, "g conv4 w")
+    close(sd[p + "fc2.weight"].grad, fx["g_fc2_w"], 1e-4, "g fc2 w")
+    close(sd[p + "ln.weight"].grad, fx["g_ln_w"], 1e-4, "g ln w")
+    if tag == "vision_gripper":
+        close(sd[p + "conv_model.7.weight"].grad[::4, ::16], fx["g_fc0_w_s"], 1e-4, "g flatten-fc w")
+
+
+def test_goal_encoders_and_proposal(sd):
+    fx = load("goal_encoders")
+    check_recipe(sd, fx)
+    zero(sd)
+    seed, B = int(fx["seed"]), int(fx["B"])
+    xv = torch.randn(B, 128, generator=syn._gen(seed, "x.visual_goal")).requires_grad_()
+    xl = (torch.randn(B, 384, generator=syn._gen(seed, "x.language_goal")) * 0.05).requires_grad_()
+    ov, ol = O.visual_goal_encoder(sd, "visual_goal.", xv), O.language_goal_encoder(sd, "language_goal.", xl)
+    close(ov, fx["out_vis"], what="visual goal")
+    close(ol, fx["out_lang"], what="language goal")
+    rv = torch.randn(B, 32, generator=syn._gen(seed, "r.visual_goal"))
+    rl = torch.randn(B, 32, generator=syn._gen(seed, "r.language_goal"))
+    ((ov * rv).sum() + (ol * rl).sum()).backward()
+    close(xv.grad, fx["gx_vis"], 1e-4, "gx vis")
+    close(xl.grad, fx["gx_lang"], 1e-4, "gx lang")
+    close(sd["visual_goal.mlp.4.weight"].grad, fx["g_vis_mlp4_w"], 1e-4, "g mlp4")
+    close(sd["language_goal.mlp.1.weight"].grad[::16], fx["g_lang_mlp1_w_s"], 1e-4, "g mlp1")
+
+    fx = load("plan_proposal")
+    check_recipe(sd, fx)
+    zero(sd)
+    e0 = torch.randn(B, 128, generator=syn._gen(seed, "x.plan_proposal.emb")).requires_grad_()
+    gl = torch.randn(B, 32, generator=syn._gen(seed, "x.plan_proposal.goal")).requires_grad_()
+    lg = O.plan_proposal(sd, "plan_proposal.", e0, gl)
+    close(lg, fx["logits"], what="prior logits")
+    (lg * torch.randn(B, 1024, generator=syn._gen(seed, "r.plan_proposal"))).sum().backward()
+    close(e0.grad, fx["g_emb"], 1e-4, "g emb")
+    close(gl.grad, fx["g_goal"], 1e-4, "g goal")
+    close(sd["plan_proposal.fc_state.0.weight"].grad[::8, ::8], fx["g_state_w_s"], 1e-4, "g fc_state")
+
+
+@pytest.mark.parametrize("S", [16, 32])
+def test_plan_recognition(sd, S):
+    fx = load(f"plan_recognition_S{S}")
+    check_recipe(sd, fx)
+    zero(sd)
+    seed, B = int(fx["seed"]), int(fx["B"])
+    x = torch.randn(B, S, 128, generator=syn._gen(seed, f"x.plan_recognition.{S}")).requires_grad_()
+    lg, feat = O.plan_recognition(sd, "plan_recognition.", x)
+    assert np.array_equal(fx["position_ids"], np.arange(S))          # integer indexing: bit-exact
+    close(lg, fx["logits"], what="posterior logits")
+    close(feat, fx["seq_feat"], what="seq_feat")
+    r1 = torch.randn(B, 1024, generator=syn._gen(seed, f"r1.plan_recognition.{S}"))
+    r2 = torch.randn(B, 4096, generator=syn._gen(seed, f"r2.plan_recognition.{S}"))
+    ((lg * r1).sum() + (feat * r2).sum()).backward()
+    close(x.grad, fx["gx"], 1e-4, "gx")
+    p = "plan_recognition."
+    close(sd[p + "position_embeddings.weight"].grad, fx["g_pos"], 1e-4, "g pos")
+    close(sd[p + "transformer_encoder.layers.0.self_attn.in_proj_weight"].grad, fx["g_inproj_w"], 1e-4, "g in_proj")
+    close(sd[p + "transformer_encoder.layers.1.self_attn.out_proj.weight"].grad, fx["g_outproj_w"], 1e-4, "g out_proj")
+    close(sd[p + "transformer_encoder.layers.0.norm1.weight"].grad, fx["g_norm1_w"], 1e-4, "g norm1")
+    close(sd[p + "fc.bias"].grad, fx["g_fc_b"], 1e-4, "g fc b")
+
+
+def test_distribution_and_kl():
+    fx = load("distribution_kl")
+    pp = torch.tensor(fx["pp"]).requires_grad_()
+    pr = torch.tensor(fx["pr"]).requires_grad_()
+    idx = torch.tensor(fx["idx"])
+    kl = O.kl_loss(pp, pr, 0.01, 0.8)
+    plan = O.straight_through_sample(pr, idx)
+    close(kl, fx["kl"], what="kl")
+    assert torch.equal(plan.detach().argmax(-1) if False else plan.detach().reshape(-1, 32, 32).argmax(-1), idx)  # bit-exact indices
+    close(plan, fx["plan"], what="plan")
+    (kl + (plan * torch.tensor(fx["r"])).sum() * 1e-3).backward()
+    close(pp.grad, fx["g_pp"], 1e-4, "g pp")
+    close(pr.grad, fx["g_pr"], 1e-4, "g pr")
+
+
+@pytest.mark.parametrize("S", [16, 32])
+def test_decoder(sd, S):
+    fx = load(f"decoder_S{S}")
+    check_recipe(sd, fx)
+    zero(sd)
+    seed, B = int(fx["seed"]), int(fx["B"])
+    idx = torch.randint(0, 32, (B, 32), generator=syn._gen(seed, f"x.dec.idx.{S}"))
+    plan = torch.nn.functional.one_hot(idx, 32).float().flatten(1).requires_grad_()
+    emb = torch.randn(B, S, 128, generator=syn._gen(seed, f"x.dec.emb.{S}")).requires_grad_()
+    goal = torch.randn(B, 32, generator=syn._gen(seed, f"x.dec.goal.{S}")).requires_grad_()
+    acts = torch.tensor(fx["acts"])
+    lp, ls, mu, grip = O.decoder_forward(sd, "action_decoder.", plan, emb, goal)
+    close(lp, fx["logit_probs"], what="logit_probs")
+    close(ls, fx["log_scales"], what="log_scales")
+    close(mu, fx["means"], what="means")
+    close(grip, fx["grip"], what="grip")
+    loss = O.decoder_loss(lp, ls, mu, grip, acts)
+    close(loss, fx["loss"], what="loss")
+    loss.backward()
+    close(plan.grad, fx["g_plan"], 2e-4, "g plan")
+    close(emb.grad, fx["g_emb"], 2e-4, "g emb")
+    close(goal.grad, fx["g_goal"], 2e-4, "g goal")
+    close(sd["action_decoder.rnn.weight_hh_l0"].grad[::16, ::16], fx["g_whh0_s"], 2e-4, "g whh0")
+    close(sd["action_decoder.rnn.weight_ih_l1"].grad[::16, ::16], fx["g_wih1_s"], 2e-4, "g wih1")
+    close(sd["action_decoder.rnn.bias_ih_l0"].grad, fx["g_bih0"], 2e-4, "g bih0")
+    close(sd["action_decoder.gripper_fc.weight"].grad, fx["g_grip_w"], 2e-4, "g gripper_fc")
+
+
+def test_logistic_mixture_edges():
+    fx = load("logistic_mixture_edges")
+    lp, ls, mu, grip = (torch.tensor(fx[k]).requires_grad_() for k in ("logit_probs", "log_scales", "means", "grip"))
+    acts = torch.tensor(fx["acts"])
+    loss = O.decoder_loss(lp, ls, mu, grip, acts)
+    close(loss, fx["loss"], what="loss")
+    loss.backward()
+    for t, k in ((lp, "g_lp"), (ls, "g_ls"), (mu, "g_mu"), (grip, "g_grip")):
+        close(t.grad, fx[k], 1e-4, k)
+    g = acts[..., 6].clone()
+    g[g == -1] = 0
+    assert np.array_equal(g.long().numpy(), fx["gripper_labels"])    # integer labels: bit-exact
+
+
+def test_clip_loss(sd):
+    fx = load("clip_loss")
+    check_recipe(sd, fx)
+    zero(sd)
+    seed, B = int(fx["seed"]), int(fx["B"])
+    feat = torch.randn(B, 4096, generator=syn._gen(seed, "x.clip.feat")).requires_grad_()
+    goal = torch.randn(B, 32, generator=syn._gen(seed, "x.clip.goal")).requires_grad_()
+    loss = O.clip_auxiliary_loss(sd, feat, goal, torch.tensor(fx["use"]))
+    close(loss, fx["loss"], what="clip loss")
+    loss.backward()
+    close(feat.grad, fx["g_feat"], 1e-4, "g feat")
+    close(goal.grad, fx["g_goal"], 1e-4, "g goal")
+    close(sd["logit_scale"].grad, fx["g_logit_scale"], 1e-4, "g logit_scale")
+
+
+def _oracle_batch(seed, B, S):
+    b = syn.make_batch(seed, B, S)
+    out = {}
+    for m, db in b.items():
+        out[m] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"],
+                      actions=db["actions"], robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+        if m == "lang":
+            out[m]["lang"] = db["lang"]
+            out[m]["use_for_aux_lang_loss"] = db["use_for_aux_lang_loss"]
+    return out
+
+
+@pytest.mark.parametrize("B,S", [(2, 16), (2, 32)])
+def test_whole_step(sd, B, S):
+    fx = load(f"step_B{B}_S{S}")
+    check_recipe(sd, fx)
+    zero(sd)
+    r = O.training_step(sd, _oracle_batch(int(fx["seed"]), B, S), dict(gripper_control=False))
+    for k in ("kl_loss", "action_loss", "clip_loss", "total_loss"):
+        close(r[k], fx[k], 5e-5, k)
+    for m in ("vis", "lang"):
+        close(r[f"emb_{m}"], fx[f"emb_{m}"], 5e-5, f"emb {m}")
+        close(r[f"goal_{m}"], fx[f"goal_{m}"], 5e-5, f"goal {m}")
+        close(r[f"pp_{m}"], fx[f"pp_{m}"], 5e-5, f"pp {m}")
+        close(r[f"pr_{m}"], fx[f"pr_{m}"], 5e-5, f"pr {m}")
+        close(r[f"seq_feat_{m}"][:, ::8], fx[f"seq_feat_{m}"], 5e-5, f"seq_feat {m}")
+    r["total_loss"].backward()
+    names = [str(n) for n in fx["grad_names"]]
+    for n, ref in zip(names, fx["grad_norms"]):
+        if ref < 0:      # parameter the reference never touches (plan_recognition.layernorm: positional_normalize=False)
+            assert sd[n].grad is None, f"{n} must stay without gradient"
+            continue
+        got = sd[n].grad.double().norm().item() if n != "logit_scale" else sd[n].grad.abs().item()
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6) + 1e-9, f"grad norm {n}: {got} vs {ref}"
+    close(sd["perceptual_encoder.rgb_static_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_static"], 2e-4, "g conv0 static")
+    close(sd["plan_recognition.position_embeddings.weight"].grad, fx["g_pos"], 2e-4, "g pos")
+
+
+def test_world_to_tcp_properties():
+    """pytorch3d-backed frame change: parity unpinned -> properties (gripper_control.py:16-63)."""
+    g = torch.Generator().manual_seed(0)
+    act = torch.rand(3, 5, 7, generator=g) * 2 - 1
+    obs = torch.randn(3, 5, 15, generator=g)
+    obs[..., 3:6] = (torch.rand(3, 5, 3, generator=g) * 2 - 1) * 1.2
+    R = O.euler_xyz_to_matrix(obs[..., 3:6])
+    eye = torch.eye(3).expand_as(R)
+    assert torch.allclose(R @ R.transpose(-1, -2), eye, atol=1e-5)
+    assert torch.allclose(O.matrix_to_euler_xyz(R), obs[..., 3:6], atol=1e-4)
+    tcp = O.world_to_tcp_frame(act, obs)
+    back = O.tcp_to_world_frame(tcp, obs)
+    assert torch.allclose(back, act, atol=2e-3)
+    obs0 = obs.clone()
+    obs0[..., 3:6] = 0
+    z = O.world_to_tcp_frame(act, obs0)
+    # at zero tcp rotation positions are unchanged and tcp_new_T_tcp_old = R(0.01*orn)^-1, i.e. the
+    # relative euler angles flip sign (to first order in the 0.01 down-scaling)
+    assert torch.allclose(z[..., :3], act[..., :3], atol=1e-6)
+    assert torch.allclose(z[..., 3:6], -act[..., 3:6], atol=1e-2)
+    assert torch.equal(z[..., 6], act[..., 6])
