@@ -1,0 +1,471 @@
+// conv.hip — the un-padded conv stacks of both camera encoders as MFMA implicit GEMMs.
+//
+// reference: hulc2/models/perceptual_encoders/vision_network.py:36-47 (static 200x200) and
+//            vision_network_gripper.py:11-20 (gripper 84x84): 8x8 s4 (3->32), 4x4 s2 (32->64),
+//            3x3 s1 (64->64), ReLU after each; backward = what autograd derives for nn.Conv2d.
+//
+// Data layout in HBM: conv1 reads the batch as the reference delivers it (NCHW fp32, k = (c,kh,kw));
+// every intermediate activation is NHWC so an im2col row is made of long contiguous channel runs and
+// an 8-element k-chunk (the MFMA operand unit) is one aligned 16/32-byte load.
+//
+//   forward / data-gradient : gather kernel.  M = output pixels, N = output channels, K = taps x inner.
+//       A[m][k] is gathered on the fly: address = pixel_base(m) + tap_off[k / inner] + k % inner with a
+//       bounds check per tap (zero fill = padding, needed by the data gradient only).
+//       The data gradient of a stride-s conv is run as s*s parity classes, each a dense stride-1
+//       correlation of dY with the matching weight taps (no multiplications by structural zeros).
+//   weight-gradient         : reduction over pixels.  dW[co][k] = sum_m dY[m][co] * A[m][k]; both
+//       operands have the reduction index outermost in memory, so they are transposed while staged
+//       (two pixels per thread -> one packed LDS write per k element).  Pixel range split over
+//       workgroups, fp32 partial slabs summed by a second deterministic pass; the bias gradient
+//       (column sums of dY) rides along.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+#define HULC_MAX_TAPS 64
+
+struct GatherP {
+    const void* X; void* Y; const void* Wt; const float* bias; const void* mask;
+    int x_dtype, y_dtype, w_dtype, mask_dtype;
+    int Nimg, OH, OW, Cout, H, W;
+    long x_sn, x_sy, x_sx;
+    long y_sn, y_sy, y_sx;
+    long ldw;
+    int stride, ntaps, inner_log2, check_bounds;
+    int relu; float mask_scale;
+    int tap_dy[HULC_MAX_TAPS], tap_dx[HULC_MAX_TAPS];
+    long tap_off[HULC_MAX_TAPS], w_tap_off[HULC_MAX_TAPS];
+};
+
+// one gathered 8-element chunk of the implicit im2col row of a pixel
+HULC_DEVICE void gather_chunk(Chunk8& c, const GatherP& p, long pix_base, int iy0, int ix0, int k0, int K) {
+    if (k0 >= K) { chunk_zero(c); return; }
+    const int t = k0 >> p.inner_log2, j = k0 & ((1 << p.inner_log2) - 1);
+    if (p.check_bounds) {
+        const int iy = iy0 + p.tap_dy[t], ix = ix0 + p.tap_dx[t];
+        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) { chunk_zero(c); return; }
+    }
+    chunk_load_contig(c, p.X, p.x_dtype, pix_base + p.tap_off[t] + j);
+}
+
+template <typename CT, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
+    using T = MmaTraits<CT>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int KT = T::KT, NCH = T::NCH, CHB = T::CHB;
+    constexpr int A_CH = BM * NCH, B_CH = BN * NCH;
+    constexpr int A_PER = (A_CH + NT - 1) / NT, B_PER = (B_CH + NT - 1) / NT;
+    static_assert(A_CH % NT == 0, "A tile must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * HULC_ROWB];
+    __shared__ long out_off[BM];      // output element offset of each tile row, -1 = out of range
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long Mtot = (long)p.Nimg * p.OH * p.OW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = p.ntaps << p.inner_log2;
+    const int nkt = (K + KT - 1) / KT;
+
+    if (tid < BM) {
+        long m = m0 + tid;
+        if (m < Mtot) {
+            int ox = (int)(m % p.OW); long r = m / p.OW; int oy = (int)(r % p.OH); long n = r / p.OH;
+            out_off[tid] = n * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx;
+        } else out_off[tid] = -1;
+    }
+
+    // per-thread gather coordinates of the A rows this thread stages (fixed over the k loop)
+    long pbase[A_PER]; int iy0[A_PER], ix0[A_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) {
+        int r = (tid + q * NT) / NCH;
+        long m = m0 + r; if (m >= Mtot) m = Mtot - 1;
+        int ox = (int)(m % p.OW); long rr = m / p.OW; int oy = (int)(rr % p.OH); long n = rr / p.OH;
+        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride;
+        pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx;
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Chunk8 ra[A_PER], rb[B_PER];
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            int ch = (tid + q * NT) % NCH;
+            gather_chunk(ra[q], p, pbase[q], iy0[q], ix0[q], kt * KT + ch * 8, K);
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            int id = tid + q * NT;
+            if (B_CH % NT == 0 || id < B_CH) {
+                int r = id / NCH, ch = id % NCH, k0 = kt * KT + ch * 8;
+                int n = n0 + r; n = n < p.Cout ? n : p.Cout - 1;
+                if (k0 >= K) chunk_zero(rb[q]);
+                else {
+                    const int t = k0 >> p.inner_log2, j = k0 & ((1 << p.inner_log2) - 1);
+                    chunk_load_contig(rb[q], p.Wt, p.w_dtype, (long)n * p.ldw + p.w_tap_off[t] + j);
+                }
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        char* Bs = As + BM * HULC_ROWB;
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            int id = tid + q * NT;
+            chunk_store_lds<CT>(As + (id / NCH) * HULC_ROWB + (id % NCH) * CHB, ra[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            int id = tid + q * NT;
+            if (B_CH % NT == 0 || id < B_CH) chunk_store_lds<CT>(Bs + (id / NCH) * HULC_ROWB + (id % NCH) * CHB, rb[q]);
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        const char* Bs = As + BM * HULC_ROWB;
+        MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long off = out_off[(wm * TM + i) * 32 + acc_row(e, lane)];
+                if (off < 0) continue;
+                float v = acc[i][j][e] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = load_elem(p.mask, p.mask_dtype, off + n) > 0.f ? v * p.mask_scale : 0.f;
+                store_elem(p.Y, p.y_dtype, off + n, v);
+            }
+    }
+}
+
+template <typename CT>
+void launch_gather(const GatherP& p, hipStream_t s) {
+    const long Mtot = (long)p.Nimg * p.OH * p.OW;
+    if (p.Cout <= 32) {
+        dim3 grid((unsigned)((Mtot + 127) / 128), 1);
+        conv_gather_kernel<CT, 1, 1, 4, 1><<<grid, 256, 0, s>>>(p);
+    } else {
+        dim3 grid((unsigned)((Mtot + 127) / 128), (p.Cout + 63) / 64);
+        conv_gather_kernel<CT, 2, 1, 2, 2><<<grid, 256, 0, s>>>(p);
+    }
+}
+
+int log2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradP {
+    GatherP g;                 // gather description of the forward input (X, taps, strides, OH/OW...)
+    const void* dY; int dy_dtype; long dy_sn, dy_sy, dy_sx;   // upstream gradient, channels contiguous
+    float* partial_w;          // [P][Cout][K]
+    float* partial_b;          // [P][Cout] or null
+    long pix_per_block;        // pixels per workgroup (multiple of the reduction tile)
+};
+
+// write two pixels' worth of one 8-wide chunk transposed into the LDS tile: element j of the chunk
+// goes to row (row0 + j), column pair (m, m+1) of the reduction tile.
+template <typename CT> HULC_DEVICE void store_pair_transposed(char* tile, int row0, int m, const Chunk8& a, const Chunk8& b);
+template <> HULC_DEVICE void store_pair_transposed<bf16_t>(char* tile, int row0, int m, const Chunk8& a, const Chunk8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(uint32_t*)(tile + (row0 + j) * HULC_ROWB + m * 2) = pack_bf16x2(a.v[j], b.v[j]);
+}
+template <> HULC_DEVICE void store_pair_transposed<float>(char* tile, int row0, int m, const Chunk8& a, const Chunk8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(float2*)(tile + (row0 + j) * HULC_ROWB + m * 4) = make_float2(a.v[j], b.v[j]);
+}
+
+// TMC = Cout / 32 (1 or 2).  Each workgroup: 4 waves, wave w owns k-tile w of its 128-wide K slice.
+template <typename CT, int TMC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+    using T = MmaTraits<CT>;
+    constexpr int KT = T::KT;                 // pixels per reduction tile (32 bf16 / 16 f32)
+    constexpr int CO = TMC * 32, KS = 128;
+    constexpr int PAIRS = KT / 2;             // pixel pairs per tile
+    constexpr int DY_ITEMS = PAIRS * (CO / 8), X_ITEMS = PAIRS * (KS / 8);
+    constexpr int X_PER = (X_ITEMS + 255) / 256;
+    static_assert(DY_ITEMS <= 256, "dY staging fits one pass");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (CO + KS) * HULC_ROWB];
+    __shared__ float bsum[CO];
+
+    const GatherP& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long Mtot = (long)g.Nimg * g.OH * g.OW;
+    const long mb = (long)blockIdx.x * p.pix_per_block;
+    long me = mb + p.pix_per_block; if (me > Mtot) me = Mtot;
+    const int K = g.ntaps << g.inner_log2;
+    const int ks0 = blockIdx.y * KS;
+    const int ntile = (int)((me - mb + KT - 1) / KT);
+
+    f32x16_t acc[TMC][1];
+#pragma unroll
+    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+    float bacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bacc[j] = 0.f;
+    if (tid < CO) bsum[tid] = 0.f;
+
+    // item -> (pixel pair, chunk): consecutive threads take consecutive chunks of one pixel pair so a
+    // wave's loads cover whole contiguous channel runs.
+    Chunk8 dya, dyb, xa[X_PER], xb[X_PER];
+    auto pixel = [&](long m, long& xbase, int& iy0, int& ix0, long& dybase) {
+        int ox = (int)(m % g.OW); long r = m / g.OW; int oy = (int)(r % g.OH); long n = r / g.OH;
+        iy0 = oy * g.stride; ix0 = ox * g.stride;
+        xbase = n * g.x_sn + (long)iy0 * g.x_sy + (long)ix0 * g.x_sx;
+        dybase = n * p.dy_sn + (long)oy * p.dy_sy + (long)ox * p.dy_sx;
+    };
+    auto load_tiles = [&](int t) {
+        const long mt = mb + (long)t * KT;
+        if (tid < DY_ITEMS) {
+            const int pr = tid / (CO / 8), ch = tid % (CO / 8);
+            long m = mt + 2 * pr, xb_, db_; int a_, b_;
+            if (m < me) { pixel(m, xb_, a_, b_, db_); chunk_load_contig(dya, p.dY, p.dy_dtype, db_ + ch * 8); } else chunk_zero(dya);
+            if (m + 1 < me) { pixel(m + 1, xb_, a_, b_, db_); chunk_load_contig(dyb, p.dY, p.dy_dtype, db_ + ch * 8); } else chunk_zero(dyb);
+        }
+#pragma unroll
+        for (int q = 0; q < X_PER; ++q) {
+            const int id = tid + q * 256;
+            if (X_ITEMS % 256 == 0 || id < X_ITEMS) {
+                const int pr = id / (KS / 8), ch = id % (KS / 8);
+                const int k0 = ks0 + ch * 8;
+                long m = mt + 2 * pr, xbase, db_; int iy0, ix0;
+                if (m < me) { pixel(m, xbase, iy0, ix0, db_); gather_chunk(xa[q], g, xbase, iy0, ix0, k0, K); } else chunk_zero(xa[q]);
+                if (m + 1 < me) { pixel(m + 1, xbase, iy0, ix0, db_); gather_chunk(xb[q], g, xbase, iy0, ix0, k0, K); } else chunk_zero(xb[q]);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* As = smem + buf * (CO + KS) * HULC_ROWB;   // dY^T : rows = output channel
+        char* Bs = As + CO * HULC_ROWB;                   // X^T  : rows = k inside the slice
+        if (tid < DY_ITEMS) {
+            const int pr = tid / (CO / 8), ch = tid % (CO / 8);
+            store_pair_transposed<CT>(As, ch * 8, 2 * pr, dya, dyb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bacc[j] += dya.v[j] + dyb.v[j];
+        }
+#pragma unroll
+        for (int q = 0; q < X_PER; ++q) {
+            const int id = tid + q * 256;
+            if (X_ITEMS % 256 == 0 || id < X_ITEMS) {
+                const int pr = id / (KS / 8), ch = id % (KS / 8);
+                store_pair_transposed<CT>(Bs, ch * 8, 2 * pr, xa[q], xb[q]);
+            }
+        }
+    };
+
+    if (ntile > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) load_tiles(t + 1);
+        const char* As = smem + buf * (CO + KS) * HULC_ROWB;
+        const char* Bs = As + CO * HULC_ROWB;
+        MmaTile<CT, TMC, 1>::run(As, Bs + wave * 32 * HULC_ROWB, acc, lane);
+        if (t + 1 < ntile) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial dW slab: rows = co, cols = k
+    float* pw = p.partial_w + (long)blockIdx.x * CO * K;
+    const int k = ks0 + wave * 32 + (lane & 31);
+    if (k < K) {
+#pragma unroll
+        for (int i = 0; i < TMC; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pw[(long)(i * 32 + acc_row(e, lane)) * K + k] = acc[i][0][e];
+    }
+    if (p.partial_b && blockIdx.y == 0) {
+        if (tid < DY_ITEMS) {
+            const int ch = tid % (CO / 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);   // LDS atomics, <=16 adders per slot
+        }
+        __syncthreads();
+        if (tid < CO) p.partial_b[(long)blockIdx.x * CO + tid] = bsum[tid];
+    }
+}
+
+// out[r] = sum_p partial[p][r]  (deterministic order)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += partial[(long)q * R + r];
+    out[r] = accumulate ? out[r] + s : s;
+}
+
+void fill_gather(GatherP& g, const hulc_conv_desc* d) {
+    g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype;
+    g.Nimg = d->N; g.H = d->H; g.W = d->W;
+    g.OH = (d->H - d->KH) / d->stride + 1; g.OW = (d->W - d->KW) / d->stride + 1;
+    g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = 0;
+    if (d->x_nchw) {   // k = (c, kh, kw): one tap per (c, kh), inner run = KW along x
+        g.x_sn = (long)d->Cin * d->H * d->W; g.x_sy = d->W; g.x_sx = 1;
+        g.ntaps = d->Cin * d->KH; g.inner_log2 = log2_exact(d->KW);
+        for (int c = 0; c < d->Cin; ++c)
+            for (int kh = 0; kh < d->KH; ++kh) {
+                int t = c * d->KH + kh;
+                g.tap_dy[t] = kh; g.tap_dx[t] = 0;
+                g.tap_off[t] = (long)c * d->H * d->W + (long)kh * d->W;
+                g.w_tap_off[t] = (long)t * d->KW;
+            }
+    } else {           // NHWC, k = (kh, kw, c): one tap per (kh, kw), inner run = Cin
+        g.x_sn = (long)d->H * d->W * d->Cin; g.x_sy = (long)d->W * d->Cin; g.x_sx = d->Cin;
+        g.ntaps = d->KH * d->KW; g.inner_log2 = log2_exact(d->Cin);
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int kw = 0; kw < d->KW; ++kw) {
+                int t = kh * d->KW + kw;
+                g.tap_dy[t] = kh; g.tap_dx[t] = kw;
+                g.tap_off[t] = (long)kh * g.x_sy + (long)kw * g.x_sx;
+                g.w_tap_off[t] = (long)t * d->Cin;
+            }
+    }
+    g.ldw = (long)g.ntaps << g.inner_log2;
+}
+
+int validate(const hulc_conv_desc* d, const char* who) {
+    if (!d) return hulc_fail(-1, "conv: null descriptor");
+    if (d->N <= 0 || d->H < d->KH || d->W < d->KW || d->stride <= 0) return hulc_fail(-2, "conv: bad geometry");
+    const int taps = d->x_nchw ? d->Cin * d->KH : d->KH * d->KW;
+    const int inner = d->x_nchw ? d->KW : d->Cin;
+    if (taps > HULC_MAX_TAPS) return hulc_fail(-3, "conv: too many taps");
+    if (log2_exact(inner) < 3) return hulc_fail(-4, "conv: inner run (KW for NCHW input, Cin for NHWC) must be a power of two >= 8");
+    if (d->Cout != 32 && d->Cout != 64) return hulc_fail(-5, "conv: Cout must be 32 or 64");
+    if (d->compute == HULC_F32 && (d->x_dtype != HULC_F32 || d->w_dtype != HULC_F32)) return hulc_fail(-6, "conv: f32 compute requires f32 operands");
+    (void)who;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
+    int rc = validate(d, "fwd"); if (rc) return rc;
+    if (!x || !w || !y) return hulc_fail(-1, "hulc_conv2d_fwd: null pointer");
+    GatherP g; fill_gather(g, d);
+    g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f;
+    g.y_dtype = d->y_dtype; g.relu = d->relu;
+    g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
+    if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
+    return hulc_check_launch("hulc_conv2d_fwd");
+}
+
+// dX (NHWC [N][H][W][Cin]) from dY (NHWC [N][OH][OW][Cout]); wt = weights permuted to [Cin][KH][KW][Cout].
+// relu_src (optional, same shape as dX): dX *= (relu_src > 0)  — the ReLU that produced this conv's input.
+extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, const void* wt, void* dx, const void* relu_src, void* stream) {
+    if (!d || !dy || !wt || !dx) return hulc_fail(-1, "hulc_conv2d_bwd_data: null pointer");
+    if (d->x_nchw) return hulc_fail(-7, "hulc_conv2d_bwd_data: only NHWC activations have a data gradient on this path");
+    if (log2_exact(d->Cout) < 3) return hulc_fail(-4, "conv bwd_data: Cout must be a power of two >= 8");
+    if (d->Cin != 32 && d->Cin != 64) return hulc_fail(-5, "conv bwd_data: Cin must be 32 or 64");
+    const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1, s = d->stride;
+    const int xsz = d->x_dtype == HULC_F32 ? 4 : 2;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            GatherP g;
+            g.X = dy; g.x_dtype = d->y_dtype; g.Wt = wt; g.w_dtype = d->w_dtype; g.bias = nullptr;
+            g.Nimg = d->N; g.H = OH; g.W = OW;                       // the gathered tensor is dY
+            g.OH = (d->H - py + s - 1) / s; g.OW = (d->W - px + s - 1) / s;   // this class' sub-grid of dX
+            if (g.OH <= 0 || g.OW <= 0) continue;
+            g.Cout = d->Cin; g.stride = 1; g.check_bounds = 1;
+            g.x_sn = (long)OH * OW * d->Cout; g.x_sy = (long)OW * d->Cout; g.x_sx = d->Cout;
+            g.inner_log2 = log2_exact(d->Cout);
+            int t = 0;
+            for (int kh = py; kh < d->KH; kh += s)
+                for (int kw = px; kw < d->KW; kw += s) {
+                    if (t >= HULC_MAX_TAPS) return hulc_fail(-3, "conv bwd_data: too many taps");
+                    const int u = (kh - py) / s, v = (kw - px) / s;
+                    g.tap_dy[t] = -u; g.tap_dx[t] = -v;
+                    g.tap_off[t] = -(long)u * g.x_sy - (long)v * g.x_sx;
+                    g.w_tap_off[t] = ((long)kh * d->KW + kw) * d->Cout;
+                    ++t;
+                }
+            if (t == 0) continue;
+            g.ntaps = t;
+            g.ldw = (long)d->KH * d->KW * d->Cout;
+            const long yoff = ((long)py * d->W + px) * d->Cin;
+            g.Y = (char*)dx + yoff * xsz; g.y_dtype = d->x_dtype;
+            g.y_sn = (long)d->H * d->W * d->Cin; g.y_sy = (long)s * d->W * d->Cin; g.y_sx = (long)s * d->Cin;
+            g.mask = relu_src ? (const char*)relu_src + yoff * xsz : nullptr; g.mask_dtype = d->x_dtype; g.mask_scale = 1.f;
+            g.relu = 0;
+            if (d->compute == HULC_F32) {
+                if (d->y_dtype != HULC_F32 || d->w_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_data: f32 compute requires f32 operands");
+                launch_gather<float>(g, (hipStream_t)stream);
+            } else launch_gather<bf16_t>(g, (hipStream_t)stream);
+        }
+    return hulc_check_launch("hulc_conv2d_bwd_data");
+}
+
+extern "C" long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d) {
+    if (!d) return -1;
+    const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1;
+    const long K = (long)d->Cin * d->KH * d->KW;
+    const long Mtot = (long)d->N * OH * OW;
+    long P = (Mtot + 4095) / 4096; if (P > 512) P = 512; if (P < 1) P = 1;
+    return P * d->Cout * (K + 1) * (long)sizeof(float);
+}
+
+// dW ([Cout][K] in the forward k order) and db ([Cout]) from x and dY; ws = workspace of
+// hulc_conv2d_bwd_weight_workspace() bytes.
+extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, const void* dy, float* dw, float* db, void* ws, void* stream) {
+    int rc = validate(d, "bwd_weight"); if (rc) return rc;
+    if (!x || !dy || !dw || !ws) return hulc_fail(-1, "hulc_conv2d_bwd_weight: null pointer");
+    WgradP p; fill_gather(p.g, d);
+    p.g.X = x; p.g.Wt = nullptr; p.g.bias = nullptr; p.g.Y = nullptr; p.g.mask = nullptr;
+    p.dY = dy; p.dy_dtype = d->y_dtype;
+    p.dy_sn = (long)p.g.OH * p.g.OW * d->Cout; p.dy_sy = (long)p.g.OW * d->Cout; p.dy_sx = d->Cout;
+    const long K = p.g.ldw, Mtot = (long)d->N * p.g.OH * p.g.OW;
+    long P = (Mtot + 4095) / 4096; if (P > 512) P = 512; if (P < 1) P = 1;
+    long ppb = (Mtot + P - 1) / P; ppb = (ppb + 31) / 32 * 32;
+    P = (Mtot + ppb - 1) / ppb;
+    p.pix_per_block = ppb;
+    p.partial_w = (float*)ws;
+    p.partial_b = db ? p.partial_w + P * d->Cout * K : nullptr;
+    dim3 grid((unsigned)P, (unsigned)((K + 127) / 128));
+    hipStream_t s = (hipStream_t)stream;
+    if (d->compute == HULC_F32) {
+        if (d->y_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_weight: f32 compute requires f32 operands");
+        if (d->Cout == 32) conv_wgrad_kernel<float, 1><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<float, 2><<<grid, 256, 0, s>>>(p);
+    } else {
+        if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p);
+    }
+    const long R = (long)d->Cout * K;
+    reduce_partials_kernel<<<(unsigned)((R + 255) / 256), 256, 0, s>>>(p.partial_w, dw, (int)P, R, 0);
+    if (db) reduce_partials_kernel<<<1, 64, 0, s>>>(p.partial_b, db, (int)P, d->Cout, 0);
+    return hulc_check_launch("hulc_conv2d_bwd_weight");
+}

@@ -73,3 +73,49 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
         raise TypeError("bias must be float32")
     _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions
+# ------------------------------------------------------------------------------------------------
+def _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, x_dt, y_dt, w_dt, relu, compute=None):
+    d = _L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = N, H, W, Cin, Cout, KH, KW, stride
+    d.x_nchw, d.x_dtype, d.y_dtype, d.w_dtype, d.relu = int(x_nchw), x_dt, y_dt, w_dt, int(relu)
+    d.compute = _compute_mode if compute is None else compute
+    return d
+
+
+def conv_out_hw(H, W, KH, KW, stride):
+    return (H - KH) // stride + 1, (W - KW) // stride + 1
+
+
+def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None):
+    """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc)."""
+    _require_cuda(x, w2d, bias, y)
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(y), _dt(w2d), relu, compute)
+    _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
+             "hulc_conv2d_fwd")
+    return y
+
+
+def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, compute=None):
+    """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout]."""
+    _require_cuda(dy, wt, dx, relu_src)
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, False, _dt(dx), _dt(dy), _dt(wt), False, compute)
+    _L.check(_L.load().hulc_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _p(relu_src),
+                                            ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None):
+    """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC)."""
+    _require_cuda(x, dy, dw, db)
+    lib = _L.load()
+    lib.hulc_conv2d_bwd_weight_workspace.restype = ctypes.c_long
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(dy), F32, False, compute)
+    nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                        ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
+    return dw, db

@@ -58,3 +58,14 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().hulc_last_error().decode(errors="replace")
         raise HulcKernelError(f"{what} failed with code {rc}: {msg}")
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
+        ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int),
+        ("x_nchw", ctypes.c_int),
+        ("x_dtype", ctypes.c_int), ("y_dtype", ctypes.c_int), ("w_dtype", ctypes.c_int),
+        ("relu", ctypes.c_int),
+        ("compute", ctypes.c_int),
+    ]

@@ -49,6 +49,30 @@ typedef struct {
 } hulc_gemm_desc;
 int hulc_gemm(const hulc_gemm_desc* d, void* stream);
 
+
+/* ---- convolutions (both camera encoders) ---------------------------------------------------- */
+/* Un-padded KHxKW stride-s convolution, replaces nn.Conv2d (+ReLU) of
+ * hulc2/models/perceptual_encoders/vision_network.py:36-47 and vision_network_gripper.py:11-20.
+ *   x_nchw = 1: x is [N][Cin][H][W] (the batch as the reference delivers it), weights [Cout][Cin*KH*KW]
+ *               (= the OIHW parameter, flat), KW must be a power of two >= 8          (conv1)
+ *   x_nchw = 0: x is NHWC [N][H][W][Cin], weights [Cout][KH*KW*Cin] (OHWI), Cin power of two >= 8
+ * y is always NHWC [N][OH][OW][Cout]; Cout in {32, 64}. */
+typedef struct {
+    int N, H, W, Cin, Cout, KH, KW, stride;
+    int x_nchw;
+    int x_dtype, y_dtype, w_dtype;
+    int relu;
+    int compute;
+} hulc_conv_desc;
+int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
+/* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]
+ * (dtype w_dtype); relu_src (same shape/dtype as dx, may be NULL): dx *= (relu_src > 0). */
+int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, const void* wt, void* dx, const void* relu_src, void* stream);
+/* dw [Cout][K] fp32 in the forward k order, db [Cout] fp32 (may be NULL); ws: device workspace of
+ * hulc_conv2d_bwd_weight_workspace(d) bytes. */
+long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d);
+int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, const void* dy, float* dw, float* db, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,93 @@
+"""GPU parity of the conv kernels (forward / data gradient / weight gradient) against torch's
+conv2d autograd in float64 on the same (bf16-rounded, for bf16 compute) operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (name, N, H, W, Cin, Cout, KH, stride, x_nchw) — the six conv layers of the two camera encoders
+LAYERS = [
+    ("static1", 3, 200, 200, 3, 32, 8, 4, True),
+    ("static2", 3, 49, 49, 32, 64, 4, 2, False),
+    ("static3", 3, 23, 23, 64, 64, 3, 1, False),
+    ("grip1", 5, 84, 84, 3, 32, 8, 4, True),
+    ("grip2", 5, 20, 20, 32, 64, 4, 2, False),
+    ("grip3", 5, 9, 9, 64, 64, 3, 1, False),
+]
+
+
+def _round(t, compute):
+    return t.to(torch.bfloat16).double() if compute == "bf16" else t.double()
+
+
+def _setup(dev, N, H, W, Cin, Cout, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(N, Cin, H, W, generator=g) * 2 - 1)
+    w = (torch.rand(Cout, Cin, K, K, generator=g) * 2 - 1) / (Cin * K * K) ** 0.5
+    b = (torch.rand(Cout, generator=g) * 2 - 1) * 0.1
+    return x.to(dev), w.to(dev), b.to(dev), g
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride,nchw", LAYERS)
+def test_conv_forward(dev, compute, name, N, H, W, Cin, Cout, K, stride, nchw):
+    from hulc2_amd import kernels as kn
+
+    x, w, b, _ = _setup(dev, N, H, W, Cin, Cout, K, 11)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    xin = x.contiguous() if nchw else x.permute(0, 2, 3, 1).contiguous()
+    w2d = w.reshape(Cout, -1).contiguous() if nchw else w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    y = torch.full((N, OH, OW, Cout), float("nan"), device=dev)
+    kn.conv2d_fwd(xin, w2d, b, y, N, H, W, Cin, Cout, K, K, stride, nchw, relu=True, compute=kn._COMPUTE[compute])
+    torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(_round(x, compute), _round(w, compute), b.double(), stride=stride)).permute(0, 2, 3, 1)
+    err = (y.double() - ref).abs().max().item()
+    assert torch.isfinite(y).all()
+    assert err < 2e-4, f"{name}: max err {err:.3e} (ref max {ref.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride,nchw", [l for l in LAYERS if not l[-1]])
+def test_conv_bwd_data(dev, compute, name, N, H, W, Cin, Cout, K, stride, nchw):
+    from hulc2_amd import kernels as kn
+
+    x, w, b, g = _setup(dev, N, H, W, Cin, Cout, K, 12)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    dy = torch.randn(N, Cout, OH, OW, generator=g).to(dev)
+    relu_src = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    wt = w.permute(1, 2, 3, 0).contiguous()            # [Cin][KH][KW][Cout]
+    dx = torch.full((N, H, W, Cin), float("nan"), device=dev)
+    kn.conv2d_bwd_data(dy.permute(0, 2, 3, 1).contiguous(), wt, dx, relu_src, N, H, W, Cin, Cout, K, K, stride,
+                       compute=kn._COMPUTE[compute])
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), _round(w, compute), _round(dy, compute), stride=stride)
+    ref = ref.permute(0, 2, 3, 1) * (relu_src > 0)
+    err = (dx.double() - ref).abs().max().item()
+    assert torch.isfinite(dx).all(), f"{name}: non-finite (uncovered output pixels?)"
+    assert err < 5e-4, f"{name}: max err {err:.3e} (ref max {ref.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride,nchw", LAYERS)
+def test_conv_bwd_weight(dev, compute, name, N, H, W, Cin, Cout, K, stride, nchw):
+    from hulc2_amd import kernels as kn
+
+    x, w, b, g = _setup(dev, N, H, W, Cin, Cout, K, 13)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    dy = torch.randn(N, Cout, OH, OW, generator=g).to(dev)
+    xin = x.contiguous() if nchw else x.permute(0, 2, 3, 1).contiguous()
+    Kd = Cin * K * K
+    dw = torch.full((Cout, Kd), float("nan"), device=dev)
+    db = torch.full((Cout,), float("nan"), device=dev)
+    kn.conv2d_bwd_weight(xin, dy.permute(0, 2, 3, 1).contiguous(), dw, db, N, H, W, Cin, Cout, K, K, stride, nchw,
+                         compute=kn._COMPUTE[compute])
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(_round(x, compute), (Cout, Cin, K, K), _round(dy, compute), stride=stride)
+    ref2d = ref.reshape(Cout, -1) if nchw else ref.permute(0, 2, 3, 1).reshape(Cout, -1)
+    scale = ref2d.abs().max().item()
+    err = (dw.double() - ref2d).abs().max().item()
+    assert err < 1e-4 * scale + 1e-4, f"{name}: dW max err {err:.3e} (scale {scale:.3e})"
+    refb = dy.double().sum(dim=(0, 2, 3))
+    errb = (db.double() - refb).abs().max().item()
+    assert errb < 1e-4 * refb.abs().max().item() + 1e-3, f"{name}: db max err {errb:.3e}"
