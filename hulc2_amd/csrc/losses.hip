@@ -1,0 +1,428 @@
+// losses.hip — the scalar heads of the HULC++ training step, forward and analytic backward.
+//
+//   discretised logistic mixture NLL + gripper cross-entropy
+//       reference: LogisticDecoderRNN._loss/_logistic_loss, hulc2/models/decoders/logistic_decoder_rnn.py:133-152,181-228
+//   KL-balanced categorical KL between plan recognition (posterior) and plan proposal (prior)
+//       reference: Hulc2.compute_kl_loss, hulc2/models/hulc2.py:444-466 (+ torch.distributions categorical KL)
+//   straight-through one-hot sample of the 32x32 latent plan
+//       reference: hulc2/utils/distributions.py:23-27 + hulc2.py:235-237
+//   CLIP-style symmetric contrastive loss on projected features
+//       reference: Hulc2.clip_auxiliary_loss, hulc2.py:472-508
+//   world -> tcp frame change of the relative actions
+//       reference: hulc2/models/decoders/utils/gripper_control.py:16-36 (pytorch3d XYZ euler maths)
+//
+// These are tiny, reduction-shaped problems (<= 2048 tokens): each is one workgroup (deterministic
+// summation order) or one thread per token; fp32 VALU throughout, libm-accurate exp/log.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+HULC_DEVICE float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch threshold = 20
+HULC_DEVICE float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// deterministic block-wide sum (blockDim.x <= 1024); result valid on every thread
+HULC_DEVICE float block_sum(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += sh[w];
+    return t;
+}
+
+struct MixP {
+    const float* y; long ld;        // [T][>=182] head outputs: logit_probs | means | log_scales | gripper(2)
+    const float* act;               // [T][A+1]
+    const float* amin; const float* amax;   // [A]
+    int T, A, NM, num_classes;
+    float log_scale_min, gripper_alpha;
+};
+
+// per (token, action dim): NLL and, when G != nullptr, gradients w.r.t. the 3*NM head outputs
+template <bool GRAD>
+HULC_DEVICE float mix_nll(const MixP& p, int t, int d, float gscale, float* dy_row) {
+    constexpr int MAXM = 16;
+    const float* row = p.y + (long)t * p.ld;
+    const int NM = p.NM;
+    const float a = p.act[(long)t * (p.A + 1) + d];
+    const float lo = p.amin[d], hi = p.amax[d];
+    const float half = (hi - lo) * 0.5f / (float)(p.num_classes - 1);
+    const float logc = logf((float)(p.num_classes - 1) * 0.5f);
+    float lp[MAXM], dmu[MAXM], dls[MAXM];
+    float lmax = -INFINITY;
+    for (int i = 0; i < NM; ++i) lmax = fmaxf(lmax, row[d * NM + i]);
+    float lsum = 0.f;
+    for (int i = 0; i < NM; ++i) lsum += expf(row[d * NM + i] - lmax);
+    const float llse = lmax + logf(lsum);
+    float m = -INFINITY;
+    for (int i = 0; i < NM; ++i) {
+        const float mu = row[p.A * NM + d * NM + i];
+        const float raw = row[2 * p.A * NM + d * NM + i];
+        const float ls = fmaxf(raw, p.log_scale_min);
+        const float inv = expf(-ls), c = a - mu;
+        const float plus = inv * (c + half), minn = inv * (c - half), mid = inv * c;
+        float v, gmu, gls;      // gmu = d logprob / d mu, gls = d logprob / d log_scale
+        if (a < lo + 1e-3f) {
+            v = plus - softplus_t(plus);
+            const float k = 1.f - sigmoid_f(plus);
+            gmu = -inv * k; gls = -plus * k;
+        } else if (a > hi - 1e-3f) {
+            v = -softplus_t(minn);
+            const float k = -sigmoid_f(minn);
+            gmu = -inv * k; gls = -minn * k;
+        } else {
+            const float sp = sigmoid_f(plus), sm = sigmoid_f(minn), delta = sp - sm;
+            if (delta > 1e-5f) {
+                v = logf(fmaxf(delta, 1e-12f));
+                const float dp = sp * (1.f - sp), dm = sm * (1.f - sm);
+                gmu = (-inv * dp + inv * dm) / delta;
+                gls = (-plus * dp + minn * dm) / delta;
+            } else {
+                v = mid - ls - 2.f * softplus_t(mid) - logc;
+                const float k = 1.f - 2.f * sigmoid_f(mid);
+                gmu = -inv * k; gls = -mid * k - 1.f;
+            }
+        }
+        if (raw < p.log_scale_min) gls = 0.f;                 // clamp(min) passes gradient only for raw >= min
+        lp[i] = v + (row[d * NM + i] - llse);
+        dmu[i] = gmu; dls[i] = gls;
+        m = fmaxf(m, lp[i]);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NM; ++i) s += expf(lp[i] - m);
+    const float lse = m + logf(s);
+    if (GRAD) {
+        for (int i = 0; i < NM; ++i) {
+            const float w = expf(lp[i] - lse);                           // responsibility
+            const float pi = expf(row[d * NM + i] - llse);
+            dy_row[d * NM + i] = -gscale * (w - pi);
+            dy_row[p.A * NM + d * NM + i] = -gscale * w * dmu[i];
+            dy_row[2 * p.A * NM + d * NM + i] = -gscale * w * dls[i];
+        }
+    }
+    return -lse;
+}
+
+// single workgroup: out[0] = total, out[1] = mixture NLL mean, out[2] = gripper CE mean
+__global__ __launch_bounds__(1024) void mix_loss_fwd_kernel(MixP p, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float nll = 0.f, ce = 0.f;
+    for (int w = threadIdx.x; w < p.T * (p.A + 1); w += blockDim.x) {
+        const int t = w / (p.A + 1), d = w % (p.A + 1);
+        if (d < p.A) nll += mix_nll<false>(p, t, d, 0.f, nullptr);
+        else {
+            const float* g = p.y + (long)t * p.ld + 3 * p.A * p.NM;
+            const float a = p.act[(long)t * (p.A + 1) + p.A];
+            const int lbl = (a == -1.f) ? 0 : (int)a;
+            const float mx = fmaxf(g[0], g[1]);
+            const float l = mx + logf(expf(g[0] - mx) + expf(g[1] - mx));
+            ce += l - g[lbl];
+        }
+    }
+    nll = block_sum(nll, sh) / p.T;
+    ce = block_sum(ce, sh) / p.T;
+    if (threadIdx.x == 0) { out[0] = nll + p.gripper_alpha * ce; out[1] = nll; out[2] = ce; }
+}
+
+__global__ __launch_bounds__(256) void mix_loss_bwd_kernel(MixP p, const float* __restrict__ gout, float* __restrict__ dy, long ld_dy) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= p.T * (p.A + 1)) return;
+    const int t = w / (p.A + 1), d = w % (p.A + 1);
+    const float g = gout[0] / p.T;
+    float* drow = dy + (long)t * ld_dy;
+    if (d < p.A) mix_nll<true>(p, t, d, g, drow);
+    else {
+        const float* gl = p.y + (long)t * p.ld + 3 * p.A * p.NM;
+        const float a = p.act[(long)t * (p.A + 1) + p.A];
+        const int lbl = (a == -1.f) ? 0 : (int)a;
+        const float mx = fmaxf(gl[0], gl[1]);
+        const float e0 = expf(gl[0] - mx), e1 = expf(gl[1] - mx), inv = 1.f / (e0 + e1);
+        drow[3 * p.A * p.NM + 0] = g * p.gripper_alpha * (e0 * inv - (lbl == 0 ? 1.f : 0.f));
+        drow[3 * p.A * p.NM + 1] = g * p.gripper_alpha * (e1 * inv - (lbl == 1 ? 1.f : 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// categorical latent plan: groups of CLS logits; 32-lane sub-wave per group
+// ------------------------------------------------------------------------------------------------
+HULC_DEVICE float sub32_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+HULC_DEVICE float sub32_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// out[0] = beta * (mix*KL + (1-mix)*KL) = beta*KL_mean (value), single workgroup, CLS == 32
+__global__ __launch_bounds__(1024) void cat_kl_fwd_kernel(const float* __restrict__ pp, const float* __restrict__ pr, int B, int G,
+                                                          float beta, float* __restrict__ out, float* __restrict__ kl_group) {
+    __shared__ float sh[16];
+    const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5, nsub = blockDim.x >> 5;
+    float acc = 0.f;
+    for (int g = sub; g < B * G; g += nsub) {
+        const float a = pr[(long)g * 32 + lane], b = pp[(long)g * 32 + lane];
+        const float ma = sub32_max(a), mb = sub32_max(b);
+        const float lp = a - (ma + logf(sub32_sum(expf(a - ma))));
+        const float lq = b - (mb + logf(sub32_sum(expf(b - mb))));
+        const float kl = sub32_sum(expf(lp) * (lp - lq));
+        if (lane == 0) { kl_group[g] = kl; acc += kl; }
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = beta * acc / B;
+}
+
+__global__ __launch_bounds__(256) void cat_kl_bwd_kernel(const float* __restrict__ pp, const float* __restrict__ pr,
+                                                         const float* __restrict__ kl_group, int B, int G, float beta, float mix,
+                                                         const float* __restrict__ gout, float* __restrict__ dpp, float* __restrict__ dpr) {
+    const int lane = threadIdx.x & 31;
+    const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (g >= B * G) return;
+    const float a = pr[(long)g * 32 + lane], b = pp[(long)g * 32 + lane];
+    const float ma = sub32_max(a), mb = sub32_max(b);
+    const float lp = a - (ma + logf(sub32_sum(expf(a - ma))));
+    const float lq = b - (mb + logf(sub32_sum(expf(b - mb))));
+    const float p = expf(lp), q = expf(lq);
+    const float s = gout[0] * beta / B;
+    dpp[(long)g * 32 + lane] = s * mix * (q - p);
+    dpr[(long)g * 32 + lane] = s * (1.f - mix) * p * (lp - lq - kl_group[g]);
+}
+
+// one-hot sample per group; idx_in (optional) injects the class indices (parity tests)
+__global__ __launch_bounds__(256) void plan_sample_kernel(const float* __restrict__ logits, const long* __restrict__ idx_in,
+                                                          unsigned long long seed, int NG, long* __restrict__ idx_out,
+                                                          float* __restrict__ plan) {
+    const int lane = threadIdx.x & 31;
+    const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (g >= NG) return;
+    int idx;
+    if (idx_in) idx = (int)idx_in[g];
+    else {
+        const float a = logits[(long)g * 32 + lane];
+        const float e = expf(a - sub32_max(a));
+        float c = e;                                           // inclusive prefix sum over the 32 classes
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const float n = __shfl_up(c, o, 32); if (lane >= o) c += n; }
+        const float total = __shfl(c, 31, 32);
+        const float u = hulc_uniform01(seed, (uint64_t)g) * total;
+        const unsigned long long ball = __ballot(c > u);
+        const unsigned int mine = (unsigned int)(ball >> (threadIdx.x & 32));   // this 32-lane half of the wave
+        idx = mine ? __ffs((int)mine) - 1 : 31;
+    }
+    if (lane == 0 && idx_out) idx_out[g] = idx;
+    plan[(long)g * 32 + lane] = lane == idx ? 1.f : 0.f;
+}
+
+// straight-through estimator: d logits = softmax jacobian^T * d plan
+__global__ __launch_bounds__(256) void plan_sample_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dplan, int NG,
+                                                              float* __restrict__ dlogits, int accumulate) {
+    const int lane = threadIdx.x & 31;
+    const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (g >= NG) return;
+    const float a = logits[(long)g * 32 + lane];
+    const float e = expf(a - sub32_max(a));
+    const float p = e / sub32_sum(e);
+    const float gd = dplan[(long)g * 32 + lane];
+    const float dot = sub32_sum(p * gd);
+    const float v = p * (gd - dot);
+    const long i = (long)g * 32 + lane;
+    dlogits[i] = accumulate ? dlogits[i] + v : v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP-style contrastive loss, single workgroup, M <= 128 rows of D = 32 features
+// ------------------------------------------------------------------------------------------------
+#define CLIP_MAXM 128
+#define CLIP_D 32
+template <bool GRAD>
+__global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ im, const float* __restrict__ tx,
+                                                        const unsigned char* __restrict__ use, const float* __restrict__ logit_scale, int M,
+                                                        float* __restrict__ out, const float* __restrict__ gout, float* __restrict__ dim_,
+                                                        float* __restrict__ dtx, float* __restrict__ dscale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* n = sm;                       // [M][D] normalised image features
+    float* t = n + M * CLIP_D;           // [M][D]
+    float* L = t + M * CLIP_D;           // [M][M] logits, later dL
+    float* ni = L + M * M;               // [M] norms
+    float* ti = ni + M;                  // [M]
+    float* rl = ti + M;                  // [M] row lse
+    float* cl = rl + M;                  // [M] col lse
+    __shared__ float sh[16];
+    const int tid = threadIdx.x;
+    const float s = expf(logit_scale[0]);
+    for (int r = tid; r < M; r += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int d = 0; d < CLIP_D; ++d) { a += im[r * CLIP_D + d] * im[r * CLIP_D + d]; b += tx[r * CLIP_D + d] * tx[r * CLIP_D + d]; }
+        ni[r] = sqrtf(a); ti[r] = sqrtf(b);
+    }
+    __syncthreads();
+    for (int i = tid; i < M * CLIP_D; i += blockDim.x) { n[i] = im[i] / ni[i / CLIP_D]; t[i] = tx[i] / ti[i / CLIP_D]; }
+    __syncthreads();
+    for (int i = tid; i < M * M; i += blockDim.x) {
+        const int r = i / M, c = i % M;
+        float a = 0.f;
+        for (int d = 0; d < CLIP_D; ++d) a += n[r * CLIP_D + d] * t[c * CLIP_D + d];
+        L[i] = s * a;
+    }
+    __syncthreads();
+    float cnt = 0.f;
+    for (int r = 0; r < M; ++r) cnt += use[r] ? 1.f : 0.f;
+    for (int r = tid; r < M; r += blockDim.x) {
+        float m1 = -INFINITY, m2 = -INFINITY;
+        for (int c = 0; c < M; ++c) if (use[c]) { m1 = fmaxf(m1, L[r * M + c]); m2 = fmaxf(m2, L[c * M + r]); }
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < M; ++c) if (use[c]) { s1 += expf(L[r * M + c] - m1); s2 += expf(L[c * M + r] - m2); }
+        rl[r] = m1 + logf(s1); cl[r] = m2 + logf(s2);
+    }
+    __syncthreads();
+    if (!GRAD) {
+        float acc = 0.f;
+        for (int r = tid; r < M; r += blockDim.x) if (use[r]) acc += (rl[r] - L[r * M + r]) + (cl[r] - L[r * M + r]);
+        acc = block_sum(acc, sh);
+        if (tid == 0) out[0] = cnt > 0.f ? acc / (2.f * cnt) : 0.f;
+        return;
+    }
+    const float g = cnt > 0.f ? gout[0] / (2.f * cnt) : 0.f;
+    float ds = 0.f;
+    for (int i = tid; i < M * M; i += blockDim.x) {
+        const int r = i / M, c = i % M;
+        float dl = 0.f;
+        if (use[r] && use[c]) {
+            const float lv = L[i];
+            dl = g * (expf(lv - rl[r]) + expf(lv - cl[c]) - (r == c ? 2.f : 0.f));
+            ds += dl * lv;                       // d/d logit_scale of s*dot = L
+        }
+        L[i] = dl;
+    }
+    ds = block_sum(ds, sh);                      // contains a __syncthreads: all dL written
+    if (tid == 0) dscale[0] = ds;
+    for (int i = tid; i < M * CLIP_D; i += blockDim.x) {
+        const int r = i / CLIP_D, d = i % CLIP_D;
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < M; ++c) { a += L[r * M + c] * t[c * CLIP_D + d]; b += L[c * M + r] * n[c * CLIP_D + d]; }
+        dim_[i] = s * a;                         // gradient w.r.t. the normalised feature (projected below)
+        dtx[i] = s * b;
+    }
+    __syncthreads();
+    for (int r = tid; r < M; r += blockDim.x) {
+        float pa = 0.f, pb = 0.f;
+        for (int d = 0; d < CLIP_D; ++d) { pa += dim_[r * CLIP_D + d] * n[r * CLIP_D + d]; pb += dtx[r * CLIP_D + d] * t[r * CLIP_D + d]; }
+        for (int d = 0; d < CLIP_D; ++d) {
+            dim_[r * CLIP_D + d] = (dim_[r * CLIP_D + d] - n[r * CLIP_D + d] * pa) / ni[r];
+            dtx[r * CLIP_D + d] = (dtx[r * CLIP_D + d] - t[r * CLIP_D + d] * pb) / ti[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// world -> tcp frame (one thread per (b, s)); R = Rx(a) Ry(b) Rz(c)
+// ------------------------------------------------------------------------------------------------
+HULC_DEVICE void euler_xyz(float a, float b, float c, float (&R)[3][3]) {
+    const float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
+    R[0][0] = cb * cc;                R[0][1] = -cb * sc;               R[0][2] = sb;
+    R[1][0] = sa * sb * cc + ca * sc; R[1][1] = -sa * sb * sc + ca * cc; R[1][2] = -sa * cb;
+    R[2][0] = -ca * sb * cc + sa * sc; R[2][1] = ca * sb * sc + sa * cc; R[2][2] = ca * cb;
+}
+__global__ void world_to_tcp_kernel(const float* __restrict__ act, const float* __restrict__ obs, int n, int obs_dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = act + (long)i * 7;
+    const float* o = obs + (long)i * obs_dim;
+    float R[3][3], Rn[3][3];
+    euler_xyz(o[3], o[4], o[5], R);
+    euler_xyz(o[3] + 0.01f * a[3], o[4] + 0.01f * a[4], o[5] + 0.01f * a[5], Rn);
+    float* y = out + (long)i * 7;
+    for (int r = 0; r < 3; ++r) y[r] = R[0][r] * a[0] + R[1][r] * a[1] + R[2][r] * a[2];      // R^-1 p = R^T p
+    float M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = Rn[0][r] * R[0][c] + Rn[1][r] * R[1][c] + Rn[2][r] * R[2][c];   // Rn^T R
+    float e[3] = {atan2f(-M[1][2], M[2][2]), asinf(fminf(fmaxf(M[0][2], -1.f), 1.f)), atan2f(-M[0][1], M[0][0])};
+    const float pi = 3.14159265358979323846f;
+    for (int r = 0; r < 3; ++r) {
+        if (e[r] < -pi) e[r] += 2 * pi;
+        if (e[r] > pi) e[r] -= 2 * pi;
+        y[3 + r] = e[r] * 100.f;
+    }
+    y[6] = a[6];
+}
+
+MixP make_mix(const hulc_mix_desc* d, const float* y, const float* act) {
+    MixP p;
+    p.y = y; p.ld = d->ld; p.act = act; p.amin = d->act_min; p.amax = d->act_max;
+    p.T = d->T; p.A = d->A; p.NM = d->n_mix; p.num_classes = d->num_classes;
+    p.log_scale_min = d->log_scale_min; p.gripper_alpha = d->gripper_alpha;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out3, void* stream) {
+    if (!d || !y || !act || !out3 || !d->act_min || !d->act_max) return hulc_fail(-1, "hulc_mix_loss_fwd: null pointer");
+    if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss_fwd: n_mix must be in 1..16");
+    mix_loss_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(make_mix(d, y, act), out3);
+    return hulc_check_launch("hulc_mix_loss_fwd");
+}
+extern "C" int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const float* act, const float* gout, float* dy, long ld_dy,
+                                 void* stream) {
+    if (!d || !y || !act || !gout || !dy) return hulc_fail(-1, "hulc_mix_loss_bwd: null pointer");
+    if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss_bwd: n_mix must be in 1..16");
+    const int n = d->T * (d->A + 1);
+    mix_loss_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(make_mix(d, y, act), gout, dy, ld_dy);
+    return hulc_check_launch("hulc_mix_loss_bwd");
+}
+
+extern "C" int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, float* out, float* kl_group, void* stream) {
+    if (!pp || !pr || !out || !kl_group) return hulc_fail(-1, "hulc_cat_kl_fwd: null pointer");
+    if (CLS != 32) return hulc_fail(-2, "hulc_cat_kl_fwd: class_size must be 32 (one 32-lane sub-wave per category)");
+    cat_kl_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pp, pr, B, G, beta, out, kl_group);
+    return hulc_check_launch("hulc_cat_kl_fwd");
+}
+extern "C" int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int B, int G, int CLS, float beta, float mix,
+                               const float* gout, float* dpp, float* dpr, void* stream) {
+    if (!pp || !pr || !kl_group || !gout || !dpp || !dpr) return hulc_fail(-1, "hulc_cat_kl_bwd: null pointer");
+    if (CLS != 32) return hulc_fail(-2, "hulc_cat_kl_bwd: class_size must be 32");
+    cat_kl_bwd_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, kl_group, B, G, beta, mix, gout, dpp, dpr);
+    return hulc_check_launch("hulc_cat_kl_bwd");
+}
+extern "C" int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, int NG, int CLS, long* idx_out,
+                                    float* plan, void* stream) {
+    if (!logits || !plan) return hulc_fail(-1, "hulc_plan_sample_fwd: null pointer");
+    if (CLS != 32) return hulc_fail(-2, "hulc_plan_sample_fwd: class_size must be 32");
+    plan_sample_kernel<<<(NG + 7) / 8, 256, 0, (hipStream_t)stream>>>(logits, idx_in, seed, NG, idx_out, plan);
+    return hulc_check_launch("hulc_plan_sample_fwd");
+}
+extern "C" int hulc_plan_sample_bwd(const float* logits, const float* dplan, int NG, int CLS, float* dlogits, int accumulate, void* stream) {
+    if (!logits || !dplan || !dlogits) return hulc_fail(-1, "hulc_plan_sample_bwd: null pointer");
+    if (CLS != 32) return hulc_fail(-2, "hulc_plan_sample_bwd: class_size must be 32");
+    plan_sample_bwd_kernel<<<(NG + 7) / 8, 256, 0, (hipStream_t)stream>>>(logits, dplan, NG, dlogits, accumulate);
+    return hulc_check_launch("hulc_plan_sample_bwd");
+}
+
+static size_t clip_smem(int M) { return ((size_t)2 * M * CLIP_D + (size_t)M * M + 4 * (size_t)M) * sizeof(float); }
+
+extern "C" int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+                                  float* out, void* stream) {
+    if (!im || !tx || !use || !logit_scale || !out) return hulc_fail(-1, "hulc_clip_loss_fwd: null pointer");
+    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_fwd: needs M <= 128 and D == 32");
+    clip_loss_kernel<false><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, out, nullptr, nullptr, nullptr, nullptr);
+    return hulc_check_launch("hulc_clip_loss_fwd");
+}
+extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+                                  const float* gout, float* dim, float* dtx, float* dscale, void* stream) {
+    if (!im || !tx || !use || !logit_scale || !gout || !dim || !dtx || !dscale) return hulc_fail(-1, "hulc_clip_loss_bwd: null pointer");
+    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128 and D == 32");
+    clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, nullptr, gout, dim, dtx, dscale);
+    return hulc_check_launch("hulc_clip_loss_bwd");
+}
+
+extern "C" int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream) {
+    if (!act || !robot_obs || !out) return hulc_fail(-1, "hulc_world_to_tcp: null pointer");
+    if (obs_dim < 6) return hulc_fail(-2, "hulc_world_to_tcp: robot_obs needs the euler angles in columns 3:6");
+    world_to_tcp_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(act, robot_obs, n, obs_dim, out);
+    return hulc_check_launch("hulc_world_to_tcp");
+}

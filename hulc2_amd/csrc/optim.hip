@@ -1,0 +1,80 @@
+// optim.hip — optimizer step and dtype shadows over the flat parameter arena.
+//
+//   Adam: torch.optim.Adam(lr=2e-4, betas=(0.9,0.999), eps=1e-8, weight_decay=0) as configured by
+//   conf/model/optimizer/adam.yaml + hulc2/models/hulc2.py:185-198, applied to one contiguous fp32
+//   arena (params / grads / exp_avg / exp_avg_sq share offsets).  HBM-bound: 4 reads + 3 writes of
+//   4 bytes (+2 for the bf16 weight shadow the MFMA kernels consume) per parameter, float4-vectorised.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 pv = *(float4*)(p + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+            float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+            float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gg = ga[k] * gscale + wd * pa[k];
+                ma[k] = b1 * ma[k] + (1.f - b1) * gg;
+                va[k] = b2 * va[k] + (1.f - b2) * gg * gg;
+                const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+                pa[k] -= (lr / bc1) * (ma[k] / denom);
+            }
+            *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+            *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+            *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+            if (shadow) {
+                uint2 s; s.x = pack_bf16x2(pa[0], pa[1]); s.y = pack_bf16x2(pa[2], pa[3]);
+                *(uint2*)(shadow + i) = s;
+            }
+        } else {
+            for (long k = i; k < n; ++k) {
+                float gg = g[k] * gscale + wd * p[k];
+                float mm = b1 * m[k] + (1.f - b1) * gg, vv = b2 * v[k] + (1.f - b2) * gg * gg;
+                m[k] = mm; v[k] = vv;
+                float pn = p[k] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+                p[k] = pn;
+                if (shadow) shadow[k] = f32_to_bf16_bits(pn);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 a = *(const float4*)(src + i);
+            uint2 s; s.x = pack_bf16x2(a.x, a.y); s.y = pack_bf16x2(a.z, a.w);
+            *(uint2*)(dst + i) = s;
+        } else for (long k = i; k < n; ++k) dst[k] = f32_to_bf16_bits(src[k]);
+    }
+}
+
+}  // namespace
+
+extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return hulc_fail(-1, "hulc_adam_step: null pointer");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return hulc_fail(-4, "hulc_adam_step: arenas must be 16-byte aligned");
+    if (step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
+                                                                   bc1, bc2s, grad_scale);
+    return hulc_check_launch("hulc_adam_step");
+}
+
+extern "C" int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+    if (!src || !dst) return hulc_fail(-1, "hulc_cast_f32_to_bf16: null pointer");
+    if (((uintptr_t)src % 16) || ((uintptr_t)dst % 8)) return hulc_fail(-4, "hulc_cast_f32_to_bf16: misaligned");
+    long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    cast_bf16_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, n);
+    return hulc_check_launch("hulc_cast_f32_to_bf16");
+}

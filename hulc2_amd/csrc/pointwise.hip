@@ -1,0 +1,501 @@
+// pointwise.hip — HBM-bound reductions of the perceptual encoders and the plan-recognition transformer,
+// written as 64-lane wavefront kernels (lane = channel / feature column, no cross-lane traffic where the
+// layout allows it).
+//
+//   spatial softmax   : hulc2/models/perceptual_encoders/vision_network.py:100-108
+//   (residual+dropout+) LayerNorm : nn.LayerNorm in vision_network.py:53, goal_encoders.py:28,61 and the
+//                       post-norm nn.TransformerEncoderLayer of plan_recognition_net.py:115-117
+//   column sums       : bias gradients of every Linear
+//   sequence mean, positional-embedding add : plan_recognition_net.py:133-136,145
+//   self-attention    : nn.MultiheadAttention inside the encoder layer (S <= 32, head_dim 16)
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// spatial softmax, NHWC input [N][HW][C], C <= 64 (lane = channel)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spatial_softmax_fwd_kernel(const void* __restrict__ x, int x_dtype, int N, int HW, int C,
+                                                                  const float* __restrict__ xmap, const float* __restrict__ ymap,
+                                                                  const float* __restrict__ temperature, float* __restrict__ out,
+                                                                  float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N || lane >= C) return;
+    const float invT = 1.0f / temperature[0];
+    const long base = (long)n * HW * C + lane;
+    float m = -INFINITY;
+    for (int p = 0; p < HW; ++p) m = fmaxf(m, load_elem(x, x_dtype, base + (long)p * C) * invT);
+    float s = 0.f, sx = 0.f, sy = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        const float e = __expf(load_elem(x, x_dtype, base + (long)p * C) * invT - m);
+        s += e; sx += e * xmap[p]; sy += e * ymap[p];
+    }
+    const float inv = 1.0f / s;
+    out[(long)n * 2 * C + 2 * lane] = sx * inv;
+    out[(long)n * 2 * C + 2 * lane + 1] = sy * inv;
+    stats[((long)n * C + lane) * 2] = m;
+    stats[((long)n * C + lane) * 2 + 1] = s;
+}
+
+// dz[n][p][c] = (x > 0) * (1/T) * softmax_p * (gx*(xmap_p - ex) + gy*(ymap_p - ey))
+__global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const void* __restrict__ x, int x_dtype, int N, int HW, int C,
+                                                                  const float* __restrict__ xmap, const float* __restrict__ ymap,
+                                                                  const float* __restrict__ temperature, const float* __restrict__ out,
+                                                                  const float* __restrict__ stats, const float* __restrict__ dout,
+                                                                  void* __restrict__ dx, int dx_dtype, int relu_mask) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N || lane >= C) return;
+    const float invT = 1.0f / temperature[0];
+    const long base = (long)n * HW * C + lane;
+    const float m = stats[((long)n * C + lane) * 2], inv = 1.0f / stats[((long)n * C + lane) * 2 + 1];
+    const float ex = out[(long)n * 2 * C + 2 * lane], ey = out[(long)n * 2 * C + 2 * lane + 1];
+    const float gx = dout[(long)n * 2 * C + 2 * lane], gy = dout[(long)n * 2 * C + 2 * lane + 1];
+    for (int p = 0; p < HW; ++p) {
+        const float xv = load_elem(x, x_dtype, base + (long)p * C);
+        const float pr = __expf(xv * invT - m) * inv;
+        float g = invT * pr * (gx * (xmap[p] - ex) + gy * (ymap[p] - ey));
+        if (relu_mask && !(xv > 0.f)) g = 0.f;
+        store_elem(dx, dx_dtype, base + (long)p * C, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension D <= 256 (one wave per row, up to 4 elements per lane)
+//   pre = x + dropout(o)   (o optional)   y = (pre - mean) * rstd * gamma + beta
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ o, float drop_p,
+                                                            unsigned long long seed, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int R, int D,
+                                                            float* __restrict__ pre_out, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + q * 64;
+        v[q] = 0.f;
+        if (c < D) {
+            const long i = (long)r * D + c;
+            float t = x[i];
+            if (o) {
+                float ov = o[i];
+                if (drop_p > 0.f) ov *= dropout_scale(seed, (uint64_t)i, drop_p);
+                t += ov;
+            }
+            v[q] = t;
+            if (pre_out) pre_out[i] = t;
+            s += t;
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + q * 64;
+        if (c < D) { const float dlt = v[q] - mean; ss += dlt * dlt; }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / D + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + q * 64;
+        if (c < D) y[(long)r * D + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (lane == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+}
+
+// dpre = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial dgamma/dbeta per block.
+// do_out (optional) = dpre * dropout keep-scale (the gradient of the dropped branch o).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ gamma, int R, int D, int rows_per_block,
+                                                            float* __restrict__ dpre, float* __restrict__ do_out, float drop_p,
+                                                            unsigned long long seed, float* __restrict__ partial) {
+    __shared__ float red[4][2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int r = r0 + wave; r < r0 + rows_per_block && r < R; r += 4) {
+        const float mean = mean_in[r], rstd = rstd_in[r];
+        float g[4], xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + q * 64;
+            g[q] = 0.f; xh[q] = 0.f;
+            if (c < D) {
+                const long i = (long)r * D + c;
+                const float d = dy[i];
+                xh[q] = (pre[i] - mean) * rstd;
+                g[q] = d * gamma[c];
+                dg[q] += d * xh[q]; db[q] += d;
+                s1 += g[q]; s2 += g[q] * xh[q];
+            }
+        }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + q * 64;
+            if (c < D) {
+                const long i = (long)r * D + c;
+                const float v = rstd * (g[q] - s1 - xh[q] * s2);
+                dpre[i] = v;
+                if (do_out) do_out[i] = drop_p > 0.f ? v * dropout_scale(seed, (uint64_t)i, drop_p) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[wave][0][lane + q * 64] = dg[q]; red[wave][1][lane + q * 64] = db[q]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { a += red[w][0][c]; b += red[w][1][c]; }
+        partial[(long)blockIdx.x * 2 * D + c] = a;
+        partial[(long)blockIdx.x * 2 * D + D + c] = b;
+    }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, long ld, int accumulate) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += partial[(long)q * ld + r];
+    out[r] = accumulate ? out[r] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: out[n] = sum_m x[m][n]   (bias gradients).  Workgroup = 4 waves x 64 columns.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int x_dtype, long M, int N, long ld, long rows_per_block,
+                                                     float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (n < N)
+        for (long r = r0 + wave; r < r1; r += 4) s += load_elem(x, x_dtype, r * ld + n);
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) partial[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequence mean and positional embedding
+// ------------------------------------------------------------------------------------------------
+__global__ void seq_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int S, int D, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D) return;
+    const int b = (int)(i / D), d = (int)(i % D);
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += x[((long)b * S + t) * D + d];
+    y[i] = scale * (s / S);
+}
+__global__ void seq_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int S, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S * D) return;
+    const int d = (int)(i % D); const long bs = i / D; const int b = (int)(bs / S);
+    dx[i] = dy[(long)b * D + d] / S;
+}
+// y[b][s][:] = dropout(x[b][s][:] + pos[pos_ids[s]][:])
+__global__ void add_pos_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, const long* __restrict__ pos_ids,
+                                   float* __restrict__ y, int B, int S, int D, float drop_p, unsigned long long seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S * D) return;
+    const int d = (int)(i % D); const int s = (int)((i / D) % S);
+    float v = x[i] + pos[pos_ids[s] * D + d];
+    if (drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)i, drop_p);
+    y[i] = v;
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n, float drop_p, unsigned long long seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dx[i] = dy[i] * dropout_scale(seed, (uint64_t)i, drop_p);
+}
+
+// dx = dy * (y > 0) * scale   (gradient through ReLU [+ inverted dropout] given the saved output y)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const void* __restrict__ y, int y_dtype, float* __restrict__ dx, long n, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dx[i] = load_elem(y, y_dtype, i) > 0.f ? dy[i] * scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-head self-attention for short sequences: one wave per (batch, head); S <= 32, head_dim = 16.
+// qkv: [B*S][3E] rows = token b*S+s, columns [q | k | v], head h owns columns h*16..h*16+15 of each.
+// ------------------------------------------------------------------------------------------------
+#define ATT_DH 16
+__global__ __launch_bounds__(64) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ probs,
+                                                           int B, int S, int H, float scale, float drop_p, unsigned long long seed) {
+    __shared__ float q[32][ATT_DH + 1], k[32][ATT_DH + 1], v[32][ATT_DH + 1];
+    const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x % H, E = H * ATT_DH;
+    for (int idx = lane; idx < S * ATT_DH; idx += 64) {
+        const int s = idx / ATT_DH, d = idx % ATT_DH;
+        const long row = ((long)b * S + s) * 3 * E + h * ATT_DH + d;
+        q[s][d] = qkv[row]; k[s][d] = qkv[row + E]; v[s][d] = qkv[row + 2 * E];
+    }
+    __syncthreads();
+    const int i = lane & 31, half = lane >> 5;
+    float sc[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = half * 16 + jj;
+        float a = -INFINITY;
+        if (i < S && j < S) {
+            a = 0.f;
+#pragma unroll
+            for (int d = 0; d < ATT_DH; ++d) a += q[i][d] * k[j][d];
+            a *= scale;
+        }
+        sc[jj] = a; m = fmaxf(m, a);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { sc[jj] = (i < S && half * 16 + jj < S) ? __expf(sc[jj] - m) : 0.f; sum += sc[jj]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = i < S ? 1.0f / sum : 0.f;
+    float o[ATT_DH];
+#pragma unroll
+    for (int d = 0; d < ATT_DH; ++d) o[d] = 0.f;
+    const long pbase = (((long)b * H + h) * S + i) * S;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = half * 16 + jj;
+        if (i < S && j < S) {
+            float p = sc[jj] * inv;
+            if (drop_p > 0.f) p *= dropout_scale(seed, (uint64_t)(pbase + j), drop_p);
+            probs[pbase + j] = p;           // post-dropout probabilities (what multiplies V)
+#pragma unroll
+            for (int d = 0; d < ATT_DH; ++d) o[d] += p * v[j][d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ATT_DH; ++d) o[d] += __shfl_xor(o[d], 32, 64);
+    if (i < S) {
+        float* dst = out + ((long)b * S + i) * E + h * ATT_DH + half * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dst[d] = o[half * 8 + d];
+    }
+}
+
+// probs holds the post-dropout probabilities P'; the pre-dropout softmax is P = P' / keepscale where
+// kept, and dropped entries contribute no gradient (their dP' is multiplied by 0).
+__global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                           const float* __restrict__ dout, float* __restrict__ dqkv, int B, int S, int H,
+                                                           float scale, float drop_p, unsigned long long seed) {
+    __shared__ float q[32][ATT_DH + 1], k[32][ATT_DH + 1], v[32][ATT_DH + 1], go[32][ATT_DH + 1];
+    __shared__ float ds[32][33], pp[32][33];
+    const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x % H, E = H * ATT_DH;
+    for (int idx = lane; idx < S * ATT_DH; idx += 64) {
+        const int s = idx / ATT_DH, d = idx % ATT_DH;
+        const long row = ((long)b * S + s) * 3 * E + h * ATT_DH + d;
+        q[s][d] = qkv[row]; k[s][d] = qkv[row + E]; v[s][d] = qkv[row + 2 * E];
+        go[s][d] = dout[((long)b * S + s) * E + h * ATT_DH + d];
+    }
+    for (int idx = lane; idx < 32 * 33; idx += 64) { (&ds[0][0])[idx] = 0.f; (&pp[0][0])[idx] = 0.f; }
+    __syncthreads();
+    const int i = lane & 31, half = lane >> 5;
+    const long pbase = (((long)b * H + h) * S + i) * S;
+    float dp[16], pr[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = half * 16 + jj;
+        dp[jj] = 0.f; pr[jj] = 0.f;
+        if (i < S && j < S) {
+            const float pd = probs[pbase + j];                   // P' (post-dropout)
+            float ks = 1.f;
+            if (drop_p > 0.f) ks = dropout_scale(seed, (uint64_t)(pbase + j), drop_p);
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < ATT_DH; ++d) a += go[i][d] * v[j][d];   // dP'
+            const float p = ks > 0.f ? pd / ks : 0.f;                    // P where kept (dropped: gradient is 0 anyway)
+            dp[jj] = a * ks;                                             // dP
+            pr[jj] = p;
+            dot += dp[jj] * p;
+            pp[i][j] = pd;
+        }
+    }
+    // note: for dropped entries p is unknown (set 0) but dP = 0 there, so dot and dS are exact except
+    // that dS for a dropped entry must still be -P*dot; recover P from a second softmax pass below.
+    dot += __shfl_xor(dot, 32, 64);
+    if (drop_p > 0.f) {
+        // recompute the exact pre-dropout softmax row (cheap: S <= 32)
+        float sc[16], m = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = half * 16 + jj;
+            float a = -INFINITY;
+            if (i < S && j < S) {
+                a = 0.f;
+#pragma unroll
+                for (int d = 0; d < ATT_DH; ++d) a += q[i][d] * k[j][d];
+                a *= scale;
+            }
+            sc[jj] = a; m = fmaxf(m, a);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) { sc[jj] = (i < S && half * 16 + jj < S) ? __expf(sc[jj] - m) : 0.f; sum += sc[jj]; }
+        sum += __shfl_xor(sum, 32, 64);
+        dot = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) { pr[jj] = i < S ? sc[jj] / sum : 0.f; dot += dp[jj] * pr[jj]; }
+        dot += __shfl_xor(dot, 32, 64);
+    }
+    float dq[ATT_DH];
+#pragma unroll
+    for (int d = 0; d < ATT_DH; ++d) dq[d] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = half * 16 + jj;
+        if (i < S && j < S) {
+            const float dsv = pr[jj] * (dp[jj] - dot) * scale;
+            ds[i][j] = dsv;
+#pragma unroll
+            for (int d = 0; d < ATT_DH; ++d) dq[d] += dsv * k[j][d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ATT_DH; ++d) dq[d] += __shfl_xor(dq[d], 32, 64);
+    if (i < S) {
+        float* dst = dqkv + ((long)b * S + i) * 3 * E + h * ATT_DH + half * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dst[d] = dq[half * 8 + d];
+    }
+    __syncthreads();
+    // key/value side: lane owns key j = lane & 31 and 8 of the 16 head dims
+    const int j = i;
+    if (j < S) {
+        float dk[8], dv[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        for (int ii = 0; ii < S; ++ii) {
+            const float a = ds[ii][j], pv = pp[ii][j];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dk[d] += a * q[ii][half * 8 + d]; dv[d] += pv * go[ii][half * 8 + d]; }
+        }
+        float* dst = dqkv + ((long)b * S + j) * 3 * E + h * ATT_DH + half * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { dst[E + d] = dk[d]; dst[2 * E + d] = dv[d]; }
+    }
+}
+
+}  // namespace
+
+extern "C" int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int HW, int C, const float* xmap, const float* ymap,
+                                        const float* temperature, float* out, float* stats, void* stream) {
+    if (!x || !xmap || !ymap || !temperature || !out || !stats) return hulc_fail(-1, "hulc_spatial_softmax_fwd: null pointer");
+    if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_fwd: C must be in 1..64 (lane = channel)");
+    spatial_softmax_fwd_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
+    return hulc_check_launch("hulc_spatial_softmax_fwd");
+}
+
+extern "C" int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int HW, int C, const float* xmap, const float* ymap,
+                                        const float* temperature, const float* out, const float* stats, const float* dout,
+                                        void* dx, int dx_dtype, int relu_mask, void* stream) {
+    if (!x || !out || !stats || !dout || !dx) return hulc_fail(-1, "hulc_spatial_softmax_bwd: null pointer");
+    if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_bwd: C must be in 1..64");
+    spatial_softmax_bwd_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats,
+                                                                             dout, dx, dx_dtype, relu_mask);
+    return hulc_check_launch("hulc_spatial_softmax_bwd");
+}
+
+extern "C" int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const float* gamma,
+                                  const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean, float* rstd,
+                                  void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return hulc_fail(-1, "hulc_layernorm_fwd: null pointer");
+    if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_fwd: D must be in 1..256");
+    if (o && !pre_out) return hulc_fail(-3, "hulc_layernorm_fwd: pre_out required with a residual branch");
+    layernorm_fwd_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, o, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, rstd);
+    return hulc_check_launch("hulc_layernorm_fwd");
+}
+
+extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
+    const int rpb = 32;
+    return (long)((R + rpb - 1) / rpb) * 2 * D * (long)sizeof(float);
+}
+
+extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R,
+                                  int D, float* dpre, float* do_out, float drop_p, unsigned long long seed, float* dgamma, float* dbeta,
+                                  void* ws, void* stream) {
+    if (!dy || !pre || !mean || !rstd || !gamma || !dpre || !dgamma || !dbeta || !ws) return hulc_fail(-1, "hulc_layernorm_bwd: null pointer");
+    if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_bwd: D must be in 1..256");
+    const int rpb = 32, nb = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, (float*)ws);
+    // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
+    reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, 0);
+    reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, 0);
+    return hulc_check_launch("hulc_layernorm_bwd");
+}
+
+extern "C" long hulc_colsum_workspace(long M, int N) {
+    long rb = (M + 511) / 512; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+    return rb * N * (long)sizeof(float);
+}
+
+extern "C" int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream) {
+    if (!x || !out || !ws) return hulc_fail(-1, "hulc_colsum: null pointer");
+    long rb = (M + 511) / 512; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+    const long rpb = (M + rb - 1) / rb;
+    rb = (M + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((N + 63) / 64, (unsigned)rb);
+    colsum_kernel<<<grid, 256, 0, s>>>(x, x_dtype, M, N, ld, rpb, (float*)ws);
+    reduce_rows_kernel<<<(N + 255) / 256, 256, 0, s>>>((const float*)ws, out, (int)rb, N, N, accumulate);
+    return hulc_check_launch("hulc_colsum");
+}
+
+extern "C" int hulc_seq_mean_fwd(const float* x, float* y, int B, int S, int D, float scale, void* stream) {
+    if (!x || !y) return hulc_fail(-1, "hulc_seq_mean_fwd: null pointer");
+    const long n = (long)B * D;
+    seq_mean_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, B, S, D, scale);
+    return hulc_check_launch("hulc_seq_mean_fwd");
+}
+extern "C" int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D, void* stream) {
+    if (!dy || !dx) return hulc_fail(-1, "hulc_seq_mean_bwd: null pointer");
+    const long n = (long)B * S * D;
+    seq_mean_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, dx, B, S, D);
+    return hulc_check_launch("hulc_seq_mean_bwd");
+}
+extern "C" int hulc_add_pos_fwd(const float* x, const float* pos, const long* pos_ids, float* y, int B, int S, int D, float drop_p,
+                                unsigned long long seed, void* stream) {
+    if (!x || !pos || !pos_ids || !y) return hulc_fail(-1, "hulc_add_pos_fwd: null pointer");
+    const long n = (long)B * S * D;
+    add_pos_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pos, pos_ids, y, B, S, D, drop_p, seed);
+    return hulc_check_launch("hulc_add_pos_fwd");
+}
+extern "C" int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, void* stream) {
+    if (!dy || !dx) return hulc_fail(-1, "hulc_dropout_bwd: null pointer");
+    dropout_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, dx, n, drop_p, seed);
+    return hulc_check_launch("hulc_dropout_bwd");
+}
+
+extern "C" int hulc_relu_bwd(const float* dy, const void* y, int y_dtype, float* dx, long n, float scale, void* stream) {
+    if (!dy || !y || !dx) return hulc_fail(-1, "hulc_relu_bwd: null pointer");
+    relu_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, y, y_dtype, dx, n, scale);
+    return hulc_check_launch("hulc_relu_bwd");
+}
+
+extern "C" int hulc_attention_fwd(const float* qkv, float* out, float* probs, int B, int S, int H, int head_dim, float drop_p,
+                                  unsigned long long seed, void* stream) {
+    if (!qkv || !out || !probs) return hulc_fail(-1, "hulc_attention_fwd: null pointer");
+    if (S > 32 || S <= 0 || head_dim != ATT_DH) return hulc_fail(-2, "hulc_attention_fwd: needs S <= 32 and head_dim == 16");
+    attention_fwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, out, probs, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed);
+    return hulc_check_launch("hulc_attention_fwd");
+}
+extern "C" int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int B, int S, int H, int head_dim,
+                                  float drop_p, unsigned long long seed, void* stream) {
+    if (!qkv || !probs || !dout || !dqkv) return hulc_fail(-1, "hulc_attention_bwd: null pointer");
+    if (S > 32 || S <= 0 || head_dim != ATT_DH) return hulc_fail(-2, "hulc_attention_bwd: needs S <= 32 and head_dim == 16");
+    attention_bwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, probs, dout, dqkv, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed);
+    return hulc_check_launch("hulc_attention_bwd");
+}

@@ -1,0 +1,506 @@
+"""Differentiable operators of the HULC++ low-level policy, each a torch.autograd.Function whose forward
+and backward are calls into libhulc2_amd.so (hulc2_amd/kernels.py).  Python only allocates buffers and
+orders launches; there is no eager-PyTorch arithmetic fallback.
+
+Layout conventions: camera frames arrive NCHW fp32 as the reference delivers them, every
+conv activation is NHWC; token tensors are (B, S, D) row-major with token index b*S+s; weights keep the
+reference's nn.Linear / nn.Conv2d / nn.RNN layouts so state_dicts interchange.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as kn
+from .shadow import weight_operand
+
+
+def _f32(*shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP chain: y = L_n(...relu(L_1(x))) — all Linear(+ReLU(+Dropout)) stacks of the policy
+# reference: plan_proposal_net.py:26-47, goal_encoders.py:21-34,53-71, vision_network.py:49-52,
+#            proj_vis_lang.py:10-21, nn.TransformerEncoderLayer feed-forward block
+# ------------------------------------------------------------------------------------------------
+class MLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, relus: Tuple[bool, ...], drops: Tuple[float, ...], seed: int, *params):
+        L = len(relus)
+        assert len(params) == 2 * L and not relus[-1], "chain must end with a plain Linear"
+        x2 = _c(x.reshape(-1, x.shape[-1]))
+        M = x2.shape[0]
+        acts: List[torch.Tensor] = []
+        inp = x2
+        for i in range(L):
+            W, b = params[2 * i], params[2 * i + 1]
+            N, K = W.shape
+            out = _f32(M, N, like=x2)
+            kn.gemm(inp, weight_operand(W), out, M, N, K, inp.stride(0), K, N, bias=b, relu=relus[i],
+                    drop_p=drops[i], drop_seed=seed + i)
+            acts.append(out)
+            inp = out
+        ctx.save_for_backward(x2, *acts[:-1], *params)
+        ctx.meta = (relus, drops, seed, L, x.shape)
+        return acts[-1].reshape(*x.shape[:-1], acts[-1].shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        relus, drops, seed, L, xshape = ctx.meta
+        saved = ctx.saved_tensors
+        x2, acts, params = saved[0], saved[1:L], saved[L:]
+        g = _c(dy.reshape(-1, dy.shape[-1]))
+        M = g.shape[0]
+        grads = [None] * (2 * L)
+        need_x = ctx.needs_input_grad[0]
+        for i in range(L - 1, -1, -1):
+            W = params[2 * i]
+            N, K = W.shape
+            inp = x2 if i == 0 else acts[i - 1]
+            dW = _f32(N, K, like=g)
+            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False)   # dW = g^T inp
+            db = _f32(N, like=g)
+            kn.colsum(g, M, N, g.stride(0), db)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0 or need_x:
+                dinp = _f32(M, K, like=g)
+                if i > 0 and relus[i - 1]:
+                    kn.gemm(g, weight_operand(W), dinp, M, K, N, g.stride(0), K, K, b_kmajor=False, mask=acts[i - 1], ld_mask=K,
+                            mask_scale=1.0 / (1.0 - drops[i - 1]))
+                else:
+                    kn.gemm(g, weight_operand(W), dinp, M, K, N, g.stride(0), K, K, b_kmajor=False)
+                g = dinp
+        dx = g.reshape(xshape) if need_x else None
+        return (dx, None, None, None, *grads)
+
+
+def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Optional[Sequence[float]] = None, seed: int = 0):
+    """layers: [(weight, bias, relu), ...]; dropout (inverted, after the ReLU) per layer optional."""
+    relus = tuple(bool(r) for _, _, r in layers)
+    drops = tuple(float(d) for d in (drops or [0.0] * len(layers)))
+    params = [t for W, b, _ in layers for t in (W, b)]
+    return MLPFn.apply(x, relus, drops, int(seed), *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv stack of a camera encoder -> NHWC ReLU activations of conv3
+# reference: vision_network.py:36-47, vision_network_gripper.py:11-20
+# ------------------------------------------------------------------------------------------------
+class ConvStackFn(torch.autograd.Function):
+    """x (N,3,H,W) NCHW -> a3 (N,OH3,OW3,64) NHWC.  `grad_premasked`: the incoming gradient has already been
+    multiplied by (a3 > 0) by the consumer (spatial softmax backward does it for free)."""
+
+    GEOM = ((8, 4), (4, 2), (3, 1))   # (kernel, stride) of the three layers
+
+    @staticmethod
+    def forward(ctx, x, grad_premasked: bool, w1, b1, w2, b2, w3, b3):
+        x = _c(x)
+        N, C, H, W = x.shape
+        ws, bs = (w1, w2, w3), (b1, b2, b3)
+        acts, dims = [], []
+        inp, h, w_, cin = x, H, W, C
+        for li, (k, s) in enumerate(ConvStackFn.GEOM):
+            cout = ws[li].shape[0]
+            nchw = li == 0
+            w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
+            oh, ow = kn.conv_out_hw(h, w_, k, k, s)
+            y = _f32(N, oh, ow, cout, like=x)
+            kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
+            dims.append((h, w_, cin, cout, k, s, nchw))
+            acts.append(y)
+            inp, h, w_, cin = y, oh, ow, cout
+        ctx.save_for_backward(x, acts[0], acts[1], acts[2], w2, w3)
+        ctx.meta = (dims, grad_premasked, N)
+        return acts[2]
+
+    @staticmethod
+    def backward(ctx, da3):
+        x, a1, a2, a3, w2, w3 = ctx.saved_tensors
+        dims, premasked, N = ctx.meta
+        g = _c(da3)
+        if not premasked:
+            gz = torch.empty_like(g)
+            kn.relu_bwd(g, a3, gz, g.numel())
+            g = gz
+        inputs = (x, a1, a2)
+        weights = (None, w2, w3)
+        grads_w, grads_b = [None] * 3, [None] * 3
+        for li in (2, 1, 0):
+            h, w_, cin, cout, k, s, nchw = dims[li]
+            inp = inputs[li]
+            dw = _f32(cout, cin * k * k, like=g)
+            db = _f32(cout, like=g)
+            kn.conv2d_bwd_weight(inp, g, dw, db, N, h, w_, cin, cout, k, k, s, nchw)
+            # back to the parameter's OIHW layout (dw is [Cout][kh][kw][cin] for NHWC layers)
+            grads_w[li] = dw.view(cout, cin, k, k) if nchw else dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
+            grads_b[li] = db
+            if li > 0:
+                wt = weight_operand(weights[li], "ihwo")
+                dx = _f32(N, h, w_, cin, like=g)
+                kn.conv2d_bwd_data(g, wt, dx, inp, N, h, w_, cin, cout, k, k, s)   # masked by relu of the layer input
+                g = dx
+        return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2])
+
+
+def conv_stack(x, params, grad_premasked=False):
+    return ConvStackFn.apply(x, grad_premasked, *params)
+
+
+class SpatialSoftmaxFn(torch.autograd.Function):
+    """NHWC (N,H,W,C) -> (N,2C); backward also applies the ReLU mask of its input (vision_network.py:100-108)."""
+
+    @staticmethod
+    def forward(ctx, a, xmap, ymap, temperature):
+        N, H, W, C = a.shape
+        out = _f32(N, 2 * C, like=a)
+        stats = _f32(N, C, 2, like=a)
+        kn.spatial_softmax_fwd(a, N, H * W, C, xmap, ymap, temperature, out, stats)
+        ctx.save_for_backward(a, xmap, ymap, temperature, out, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, xmap, ymap, temperature, out, stats = ctx.saved_tensors
+        N, H, W, C = a.shape
+        dx = torch.empty_like(a)
+        kn.spatial_softmax_bwd(a, N, H * W, C, xmap, ymap, temperature, out, stats, _c(dout), dx, relu_mask=True)
+        return dx, None, None, None
+
+
+def spatial_softmax(a, xmap, ymap, temperature):
+    return SpatialSoftmaxFn.apply(a, xmap, ymap, temperature)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (optionally fused with residual add + dropout of the residual branch)
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, o, gamma, beta, eps: float, drop_p: float, seed: int):
+        D = x.shape[-1]
+        x2 = _c(x.reshape(-1, D))
+        o2 = _c(o.reshape(-1, D)) if o is not None else None
+        R = x2.shape[0]
+        y = _f32(R, D, like=x2)
+        mean, rstd = _f32(R, like=x2), _f32(R, like=x2)
+        pre = _f32(R, D, like=x2) if o2 is not None else None
+        kn.layernorm_fwd(x2, o2, drop_p, seed, gamma, beta, eps, R, D, pre, y, mean, rstd)
+        ctx.save_for_backward(pre if pre is not None else x2, mean, rstd, gamma)
+        ctx.meta = (x.shape, o is not None, drop_p, seed)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pre, mean, rstd, gamma = ctx.saved_tensors
+        shape, has_o, drop_p, seed = ctx.meta
+        R, D = pre.shape
+        dy2 = _c(dy.reshape(R, D))
+        dpre = _f32(R, D, like=dy2)
+        do = _f32(R, D, like=dy2) if (has_o and drop_p > 0) else None
+        dg, db = _f32(D, like=dy2), _f32(D, like=dy2)
+        kn.layernorm_bwd(dy2, pre, mean, rstd, gamma, R, D, dpre, do, drop_p, seed, dg, db)
+        dx = dpre.reshape(shape)
+        d_o = None
+        if has_o:
+            d_o = (do if do is not None else dpre).reshape(shape)
+        return dx, d_o, dg, db, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, None, gamma, beta, eps, 0.0, 0)
+
+
+def add_layer_norm(x, o, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
+    """LayerNorm(x + dropout(o)) — the post-norm residual step of nn.TransformerEncoderLayer."""
+    return LayerNormFn.apply(x, o, gamma, beta, eps, drop_p, seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer pieces
+# ------------------------------------------------------------------------------------------------
+class AddPosFn(torch.autograd.Function):
+    """dropout(x + pos[position_ids]) — plan_recognition_net.py:133-136,142."""
+
+    @staticmethod
+    def forward(ctx, x, pos, pos_ids, drop_p: float, seed: int):
+        B, S, D = x.shape
+        y = _f32(B, S, D, like=x)
+        kn.add_pos_fwd(_c(x), pos, pos_ids, y, B, S, D, drop_p, seed)
+        ctx.save_for_backward(pos_ids)
+        ctx.meta = (B, S, D, drop_p, seed, pos.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pos_ids,) = ctx.saved_tensors
+        B, S, D, drop_p, seed, pshape = ctx.meta
+        dy = _c(dy)
+        if drop_p > 0:
+            dx = torch.empty_like(dy)
+            kn.dropout_bwd(dy, dx, dy.numel(), drop_p, seed)
+        else:
+            dx = dy
+        dsum = _f32(S, D, like=dy)
+        kn.colsum(dx, B, S * D, S * D, dsum)                 # sum over the batch
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=dy.device)
+        dpos.index_copy_(0, pos_ids, dsum)                   # row placement by (unique) position id: a copy, no arithmetic
+        return dx, dpos, None, None, None
+
+
+class SeqMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, S, D = x.shape
+        y = _f32(B, D, like=x)
+        kn.seq_mean_fwd(_c(x), y, B, S, D)
+        ctx.meta = (B, S, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, D = ctx.meta
+        dx = _f32(B, S, D, like=dy)
+        kn.seq_mean_bwd(_c(dy), dx, B, S, D)
+        return dx
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v per (batch, head) on packed qkv (B*S, 3E)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B: int, S: int, H: int, drop_p: float, seed: int):
+        E = qkv.shape[-1] // 3
+        dh = E // H
+        qkv = _c(qkv)
+        out = _f32(B * S, E, like=qkv)
+        probs = _f32(B, H, S, S, like=qkv)
+        kn.attention_fwd(qkv, out, probs, B, S, H, dh, drop_p, seed)
+        ctx.save_for_backward(qkv, probs)
+        ctx.meta = (B, S, H, dh, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, probs = ctx.saved_tensors
+        B, S, H, dh, drop_p, seed = ctx.meta
+        dqkv = torch.empty_like(qkv)
+        kn.attention_bwd(qkv, probs, _c(dout), dqkv, B, S, H, dh, drop_p, seed)
+        return dqkv, None, None, None, None, None
+
+
+def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: float, seed: int):
+    """Post-norm nn.TransformerEncoderLayer (ReLU, eps 1e-5) on tokens x (B*S, E) — plan_recognition_net.py:115-117."""
+    qkv = mlp(x, [(p["in_proj_weight"], p["in_proj_bias"], False)])
+    att = AttentionFn.apply(qkv, B, S, nhead, drop_p, seed + 11)
+    o = mlp(att, [(p["out_proj.weight"], p["out_proj.bias"], False)])
+    x = add_layer_norm(x, o, p["norm1.weight"], p["norm1.bias"], 1e-5, drop_p, seed + 12)
+    ff = mlp(x, [(p["linear1.weight"], p["linear1.bias"], True), (p["linear2.weight"], p["linear2.bias"], False)],
+             drops=[drop_p, 0.0], seed=seed + 13)
+    return add_layer_norm(x, ff, p["norm2.weight"], p["norm2.bias"], 1e-5, drop_p, seed + 15)
+
+
+# ------------------------------------------------------------------------------------------------
+# action decoder recurrence: 2-layer ReLU RNN over [plan | emb_slice | goal]
+# reference: logistic_decoder_rnn.py:257-270 + decoders/utils/rnn.py:5-14
+# ------------------------------------------------------------------------------------------------
+class DecoderRNNFn(torch.autograd.Function):
+    """The input projection of layer 0 is split by linearity: the plan and goal columns of W_ih are applied
+    once per sequence (they are constant over time), only the 64 per-timestep embedding columns are applied
+    per token.  Same sums, different association; parity is checked at fp32 tolerance."""
+
+    @staticmethod
+    def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+        B, S, _ = emb.shape
+        Hd = w_hh0.shape[0]
+        P, G, E = plan.shape[1], goal.shape[1], hi - lo
+        plan, emb, goal = _c(plan), _c(emb), _c(goal)
+        dev = emb
+        wih0 = weight_operand(w_ih0)
+        Kin = w_ih0.shape[1]
+        # per-sequence constant part c = plan Wp^T + goal Wg^T + b_ih (b_hh is added in the recurrent step)
+        c = _f32(B, Hd, like=dev)
+        kn.gemm(plan, wih0, c, B, Hd, P, P, Kin, Hd, bias=b_ih0)
+        kn.gemm(goal, wih0[:, P + E:], c, B, Hd, G, G, Kin, Hd, accumulate=True)
+        pre0 = c.unsqueeze(1).expand(B, S, Hd).contiguous()
+        emb_s = emb[:, :, lo:hi]
+        kn.gemm(emb_s, wih0[:, P:P + E], pre0, B * S, Hd, E, emb.shape[2], Kin, Hd, accumulate=True)
+        zeros = torch.zeros(B, Hd, dtype=torch.float32, device=emb.device)
+        h0 = _f32(B, S, Hd, like=dev)
+        whh0 = weight_operand(w_hh0)
+        for t in range(S):
+            prev = zeros if t == 0 else h0[:, t - 1]
+            kn.gemm(prev, whh0, h0[:, t], B, Hd, Hd, Hd if t == 0 else S * Hd, Hd, S * Hd, bias=b_hh0, add=pre0[:, t],
+                    ld_add=S * Hd, relu=True)
+        pre1 = _f32(B, S, Hd, like=dev)
+        kn.gemm(h0, weight_operand(w_ih1), pre1, B * S, Hd, Hd, Hd, Hd, Hd, bias=b_ih1)
+        h1 = _f32(B, S, Hd, like=dev)
+        whh1 = weight_operand(w_hh1)
+        for t in range(S):
+            prev = zeros if t == 0 else h1[:, t - 1]
+            kn.gemm(prev, whh1, h1[:, t], B, Hd, Hd, Hd if t == 0 else S * Hd, Hd, S * Hd, bias=b_hh1, add=pre1[:, t],
+                    ld_add=S * Hd, relu=True)
+        ctx.save_for_backward(plan, emb, goal, h0, h1, w_ih0, w_hh0, w_ih1, w_hh1)
+        ctx.meta = (B, S, Hd, P, G, E, lo, hi)
+        return h1
+
+    @staticmethod
+    def _bptt(dH, h, w_hh, B, S, Hd):
+        """delta_t = (dH_t + delta_{t+1} W_hh) * (h_t > 0), t = S-1..0."""
+        delta = torch.empty_like(dH)
+        whh = weight_operand(w_hh)
+        last = torch.empty(B, Hd, dtype=torch.float32, device=dH.device)
+        kn.relu_bwd(_c(dH[:, S - 1]), _c(h[:, S - 1]), last, B * Hd)
+        delta[:, S - 1] = last
+        for t in range(S - 2, -1, -1):
+            kn.gemm(delta[:, t + 1], whh, delta[:, t], B, Hd, Hd, S * Hd, Hd, S * Hd, b_kmajor=False, add=dH[:, t], ld_add=S * Hd,
+                    mask=h[:, t], ld_mask=S * Hd)
+        return delta
+
+    @staticmethod
+    def backward(ctx, dH1):
+        plan, emb, goal, h0, h1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
+        B, S, Hd, P, G, E, lo, hi = ctx.meta
+        dH1 = _c(dH1)
+        dev = dH1
+        Kin = w_ih0.shape[1]
+
+        def shifted(h):
+            hp = torch.zeros_like(h)
+            hp[:, 1:] = h[:, :-1]
+            return hp
+
+        # ---- layer 1
+        d1 = DecoderRNNFn._bptt(dH1, h1, w_hh1, B, S, Hd)
+        dw_hh1 = _f32(Hd, Hd, like=dev)
+        kn.gemm(d1, shifted(h1), dw_hh1, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
+        dw_ih1 = _f32(Hd, Hd, like=dev)
+        kn.gemm(d1, h0, dw_ih1, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
+        db1 = _f32(Hd, like=dev)
+        kn.colsum(d1, B * S, Hd, Hd, db1)
+        dH0 = _f32(B, S, Hd, like=dev)
+        kn.gemm(d1, weight_operand(w_ih1), dH0, B * S, Hd, Hd, Hd, Hd, Hd, b_kmajor=False)
+        # ---- layer 0
+        d0 = DecoderRNNFn._bptt(dH0, h0, w_hh0, B, S, Hd)
+        dw_hh0 = _f32(Hd, Hd, like=dev)
+        kn.gemm(d0, shifted(h0), dw_hh0, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
+        db0 = _f32(Hd, like=dev)
+        kn.colsum(d0, B * S, Hd, Hd, db0)
+        dc = _f32(B, Hd, like=dev)                       # sum over time of delta0 (gradient of the constant part)
+        kn.seq_mean_fwd(d0, dc, B, S, Hd, scale=float(S))
+        wih0 = weight_operand(w_ih0)
+        dw_ih0 = _f32(Hd, Kin, like=dev)
+        kn.gemm(dc, plan, dw_ih0, Hd, P, B, Hd, P, Kin, a_kmajor=False, b_kmajor=False)
+        kn.gemm(d0, emb[:, :, lo:hi], dw_ih0[:, P:P + E], Hd, E, B * S, Hd, emb.shape[2], Kin, a_kmajor=False, b_kmajor=False)
+        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, Hd, G, Kin, a_kmajor=False, b_kmajor=False)
+        dplan = _f32(B, P, like=dev)
+        kn.gemm(dc, wih0, dplan, B, P, Hd, Hd, Kin, P, b_kmajor=False)
+        dgoal = _f32(B, G, like=dev)
+        kn.gemm(dc, wih0[:, P + E:], dgoal, B, G, Hd, Hd, Kin, G, b_kmajor=False)
+        demb = torch.zeros_like(emb)
+        kn.gemm(d0, wih0[:, P:P + E], demb[:, :, lo:hi], B * S, E, Hd, Hd, Kin, emb.shape[2], b_kmajor=False)
+        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+class MixLossFn(torch.autograd.Function):
+    """y (T, 3*A*n_mix + 2) head outputs, actions (T, A+1) -> scalar NLL + alpha * gripper CE."""
+
+    @staticmethod
+    def forward(ctx, y, act, act_min, act_max, n_mix: int, num_classes: int, log_scale_min: float, gripper_alpha: float):
+        y, act = _c(y), _c(act)
+        T, A = act.shape[0], act.shape[1] - 1
+        out3 = _f32(3, like=y)
+        cfg = (T, A, n_mix, num_classes, y.stride(0), log_scale_min, gripper_alpha)
+        kn.mix_loss_fwd(y, act, out3, *cfg, act_min, act_max)
+        ctx.save_for_backward(y, act, act_min, act_max)
+        ctx.cfg = cfg
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        y, act, act_min, act_max = ctx.saved_tensors
+        dy = torch.zeros_like(y)           # pad columns (beyond 3*A*n_mix + 2) must carry zero gradient
+        kn.mix_loss_bwd(y, act, _c(g.reshape(1)), dy, dy.stride(0), *ctx.cfg, act_min, act_max)
+        return dy, None, None, None, None, None, None, None
+
+
+class CatKLFn(torch.autograd.Function):
+    """KL balancing of hulc2.py:444-466 on (B, G*32) logits of prior (pp) and posterior (pr)."""
+
+    @staticmethod
+    def forward(ctx, pp, pr, G: int, CLS: int, beta: float, mix: float):
+        pp, pr = _c(pp), _c(pr)
+        B = pp.shape[0]
+        out = _f32(1, like=pp)
+        klg = _f32(B * G, like=pp)
+        kn.cat_kl_fwd(pp, pr, B, G, CLS, beta, out, klg)
+        ctx.save_for_backward(pp, pr, klg)
+        ctx.meta = (B, G, CLS, beta, mix)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pp, pr, klg = ctx.saved_tensors
+        B, G, CLS, beta, mix = ctx.meta
+        dpp, dpr = torch.empty_like(pp), torch.empty_like(pr)
+        kn.cat_kl_bwd(pp, pr, klg, B, G, CLS, beta, mix, _c(g.reshape(1)), dpp, dpr)
+        return dpp, dpr, None, None, None, None
+
+
+class PlanSampleFn(torch.autograd.Function):
+    """Straight-through one-hot sample; returns (plan (B, G*CLS), idx (B, G))."""
+
+    @staticmethod
+    def forward(ctx, logits, idx_in, G: int, CLS: int, seed: int):
+        logits = _c(logits)
+        B = logits.shape[0]
+        plan = _f32(B, G * CLS, like=logits)
+        idx = torch.empty(B, G, dtype=torch.long, device=logits.device)
+        kn.plan_sample_fwd(logits, _c(idx_in) if idx_in is not None else None, seed, B * G, CLS, idx, plan)
+        ctx.save_for_backward(logits)
+        ctx.meta = (B, G, CLS)
+        ctx.mark_non_differentiable(idx)
+        return plan, idx
+
+    @staticmethod
+    def backward(ctx, dplan, _didx):
+        (logits,) = ctx.saved_tensors
+        B, G, CLS = ctx.meta
+        dl = torch.empty_like(logits)
+        kn.plan_sample_bwd(logits, _c(dplan), B * G, CLS, dl)
+        return dl, None, None, None, None
+
+
+class ClipLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, tx, use, logit_scale):
+        im, tx = _c(im), _c(tx)
+        use_u8 = use.to(torch.uint8)
+        M, D = im.shape
+        out = _f32(1, like=im)
+        ls = logit_scale.reshape(1)
+        kn.clip_loss_fwd(im, tx, use_u8, ls, M, D, out)
+        ctx.save_for_backward(im, tx, use_u8, ls)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        im, tx, use_u8, ls = ctx.saved_tensors
+        M, D = im.shape
+        dim, dtx, dscale = torch.empty_like(im), torch.empty_like(tx), _f32(1, like=im)
+        kn.clip_loss_bwd(im, tx, use_u8, ls, M, D, _c(g.reshape(1)), dim, dtx, dscale)
+        return dim, dtx, None, dscale.reshape(())
+
+
+def world_to_tcp_frame(actions, robot_obs):
+    """gripper_control.py:16-36 (no gradient: actions are data)."""
+    B, S, _ = actions.shape
+    out = torch.empty_like(actions)
+    kn.world_to_tcp(_c(actions.float()), _c(robot_obs.float()), B * S, robot_obs.shape[-1], out)
+    return out

@@ -119,3 +119,155 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                         ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
     return dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# generic call helper: tensors -> pointers, python numbers -> ctypes by annotation
+# ------------------------------------------------------------------------------------------------
+_c = ctypes
+
+
+def _call(name, *args):
+    lib = _L.load()
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            _require_cuda(a)
+            conv.append(_c.c_void_p(a.data_ptr()))
+        elif a is None:
+            conv.append(_c.c_void_p(0))
+        else:
+            conv.append(a)
+    conv.append(_c.c_void_p(_stream()))
+    _L.check(getattr(lib, name)(*conv), name)
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+
+
+def _i(v):
+    return _c.c_int(int(v))
+
+
+def _l(v):
+    return _c.c_long(int(v))
+
+
+def _f(v):
+    return _c.c_float(float(v))
+
+
+def _u64(v):
+    return _c.c_ulonglong(int(v) & 0xFFFFFFFFFFFFFFFF)
+
+
+def spatial_softmax_fwd(x, N, HW, C, xmap, ymap, temperature, out, stats):
+    _call("hulc_spatial_softmax_fwd", x, _i(_dt(x)), _i(N), _i(HW), _i(C), xmap, ymap, temperature, out, stats)
+
+
+def spatial_softmax_bwd(x, N, HW, C, xmap, ymap, temperature, out, stats, dout, dx, relu_mask=True):
+    _call("hulc_spatial_softmax_bwd", x, _i(_dt(x)), _i(N), _i(HW), _i(C), xmap, ymap, temperature, out, stats, dout, dx,
+          _i(_dt(dx)), _i(relu_mask))
+
+
+def layernorm_fwd(x, o, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, rstd):
+    _call("hulc_layernorm_fwd", x, o, _f(drop_p), _u64(seed), gamma, beta, _f(eps), _i(R), _i(D), pre_out, y, mean, rstd)
+
+
+def layernorm_bwd(dy, pre, mean, rstd, gamma, R, D, dpre, do_out, drop_p, seed, dgamma, dbeta):
+    lib = _L.load()
+    lib.hulc_layernorm_bwd_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_layernorm_bwd_workspace(_i(R), _i(D)), dy.device)
+    _call("hulc_layernorm_bwd", dy, pre, mean, rstd, gamma, _i(R), _i(D), dpre, do_out, _f(drop_p), _u64(seed), dgamma, dbeta, ws)
+
+
+def colsum(x, M, N, ld, out, accumulate=False):
+    lib = _L.load()
+    lib.hulc_colsum_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_colsum_workspace(_l(M), _i(N)), x.device)
+    _call("hulc_colsum", x, _i(_dt(x)), _l(M), _i(N), _l(ld), out, _i(accumulate), ws)
+
+
+def seq_mean_fwd(x, y, B, S, D, scale=1.0):
+    _call("hulc_seq_mean_fwd", x, y, _i(B), _i(S), _i(D), _f(scale))
+
+
+def seq_mean_bwd(dy, dx, B, S, D):
+    _call("hulc_seq_mean_bwd", dy, dx, _i(B), _i(S), _i(D))
+
+
+def add_pos_fwd(x, pos, pos_ids, y, B, S, D, drop_p, seed):
+    _call("hulc_add_pos_fwd", x, pos, pos_ids, y, _i(B), _i(S), _i(D), _f(drop_p), _u64(seed))
+
+
+def dropout_bwd(dy, dx, n, drop_p, seed):
+    _call("hulc_dropout_bwd", dy, dx, _l(n), _f(drop_p), _u64(seed))
+
+
+def relu_bwd(dy, y, dx, n, scale=1.0):
+    _call("hulc_relu_bwd", dy, y, _i(_dt(y)), dx, _l(n), _f(scale))
+
+
+def attention_fwd(qkv, out, probs, B, S, H, head_dim, drop_p, seed):
+    _call("hulc_attention_fwd", qkv, out, probs, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed))
+
+
+def attention_bwd(qkv, probs, dout, dqkv, B, S, H, head_dim, drop_p, seed):
+    _call("hulc_attention_bwd", qkv, probs, dout, dqkv, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed))
+
+
+def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
+    d = _L.MixDesc()
+    d.T, d.A, d.n_mix, d.num_classes, d.ld = T, A, n_mix, num_classes, ld
+    d.log_scale_min, d.gripper_alpha = log_scale_min, gripper_alpha
+    _require_cuda(act_min, act_max)
+    d.act_min, d.act_max = act_min.data_ptr(), act_max.data_ptr()
+    return d
+
+
+def mix_loss_fwd(y, act, out3, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max)
+    _call("hulc_mix_loss_fwd", _c.byref(d), y, act, out3)
+
+
+def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max)
+    _call("hulc_mix_loss_bwd", _c.byref(d), y, act, gout, dy, _l(ld_dy))
+
+
+def cat_kl_fwd(pp, pr, B, G, CLS, beta, out, kl_group):
+    _call("hulc_cat_kl_fwd", pp, pr, _i(B), _i(G), _i(CLS), _f(beta), out, kl_group)
+
+
+def cat_kl_bwd(pp, pr, kl_group, B, G, CLS, beta, mix, gout, dpp, dpr):
+    _call("hulc_cat_kl_bwd", pp, pr, kl_group, _i(B), _i(G), _i(CLS), _f(beta), _f(mix), gout, dpp, dpr)
+
+
+def plan_sample_fwd(logits, idx_in, seed, NG, CLS, idx_out, plan):
+    _call("hulc_plan_sample_fwd", logits, idx_in, _u64(seed), _i(NG), _i(CLS), idx_out, plan)
+
+
+def plan_sample_bwd(logits, dplan, NG, CLS, dlogits, accumulate=False):
+    _call("hulc_plan_sample_bwd", logits, dplan, _i(NG), _i(CLS), dlogits, _i(accumulate))
+
+
+def clip_loss_fwd(im, tx, use, logit_scale, M, D, out):
+    _call("hulc_clip_loss_fwd", im, tx, use, logit_scale, _i(M), _i(D), out)
+
+
+def clip_loss_bwd(im, tx, use, logit_scale, M, D, gout, dim, dtx, dscale):
+    _call("hulc_clip_loss_bwd", im, tx, use, logit_scale, _i(M), _i(D), gout, dim, dtx, dscale)
+
+
+def world_to_tcp(act, robot_obs, n, obs_dim, out):
+    _call("hulc_world_to_tcp", act, robot_obs, _i(n), _i(obs_dim), out)
+
+
+def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
+          _f(grad_scale))
+
+
+def cast_f32_to_bf16(src, dst, n):
+    _call("hulc_cast_f32_to_bf16", src, dst, _l(n))

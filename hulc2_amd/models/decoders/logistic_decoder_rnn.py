@@ -1,0 +1,97 @@
+"""Action decoder: 2-layer ReLU RNN + discretised logistic mixture / gripper heads.
+
+Mirrors hulc2.models.decoders.logistic_decoder_rnn.LogisticDecoderRNN (reference logistic_decoder_rnn.py:27-284):
+same 19 constructor kwargs, same parameter/buffer names (rnn.*, mean_fc, log_scale_fc, prob_fc, gripper_fc,
+one_hot_embedding_eye, ones, gripper_bounds, action_{max,min}_bound).  nn.RNN is only the parameter container.
+Training path (`loss`) = DecoderRNNFn -> one fused head GEMM (182 outputs, padded to 184) -> MixLossFn.
+"""
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from hulc2_amd import functional as HF
+from hulc2_amd.models.decoders.action_decoder import ActionDecoder
+
+
+class LogisticDecoderRNN(ActionDecoder):
+    def __init__(self, perceptual_features: int, latent_goal_features: int, plan_features: int, n_mixtures: int, hidden_size: int,
+                 out_features: int, log_scale_min: float, act_max_bound: Union[List[float], tuple], act_min_bound: Union[List[float], tuple],
+                 dataset_dir: str, load_action_bounds: bool, num_classes: int, gripper_alpha: float, perceptual_emb_slice: tuple,
+                 policy_rnn_dropout_p: float, num_layers: int, rnn_model: str, gripper_control: bool, discrete_gripper: bool):
+        super().__init__()
+        if rnn_model != "rnn_decoder" or num_layers != 2 or not discrete_gripper or policy_rnn_dropout_p != 0.0:
+            raise NotImplementedError("configured path: 2-layer ReLU rnn_decoder, discrete gripper, no RNN dropout "
+                                      "(conf/model/action_decoder/logistic_decoder_rnn_calvin.yaml)")
+        if load_action_bounds:
+            raise NotImplementedError("load_action_bounds reads dataset statistics (file IO outside the hot path); "
+                                      "pass the bounds in the config")
+        self.n_dist = n_mixtures
+        self.gripper_control, self.discrete_gripper = gripper_control, discrete_gripper
+        self.log_scale_min, self.num_classes, self.plan_features = log_scale_min, num_classes, plan_features
+        self.perceptual_emb_slice = tuple(int(v) for v in perceptual_emb_slice)
+        in_features = (self.perceptual_emb_slice[1] - self.perceptual_emb_slice[0]) + latent_goal_features + plan_features
+        self.out_features = out_features - 1
+        self.gripper_alpha = gripper_alpha
+        self.rnn = nn.RNN(input_size=in_features, hidden_size=hidden_size, num_layers=num_layers, nonlinearity="relu",
+                          bidirectional=False, batch_first=True, dropout=policy_rnn_dropout_p)
+        self.mean_fc = nn.Linear(hidden_size, self.out_features * self.n_dist)
+        self.log_scale_fc = nn.Linear(hidden_size, self.out_features * self.n_dist)
+        self.prob_fc = nn.Linear(hidden_size, self.out_features * self.n_dist)
+        self.register_buffer("one_hot_embedding_eye", torch.eye(self.n_dist))
+        self.register_buffer("ones", torch.ones(1, 1, self.n_dist))
+        amax, amin = list(act_max_bound), list(act_min_bound)
+        self.register_buffer("gripper_bounds", torch.tensor([amin[-1], amax[-1]], dtype=torch.float32))
+        hi = torch.tensor(amax[:-1], dtype=torch.float32)
+        lo = torch.tensor(amin[:-1], dtype=torch.float32)
+        assert hi.shape[0] == self.out_features and lo.shape[0] == self.out_features
+        self.register_buffer("action_max_bound", hi.view(1, 1, -1, 1) * self.ones)
+        self.register_buffer("action_min_bound", lo.view(1, 1, -1, 1) * self.ones)
+        self.gripper_fc = nn.Linear(hidden_size, 2)
+        self.criterion = nn.CrossEntropyLoss()
+        self.hidden_state = None
+
+    def clear_hidden_state(self) -> None:
+        self.hidden_state = None
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def _heads(self, h: torch.Tensor) -> torch.Tensor:
+        """(B,S,H) -> (B*S, 184): [logit_probs 60 | means 60 | log_scales 60 | gripper 2 | 2 zero pad columns]."""
+        w = torch.cat([self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight,
+                       self.prob_fc.weight.new_zeros(2, self.prob_fc.weight.shape[1])], dim=0)
+        b = torch.cat([self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias,
+                       self.prob_fc.bias.new_zeros(2)], dim=0)
+        return HF.mlp(h.reshape(-1, h.shape[-1]), [(w, b, False)])
+
+    def _rnn(self, latent_plan, perceptual_emb, latent_goal) -> torch.Tensor:
+        r = self.rnn
+        lo, hi = self.perceptual_emb_slice
+        return HF.DecoderRNNFn.apply(latent_plan, perceptual_emb, latent_goal, lo, hi, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0,
+                                     r.bias_hh_l0, r.weight_ih_l1, r.weight_hh_l1, r.bias_ih_l1, r.bias_hh_l1)
+
+    def loss(self, latent_plan, perceptual_emb, latent_goal, actions, robot_obs) -> torch.Tensor:
+        y = self._heads(self._rnn(latent_plan, perceptual_emb, latent_goal))
+        acts = HF.world_to_tcp_frame(actions, robot_obs) if self.gripper_control else actions
+        return HF.MixLossFn.apply(y, acts.reshape(-1, acts.shape[-1]), self.action_min_bound[0, 0, :, 0].contiguous(),
+                                  self.action_max_bound[0, 0, :, 0].contiguous(), self.n_dist, self.num_classes,
+                                  float(self.log_scale_min), float(self.gripper_alpha))
+
+    def forward(self, latent_plan, perceptual_emb, latent_goal, h_0: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        if h_0 is not None:
+            raise NotImplementedError("stateful single-step decoding (inference `act`) is SURVEY.md §8 row f-1, not built yet")
+        B, S = perceptual_emb.shape[0], perceptual_emb.shape[1]
+        h = self._rnn(latent_plan, perceptual_emb, latent_goal)
+        y = self._heads(h).reshape(B, S, -1)
+        n = self.out_features * self.n_dist
+        shp = (B, S, self.out_features, self.n_dist)
+        logit_probs, means = y[..., :n].reshape(shp), y[..., n:2 * n].reshape(shp)
+        log_scales = torch.clamp(y[..., 2 * n:3 * n], min=self.log_scale_min).reshape(shp)
+        h_n = torch.stack([h.new_zeros(B, h.shape[-1]), h[:, -1]])   # layer-0 final state is not exported by the fused recurrence
+        return logit_probs, log_scales, means, y[..., 3 * n:3 * n + 2], h_n
+
+    def act(self, *a, **k):
+        raise NotImplementedError("inference sampling is SURVEY.md §8 row f-1 (next), not part of the training_step path")
+
+    def loss_and_act(self, *a, **k):
+        raise NotImplementedError("validation sampling is SURVEY.md §8 row f-1 (next), not part of the training_step path")

@@ -1,0 +1,53 @@
+"""Goal encoders: 3-layer MLP + LayerNorm on the MFMA GEMM chain.
+
+Mirrors hulc2.models.encoders.goal_encoders.{VisualGoalEncoder, LanguageGoalEncoder} (reference
+goal_encoders.py:8-71); keys mlp.{0,2,4} / mlp.{1,3,5} (+ ln) as in the reference's Sequentials.
+"""
+import torch
+import torch.nn as nn
+
+from hulc2_amd import functional as HF
+
+
+def _check(l2: bool, act: str, who: str):
+    if l2 or act != "ReLU":
+        raise NotImplementedError(f"hulc2_amd {who}: configured path only (ReLU, no l2-normalise)")
+
+
+class VisualGoalEncoder(nn.Module):
+    def __init__(self, hidden_size: int, latent_goal_features: int, in_features: int, l2_normalize_goal_embeddings: bool,
+                 activation_function: str):
+        super().__init__()
+        _check(l2_normalize_goal_embeddings, activation_function, "VisualGoalEncoder")
+        self.l2_normalize_output = l2_normalize_goal_embeddings
+        self.act_fn = nn.ReLU()
+        self.mlp = nn.Sequential(nn.Linear(in_features, hidden_size), self.act_fn, nn.Linear(hidden_size, hidden_size), self.act_fn,
+                                 nn.Linear(hidden_size, latent_goal_features))
+        self.ln = nn.LayerNorm(latent_goal_features)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        m = self.mlp
+        y = HF.mlp(x, [(m[0].weight, m[0].bias, True), (m[2].weight, m[2].bias, True), (m[4].weight, m[4].bias, False)])
+        return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)
+
+
+class LanguageGoalEncoder(nn.Module):
+    def __init__(self, lang_net, in_features: int, hidden_size: int, latent_goal_features: int, l2_normalize_goal_embeddings: bool,
+                 word_dropout_p: float, activation_function: str):
+        super().__init__()
+        _check(l2_normalize_goal_embeddings, activation_function, "LanguageGoalEncoder")
+        if word_dropout_p != 0.0:
+            raise NotImplementedError("word_dropout_p != 0 is not on the configured path (conf/model/language_goal/default.yaml)")
+        self.lang_net = lang_net
+        self.l2_normalize_output = l2_normalize_goal_embeddings
+        self.act_fn = nn.ReLU()
+        self.mlp = nn.Sequential(nn.Dropout(word_dropout_p), nn.Linear(in_features, hidden_size), self.act_fn,
+                                 nn.Linear(hidden_size, hidden_size), self.act_fn, nn.Linear(hidden_size, latent_goal_features))
+        self.ln = nn.LayerNorm(latent_goal_features)
+
+    def forward(self, x) -> torch.Tensor:
+        if self.lang_net is not None:           # list[str] -> (B, 384); SBERT stays third-party
+            x = self.lang_net(x)
+        m = self.mlp
+        y = HF.mlp(x, [(m[1].weight, m[1].bias, True), (m[3].weight, m[3].bias, True), (m[5].weight, m[5].bias, False)])
+        return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)

@@ -1,0 +1,153 @@
+"""Hulc2 — the low-level policy LightningModule on MI355X kernels.
+
+Mirrors hulc2.models.hulc2.Hulc2 (reference hulc2/models/hulc2.py:27-508) for the training path: the same 16
+constructor arguments (un-instantiated configs, `_recursive_: false`), `setup_input_sizes`, `training_step`,
+`lmp_train`, `compute_kl_loss`, `clip_auxiliary_loss`, `configure_optimizers`, `set_kl_beta`, the same logged
+metric names and the same attribute names (hence state_dict keys).  Validation / rollout inference
+(`validation_step`, `step`, `reset`) is SURVEY.md §8 row f-1 and raises NotImplementedError for now.
+
+Differences that do not change results:
+  * the categorical plan sample can be injected through `dataset_batch["plan_idx"]` (parity tests); otherwise it
+    is drawn on-device by the counter RNG (the reference uses torch.multinomial — no shared RNG stream exists)
+  * `use_for_aux_lang_loss` is applied inside the CLIP loss kernel instead of boolean-mask indexing, so the step
+    has no host synchronisation (the reference's `torch.any` / dynamic shapes, hulc2.py:391-394,490-493)
+"""
+import logging
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from hulc2_amd import functional as HF
+from hulc2_amd.compat import LightningModule, instantiate
+from hulc2_amd.utils.distributions import State
+
+logger = logging.getLogger(__name__)
+
+
+class Hulc2(LightningModule):
+    def __init__(self, perceptual_encoder, plan_proposal, plan_recognition, language_encoder, language_goal, visual_goal,
+                 action_decoder, kl_beta: float, kl_balancing_mix: float, optimizer, lr_scheduler, distribution,
+                 use_clip_auxiliary_loss: bool, clip_auxiliary_loss_beta: float, replan_freq: int = 30, proj_vis_lang=None):
+        super().__init__()
+        self.perceptual_encoder = instantiate(perceptual_encoder, device=self.device)
+        self.setup_input_sizes(self.perceptual_encoder, plan_proposal, plan_recognition, visual_goal, action_decoder, distribution)
+        self.dist = instantiate(distribution)
+        self.plan_proposal = instantiate(plan_proposal, dist=self.dist)
+        self.plan_recognition = instantiate(plan_recognition, dist=self.dist)
+        self.visual_goal = instantiate(visual_goal)
+        self.lang_encoder = instantiate(language_encoder) if language_encoder else None
+        self.language_goal = instantiate(language_goal, lang_net=self.lang_encoder) if language_goal else None
+        self.action_decoder = instantiate(action_decoder)
+        self.use_clip_auxiliary_loss = use_clip_auxiliary_loss
+        self.clip_auxiliary_loss_beta = clip_auxiliary_loss_beta
+        if use_clip_auxiliary_loss:
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+            self.proj_vis_lang = instantiate(proj_vis_lang)
+        self.kl_beta = kl_beta
+        self.kl_balancing_mix = kl_balancing_mix
+        self.modality_scope = "vis"
+        self.optimizer_config = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.save_hyperparameters()
+        self.rollout_step_counter = 0
+        self.replan_freq = replan_freq
+        self.latent_goal = None
+        self.plan = None
+        self._sample_step = 0
+
+    @staticmethod
+    def setup_input_sizes(perceptual_encoder, plan_proposal, plan_recognition, visual_goal, action_decoder, distribution):
+        """hulc2.py:126-158: patch the `???` sizes of the child configs."""
+        n = perceptual_encoder.latent_size
+        plan_proposal.perceptual_features = n
+        plan_recognition.in_features = n
+        visual_goal.in_features = n
+        action_decoder.perceptual_features = n
+        if distribution.dist == "discrete":
+            pf = distribution.class_size * distribution.category_size
+        else:
+            pf = distribution.plan_features
+        plan_proposal.plan_features = plan_recognition.plan_features = action_decoder.plan_features = pf
+
+    def configure_optimizers(self):
+        """hulc2.py:185-198 (Adam lr 2e-4 + constant schedule).  The native trainer (hulc2_amd/trainer.py) replaces this
+        with the fused arena Adam; under Lightning any torch optimizer works (bf16 shadows refresh by version)."""
+        opt = instantiate(self.optimizer_config, params=self.parameters())
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda _: 1.0)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def lmp_train(self, perceptual_emb, latent_goal, train_acts, robot_obs, plan_idx: Optional[torch.Tensor] = None
+                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, State, State, torch.Tensor]:
+        """hulc2.py:200-245; returns the prior/posterior *states* in place of torch.distributions objects."""
+        pp_state = self.plan_proposal(perceptual_emb[:, 0], latent_goal)
+        pr_state, seq_feat = self.plan_recognition(perceptual_emb)
+        self._sample_step += 1
+        sampled_plan, _ = self.dist.rsample_plan(pr_state, seed=self._sample_step * 104729 + 3, idx=plan_idx)
+        action_loss = self.action_decoder.loss(sampled_plan, perceptual_emb, latent_goal, train_acts, robot_obs)
+        kl_loss = self.compute_kl_loss(pp_state, pr_state)
+        return kl_loss, action_loss, action_loss + kl_loss, pp_state, pr_state, seq_feat
+
+    def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
+        """hulc2.py:336-442."""
+        kl_loss = action_loss = total_loss = lang_clip_loss = None
+        batch_size: Dict[str, int] = {}
+        total_bs = 0
+
+        def acc(a, b):
+            return b if a is None else a + b
+
+        for self.modality_scope, db in batch.items():
+            emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
+            latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
+            kl, act_loss, mod_loss, _, _, seq_feat = self.lmp_train(emb, latent_goal, db["actions"], db["state_info"]["robot_obs"],
+                                                                    db.get("plan_idx"))
+            if "lang" in self.modality_scope:
+                batch_size["aux_lang"] = db["actions"].shape[0]
+                if self.use_clip_auxiliary_loss:
+                    lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"]))
+            kl_loss, action_loss, total_loss = acc(kl_loss, kl), acc(action_loss, act_loss), acc(total_loss, mod_loss)
+            bs = db["actions"].shape[0]
+            batch_size[self.modality_scope] = bs
+            total_bs += bs
+            self.log(f"train/kl_loss_scaled_{self.modality_scope}", kl, on_step=False, on_epoch=True, batch_size=bs)
+            self.log(f"train/action_loss_{self.modality_scope}", act_loss, on_step=False, on_epoch=True, batch_size=bs)
+            self.log(f"train/total_loss_{self.modality_scope}", mod_loss, on_step=False, on_epoch=True, batch_size=bs)
+        n = len(batch)
+        total_loss, kl_loss, action_loss = total_loss / n, kl_loss / n, action_loss / n
+        if self.use_clip_auxiliary_loss and lang_clip_loss is not None:
+            total_loss = total_loss + self.clip_auxiliary_loss_beta * lang_clip_loss
+            self.log("train/lang_clip_loss", self.clip_auxiliary_loss_beta * lang_clip_loss, on_step=False, on_epoch=True,
+                     batch_size=batch_size.get("aux_lang", 1), sync_dist=True)
+        self.log("train/kl_loss", kl_loss, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/action_loss", action_loss, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/total_loss", total_loss, on_step=False, on_epoch=True, batch_size=total_bs)
+        return total_loss
+
+    def compute_kl_loss(self, pp_state: State, pr_state: State) -> torch.Tensor:
+        """hulc2.py:444-466."""
+        return self.dist.kl_balanced(pp_state, pr_state, self.kl_beta, self.kl_balancing_mix)
+
+    def set_kl_beta(self, kl_beta):
+        self.kl_beta = kl_beta
+
+    def clip_auxiliary_loss(self, seq_vis_feat, encoded_lang, use_for_aux_loss):
+        """hulc2.py:472-508; rows with use_for_aux_loss == False are excluded inside the kernel."""
+        if use_for_aux_loss is None:
+            use_for_aux_loss = torch.ones(seq_vis_feat.shape[0], dtype=torch.bool, device=seq_vis_feat.device)
+        im, tx = self.proj_vis_lang(seq_vis_feat, encoded_lang)
+        return HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale)
+
+    # ---- outside the accelerated path ---------------------------------------------
+    def validation_step(self, batch, batch_idx):
+        raise NotImplementedError("validation_step (lmp_val + sampling) is SURVEY.md §8 row f-1: next, not built yet")
+
+    def reset(self):
+        self.plan = None
+        self.latent_goal = None
+        self.rollout_step_counter = 0
+
+    def step(self, obs, goal):
+        raise NotImplementedError("rollout inference is SURVEY.md §8 row f-1: next, not built yet")

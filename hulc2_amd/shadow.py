@@ -1,0 +1,65 @@
+"""Kernel-side views of the parameters: layout repacks and bf16 shadows.
+
+The checkpoint contract keeps parameters fp32 in the reference's layouts (OIHW convs, [out][in] linears).
+The MFMA kernels want (a) conv weights with the k axis ordered like the NHWC gather and (b) in bf16
+compute mode, bf16 operands so weight panels stream at half the HBM/L2 bytes.  Shadows are refreshed
+lazily when a parameter's version counter changes (any optimizer works); the fused Adam kernel writes
+the bf16 arena directly and marks shadows fresh (hulc2_amd/trainer.py).
+"""
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import kernels as kn
+
+_cache: Dict[Tuple[int, Optional[str], int], Tuple[int, torch.Tensor, "weakref.ref"]] = {}
+_arena: Dict[int, torch.Tensor] = {}      # id(param) -> bf16 view into the trainer's shadow arena
+
+
+def clear() -> None:
+    _cache.clear()
+    _arena.clear()
+
+
+def register_arena_view(param: torch.Tensor, view_bf16: torch.Tensor) -> None:
+    """The native trainer keeps one flat bf16 arena that the Adam kernel refreshes in place."""
+    _arena[id(param)] = view_bf16
+
+
+def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
+    if layout is None:
+        return w
+    if layout == "oihw_flat":          # conv1: k = (c, kh, kw) — the parameter itself, flattened
+        return w.reshape(w.shape[0], -1)
+    if layout == "ohwi":               # NHWC forward: k = (kh, kw, c)
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    if layout == "ihwo":               # data gradient: rows = input channel, k = (kh, kw, cout)
+        return w.permute(1, 2, 3, 0)
+    raise ValueError(layout)
+
+
+@torch.no_grad()
+def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tensor:
+    """Tensor handed to the kernels for parameter `w`: fp32 (repacked if asked) in fp32 compute mode, a
+    cached bf16 copy in bf16 mode."""
+    bf16 = kn.get_compute() == "bf16"
+    base = w.detach()
+    if not bf16:
+        if layout in (None, "oihw_flat"):
+            return _layout(base, layout) if layout else base
+    elif layout is None and id(w) in _arena:
+        return _arena[id(w)]
+    key = (id(w), layout, int(bf16))
+    ver = w._version
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
+        return hit[1]
+    src = _layout(base, layout).contiguous()
+    if bf16:
+        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+        kn.cast_f32_to_bf16(src, out, src.numel())
+    else:
+        out = src
+    _cache[key] = (ver, out, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)))
+    return out

@@ -73,6 +73,85 @@ int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, const void* wt
 long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d);
 int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, const void* dy, float* dw, float* db, void* ws, void* stream);
 
+/* ---- reductions of the encoders and the plan-recognition transformer ------------------------ */
+/* Spatial softmax over NHWC activations x[N][HW][C] (C <= 64): out[N][2C] = interleaved (E[xmap], E[ymap])
+ * per channel, stats[N][C][2] = (max, sum) kept for the backward.  Replaces SpatialSoftmax.forward,
+ * vision_network.py:100-108 (xmap/ymap/temperature are that module's registered buffers).
+ * bwd writes dx (same layout as x) and, with relu_mask, multiplies by (x > 0) — the ReLU after conv3. */
+int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int HW, int C, const float* xmap, const float* ymap,
+                             const float* temperature, float* out, float* stats, void* stream);
+int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int HW, int C, const float* xmap, const float* ymap,
+                             const float* temperature, const float* out, const float* stats, const float* dout,
+                             void* dx, int dx_dtype, int relu_mask, void* stream);
+/* y = LayerNorm(x + dropout(o)) over rows of D <= 256 (o may be NULL; pre_out receives x + dropout(o)).
+ * Replaces nn.LayerNorm (vision_network.py:53, goal_encoders.py:28,61) and the residual+norm of the
+ * post-norm nn.TransformerEncoderLayer (plan_recognition_net.py:115-117).  bwd: dpre = grad of the LN
+ * input, do_out (optional) = dpre * dropout mask (grad of o), dgamma/dbeta summed deterministically. */
+int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const float* gamma,
+                       const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean, float* rstd, void* stream);
+long hulc_layernorm_bwd_workspace(int R, int D);
+int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
+                       float* dpre, float* do_out, float drop_p, unsigned long long seed, float* dgamma, float* dbeta, void* ws,
+                       void* stream);
+/* out[n] (+)= sum_m x[m*ld + n]: bias gradients of nn.Linear / position-embedding gradient. */
+long hulc_colsum_workspace(long M, int N);
+int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream);
+/* y = scale * mean over the sequence axis of x[B][S][D] (plan_recognition_net.py:145; scale = S gives the
+ * plain sum used by the decoder backward) and the gradient of the mean. */
+int hulc_seq_mean_fwd(const float* x, float* y, int B, int S, int D, float scale, void* stream);
+int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D, void* stream);
+/* y = dropout(x[B][S][D] + pos[pos_ids[s]][:]) (plan_recognition_net.py:133-136,142); dropout_bwd: dx = dy * mask. */
+int hulc_add_pos_fwd(const float* x, const float* pos, const long* pos_ids, float* y, int B, int S, int D, float drop_p,
+                     unsigned long long seed, void* stream);
+int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, void* stream);
+/* dx = dy * (y > 0) * scale: gradient through ReLU (+ inverted dropout) from the saved activation. */
+int hulc_relu_bwd(const float* dy, const void* y, int y_dtype, float* dx, long n, float scale, void* stream);
+/* Multi-head self-attention for S <= 32, head_dim 16: qkv[B*S][3E] (token b*S+s; q|k|v), out[B*S][E],
+ * probs[B][H][S][S] (post-dropout).  Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer. */
+int hulc_attention_fwd(const float* qkv, float* out, float* probs, int B, int S, int H, int head_dim, float drop_p,
+                       unsigned long long seed, void* stream);
+int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int B, int S, int H, int head_dim,
+                       float drop_p, unsigned long long seed, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------------- */
+/* Discretised logistic mixture NLL + gripper cross-entropy over y[T][ld] = [logit_probs(A*n_mix) |
+ * means | log_scales | gripper(2)] and act[T][A+1]; out3 = {total, nll_mean, ce_mean}.
+ * Replaces LogisticDecoderRNN._loss/_logistic_loss, logistic_decoder_rnn.py:133-152,181-228. */
+typedef struct {
+    int T, A, n_mix, num_classes;
+    long ld;
+    float log_scale_min, gripper_alpha;
+    const float* act_min; const float* act_max;   /* device [A] */
+} hulc_mix_desc;
+int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out3, void* stream);
+int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const float* act, const float* gout, float* dy, long ld_dy, void* stream);
+/* KL-balanced categorical KL (hulc2.py:444-466): out[0] = beta * mean_b sum_g KL(post_g || prior_g);
+ * bwd: dpp gets mix * d/d prior, dpr gets (1 - mix) * d/d posterior. pp/pr: [B][G*CLS], CLS == 32. */
+int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, float* out, float* kl_group, void* stream);
+int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int B, int G, int CLS, float beta, float mix,
+                    const float* gout, float* dpp, float* dpr, void* stream);
+/* Straight-through one-hot sample of each of NG categorical groups (distributions.py:23-27, hulc2.py:235-237):
+ * plan = one_hot(idx); idx from idx_in (injected) or inverse-CDF sampling with the counter RNG. */
+int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, int NG, int CLS, long* idx_out,
+                         float* plan, void* stream);
+int hulc_plan_sample_bwd(const float* logits, const float* dplan, int NG, int CLS, float* dlogits, int accumulate, void* stream);
+/* CLIP-style symmetric contrastive loss on projected features im/tx [M][32] restricted to rows with
+ * use[m] != 0 (hulc2.py:472-508); dscale = d loss / d logit_scale. */
+int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+                       float* out, void* stream);
+int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+                       const float* gout, float* dim, float* dtx, float* dscale, void* stream);
+/* Relative actions world -> tcp frame, act[n][7], robot_obs[n][obs_dim] (euler angles in 3:6),
+ * gripper_control.py:16-36 (pytorch3d XYZ convention restated; parity unpinned). */
+int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------- */
+/* torch.optim.Adam semantics (hulc2.py:185-198, conf/model/optimizer/adam.yaml) over a flat fp32 arena;
+ * bf16_shadow (optional) receives the updated weights rounded to bf16 for the MFMA kernels. */
+int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""CPU-side checks (no GPU compute): the checkpoint contract, config plumbing, the C-ABI surface and the
+"fail loudly, never fall back" rule."""
+import ctypes
+import re
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from hulc2_amd import param_spec, synthetic as syn  # noqa: E402
+from hulc2_amd.compat import Config, instantiate, install_as_hulc2  # noqa: E402
+from hulc2_amd.config import default_model_config  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def model():
+    return instantiate(default_model_config())
+
+
+def test_state_dict_matches_reference_contract(model):
+    """parameter names/shapes = SURVEY.md §8b (enumerated from the reference modules)"""
+    sd = model.state_dict()
+    want = param_spec.trainable_shapes()
+    got_params = {k: tuple(v.shape) for k, v in model.named_parameters()}
+    assert set(got_params) == set(want), (sorted(set(got_params) ^ set(want)))
+    for k, shp in want.items():
+        assert got_params[k] == tuple(shp), k
+    for k, shp in param_spec.buffer_shapes().items():
+        assert k in sd and tuple(sd[k].shape) == tuple(shp), k
+    assert sum(p.numel() for p in model.parameters()) == param_spec.num_trainable()
+
+
+def test_spatial_softmax_buffers_follow_reference_quirk(model):
+    ss = model.perceptual_encoder.rgb_static_encoder.spatial_softmax
+    lin = torch.linspace(-1, 1, 21)
+    assert torch.equal(ss.x_map.view(21, 21)[:, 0], lin)      # x_map varies along rows (vision_network.py:88-92)
+    assert torch.equal(ss.y_map.view(21, 21)[0, :], lin)
+    assert torch.equal(ss.x_map.view(21, 21)[3], lin[3].expand(21))
+
+
+def test_setup_input_sizes_and_targets():
+    cfg = default_model_config()
+    m = instantiate(cfg)
+    assert cfg.plan_proposal.perceptual_features == 128 and cfg.action_decoder.plan_features == 1024
+    assert type(m).__name__ == "Hulc2" and type(m.action_decoder).__name__ == "LogisticDecoderRNN"
+    install_as_hulc2()
+    import hulc2.models.hulc2 as ref_path   # the reference's import path now resolves to this package
+    assert ref_path.Hulc2 is type(m)
+
+
+def test_unsupported_configs_fail_loudly():
+    cfg = default_model_config()
+    cfg.plan_recognition.positional_normalize = True
+    with pytest.raises(NotImplementedError):
+        instantiate(cfg)
+    cfg = default_model_config()
+    cfg.action_decoder.rnn_model = "gru_decoder"
+    with pytest.raises(NotImplementedError):
+        instantiate(cfg)
+
+
+def test_no_cpu_fallback(model):
+    """a CPU batch must raise, not silently run something else"""
+    from hulc2_amd.lib import HulcKernelError
+
+    batch = syn.make_batch(0, 1, 2)
+    with pytest.raises(HulcKernelError):
+        model.training_step(batch, 0)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from hulc2_amd import build, lib
+
+    build.build(verbose=False)
+    header = (ROOT / "include" / "hulc2_amd.h").read_text()
+    names = sorted(set(re.findall(r"\b(hulc_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 30
+    so = ctypes.CDLL(str(lib.lib_path()))
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+    assert so.hulc_abi_version() == 1
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "hulc2_amd").rglob("*.py"):
+        txt = p.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, p
+
+
+def test_synthetic_recipe_is_order_independent():
+    a = {"x.weight": torch.empty(4, 3), "y.bias": torch.empty(5)}
+    b = {"y.bias": torch.empty(5), "x.weight": torch.empty(4, 3)}
+    syn.fill_state_dict_(a, 3)
+    syn.fill_state_dict_(b, 3)
+    assert torch.equal(a["x.weight"], b["x.weight"]) and torch.equal(a["y.bias"], b["y.bias"])
