@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: play-sequences/sec/node of the HULC++ low-level policy training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+
+A "step" = one full optimizer step of `Hulc2.training_step` (forward + backward + gradient all-reduce + Adam) over
+one device-resident synthetic CALVIN-shaped batch: 2 modalities x 32 play sequences x 32 timesteps, 200x200 static +
+84x84 gripper RGB, random (B,384) language embeddings (BASELINE.json configs[1]/[2]).  Weak scaling:
+each rank processes its own 64 sequences per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     — the dominant kernel's algorithmic FLOP/s from HIP events recorded live on the launch stream
+  cpu_baseline — the CPU oracle (fp32 torch restatement, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SEQ_FLOP_TRAIN = 14.13e9        # 3 x 4.710 GFLOP forward per play sequence
+PEAK_BF16 = 2.5e15              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32 = 157.3e12
+
+
+def conv_macs(N, H, W, Cin, Cout, K, stride):
+    oh, ow = (H - K) // stride + 1, (W - K) // stride + 1
+    return N * oh * ow * Cout * Cin * K * K
+
+
+def kernel_flops(key):
+    """algorithmic FLOPs of one launch, from its shape key (2 x MACs)"""
+    name = key[0]
+    if name == "gemm":
+        return 2.0 * key[1] * key[2] * key[3]
+    if name in ("conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_weight"):
+        return 2.0 * conv_macs(*key[1:])
+    return 0.0
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """oracle training step (fwd + bwd + Adam) on the host cores, B=4/modality, S=32, fp32"""
+    from hulc2_amd import param_spec, synthetic as syn
+    from oracle import hulc2_oracle as O
+
+    B, S = 4, 32
+    torch.manual_seed(0)
+    sd = {k: torch.empty(s) for k, s in param_spec.trainable_shapes().items()}
+    syn.fill_state_dict_(sd, 42)
+    for v in sd.values():
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(list(sd.values()), lr=2e-4)
+    raw = syn.make_batch(42, B, S)
+    batch = {}
+    for m, db in raw.items():
+        batch[m] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
+                        robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+        if m == "lang":
+            batch[m].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
+    times = []
+    t_start = time.time()
+    for i in range(6):
+        t0 = time.time()
+        opt.zero_grad(set_to_none=True)
+        out = O.training_step(sd, batch, dict(gripper_control=True))
+        out["total_loss"].backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget and i >= 1:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {"value": round(2 * B / t, 3), "unit": "play-sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} steps of B={B}/modality S={S} (8 sequences/step), fp32 torch CPU oracle, median of steps after the first"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="play sequences per modality per GPU")
+    ap.add_argument("--seq-len", type=int, default=32)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hulc2_amd import kernels as kn, synthetic as syn
+    from hulc2_amd.compat import instantiate
+    from hulc2_amd.config import default_model_config
+    from hulc2_amd.trainer import ArenaTrainer
+
+    kn.set_compute(args.compute)
+    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    syn.fill_state_dict_(model.state_dict(), 42)            # same weights on every rank
+    model.train()
+    trainer = ArenaTrainer(model, lr=2e-4)
+    batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev)
+    for db in batch.values():
+        db.pop("plan_idx", None)                            # benchmark samples the latent plan on-device
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = trainer.step(batch, i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.step(batch, i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    # ---- roofline leg: per-launch HIP events over 3 more steps (outside the timed region) -------------
+    kn.start_timing()
+    for i in range(3):
+        trainer.step(batch, i)
+    table = kn.stop_timing()
+    total_ms = sum(t for _, t in table.values())
+    by_kind = {}
+    for key, (n, t) in table.items():
+        a = by_kind.setdefault(key[0], [0, 0.0, 0.0])
+        a[0] += n; a[1] += t; a[2] += kernel_flops(key) * n
+    dom_key, (dom_n, dom_t) = max(table.items(), key=lambda kv: kv[1][1])
+    dom_flops = kernel_flops(dom_key)
+    peak = PEAK_BF16 if args.compute == "bf16" else PEAK_F32
+    achieved = dom_flops / (dom_t / dom_n * 1e-3) if dom_t > 0 else 0.0
+    if args.breakdown and rank == 0:
+        for key, (n, t) in sorted(table.items(), key=lambda kv: -kv[1][1])[:25]:
+            f = kernel_flops(key)
+            print(f"  {t / 3:9.3f} ms/step  {n // 3:4d} launches  {f * n / max(t, 1e-9) / 1e9:9.1f} TFLOP/s  {key}", file=sys.stderr)
+        print(f"  sum of kernel time: {total_ms / 3:.3f} ms/step", file=sys.stderr)
+
+    seqs = 2 * args.batch * world * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    value = seqs / elapsed
+    out = {
+        "metric": "play-sequences/sec/node (seq_len=32, 200x200 RGB)",
+        "value": round(value, 2), "unit": "play-sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic CALVIN-shaped batch, Hulc2.training_step fwd+bwd+allreduce+Adam, "
+                               "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on",
+                   "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
+                   "final_loss": round(final_loss, 4)},
+        "roofline": {"bound": "mfma", "kernel": "/".join(str(k) for k in dom_key), "achieved": round(achieved / 1e12, 2),
+                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                     "launches_per_step": dom_n // 3, "avg_launch_ms": round(dom_t / dom_n, 4),
+                     "kernel_share_of_step": round(dom_t / max(total_ms, 1e-9), 3),
+                     "step_frac_of_peak": round(value / world * SEQ_FLOP_TRAIN / peak, 4),
+                     "gpu_kernel_ms_per_step": round(total_ms / 3, 3)},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

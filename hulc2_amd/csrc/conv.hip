@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     static_assert(DY_ITEMS <= 256, "dY staging fits one pass");
 
     __shared__ __attribute__((aligned(16))) char smem[2 * (CO + KS) * HULC_ROWB];
-    __shared__ float bsum[CO];
+    __shared__ float bpart[DY_ITEMS][8];   // per-thread bias partials, summed in a fixed order
 
     const GatherP& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     float bacc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bacc[j] = 0.f;
-    if (tid < CO) bsum[tid] = 0.f;
 
     // item -> (pixel pair, chunk): consecutive threads take consecutive chunks of one pixel pair so a
     // wave's loads cover whole contiguous channel runs.
@@ -313,12 +312,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
     if (p.partial_b && blockIdx.y == 0) {
         if (tid < DY_ITEMS) {
-            const int ch = tid % (CO / 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&bsum[ch * 8 + j], bacc[j]);   // LDS atomics, <=16 adders per slot
+            for (int j = 0; j < 8; ++j) bpart[tid][j] = bacc[j];
         }
         __syncthreads();
-        if (tid < CO) p.partial_b[(long)blockIdx.x * CO + tid] = bsum[tid];
+        if (tid < CO) {
+            float sacc = 0.f;
+            for (int pr = 0; pr < PAIRS; ++pr) sacc += bpart[pr * (CO / 8) + tid / 8][tid % 8];
+            p.partial_b[(long)blockIdx.x * CO + tid] = sacc;
+        }
     }
 }
 

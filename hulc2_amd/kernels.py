@@ -25,6 +25,48 @@ def get_compute() -> str:
     return "bf16" if _compute_mode == BF16 else "fp32"
 
 
+# ------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): HIP events recorded on the stream the kernels are
+# launched on (torch's current stream), collected per (entry point, shape key)
+# ------------------------------------------------------------------------------------------------
+_timing = None
+
+
+def start_timing() -> None:
+    global _timing
+    _timing = []
+
+
+def stop_timing():
+    """-> {key: (launches, total_ms)}; synchronises the device."""
+    global _timing
+    rec, _timing = _timing or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for key, e0, e1 in rec:
+        n, t = out.get(key, (0, 0.0))
+        out[key] = (n + 1, t + e0.elapsed_time(e1))
+    return out
+
+
+class _Timed:
+    __slots__ = ("key", "e0")
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _timing is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _timing.append((self.key, self.e0, e1))
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -71,7 +113,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
     d.compute = _compute_mode if compute is None else compute
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
-    _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
+    with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor))):
+        _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C
 
 
@@ -94,8 +137,9 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc)."""
     _require_cuda(x, w2d, bias, y)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(y), _dt(w2d), relu, compute)
-    _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
-             "hulc_conv2d_fwd")
+    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride)):
+        _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
+                 "hulc_conv2d_fwd")
     return y
 
 
@@ -103,8 +147,9 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
     """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout]."""
     _require_cuda(dy, wt, dx, relu_src)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, False, _dt(dx), _dt(dy), _dt(wt), False, compute)
-    _L.check(_L.load().hulc_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _p(relu_src),
-                                            ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_data")
+    with _Timed(("conv2d_bwd_data", N, H, W, Cin, Cout, KH, stride)):
+        _L.check(_L.load().hulc_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _p(relu_src),
+                                                ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_data")
     return dx
 
 
@@ -116,8 +161,9 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(dy), F32, False, compute)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
-                                        ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
+    with _Timed(("conv2d_bwd_weight", N, H, W, Cin, Cout, KH, stride)):
+        _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                            ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
     return dw, db
 
 
@@ -139,7 +185,8 @@ def _call(name, *args):
         else:
             conv.append(a)
     conv.append(_c.c_void_p(_stream()))
-    _L.check(getattr(lib, name)(*conv), name)
+    with _Timed((name,)):
+        _L.check(getattr(lib, name)(*conv), name)
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:

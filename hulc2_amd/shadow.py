@@ -15,11 +15,19 @@ from . import kernels as kn
 
 _cache: Dict[Tuple[int, Optional[str], int], Tuple[int, torch.Tensor, "weakref.ref"]] = {}
 _arena: Dict[int, torch.Tensor] = {}      # id(param) -> bf16 view into the trainer's shadow arena
+_epoch = 0                                # bumped by optimizers that update parameters through raw pointers
 
 
 def clear() -> None:
     _cache.clear()
     _arena.clear()
+
+
+def bump_epoch() -> None:
+    """Invalidate every cached repack/shadow (called after an in-place kernel update of the parameters,
+    which does not touch torch's version counters)."""
+    global _epoch
+    _epoch += 1
 
 
 def register_arena_view(param: torch.Tensor, view_bf16: torch.Tensor) -> None:
@@ -51,7 +59,7 @@ def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tenso
     elif layout is None and id(w) in _arena:
         return _arena[id(w)]
     key = (id(w), layout, int(bf16))
-    ver = w._version
+    ver = (w._version, _epoch)
     hit = _cache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
         return hit[1]

@@ -1,0 +1,144 @@
+"""Native training loop for the hot path: flat HBM arenas, fused Adam, RCCL gradient all-reduce.
+
+The reference trains through pytorch-lightning (hulc2/training.py:64-82: Trainer.fit -> training_step ->
+backward -> DDP bucketed all-reduce -> Adam step).  Lightning is a third-party layer outside the hot-path scope
+(SURVEY.md §2 L3); this file is the MI355X-native equivalent of exactly that inner loop:
+
+  * all trainable parameters live in ONE contiguous fp32 arena (params / grads / exp_avg / exp_avg_sq share
+    offsets) plus a bf16 shadow arena the MFMA kernels read — 47 M params = 188 MB x4 + 94 MB of 288 GB HBM
+  * the optimizer is one HBM-streaming kernel launch over the arena (hulc_adam_step) that also refreshes the
+    bf16 shadow — torch.optim.Adam semantics (hulc2.py:185-198, lr 2e-4)
+  * data parallelism: gradient buckets are contiguous slices of the grad arena, all-reduced in place (no
+    flatten/unflatten copies) on a side HIP stream as soon as autograd has produced every gradient of the
+    bucket; the 1/world scale is folded into the Adam kernel.  One process per GPU, torch.distributed
+    ("nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as kn
+from . import shadow
+
+
+class GradBuckets:
+    """Contiguous slices of the gradient arena reduced across ranks, overlapped with backward."""
+
+    def __init__(self, params: List[torch.nn.Parameter], offsets: List[int], flat_grad: torch.Tensor, bucket_bytes: int,
+                 group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.flat_grad = flat_grad
+        self.on_gpu = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
+        # autograd finishes parameters roughly in reverse registration order: build buckets from the arena's tail
+        self.buckets: List[Dict] = []
+        cur = {"lo": None, "hi": None, "n": 0, "pending": 0}
+        cap = max(bucket_bytes // 4, 1)
+        self.param_bucket: Dict[int, int] = {}
+        for p, off in reversed(list(zip(params, offsets))):
+            n = p.numel()
+            if cur["n"] and cur["n"] + n > cap:
+                self.buckets.append(cur)
+                cur = {"lo": None, "hi": None, "n": 0, "pending": 0}
+            cur["lo"] = off
+            cur["hi"] = cur["hi"] if cur["hi"] is not None else off + n
+            cur["n"] += n
+            self.param_bucket[id(p)] = len(self.buckets)
+        if cur["n"]:
+            self.buckets.append(cur)
+        self.members = [0] * len(self.buckets)
+        for b in self.param_bucket.values():
+            self.members[b] += 1
+        self.handles = []
+        if self.world > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.reset()
+
+    def reset(self):
+        for i, b in enumerate(self.buckets):
+            b["pending"] = self.members[i]
+        self.handles = []
+
+    def _launch(self, b):
+        view = self.flat_grad[b["lo"]:b["hi"]]
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _hook(self, p):
+        b = self.buckets[self.param_bucket[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Flush buckets whose parameters produced no gradient this step, then join the comm stream."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b["pending"] > 0:
+                    b["pending"] = 0
+                    self._launch(b)
+            for h in self.handles:
+                h.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()
+
+
+class ArenaTrainer:
+    def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 bucket_mb: int = 32, group=None):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the arena
+        self.total = total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                if self.flat_bf16 is not None and p.dim() == 2:
+                    shadow.register_arena_view(p, self.flat_bf16[off:off + n].view(p.shape))
+        if self.flat_bf16 is not None:
+            kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, total)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point at the arena
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
+                p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+
+    def optimizer_step(self):
+        self.step_count += 1
+        kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
+                     self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world)
+        shadow.bump_epoch()
+
+    def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        """zero grads -> training_step -> backward (+ overlapped all-reduce) -> fused Adam.  Returns the detached loss."""
+        self.zero_grad()
+        loss = self.model.training_step(batch, batch_idx)
+        loss.backward()
+        self.buckets.finish()
+        self.optimizer_step()
+        return loss.detach()
