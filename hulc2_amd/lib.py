@@ -8,6 +8,9 @@ import ctypes
 import os
 from pathlib import Path
 
+import torch  # noqa: F401  -- must be imported BEFORE the CDLL below: torch ships its own libamdhip64; loading ours first
+#                              would bring a second HIP runtime into the process that owns no device context
+
 _LIB_PATH = Path(__file__).resolve().parent / "libhulc2_amd.so"
 _lib = None
 

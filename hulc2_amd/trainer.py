@@ -101,7 +101,7 @@ class ArenaTrainer:
         self.offsets, total = [], 0
         for p in self.params:
             self.offsets.append(total)
-            total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the arena
+            total += (p.numel() + 7) // 8 * 8            # 16-byte alignment in both the fp32 and the bf16 arena
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
