@@ -155,6 +155,142 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// skinny-M GEMM (M <= 64): the per-sequence layers (batch = 32 rows) and the recurrent step.
+// These are weight-streaming problems: 0.27 GFLOP against an 8 MB weight panel, so the tile machinery
+// above (few workgroups, long serial k loop) is the wrong shape.  Here every wave owns a 32-column
+// strip and a private K slice, pulls its MFMA fragments straight from L2/HBM into registers (no LDS
+// staging: nothing is shared between waves), keeps >= 12 loads in flight per lane, and the K slices
+// are combined in a fixed order: 4 waves through LDS, SPLITK workgroups through fp32 slabs + a
+// second tiny kernel that also applies the epilogue.  No atomics -> bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+template <typename CT> struct Frag;
+template <> struct Frag<bf16_t> {
+    bf16x8_t v;
+    HULC_DEVICE void set(const Chunk8& c) {
+        union { uint4 u; bf16x8_t b; } x;
+        x.u.x = pack_bf16x2(c.v[0], c.v[1]); x.u.y = pack_bf16x2(c.v[2], c.v[3]);
+        x.u.z = pack_bf16x2(c.v[4], c.v[5]); x.u.w = pack_bf16x2(c.v[6], c.v[7]);
+        v = x.b;
+    }
+};
+template <> struct Frag<float> {
+    float v[8];
+    HULC_DEVICE void set(const Chunk8& c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = c.v[j];
+    }
+};
+HULC_DEVICE void frag_mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+HULC_DEVICE void frag_mma(const Frag<float>& a, const Frag<float>& b, f32x16_t& acc) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
+    float v = p.alpha * acc + (p.bias ? p.bias[n] : 0.f);
+    if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
+    if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
+    const long ci = (long)m * p.ldc + n;
+    if (p.accumulate) v += load_elem(p.C, p.c_dtype, ci);
+    return v;
+}
+
+template <typename CT, int TM, bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw) {
+    __shared__ float red[4][TM][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kbeg = (blockIdx.y * 4 + wave) * kw;            // this wave's K slice [kbeg, kbeg + kw)
+    int kend = kbeg + kw; if (kend > p.K) kend = p.K;
+
+    f32x16_t acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    constexpr int UN = 4;                                      // k-steps (of 16) fetched per batch
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * UN) {
+        Chunk8 ca[UN][TM], cb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + u * 16 + h * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (k < kend) load_operand_chunk<AK>(ca[u][i], p.A, p.a_dtype, p.lda, p.M, kend, i * 32 + r, k);
+                else chunk_zero(ca[u][i]);
+            }
+            if (k < kend) load_operand_chunk<BK>(cb[u], p.B, p.b_dtype, p.ldb, p.N, kend, n0 + r, k);
+            else chunk_zero(cb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            Frag<CT> fb; fb.set(cb[u]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { Frag<CT> fa; fa.set(ca[u][i]); frag_mma(fa, fb, acc[i]); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][i][acc_row(e, lane)][r] = acc[i][e];
+    __syncthreads();
+    for (int idx = tid; idx < TM * 1024; idx += 256) {
+        const int i = idx >> 10, row = (idx >> 5) & 31, col = idx & 31;
+        const int m = i * 32 + row, n = n0 + col;
+        if (m >= p.M || n >= p.N) continue;
+        const float v = red[0][i][row][col] + red[1][i][row][col] + red[2][i][row][col] + red[3][i][row][col];
+        if (splitk == 1) store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
+        else slabs[((long)blockIdx.y * p.M + m) * p.N + n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, const float* __restrict__ slabs, int splitk) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = 0.f;
+    for (int s = 0; s < splitk; ++s) v += slabs[(long)s * p.M * p.N + i];
+    store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
+}
+
+// K slices: aim at >= 256 workgroups (one per CU) while every wave keeps at least 64 k of work.
+int skinny_splitk(int M, int N, int K, long ws_bytes) {
+    const int colblocks = (N + 31) / 32;
+    int s = 1;
+    while (colblocks * s < 256 && K / (4 * (s * 2)) >= 64) s *= 2;
+    while (s > 1 && (long)s * M * N * 4 > ws_bytes) s /= 2;
+    return s;
+}
+
+template <typename CT>
+void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
+    const int splitk = skinny_splitk(p.M, p.N, p.K, ws_bytes);
+    int kw = (p.K + splitk * 4 - 1) / (splitk * 4);
+    kw = (kw + 15) / 16 * 16;
+    dim3 grid((p.N + 31) / 32, splitk);
+#define HULC_SK(TMv, AKv, BKv) gemm_skinny_kernel<CT, TMv, AKv, BKv><<<grid, 256, 0, s>>>(p, ws, splitk, kw)
+    if (p.M <= 32) {
+        if (ak && bk) HULC_SK(1, true, true); else if (ak && !bk) HULC_SK(1, true, false);
+        else if (!ak && !bk) HULC_SK(1, false, false); else HULC_SK(1, false, true);
+    } else {
+        if (ak && bk) HULC_SK(2, true, true); else if (ak && !bk) HULC_SK(2, true, false);
+        else if (!ak && !bk) HULC_SK(2, false, false); else HULC_SK(2, false, true);
+    }
+#undef HULC_SK
+    if (splitk > 1) {
+        const long n = (long)p.M * p.N;
+        gemm_splitk_epilogue_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, ws, splitk);
+    }
+}
+
 template <typename CT, int TM, int TN, int WM, int WN>
 void launch_cfg(const GemmP& p, int ak, int bk, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -167,11 +303,10 @@ void launch_cfg(const GemmP& p, int ak, int bk, hipStream_t s) {
 
 template <typename CT>
 void launch_ct(const GemmP& p, int ak, int bk, hipStream_t s) {
-    // tile choice: keep >= ~256 workgroups when the problem allows it (256 CUs), shrink BM for the
-    // skinny per-sequence layers (M = batch = 32) so no MFMA rows are wasted.
+    // tile choice: keep >= ~256 workgroups when the problem allows it (256 CUs); M <= 64 never gets here
+    // (skinny path above).
     const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (p.M <= 32) launch_cfg<CT, 1, 1, 1, 4>(p, ak, bk, s);          // 32 x 128
-    else if (p.M <= 64 || blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, s);   // 64 x 64
+    if (blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, s);   // 64 x 64
     else launch_cfg<CT, 2, 2, 2, 2>(p, ak, bk, s);                    // 128 x 128
 }
 
@@ -195,7 +330,10 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     p.relu = d->relu; p.accumulate = d->accumulate;
     p.alpha = d->alpha; p.mask_scale = d->mask_scale; p.drop_p = d->drop_p; p.drop_seed = d->drop_seed;
     hipStream_t s = (hipStream_t)stream;
-    if (d->compute == HULC_F32) launch_ct<float>(p, d->a_kmajor, d->b_kmajor, s);
+    if (d->M <= 64) {
+        if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
+        else launch_skinny<bf16_t>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
+    } else if (d->compute == HULC_F32) launch_ct<float>(p, d->a_kmajor, d->b_kmajor, s);
     else launch_ct<bf16_t>(p, d->a_kmajor, d->b_kmajor, s);
     return hulc_check_launch("hulc_gemm");
 }

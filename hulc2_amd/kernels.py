@@ -92,6 +92,16 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_scratch = {}
+
+
+def _gemm_scratch(device) -> torch.Tensor:
+    t = _scratch.get(device)
+    if t is None:
+        t = _scratch[device] = torch.empty(4 << 20, dtype=torch.float32, device=device)   # 16 MiB
+    return t
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=None, add=None, ld_add=0,
          mask=None, ld_mask=0, mask_scale=1.0, relu=False, accumulate=False, alpha=1.0, drop_p=0.0,
          drop_seed=0, compute=None):
@@ -113,6 +123,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
     d.compute = _compute_mode if compute is None else compute
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
+    if M <= 64:                       # split-K slabs of the skinny path (stream-ordered reuse of one scratch buffer)
+        ws = _gemm_scratch(C.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor))):
         _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C

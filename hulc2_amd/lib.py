@@ -33,6 +33,7 @@ class GemmDesc(ctypes.Structure):
         ("alpha", ctypes.c_float), ("mask_scale", ctypes.c_float), ("drop_p", ctypes.c_float),
         ("drop_seed", ctypes.c_ulonglong),
         ("compute", ctypes.c_int),
+        ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long),
     ]
 
 

@@ -46,6 +46,7 @@ typedef struct {
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
     int compute;
+    void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K path of skinny (M <= 64) problems */
 } hulc_gemm_desc;
 int hulc_gemm(const hulc_gemm_desc* d, void* stream);
 

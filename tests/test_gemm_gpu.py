@@ -69,11 +69,12 @@ def test_gemm_asymmetric_identity(dev, compute):
     assert torch.equal(C, B.t().contiguous()), f"C != B^T; max diff {(C - B.t()).abs().max().item()}"
 
 
+@pytest.mark.parametrize("M", [96, 48, 20])      # LDS-tiled path, skinny path with two / one row tiles (split-K epilogue)
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
-def test_gemm_epilogue(dev, compute):
+def test_gemm_epilogue(dev, compute, M):
     from hulc2_amd import kernels as kn
 
-    M, N, K = 96, 200, 256
+    N, K = 200, 2048
     g = torch.Generator().manual_seed(7)
     A = torch.randn(M, K, generator=g).to(dev)
     B = torch.randn(N, K, generator=g).to(dev)
@@ -89,7 +90,7 @@ def test_gemm_epilogue(dev, compute):
     ref = torch.relu(ref)
     ref = torch.where(mask > 0, ref * 1.5, torch.zeros_like(ref)) + C0.double()
     err = (C.double() - ref).abs().max().item()
-    assert err < 2e-3, f"epilogue max err {err:.3e}"
+    assert err < 5e-3, f"epilogue max err {err:.3e}"
 
 
 def test_gemm_strided_views_and_bf16_storage(dev):
