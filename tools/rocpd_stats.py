@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-kernel summary (calls, total, average, share) from a rocprofv3 rocpd SQLite database.
+
+usage: python tools/rocpd_stats.py gpurun_out/prof/x_results.db [> profiles/xxx.txt]
+Equivalent to rocprofv3's kernel stats table; used because this rocprofv3 build writes rocpd databases by default.
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name if len(name) <= 150 else name[:147] + "..."
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info('kernels')")]
+    rows = c.execute("select name, count(*), sum(end-start), min(end-start), max(end-start) from kernels group by name").fetchall() \
+        if "name" in cols else []
+    if not rows:
+        rows = c.execute(
+            "select s.kernel_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+            "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    rows.sort(key=lambda r: -r[2])
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'%':>6}  kernel")
+    for name, n, t, mn, mx in rows:
+        print(f"{n:7d} {t / 1e6:10.3f} {t / n / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * t / total:6.2f}  {short(name)}")
+    print(f"\ntotal kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
