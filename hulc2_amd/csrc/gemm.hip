@@ -201,13 +201,13 @@ HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
     return v;
 }
 
-template <typename CT, int TM, bool AK, bool BK>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw) {
-    __shared__ float red[4][TM][32][33];
+template <typename CT, int TM, bool AK, bool BK, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw) {
+    __shared__ float red[NW][TM][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    const int kbeg = (blockIdx.y * 4 + wave) * kw;            // this wave's K slice [kbeg, kbeg + kw)
+    const int kbeg = (blockIdx.y * NW + wave) * kw;           // this wave's K slice [kbeg, kbeg + kw)
     int kend = kbeg + kw; if (kend > p.K) kend = p.K;
 
     f32x16_t acc[TM];
@@ -242,11 +242,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, float* __rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[wave][i][acc_row(e, lane)][r] = acc[i][e];
     __syncthreads();
-    for (int idx = tid; idx < TM * 1024; idx += 256) {
+    for (int idx = tid; idx < TM * 1024; idx += NW * 64) {
         const int i = idx >> 10, row = (idx >> 5) & 31, col = idx & 31;
         const int m = i * 32 + row, n = n0 + col;
         if (m >= p.M || n >= p.N) continue;
-        const float v = red[0][i][row][col] + red[1][i][row][col] + red[2][i][row][col] + red[3][i][row][col];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][i][row][col];
         if (splitk == 1) store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
         else slabs[((long)blockIdx.y * p.M + m) * p.N + n] = v;
     }
@@ -261,28 +263,29 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, cons
     store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
 }
 
-// K slices: aim at >= 256 workgroups (one per CU) while every wave keeps at least 64 k of work.
-int skinny_splitk(int M, int N, int K, long ws_bytes) {
-    const int colblocks = (N + 31) / 32;
-    int s = 1;
-    while (colblocks * s < 256 && K / (4 * (s * 2)) >= 64) s *= 2;
-    while (s > 1 && (long)s * M * N * 4 > ws_bytes) s /= 2;
-    return s;
-}
-
+// K slices: waves first (up to 16 per workgroup: combined through LDS in the same launch, epilogue fused),
+// then workgroups (fp32 slabs + epilogue kernel) until ~256 workgroups exist; every wave keeps >= 64 k.
 template <typename CT>
 void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
-    const int splitk = skinny_splitk(p.M, p.N, p.K, ws_bytes);
-    int kw = (p.K + splitk * 4 - 1) / (splitk * 4);
+    const int colblocks = (p.N + 31) / 32;
+    const bool big = p.M <= 32 && p.K >= 1024;                  // 16 waves x TM=1: 66 KB of LDS for the reduction
+    const int nw = big ? 16 : 4;
+    int splitk = 1;
+    while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= 64) splitk *= 2;
+    while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
+    int kw = (p.K + splitk * nw - 1) / (splitk * nw);
     kw = (kw + 15) / 16 * 16;
-    dim3 grid((p.N + 31) / 32, splitk);
-#define HULC_SK(TMv, AKv, BKv) gemm_skinny_kernel<CT, TMv, AKv, BKv><<<grid, 256, 0, s>>>(p, ws, splitk, kw)
-    if (p.M <= 32) {
-        if (ak && bk) HULC_SK(1, true, true); else if (ak && !bk) HULC_SK(1, true, false);
-        else if (!ak && !bk) HULC_SK(1, false, false); else HULC_SK(1, false, true);
+    dim3 grid(colblocks, splitk);
+#define HULC_SK(TMv, AKv, BKv, NWv) gemm_skinny_kernel<CT, TMv, AKv, BKv, NWv><<<grid, NWv * 64, 0, s>>>(p, ws, splitk, kw)
+    if (big) {
+        if (ak && bk) HULC_SK(1, true, true, 16); else if (ak && !bk) HULC_SK(1, true, false, 16);
+        else if (!ak && !bk) HULC_SK(1, false, false, 16); else HULC_SK(1, false, true, 16);
+    } else if (p.M <= 32) {
+        if (ak && bk) HULC_SK(1, true, true, 4); else if (ak && !bk) HULC_SK(1, true, false, 4);
+        else if (!ak && !bk) HULC_SK(1, false, false, 4); else HULC_SK(1, false, true, 4);
     } else {
-        if (ak && bk) HULC_SK(2, true, true); else if (ak && !bk) HULC_SK(2, true, false);
-        else if (!ak && !bk) HULC_SK(2, false, false); else HULC_SK(2, false, true);
+        if (ak && bk) HULC_SK(2, true, true, 4); else if (ak && !bk) HULC_SK(2, true, false, 4);
+        else if (!ak && !bk) HULC_SK(2, false, false, 4); else HULC_SK(2, false, true, 4);
     }
 #undef HULC_SK
     if (splitk > 1) {

@@ -351,12 +351,12 @@ class DecoderRNNFn(torch.autograd.Function):
     def _bptt(dH, h, w_hh, B, S, Hd):
         """delta_t = (dH_t + delta_{t+1} W_hh) * (h_t > 0), t = S-1..0."""
         delta = torch.empty_like(dH)
-        whh = weight_operand(w_hh)
+        whh_t = weight_operand(w_hh, "t")           # [k][n] -> rows = output index of dX: k-major panel for the skinny GEMM
         last = torch.empty(B, Hd, dtype=torch.float32, device=dH.device)
         kn.relu_bwd(_c(dH[:, S - 1]), _c(h[:, S - 1]), last, B * Hd)
         delta[:, S - 1] = last
         for t in range(S - 2, -1, -1):
-            kn.gemm(delta[:, t + 1], whh, delta[:, t], B, Hd, Hd, S * Hd, Hd, S * Hd, b_kmajor=False, add=dH[:, t], ld_add=S * Hd,
+            kn.gemm(delta[:, t + 1], whh_t, delta[:, t], B, Hd, Hd, S * Hd, Hd, S * Hd, add=dH[:, t], ld_add=S * Hd,
                     mask=h[:, t], ld_mask=S * Hd)
         return delta
 

@@ -44,6 +44,8 @@ def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
         return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     if layout == "ihwo":               # data gradient: rows = input channel, k = (kh, kw, cout)
         return w.permute(1, 2, 3, 0)
+    if layout == "t":                  # transposed 2-D weight: lets dX = dY W stream W k-major
+        return w.t()
     raise ValueError(layout)
 
 
