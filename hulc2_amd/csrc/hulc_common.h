@@ -27,17 +27,18 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------
 HULC_DEVICE float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
-HULC_DEVICE uint16_t f32_to_bf16_bits(float f) {
-    // round-to-nearest-even, NaN kept quiet (same rounding torch uses for .to(bfloat16))
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 goes through the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, the rounding
+// torch uses for .to(bfloat16)); one instruction per pair instead of ~6 VALU ops per element in software.
+HULC_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t f = {lo, hi};
+    union { bf16x2_t b; uint32_t u; } x;
+    x.b = __builtin_convertvector(f, bf16x2_t);
+    return x.u;
 }
 
-HULC_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
-}
+HULC_DEVICE uint16_t f32_to_bf16_bits(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // generic typed element load/store by runtime dtype code
 HULC_DEVICE float load_elem(const void* p, int dtype, long idx) {
