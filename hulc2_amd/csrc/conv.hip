@@ -206,12 +206,24 @@ template <> HULC_DEVICE void store_pair_transposed<float>(char* tile, int row0, 
     for (int j = 0; j < 8; ++j) *(float2*)(tile + (row0 + j) * HULC_ROWB + m * 4) = make_float2(a.v[j], b.v[j]);
 }
 
-// TMC = Cout / 32 (1 or 2).  Each workgroup: 4 waves, wave w owns k-tile w of its 128-wide K slice.
-template <typename CT, int TMC>
+// running (image, row, col) of an output pixel; advanced by a fixed step per reduction tile instead of
+// re-dividing the flat pixel index every tile
+struct PixIter {
+    int n, oy, ox;
+    HULC_DEVICE void init(long m, int OH, int OW) { ox = (int)(m % OW); long r = m / OW; oy = (int)(r % OH); n = (int)(r / OH); }
+    HULC_DEVICE void advance(int step, int OH, int OW) {
+        ox += step;
+        while (ox >= OW) { ox -= OW; if (++oy >= OH) { oy = 0; ++n; } }
+    }
+};
+
+// TMC = Cout / 32 (1 or 2), TNW = 32-wide k tiles per wave (workgroup k slice = 128 * TNW).
+// Each workgroup: 4 waves; wave w owns k tiles [w*TNW, (w+1)*TNW) of the slice and all output channels.
+template <typename CT, int TMC, int TNW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     using T = MmaTraits<CT>;
     constexpr int KT = T::KT;                 // pixels per reduction tile (32 bf16 / 16 f32)
-    constexpr int CO = TMC * 32, KS = 128;
+    constexpr int CO = TMC * 32, KS = 128 * TNW;
     constexpr int PAIRS = KT / 2;             // pixel pairs per tile
     constexpr int DY_ITEMS = PAIRS * (CO / 8), X_ITEMS = PAIRS * (KS / 8);
     constexpr int X_PER = (X_ITEMS + 255) / 256;
@@ -229,41 +241,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int ks0 = blockIdx.y * KS;
     const int ntile = (int)((me - mb + KT - 1) / KT);
 
-    f32x16_t acc[TMC][1];
+    f32x16_t acc[TMC][TNW];
 #pragma unroll
     for (int i = 0; i < TMC; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float bacc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bacc[j] = 0.f;
 
     // item -> (pixel pair, chunk): consecutive threads take consecutive chunks of one pixel pair so a
-    // wave's loads cover whole contiguous channel runs.
-    Chunk8 dya, dyb, xa[X_PER], xb[X_PER];
-    auto pixel = [&](long m, long& xbase, int& iy0, int& ix0, long& dybase) {
-        int ox = (int)(m % g.OW); long r = m / g.OW; int oy = (int)(r % g.OH); long n = r / g.OH;
-        iy0 = oy * g.stride; ix0 = ox * g.stride;
-        xbase = n * g.x_sn + (long)iy0 * g.x_sy + (long)ix0 * g.x_sx;
-        dybase = n * p.dy_sn + (long)oy * p.dy_sy + (long)ox * p.dy_sx;
+    // wave's loads cover whole contiguous channel runs.  Pixel coordinates are carried incrementally.
+    const int dy_pr = tid / (CO / 8), dy_ch = tid % (CO / 8);
+    PixIter dyit; dyit.init(mb + 2 * dy_pr < Mtot ? mb + 2 * dy_pr : Mtot - 1, g.OH, g.OW);
+    PixIter xit[X_PER]; int x_pr[X_PER], x_ch[X_PER];
+#pragma unroll
+    for (int q = 0; q < X_PER; ++q) {
+        const int id = tid + q * 256;
+        x_pr[q] = id / (KS / 8); x_ch[q] = id % (KS / 8);
+        const long m = mb + 2 * x_pr[q];
+        xit[q].init(m < Mtot ? m : Mtot - 1, g.OH, g.OW);
+    }
+    auto x_base = [&](const PixIter& it, int& iy0, int& ix0) -> long {
+        iy0 = it.oy * g.stride; ix0 = it.ox * g.stride;
+        return (long)it.n * g.x_sn + (long)iy0 * g.x_sy + (long)ix0 * g.x_sx;
     };
+    auto dy_base = [&](const PixIter& it) -> long { return (long)it.n * p.dy_sn + (long)it.oy * p.dy_sy + (long)it.ox * p.dy_sx; };
+
+    Chunk8 dya, dyb, xa[X_PER], xb[X_PER];
     auto load_tiles = [&](int t) {
         const long mt = mb + (long)t * KT;
         if (tid < DY_ITEMS) {
-            const int pr = tid / (CO / 8), ch = tid % (CO / 8);
-            long m = mt + 2 * pr, xb_, db_; int a_, b_;
-            if (m < me) { pixel(m, xb_, a_, b_, db_); chunk_load_contig(dya, p.dY, p.dy_dtype, db_ + ch * 8); } else chunk_zero(dya);
-            if (m + 1 < me) { pixel(m + 1, xb_, a_, b_, db_); chunk_load_contig(dyb, p.dY, p.dy_dtype, db_ + ch * 8); } else chunk_zero(dyb);
+            const long m = mt + 2 * dy_pr;
+            if (m < me) chunk_load_contig(dya, p.dY, p.dy_dtype, dy_base(dyit) + dy_ch * 8); else chunk_zero(dya);
+            if (m + 1 < me) { PixIter nx = dyit; nx.advance(1, g.OH, g.OW); chunk_load_contig(dyb, p.dY, p.dy_dtype, dy_base(nx) + dy_ch * 8); }
+            else chunk_zero(dyb);
+            dyit.advance(KT, g.OH, g.OW);
         }
 #pragma unroll
         for (int q = 0; q < X_PER; ++q) {
-            const int id = tid + q * 256;
-            if (X_ITEMS % 256 == 0 || id < X_ITEMS) {
-                const int pr = id / (KS / 8), ch = id % (KS / 8);
-                const int k0 = ks0 + ch * 8;
-                long m = mt + 2 * pr, xbase, db_; int iy0, ix0;
-                if (m < me) { pixel(m, xbase, iy0, ix0, db_); gather_chunk(xa[q], g, xbase, iy0, ix0, k0, K); } else chunk_zero(xa[q]);
-                if (m + 1 < me) { pixel(m + 1, xbase, iy0, ix0, db_); gather_chunk(xb[q], g, xbase, iy0, ix0, k0, K); } else chunk_zero(xb[q]);
+            if (X_ITEMS % 256 == 0 || tid + q * 256 < X_ITEMS) {
+                const int k0 = ks0 + x_ch[q] * 8;
+                const long m = mt + 2 * x_pr[q];
+                int iy0, ix0;
+                if (m < me) { const long b = x_base(xit[q], iy0, ix0); gather_chunk(xa[q], g, b, iy0, ix0, k0, K); } else chunk_zero(xa[q]);
+                if (m + 1 < me) { PixIter nx = xit[q]; nx.advance(1, g.OH, g.OW); const long b = x_base(nx, iy0, ix0); gather_chunk(xb[q], g, b, iy0, ix0, k0, K); }
+                else chunk_zero(xb[q]);
+                xit[q].advance(KT, g.OH, g.OW);
             }
         }
     };
@@ -271,19 +297,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         char* As = smem + buf * (CO + KS) * HULC_ROWB;   // dY^T : rows = output channel
         char* Bs = As + CO * HULC_ROWB;                   // X^T  : rows = k inside the slice
         if (tid < DY_ITEMS) {
-            const int pr = tid / (CO / 8), ch = tid % (CO / 8);
-            store_pair_transposed<CT>(As, ch * 8, 2 * pr, dya, dyb);
+            store_pair_transposed<CT>(As, dy_ch * 8, 2 * dy_pr, dya, dyb);
 #pragma unroll
             for (int j = 0; j < 8; ++j) bacc[j] += dya.v[j] + dyb.v[j];
         }
 #pragma unroll
-        for (int q = 0; q < X_PER; ++q) {
-            const int id = tid + q * 256;
-            if (X_ITEMS % 256 == 0 || id < X_ITEMS) {
-                const int pr = id / (KS / 8), ch = id % (KS / 8);
-                store_pair_transposed<CT>(Bs, ch * 8, 2 * pr, xa[q], xb[q]);
-            }
-        }
+        for (int q = 0; q < X_PER; ++q)
+            if (X_ITEMS % 256 == 0 || tid + q * 256 < X_ITEMS) store_pair_transposed<CT>(Bs, x_ch[q] * 8, 2 * x_pr[q], xa[q], xb[q]);
     };
 
     if (ntile > 0) {
@@ -296,19 +316,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         if (t + 1 < ntile) load_tiles(t + 1);
         const char* As = smem + buf * (CO + KS) * HULC_ROWB;
         const char* Bs = As + CO * HULC_ROWB;
-        MmaTile<CT, TMC, 1>::run(As, Bs + wave * 32 * HULC_ROWB, acc, lane);
+        MmaTile<CT, TMC, TNW>::run(As, Bs + wave * TNW * 32 * HULC_ROWB, acc, lane);
         if (t + 1 < ntile) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
     // partial dW slab: rows = co, cols = k
     float* pw = p.partial_w + (long)blockIdx.x * CO * K;
-    const int k = ks0 + wave * 32 + (lane & 31);
-    if (k < K) {
 #pragma unroll
-        for (int i = 0; i < TMC; ++i)
+    for (int j = 0; j < TNW; ++j) {
+        const int k = ks0 + (wave * TNW + j) * 32 + (lane & 31);
+        if (k < K) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) pw[(long)(i * 32 + acc_row(e, lane)) * K + k] = acc[i][0][e];
+            for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pw[(long)(i * 32 + acc_row(e, lane)) * K + k] = acc[i][j][e];
+        }
     }
     if (p.partial_b && blockIdx.y == 0) {
         if (tid < DY_ITEMS) {
@@ -433,12 +456,22 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
     return hulc_check_launch("hulc_conv2d_bwd_data");
 }
 
+// pixel split: ~1024 workgroups in total (4 per CU) with at least 256 pixels each
+static void wgrad_split(const hulc_conv_desc* d, long& P, long& ppb, long& K, long& Mtot) {
+    const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1;
+    K = (long)d->Cin * d->KH * d->KW;
+    Mtot = (long)d->N * OH * OW;
+    const long kslices = (K + 255) / 256;
+    ppb = (Mtot * kslices + 1023) / 1024;
+    if (ppb < 256) ppb = 256;
+    ppb = (ppb + 31) / 32 * 32;
+    P = (Mtot + ppb - 1) / ppb;
+}
+
 extern "C" long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d) {
     if (!d) return -1;
-    const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1;
-    const long K = (long)d->Cin * d->KH * d->KW;
-    const long Mtot = (long)d->N * OH * OW;
-    long P = (Mtot + 4095) / 4096; if (P > 512) P = 512; if (P < 1) P = 1;
+    long P, ppb, K, Mtot;
+    wgrad_split(d, P, ppb, K, Mtot);
     return P * d->Cout * (K + 1) * (long)sizeof(float);
 }
 
@@ -451,20 +484,18 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
     p.g.X = x; p.g.Wt = nullptr; p.g.bias = nullptr; p.g.Y = nullptr; p.g.mask = nullptr;
     p.dY = dy; p.dy_dtype = d->y_dtype;
     p.dy_sn = (long)p.g.OH * p.g.OW * d->Cout; p.dy_sy = (long)p.g.OW * d->Cout; p.dy_sx = d->Cout;
-    const long K = p.g.ldw, Mtot = (long)d->N * p.g.OH * p.g.OW;
-    long P = (Mtot + 4095) / 4096; if (P > 512) P = 512; if (P < 1) P = 1;
-    long ppb = (Mtot + P - 1) / P; ppb = (ppb + 31) / 32 * 32;
-    P = (Mtot + ppb - 1) / ppb;
+    long P, ppb, K, Mtot;
+    wgrad_split(d, P, ppb, K, Mtot);
     p.pix_per_block = ppb;
     p.partial_w = (float*)ws;
     p.partial_b = db ? p.partial_w + P * d->Cout * K : nullptr;
-    dim3 grid((unsigned)P, (unsigned)((K + 127) / 128));
+    dim3 grid((unsigned)P, (unsigned)((K + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
     if (d->compute == HULC_F32) {
         if (d->y_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_weight: f32 compute requires f32 operands");
-        if (d->Cout == 32) conv_wgrad_kernel<float, 1><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<float, 2><<<grid, 256, 0, s>>>(p);
+        if (d->Cout == 32) conv_wgrad_kernel<float, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<float, 2, 2><<<grid, 256, 0, s>>>(p);
     } else {
-        if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2><<<grid, 256, 0, s>>>(p);
+        if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, 256, 0, s>>>(p);
     }
     const long R = (long)d->Cout * K;
     reduce_partials_kernel<<<(unsigned)((R + 255) / 256), 256, 0, s>>>(p.partial_w, dw, (int)P, R, 0);

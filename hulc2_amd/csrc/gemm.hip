@@ -46,7 +46,7 @@ HULC_DEVICE void load_operand_chunk(Chunk8& c, const void* base, int dtype, long
 }
 
 template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __restrict__ slabs, int splitk) {
     using T = MmaTraits<CT>;
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -70,7 +70,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     Chunk8 ra[A_PER], rb[B_PER];
-    const int nkt = (p.K + KT - 1) / KT;
+    const int nkt_all = (p.K + KT - 1) / KT;
+    const int kt_per = (nkt_all + splitk - 1) / splitk;            // blockIdx.z owns k tiles [kt0, kt1)
+    const int kt0 = blockIdx.z * kt_per;
+    const int kt1 = kt0 + kt_per < nkt_all ? kt0 + kt_per : nkt_all;
 
     // chunk id -> (row, chunk-in-row).  k-major sources: consecutive threads walk k first (one row's
     // 64..128 contiguous bytes per 2..4 threads); row-major sources: consecutive threads walk rows
@@ -117,17 +120,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
         }
     };
 
-    load_tiles(0);
-    store_tiles(0);
+    if (kt0 < kt1) {
+        load_tiles(kt0);
+        store_tiles(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tiles(kt + 1);
         const char* As = smem + buf * (BM + BN) * HULC_ROWB;
         const char* Bs = As + BM * HULC_ROWB;
         MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
-        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        if (kt + 1 < kt1) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+
+    if (splitk > 1) {   // raw partial sums; gemm_splitk_epilogue_kernel combines the slabs in a fixed order
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
+                    if (m < p.M) slabs[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][e];
+                }
+        }
+        return;
     }
 
     // epilogue: lane owns column n = lane & 31 of each tile; each accumulator register is one row.
@@ -295,22 +316,33 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
 }
 
 template <typename CT, int TM, int TN, int WM, int WN>
-void launch_cfg(const GemmP& p, int ak, int bk, hipStream_t s) {
+void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), block(WM * WN * 64);
-    if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p);
-    else if (ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, true, false><<<grid, block, 0, s>>>(p);
-    else if (!ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, false, false><<<grid, block, 0, s>>>(p);
-    else gemm_kernel<CT, TM, TN, WM, WN, false, true><<<grid, block, 0, s>>>(p);
+    const int gx = (p.M + BM - 1) / BM, gy = (p.N + BN - 1) / BN;
+    // few output tiles but a long reduction (dgrads into narrow layers, wgrads of narrow layers): split K over
+    // workgroups until ~256 exist, keeping >= 8 k-tiles per slice
+    const int nkt = (p.K + MmaTraits<CT>::KT - 1) / MmaTraits<CT>::KT;
+    int splitk = 1;
+    while (gx * gy * splitk < 192 && nkt / (splitk * 2) >= 8) splitk *= 2;
+    while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
+    dim3 grid(gx, gy, splitk), block(WM * WN * 64);
+    if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p, ws, splitk);
+    else if (ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, true, false><<<grid, block, 0, s>>>(p, ws, splitk);
+    else if (!ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, false, false><<<grid, block, 0, s>>>(p, ws, splitk);
+    else gemm_kernel<CT, TM, TN, WM, WN, false, true><<<grid, block, 0, s>>>(p, ws, splitk);
+    if (splitk > 1) {
+        const long n = (long)p.M * p.N;
+        gemm_splitk_epilogue_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, ws, splitk);
+    }
 }
 
 template <typename CT>
-void launch_ct(const GemmP& p, int ak, int bk, hipStream_t s) {
+void launch_ct(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
     // tile choice: keep >= ~256 workgroups when the problem allows it (256 CUs); M <= 64 never gets here
     // (skinny path above).
     const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, s);   // 64 x 64
-    else launch_cfg<CT, 2, 2, 2, 2>(p, ak, bk, s);                    // 128 x 128
+    if (blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, ws, ws_bytes, s);   // 64 x 64
+    else launch_cfg<CT, 2, 2, 2, 2>(p, ak, bk, ws, ws_bytes, s);                    // 128 x 128
 }
 
 }  // namespace
@@ -336,7 +368,7 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     if (d->M <= 64) {
         if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
         else launch_skinny<bf16_t>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
-    } else if (d->compute == HULC_F32) launch_ct<float>(p, d->a_kmajor, d->b_kmajor, s);
-    else launch_ct<bf16_t>(p, d->a_kmajor, d->b_kmajor, s);
+    } else if (d->compute == HULC_F32) launch_ct<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
+    else launch_ct<bf16_t>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
     return hulc_check_launch("hulc_gemm");
 }

@@ -171,7 +171,7 @@ __global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __r
 // column sums: out[n] = sum_m x[m][n]   (bias gradients).  Workgroup = 4 waves x 64 columns.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int x_dtype, long M, int N, long ld, long rows_per_block,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, float* __restrict__ direct_out, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
@@ -182,7 +182,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
         for (long r = r0 + wave; r < r1; r += 4) s += load_elem(x, x_dtype, r * ld + n);
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && n < N) partial[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave == 0 && n < N) {
+        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (direct_out) direct_out[n] = accumulate ? direct_out[n] + v : v;      // single row block: no second pass
+        else partial[(long)blockIdx.y * N + n] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,12 +449,13 @@ extern "C" long hulc_colsum_workspace(long M, int N) {
 extern "C" int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream) {
     if (!x || !out || !ws) return hulc_fail(-1, "hulc_colsum: null pointer");
     long rb = (M + 511) / 512; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+    if (M <= 2048 && N >= 1024) rb = 1;                 // wide and short: enough column groups to fill the chip alone
     const long rpb = (M + rb - 1) / rb;
     rb = (M + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((N + 63) / 64, (unsigned)rb);
-    colsum_kernel<<<grid, 256, 0, s>>>(x, x_dtype, M, N, ld, rpb, (float*)ws);
-    reduce_rows_kernel<<<(N + 255) / 256, 256, 0, s>>>((const float*)ws, out, (int)rb, N, N, accumulate);
+    colsum_kernel<<<grid, 256, 0, s>>>(x, x_dtype, M, N, ld, rpb, (float*)ws, rb == 1 ? out : nullptr, accumulate);
+    if (rb > 1) reduce_rows_kernel<<<(N + 255) / 256, 256, 0, s>>>((const float*)ws, out, (int)rb, N, N, accumulate);
     return hulc_check_launch("hulc_colsum");
 }
 

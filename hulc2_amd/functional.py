@@ -22,6 +22,13 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _act_dtype() -> torch.dtype:
+    """Storage type of the conv-stack activations and their gradients: the MFMA kernels round operands to the
+    compute type while staging anyway, so in bf16 mode keeping them bf16 in HBM halves the traffic at identical
+    arithmetic (fp32 mode keeps fp32)."""
+    return torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
+
+
 # ------------------------------------------------------------------------------------------------
 # MLP chain: y = L_n(...relu(L_1(x))) — all Linear(+ReLU(+Dropout)) stacks of the policy
 # reference: plan_proposal_net.py:26-47, goal_encoders.py:21-34,53-71, vision_network.py:49-52,
@@ -108,7 +115,7 @@ class ConvStackFn(torch.autograd.Function):
             nchw = li == 0
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
-            y = _f32(N, oh, ow, cout, like=x)
+            y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=x.device)
             kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
             dims.append((h, w_, cin, cout, k, s, nchw))
             acts.append(y)
@@ -123,8 +130,8 @@ class ConvStackFn(torch.autograd.Function):
         dims, premasked, N = ctx.meta
         g = _c(da3)
         if not premasked:
-            gz = torch.empty_like(g)
-            kn.relu_bwd(g, a3, gz, g.numel())
+            gz = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+            kn.relu_bwd(g.float() if g.dtype != torch.float32 else g, a3, gz, g.numel())
             g = gz
         inputs = (x, a1, a2)
         weights = (None, w2, w3)
@@ -140,7 +147,7 @@ class ConvStackFn(torch.autograd.Function):
             grads_b[li] = db
             if li > 0:
                 wt = weight_operand(weights[li], "ihwo")
-                dx = _f32(N, h, w_, cin, like=g)
+                dx = torch.empty(N, h, w_, cin, dtype=inp.dtype, device=g.device)
                 kn.conv2d_bwd_data(g, wt, dx, inp, N, h, w_, cin, cout, k, k, s)   # masked by relu of the layer input
                 g = dx
         return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2])

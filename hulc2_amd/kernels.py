@@ -98,7 +98,7 @@ _scratch = {}
 def _gemm_scratch(device) -> torch.Tensor:
     t = _scratch.get(device)
     if t is None:
-        t = _scratch[device] = torch.empty(4 << 20, dtype=torch.float32, device=device)   # 16 MiB
+        t = _scratch[device] = torch.empty(8 << 20, dtype=torch.float32, device=device)   # 32 MiB
     return t
 
 
@@ -123,9 +123,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
     d.compute = _compute_mode if compute is None else compute
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
-    if M <= 64:                       # split-K slabs of the skinny path (stream-ordered reuse of one scratch buffer)
-        ws = _gemm_scratch(C.device)
-        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    ws = _gemm_scratch(C.device)      # split-K slabs (stream-ordered reuse of one scratch buffer)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor))):
         _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C
