@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=32)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
 
@@ -111,7 +112,8 @@ def main():
     model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
     syn.fill_state_dict_(model.state_dict(), 42)            # same weights on every rank
     model.train()
-    trainer = ArenaTrainer(model, lr=2e-4)
+    use_graph = not args.no_graph
+    trainer = ArenaTrainer(model, lr=2e-4, overlap=not use_graph)
     batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev)
     for db in batch.values():
         db.pop("plan_idx", None)                            # benchmark samples the latent plan on-device
@@ -122,12 +124,21 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
+    if use_graph:
+        for i in range(2):                                  # eager steps: allocator pools + lazy buffers before capture
+            loss = trainer.step(batch, i)
+        try:
+            trainer.capture(batch)
+        except Exception as e:                              # noqa: BLE001 - report and fall back to eager launches
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+    run_step = (lambda i: trainer.replay()) if use_graph else (lambda i: trainer.step(batch, i))
     for i in range(args.warmup):
-        loss = trainer.step(batch, i)
+        loss = run_step(i)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.step(batch, i)
+        loss = run_step(i)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -167,6 +178,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: synthetic CALVIN-shaped batch, Hulc2.training_step fwd+bwd+allreduce+Adam, "
                                "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on",
                    "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
                    "final_loss": round(final_loss, 4)},
         "roofline": {"bound": "mfma", "kernel": "/".join(str(k) for k in dom_key), "achieved": round(achieved / 1e12, 2),
                      "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,

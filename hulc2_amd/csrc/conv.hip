@@ -20,6 +20,7 @@
 //       (column sums of dY) rides along.
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -192,6 +193,7 @@ struct WgradP {
     float* partial_w;          // [P][Cout][K]
     float* partial_b;          // [P][Cout] or null
     long pix_per_block;        // pixels per workgroup (multiple of the reduction tile)
+    int pair_fastest;          // staging item order: consecutive lanes walk pixel pairs (1) or k-chunks (0)
 };
 
 // write two pixels' worth of one 8-wide chunk transposed into the LDS tile: element j of the chunk
@@ -254,13 +256,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 
     // item -> (pixel pair, chunk): consecutive threads take consecutive chunks of one pixel pair so a
     // wave's loads cover whole contiguous channel runs.  Pixel coordinates are carried incrementally.
-    const int dy_pr = tid / (CO / 8), dy_ch = tid % (CO / 8);
+    const int dy_pr = p.pair_fastest ? tid % PAIRS : tid / (CO / 8), dy_ch = p.pair_fastest ? tid / PAIRS : tid % (CO / 8);
     PixIter dyit; dyit.init(mb + 2 * dy_pr < Mtot ? mb + 2 * dy_pr : Mtot - 1, g.OH, g.OW);
     PixIter xit[X_PER]; int x_pr[X_PER], x_ch[X_PER];
 #pragma unroll
     for (int q = 0; q < X_PER; ++q) {
         const int id = tid + q * 256;
-        x_pr[q] = id / (KS / 8); x_ch[q] = id % (KS / 8);
+        x_pr[q] = p.pair_fastest ? id % PAIRS : id / (KS / 8); x_ch[q] = p.pair_fastest ? id / PAIRS : id % (KS / 8);
         const long m = mb + 2 * x_pr[q];
         xit[q].init(m < Mtot ? m : Mtot - 1, g.OH, g.OW);
     }
@@ -341,19 +343,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         __syncthreads();
         if (tid < CO) {
             float sacc = 0.f;
-            for (int pr = 0; pr < PAIRS; ++pr) sacc += bpart[pr * (CO / 8) + tid / 8][tid % 8];
+            for (int pr = 0; pr < PAIRS; ++pr) sacc += bpart[p.pair_fastest ? (tid / 8) * PAIRS + pr : pr * (CO / 8) + tid / 8][tid % 8];
             p.partial_b[(long)blockIdx.x * CO + tid] = sacc;
         }
     }
 }
 
-// out[r] = sum_p partial[p][r]  (deterministic order)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
+// out[r] = sum_p partial[p][r]: workgroup = 64 outputs x 16 P-slices (fixed slice boundaries and a fixed
+// combine order -> deterministic), so the P-long loop is 16x shorter and the grid is R/64 workgroups of 1024.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 64 + lane;
+    const int per = (P + 15) / 16;
+    const int q0 = sl * per, q1 = q0 + per < P ? q0 + per : P;
     float s = 0.f;
-    for (int q = 0; q < P; ++q) s += partial[(long)q * R + r];
-    out[r] = accumulate ? out[r] + s : s;
+    if (r < R)
+        for (int q = q0; q < q1; ++q) s += partial[(long)q * R + r];
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && r < R) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[r] = accumulate ? out[r] + t : t;
+    }
 }
 
 void fill_gather(GatherP& g, const hulc_conv_desc* d) {
@@ -487,6 +501,12 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
     long P, ppb, K, Mtot;
     wgrad_split(d, P, ppb, K, Mtot);
     p.pix_per_block = ppb;
+    {
+        // staging order: consecutive lanes walk pixel pairs (conflict-light transposed LDS writes; measured faster than
+        // chunk-fastest on all six layers: tools/wgrad_bench.py).  HULC_WGRAD_PAIR_FASTEST=0 keeps the other order for A/B runs.
+        const char* e = getenv("HULC_WGRAD_PAIR_FASTEST");
+        p.pair_fastest = e ? atoi(e) : 1;
+    }
     p.partial_w = (float*)ws;
     p.partial_b = db ? p.partial_w + P * d->Cout * K : nullptr;
     dim3 grid((unsigned)P, (unsigned)((K + 255) / 256));
@@ -498,7 +518,7 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
         if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, 256, 0, s>>>(p);
     }
     const long R = (long)d->Cout * K;
-    reduce_partials_kernel<<<(unsigned)((R + 255) / 256), 256, 0, s>>>(p.partial_w, dw, (int)P, R, 0);
-    if (db) reduce_partials_kernel<<<1, 64, 0, s>>>(p.partial_b, db, (int)P, d->Cout, 0);
+    reduce_partials_kernel<<<(unsigned)((R + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, (int)P, R, 0);
+    if (db) reduce_partials_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, (int)P, d->Cout, 0);
     return hulc_check_launch("hulc_conv2d_bwd_weight");
 }

@@ -28,6 +28,7 @@ struct GemmP {
     int relu, accumulate;
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
+    const unsigned long long* seed_dev;   // optional device word xor-ed into drop_seed (graph-replay safe RNG stream)
 };
 
 // Load the 8-element k-chunk (row r, k0..k0+7) of an operand.
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
-                if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
+                if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed ^ (p.seed_dev ? p.seed_dev[0] : 0ull), (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
                 const long ci = (long)m * p.ldc + n;
                 if (p.accumulate) v += load_elem(p.C, p.c_dtype, ci);
                 store_elem(p.C, p.c_dtype, ci, v);
@@ -216,7 +217,7 @@ HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
     if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
     if (p.relu) v = fmaxf(v, 0.f);
     if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
-    if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
+    if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed ^ (p.seed_dev ? p.seed_dev[0] : 0ull), (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
     const long ci = (long)m * p.ldc + n;
     if (p.accumulate) v += load_elem(p.C, p.c_dtype, ci);
     return v;
@@ -364,6 +365,7 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     p.add_dtype = d->add_dtype; p.mask_dtype = d->mask_dtype;
     p.relu = d->relu; p.accumulate = d->accumulate;
     p.alpha = d->alpha; p.mask_scale = d->mask_scale; p.drop_p = d->drop_p; p.drop_seed = d->drop_seed;
+    p.seed_dev = d->seed_dev;
     hipStream_t s = (hipStream_t)stream;
     if (d->M <= 64) {
         if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);

@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256) void cat_kl_bwd_kernel(const float* __restrict
 
 // one-hot sample per group; idx_in (optional) injects the class indices (parity tests)
 __global__ __launch_bounds__(256) void plan_sample_kernel(const float* __restrict__ logits, const long* __restrict__ idx_in,
-                                                          unsigned long long seed, int NG, long* __restrict__ idx_out,
-                                                          float* __restrict__ plan) {
+                                                          unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int NG,
+                                                          long* __restrict__ idx_out, float* __restrict__ plan) {
     const int lane = threadIdx.x & 31;
+    if (seed_dev) seed ^= seed_dev[0];
     const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (g >= NG) return;
     int idx;
@@ -389,11 +390,11 @@ extern "C" int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl
     cat_kl_bwd_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, kl_group, B, G, beta, mix, gout, dpp, dpr);
     return hulc_check_launch("hulc_cat_kl_bwd");
 }
-extern "C" int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, int NG, int CLS, long* idx_out,
-                                    float* plan, void* stream) {
+extern "C" int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, const unsigned long long* seed_dev,
+                                    int NG, int CLS, long* idx_out, float* plan, void* stream) {
     if (!logits || !plan) return hulc_fail(-1, "hulc_plan_sample_fwd: null pointer");
     if (CLS != 32) return hulc_fail(-2, "hulc_plan_sample_fwd: class_size must be 32");
-    plan_sample_kernel<<<(NG + 7) / 8, 256, 0, (hipStream_t)stream>>>(logits, idx_in, seed, NG, idx_out, plan);
+    plan_sample_kernel<<<(NG + 7) / 8, 256, 0, (hipStream_t)stream>>>(logits, idx_in, seed, seed_dev, NG, idx_out, plan);
     return hulc_check_launch("hulc_plan_sample_fwd");
 }
 extern "C" int hulc_plan_sample_bwd(const float* logits, const float* dplan, int NG, int CLS, float* dlogits, int accumulate, void* stream) {

@@ -11,7 +11,13 @@ namespace {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
-                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                                                   const unsigned long long* __restrict__ step_state) {
+    if (step_state) {                       // bias corrections from the device-resident step count (graph replay)
+        const float t = (float)step_state[1];
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -46,6 +52,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+__global__ void step_state_advance_kernel(unsigned long long* state) {
+    state[0] = state[0] * 6364136223846793005ull + 1442695040888963407ull;   // 64-bit LCG walk of the RNG word
+    state[1] += 1ull;                                                           // optimizer step count
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n) {
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -59,15 +70,22 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int hulc_step_state_advance(unsigned long long* state, void* stream) {
+    if (!state) return hulc_fail(-1, "hulc_step_state_advance: null pointer");
+    step_state_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state);
+    return hulc_check_launch("hulc_step_state_advance");
+}
+
 extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                              float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, void* stream) {
     if (!p || !g || !m || !v) return hulc_fail(-1, "hulc_adam_step: null pointer");
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return hulc_fail(-4, "hulc_adam_step: arenas must be 16-byte aligned");
-    if (step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
+    if (!step_state && step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
+    if (step < 1) step = 1;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
-                                                                   bc1, bc2s, grad_scale);
+                                                                   bc1, bc2s, grad_scale, step_state);
     return hulc_check_launch("hulc_adam_step");
 }
 

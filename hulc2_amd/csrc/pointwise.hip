@@ -67,13 +67,15 @@ __global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const void* __
 //   pre = x + dropout(o)   (o optional)   y = (pre - mean) * rstd * gamma + beta
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ o, float drop_p,
-                                                            unsigned long long seed, const float* __restrict__ gamma,
+                                                            unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                            const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int R, int D,
                                                             float* __restrict__ pre_out, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
+    if (seed_dev) seed ^= seed_dev[0];
     float v[4];
     float s = 0.f;
 #pragma unroll
@@ -115,8 +117,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, int R, int D, int rows_per_block,
                                                             float* __restrict__ dpre, float* __restrict__ do_out, float drop_p,
-                                                            unsigned long long seed, float* __restrict__ partial) {
+                                                            unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                            float* __restrict__ partial) {
     __shared__ float red[4][2][256];
+    if (seed_dev) seed ^= seed_dev[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
     const int r0 = blockIdx.x * rows_per_block;
@@ -208,17 +212,21 @@ __global__ void seq_mean_bwd_kernel(const float* __restrict__ dy, float* __restr
 }
 // y[b][s][:] = dropout(x[b][s][:] + pos[pos_ids[s]][:])
 __global__ void add_pos_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, const long* __restrict__ pos_ids,
-                                   float* __restrict__ y, int B, int S, int D, float drop_p, unsigned long long seed) {
+                                   float* __restrict__ y, int B, int S, int D, float drop_p, unsigned long long seed,
+                                   const unsigned long long* __restrict__ seed_dev) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * D) return;
+    if (seed_dev) seed ^= seed_dev[0];
     const int d = (int)(i % D); const int s = (int)((i / D) % S);
     float v = x[i] + pos[pos_ids[s] * D + d];
     if (drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)i, drop_p);
     y[i] = v;
 }
-__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n, float drop_p, unsigned long long seed) {
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n, float drop_p, unsigned long long seed,
+                                   const unsigned long long* __restrict__ seed_dev) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (seed_dev) seed ^= seed_dev[0];
     dx[i] = dy[i] * dropout_scale(seed, (uint64_t)i, drop_p);
 }
 
@@ -235,8 +243,10 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const void* __rest
 // ------------------------------------------------------------------------------------------------
 #define ATT_DH 16
 __global__ __launch_bounds__(64) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ probs,
-                                                           int B, int S, int H, float scale, float drop_p, unsigned long long seed) {
+                                                           int B, int S, int H, float scale, float drop_p, unsigned long long seed,
+                                                           const unsigned long long* __restrict__ seed_dev) {
     __shared__ float q[32][ATT_DH + 1], k[32][ATT_DH + 1], v[32][ATT_DH + 1];
+    if (seed_dev) seed ^= seed_dev[0];
     const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x % H, E = H * ATT_DH;
     for (int idx = lane; idx < S * ATT_DH; idx += 64) {
         const int s = idx / ATT_DH, d = idx % ATT_DH;
@@ -293,8 +303,10 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(const float* __restri
 // kept, and dropped entries contribute no gradient (their dP' is multiplied by 0).
 __global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
                                                            const float* __restrict__ dout, float* __restrict__ dqkv, int B, int S, int H,
-                                                           float scale, float drop_p, unsigned long long seed) {
+                                                           float scale, float drop_p, unsigned long long seed,
+                                                           const unsigned long long* __restrict__ seed_dev) {
     __shared__ float q[32][ATT_DH + 1], k[32][ATT_DH + 1], v[32][ATT_DH + 1], go[32][ATT_DH + 1];
+    if (seed_dev) seed ^= seed_dev[0];
     __shared__ float ds[32][33], pp[32][33];
     const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x % H, E = H * ATT_DH;
     for (int idx = lane; idx < S * ATT_DH; idx += 64) {
@@ -412,13 +424,13 @@ extern "C" int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int H
     return hulc_check_launch("hulc_spatial_softmax_bwd");
 }
 
-extern "C" int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const float* gamma,
-                                  const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean, float* rstd,
-                                  void* stream) {
+extern "C" int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                  const float* gamma, const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean,
+                                  float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd) return hulc_fail(-1, "hulc_layernorm_fwd: null pointer");
     if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_fwd: D must be in 1..256");
     if (o && !pre_out) return hulc_fail(-3, "hulc_layernorm_fwd: pre_out required with a residual branch");
-    layernorm_fwd_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, o, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, rstd);
+    layernorm_fwd_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, o, drop_p, seed, seed_dev, gamma, beta, eps, R, D, pre_out, y, mean, rstd);
     return hulc_check_launch("hulc_layernorm_fwd");
 }
 
@@ -428,13 +440,13 @@ extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
 }
 
 extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R,
-                                  int D, float* dpre, float* do_out, float drop_p, unsigned long long seed, float* dgamma, float* dbeta,
-                                  void* ws, void* stream) {
+                                  int D, float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                  float* dgamma, float* dbeta, void* ws, void* stream) {
     if (!dy || !pre || !mean || !rstd || !gamma || !dpre || !dgamma || !dbeta || !ws) return hulc_fail(-1, "hulc_layernorm_bwd: null pointer");
     if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_bwd: D must be in 1..256");
     const int rpb = 32, nb = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
-    layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, (float*)ws);
+    layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, seed_dev, (float*)ws);
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
     reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, 0);
     reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, 0);
@@ -472,15 +484,16 @@ extern "C" int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D
     return hulc_check_launch("hulc_seq_mean_bwd");
 }
 extern "C" int hulc_add_pos_fwd(const float* x, const float* pos, const long* pos_ids, float* y, int B, int S, int D, float drop_p,
-                                unsigned long long seed, void* stream) {
+                                unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
     if (!x || !pos || !pos_ids || !y) return hulc_fail(-1, "hulc_add_pos_fwd: null pointer");
     const long n = (long)B * S * D;
-    add_pos_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pos, pos_ids, y, B, S, D, drop_p, seed);
+    add_pos_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pos, pos_ids, y, B, S, D, drop_p, seed, seed_dev);
     return hulc_check_launch("hulc_add_pos_fwd");
 }
-extern "C" int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, void* stream) {
+extern "C" int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                void* stream) {
     if (!dy || !dx) return hulc_fail(-1, "hulc_dropout_bwd: null pointer");
-    dropout_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, dx, n, drop_p, seed);
+    dropout_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, dx, n, drop_p, seed, seed_dev);
     return hulc_check_launch("hulc_dropout_bwd");
 }
 
@@ -491,16 +504,16 @@ extern "C" int hulc_relu_bwd(const float* dy, const void* y, int y_dtype, float*
 }
 
 extern "C" int hulc_attention_fwd(const float* qkv, float* out, float* probs, int B, int S, int H, int head_dim, float drop_p,
-                                  unsigned long long seed, void* stream) {
+                                  unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
     if (!qkv || !out || !probs) return hulc_fail(-1, "hulc_attention_fwd: null pointer");
     if (S > 32 || S <= 0 || head_dim != ATT_DH) return hulc_fail(-2, "hulc_attention_fwd: needs S <= 32 and head_dim == 16");
-    attention_fwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, out, probs, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed);
+    attention_fwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, out, probs, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed, seed_dev);
     return hulc_check_launch("hulc_attention_fwd");
 }
 extern "C" int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int B, int S, int H, int head_dim,
-                                  float drop_p, unsigned long long seed, void* stream) {
+                                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
     if (!qkv || !probs || !dout || !dqkv) return hulc_fail(-1, "hulc_attention_bwd: null pointer");
     if (S > 32 || S <= 0 || head_dim != ATT_DH) return hulc_fail(-2, "hulc_attention_bwd: needs S <= 32 and head_dim == 16");
-    attention_bwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, probs, dout, dqkv, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed);
+    attention_bwd_kernel<<<B * H, 64, 0, (hipStream_t)stream>>>(qkv, probs, dout, dqkv, B, S, H, 1.0f / sqrtf((float)head_dim), drop_p, seed, seed_dev);
     return hulc_check_launch("hulc_attention_bwd");
 }

@@ -93,6 +93,26 @@ def _p(t: Optional[torch.Tensor]):
 
 
 _scratch = {}
+_step_state = {}
+
+
+def step_state(device) -> torch.Tensor:
+    """Device-resident {rng word, optimizer step count} (two uint64 stored as int64).  Every RNG kernel xors word 0
+    into its site seed and the fused Adam reads word 1, so a captured hipGraph replays with fresh randomness and
+    the right bias correction; `advance_step_state` is the one-thread kernel that moves both forward."""
+    t = _step_state.get(device)
+    if t is None:
+        t = _step_state[device] = torch.tensor([0x243F6A8885A308D3 >> 1, 0], dtype=torch.int64, device=device)
+    return t
+
+
+def advance_step_state(device) -> None:
+    _call("hulc_step_state_advance", step_state(device))
+
+
+def reset_step_state(device, seed: int = 0x243F6A8885A308D3 >> 1, step: int = 0) -> None:
+    step_state(device).copy_(torch.tensor([seed, step], dtype=torch.int64))
+
 
 
 def _gemm_scratch(device) -> torch.Tensor:
@@ -125,6 +145,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
         raise TypeError("bias must be float32")
     ws = _gemm_scratch(C.device)      # split-K slabs (stream-ordered reuse of one scratch buffer)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    d.seed_dev = step_state(C.device).data_ptr() if drop_p > 0.0 else None
     with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor))):
         _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C
@@ -230,15 +251,20 @@ def spatial_softmax_bwd(x, N, HW, C, xmap, ymap, temperature, out, stats, dout, 
           _i(_dt(dx)), _i(relu_mask))
 
 
+def _sd(t, drop_p):
+    return step_state(t.device) if drop_p > 0.0 else None
+
+
 def layernorm_fwd(x, o, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, rstd):
-    _call("hulc_layernorm_fwd", x, o, _f(drop_p), _u64(seed), gamma, beta, _f(eps), _i(R), _i(D), pre_out, y, mean, rstd)
+    _call("hulc_layernorm_fwd", x, o, _f(drop_p), _u64(seed), _sd(x, drop_p), gamma, beta, _f(eps), _i(R), _i(D), pre_out, y, mean, rstd)
 
 
 def layernorm_bwd(dy, pre, mean, rstd, gamma, R, D, dpre, do_out, drop_p, seed, dgamma, dbeta):
     lib = _L.load()
     lib.hulc_layernorm_bwd_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_layernorm_bwd_workspace(_i(R), _i(D)), dy.device)
-    _call("hulc_layernorm_bwd", dy, pre, mean, rstd, gamma, _i(R), _i(D), dpre, do_out, _f(drop_p), _u64(seed), dgamma, dbeta, ws)
+    _call("hulc_layernorm_bwd", dy, pre, mean, rstd, gamma, _i(R), _i(D), dpre, do_out, _f(drop_p), _u64(seed), _sd(dy, drop_p), dgamma,
+          dbeta, ws)
 
 
 def colsum(x, M, N, ld, out, accumulate=False):
@@ -257,11 +283,11 @@ def seq_mean_bwd(dy, dx, B, S, D):
 
 
 def add_pos_fwd(x, pos, pos_ids, y, B, S, D, drop_p, seed):
-    _call("hulc_add_pos_fwd", x, pos, pos_ids, y, _i(B), _i(S), _i(D), _f(drop_p), _u64(seed))
+    _call("hulc_add_pos_fwd", x, pos, pos_ids, y, _i(B), _i(S), _i(D), _f(drop_p), _u64(seed), _sd(x, drop_p))
 
 
 def dropout_bwd(dy, dx, n, drop_p, seed):
-    _call("hulc_dropout_bwd", dy, dx, _l(n), _f(drop_p), _u64(seed))
+    _call("hulc_dropout_bwd", dy, dx, _l(n), _f(drop_p), _u64(seed), _sd(dy, drop_p))
 
 
 def relu_bwd(dy, y, dx, n, scale=1.0):
@@ -269,11 +295,11 @@ def relu_bwd(dy, y, dx, n, scale=1.0):
 
 
 def attention_fwd(qkv, out, probs, B, S, H, head_dim, drop_p, seed):
-    _call("hulc_attention_fwd", qkv, out, probs, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed))
+    _call("hulc_attention_fwd", qkv, out, probs, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed), _sd(qkv, drop_p))
 
 
 def attention_bwd(qkv, probs, dout, dqkv, B, S, H, head_dim, drop_p, seed):
-    _call("hulc_attention_bwd", qkv, probs, dout, dqkv, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed))
+    _call("hulc_attention_bwd", qkv, probs, dout, dqkv, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed), _sd(qkv, drop_p))
 
 
 def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
@@ -304,7 +330,8 @@ def cat_kl_bwd(pp, pr, kl_group, B, G, CLS, beta, mix, gout, dpp, dpr):
 
 
 def plan_sample_fwd(logits, idx_in, seed, NG, CLS, idx_out, plan):
-    _call("hulc_plan_sample_fwd", logits, idx_in, _u64(seed), _i(NG), _i(CLS), idx_out, plan)
+    _call("hulc_plan_sample_fwd", logits, idx_in, _u64(seed), step_state(logits.device) if idx_in is None else None, _i(NG), _i(CLS),
+          idx_out, plan)
 
 
 def plan_sample_bwd(logits, dplan, NG, CLS, dlogits, accumulate=False):
@@ -323,9 +350,10 @@ def world_to_tcp(act, robot_obs, n, obs_dim, out):
     _call("hulc_world_to_tcp", act, robot_obs, _i(n), _i(obs_dim), out)
 
 
-def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None):
+    """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device."""
     _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
-          _f(grad_scale))
+          step_state_dev, _f(grad_scale))
 
 
 def cast_f32_to_bf16(src, dst, n):

@@ -34,6 +34,7 @@ class GemmDesc(ctypes.Structure):
         ("drop_seed", ctypes.c_ulonglong),
         ("compute", ctypes.c_int),
         ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long),
+        ("seed_dev", ctypes.c_void_p),
     ]
 
 

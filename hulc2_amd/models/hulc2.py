@@ -55,7 +55,6 @@ class Hulc2(LightningModule):
         self.replan_freq = replan_freq
         self.latent_goal = None
         self.plan = None
-        self._sample_step = 0
 
     @staticmethod
     def setup_input_sizes(perceptual_encoder, plan_proposal, plan_recognition, visual_goal, action_decoder, distribution):
@@ -84,8 +83,8 @@ class Hulc2(LightningModule):
         """hulc2.py:200-245; returns the prior/posterior *states* in place of torch.distributions objects."""
         pp_state = self.plan_proposal(perceptual_emb[:, 0], latent_goal)
         pr_state, seq_feat = self.plan_recognition(perceptual_emb)
-        self._sample_step += 1
-        sampled_plan, _ = self.dist.rsample_plan(pr_state, seed=self._sample_step * 104729 + 3, idx=plan_idx)
+        site = 0xA11CE if "lang" in self.modality_scope else 0xB0B       # distinct RNG sites for the two modalities
+        sampled_plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=plan_idx)
         action_loss = self.action_decoder.loss(sampled_plan, perceptual_emb, latent_goal, train_acts, robot_obs)
         kl_loss = self.compute_kl_loss(pp_state, pr_state)
         return kl_loss, action_loss, action_loss + kl_loss, pp_state, pr_state, seq_feat

@@ -41,7 +41,6 @@ class PlanRecognitionTransformersNetwork(nn.Module):
         self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers, norm=None, enable_nested_tensor=False)
         self.fc = nn.Linear(in_features, fc_hidden_size)
         self.fc_state = self.dist.build_state(fc_hidden_size, plan_features)
-        self._step = 0
 
     def _layer_params(self, l: int) -> dict:
         m = self.transformer_encoder.layers[l]
@@ -55,8 +54,7 @@ class PlanRecognitionTransformersNetwork(nn.Module):
     def forward(self, perceptual_emb: torch.Tensor) -> Tuple[State, torch.Tensor]:
         B, S, E = perceptual_emb.shape
         p = self.dropout_p if self.training else 0.0
-        self._step += 1
-        seed = (self._step * 7919 + 17) & 0x7FFFFFFF
+        seed = 0x5EED0001           # site id; the per-step stream comes from the device step state (kernels.step_state)
         position_ids = torch.arange(S, dtype=torch.long, device=perceptual_emb.device)
         x = HF.AddPosFn.apply(perceptual_emb, self.position_embeddings.weight, position_ids, p, seed)
         x = x.reshape(B * S, E)

@@ -26,7 +26,7 @@ class GradBuckets:
     """Contiguous slices of the gradient arena reduced across ranks, overlapped with backward."""
 
     def __init__(self, params: List[torch.nn.Parameter], offsets: List[int], flat_grad: torch.Tensor, bucket_bytes: int,
-                 group=None):
+                 group=None, overlap: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flat_grad = flat_grad
@@ -52,7 +52,8 @@ class GradBuckets:
         for b in self.param_bucket.values():
             self.members[b] += 1
         self.handles = []
-        if self.world > 1:
+        self.overlap = overlap
+        if self.world > 1 and overlap:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
@@ -79,6 +80,9 @@ class GradBuckets:
 
     def finish(self):
         """Flush buckets whose parameters produced no gradient this step, then join the comm stream."""
+        if self.world > 1 and not self.overlap:       # graph mode: one in-place all-reduce of the whole arena, same stream
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            return
         if self.world > 1:
             for b in self.buckets:
                 if b["pending"] > 0:
@@ -93,7 +97,7 @@ class GradBuckets:
 
 class ArenaTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 bucket_mb: int = 32, group=None):
+                 bucket_mb: int = 32, group=None, overlap: bool = True):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -119,8 +123,11 @@ class ArenaTrainer:
         if self.flat_bf16 is not None:
             kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, total)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group)
+        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
         self.step_count = 0
+        self.dev = dev
+        self.graph_fb = self.graph_opt = None
+        self.static_loss = None
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -131,14 +138,44 @@ class ArenaTrainer:
     def optimizer_step(self):
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
-                     self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world)
+                     self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,
+                     step_state_dev=kn.step_state(self.dev))      # step count lives on the device (graph replay)
         shadow.bump_epoch()
 
-    def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        """zero grads -> training_step -> backward (+ overlapped all-reduce) -> fused Adam.  Returns the detached loss."""
+    def _forward_backward(self, batch, batch_idx: int) -> torch.Tensor:
+        shadow.bump_epoch()                    # every repack/shadow is re-made inside this step (and inside a capture)
+        kn.advance_step_state(self.dev)        # fresh dropout / plan-sample stream, step count + 1
         self.zero_grad()
         loss = self.model.training_step(batch, batch_idx)
         loss.backward()
+        return loss.detach()
+
+    def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        """zero grads -> training_step -> backward (+ overlapped all-reduce) -> fused Adam.  Returns the detached loss."""
+        loss = self._forward_backward(batch, batch_idx)
         self.buckets.finish()
         self.optimizer_step()
-        return loss.detach()
+        return loss
+
+    # ---- hipGraph mode: the ~900 launches of a step are captured once and replayed ----------------------
+    def capture(self, batch) -> None:
+        """Capture forward+backward and the optimizer as two HIP graphs over the (static, device-resident) batch.
+        Between them the gradient arena is all-reduced eagerly when world > 1 (construct with overlap=False).
+        Call after a few eager warm-up steps (allocator pools, lazy scratch buffers and kernels are then live)."""
+        assert self.dev.type == "cuda"
+        if self.world > 1 and self.buckets.overlap:
+            raise RuntimeError("graph mode needs ArenaTrainer(overlap=False): bucket hooks cannot run inside a replayed graph")
+        torch.cuda.synchronize()
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self.static_loss = self._forward_backward(batch, 0)
+        self.graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+            self.optimizer_step()
+        torch.cuda.synchronize()
+
+    def replay(self) -> torch.Tensor:
+        self.graph_fb.replay()
+        self.buckets.finish()
+        self.graph_opt.replay()
+        return self.static_loss

@@ -46,7 +46,8 @@ typedef struct {
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
     int compute;
-    void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K path of skinny (M <= 64) problems */
+    void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K paths */
+    const unsigned long long* seed_dev;   /* optional device word xor-ed into drop_seed (see hulc_step_state_advance) */
 } hulc_gemm_desc;
 int hulc_gemm(const hulc_gemm_desc* d, void* stream);
 
@@ -88,12 +89,13 @@ int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int HW, int C, c
  * Replaces nn.LayerNorm (vision_network.py:53, goal_encoders.py:28,61) and the residual+norm of the
  * post-norm nn.TransformerEncoderLayer (plan_recognition_net.py:115-117).  bwd: dpre = grad of the LN
  * input, do_out (optional) = dpre * dropout mask (grad of o), dgamma/dbeta summed deterministically. */
-int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const float* gamma,
-                       const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean, float* rstd, void* stream);
+int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                       const float* gamma, const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean,
+                       float* rstd, void* stream);
 long hulc_layernorm_bwd_workspace(int R, int D);
 int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
-                       float* dpre, float* do_out, float drop_p, unsigned long long seed, float* dgamma, float* dbeta, void* ws,
-                       void* stream);
+                       float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                       float* dgamma, float* dbeta, void* ws, void* stream);
 /* out[n] (+)= sum_m x[m*ld + n]: bias gradients of nn.Linear / position-embedding gradient. */
 long hulc_colsum_workspace(long M, int N);
 int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream);
@@ -103,16 +105,17 @@ int hulc_seq_mean_fwd(const float* x, float* y, int B, int S, int D, float scale
 int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D, void* stream);
 /* y = dropout(x[B][S][D] + pos[pos_ids[s]][:]) (plan_recognition_net.py:133-136,142); dropout_bwd: dx = dy * mask. */
 int hulc_add_pos_fwd(const float* x, const float* pos, const long* pos_ids, float* y, int B, int S, int D, float drop_p,
-                     unsigned long long seed, void* stream);
-int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, void* stream);
+                     unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+int hulc_dropout_bwd(const float* dy, float* dx, long n, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                     void* stream);
 /* dx = dy * (y > 0) * scale: gradient through ReLU (+ inverted dropout) from the saved activation. */
 int hulc_relu_bwd(const float* dy, const void* y, int y_dtype, float* dx, long n, float scale, void* stream);
 /* Multi-head self-attention for S <= 32, head_dim 16: qkv[B*S][3E] (token b*S+s; q|k|v), out[B*S][E],
  * probs[B][H][S][S] (post-dropout).  Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer. */
 int hulc_attention_fwd(const float* qkv, float* out, float* probs, int B, int S, int H, int head_dim, float drop_p,
-                       unsigned long long seed, void* stream);
+                       unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int B, int S, int H, int head_dim,
-                       float drop_p, unsigned long long seed, void* stream);
+                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* Discretised logistic mixture NLL + gripper cross-entropy over y[T][ld] = [logit_probs(A*n_mix) |
@@ -133,8 +136,8 @@ int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int
                     const float* gout, float* dpp, float* dpr, void* stream);
 /* Straight-through one-hot sample of each of NG categorical groups (distributions.py:23-27, hulc2.py:235-237):
  * plan = one_hot(idx); idx from idx_in (injected) or inverse-CDF sampling with the counter RNG. */
-int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, int NG, int CLS, long* idx_out,
-                         float* plan, void* stream);
+int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, const unsigned long long* seed_dev,
+                         int NG, int CLS, long* idx_out, float* plan, void* stream);
 int hulc_plan_sample_bwd(const float* logits, const float* dplan, int NG, int CLS, float* dlogits, int accumulate, void* stream);
 /* CLIP-style symmetric contrastive loss on projected features im/tx [M][32] restricted to rows with
  * use[m] != 0 (hulc2.py:472-508); dscale = d loss / d logit_scale. */
@@ -150,7 +153,12 @@ int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_d
 /* torch.optim.Adam semantics (hulc2.py:185-198, conf/model/optimizer/adam.yaml) over a flat fp32 arena;
  * bf16_shadow (optional) receives the updated weights rounded to bf16 for the MFMA kernels. */
 int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+                   float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, void* stream);
+/* Device-resident step state {rng word, optimizer step count}: advanced by one kernel per training step so that
+ * a captured hipGraph replays with fresh dropout masks / plan samples and the right Adam bias correction.
+ * RNG kernels xor state[0] into their site seed (seed_dev = state); hulc_adam_step reads state[1] when
+ * step_state != NULL (the `step` argument is then ignored). */
+int hulc_step_state_advance(unsigned long long* state, void* stream);
 int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 
 #ifdef __cplusplus
