@@ -291,7 +291,8 @@ template <typename CT>
 void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
     const int colblocks = (p.N + 31) / 32;
     const bool big = p.M <= 32 && p.K >= 1024;                  // 16 waves x TM=1: 66 KB of LDS for the reduction
-    const int nw = big ? 16 : 4;
+    const bool big2 = !big && p.K >= 1024;                       // 33..64 rows: 8 waves x TM=2, same LDS footprint
+    const int nw = big ? 16 : (big2 ? 8 : 4);
     int splitk = 1;
     while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= 64) splitk *= 2;
     while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
@@ -302,6 +303,9 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     if (big) {
         if (ak && bk) HULC_SK(1, true, true, 16); else if (ak && !bk) HULC_SK(1, true, false, 16);
         else if (!ak && !bk) HULC_SK(1, false, false, 16); else HULC_SK(1, false, true, 16);
+    } else if (big2) {
+        if (ak && bk) HULC_SK(2, true, true, 8); else if (ak && !bk) HULC_SK(2, true, false, 8);
+        else if (!ak && !bk) HULC_SK(2, false, false, 8); else HULC_SK(2, false, true, 8);
     } else if (p.M <= 32) {
         if (ak && bk) HULC_SK(1, true, true, 4); else if (ak && !bk) HULC_SK(1, true, false, 4);
         else if (!ak && !bk) HULC_SK(1, false, false, 4); else HULC_SK(1, false, true, 4);

@@ -106,32 +106,47 @@ HULC_DEVICE float mix_nll(const MixP& p, int t, int d, float gscale, float* dy_r
     return -lse;
 }
 
-// single workgroup: out[0] = total, out[1] = mixture NLL mean, out[2] = gripper CE mean
-__global__ __launch_bounds__(1024) void mix_loss_fwd_kernel(MixP p, float* __restrict__ out) {
+// Tokens are split into `nseg` equal segments (one per modality when both are batched through the decoder); every
+// segment gets its own mean.  Pass 1: one (token, dim) item per thread, per-workgroup (nll, ce) partials; a workgroup
+// never straddles a segment (items per segment are padded to the workgroup size).  Pass 2: one workgroup per segment
+// adds the partials in a fixed order.  out[seg] = {total, nll_mean, ce_mean}.
+__global__ __launch_bounds__(256) void mix_loss_partial_kernel(MixP p, int seg_tokens, int blocks_per_seg, float* __restrict__ partial) {
     __shared__ float sh[16];
+    const int seg = blockIdx.x / blocks_per_seg, bl = blockIdx.x % blocks_per_seg;
+    const int w = bl * 256 + threadIdx.x;                  // item inside the segment
     float nll = 0.f, ce = 0.f;
-    for (int w = threadIdx.x; w < p.T * (p.A + 1); w += blockDim.x) {
-        const int t = w / (p.A + 1), d = w % (p.A + 1);
-        if (d < p.A) nll += mix_nll<false>(p, t, d, 0.f, nullptr);
+    if (w < seg_tokens * (p.A + 1)) {
+        const int t = seg * seg_tokens + w / (p.A + 1), d = w % (p.A + 1);
+        if (d < p.A) nll = mix_nll<false>(p, t, d, 0.f, nullptr);
         else {
             const float* g = p.y + (long)t * p.ld + 3 * p.A * p.NM;
             const float a = p.act[(long)t * (p.A + 1) + p.A];
             const int lbl = (a == -1.f) ? 0 : (int)a;
             const float mx = fmaxf(g[0], g[1]);
-            const float l = mx + logf(expf(g[0] - mx) + expf(g[1] - mx));
-            ce += l - g[lbl];
+            ce = mx + logf(expf(g[0] - mx) + expf(g[1] - mx)) - g[lbl];
         }
     }
-    nll = block_sum(nll, sh) / p.T;
-    ce = block_sum(ce, sh) / p.T;
-    if (threadIdx.x == 0) { out[0] = nll + p.gripper_alpha * ce; out[1] = nll; out[2] = ce; }
+    nll = block_sum(nll, sh);
+    ce = block_sum(ce, sh);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = nll; partial[2 * blockIdx.x + 1] = ce; }
 }
 
-__global__ __launch_bounds__(256) void mix_loss_bwd_kernel(MixP p, const float* __restrict__ gout, float* __restrict__ dy, long ld_dy) {
+__global__ __launch_bounds__(64) void mix_loss_final_kernel(const float* __restrict__ partial, int blocks_per_seg, int seg_tokens,
+                                                            float gripper_alpha, float* __restrict__ out) {
+    const int seg = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    float nll = 0.f, ce = 0.f;
+    for (int b = 0; b < blocks_per_seg; ++b) { nll += partial[2 * (seg * blocks_per_seg + b)]; ce += partial[2 * (seg * blocks_per_seg + b) + 1]; }
+    nll /= seg_tokens; ce /= seg_tokens;
+    out[3 * seg] = nll + gripper_alpha * ce; out[3 * seg + 1] = nll; out[3 * seg + 2] = ce;
+}
+
+// gout[seg] scales segment seg's tokens
+__global__ __launch_bounds__(256) void mix_loss_bwd_kernel(MixP p, int seg_tokens, const float* __restrict__ gout, float* __restrict__ dy, long ld_dy) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= p.T * (p.A + 1)) return;
     const int t = w / (p.A + 1), d = w % (p.A + 1);
-    const float g = gout[0] / p.T;
+    const float g = gout[t / seg_tokens] / seg_tokens;
     float* drow = dy + (long)t * ld_dy;
     if (d < p.A) mix_nll<true>(p, t, d, g, drow);
     else {
@@ -362,18 +377,32 @@ MixP make_mix(const hulc_mix_desc* d, const float* y, const float* act) {
 
 }  // namespace
 
-extern "C" int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out3, void* stream) {
-    if (!d || !y || !act || !out3 || !d->act_min || !d->act_max) return hulc_fail(-1, "hulc_mix_loss_fwd: null pointer");
-    if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss_fwd: n_mix must be in 1..16");
-    mix_loss_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(make_mix(d, y, act), out3);
+static int mix_check(const hulc_mix_desc* d, const char* who) {
+    if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss: n_mix must be in 1..16");
+    if (d->nseg < 1 || d->T % d->nseg != 0) return hulc_fail(-3, "hulc_mix_loss: T must split into nseg equal segments");
+    (void)who;
+    return 0;
+}
+extern "C" long hulc_mix_loss_workspace(const hulc_mix_desc* d) {
+    if (!d || d->nseg < 1) return -1;
+    const int items = (d->T / d->nseg) * (d->A + 1);
+    return (long)d->nseg * ((items + 255) / 256) * 2 * (long)sizeof(float);
+}
+extern "C" int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out, void* ws, void* stream) {
+    if (!d || !y || !act || !out || !ws || !d->act_min || !d->act_max) return hulc_fail(-1, "hulc_mix_loss_fwd: null pointer");
+    int rc = mix_check(d, "fwd"); if (rc) return rc;
+    const int seg_tokens = d->T / d->nseg, bps = (seg_tokens * (d->A + 1) + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    mix_loss_partial_kernel<<<d->nseg * bps, 256, 0, s>>>(make_mix(d, y, act), seg_tokens, bps, (float*)ws);
+    mix_loss_final_kernel<<<d->nseg, 64, 0, s>>>((const float*)ws, bps, seg_tokens, d->gripper_alpha, out);
     return hulc_check_launch("hulc_mix_loss_fwd");
 }
 extern "C" int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const float* act, const float* gout, float* dy, long ld_dy,
                                  void* stream) {
     if (!d || !y || !act || !gout || !dy) return hulc_fail(-1, "hulc_mix_loss_bwd: null pointer");
-    if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss_bwd: n_mix must be in 1..16");
+    int rc = mix_check(d, "bwd"); if (rc) return rc;
     const int n = d->T * (d->A + 1);
-    mix_loss_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(make_mix(d, y, act), gout, dy, ld_dy);
+    mix_loss_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(make_mix(d, y, act), d->T / d->nseg, gout, dy, ld_dy);
     return hulc_check_launch("hulc_mix_loss_bwd");
 }
 

@@ -16,44 +16,61 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // spatial softmax, NHWC input [N][HW][C], C <= 64 (lane = channel)
 // ------------------------------------------------------------------------------------------------
+// One workgroup (4 waves) per frame, lane = channel; each wave walks a quarter of the HW positions and the four
+// (max, sum, sum*x, sum*y) partials are merged through LDS in a fixed order.
 __global__ __launch_bounds__(256) void spatial_softmax_fwd_kernel(const void* __restrict__ x, int x_dtype, int N, int HW, int C,
                                                                   const float* __restrict__ xmap, const float* __restrict__ ymap,
                                                                   const float* __restrict__ temperature, float* __restrict__ out,
                                                                   float* __restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N || lane >= C) return;
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const bool act = lane < C;
     const float invT = 1.0f / temperature[0];
     const long base = (long)n * HW * C + lane;
+    const int per = (HW + 3) / 4, p0 = wave * per, p1 = p0 + per < HW ? p0 + per : HW;
     float m = -INFINITY;
-    for (int p = 0; p < HW; ++p) m = fmaxf(m, load_elem(x, x_dtype, base + (long)p * C) * invT);
+    if (act)
+        for (int p = p0; p < p1; ++p) m = fmaxf(m, load_elem(x, x_dtype, base + (long)p * C) * invT);
+    red[wave][0][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0][lane], red[1][0][lane]), fmaxf(red[2][0][lane], red[3][0][lane]));
     float s = 0.f, sx = 0.f, sy = 0.f;
-    for (int p = 0; p < HW; ++p) {
-        const float e = __expf(load_elem(x, x_dtype, base + (long)p * C) * invT - m);
-        s += e; sx += e * xmap[p]; sy += e * ymap[p];
+    if (act)
+        for (int p = p0; p < p1; ++p) {
+            const float e = __expf(load_elem(x, x_dtype, base + (long)p * C) * invT - m);
+            s += e; sx += e * xmap[p]; sy += e * ymap[p];
+        }
+    red[wave][1][lane] = s; red[wave][2][lane] = sx; red[wave][3][lane] = sy;
+    __syncthreads();
+    if (wave == 0 && act) {
+        s = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+        sx = red[0][2][lane] + red[1][2][lane] + red[2][2][lane] + red[3][2][lane];
+        sy = red[0][3][lane] + red[1][3][lane] + red[2][3][lane] + red[3][3][lane];
+        const float inv = 1.0f / s;
+        out[(long)n * 2 * C + 2 * lane] = sx * inv;
+        out[(long)n * 2 * C + 2 * lane + 1] = sy * inv;
+        stats[((long)n * C + lane) * 2] = m;
+        stats[((long)n * C + lane) * 2 + 1] = s;
     }
-    const float inv = 1.0f / s;
-    out[(long)n * 2 * C + 2 * lane] = sx * inv;
-    out[(long)n * 2 * C + 2 * lane + 1] = sy * inv;
-    stats[((long)n * C + lane) * 2] = m;
-    stats[((long)n * C + lane) * 2 + 1] = s;
 }
 
-// dz[n][p][c] = (x > 0) * (1/T) * softmax_p * (gx*(xmap_p - ex) + gy*(ymap_p - ey))
+// dz[n][p][c] = (x > 0) * (1/T) * softmax_p * (gx*(xmap_p - ex) + gy*(ymap_p - ey)); 4 waves split the positions
 __global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const void* __restrict__ x, int x_dtype, int N, int HW, int C,
                                                                   const float* __restrict__ xmap, const float* __restrict__ ymap,
                                                                   const float* __restrict__ temperature, const float* __restrict__ out,
                                                                   const float* __restrict__ stats, const float* __restrict__ dout,
                                                                   void* __restrict__ dx, int dx_dtype, int relu_mask) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N || lane >= C) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    if (lane >= C) return;
     const float invT = 1.0f / temperature[0];
     const long base = (long)n * HW * C + lane;
     const float m = stats[((long)n * C + lane) * 2], inv = 1.0f / stats[((long)n * C + lane) * 2 + 1];
     const float ex = out[(long)n * 2 * C + 2 * lane], ey = out[(long)n * 2 * C + 2 * lane + 1];
     const float gx = dout[(long)n * 2 * C + 2 * lane], gy = dout[(long)n * 2 * C + 2 * lane + 1];
-    for (int p = 0; p < HW; ++p) {
+    const int per = (HW + 3) / 4, p0 = wave * per, p1 = p0 + per < HW ? p0 + per : HW;
+    for (int p = p0; p < p1; ++p) {
         const float xv = load_elem(x, x_dtype, base + (long)p * C);
         const float pr = __expf(xv * invT - m) * inv;
         float g = invT * pr * (gx * (xmap[p] - ex) + gy * (ymap[p] - ey));
@@ -410,7 +427,7 @@ extern "C" int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int H
                                         const float* temperature, float* out, float* stats, void* stream) {
     if (!x || !xmap || !ymap || !temperature || !out || !stats) return hulc_fail(-1, "hulc_spatial_softmax_fwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_fwd: C must be in 1..64 (lane = channel)");
-    spatial_softmax_fwd_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
+    spatial_softmax_fwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
     return hulc_check_launch("hulc_spatial_softmax_fwd");
 }
 
@@ -419,7 +436,7 @@ extern "C" int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int H
                                         void* dx, int dx_dtype, int relu_mask, void* stream) {
     if (!x || !out || !stats || !dout || !dx) return hulc_fail(-1, "hulc_spatial_softmax_bwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_bwd: C must be in 1..64");
-    spatial_softmax_bwd_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats,
+    spatial_softmax_bwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats,
                                                                              dout, dx, dx_dtype, relu_mask);
     return hulc_check_launch("hulc_spatial_softmax_bwd");
 }

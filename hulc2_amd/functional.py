@@ -416,25 +416,26 @@ class DecoderRNNFn(torch.autograd.Function):
 # losses
 # ------------------------------------------------------------------------------------------------
 class MixLossFn(torch.autograd.Function):
-    """y (T, 3*A*n_mix + 2) head outputs, actions (T, A+1) -> scalar NLL + alpha * gripper CE."""
+    """y (T, 3*A*n_mix + 2 [+pad]) head outputs, actions (T, A+1) -> (nseg,) losses NLL + alpha * gripper CE, each the
+    mean over its own T/nseg tokens (nseg = 1: the reference's single mean; nseg = 2: vis and lang batched together)."""
 
     @staticmethod
-    def forward(ctx, y, act, act_min, act_max, n_mix: int, num_classes: int, log_scale_min: float, gripper_alpha: float):
+    def forward(ctx, y, act, act_min, act_max, n_mix: int, num_classes: int, log_scale_min: float, gripper_alpha: float, nseg: int = 1):
         y, act = _c(y), _c(act)
         T, A = act.shape[0], act.shape[1] - 1
-        out3 = _f32(3, like=y)
+        out = _f32(nseg, 3, like=y)
         cfg = (T, A, n_mix, num_classes, y.stride(0), log_scale_min, gripper_alpha)
-        kn.mix_loss_fwd(y, act, out3, *cfg, act_min, act_max)
+        kn.mix_loss_fwd(y, act, out, *cfg, act_min, act_max, nseg=nseg)
         ctx.save_for_backward(y, act, act_min, act_max)
-        ctx.cfg = cfg
-        return out3[0]
+        ctx.cfg, ctx.nseg = cfg, nseg
+        return out[:, 0].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         y, act, act_min, act_max = ctx.saved_tensors
         dy = torch.zeros_like(y)           # pad columns (beyond 3*A*n_mix + 2) must carry zero gradient
-        kn.mix_loss_bwd(y, act, _c(g.reshape(1)), dy, dy.stride(0), *ctx.cfg, act_min, act_max)
-        return dy, None, None, None, None, None, None, None
+        kn.mix_loss_bwd(y, act, _c(g.reshape(ctx.nseg)), dy, dy.stride(0), *ctx.cfg, act_min, act_max, nseg=ctx.nseg)
+        return dy, None, None, None, None, None, None, None, None
 
 
 class CatKLFn(torch.autograd.Function):

@@ -302,22 +302,26 @@ def attention_bwd(qkv, probs, dout, dqkv, B, S, H, head_dim, drop_p, seed):
     _call("hulc_attention_bwd", qkv, probs, dout, dqkv, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed), _sd(qkv, drop_p))
 
 
-def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
+def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
     d = _L.MixDesc()
-    d.T, d.A, d.n_mix, d.num_classes, d.ld = T, A, n_mix, num_classes, ld
+    d.T, d.A, d.n_mix, d.num_classes, d.ld, d.nseg = T, A, n_mix, num_classes, ld, nseg
     d.log_scale_min, d.gripper_alpha = log_scale_min, gripper_alpha
     _require_cuda(act_min, act_max)
     d.act_min, d.act_max = act_min.data_ptr(), act_max.data_ptr()
     return d
 
 
-def mix_loss_fwd(y, act, out3, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
-    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max)
-    _call("hulc_mix_loss_fwd", _c.byref(d), y, act, out3)
+def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
+    """out: (nseg, 3) = {total, nll_mean, ce_mean} per segment of T / nseg tokens."""
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg)
+    lib = _L.load()
+    lib.hulc_mix_loss_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_mix_loss_workspace(_c.byref(d)), y.device)
+    _call("hulc_mix_loss_fwd", _c.byref(d), y, act, out, ws)
 
 
-def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max):
-    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max)
+def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg)
     _call("hulc_mix_loss_bwd", _c.byref(d), y, act, gout, dy, _l(ld_dy))
 
 

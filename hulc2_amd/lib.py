@@ -78,7 +78,7 @@ class ConvDesc(ctypes.Structure):
 
 class MixDesc(ctypes.Structure):
     _fields_ = [
-        ("T", ctypes.c_int), ("A", ctypes.c_int), ("n_mix", ctypes.c_int), ("num_classes", ctypes.c_int),
+        ("T", ctypes.c_int), ("A", ctypes.c_int), ("n_mix", ctypes.c_int), ("num_classes", ctypes.c_int), ("nseg", ctypes.c_int),
         ("ld", ctypes.c_long),
         ("log_scale_min", ctypes.c_float), ("gripper_alpha", ctypes.c_float),
         ("act_min", ctypes.c_void_p), ("act_max", ctypes.c_void_p),

@@ -98,11 +98,23 @@ class Hulc2(LightningModule):
         def acc(a, b):
             return b if a is None else a + b
 
+        # pass 1 — per modality: encoders, goal, prior/posterior, latent plan sample, KL (hulc2.py:380-386,228-237,242)
+        per = []
         for self.modality_scope, db in batch.items():
             emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
             latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
-            kl, act_loss, mod_loss, _, _, seq_feat = self.lmp_train(emb, latent_goal, db["actions"], db["state_info"]["robot_obs"],
-                                                                    db.get("plan_idx"))
+            pp_state = self.plan_proposal(emb[:, 0], latent_goal)
+            pr_state, seq_feat = self.plan_recognition(emb)
+            site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
+            plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
+            per.append((self.modality_scope, db, emb, latent_goal, seq_feat, plan, self.compute_kl_loss(pp_state, pr_state)))
+        # pass 2 — the action decoder sees all modalities at once (shared weights, independent sequences); it returns
+        # one loss per modality, each the mean over that modality's own tokens as in the reference (hulc2.py:239-241)
+        act_losses = self.action_decoder.loss_segments([p[5] for p in per], [p[2] for p in per], [p[3] for p in per],
+                                                       [p[1]["actions"] for p in per], [p[1]["state_info"]["robot_obs"] for p in per])
+        for i, (self.modality_scope, db, emb, latent_goal, seq_feat, plan, kl) in enumerate(per):
+            act_loss = act_losses[i]
+            mod_loss = act_loss + kl
             if "lang" in self.modality_scope:
                 batch_size["aux_lang"] = db["actions"].shape[0]
                 if self.use_clip_auxiliary_loss:

@@ -119,15 +119,18 @@ int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, 
 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* Discretised logistic mixture NLL + gripper cross-entropy over y[T][ld] = [logit_probs(A*n_mix) |
- * means | log_scales | gripper(2)] and act[T][A+1]; out3 = {total, nll_mean, ce_mean}.
+ * means | log_scales | gripper(2)] and act[T][A+1].  The T tokens form nseg equal segments (one per modality when
+ * both are batched through the decoder); out[seg] = {total, nll_mean, ce_mean} with means over the segment's tokens,
+ * gout[seg] is the upstream gradient of out[seg][0].
  * Replaces LogisticDecoderRNN._loss/_logistic_loss, logistic_decoder_rnn.py:133-152,181-228. */
 typedef struct {
-    int T, A, n_mix, num_classes;
+    int T, A, n_mix, num_classes, nseg;
     long ld;
     float log_scale_min, gripper_alpha;
     const float* act_min; const float* act_max;   /* device [A] */
 } hulc_mix_desc;
-int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out3, void* stream);
+long hulc_mix_loss_workspace(const hulc_mix_desc* d);
+int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out, void* ws, void* stream);
 int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const float* act, const float* gout, float* dy, long ld_dy, void* stream);
 /* KL-balanced categorical KL (hulc2.py:444-466): out[0] = beta * mean_b sum_g KL(post_g || prior_g);
  * bwd: dpp gets mix * d/d prior, dpr gets (1 - mix) * d/d posterior. pp/pr: [B][G*CLS], CLS == 32. */

@@ -219,6 +219,29 @@ def test_decoder(dev, model, mode, S):
     close(dec.gripper_fc.weight.grad, fx["g_grip_w"], t["grad"], "g gripper_fc")
 
 
+def test_decoder_segments_equal_separate_passes(dev, model, mode):
+    """both modalities through one recurrence == two separate decoder.loss calls (values and gradients)"""
+    zero(model)
+    g = torch.Generator().manual_seed(21)
+    B, S = 3, 8
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    plans = [torch.nn.functional.one_hot(torch.randint(0, 32, (B, 32), generator=g), 32).float().flatten(1).to(dev) for _ in range(2)]
+    embs, goals = [mk(B, S, 128) for _ in range(2)], [mk(B, 32) for _ in range(2)]
+    acts = [torch.cat([torch.rand(B, S, 6, generator=g) * 2 - 1, (torch.rand(B, S, 1, generator=g) < 0.5).float() * 2 - 1], -1).to(dev) for _ in range(2)]
+    obs = [mk(B, S, 15) for _ in range(2)]
+    dec = model.action_decoder
+    both = dec.loss_segments(plans, embs, goals, acts, obs)
+    (both[0] + 2.0 * both[1]).backward()
+    g_both = dec.rnn.weight_hh_l1.grad.clone()
+    zero(model)
+    l0, l1 = dec.loss(plans[0], embs[0], goals[0], acts[0], obs[0]), dec.loss(plans[1], embs[1], goals[1], acts[1], obs[1])
+    (l0 + 2.0 * l1).backward()
+    tol = 1e-5 if mode == "fp32" else 1e-4
+    close(both[0], l0.detach().cpu().numpy(), tol, "segment 0 loss")
+    close(both[1], l1.detach().cpu().numpy(), tol, "segment 1 loss")
+    close(g_both, dec.rnn.weight_hh_l1.grad.cpu().numpy(), 1e-3 if mode == "fp32" else 2e-2, "g whh1 (segments vs separate)")
+
+
 def test_logistic_mixture_edges(dev):
     """every branch of the torch.where ladder of _logistic_loss (logistic_decoder_rnn.py:206-225)"""
     from hulc2_amd import functional as HF
@@ -229,7 +252,7 @@ def test_logistic_mixture_edges(dev):
     y = torch.cat([lp, mu, ls, torch.tensor(fx["grip"]).reshape(T, 2), torch.zeros(T, 2)], 1).to(dev).requires_grad_()
     acts = torch.tensor(fx["acts"]).reshape(T, 7).to(dev)
     lo, hi = -torch.ones(6, device=dev), torch.ones(6, device=dev)
-    loss = HF.MixLossFn.apply(y, acts, lo, hi, 10, 10, -7.0, 1.0)
+    loss = HF.MixLossFn.apply(y, acts, lo, hi, 10, 10, -7.0, 1.0)[0]
     close(loss, fx["loss"], 2e-5, "loss")
     loss.backward()
     g = y.grad.cpu()
