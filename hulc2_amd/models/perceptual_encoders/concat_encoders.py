@@ -43,6 +43,6 @@ class ConcatEncoders(nn.Module):
             g = imgs["rgb_gripper"]
             b, s, c, h, w = g.shape
             enc = torch.cat([enc, self.rgb_gripper_encoder(g.reshape(-1, c, h, w)).reshape(b, s, -1)], dim=-1)
-        self.current_visual_embedding = enc
+        self.current_visual_embedding = enc.detach()   # detached: holding the graph across steps breaks HIP-graph capture
         self.current_state_obs = state_obs
         return enc

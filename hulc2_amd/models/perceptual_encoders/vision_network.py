@@ -35,8 +35,9 @@ class SpatialSoftmax(nn.Module):
         if isinstance(self.temperature, nn.Parameter) and self.temperature.requires_grad:
             raise NotImplementedError("learnable spatial-softmax temperature is not on the configured path "
                                       "(conf/model/perceptual_encoder/rgb_static/default.yaml: spatial_softmax_temp 1.0)")
-        self.coords = HF.spatial_softmax(a_nhwc, self.x_map, self.y_map, self.temperature)
-        return self.coords
+        out = HF.spatial_softmax(a_nhwc, self.x_map, self.y_map, self.temperature)
+        self.coords = out.detach()     # kept for visualisation like the reference; detached so no autograd graph outlives the step
+        return out
 
 
 class VisionNetwork(nn.Module):

@@ -165,12 +165,20 @@ class ArenaTrainer:
         assert self.dev.type == "cuda"
         if self.world > 1 and self.buckets.overlap:
             raise RuntimeError("graph mode needs ArenaTrainer(overlap=False): bucket hooks cannot run inside a replayed graph")
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # AccumulateGrad nodes must be born on the capture stream
+            for i in range(2):
+                self.step(batch, i)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
+        with torch.cuda.graph(self.graph_fb, stream=side):
             self.static_loss = self._forward_backward(batch, 0)
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), stream=side):
             self.optimizer_step()
         torch.cuda.synchronize()
 
