@@ -14,7 +14,7 @@ import torch
 from . import kernels as kn
 
 _cache: Dict[Tuple[int, Optional[str], int], Tuple[int, torch.Tensor, "weakref.ref"]] = {}
-_arena: Dict[int, torch.Tensor] = {}      # id(param) -> bf16 view into the trainer's shadow arena
+_arena: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}   # id(param) -> (weakref(param), bf16 view into the shadow arena)
 _epoch = 0                                # bumped by optimizers that update parameters through raw pointers
 
 
@@ -32,7 +32,8 @@ def bump_epoch() -> None:
 
 def register_arena_view(param: torch.Tensor, view_bf16: torch.Tensor) -> None:
     """The native trainer keeps one flat bf16 arena that the Adam kernel refreshes in place."""
-    _arena[id(param)] = view_bf16
+    key = id(param)
+    _arena[key] = (weakref.ref(param, lambda _r, k=key: _arena.pop(k, None)), view_bf16)
 
 
 def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
@@ -58,8 +59,10 @@ def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tenso
     if not bf16:
         if layout in (None, "oihw_flat"):
             return _layout(base, layout) if layout else base
-    elif layout is None and id(w) in _arena:
-        return _arena[id(w)]
+    elif layout is None:
+        hit = _arena.get(id(w))
+        if hit is not None and hit[0]() is w:       # ids are recycled: trust the entry only for the very same tensor object
+            return hit[1]
     key = (id(w), layout, int(bf16))
     ver = (w._version, _epoch)
     hit = _cache.get(key)
