@@ -16,6 +16,7 @@
 // while staged (global -> registers -> LDS, double-buffered, next tile's loads in flight during MFMA).
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -294,7 +295,10 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     const bool big2 = !big && p.K >= 1024;                       // 33..64 rows: 8 waves x TM=2, same LDS footprint
     const int nw = big ? 16 : (big2 ? 8 : 4);
     int splitk = 1;
-    while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= 64) splitk *= 2;
+    const char* force = getenv("HULC_SKINNY_SPLITK");           // tuning knob for A/B runs
+    const int min_kw = 64;   // measured (tools/rnn_bench.py): more, shorter K slices win even with the extra epilogue launch
+    while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= min_kw) splitk *= 2;
+    if (force) splitk = atoi(force);
     while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
     int kw = (p.K + splitk * nw - 1) / (splitk * nw);
     kw = (kw + 15) / 16 * 16;
