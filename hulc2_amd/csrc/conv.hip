@@ -349,164 +349,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// bf16 weight gradient, v3 staging: a thread owns an (8 pixels x 8 k) block, transposes it in registers with
-// v_perm_b32 (32 perms for 64 elements) and writes eight 16-byte LDS rows — 4x fewer LDS write instructions
-// than the pixel-pair path and no fp32 round trip for bf16 sources.
-// ------------------------------------------------------------------------------------------------
-HULC_DEVICE uint4 load_chunk_bf16_bits(const void* base, int dtype, long off) {
-    if (dtype == HULC_BF16) return *(const uint4*)((const uint16_t*)base + off);
-    const float4* p = (const float4*)((const float*)base + off);
-    const float4 a = p[0], b = p[1];
-    uint4 r;
-    r.x = pack_bf16x2(a.x, a.y); r.y = pack_bf16x2(a.z, a.w); r.z = pack_bf16x2(b.x, b.y); r.w = pack_bf16x2(b.z, b.w);
-    return r;
-}
-HULC_DEVICE uint4 gather_chunk_bf16_bits(const GatherP& p, long pix_base, int iy0, int ix0, int k0, int K) {
-    if (k0 >= K) return make_uint4(0, 0, 0, 0);
-    const int t = k0 >> p.inner_log2, j = k0 & ((1 << p.inner_log2) - 1);
-    if (p.check_bounds) {
-        const int iy = iy0 + p.tap_dy[t], ix = ix0 + p.tap_dx[t];
-        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) return make_uint4(0, 0, 0, 0);
-    }
-    return load_chunk_bf16_bits(p.X, p.x_dtype, pix_base + p.tap_off[t] + j);
-}
-// v[i] = 8 bf16 (k..k+7) of pixel i  ->  LDS rows row0+j (one per k) each receiving the 8 pixels as 16 bytes
-HULC_DEVICE void store_octet_transposed(char* tile, int row0, int col_byte, const uint4 (&v)[8]) {
-    const uint32_t w[8][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w}, {v[2].x, v[2].y, v[2].z, v[2].w},
-                              {v[3].x, v[3].y, v[3].z, v[3].w}, {v[4].x, v[4].y, v[4].z, v[4].w}, {v[5].x, v[5].y, v[5].z, v[5].w},
-                              {v[6].x, v[6].y, v[6].z, v[6].w}, {v[7].x, v[7].y, v[7].z, v[7].w}};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-        uint4 o;
-        o.x = __builtin_amdgcn_perm(w[1][j >> 1], w[0][j >> 1], sel);
-        o.y = __builtin_amdgcn_perm(w[3][j >> 1], w[2][j >> 1], sel);
-        o.z = __builtin_amdgcn_perm(w[5][j >> 1], w[4][j >> 1], sel);
-        o.w = __builtin_amdgcn_perm(w[7][j >> 1], w[6][j >> 1], sel);
-        *(uint4*)(tile + (row0 + j) * HULC_ROWB + col_byte) = o;
-    }
-}
-
-template <int TMC, int TNW>
-__global__ __launch_bounds__(256) void conv_wgrad_oct_kernel(WgradP p) {
-    constexpr int KT = 32, CO = TMC * 32, KS = 128 * TNW;
-    constexpr int X_ITEMS = 4 * (KS / 8), DY_ITEMS = 4 * (CO / 8);      // (octet, chunk) blocks per reduction tile
-    static_assert(X_ITEMS + DY_ITEMS <= 256 || X_ITEMS == 256, "items must fit the workgroup");
-    constexpr bool SPLIT = X_ITEMS + DY_ITEMS <= 256;                    // X and dY items on different threads
-    __shared__ __attribute__((aligned(16))) char smem[2 * (CO + KS) * HULC_ROWB];
-    __shared__ float bpart[DY_ITEMS][8];
-
-    const GatherP& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long Mtot = (long)g.Nimg * g.OH * g.OW;
-    const long mb = (long)blockIdx.x * p.pix_per_block;
-    long me = mb + p.pix_per_block; if (me > Mtot) me = Mtot;
-    const int K = g.ntaps << g.inner_log2;
-    const int ks0 = blockIdx.y * KS;
-    const int ntile = (int)((me - mb + KT - 1) / KT);
-
-    f32x16_t acc[TMC][TNW];
-#pragma unroll
-    for (int i = 0; i < TMC; ++i)
-#pragma unroll
-        for (int j = 0; j < TNW; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float bacc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bacc[j] = 0.f;
-
-    const bool has_x = tid < X_ITEMS;
-    const int dy_id = SPLIT ? tid - X_ITEMS : tid;
-    const bool has_dy = dy_id >= 0 && dy_id < DY_ITEMS;
-    const int x_o = tid & 3, x_ch = tid >> 2, dy_o = dy_id & 3, dy_ch = dy_id >> 2;
-    PixIter xit, dyit;
-    { long m = mb + 8 * x_o; xit.init(m < Mtot ? m : Mtot - 1, g.OH, g.OW); }
-    { long m = mb + 8 * (has_dy ? dy_o : 0); dyit.init(m < Mtot ? m : Mtot - 1, g.OH, g.OW); }
-
-    uint4 xv[8], dv[8];
-    auto load_tiles = [&](int t) {
-        const long mt = mb + (long)t * KT;
-        if (has_x) {
-            PixIter it = xit;
-            const int k0 = ks0 + x_ch * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long m = mt + 8 * x_o + i;
-                if (m < me) {
-                    const int iy0 = it.oy * g.stride, ix0 = it.ox * g.stride;
-                    xv[i] = gather_chunk_bf16_bits(g, (long)it.n * g.x_sn + (long)iy0 * g.x_sy + (long)ix0 * g.x_sx, iy0, ix0, k0, K);
-                } else xv[i] = make_uint4(0, 0, 0, 0);
-                it.advance(1, g.OH, g.OW);
-            }
-            xit.advance(KT, g.OH, g.OW);
-        }
-        if (has_dy) {
-            PixIter it = dyit;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long m = mt + 8 * dy_o + i;
-                if (m < me) dv[i] = load_chunk_bf16_bits(p.dY, p.dy_dtype, (long)it.n * p.dy_sn + (long)it.oy * p.dy_sy + (long)it.ox * p.dy_sx + dy_ch * 8);
-                else dv[i] = make_uint4(0, 0, 0, 0);
-                it.advance(1, g.OH, g.OW);
-            }
-            dyit.advance(KT, g.OH, g.OW);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* As = smem + buf * (CO + KS) * HULC_ROWB;
-        char* Bs = As + CO * HULC_ROWB;
-        if (has_x) store_octet_transposed(Bs, x_ch * 8, x_o * 16, xv);
-        if (has_dy) {
-            store_octet_transposed(As, dy_ch * 8, dy_o * 16, dv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bacc[0] += __uint_as_float(dv[i].x << 16); bacc[1] += __uint_as_float(dv[i].x & 0xffff0000u);
-                bacc[2] += __uint_as_float(dv[i].y << 16); bacc[3] += __uint_as_float(dv[i].y & 0xffff0000u);
-                bacc[4] += __uint_as_float(dv[i].z << 16); bacc[5] += __uint_as_float(dv[i].z & 0xffff0000u);
-                bacc[6] += __uint_as_float(dv[i].w << 16); bacc[7] += __uint_as_float(dv[i].w & 0xffff0000u);
-            }
-        }
-    };
-
-    if (ntile > 0) { load_tiles(0); store_tiles(0); }
-    __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntile) load_tiles(t + 1);
-        const char* As = smem + buf * (CO + KS) * HULC_ROWB;
-        const char* Bs = As + CO * HULC_ROWB;
-        MmaTile<bf16_t, TMC, TNW>::run(As, Bs + wave * TNW * 32 * HULC_ROWB, acc, lane);
-        if (t + 1 < ntile) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    float* pw = p.partial_w + (long)blockIdx.x * CO * K;
-#pragma unroll
-    for (int j = 0; j < TNW; ++j) {
-        const int k = ks0 + (wave * TNW + j) * 32 + (lane & 31);
-        if (k < K) {
-#pragma unroll
-            for (int i = 0; i < TMC; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pw[(long)(i * 32 + acc_row(e, lane)) * K + k] = acc[i][j][e];
-        }
-    }
-    if (p.partial_b && blockIdx.y == 0) {
-        if (has_dy) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bpart[dy_id][j] = bacc[j];
-        }
-        __syncthreads();
-        if (tid < CO) {
-            float sacc = 0.f;
-            for (int o = 0; o < 4; ++o) sacc += bpart[(tid / 8) * 4 + o][tid % 8];
-            p.partial_b[(long)blockIdx.x * CO + tid] = sacc;
-        }
-    }
-}
-
 // out[r] = sum_p partial[p][r]: workgroup = 64 outputs x 16 P-slices (fixed slice boundaries and a fixed
 // combine order -> deterministic), so the P-long loop is 16x shorter and the grid is R/64 workgroups of 1024.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate) {
@@ -672,10 +514,8 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
     if (d->compute == HULC_F32) {
         if (d->y_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_weight: f32 compute requires f32 operands");
         if (d->Cout == 32) conv_wgrad_kernel<float, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<float, 2, 2><<<grid, 256, 0, s>>>(p);
-    } else if (getenv("HULC_WGRAD_V2")) {      // previous pixel-pair staging, kept for A/B runs (tools/wgrad_bench.py)
-        if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, 256, 0, s>>>(p);
     } else {
-        if (d->Cout == 32) conv_wgrad_oct_kernel<1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_oct_kernel<2, 2><<<grid, 256, 0, s>>>(p);
+        if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, 256, 0, s>>>(p);
     }
     const long R = (long)d->Cout * K;
     reduce_partials_kernel<<<(unsigned)((R + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, (int)P, R, 0);

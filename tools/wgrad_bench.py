@@ -9,13 +9,12 @@ for name,N,H,W,Cin,Cout,K,s,nchw in L:
     x = torch.randn(N,Cin,H,W,device=dev) if nchw else torch.randn(N,H,W,Cin,device=dev).to(torch.bfloat16)
     dy = torch.randn(N,OH,OW,Cout,device=dev).to(torch.bfloat16)
     dw = torch.empty(Cout,Cin*K*K,device=dev); db = torch.empty(Cout,device=dev)
-    for pf in ("v2","v3"):
-        if pf == "v2": os.environ["HULC_WGRAD_V2"] = "1"
-        else: os.environ.pop("HULC_WGRAD_V2", None)
+    for pf in ("0","1"):
+        os.environ["HULC_WGRAD_PAIR_FASTEST"] = pf
         for _ in range(2): kn.conv2d_bwd_weight(x,dy,dw,db,N,H,W,Cin,Cout,K,K,s,nchw)
         torch.cuda.synchronize()
         e0,e1 = torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): kn.conv2d_bwd_weight(x,dy,dw,db,N,H,W,Cin,Cout,K,K,s,nchw)
         e1.record(); torch.cuda.synchronize()
-        print(f"{name:8s} {pf}  {e0.elapsed_time(e1)/5:.3f} ms")
+        print(f"{name:8s} pair_fastest={pf}  {e0.elapsed_time(e1)/5:.3f} ms")
