@@ -315,101 +315,108 @@ def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: fl
 # reference: logistic_decoder_rnn.py:257-270 + decoders/utils/rnn.py:5-14
 # ------------------------------------------------------------------------------------------------
 class DecoderRNNFn(torch.autograd.Function):
-    """The input projection of layer 0 is split by linearity: the plan and goal columns of W_ih are applied
-    once per sequence (they are constant over time), only the 64 per-timestep embedding columns are applied
-    per token.  Same sums, different association; parity is checked at fp32 tolerance."""
+    """2-layer ReLU RNN over x_t = [plan | emb_t[lo:hi] | goal], h_{-1} = 0  ->  h1 (B, S, H).
+
+    Restructured for a latency-bound recurrence on 256 CUs (same sums, different association; fp32-parity-checked):
+      * layer 0's input projection is split by linearity: plan/goal columns of W_ih0 once per sequence, the embedding
+        columns per token (one batched GEMM);
+      * layer 1's input projection is fused into its recurrent GEMM: h1_t = relu([h0_t | h1_{t-1}] [W_ih1 | W_hh1]^T + b)
+        (K = 2H), so layer 1 needs nothing but h0_t — the two layers then run as a WAVEFRONT on two HIP streams
+        (layer 1 step t next to layer 0 step t+1): 33 dependent stages instead of 64;
+      * activations are time-major (S, B, .) so each step's rows are contiguous; zbuf[t+1] = [h0_t | h1_{t-1}].
+    Backward mirrors it: delta0_t = ([delta1_t | delta0_{t+1}] [W_ih1^T | W_hh0^T]^T) * (h0_t > 0), again a wavefront.
+    """
 
     @staticmethod
     def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
         B, S, _ = emb.shape
         Hd = w_hh0.shape[0]
         P, G, E = plan.shape[1], goal.shape[1], hi - lo
-        plan, emb, goal = _c(plan), _c(emb), _c(goal)
-        dev = emb
-        wih0 = weight_operand(w_ih0)
+        plan, goal = _c(plan), _c(goal)
+        dev = emb.device
         Kin = w_ih0.shape[1]
-        # per-sequence constant part c = plan Wp^T + goal Wg^T + b_ih (b_hh is added in the recurrent step)
-        c = _f32(B, Hd, like=dev)
+        wih0 = weight_operand(w_ih0)
+        # per-sequence constant part c = plan Wp^T + goal Wg^T + b_ih0 (b_hh0 is added in the recurrent step)
+        c = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         kn.gemm(plan, wih0, c, B, Hd, P, P, Kin, Hd, bias=b_ih0)
         kn.gemm(goal, wih0[:, P + E:], c, B, Hd, G, G, Kin, Hd, accumulate=True)
-        pre0 = c.unsqueeze(1).expand(B, S, Hd).contiguous()
-        emb_s = emb[:, :, lo:hi]
-        kn.gemm(emb_s, wih0[:, P:P + E], pre0, B * S, Hd, E, emb.shape[2], Kin, Hd, accumulate=True)
-        zeros = torch.zeros(B, Hd, dtype=torch.float32, device=emb.device)
-        h0 = _f32(B, S, Hd, like=dev)
+        emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
+        pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
+        kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
+        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=torch.float32, device=dev)     # zbuf[t+1] = [h0_t | h1_{t-1}]
         whh0 = weight_operand(w_hh0)
+        w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
+        s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
+        s1.wait_stream(s0)
         for t in range(S):
-            prev = zeros if t == 0 else h0[:, t - 1]
-            kn.gemm(prev, whh0, h0[:, t], B, Hd, Hd, Hd if t == 0 else S * Hd, Hd, S * Hd, bias=b_hh0, add=pre0[:, t],
-                    ld_add=S * Hd, relu=True)
-        pre1 = _f32(B, S, Hd, like=dev)
-        kn.gemm(h0, weight_operand(w_ih1), pre1, B * S, Hd, Hd, Hd, Hd, Hd, bias=b_ih1)
-        h1 = _f32(B, S, Hd, like=dev)
-        whh1 = weight_operand(w_hh1)
-        for t in range(S):
-            prev = zeros if t == 0 else h1[:, t - 1]
-            kn.gemm(prev, whh1, h1[:, t], B, Hd, Hd, Hd if t == 0 else S * Hd, Hd, S * Hd, bias=b_hh1, add=pre1[:, t],
-                    ld_add=S * Hd, relu=True)
-        ctx.save_for_backward(plan, emb, goal, h0, h1, w_ih0, w_hh0, w_ih1, w_hh1)
-        ctx.meta = (B, S, Hd, P, G, E, lo, hi)
+            kn.gemm(zbuf[t][:, :Hd], whh0, zbuf[t + 1][:, :Hd], B, Hd, Hd, 2 * Hd, Hd, 2 * Hd, bias=b_hh0, add=pre0[t], ld_add=Hd, relu=True)
+            ev = torch.cuda.Event()
+            ev.record(s0)
+            with torch.cuda.stream(s1):
+                s1.wait_event(ev)
+                kn.gemm(zbuf[t + 1], w1cat, zbuf[t + 2][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, bias=b_ih1, add=b_hh1, ld_add=0,
+                        relu=True)
+        s0.wait_stream(s1)
+        h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()                  # (B, S, H) for the heads
+        ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
+        ctx.meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
         return h1
 
     @staticmethod
-    def _bptt(dH, h, w_hh, B, S, Hd):
-        """delta_t = (dH_t + delta_{t+1} W_hh) * (h_t > 0), t = S-1..0."""
-        delta = torch.empty_like(dH)
-        whh_t = weight_operand(w_hh, "t")           # [k][n] -> rows = output index of dX: k-major panel for the skinny GEMM
-        last = torch.empty(B, Hd, dtype=torch.float32, device=dH.device)
-        kn.relu_bwd(_c(dH[:, S - 1]), _c(h[:, S - 1]), last, B * Hd)
-        delta[:, S - 1] = last
-        for t in range(S - 2, -1, -1):
-            kn.gemm(delta[:, t + 1], whh_t, delta[:, t], B, Hd, Hd, S * Hd, Hd, S * Hd, add=dH[:, t], ld_add=S * Hd,
-                    mask=h[:, t], ld_mask=S * Hd)
-        return delta
-
-    @staticmethod
     def backward(ctx, dH1):
-        plan, emb, goal, h0, h1, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
-        B, S, Hd, P, G, E, lo, hi = ctx.meta
-        dH1 = _c(dH1)
-        dev = dH1
+        plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
+        B, S, Hd, P, G, E, lo, hi, Etot = ctx.meta
+        dev = dH1.device
         Kin = w_ih0.shape[1]
-
-        def shifted(h):
-            hp = torch.zeros_like(h)
-            hp[:, 1:] = h[:, :-1]
-            return hp
-
-        # ---- layer 1
-        d1 = DecoderRNNFn._bptt(dH1, h1, w_hh1, B, S, Hd)
-        dw_hh1 = _f32(Hd, Hd, like=dev)
-        kn.gemm(d1, shifted(h1), dw_hh1, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
-        dw_ih1 = _f32(Hd, Hd, like=dev)
-        kn.gemm(d1, h0, dw_ih1, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
-        db1 = _f32(Hd, like=dev)
-        kn.colsum(d1, B * S, Hd, Hd, db1)
-        dH0 = _f32(B, S, Hd, like=dev)
-        kn.gemm(d1, weight_operand(w_ih1), dH0, B * S, Hd, Hd, Hd, Hd, Hd, b_kmajor=False)
-        # ---- layer 0
-        d0 = DecoderRNNFn._bptt(dH0, h0, w_hh0, B, S, Hd)
-        dw_hh0 = _f32(Hd, Hd, like=dev)
-        kn.gemm(d0, shifted(h0), dw_hh0, Hd, Hd, B * S, Hd, Hd, Hd, a_kmajor=False, b_kmajor=False)
-        db0 = _f32(Hd, like=dev)
-        kn.colsum(d0, B * S, Hd, Hd, db0)
-        dc = _f32(B, Hd, like=dev)                       # sum over time of delta0 (gradient of the constant part)
-        kn.seq_mean_fwd(d0, dc, B, S, Hd, scale=float(S))
+        f32 = dict(dtype=torch.float32, device=dev)
+        dH1_t = dH1.permute(1, 0, 2).contiguous()                                  # (S, B, H) time-major
+        dbuf = torch.zeros(S + 1, B, 2 * Hd, **f32)                                # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
+        whh1_t = weight_operand(w_hh1, "t")
+        wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
+        s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
+        s1.wait_stream(s0)
+        for t in range(S - 1, -1, -1):
+            h1_t, h0_t = zbuf[t + 2][:, Hd:], zbuf[t + 1][:, :Hd]
+            # delta1_t = (dH1_t + delta1_{t+1} W_hh1) * (h1_t > 0)      (dbuf[S+1] does not exist: delta1_S = 0 -> zero rows of zbuf[0])
+            prev = dbuf[t + 2][:, :Hd] if t + 2 <= S else zbuf[0][:, :Hd]
+            kn.gemm(prev, whh1_t, dbuf[t + 1][:, :Hd], B, Hd, Hd, 2 * Hd, Hd, 2 * Hd, add=dH1_t[t], ld_add=Hd, mask=h1_t, ld_mask=2 * Hd)
+            ev = torch.cuda.Event()
+            ev.record(s0)
+            with torch.cuda.stream(s1):
+                s1.wait_event(ev)
+                # delta0_t = ([delta1_t | delta0_{t+1}] [W_ih1^T | W_hh0^T]^T) * (h0_t > 0)
+                kn.gemm(dbuf[t + 1], wb0, dbuf[t][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, mask=h0_t, ld_mask=2 * Hd)
+        s0.wait_stream(s1)
+        d1 = dbuf[1:S + 1]            # rows (t, b): [delta1_t | delta0_{t+1}]
+        d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
+        M = S * B
+        # layer 1: [dW_ih1 | dW_hh1] = delta1^T [h0_t | h1_{t-1}]
+        dw1 = torch.empty(Hd, 2 * Hd, **f32)
+        kn.gemm(d1, zbuf[1:S + 1], dw1, Hd, 2 * Hd, M, 2 * Hd, 2 * Hd, 2 * Hd, a_kmajor=False, b_kmajor=False)
+        db1 = torch.empty(Hd, **f32)
+        kn.colsum(d1, M, Hd, 2 * Hd, db1)
+        # layer 0
+        dw_hh0 = torch.empty(Hd, Hd, **f32)
+        kn.gemm(d0, zbuf[0:S], dw_hh0, Hd, Hd, M, 2 * Hd, 2 * Hd, Hd, a_kmajor=False, b_kmajor=False)      # h0_{t-1} = zbuf[t][:, :H]
+        db0 = torch.empty(Hd, **f32)
+        kn.colsum(d0, M, Hd, 2 * Hd, db0)
+        dcs = torch.empty(B, 2 * Hd, **f32)                                         # sum over time of dbuf[0:S] rows
+        kn.colsum(dbuf, S, B * 2 * Hd, B * 2 * Hd, dcs)
+        dc = dcs[:, Hd:]                                                            # (B, H) strided view, ld 2H
         wih0 = weight_operand(w_ih0)
-        dw_ih0 = _f32(Hd, Kin, like=dev)
-        kn.gemm(dc, plan, dw_ih0, Hd, P, B, Hd, P, Kin, a_kmajor=False, b_kmajor=False)
-        kn.gemm(d0, emb[:, :, lo:hi], dw_ih0[:, P:P + E], Hd, E, B * S, Hd, emb.shape[2], Kin, a_kmajor=False, b_kmajor=False)
-        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, Hd, G, Kin, a_kmajor=False, b_kmajor=False)
-        dplan = _f32(B, P, like=dev)
-        kn.gemm(dc, wih0, dplan, B, P, Hd, Hd, Kin, P, b_kmajor=False)
-        dgoal = _f32(B, G, like=dev)
-        kn.gemm(dc, wih0[:, P + E:], dgoal, B, G, Hd, Hd, Kin, G, b_kmajor=False)
-        demb = torch.zeros_like(emb)
-        kn.gemm(d0, wih0[:, P:P + E], demb[:, :, lo:hi], B * S, E, Hd, Hd, Kin, emb.shape[2], b_kmajor=False)
-        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db0, db0, dw_ih1, dw_hh1, db1, db1)
+        dw_ih0 = torch.empty(Hd, Kin, **f32)
+        kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False)
+        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False)
+        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False)
+        dplan = torch.empty(B, P, **f32)
+        kn.gemm(dc, wih0, dplan, B, P, Hd, 2 * Hd, Kin, P, b_kmajor=False)
+        dgoal = torch.empty(B, G, **f32)
+        kn.gemm(dc, wih0[:, P + E:], dgoal, B, G, Hd, 2 * Hd, Kin, G, b_kmajor=False)
+        demb_t = torch.empty(S, B, E, **f32)
+        kn.gemm(d0, wih0[:, P:P + E], demb_t, M, E, Hd, 2 * Hd, Kin, E, b_kmajor=False)
+        demb = torch.zeros(B, S, Etot, **f32)
+        demb[:, :, lo:hi] = demb_t.permute(1, 0, 2)
+        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db0, db0, dw1[:, :Hd], dw1[:, Hd:], db1, db1)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -116,10 +116,23 @@ def reset_step_state(device, seed: int = 0x243F6A8885A308D3 >> 1, step: int = 0)
 
 
 def _gemm_scratch(device) -> torch.Tensor:
-    t = _scratch.get(device)
+    """split-K slab buffer, one per (device, stream): reuse is stream-ordered, concurrent streams never share it"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _scratch.get(key)
     if t is None:
-        t = _scratch[device] = torch.empty(8 << 20, dtype=torch.float32, device=device)   # 32 MiB
+        t = _scratch[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)   # 32 MiB
     return t
+
+
+_side = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """second HIP stream used to run independent kernel chains concurrently (the two RNN layers as a wavefront)"""
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=None, add=None, ld_add=0,
