@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    const int kbeg = (blockIdx.y * NW + wave) * kw;           // this wave's K slice [kbeg, kbeg + kw)
+    const int kbeg = (blockIdx.y * NW + (wave + blockIdx.x) % NW) * kw;   // this wave's K slice, rotated per column strip (L2 hot-spot avoidance)
     int kend = kbeg + kw; if (kend > p.K) kend = p.K;
 
     f32x16_t acc[TM];
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, cons
     for (int s = 0; s < splitk; ++s) v += slabs[(long)s * p.M * p.N + i];
     store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
 }
+
 
 // K slices: waves first (up to 16 per workgroup: combined through LDS in the same launch, epilogue fused),
 // then workgroups (fp32 slabs + epilogue kernel) until ~256 workgroups exist; every wave keeps >= 64 k.

@@ -321,8 +321,9 @@ class DecoderRNNFn(torch.autograd.Function):
       * layer 0's input projection is split by linearity: plan/goal columns of W_ih0 once per sequence, the embedding
         columns per token (one batched GEMM);
       * layer 1's input projection is fused into its recurrent GEMM: h1_t = relu([h0_t | h1_{t-1}] [W_ih1 | W_hh1]^T + b)
-        (K = 2H), so layer 1 needs nothing but h0_t — the two layers then run as a WAVEFRONT on two HIP streams
-        (layer 1 step t next to layer 0 step t+1): 33 dependent stages instead of 64;
+        (K = 2H), so layer 1 needs nothing but h0_t; the two layers can run as a wavefront on two HIP streams
+        (HULC_WAVEFRONT=1) — measured neutral-to-slower on MI355X because each launch already fills the chip, so the
+        default is one stream;
       * activations are time-major (S, B, .) so each step's rows are contiguous; zbuf[t+1] = [h0_t | h1_{t-1}].
     Backward mirrors it: delta0_t = ([delta1_t | delta0_{t+1}] [W_ih1^T | W_hh0^T]^T) * (h0_t > 0), again a wavefront.
     """
@@ -343,7 +344,8 @@ class DecoderRNNFn(torch.autograd.Function):
         emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
         pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
         kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
-        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=torch.float32, device=dev)     # zbuf[t+1] = [h0_t | h1_{t-1}]
+        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=_act_dtype(), device=dev)       # zbuf[t+1] = [h0_t | h1_{t-1}]; bf16 in bf16 mode:
+        # the MFMA rounds its operands to bf16 anyway, so keeping the state bf16 in HBM halves the traffic at identical numerics
         whh0 = weight_operand(w_hh0)
         w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
         s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
@@ -370,7 +372,7 @@ class DecoderRNNFn(torch.autograd.Function):
         Kin = w_ih0.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
         dH1_t = dH1.permute(1, 0, 2).contiguous()                                  # (S, B, H) time-major
-        dbuf = torch.zeros(S + 1, B, 2 * Hd, **f32)                                # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
+        dbuf = torch.zeros(S + 1, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
         whh1_t = weight_operand(w_hh1, "t")
         wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
         s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)

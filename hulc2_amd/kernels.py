@@ -129,6 +129,9 @@ _side = {}
 
 def side_stream(device) -> "torch.cuda.Stream":
     """second HIP stream used to run independent kernel chains concurrently (the two RNN layers as a wavefront)"""
+    import os
+    if not os.environ.get("HULC_WAVEFRONT"):            # measured (tools/decoder_bench.py): the two recurrent chains do not overlap
+        return torch.cuda.current_stream(device)        # usefully (each launch already fills the chip) -> default: one stream
     s = _side.get(device)
     if s is None:
         s = _side[device] = torch.cuda.Stream(device=device)
