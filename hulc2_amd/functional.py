@@ -344,8 +344,11 @@ class DecoderRNNFn(torch.autograd.Function):
         emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
         pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
         kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
-        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=_act_dtype(), device=dev)       # zbuf[t+1] = [h0_t | h1_{t-1}]; bf16 in bf16 mode:
-        # the MFMA rounds its operands to bf16 anyway, so keeping the state bf16 in HBM halves the traffic at identical numerics
+        import os
+        # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
+        # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
+        zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
+        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)                # zbuf[t+1] = [h0_t | h1_{t-1}]
         whh0 = weight_operand(w_hh0)
         w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
         s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
