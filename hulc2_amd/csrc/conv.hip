@@ -22,6 +22,12 @@
 #include "hulc_abi_internal.h"
 #include <stdlib.h>
 
+// LDS-band kernel (conv_band.hip): 0 = launched, 1 = geometry not covered (use the gather kernel), < 0 = error
+int hulc_conv_band_dispatch(int C, int COUT, int TH, int TW, int S, const void* x, int x_dtype, int N, int H, int W, int OH, int OW,
+                            int pad_y, int pad_x, long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx,
+                            const void* wt, int w_dtype, long ldw, const long* w_tap_off, const float* bias, const void* mask,
+                            int mask_dtype, int relu, hipStream_t s);
+
 namespace {
 
 #define HULC_MAX_TAPS 64
@@ -421,6 +427,13 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
+    if (d->compute == HULC_BF16 && !d->x_nchw && d->KH * d->KW <= 16) {
+        rc = hulc_conv_band_dispatch(d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, g.OH, g.OW, 0, 0,
+                                     g.x_sn, g.x_sy, g.x_sx, y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, g.w_tap_off,
+                                     bias, nullptr, HULC_F32, d->relu, (hipStream_t)stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
+    }
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_fwd");
 }
@@ -462,6 +475,20 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             g.y_sn = (long)d->H * d->W * d->Cin; g.y_sy = (long)s * d->W * d->Cin; g.y_sx = (long)s * d->Cin;
             g.mask = relu_src ? (const char*)relu_src + yoff * xsz : nullptr; g.mask_dtype = d->x_dtype; g.mask_scale = 1.f;
             g.relu = 0;
+            if (d->compute == HULC_BF16) {      // dense stride-1 correlation of dY with this class' taps: LDS-band kernel
+                const int Uy = (d->KH - py + s - 1) / s, Ux = (d->KW - px + s - 1) / s;
+                if (Uy * Ux <= 16) {
+                    long woff[16];
+                    for (int ty = 0; ty < Uy; ++ty)
+                        for (int tx = 0; tx < Ux; ++tx)
+                            woff[ty * Ux + tx] = ((long)(py + s * (Uy - 1 - ty)) * d->KW + (px + s * (Ux - 1 - tx))) * d->Cout;
+                    int brc = hulc_conv_band_dispatch(d->Cout, d->Cin, Uy, Ux, 1, dy, d->y_dtype, d->N, OH, OW, g.OH, g.OW, Uy - 1, Ux - 1,
+                                                      g.x_sn, g.x_sy, g.x_sx, g.Y, g.y_dtype, g.y_sn, g.y_sy, g.y_sx, wt, d->w_dtype, g.ldw,
+                                                      woff, nullptr, g.mask, g.mask_dtype, 0, (hipStream_t)stream);
+                    if (brc < 0) return brc;
+                    if (brc == 0) continue;
+                }
+            }
             if (d->compute == HULC_F32) {
                 if (d->y_dtype != HULC_F32 || d->w_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_data: f32 compute requires f32 operands");
                 launch_gather<float>(g, (hipStream_t)stream);
