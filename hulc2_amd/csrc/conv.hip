@@ -47,13 +47,17 @@ struct GatherP {
 
 // one gathered 8-element chunk of the implicit im2col row of a pixel
 HULC_DEVICE void gather_chunk(Chunk8& c, const GatherP& p, long pix_base, int iy0, int ix0, int k0, int K) {
-    if (k0 >= K) { chunk_zero(c); return; }
-    const int t = k0 >> p.inner_log2, j = k0 & ((1 << p.inner_log2) - 1);
+    bool keep = k0 < K;
+    const int kc = keep ? k0 : 0;
+    const int t = kc >> p.inner_log2, j = kc & ((1 << p.inner_log2) - 1);
     if (p.check_bounds) {
         const int iy = iy0 + p.tap_dy[t], ix = ix0 + p.tap_dx[t];
-        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) { chunk_zero(c); return; }
+        keep = keep && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     }
-    chunk_load_contig(c, p.X, p.x_dtype, pix_base + p.tap_off[t] + j);
+    // unconditional load from a clamped address + select (no branch around the load: see chunk_keep_if)
+    const long off = keep ? pix_base + p.tap_off[t] + j : 0;
+    chunk_load_contig(c, p.X, p.x_dtype, off);
+    chunk_keep_if(c, keep);
 }
 
 template <typename CT, int TM, int TN, int WM, int WN>
@@ -117,11 +121,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
             if (B_CH % NT == 0 || id < B_CH) {
                 int r = id / NCH, ch = id % NCH, k0 = kt * KT + ch * 8;
                 int n = n0 + r; n = n < p.Cout ? n : p.Cout - 1;
-                if (k0 >= K) chunk_zero(rb[q]);
-                else {
-                    const int t = k0 >> p.inner_log2, j = k0 & ((1 << p.inner_log2) - 1);
-                    chunk_load_contig(rb[q], p.Wt, p.w_dtype, (long)n * p.ldw + p.w_tap_off[t] + j);
-                }
+                const bool keep = k0 < K;
+                const int kc = keep ? k0 : 0;
+                const int t = kc >> p.inner_log2, j = kc & ((1 << p.inner_log2) - 1);
+                chunk_load_contig(rb[q], p.Wt, p.w_dtype, (long)n * p.ldw + p.w_tap_off[t] + j);
+                chunk_keep_if(rb[q], keep);
             }
         }
     };
@@ -283,9 +287,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         const long mt = mb + (long)t * KT;
         if (tid < DY_ITEMS) {
             const long m = mt + 2 * dy_pr;
-            if (m < me) chunk_load_contig(dya, p.dY, p.dy_dtype, dy_base(dyit) + dy_ch * 8); else chunk_zero(dya);
-            if (m + 1 < me) { PixIter nx = dyit; nx.advance(1, g.OH, g.OW); chunk_load_contig(dyb, p.dY, p.dy_dtype, dy_base(nx) + dy_ch * 8); }
-            else chunk_zero(dyb);
+            PixIter nx = dyit; nx.advance(1, g.OH, g.OW);
+            chunk_load_contig(dya, p.dY, p.dy_dtype, m < me ? dy_base(dyit) + dy_ch * 8 : 0);
+            chunk_keep_if(dya, m < me);
+            chunk_load_contig(dyb, p.dY, p.dy_dtype, m + 1 < me ? dy_base(nx) + dy_ch * 8 : 0);
+            chunk_keep_if(dyb, m + 1 < me);
             dyit.advance(KT, g.OH, g.OW);
         }
 #pragma unroll
@@ -294,9 +300,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
                 const int k0 = ks0 + x_ch[q] * 8;
                 const long m = mt + 2 * x_pr[q];
                 int iy0, ix0;
-                if (m < me) { const long b = x_base(xit[q], iy0, ix0); gather_chunk(xa[q], g, b, iy0, ix0, k0, K); } else chunk_zero(xa[q]);
-                if (m + 1 < me) { PixIter nx = xit[q]; nx.advance(1, g.OH, g.OW); const long b = x_base(nx, iy0, ix0); gather_chunk(xb[q], g, b, iy0, ix0, k0, K); }
-                else chunk_zero(xb[q]);
+                PixIter nx = xit[q]; nx.advance(1, g.OH, g.OW);
+                const long b0 = x_base(xit[q], iy0, ix0);
+                gather_chunk(xa[q], g, b0, iy0, ix0, m < me ? k0 : K, K);           // k0 = K -> zero chunk, still one unconditional load
+                const long b1 = x_base(nx, iy0, ix0);
+                gather_chunk(xb[q], g, b1, iy0, ix0, m + 1 < me ? k0 : K, K);
                 xit[q].advance(KT, g.OH, g.OW);
             }
         }
@@ -475,7 +483,10 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             g.y_sn = (long)d->H * d->W * d->Cin; g.y_sy = (long)s * d->W * d->Cin; g.y_sx = (long)s * d->Cin;
             g.mask = relu_src ? (const char*)relu_src + yoff * xsz : nullptr; g.mask_dtype = d->x_dtype; g.mask_scale = 1.f;
             g.relu = 0;
-            if (d->compute == HULC_BF16) {      // dense stride-1 correlation of dY with this class' taps: LDS-band kernel
+            // LDS-band kernel for the data gradient: correct (tests run it with HULC_BAND_DGRAD=1) but, re-staging dY once per
+            // parity class and with a 2-byte-store epilogue, it measures slower than the gather kernel (tools/conv_bench.py:
+            // conv2 0.75 vs 0.61 ms, conv3 0.26 vs 0.27 ms) -> opt-in until the classes share one staged band
+            if (d->compute == HULC_BF16 && getenv("HULC_BAND_DGRAD")) {
                 const int Uy = (d->KH - py + s - 1) / s, Ux = (d->KW - px + s - 1) / s;
                 if (Uy * Ux <= 16) {
                     long woff[16];

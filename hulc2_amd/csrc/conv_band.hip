@@ -29,6 +29,7 @@ struct BandP {
     long ldw;                       // global weight row stride (elements)
     long w_tap_off[16];             // global offset (elements, inside a weight row) of tap (ty, tx)
     int relu; float mask_scale;
+    long long* dbg;                 // optional per-workgroup phase cycle counters (tools/conv_one.py), normally null
 };
 
 template <int C, int COUT, int TH, int TW, int S>
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int TN = COUT / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wlds = smem;                      // [COUT][WS]
-    char* band = smem + COUT * WS;          // [rows][Wb][PS]
+    long* ooff = (long*)(smem + COUT * WS); // [8 waves][2 tiles][32] output element offsets (no divisions in the epilogue)
+    char* band = smem + COUT * WS + 8 * 2 * 32 * 8;   // [rows][Wb][PS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -48,13 +50,17 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     const int bands = (p.OH + p.R - 1) / p.R;
     const int nunits = p.Nimg * bands;
 
+    long long t_w = 0, t_s = 0, t_c = 0, t0 = clock64();
     // ---- weights -> LDS (once per workgroup), dense [cout][(ty,tx,c)] from the tap table
-    for (int id = tid; id < COUT * (K / 8); id += NT) {
-        const int co = id / (K / 8), kc = id % (K / 8);
+    constexpr int WCH = COUT * (K / 8);
+#pragma unroll 4
+    for (int id = tid; id < (WCH + NT - 1) / NT * NT; id += NT) {
+        const int idc = id < WCH ? id : 0;
+        const int co = idc / (K / 8), kc = idc % (K / 8);
         const int t = (kc * 8) / C, c0 = (kc * 8) % C;
         Chunk8 ch;
         chunk_load_contig(ch, p.Wt, p.w_dtype, (long)co * p.ldw + p.w_tap_off[t] + c0);
-        chunk_store_lds<bf16_t>(wlds + co * WS + kc * 16, ch);
+        if (id < WCH) chunk_store_lds<bf16_t>(wlds + co * WS + kc * 16, ch);
     }
 
     for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
@@ -64,25 +70,40 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         const int rows = (R - 1) * S + TH;
         const int iy0 = r0 * S - p.pad_y, ix0 = -p.pad_x;
         __syncthreads();                                    // previous unit's reads are done (and weights are visible)
-        // ---- stage the input band (zero outside the tensor)
+        if (unit == (int)blockIdx.x) { t_w = clock64() - t0; }
+        long long t1 = clock64();
+        // ---- stage the input band (zero outside the tensor).  Loads are issued UNR deep before the first LDS write so
+        //      the band arrives at memory-level parallelism instead of one L2/HBM round trip per chunk.
         const int nchunk = rows * Wb * (C / 8);
-        for (int id = tid; id < nchunk; id += NT) {
-            const int cc = id % (C / 8); const int px = id / (C / 8);
-            const int bc = px % Wb, br = px / Wb;
-            const int iy = iy0 + br, ix = ix0 + bc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                const long off = (long)n * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8;
-                if (p.x_dtype == HULC_BF16) v = *(const uint4*)((const uint16_t*)p.X + off);
+        constexpr int UNR = 8;
+        for (int base = 0; base < nchunk; base += NT * UNR) {
+            uint4 v[UNR]; int dst[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int id = base + u * NT + tid;
+                const int idc = id < nchunk ? id : 0;
+                const int cc = idc % (C / 8); const int px = idc / (C / 8);
+                const int bc = px % Wb, br = px / Wb;
+                const int iy = iy0 + br, ix = ix0 + bc;
+                dst[u] = id < nchunk ? (br * Wb + bc) * PS + cc * 16 : -1;
+                const bool inb = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                // unconditional load from a clamped address, then select: no branch (and no vmcnt(0)) around the load
+                const long off = inb ? (long)n * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
+                uint4 t;
+                if (p.x_dtype == HULC_BF16) t = *(const uint4*)((const uint16_t*)p.X + off);
                 else {
                     const float4* q = (const float4*)((const float*)p.X + off);
                     const float4 a = q[0], c = q[1];
-                    v.x = pack_bf16x2(a.x, a.y); v.y = pack_bf16x2(a.z, a.w); v.z = pack_bf16x2(c.x, c.y); v.w = pack_bf16x2(c.z, c.w);
+                    t.x = pack_bf16x2(a.x, a.y); t.y = pack_bf16x2(a.z, a.w); t.z = pack_bf16x2(c.x, c.y); t.w = pack_bf16x2(c.z, c.w);
                 }
+                v[u].x = inb ? t.x : 0u; v[u].y = inb ? t.y : 0u; v[u].z = inb ? t.z : 0u; v[u].w = inb ? t.w : 0u;
             }
-            *(uint4*)(band + (br * Wb + bc) * PS + cc * 16) = v;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (dst[u] >= 0) *(uint4*)(band + dst[u]) = v[u];
         }
         __syncthreads();
+        t_s += clock64() - t1; t1 = clock64();
 
         // ---- compute: pairs of 32-pixel tiles per wave
         const int npix = R * p.OW;
@@ -96,6 +117,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 if (q >= npix) q = npix - 1;
                 const int oy = q / p.OW, ox = q % p.OW;
                 abase[i] = ((oy * S) * Wb + ox * S) * PS + h * 16;
+                if (h == 0) ooff[(wave * 2 + i) * 32 + r] = pix[i] < npix ? (long)n * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx : -1;
             }
             f32x16_t acc[2][TN];
 #pragma unroll
@@ -131,10 +153,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int q = (tp * 2 + i) * 32 + acc_row(e, lane);
-                        if (q >= npix) continue;
-                        const int oy = r0 + q / p.OW, ox = q % p.OW;
-                        const long off = (long)n * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + co;
+                        const long po = ooff[(wave * 2 + i) * 32 + acc_row(e, lane)];   // written by this wave above: wave-local LDS, in order
+                        if (po < 0) continue;
+                        const long off = po + co;
                         float v = acc[i][j][e] + bv;
                         if (p.relu) v = fmaxf(v, 0.f);
                         if (p.mask) v = load_elem(p.mask, p.mask_dtype, off) > 0.f ? v * p.mask_scale : 0.f;
@@ -143,7 +164,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             }
             (void)pix;
         }
+        t_c += clock64() - t1;
     }
+    if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 4] = t_w; p.dbg[blockIdx.x * 4 + 1] = t_s; p.dbg[blockIdx.x * 4 + 2] = t_c; p.dbg[blockIdx.x * 4 + 3] = clock64() - t0; }
 }
 
 template <int C, int COUT, int TH, int TW, int S>
@@ -151,7 +174,7 @@ int launch_band(BandP& p, hipStream_t s) {
     constexpr int K = TH * TW * C, PS = C * 2 + 16, WS = K * 2 + 16;
     const int Wb = (p.OW - 1) * S + TW;
     const long wbytes = (long)COUT * WS;
-    const long budget = 160 * 1024 - wbytes - 256;
+    const long budget = 160 * 1024 - wbytes - 8 * 2 * 32 * 8 - 256;
     // rows per unit: as many output rows as the LDS band allows (whole frame when it fits)
     int R = p.OH;
     while (R > 1 && (long)((R - 1) * S + TH) * Wb * PS > budget) --R;
@@ -160,7 +183,8 @@ int launch_band(BandP& p, hipStream_t s) {
     const int bands = (p.OH + R - 1) / R;
     R = (p.OH + bands - 1) / bands;
     p.R = R;
-    const size_t lds = (size_t)wbytes + (size_t)((R - 1) * S + TH) * Wb * PS;
+    const size_t lds = (size_t)wbytes + 8 * 2 * 32 * 8 + (size_t)((R - 1) * S + TH) * Wb * PS;
+    if ((long)R * p.OW < 128) return -1;        // tiny frames: one unit cannot feed 8 waves, the gather kernel is faster
     const int nunits = p.Nimg * bands;
     const int grid = nunits < 256 ? nunits : 256;
     auto kern = conv_band_kernel<C, COUT, TH, TW, S>;
@@ -188,8 +212,10 @@ int hulc_conv_band_dispatch(int C, int COUT, int TH, int TW, int S, const void* 
     p.Nimg = N; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x; p.R = OH;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
     p.ldw = ldw; p.relu = relu; p.mask_scale = 1.f;
+    { const char* e = getenv("HULC_BAND_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     for (int t = 0; t < TH * TW && t < 16; ++t) p.w_tap_off[t] = w_tap_off[t];
     int rc = 1;
+    // measured (tools/conv_bench.py, 1024 frames): conv3 forward 0.090 ms vs 0.143 ms gather; conv2 forward on par
     if (C == 32 && COUT == 64 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 64, 4, 4, 2>(p, s);
     else if (C == 64 && COUT == 64 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 64, 3, 3, 1>(p, s);
     else if (C == 64 && COUT == 32 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 32, 2, 2, 1>(p, s);

@@ -37,13 +37,20 @@ struct GemmP {
 //   !KMAJOR: operand stored [K][rows], row contiguous -> 8 strided loads (coalesced across lanes)
 template <bool KMAJOR>
 HULC_DEVICE void load_operand_chunk(Chunk8& c, const void* base, int dtype, long ld, int rows, int K, int r, int k0) {
-    if (k0 >= K) { chunk_zero(c); return; }
+    const bool in_k = k0 < K;
+    const int kc = in_k ? k0 : 0;  // branch-free: load from a clamped address, zero afterwards (see chunk_keep_if)
     r = r < rows ? r : rows - 1;   // clamp: out-of-range rows are computed but never stored
     if (KMAJOR) {
-        chunk_load_contig(c, base, dtype, (long)r * ld + k0);
+        chunk_load_contig(c, base, dtype, (long)r * ld + kc);
+        chunk_keep_if(c, in_k);
     } else {
-        int nvalid = K - k0; nvalid = nvalid > 8 ? 8 : nvalid;
-        chunk_load_strided(c, base, dtype, (long)k0 * ld + r, ld, nvalid);
+        const int nvalid = in_k ? K - k0 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = (j < nvalid) ? kc + j : 0;
+            const float v = load_elem(base, dtype, (long)kk * ld + r);
+            c.v[j] = (j < nvalid) ? v : 0.f;
+        }
     }
 }
 

@@ -63,6 +63,15 @@ HULC_DEVICE void chunk_zero(Chunk8& c) {
     for (int j = 0; j < 8; ++j) c.v[j] = 0.f;
 }
 
+// keep the chunk when `keep`, else zeros — as selects, never as a branch around the load that produced it: hipcc
+// wraps a conditionally executed load in a branch and waits vmcnt(0) behind it, which serialises every load of a
+// tile stage into its own memory round trip (cdna_hip_programming.md §5 "Three .s-level traps", c).  All operand
+// loaders therefore load unconditionally from a clamped (always valid) address and zero the result afterwards.
+HULC_DEVICE void chunk_keep_if(Chunk8& c, bool keep) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.v[j] = keep ? c.v[j] : 0.f;
+}
+
 // 8 contiguous elements starting at element offset `off` (off % 8 == 0, base 16B aligned)
 HULC_DEVICE void chunk_load_contig(Chunk8& c, const void* base, int dtype, long off) {
     if (dtype == HULC_F32) {
