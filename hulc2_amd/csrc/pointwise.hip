@@ -221,6 +221,17 @@ __global__ void seq_mean_fwd_kernel(const float* __restrict__ x, float* __restri
     for (int t = 0; t < S; ++t) s += x[((long)b * S + t) * D + d];
     y[i] = scale * (s / S);
 }
+// y[b][d] = scale * sum_s x[b*stride_b + s*stride_s + d]  (any layout: time-major recurrent buffers, strided halves)
+__global__ void strided_seq_sum_kernel(const void* __restrict__ x, int x_dtype, float* __restrict__ y, int B, int S, int D, long stride_b,
+                                       long stride_s, long ldy, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D) return;
+    const int b = (int)(i / D), d = (int)(i % D);
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += load_elem(x, x_dtype, (long)b * stride_b + (long)t * stride_s + d);
+    y[(long)b * ldy + d] = scale * s;
+}
+
 __global__ void seq_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int S, int D) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * D) return;
@@ -494,6 +505,14 @@ extern "C" int hulc_seq_mean_fwd(const float* x, float* y, int B, int S, int D, 
     seq_mean_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, B, S, D, scale);
     return hulc_check_launch("hulc_seq_mean_fwd");
 }
+extern "C" int hulc_strided_seq_sum(const void* x, int x_dtype, float* y, int B, int S, int D, long stride_b, long stride_s, long ldy,
+                                    float scale, void* stream) {
+    if (!x || !y) return hulc_fail(-1, "hulc_strided_seq_sum: null pointer");
+    const long n = (long)B * D;
+    strided_seq_sum_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, x_dtype, y, B, S, D, stride_b, stride_s, ldy, scale);
+    return hulc_check_launch("hulc_strided_seq_sum");
+}
+
 extern "C" int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D, void* stream) {
     if (!dy || !dx) return hulc_fail(-1, "hulc_seq_mean_bwd: null pointer");
     const long n = (long)B * S * D;

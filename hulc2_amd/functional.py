@@ -10,6 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
+from . import gradsink
 from . import kernels as kn
 from .shadow import weight_operand
 
@@ -68,11 +69,14 @@ class MLPFn(torch.autograd.Function):
             W = params[2 * i]
             N, K = W.shape
             inp = x2 if i == 0 else acts[i - 1]
-            dW = _f32(N, K, like=g)
-            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False)   # dW = g^T inp
-            db = _f32(N, like=g)
-            kn.colsum(g, M, N, g.stride(0), db)
-            grads[2 * i], grads[2 * i + 1] = dW, db
+            sw, sb = gradsink.get(W), gradsink.get(params[2 * i + 1])
+            dW = sw if sw is not None else _f32(N, K, like=g)
+            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False,
+                    accumulate=sw is not None)                                                                # dW (+)= g^T inp
+            db = sb if sb is not None else _f32(N, like=g)
+            kn.colsum(g, M, N, g.stride(0), db, accumulate=sb is not None)
+            grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
+            grads[2 * i + 1] = None if sb is not None else db
             if i > 0 or need_x:
                 dinp = _f32(M, K, like=g)
                 if i > 0 and relus[i - 1]:
@@ -364,6 +368,7 @@ class DecoderRNNFn(torch.autograd.Function):
         s0.wait_stream(s1)
         h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()                  # (B, S, H) for the heads
         ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
+        ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)          # only their identity is needed (gradient sinks)
         ctx.meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
         return h1
 
@@ -395,24 +400,39 @@ class DecoderRNNFn(torch.autograd.Function):
         d1 = dbuf[1:S + 1]            # rows (t, b): [delta1_t | delta0_{t+1}]
         d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
         M = S * B
-        # layer 1: [dW_ih1 | dW_hh1] = delta1^T [h0_t | h1_{t-1}]
-        dw1 = torch.empty(Hd, 2 * Hd, **f32)
-        kn.gemm(d1, zbuf[1:S + 1], dw1, Hd, 2 * Hd, M, 2 * Hd, 2 * Hd, 2 * Hd, a_kmajor=False, b_kmajor=False)
-        db1 = torch.empty(Hd, **f32)
-        kn.colsum(d1, M, Hd, 2 * Hd, db1)
+        def wgrad(dlt, inp_rows, ncols, param):
+            """param.grad (+)= dlt^T inp_rows; straight into the gradient arena when the trainer registered a sink"""
+            sink = gradsink.get(param)
+            out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
+            kn.gemm(dlt, inp_rows, out, Hd, ncols, M, 2 * Hd, 2 * Hd, ncols, a_kmajor=False, b_kmajor=False, accumulate=sink is not None)
+            return None if sink is not None else out
+
+        def bgrad(dlt, param):
+            sink = gradsink.get(param)
+            out = sink if sink is not None else torch.empty(Hd, **f32)
+            kn.colsum(dlt, M, Hd, 2 * Hd, out, accumulate=sink is not None)
+            return None if sink is not None else out
+
+        b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
+        # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}])
+        dw_ih1 = wgrad(d1, zbuf[1:S + 1], Hd, w_ih1)
+        dw_hh1 = wgrad(d1, zbuf[1:S + 1][:, :, Hd:], Hd, w_hh1)
+        db_ih1, db_hh1 = bgrad(d1, b_ih1), bgrad(d1, b_hh1)
         # layer 0
-        dw_hh0 = torch.empty(Hd, Hd, **f32)
-        kn.gemm(d0, zbuf[0:S], dw_hh0, Hd, Hd, M, 2 * Hd, 2 * Hd, Hd, a_kmajor=False, b_kmajor=False)      # h0_{t-1} = zbuf[t][:, :H]
-        db0 = torch.empty(Hd, **f32)
-        kn.colsum(d0, M, Hd, 2 * Hd, db0)
-        dcs = torch.empty(B, 2 * Hd, **f32)                                         # sum over time of dbuf[0:S] rows
-        kn.colsum(dbuf, S, B * 2 * Hd, B * 2 * Hd, dcs)
+        dw_hh0 = wgrad(d0, zbuf[0:S], Hd, w_hh0)                                    # h0_{t-1} = zbuf[t][:, :H]
+        db_ih0, db_hh0 = bgrad(d0, b_ih0), bgrad(d0, b_hh0)
+        dcs = torch.empty(B, 2 * Hd, **f32)
         dc = dcs[:, Hd:]                                                            # (B, H) strided view, ld 2H
+        kn.strided_seq_sum(d0, dc, B, S, Hd, 2 * Hd, B * 2 * Hd, 2 * Hd)            # dc = sum_t delta0_t
         wih0 = weight_operand(w_ih0)
-        dw_ih0 = torch.empty(Hd, Kin, **f32)
-        kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False)
-        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False)
-        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False)
+        s_ih0 = gradsink.get(w_ih0)
+        dw_ih0 = s_ih0 if s_ih0 is not None else torch.empty(Hd, Kin, **f32)
+        acc0 = s_ih0 is not None
+        kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        if acc0:
+            dw_ih0 = None
         dplan = torch.empty(B, P, **f32)
         kn.gemm(dc, wih0, dplan, B, P, Hd, 2 * Hd, Kin, P, b_kmajor=False)
         dgoal = torch.empty(B, G, **f32)
@@ -421,7 +441,7 @@ class DecoderRNNFn(torch.autograd.Function):
         kn.gemm(d0, wih0[:, P:P + E], demb_t, M, E, Hd, 2 * Hd, Kin, E, b_kmajor=False)
         demb = torch.zeros(B, S, Etot, **f32)
         demb[:, :, lo:hi] = demb_t.permute(1, 0, 2)
-        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db0, db0, dw1[:, :Hd], dw1[:, Hd:], db1, db1)
+        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1)
 
 
 # ------------------------------------------------------------------------------------------------

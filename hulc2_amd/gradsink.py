@@ -1,0 +1,31 @@
+"""Direct-to-arena weight gradients.
+
+torch autograd hands every weight gradient to an AccumulateGrad node that does `param.grad += g`: one extra
+elementwise kernel and a 3x (read, read, write) pass over each of the 47 M gradient elements per contribution.
+When the native trainer owns a flat gradient arena it registers each parameter's arena slice here; the backward
+kernels (wgrad GEMM epilogue `accumulate`, column-sum kernels) then add straight into the slice and the autograd
+Function returns None for that parameter.  Only enabled when no per-parameter all-reduce hooks depend on
+AccumulateGrad (single GPU, or graph mode where the arena is reduced in one piece).
+"""
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_sinks: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}
+
+
+def clear() -> None:
+    _sinks.clear()
+
+
+def register(param: torch.Tensor, grad_view: torch.Tensor) -> None:
+    key = id(param)
+    _sinks[key] = (weakref.ref(param, lambda _r, k=key: _sinks.pop(k, None)), grad_view)
+
+
+def get(param: torch.Tensor) -> Optional[torch.Tensor]:
+    hit = _sinks.get(id(param))
+    if hit is not None and hit[0]() is param:
+        return hit[1]
+    return None

@@ -294,6 +294,10 @@ def seq_mean_fwd(x, y, B, S, D, scale=1.0):
     _call("hulc_seq_mean_fwd", x, y, _i(B), _i(S), _i(D), _f(scale))
 
 
+def strided_seq_sum(x, y, B, S, D, stride_b, stride_s, ldy, scale=1.0):
+    _call("hulc_strided_seq_sum", x, _i(_dt(x)), y, _i(B), _i(S), _i(D), _l(stride_b), _l(stride_s), _l(ldy), _f(scale))
+
+
 def seq_mean_bwd(dy, dx, B, S, D):
     _call("hulc_seq_mean_bwd", dy, dx, _i(B), _i(S), _i(D))
 

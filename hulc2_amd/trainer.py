@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import gradsink
 from . import kernels as kn
 from . import shadow
 
@@ -124,6 +125,10 @@ class ArenaTrainer:
             kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, total)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
+        gradsink.clear()
+        if dev.type == "cuda" and (self.world == 1 or not overlap):     # no per-parameter all-reduce hooks depend on AccumulateGrad
+            for p, off in zip(self.params, self.offsets):
+                gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape))
         self.step_count = 0
         self.dev = dev
         self.graph_fb = self.graph_opt = None

@@ -103,6 +103,10 @@ int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, 
  * plain sum used by the decoder backward) and the gradient of the mean. */
 int hulc_seq_mean_fwd(const float* x, float* y, int B, int S, int D, float scale, void* stream);
 int hulc_seq_mean_bwd(const float* dy, float* dx, int B, int S, int D, void* stream);
+/* y[b*ldy + d] = scale * sum_s x[b*stride_b + s*stride_s + d]: time sums over the time-major recurrent buffers
+ * (gradient of the per-sequence constant part of the decoder's input projection). */
+int hulc_strided_seq_sum(const void* x, int x_dtype, float* y, int B, int S, int D, long stride_b, long stride_s, long ldy,
+                         float scale, void* stream);
 /* y = dropout(x[B][S][D] + pos[pos_ids[s]][:]) (plan_recognition_net.py:133-136,142); dropout_bwd: dx = dy * mask. */
 int hulc_add_pos_fwd(const float* x, const float* pos, const long* pos_ids, float* y, int B, int S, int D, float drop_p,
                      unsigned long long seed, const unsigned long long* seed_dev, void* stream);
