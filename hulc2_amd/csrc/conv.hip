@@ -23,10 +23,11 @@
 #include <stdlib.h>
 
 // LDS-band kernel (conv_band.hip): 0 = launched, 1 = geometry not covered (use the gather kernel), < 0 = error
-int hulc_conv_band_dispatch(int C, int COUT, int TH, int TW, int S, const void* x, int x_dtype, int N, int H, int W, int OH, int OW,
-                            int pad_y, int pad_x, long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx,
-                            const void* wt, int w_dtype, long ldw, const long* w_tap_off, const float* bias, const void* mask,
-                            int mask_dtype, int relu, hipStream_t s);
+int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* x, int x_dtype, int N, int H, int W, int pad_y, int pad_x,
+                            long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
+                            int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
+                            const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
+                            const long* cls_wtap, hipStream_t s);
 
 namespace {
 
@@ -435,10 +436,16 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
-    if (d->compute == HULC_BF16 && !d->x_nchw && d->KH * d->KW <= 16) {
-        rc = hulc_conv_band_dispatch(d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, g.OH, g.OW, 0, 0,
-                                     g.x_sn, g.x_sy, g.x_sx, y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, g.w_tap_off,
-                                     bias, nullptr, HULC_F32, d->relu, (hipStream_t)stream);
+    if (d->compute == HULC_BF16 && !d->x_nchw && d->KH * d->KW <= 16 && d->Cout % 32 == 0 && d->Cout / 32 <= 4) {
+        const int nset = d->Cout / 32;
+        int cOH[4], cOW[4], cco[4]; long cyo[4], cw0[4], ctap[4 * 16];
+        for (int c = 0; c < nset; ++c) {
+            cOH[c] = g.OH; cOW[c] = g.OW; cyo[c] = 0; cco[c] = 32 * c; cw0[c] = 32 * c;
+            for (int t = 0; t < 16; ++t) ctap[c * 16 + t] = t < d->KH * d->KW ? g.w_tap_off[t] : 0;
+        }
+        rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
+                                     y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
+                                     cOH, cOW, cyo, cco, cw0, ctap, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
     }
@@ -455,6 +462,30 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
     if (d->Cin != 32 && d->Cin != 64) return hulc_fail(-5, "conv bwd_data: Cin must be 32 or 64");
     const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1, s = d->stride;
     const int xsz = d->x_dtype == HULC_F32 ? 4 : 2;
+    // LDS-band kernel: all stride^2 parity classes x Cin/32 channel tiles in ONE launch sharing one staged dY band
+    if (d->compute == HULC_BF16 && !getenv("HULC_NO_BAND_DGRAD") && d->Cin % 32 == 0 && d->KH % s == 0 && d->KW % s == 0) {
+        const int U = d->KH / s, V = d->KW / s, tiles = d->Cin / 32, nset = s * s * tiles;
+        if (nset <= 4 && U * V <= 16) {
+            int cOH[4], cOW[4], cco[4]; long cyo[4], cw0[4], ctap[4 * 16];
+            int c = 0;
+            for (int py = 0; py < s; ++py)
+                for (int px = 0; px < s; ++px)
+                    for (int j = 0; j < tiles; ++j, ++c) {
+                        cOH[c] = (d->H - py + s - 1) / s; cOW[c] = (d->W - px + s - 1) / s;
+                        cyo[c] = ((long)py * d->W + px) * d->Cin; cco[c] = 32 * j; cw0[c] = 32 * j;
+                        for (int t = 0; t < 16; ++t) ctap[c * 16 + t] = 0;
+                        for (int ty = 0; ty < U; ++ty)
+                            for (int tx = 0; tx < V; ++tx)
+                                ctap[c * 16 + ty * V + tx] = ((long)(py + s * (U - 1 - ty)) * d->KW + (px + s * (V - 1 - tx))) * d->Cout;
+                    }
+            const int brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
+                                                    (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
+                                                    (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
+                                                    nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, (hipStream_t)stream);
+            if (brc < 0) return brc;
+            if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_data(band)");
+        }
+    }
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
             GatherP g;
@@ -483,23 +514,6 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             g.y_sn = (long)d->H * d->W * d->Cin; g.y_sy = (long)s * d->W * d->Cin; g.y_sx = (long)s * d->Cin;
             g.mask = relu_src ? (const char*)relu_src + yoff * xsz : nullptr; g.mask_dtype = d->x_dtype; g.mask_scale = 1.f;
             g.relu = 0;
-            // LDS-band kernel for the data gradient: correct (tests run it with HULC_BAND_DGRAD=1) but, re-staging dY once per
-            // parity class and with a 2-byte-store epilogue, it measures slower than the gather kernel (tools/conv_bench.py:
-            // conv2 0.75 vs 0.61 ms, conv3 0.26 vs 0.27 ms) -> opt-in until the classes share one staged band
-            if (d->compute == HULC_BF16 && getenv("HULC_BAND_DGRAD")) {
-                const int Uy = (d->KH - py + s - 1) / s, Ux = (d->KW - px + s - 1) / s;
-                if (Uy * Ux <= 16) {
-                    long woff[16];
-                    for (int ty = 0; ty < Uy; ++ty)
-                        for (int tx = 0; tx < Ux; ++tx)
-                            woff[ty * Ux + tx] = ((long)(py + s * (Uy - 1 - ty)) * d->KW + (px + s * (Ux - 1 - tx))) * d->Cout;
-                    int brc = hulc_conv_band_dispatch(d->Cout, d->Cin, Uy, Ux, 1, dy, d->y_dtype, d->N, OH, OW, g.OH, g.OW, Uy - 1, Ux - 1,
-                                                      g.x_sn, g.x_sy, g.x_sx, g.Y, g.y_dtype, g.y_sn, g.y_sy, g.y_sx, wt, d->w_dtype, g.ldw,
-                                                      woff, nullptr, g.mask, g.mask_dtype, 0, (hipStream_t)stream);
-                    if (brc < 0) return brc;
-                    if (brc == 0) continue;
-                }
-            }
             if (d->compute == HULC_F32) {
                 if (d->y_dtype != HULC_F32 || d->w_dtype != HULC_F32) return hulc_fail(-6, "conv bwd_data: f32 compute requires f32 operands");
                 launch_gather<float>(g, (hipStream_t)stream);

@@ -3,191 +3,203 @@
 // reference arithmetic: nn.Conv2d(+ReLU) of hulc2/models/perceptual_encoders/vision_network.py:41-46 and
 // vision_network_gripper.py:15-19, and autograd's conv2d input gradient.
 //
-// The gather kernel in conv.hip re-reads every input element KH*KW/s^2 times through L1 in 16-byte pieces; here
-// a workgroup stages (once, coalesced) the band of input rows its output rows need AND the layer's whole weight
-// matrix into LDS, after which the k-loop has no global loads and no barriers: every MFMA operand is one
-// ds_read_b128 — pixel fragment straight out of the band (pixel stride padded by 16 B: conflict-free), weight
-// fragment out of the resident [Cout][K] image.  Zero padding (data gradients) is written into the band.
-//   work unit  = (frame, band of R output rows); workgroups walk units persistently, weights are loaded once
-//   wave       = two 32-pixel tiles x all output channels (TM = 2, TN = Cout/32)
-//   correlation: in(y,x) = band[(oy*S + ty)][(ox*S + tx)], ty < TH, tx < TW (pad folded into the band origin)
+// The gather kernel in conv.hip re-reads every input element KH*KW/s^2 times through L1 in 16-byte pieces.  Here:
+//   * weight-stationary: each of the 8 waves keeps ONE 32-row weight tile (32 output channels x K) in registers for the
+//     whole launch (144 VGPRs at K = 576) — "weight sets" are the output-channel tiles of a forward conv, or the
+//     stride^2 parity classes of a data gradient (each class = a dense stride-1 correlation with its own taps);
+//   * the band of input rows a work unit (frame x band of output rows) needs is staged ONCE into LDS, coalesced, zero
+//     padding included; the NEXT unit's band is prefetched into registers before the MFMA loop and written to LDS after
+//     it, so HBM latency and the all-workgroups-at-once bandwidth burst hide under compute with a single LDS buffer;
+//   * the k-loop has no global loads and no barriers: one ds_read_b128 per MFMA (pixel fragment straight out of the band,
+//     pixel stride padded by 16 B -> conflict-free);
+//   * MFMA roles are swapped (A = weights, B = pixels) so D[channel][pixel] leaves every lane with ONE pixel and groups of
+//     four consecutive channels: the epilogue is 8-byte (bf16) / 16-byte (fp32) stores, no LDS transpose, no divisions.
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 #include <stdlib.h>
 
 namespace {
 
+#define BAND_MAXCLS 4
+struct BandCls {
+    int OH, OW;                     // output grid of this weight set's class
+    long y_off;                     // element offset of the class inside Y / mask (parity classes of a data gradient)
+    int co_base;                    // first output channel of the set's 32-channel tile
+    long w_row0;                    // first global weight row of the set
+    long w_tap_off[16];             // global offset (elements, inside a weight row) of tap (ty, tx)
+};
 struct BandP {
     const void* X; void* Y; const void* Wt; const float* bias; const void* mask;
     int x_dtype, y_dtype, w_dtype, mask_dtype;
     int Nimg, H, W;                 // input tensor dims (NHWC, C = template)
-    int OH, OW;                     // output grid of this launch
+    int OHmax, OWmax;               // largest class grid: defines the staged band
     int pad_y, pad_x;               // band origin: input row = oy*S + ty - pad_y
     int R;                          // output rows per work unit
     long x_sn, x_sy, x_sx;          // input element strides
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
-    long w_tap_off[16];             // global offset (elements, inside a weight row) of tap (ty, tx)
-    int relu; float mask_scale;
-    long long* dbg;                 // optional per-workgroup phase cycle counters (tools/conv_one.py), normally null
+    int relu;
+    BandCls cls[BAND_MAXCLS];
 };
 
-template <int C, int COUT, int TH, int TW, int S>
+HULC_DEVICE uint4 band_load_bits(const void* X, int dtype, long off) {
+    if (dtype == HULC_BF16) return *(const uint4*)((const uint16_t*)X + off);
+    const float4* q = (const float4*)((const float*)X + off);
+    const float4 a = q[0], c = q[1];
+    uint4 t;
+    t.x = pack_bf16x2(a.x, a.y); t.y = pack_bf16x2(a.z, a.w); t.z = pack_bf16x2(c.x, c.y); t.w = pack_bf16x2(c.z, c.w);
+    return t;
+}
+
+// C: input channels, NSET: weight sets (32 output channels each), TH x TW taps, S: input stride, MAXCH: band chunks/thread
+template <int C, int NSET, int TH, int TW, int S, int MAXCH>
 __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
-    constexpr int NT = 512, NWAVE = 8;
-    constexpr int K = TH * TW * C;
+    constexpr int NT = 512;
+    constexpr int K = TH * TW * C, KSTEPS = K / 16;
     constexpr int PS = C * 2 + 16;          // band pixel stride (bytes): +16 B keeps ds_read_b128 conflict-free
-    constexpr int WS = K * 2 + 16;          // weight row stride (bytes)
-    constexpr int TN = COUT / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wlds = smem;                      // [COUT][WS]
-    long* ooff = (long*)(smem + COUT * WS); // [8 waves][2 tiles][32] output element offsets (no divisions in the epilogue)
-    char* band = smem + COUT * WS + 8 * 2 * 32 * 8;   // [rows][Wb][PS]
+    constexpr int WPS = 8 / NSET;           // waves per weight set
+    constexpr int CPP = C / 8;              // 16-byte chunks per pixel
+    static_assert(NT % CPP == 0, "a thread keeps one channel chunk");
+    extern __shared__ __attribute__((aligned(16))) char band[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int Wb = (p.OW - 1) * S + TW;                     // band columns (padding included)
-    const int bands = (p.OH + p.R - 1) / p.R;
+    const int set = wave % NSET, part = wave / NSET;
+    const BandCls& cl = p.cls[set];
+    const int Wb = (p.OWmax - 1) * S + TW;                  // band columns (padding included)
+    const int bands = (p.OHmax + p.R - 1) / p.R;
     const int nunits = p.Nimg * bands;
 
-    long long t_w = 0, t_s = 0, t_c = 0, t0 = clock64();
-    // ---- weights -> LDS (once per workgroup), dense [cout][(ty,tx,c)] from the tap table
-    constexpr int WCH = COUT * (K / 8);
-#pragma unroll 4
-    for (int id = tid; id < (WCH + NT - 1) / NT * NT; id += NT) {
-        const int idc = id < WCH ? id : 0;
-        const int co = idc / (K / 8), kc = idc % (K / 8);
-        const int t = (kc * 8) / C, c0 = (kc * 8) % C;
-        Chunk8 ch;
-        chunk_load_contig(ch, p.Wt, p.w_dtype, (long)co * p.ldw + p.w_tap_off[t] + c0);
-        if (id < WCH) chunk_store_lds<bf16_t>(wlds + co * WS + kc * 16, ch);
+    // ---- this wave's weight tile -> registers (A operand: lane = output channel row, 8 consecutive k)
+    bf16x8_t wfrag[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int k0 = ks * 16 + h * 8;
+        const int t = k0 / C, c0 = k0 % C;
+        union { uint4 u; bf16x8_t b; } x;
+        x.u = band_load_bits(p.Wt, p.w_dtype, (cl.w_row0 + r) * p.ldw + cl.w_tap_off[t] + c0);
+        wfrag[ks] = x.b;
     }
 
-    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-        const int n = unit / bands, b = unit % bands;
-        const int r0 = b * p.R;
-        const int R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0;
-        const int rows = (R - 1) * S + TH;
-        const int iy0 = r0 * S - p.pad_y, ix0 = -p.pad_x;
-        __syncthreads();                                    // previous unit's reads are done (and weights are visible)
-        if (unit == (int)blockIdx.x) { t_w = clock64() - t0; }
-        long long t1 = clock64();
-        // ---- stage the input band (zero outside the tensor).  Loads are issued UNR deep before the first LDS write so
-        //      the band arrives at memory-level parallelism instead of one L2/HBM round trip per chunk.
-        const int nchunk = rows * Wb * (C / 8);
-        constexpr int UNR = 8;
-        for (int base = 0; base < nchunk; base += NT * UNR) {
-            uint4 v[UNR]; int dst[UNR];
+    // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
+    const int cc = tid % CPP;
+    uint4 pre[MAXCH];
+    auto band_rows = [&](int unit, int& n, int& r0, int& R, int& rows) {
+        n = unit / bands; const int b = unit % bands;
+        r0 = b * p.R; R = (r0 + p.R <= p.OHmax) ? p.R : p.OHmax - r0; rows = (R - 1) * S + TH;
+    };
+    auto stage_load = [&](int unit) {
+        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
+        const int iy0 = r0 * S - p.pad_y, npx = rows * Wb;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int id = base + u * NT + tid;
-                const int idc = id < nchunk ? id : 0;
-                const int cc = idc % (C / 8); const int px = idc / (C / 8);
-                const int bc = px % Wb, br = px / Wb;
-                const int iy = iy0 + br, ix = ix0 + bc;
-                dst[u] = id < nchunk ? (br * Wb + bc) * PS + cc * 16 : -1;
-                const bool inb = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                // unconditional load from a clamped address, then select: no branch (and no vmcnt(0)) around the load
-                const long off = inb ? (long)n * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
-                uint4 t;
-                if (p.x_dtype == HULC_BF16) t = *(const uint4*)((const uint16_t*)p.X + off);
-                else {
-                    const float4* q = (const float4*)((const float*)p.X + off);
-                    const float4 a = q[0], c = q[1];
-                    t.x = pack_bf16x2(a.x, a.y); t.y = pack_bf16x2(a.z, a.w); t.z = pack_bf16x2(c.x, c.y); t.w = pack_bf16x2(c.z, c.w);
-                }
-                v[u].x = inb ? t.x : 0u; v[u].y = inb ? t.y : 0u; v[u].z = inb ? t.z : 0u; v[u].w = inb ? t.w : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u)
-                if (dst[u] >= 0) *(uint4*)(band + dst[u]) = v[u];
+        for (int j = 0; j < MAXCH; ++j) {
+            const int px = tid / CPP + j * (NT / CPP);
+            const int pxc = px < npx ? px : 0;
+            const int br = pxc / Wb, bc = pxc % Wb;
+            const int iy = iy0 + br, ix = bc - p.pad_x;
+            const bool inb = px < npx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            // unconditional load from a clamped address, then select (no branch around the load)
+            const long off = inb ? (long)n * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
+            const uint4 t = band_load_bits(p.X, p.x_dtype, off);
+            pre[j].x = inb ? t.x : 0u; pre[j].y = inb ? t.y : 0u; pre[j].z = inb ? t.z : 0u; pre[j].w = inb ? t.w : 0u;
         }
-        __syncthreads();
-        t_s += clock64() - t1; t1 = clock64();
+    };
+    auto stage_store = [&](int unit) {
+        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
+        const int npx = rows * Wb;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int px = tid / CPP + j * (NT / CPP);
+            if (px < npx) *(uint4*)(band + px * PS + cc * 16) = pre[j];
+        }
+    };
 
-        // ---- compute: pairs of 32-pixel tiles per wave
-        const int npix = R * p.OW;
+    int unit = blockIdx.x;
+    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    __syncthreads();
+    for (; unit < nunits; unit += gridDim.x) {
+        const int next = unit + gridDim.x;
+        if (next < nunits) stage_load(next);                 // in flight during the MFMA loop below
+
+        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
+        const int Rc = r0 < cl.OH ? ((r0 + R <= cl.OH) ? R : cl.OH - r0) : 0;   // this class may have fewer rows/cols
+        const int npix = Rc * cl.OW;
         const int ntile = (npix + 31) / 32;
-        for (int tp = wave; tp * 2 < ntile; tp += NWAVE) {
-            int pix[2], abase[2];
+        for (int tile = part; tile < ntile; tile += WPS) {
+            int q = tile * 32 + r;
+            const bool live = q < npix;
+            if (!live) q = npix - 1;
+            const int oy = q / cl.OW, ox = q % cl.OW;
+            const char* a0 = band + ((oy * S) * Wb + ox * S) * PS + h * 16;
+            f32x16_t acc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int q = (tp * 2 + i) * 32 + r;
-                pix[i] = q;
-                if (q >= npix) q = npix - 1;
-                const int oy = q / p.OW, ox = q % p.OW;
-                abase[i] = ((oy * S) * Wb + ox * S) * PS + h * 16;
-                if (h == 0) ooff[(wave * 2 + i) * 32 + r] = pix[i] < npix ? (long)n * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx : -1;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int k0 = ks * 16;
+                const int t = k0 / C, c0 = k0 % C;
+                const int ty = t / TW, tx = t % TW;
+                const bf16x8_t px = *(const bf16x8_t*)(a0 + (ty * Wb + tx) * PS + c0 * 2);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);   // D[channel][pixel]
             }
-            f32x16_t acc[2][TN];
+            // ---- epilogue: lane = pixel; registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}
+            if (live) {
+                const long off = cl.y_off + (long)n * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int g = 0; g < 4; ++g) {
+                    // registers 4g..4g+3 hold channels co_base + 8g + 4h + {0..3}: one aligned float4 of the bias vector
+                    const float4 bv = p.bias ? *(const float4*)(p.bias + cl.co_base + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    if (p.relu) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-            for (int ty = 0; ty < TH; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < TW; ++tx)
-#pragma unroll
-                    for (int c0 = 0; c0 < C; c0 += 16) {
-                        const int aoff = (ty * Wb + tx) * PS + c0 * 2;
-                        const int koff = ((ty * TW + tx) * C + c0) * 2 + h * 16;
-                        bf16x8_t a[2], bw[TN];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8_t*)(band + abase[i] + aoff);
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) bw[j] = *(const bf16x8_t*)(wlds + (j * 32 + r) * WS + koff);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bw[j], acc[i][j], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-            // ---- epilogue: lane = output channel, accumulator register = pixel
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = j * 32 + r;
-                const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const long po = ooff[(wave * 2 + i) * 32 + acc_row(e, lane)];   // written by this wave above: wave-local LDS, in order
-                        if (po < 0) continue;
-                        const long off = po + co;
-                        float v = acc[i][j][e] + bv;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (p.mask) v = load_elem(p.mask, p.mask_dtype, off) > 0.f ? v * p.mask_scale : 0.f;
-                        store_elem(p.Y, p.y_dtype, off, v);
+                    if (p.mask) {
+                        if (p.mask_dtype == HULC_BF16) {
+                            const uint2 m = *(const uint2*)((const uint16_t*)p.mask + off + 8 * g);
+                            if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+                            if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                            if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+                            if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+                        } else {
+                            const float4 m = *(const float4*)((const float*)p.mask + off + 8 * g);
+                            if (!(m.x > 0.f)) v[0] = 0.f;
+                            if (!(m.y > 0.f)) v[1] = 0.f;
+                            if (!(m.z > 0.f)) v[2] = 0.f;
+                            if (!(m.w > 0.f)) v[3] = 0.f;
+                        }
                     }
+                    if (p.y_dtype == HULC_BF16) {
+                        uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)((uint16_t*)p.Y + off + 8 * g) = o;
+                    } else *(float4*)((float*)p.Y + off + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
-            (void)pix;
         }
-        t_c += clock64() - t1;
+        __syncthreads();                                     // every wave is done reading this band
+        if (next < nunits) stage_store(next);
+        __syncthreads();
     }
-    if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 4] = t_w; p.dbg[blockIdx.x * 4 + 1] = t_s; p.dbg[blockIdx.x * 4 + 2] = t_c; p.dbg[blockIdx.x * 4 + 3] = clock64() - t0; }
 }
 
-template <int C, int COUT, int TH, int TW, int S>
+template <int C, int NSET, int TH, int TW, int S, int MAXCH>
 int launch_band(BandP& p, hipStream_t s) {
-    constexpr int K = TH * TW * C, PS = C * 2 + 16, WS = K * 2 + 16;
-    const int Wb = (p.OW - 1) * S + TW;
-    const long wbytes = (long)COUT * WS;
-    const long budget = 160 * 1024 - wbytes - 8 * 2 * 32 * 8 - 256;
-    // rows per unit: as many output rows as the LDS band allows (whole frame when it fits)
-    int R = p.OH;
-    while (R > 1 && (long)((R - 1) * S + TH) * Wb * PS > budget) --R;
-    if ((long)((R - 1) * S + TH) * Wb * PS > budget) return -1;
-    // balance: equal-ish bands
-    const int bands = (p.OH + R - 1) / R;
-    R = (p.OH + bands - 1) / bands;
+    constexpr int PS = C * 2 + 16, CPP = C / 8;
+    const int Wb = (p.OWmax - 1) * S + TW;
+    const long budget = 160 * 1024 - 512;
+    const long max_px = (long)MAXCH * (512 / CPP);           // pixels one register-staged band can hold
+    int R = p.OHmax;
+    auto px_of = [&](int rr) { return (long)((rr - 1) * S + TH) * Wb; };
+    while (R > 1 && (px_of(R) * PS > budget || px_of(R) > max_px)) --R;
+    if (px_of(R) * PS > budget || px_of(R) > max_px) return -1;
+    const int bands = (p.OHmax + R - 1) / R;
+    R = (p.OHmax + bands - 1) / bands;                       // equal-ish bands
     p.R = R;
-    const size_t lds = (size_t)wbytes + 8 * 2 * 32 * 8 + (size_t)((R - 1) * S + TH) * Wb * PS;
-    if ((long)R * p.OW < 128) return -1;        // tiny frames: one unit cannot feed 8 waves, the gather kernel is faster
+    if ((long)R * p.OWmax < 128) return -1;                  // tiny frames: one unit cannot feed 8 waves, the gather kernel is faster
+    const size_t lds = (size_t)px_of(R) * PS;
     const int nunits = p.Nimg * bands;
     const int grid = nunits < 256 ? nunits : 256;
-    auto kern = conv_band_kernel<C, COUT, TH, TW, S>;
+    auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
@@ -199,28 +211,36 @@ int launch_band(BandP& p, hipStream_t s) {
 
 }  // namespace
 
+// One launch covering `ncls` weight sets (output-channel tiles of a forward conv, or parity classes of a data gradient).
 // returns 0 when the band kernel took the launch, 1 when the geometry is not covered (caller falls back to the gather
-// kernel), negative on error.  Only bf16 compute; NHWC input with C in {32, 64}.
-int hulc_conv_band_dispatch(int C, int COUT, int TH, int TW, int S, const void* x, int x_dtype, int N, int H, int W, int OH, int OW,
-                            int pad_y, int pad_x, long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx,
-                            const void* wt, int w_dtype, long ldw, const long* w_tap_off, const float* bias, const void* mask,
-                            int mask_dtype, int relu, hipStream_t s) {
+// kernel), negative on error.  bf16 compute only; NHWC input with C in {32, 64}; 32 output channels per set.
+int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* x, int x_dtype, int N, int H, int W, int pad_y, int pad_x,
+                            long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
+                            int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
+                            const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
+                            const long* cls_wtap /* [ncls][16] */, hipStream_t s) {
     if (getenv("HULC_NO_BAND")) return 1;
+    if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
     BandP p;
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
-    p.Nimg = N; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x; p.R = OH;
+    p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
-    p.ldw = ldw; p.relu = relu; p.mask_scale = 1.f;
-    { const char* e = getenv("HULC_BAND_DBG"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-    for (int t = 0; t < TH * TW && t < 16; ++t) p.w_tap_off[t] = w_tap_off[t];
+    p.ldw = ldw; p.relu = relu;
+    p.OHmax = 0; p.OWmax = 0;
+    for (int c = 0; c < ncls; ++c) {
+        p.cls[c].OH = cls_OH[c]; p.cls[c].OW = cls_OW[c]; p.cls[c].y_off = cls_yoff[c]; p.cls[c].co_base = cls_cobase[c];
+        p.cls[c].w_row0 = cls_wrow0[c];
+        for (int t = 0; t < 16; ++t) p.cls[c].w_tap_off[t] = t < TH * TW ? cls_wtap[c * 16 + t] : 0;
+        if (cls_OH[c] > p.OHmax) p.OHmax = cls_OH[c];
+        if (cls_OW[c] > p.OWmax) p.OWmax = cls_OW[c];
+    }
     int rc = 1;
-    // measured (tools/conv_bench.py, 1024 frames): conv3 forward 0.090 ms vs 0.143 ms gather; conv2 forward on par
-    if (C == 32 && COUT == 64 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 64, 4, 4, 2>(p, s);
-    else if (C == 64 && COUT == 64 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 64, 3, 3, 1>(p, s);
-    else if (C == 64 && COUT == 32 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 32, 2, 2, 1>(p, s);
+    if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12>(p, s);        // conv2 forward
+    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10>(p, s);   // conv3 forward / data gradient
+    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12>(p, s);   // conv2 data gradient, 4 parity classes
     else return 1;
-    if (rc == -1) return 1;                      // band does not fit LDS: gather kernel
+    if (rc == -1) return 1;                      // band does not fit: gather kernel
     if (rc < 0) return hulc_fail(-8, "conv band: could not raise the dynamic LDS limit");
     return 0;
 }
