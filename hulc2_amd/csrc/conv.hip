@@ -28,6 +28,9 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
                             const long* cls_wtap, hipStream_t s);
+// LDS-band weight gradient (conv_wgrad_band.hip): same return convention
+int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
+                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, hipStream_t s);
 
 namespace {
 
@@ -538,6 +541,7 @@ extern "C" long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d) {
     if (!d) return -1;
     long P, ppb, K, Mtot;
     wgrad_split(d, P, ppb, K, Mtot);
+    if (P < 512) P = 512;                                    // the band kernel writes one slab per persistent workgroup (<= 512)
     return P * d->Cout * (K + 1) * (long)sizeof(float);
 }
 
@@ -546,6 +550,13 @@ extern "C" long hulc_conv2d_bwd_weight_workspace(const hulc_conv_desc* d) {
 extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, const void* dy, float* dw, float* db, void* ws, void* stream) {
     int rc = validate(d, "bwd_weight"); if (rc) return rc;
     if (!x || !dy || !dw || !ws) return hulc_fail(-1, "hulc_conv2d_bwd_weight: null pointer");
+    if (d->compute == HULC_BF16) {                           // LDS-band kernel (conv_wgrad_band.hip) for the geometries it covers
+        const long wsb = hulc_conv2d_bwd_weight_workspace(d);
+        const int brc = hulc_conv_wgrad_band_dispatch(d->x_nchw, d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, dy, d->y_dtype,
+                                                      d->N, d->H, d->W, dw, db, ws, wsb, (hipStream_t)stream);
+        if (brc < 0) return brc;
+        if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_weight(band)");
+    }
     WgradP p; fill_gather(p.g, d);
     p.g.X = x; p.g.Wt = nullptr; p.g.bias = nullptr; p.g.Y = nullptr; p.g.mask = nullptr;
     p.dY = dy; p.dy_dtype = d->y_dtype;
