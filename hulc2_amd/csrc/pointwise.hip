@@ -180,33 +180,77 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, long ld, int accumulate) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float s = 0.f;
-    for (int q = 0; q < P; ++q) s += partial[(long)q * ld + r];
-    out[r] = accumulate ? out[r] + s : s;
+// ------------------------------------------------------------------------------------------------
+// column sums: out[n] = sum_m x[m][n]   (bias gradients).  HBM-bound: M*N*sizeof(x) bytes read once.
+// Workgroup = 4 waves; a lane owns 4 adjacent columns (one 16-byte / 8-byte load per row), the waves interleave rows,
+// 4 rows are in flight per lane.  Row blocks are sized so that >= ~1024 workgroups exist; partials are summed in a
+// fixed order by reduce_rows_wide_kernel (deterministic).
+// ------------------------------------------------------------------------------------------------
+__device__ inline float4 load4(const void* x, int dt, long off) {
+    if (dt == HULC_F32) return *(const float4*)((const float*)x + off);
+    const uint2 v = *(const uint2*)((const uint16_t*)x + off);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
 }
-
-// ------------------------------------------------------------------------------------------------
-// column sums: out[n] = sum_m x[m][n]   (bias gradients).  Workgroup = 4 waves x 64 columns.
-// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int x_dtype, long M, int N, long ld, long rows_per_block,
-                                                     float* __restrict__ partial, float* __restrict__ direct_out, int accumulate) {
-    __shared__ float red[4][64];
+                                                     float* __restrict__ partial, float* __restrict__ direct_out, int accumulate, int vec) {
+    __shared__ float4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int n = (blockIdx.x * 64 + lane) * 4;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
-    float s = 0.f;
-    if (n < N)
-        for (long r = r0 + wave; r < r1; r += 4) s += load_elem(x, x_dtype, r * ld + n);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+        if (n < N) {
+            long r = r0 + wave;
+            float4 a0 = s, a1 = s, a2 = s, a3 = s;
+            for (; r + 12 < r1; r += 16) {
+                const float4 v0 = load4(x, x_dtype, r * ld + n), v1 = load4(x, x_dtype, (r + 4) * ld + n);
+                const float4 v2 = load4(x, x_dtype, (r + 8) * ld + n), v3 = load4(x, x_dtype, (r + 12) * ld + n);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; r < r1; r += 4) { const float4 v = load4(x, x_dtype, r * ld + n); a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
+            s.x = (a0.x + a1.x) + (a2.x + a3.x); s.y = (a0.y + a1.y) + (a2.y + a3.y);
+            s.z = (a0.z + a1.z) + (a2.z + a3.z); s.w = (a0.w + a1.w) + (a2.w + a3.w);
+        }
+    } else {
+        float* sp = (float*)&s;
+        for (int j = 0; j < 4; ++j)
+            if (n + j < N)
+                for (long r = r0 + wave; r < r1; r += 4) sp[j] += load_elem(x, x_dtype, r * ld + n + j);
+    }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && n < N) {
-        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        if (direct_out) direct_out[n] = accumulate ? direct_out[n] + v : v;      // single row block: no second pass
-        else partial[(long)blockIdx.y * N + n] = v;
+    if (wave == 0) {
+        const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+        const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+        for (int j = 0; j < 4; ++j) {
+            if (n + j >= N) break;
+            if (direct_out) direct_out[n + j] = accumulate ? direct_out[n + j] + v[j] : v[j];      // single row block: no second pass
+            else partial[(long)blockIdx.y * N + n + j] = v[j];
+        }
+    }
+}
+// out[r] (+)= sum_q partial[q*ld + r]: 64 columns x 16 row slices per workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void reduce_rows_wide_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, long ld,
+                                                                int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long rr = (long)blockIdx.x * 64 + lane;
+    const int per = (P + 15) / 16;
+    const int q0 = sl * per, q1 = q0 + per < P ? q0 + per : P;
+    float s = 0.f;
+    if (rr < R)
+        for (int q = q0; q < q1; ++q) s += partial[(long)q * ld + rr];
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && rr < R) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[rr] = accumulate ? out[rr] + t : t;
     }
 }
 
@@ -476,26 +520,33 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
     hipStream_t s = (hipStream_t)stream;
     layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, seed_dev, (float*)ws);
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
-    reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, 0);
-    reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, 0);
+    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, 0);
+    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, 0);
     return hulc_check_launch("hulc_layernorm_bwd");
 }
 
-extern "C" long hulc_colsum_workspace(long M, int N) {
-    long rb = (M + 511) / 512; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-    return rb * N * (long)sizeof(float);
+static long colsum_row_blocks(long M, int N) {
+    const long gx = (N + 255) / 256;
+    long rb = (1024 + gx - 1) / gx;                     // >= ~1024 workgroups ...
+    const long cap = (M + 31) / 32;                     // ... of at least 32 rows each
+    if (rb > cap) rb = cap;
+    if (rb > 512) rb = 512;
+    if (rb < 1) rb = 1;
+    return rb;
 }
+extern "C" long hulc_colsum_workspace(long M, int N) { return colsum_row_blocks(M, N) * N * (long)sizeof(float); }
 
 extern "C" int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream) {
     if (!x || !out || !ws) return hulc_fail(-1, "hulc_colsum: null pointer");
-    long rb = (M + 511) / 512; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-    if (M <= 2048 && N >= 1024) rb = 1;                 // wide and short: enough column groups to fill the chip alone
+    long rb = colsum_row_blocks(M, N);
     const long rpb = (M + rb - 1) / rb;
     rb = (M + rpb - 1) / rpb;
+    const int esz = x_dtype == HULC_F32 ? 4 : 2;
+    const int vec = (N % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((N + 63) / 64, (unsigned)rb);
-    colsum_kernel<<<grid, 256, 0, s>>>(x, x_dtype, M, N, ld, rpb, (float*)ws, rb == 1 ? out : nullptr, accumulate);
-    if (rb > 1) reduce_rows_kernel<<<(N + 255) / 256, 256, 0, s>>>((const float*)ws, out, (int)rb, N, N, accumulate);
+    dim3 grid((N + 255) / 256, (unsigned)rb);
+    colsum_kernel<<<grid, 256, 0, s>>>(x, x_dtype, M, N, ld, rpb, (float*)ws, rb == 1 ? out : nullptr, accumulate, vec);
+    if (rb > 1) reduce_rows_wide_kernel<<<(N + 63) / 64, 1024, 0, s>>>((const float*)ws, out, (int)rb, N, N, accumulate);
     return hulc_check_launch("hulc_colsum");
 }
 
