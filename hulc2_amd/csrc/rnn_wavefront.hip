@@ -1,0 +1,243 @@
+// rnn_wavefront.hip — the 2-layer ReLU RNN of the action decoder as ONE persistent kernel per direction (bf16 compute).
+//
+// reference arithmetic: nn.RNN(num_layers=2, nonlinearity="relu", batch_first=True) of
+// hulc2/models/decoders/logistic_decoder_rnn.py:70-79 (forward) and its autograd backward.
+//
+// The recurrence is latency-bound: per time step two skinny GEMMs (64 rows, K = 2048 / 4096) whose 25 MB of weights were
+// re-streamed by ~130 launches per direction (12 us kernel + 4 us split-K epilogue each).  With
+//     z_t = [h0_t | h1_{t-1}]  (one row block of the time-major state buffer)
+// both layers advance together as a wavefront:     z_{t+1} = f( z_t W^T + add_t ),   W = [[W_hh0, 0], [W_ih1, W_hh1]]
+// and the backward pass has the same shape on d_t = [delta1_t | delta0_{t+1}] with W = [[W_hh1^T, 0], [W_ih1^T, W_hh0^T]].
+// So one kernel serves both directions:
+//   * 256 workgroups (one per CU) = 2 row halves x H/16 column groups; a workgroup owns 16 "first" + 16 "second" output
+//     columns for 32 batch rows and keeps its 16+16 weight columns (x K = 2H) in REGISTERS for all S+1 wave steps
+//     (96 VGPRs per wave) — weights are read from HBM once per pass instead of once per step;
+//   * per wave step a workgroup reads its 32 rows of the bf16 state copy (256 KB, from L2), runs v_mfma_f32_16x16x32_bf16
+//     with the 8 waves splitting K, sums the 8 partial tiles through LDS in a fixed order (deterministic), applies the
+//     epilogue (bias / external add / ReLU or stored-activation mask) and writes fp32 (for the weight-gradient GEMMs) and
+//     bf16 (its own next operand, ping-pong) state;
+//   * wave steps are separated by a device-wide barrier (agent-scope release/acquire on one counter).  All 256 workgroups
+//     are co-resident (1 per CU by register footprint; the stream runs nothing else), the spin is bounded, and a timeout
+//     poisons the output with NaN instead of hanging the GPU.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+struct WaveP {
+    float* z; long z_step;                       // fp32 state rows: wave step tau reads z + tau*z_step, writes z + (tau+1)*z_step
+    uint16_t* zb;                                // bf16 copy of the state rows, one region per wave step: [S+2][B][2H]
+    const uint16_t *wA, *wB1, *wB2;              // first (H x H), second k < H (H x H), second k >= H (H x H)
+    long ldA, ldB1, ldB2; int tA, tB1, tB2;      // t: element (n, k) is w[k*ld + n] instead of w[n*ld + k]
+    const float* add1; long add1_step, ld_add1;  // per-step external term of the first half (nullable)
+    const float *bias1a, *bias1b, *bias2a, *bias2b;
+    const float* mask1; long mask1_step, ld_mask1;   // stored activations: output kept where mask > 0 (nullable)
+    const float* mask2; long mask2_step, ld_mask2;
+    int relu, S, B, H;
+    unsigned* bar; int* err;
+};
+
+// The bf16 state copy is the only data exchanged between workgroups inside the kernel.  Measured alternatives:
+//   * agent-scope release/acquire fences around the barrier: buffer_wbl2 / buffer_inv from 2048 waves per step, ~90 us/step;
+//   * device-coherent (sc1) loads and stores on a ping-pong buffer: no cache maintenance, but every read bypasses the
+//     per-XCD L2 -> 64 MB per step from memory, 14 us/step;
+//   * (this) every wave step writes its OWN region of the copy with write-through sc1 stores and readers use ordinary
+//     loads: a region's addresses are never cached before they are complete (first touch after the barrier; the caches
+//     start clean at kernel launch), so the 128 workgroups sharing a row half hit the XCD's L2 instead of memory.
+//     The workgroup -> (row half, column group) map keeps the four writers of every 128-byte line on one XCD.
+HULC_DEVICE bf16x8_t load_state8(const uint16_t* p) { return *(const bf16x8_t*)p; }
+
+HULC_DEVICE bf16x8_t load_w(const uint16_t* w, long ld, int t, int n, int k) {
+    union { uint4 u; bf16x8_t b; uint16_t h[8]; } x;
+    if (!t) x.u = *(const uint4*)(w + (long)n * ld + k);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x.h[j] = w[(long)(k + j) * ld + n];
+    }
+    return x.b;
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
+    constexpr int KS = H / 32;                   // k-steps (of 32) per half of the state row
+    constexpr int KPW = KS / 8;                  // per wave
+    static_assert(KS % 8 == 0, "H must be a multiple of 256");
+    __shared__ float red[8][4][256];             // [wave][mt*2 + ct][reg*64 + lane]
+    __shared__ uint4 wlds[8][KPW][64];           // second-half weights of the "second" columns (the registers hold the rest)
+    __shared__ __attribute__((aligned(16))) uint16_t otile[32][2][16 + 8];    // bf16 outputs of the step, [row][half][col] (+pad), for 16-byte coherent stores
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kb = lane >> 4;
+    // workgroups are dispatched round-robin over the 8 XCDs: xcd = blockIdx % 8.  64 "line groups" (row half x 64 columns)
+    // of 4 workgroups each; line group L lives on XCD L % 8.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lgrp = xcd + 8 * (slot >> 2);
+    const int rowhalf = lgrp & 1, n0 = ((lgrp >> 1) * 4 + (slot & 3)) * 16;
+    const int nblk = gridDim.x;
+    const long ldz = 2 * H;
+
+    // ---- resident weights: B-operand fragments (lane = column n0 + i, 8 consecutive k)
+    bf16x8_t wfa[KPW], wfb[KPW];
+#pragma unroll
+    for (int q = 0; q < KPW; ++q) {
+        const int k = (wave * KPW + q) * 32 + kb * 8;
+        wfa[q] = load_w(p.wA, p.ldA, p.tA, n0 + i, k);
+        wfb[q] = load_w(p.wB1, p.ldB1, p.tB1, n0 + i, k);
+        union { bf16x8_t b; uint4 u; } wc; wc.b = load_w(p.wB2, p.ldB2, p.tB2, n0 + i, k);
+        wlds[wave][q][lane] = wc.u;                                          // read back only by this wave: no barrier needed
+    }
+    int mrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { const int m = rowhalf * 32 + mt * 16 + i; mrow[mt] = m < p.B ? m : p.B - 1; }
+    bool timed_out = false;
+    // ---- this thread's two outputs per wave step (fixed): tile t4 = mt*2 + ct, accumulator element e
+    int om[2], on[2]; float obias[2];
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int o = tid + rep * 512, t4 = o >> 8, e = o & 255, ln = e & 63;
+        om[rep] = rowhalf * 32 + (t4 >> 1) * 16 + 4 * (ln >> 4) + (e >> 6);
+        on[rep] = n0 + (ln & 15);
+        const float* ba = (t4 & 1) ? p.bias2a : p.bias1a;
+        const float* bb = (t4 & 1) ? p.bias2b : p.bias1b;
+        obias[rep] = (ba ? ba[on[rep]] : 0.f) + (bb ? bb[on[rep]] : 0.f);
+    }
+
+    for (int tau = 0; tau <= p.S; ++tau) {
+        const bool first_on = tau < p.S, second_on = tau >= 1;
+        f32x4_t acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // epilogue operands first: their latency hides behind the state loads and the MFMAs
+        float oadd[2], omask[2];
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int ct = ((tid + rep * 512) >> 8) & 1;
+            const int m = om[rep] < p.B ? om[rep] : p.B - 1, n = on[rep];
+            oadd[rep] = 0.f; omask[rep] = 1.f;
+            if (ct == 0) {
+                if (p.add1 && first_on) oadd[rep] = p.add1[(long)tau * p.add1_step + (long)m * p.ld_add1 + n];
+                if (p.mask1 && first_on) omask[rep] = p.mask1[(long)tau * p.mask1_step + (long)m * p.ld_mask1 + n];
+            } else if (p.mask2 && second_on) omask[rep] = p.mask2[(long)tau * p.mask2_step + (long)m * p.ld_mask2 + n];
+        }
+        if (tau > 0) {                                       // z_0 = 0: nothing to multiply
+            const uint16_t* a = p.zb + (long)tau * p.B * ldz;
+            // the step's 32 fragment loads are independent of the MFMAs: the scheduler keeps as many in flight as registers allow
+            bf16x8_t af[2][KPW][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int q = 0; q < KPW; ++q)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        af[hf][q][mt] = load_state8(a + (long)mrow[mt] * ldz + hf * H + (wave * KPW + q) * 32 + kb * 8);
+#pragma unroll
+            for (int q = 0; q < KPW; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][q][mt], wfa[q], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][q][mt], wfb[q], acc[mt][1], 0, 0, 0);
+                }
+#pragma unroll
+            for (int q = 0; q < KPW; ++q) {
+                union { bf16x8_t b; uint4 u; } wc; wc.u = wlds[wave][q][lane];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][q][mt], wc.b, acc[mt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave][mt * 2 + ct][e * 64 + lane] = acc[mt][ct][e];
+        __syncthreads();
+
+        // ---- fixed-order sum over the 8 K slices + epilogue; 1024 outputs, 2 per thread
+        float* zn = p.z + (long)(tau + 1) * p.z_step;
+        uint16_t* zbn = p.zb + (long)(tau + 1) * p.B * ldz;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int o = tid + rep * 512, t4 = o >> 8, e = o & 255, ct = t4 & 1;
+            const int m = om[rep], n = on[rep];
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w][t4][e];
+            if (m >= p.B) continue;
+            const bool on_ = ct == 0 ? first_on : second_on;
+            if (ct == 0 && !on_) continue;                               // last wave step: the first half is not produced
+            v += oadd[rep] + obias[rep];
+            if ((ct == 0 ? p.mask1 : p.mask2) != nullptr) v = omask[rep] > 0.f ? v : 0.f;
+            else if (p.relu) v = fmaxf(v, 0.f);
+            if (!on_) v = 0.f;                                           // wave step 0: the second half (h1_{-1}) is zero
+            zn[(long)m * ldz + ct * H + n] = v;
+            otile[m - rowhalf * 32][ct][n - n0] = f32_to_bf16_bits(v);
+        }
+        __syncthreads();
+        if (tid < 128) {                                                     // 32 rows x 2 halves x 2 chunks of 8 columns = 128 16-byte stores
+            const int row = tid >> 2, ct = (tid >> 1) & 1, ch = tid & 1;
+            const int m = rowhalf * 32 + row;
+            if (m < p.B && (ct == 1 || first_on)) {
+                const uint4 v = *(const uint4*)&otile[row][ct][ch * 8];
+                unsigned long long* dst = (unsigned long long*)(zbn + (long)m * ldz + ct * H + n0 + ch * 8);
+                __hip_atomic_store(dst, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tau == p.S) break;
+
+        // ---- device-wide barrier: everybody's z_{tau+1} is visible before anybody reads it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's coherent stores have been acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(tau + 1) * (unsigned)nblk;
+            long spins = 0;
+            while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1L << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        asm volatile("" ::: "memory");
+    }
+    // a barrier timeout anywhere poisons the state so the failure is loud (NaN loss) instead of silent
+    __syncthreads();
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = true;
+    if (timed_out) {
+        float* zn = p.z + (long)(p.S + 1) * p.z_step;
+        for (int o = tid; o < 32 * 16; o += 512) {
+            const int m = rowhalf * 32 + o / 16, n = n0 + o % 16;
+            if (m < p.B) { zn[(long)m * ldz + n] = __builtin_nanf(""); zn[(long)m * ldz + H + n] = __builtin_nanf(""); }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long hulc_rnn_wavefront_workspace(int S, int B, int H) { return 256 + (long)(S + 2) * B * 2 * H * 2; }
+
+// see include/hulc2_amd.h
+extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream) {
+    if (!d || !ws || !d->z || !d->wA || !d->wB1 || !d->wB2) return hulc_fail(-1, "hulc_rnn_wavefront: null pointer");
+    if (d->H != 2048) return hulc_fail(-2, "hulc_rnn_wavefront: built for hidden size 2048 (use the per-step hulc_gemm path otherwise)");
+    if (d->B < 1 || d->B > 64 || d->S < 1) return hulc_fail(-2, "hulc_rnn_wavefront: needs 1 <= B <= 64 rows and S >= 1");
+    if ((!d->tA && (d->ldA % 8 || (uintptr_t)d->wA % 16)) || (!d->tB1 && (d->ldB1 % 8 || (uintptr_t)d->wB1 % 16)) ||
+        (!d->tB2 && (d->ldB2 % 8 || (uintptr_t)d->wB2 % 16)))
+        return hulc_fail(-4, "hulc_rnn_wavefront: k-major weights must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    WaveP p;
+    p.z = d->z; p.z_step = d->z_step;
+    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 64); p.zb = (uint16_t*)((char*)ws + 256);
+    p.wA = (const uint16_t*)d->wA; p.wB1 = (const uint16_t*)d->wB1; p.wB2 = (const uint16_t*)d->wB2;
+    p.ldA = d->ldA; p.ldB1 = d->ldB1; p.ldB2 = d->ldB2; p.tA = d->tA; p.tB1 = d->tB1; p.tB2 = d->tB2;
+    p.add1 = d->add1; p.add1_step = d->add1_step; p.ld_add1 = d->ld_add1;
+    p.bias1a = d->bias1a; p.bias1b = d->bias1b; p.bias2a = d->bias2a; p.bias2b = d->bias2b;
+    p.mask1 = d->mask1; p.mask1_step = d->mask1_step; p.ld_mask1 = d->ld_mask1;
+    p.mask2 = d->mask2; p.mask2_step = d->mask2_step; p.ld_mask2 = d->ld_mask2;
+    p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H;
+    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
+    rnn_wavefront_kernel<2048><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    return hulc_check_launch("hulc_rnn_wavefront");
+}

@@ -318,6 +318,14 @@ def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: fl
 # action decoder recurrence: 2-layer ReLU RNN over [plan | emb_slice | goal]
 # reference: logistic_decoder_rnn.py:257-270 + decoders/utils/rnn.py:5-14
 # ------------------------------------------------------------------------------------------------
+def _rnn_persistent(B: int, Hd: int, state_dtype) -> bool:
+    """the persistent wavefront kernel covers the benchmarked geometry (bf16 compute, H = 2048, <= 64 rows, fp32 state);
+    other geometries and the exact-fp32 mode use the per-step GEMMs.  HULC_NO_RNN_WAVEFRONT=1 forces the per-step path."""
+    import os
+    return (kn.get_compute() == "bf16" and Hd == 2048 and B <= 64 and state_dtype == torch.float32
+            and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
+
+
 class DecoderRNNFn(torch.autograd.Function):
     """2-layer ReLU RNN over x_t = [plan | emb_t[lo:hi] | goal], h_{-1} = 0  ->  h1 (B, S, H).
 
@@ -354,6 +362,16 @@ class DecoderRNNFn(torch.autograd.Function):
         zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
         zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)                # zbuf[t+1] = [h0_t | h1_{t-1}]
         whh0 = weight_operand(w_hh0)
+        ctx.persistent = _rnn_persistent(B, Hd, zdt)
+        if ctx.persistent:
+            # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
+            kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
+                             add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
+            h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()
+            ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
+            ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)
+            ctx.meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
+            return h1
         w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
         s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
         s1.wait_stream(s0)
@@ -380,12 +398,19 @@ class DecoderRNNFn(torch.autograd.Function):
         Kin = w_ih0.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
         dH1_t = dH1.permute(1, 0, 2).contiguous()                                  # (S, B, H) time-major
-        dbuf = torch.zeros(S + 1, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
-        whh1_t = weight_operand(w_hh1, "t")
-        wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
-        s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
-        s1.wait_stream(s0)
-        for t in range(S - 1, -1, -1):
+        dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
+        if ctx.persistent:
+            # reversed sweep: wave step s reads dbuf[S+1-s] (row S+1 = 0) and writes dbuf[S-s]; weights read transposed in place
+            kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
+                             add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
+                             mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
+                             mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd)
+        else:
+            whh1_t = weight_operand(w_hh1, "t")
+            wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
+            s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
+            s1.wait_stream(s0)
+        for t in (range(S - 1, -1, -1) if not ctx.persistent else ()):
             h1_t, h0_t = zbuf[t + 2][:, Hd:], zbuf[t + 1][:, :Hd]
             # delta1_t = (dH1_t + delta1_{t+1} W_hh1) * (h1_t > 0)      (dbuf[S+1] does not exist: delta1_S = 0 -> zero rows of zbuf[0])
             prev = dbuf[t + 2][:, :Hd] if t + 2 <= S else zbuf[0][:, :Hd]
@@ -396,7 +421,8 @@ class DecoderRNNFn(torch.autograd.Function):
                 s1.wait_event(ev)
                 # delta0_t = ([delta1_t | delta0_{t+1}] [W_ih1^T | W_hh0^T]^T) * (h0_t > 0)
                 kn.gemm(dbuf[t + 1], wb0, dbuf[t][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, mask=h0_t, ld_mask=2 * Hd)
-        s0.wait_stream(s1)
+        if not ctx.persistent:
+            s0.wait_stream(s1)
         d1 = dbuf[1:S + 1]            # rows (t, b): [delta1_t | delta0_{t+1}]
         d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
         M = S * B

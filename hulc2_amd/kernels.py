@@ -331,6 +331,31 @@ def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_mi
     return d
 
 
+def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1_step=0, ld_add1=0, bias1=(None, None), bias2=(None, None),
+                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False):
+    """Both RNN layers of one direction as one persistent kernel (csrc/rnn_wavefront.hip).  z0: view of the (zero) state row
+    wave step 0 reads; rows advance by z_step elements.  Weights are bf16 (H, H) matrices, `transposed` applies to all three."""
+    for w in (wA, wB1, wB2):
+        if w.dtype != torch.bfloat16:
+            raise _L.HulcKernelError("rnn_wavefront: weights must be bf16 shadows (bf16 compute mode)")
+    d = _L.RnnWaveDesc()
+    d.z, d.z_step = z0.data_ptr(), int(z_step)
+    d.wA, d.wB1, d.wB2 = wA.data_ptr(), wB1.data_ptr(), wB2.data_ptr()
+    d.ldA, d.ldB1, d.ldB2 = wA.stride(0), wB1.stride(0), wB2.stride(0)
+    d.tA = d.tB1 = d.tB2 = int(bool(transposed))
+    d.add1, d.add1_step, d.ld_add1 = (add1.data_ptr() if add1 is not None else None), int(add1_step), int(ld_add1)
+    d.bias1a, d.bias1b = [b.data_ptr() if b is not None else None for b in bias1]
+    d.bias2a, d.bias2b = [b.data_ptr() if b is not None else None for b in bias2]
+    d.mask1, d.mask1_step, d.ld_mask1 = (mask1.data_ptr() if mask1 is not None else None), int(mask1_step), int(ld_mask1)
+    d.mask2, d.mask2_step, d.ld_mask2 = (mask2.data_ptr() if mask2 is not None else None), int(mask2_step), int(ld_mask2)
+    d.relu, d.S, d.B, d.H = int(relu), int(S), int(B), int(H)
+    lib = _L.load()
+    lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)
+    _call("hulc_rnn_wavefront", _c.byref(d), ws)
+    return ws
+
+
 def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
     """out: (nseg, 3) = {total, nll_mean, ce_mean} per segment of T / nseg tokens."""
     d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg)

@@ -76,6 +76,21 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class RnnWaveDesc(ctypes.Structure):
+    """mirror of hulc_rnn_wave_desc (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("z", ctypes.c_void_p), ("z_step", ctypes.c_long),
+        ("wA", ctypes.c_void_p), ("wB1", ctypes.c_void_p), ("wB2", ctypes.c_void_p),
+        ("ldA", ctypes.c_long), ("ldB1", ctypes.c_long), ("ldB2", ctypes.c_long),
+        ("tA", ctypes.c_int), ("tB1", ctypes.c_int), ("tB2", ctypes.c_int),
+        ("add1", ctypes.c_void_p), ("add1_step", ctypes.c_long), ("ld_add1", ctypes.c_long),
+        ("bias1a", ctypes.c_void_p), ("bias1b", ctypes.c_void_p), ("bias2a", ctypes.c_void_p), ("bias2b", ctypes.c_void_p),
+        ("mask1", ctypes.c_void_p), ("mask1_step", ctypes.c_long), ("ld_mask1", ctypes.c_long),
+        ("mask2", ctypes.c_void_p), ("mask2_step", ctypes.c_long), ("ld_mask2", ctypes.c_long),
+        ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
+    ]
+
+
 class MixDesc(ctypes.Structure):
     _fields_ = [
         ("T", ctypes.c_int), ("A", ctypes.c_int), ("n_mix", ctypes.c_int), ("num_classes", ctypes.c_int), ("nseg", ctypes.c_int),

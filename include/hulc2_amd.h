@@ -156,6 +156,29 @@ int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* us
  * gripper_control.py:16-36 (pytorch3d XYZ convention restated; parity unpinned). */
 int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
 
+/* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
+/* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.
+ * State rows z_t = [first half | second half] (B x 2H fp32, time-major, consecutive wave steps z_step elements apart,
+ * negative for the reversed backward sweep).  Wave step tau = 0..S reads row tau (row 0 must be zero and is not read)
+ * and writes row tau+1:
+ *     first  half (written for tau < S):  f1( z_tau[:, :H] wA^T + add1[tau] + bias1a + bias1b )
+ *     second half (written for tau >= 1, zero at tau = 0):  f2( z_tau[:, :H] wB1^T + z_tau[:, H:] wB2^T + bias2a + bias2b )
+ * f = keep where mask[tau] > 0 when a mask is given (backward: stored activations), else ReLU when relu != 0.
+ * Weights are bf16, element (n, k) at w[n*ld + k] (t = 0) or w[k*ld + n] (t = 1); H must be 2048, B <= 64.
+ * ws: hulc_rnn_wavefront_workspace(S, B, H) bytes.  A device-wide barrier separates wave steps: the stream must not run
+ * another kernel concurrently; a barrier timeout writes NaN into the last state row instead of hanging. */
+typedef struct hulc_rnn_wave_desc {
+    float* z; long z_step;
+    const void *wA, *wB1, *wB2; long ldA, ldB1, ldB2; int tA, tB1, tB2;
+    const float* add1; long add1_step, ld_add1;
+    const float *bias1a, *bias1b, *bias2a, *bias2b;
+    const float* mask1; long mask1_step, ld_mask1;
+    const float* mask2; long mask2_step, ld_mask2;
+    int relu, S, B, H;
+} hulc_rnn_wave_desc;
+long hulc_rnn_wavefront_workspace(int S, int B, int H);
+int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream);
+
 /* ---- optimizer ------------------------------------------------------------------------------- */
 /* torch.optim.Adam semantics (hulc2.py:185-198, conf/model/optimizer/adam.yaml) over a flat fp32 arena;
  * bf16_shadow (optional) receives the updated weights rounded to bf16 for the MFMA kernels. */
