@@ -162,7 +162,7 @@ def main():
     peak = PEAK_BF16 if args.compute == "bf16" else PEAK_F32
     achieved = dom_flops / (dom_t / dom_n * 1e-3) if dom_t > 0 else 0.0
     if args.breakdown and rank == 0:
-        for key, (n, t) in sorted(table.items(), key=lambda kv: -kv[1][1])[:25]:
+        for key, (n, t) in sorted(table.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("HULC_BREAKDOWN_ROWS", "25"))]:
             f = kernel_flops(key)
             print(f"  {t / 3:9.3f} ms/step  {n // 3:4d} launches  {f * n / max(t, 1e-9) / 1e9:9.1f} TFLOP/s  {key}", file=sys.stderr)
         print(f"  sum of kernel time: {total_ms / 3:.3f} ms/step", file=sys.stderr)

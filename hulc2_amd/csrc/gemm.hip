@@ -78,7 +78,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    Chunk8 ra[A_PER], rb[B_PER];
+    // Row-major (reduction-major) fp32 operands — the weight-gradient GEMMs dW = dY^T X — are staged as 8(k) x 4(rows)
+    // micro-tiles: eight 16-byte loads per thread give four complete k-chunks (an in-register transpose), instead of
+    // 32 scalar loads.  lane -> (k-group fastest, row group) keeps the LDS chunk writes conflict-free and each load
+    // instruction a set of 256-byte row segments.  A micro-tiles go to the first threads, B micro-tiles to the next.
+    constexpr int MTA = BM / 4 * NCH, MTB = BN / 4 * NCH;
+    constexpr int MICRO_B0 = (!AK && MTA + MTB <= NT) ? MTA : 0;          // first thread of the B micro-tiles
+    const bool a_micro = !AK && p.a_dtype == HULC_F32 && p.lda % 4 == 0 && ((uintptr_t)p.A % 16) == 0 && m0 + BM <= p.M && m0 % 4 == 0;
+    const bool b_micro = !BK && p.b_dtype == HULC_F32 && p.ldb % 4 == 0 && ((uintptr_t)p.B % 16) == 0 && n0 + BN <= p.N && n0 % 4 == 0;
+    Chunk8 ra[AK ? A_PER : (A_PER > 4 ? A_PER : 4)], rb[BK ? B_PER : (B_PER > 4 ? B_PER : 4)];
     const int nkt_all = (p.K + KT - 1) / KT;
     const int kt_per = (nkt_all + splitk - 1) / splitk;            // blockIdx.z owns k tiles [kt0, kt1)
     const int kt0 = blockIdx.z * kt_per;
@@ -90,7 +98,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     auto a_map = [&](int id, int& r, int& ch) { if (AK) { r = id / NCH; ch = id % NCH; } else { r = id % BM; ch = id / BM; } };
     auto b_map = [&](int id, int& r, int& ch) { if (BK) { r = id / NCH; ch = id % NCH; } else { r = id % BN; ch = id / BN; } };
 
+    // 8 x 4 micro-tile: chunks c[i] (i = row within the group) from eight float4 rows of the source
+    auto load_micro = [&](Chunk8* c, const void* base, long ld, int row0, int k0, int K) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in_k = k0 + j < K;
+            const float4 v = *(const float4*)((const float*)base + (long)(in_k ? k0 + j : 0) * ld + row0);
+            c[0].v[j] = in_k ? v.x : 0.f; c[1].v[j] = in_k ? v.y : 0.f; c[2].v[j] = in_k ? v.z : 0.f; c[3].v[j] = in_k ? v.w : 0.f;
+        }
+    };
     auto load_tiles = [&](int kt) {
+        if (!AK && a_micro) {
+            if (tid < MTA) load_micro(ra, p.A, p.lda, m0 + (tid / NCH) * 4, kt * KT + (tid % NCH) * 8, p.K);
+        } else
 #pragma unroll
         for (int q = 0; q < A_PER; ++q) {
             int id = tid + q * NT;
@@ -99,6 +119,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 load_operand_chunk<AK>(ra[q], p.A, p.a_dtype, p.lda, p.M, p.K, m0 + r, kt * KT + ch * 8);
             }
         }
+        if (!BK && b_micro) {
+            const int t = tid - MICRO_B0;
+            if (t >= 0 && t < MTB) load_micro(rb, p.B, p.ldb, n0 + (t / NCH) * 4, kt * KT + (t % NCH) * 8, p.K);
+        } else
 #pragma unroll
         for (int q = 0; q < B_PER; ++q) {
             int id = tid + q * NT;
@@ -111,6 +135,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     auto store_tiles = [&](int buf) {
         char* As = smem + buf * (BM + BN) * HULC_ROWB;
         char* Bs = As + BM * HULC_ROWB;
+        if (!AK && a_micro) {
+            if (tid < MTA) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(As + ((tid / NCH) * 4 + i) * HULC_ROWB + (tid % NCH) * CHB, ra[i]);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < A_PER; ++q) {
             int id = tid + q * NT;
@@ -119,6 +149,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
             }
         }
+        if (!BK && b_micro) {
+            const int t = tid - MICRO_B0;
+            if (t >= 0 && t < MTB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(Bs + ((t / NCH) * 4 + i) * HULC_ROWB + (t % NCH) * CHB, rb[i]);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < B_PER; ++q) {
             int id = tid + q * NT;
@@ -160,26 +197,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         return;
     }
 
-    // epilogue: lane owns column n = lane & 31 of each tile; each accumulator register is one row.
+    // epilogue: lane owns column n = lane & 31 of each tile; each accumulator register is one row.  All reads of the
+    // tile's side operands (C when accumulating, add, mask) are issued before the first store: C is not provably distinct
+    // from them for the compiler, so an interleaved read-modify-write loop serialises into one memory round trip per element.
+    const unsigned long long seed = p.drop_seed ^ (p.seed_dev ? p.seed_dev[0] : 0ull);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const bool n_ok = n < p.N;
+        const int nc = n_ok ? n : 0;
+        const float bv = p.bias ? p.bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float cold[16], addv[16], maskv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
-                if (m >= p.M) continue;
-                float v = p.alpha * acc[i][j][e] + bv;
-                if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
+                const int mc = m < p.M ? m : 0;
+                cold[e] = p.accumulate ? load_elem(p.C, p.c_dtype, (long)mc * p.ldc + nc) : 0.f;
+                addv[e] = p.add ? load_elem(p.add, p.add_dtype, (long)mc * p.ld_add + nc) : 0.f;
+                maskv[e] = p.mask ? load_elem(p.mask, p.mask_dtype, (long)mc * p.ld_mask + nc) : 1.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
+                if (m >= p.M || !n_ok) continue;
+                float v = p.alpha * acc[i][j][e] + bv + addv[e];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
-                if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed ^ (p.seed_dev ? p.seed_dev[0] : 0ull), (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
-                const long ci = (long)m * p.ldc + n;
-                if (p.accumulate) v += load_elem(p.C, p.c_dtype, ci);
-                store_elem(p.C, p.c_dtype, ci, v);
+                if (p.mask) v = maskv[e] > 0.f ? v * p.mask_scale : 0.f;
+                if (p.drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
+                store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, v + cold[e]);
             }
         }
     }
