@@ -102,63 +102,86 @@ def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Opt
 # reference: vision_network.py:36-47, vision_network_gripper.py:11-20
 # ------------------------------------------------------------------------------------------------
 class ConvStackFn(torch.autograd.Function):
-    """x (N,3,H,W) NCHW -> a3 (N,OH3,OW3,64) NHWC.  `grad_premasked`: the incoming gradient has already been
-    multiplied by (a3 > 0) by the consumer (spatial softmax backward does it for free)."""
+    """xs: one or more (N_i,3,H,W) NCHW frame tensors -> a3 (sum N_i, OH3, OW3, 64) NHWC.  Several inputs (the vis and lang
+    modalities of a step) share one activation buffer from conv1 on: conv1 runs per input (no 1 GB concat of the frames),
+    every later layer once over all frames.  `grad_premasked`: the incoming gradient has already been multiplied by
+    (a3 > 0) by the consumer (spatial softmax backward does it for free)."""
 
     GEOM = ((8, 4), (4, 2), (3, 1))   # (kernel, stride) of the three layers
 
     @staticmethod
-    def forward(ctx, x, grad_premasked: bool, w1, b1, w2, b2, w3, b3):
-        x = _c(x)
-        N, C, H, W = x.shape
+    def forward(ctx, grad_premasked: bool, w1, b1, w2, b2, w3, b3, *xs):
+        xs = [_c(x) for x in xs]
+        Ns = [x.shape[0] for x in xs]
+        N = sum(Ns)
+        _, C, H, W = xs[0].shape
         ws, bs = (w1, w2, w3), (b1, b2, b3)
         acts, dims = [], []
-        inp, h, w_, cin = x, H, W, C
+        inp, h, w_, cin = None, H, W, C
         for li, (k, s) in enumerate(ConvStackFn.GEOM):
             cout = ws[li].shape[0]
             nchw = li == 0
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
-            y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=x.device)
-            kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
+            y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=xs[0].device)
+            if li == 0:
+                off = 0
+                for x, n in zip(xs, Ns):
+                    kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True)
+                    off += n
+            else:
+                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
             dims.append((h, w_, cin, cout, k, s, nchw))
             acts.append(y)
             inp, h, w_, cin = y, oh, ow, cout
-        ctx.save_for_backward(x, acts[0], acts[1], acts[2], w2, w3)
-        ctx.meta = (dims, grad_premasked, N)
+        ctx.save_for_backward(acts[0], acts[1], acts[2], w2, w3, *xs)
+        ctx.meta = (dims, grad_premasked, Ns)
         return acts[2]
 
     @staticmethod
     def backward(ctx, da3):
-        x, a1, a2, a3, w2, w3 = ctx.saved_tensors
-        dims, premasked, N = ctx.meta
+        a1, a2, a3, w2, w3, *xs = ctx.saved_tensors
+        dims, premasked, Ns = ctx.meta
+        N = sum(Ns)
         g = _c(da3)
         if not premasked:
             gz = torch.empty(g.shape, dtype=torch.float32, device=g.device)
             kn.relu_bwd(g.float() if g.dtype != torch.float32 else g, a3, gz, g.numel())
             g = gz
-        inputs = (x, a1, a2)
+        inputs = (None, a1, a2)
         weights = (None, w2, w3)
         grads_w, grads_b = [None] * 3, [None] * 3
         for li in (2, 1, 0):
             h, w_, cin, cout, k, s, nchw = dims[li]
-            inp = inputs[li]
-            dw = _f32(cout, cin * k * k, like=g)
-            db = _f32(cout, like=g)
-            kn.conv2d_bwd_weight(inp, g, dw, db, N, h, w_, cin, cout, k, k, s, nchw)
+            if li == 0:                                  # per input tensor; partial gradients summed (tiny tensors)
+                dw = db = None
+                off = 0
+                for x, n in zip(xs, Ns):
+                    dwi, dbi = _f32(cout, cin * k * k, like=g), _f32(cout, like=g)
+                    kn.conv2d_bwd_weight(x, g[off:off + n], dwi, dbi, n, h, w_, cin, cout, k, k, s, nchw)
+                    dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+                    off += n
+            else:
+                inp = inputs[li]
+                dw = _f32(cout, cin * k * k, like=g)
+                db = _f32(cout, like=g)
+                kn.conv2d_bwd_weight(inp, g, dw, db, N, h, w_, cin, cout, k, k, s, nchw)
             # back to the parameter's OIHW layout (dw is [Cout][kh][kw][cin] for NHWC layers)
             grads_w[li] = dw.view(cout, cin, k, k) if nchw else dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
             grads_b[li] = db
             if li > 0:
+                inp = inputs[li]
                 wt = weight_operand(weights[li], "ihwo")
                 dx = torch.empty(N, h, w_, cin, dtype=inp.dtype, device=g.device)
                 kn.conv2d_bwd_data(g, wt, dx, inp, N, h, w_, cin, cout, k, k, s)   # masked by relu of the layer input
                 g = dx
-        return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2])
+        return (None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], *([None] * len(xs)))
 
 
 def conv_stack(x, params, grad_premasked=False):
-    return ConvStackFn.apply(x, grad_premasked, *params)
+    """x: a frame tensor or a list of them (batched from conv1's output on)."""
+    xs = list(x) if isinstance(x, (list, tuple)) else [x]
+    return ConvStackFn.apply(grad_premasked, *params, *xs)
 
 
 class SpatialSoftmaxFn(torch.autograd.Function):

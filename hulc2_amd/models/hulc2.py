@@ -98,16 +98,34 @@ class Hulc2(LightningModule):
         def acc(a, b):
             return b if a is None else a + b
 
-        # pass 1 — per modality: encoders, goal, prior/posterior, latent plan sample, KL (hulc2.py:380-386,228-237,242)
+        # pass 1 — encoders, goal, prior/posterior, latent plan sample, KL (hulc2.py:380-386,228-237,242).  Modalities of
+        # identical shape go through the shared networks together (same per-row arithmetic, half the launches); the goal
+        # encoders, the plan sample and the KL stay per modality.
         per = []
-        for self.modality_scope, db in batch.items():
-            emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
-            latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
-            pp_state = self.plan_proposal(emb[:, 0], latent_goal)
-            pr_state, seq_feat = self.plan_recognition(emb)
-            site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
-            plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
-            per.append((self.modality_scope, db, emb, latent_goal, seq_feat, plan, self.compute_kl_loss(pp_state, pr_state)))
+        mods = list(batch.items())
+        if self._batchable(mods):
+            from hulc2_amd.utils.distributions import DiscState
+            emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
+            B = mods[0][1]["actions"].shape[0]
+            embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
+            goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
+            pp_all = self.plan_proposal(emb_all[:, 0], torch.cat(goals, dim=0))
+            pr_all, seq_all = self.plan_recognition(emb_all)
+            for i, (self.modality_scope, db) in enumerate(mods):
+                sl = slice(i * B, (i + 1) * B)
+                pp_state, pr_state = DiscState(pp_all.logit[sl]), DiscState(pr_all.logit[sl])
+                site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
+                plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
+                per.append((self.modality_scope, db, embs[i], goals[i], seq_all[sl], plan, self.compute_kl_loss(pp_state, pr_state)))
+        else:
+            for self.modality_scope, db in mods:
+                emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
+                latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
+                pp_state = self.plan_proposal(emb[:, 0], latent_goal)
+                pr_state, seq_feat = self.plan_recognition(emb)
+                site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
+                plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
+                per.append((self.modality_scope, db, emb, latent_goal, seq_feat, plan, self.compute_kl_loss(pp_state, pr_state)))
         # pass 2 — the action decoder sees all modalities at once (shared weights, independent sequences); it returns
         # one loss per modality, each the mean over that modality's own tokens as in the reference (hulc2.py:239-241)
         act_losses = self.action_decoder.loss_segments([p[5] for p in per], [p[2] for p in per], [p[3] for p in per],
@@ -136,6 +154,20 @@ class Hulc2(LightningModule):
         self.log("train/action_loss", action_loss, on_step=False, on_epoch=True, batch_size=total_bs)
         self.log("train/total_loss", total_loss, on_step=False, on_epoch=True, batch_size=total_bs)
         return total_loss
+
+    @staticmethod
+    def _batchable(mods) -> bool:
+        """all modalities carry the same cameras and tensor shapes (the CALVIN vis/lang batches do)"""
+        import os
+        if len(mods) < 2 or os.environ.get("HULC_NO_MODALITY_BATCHING"):
+            return False
+        ref = mods[0][1]
+        for _, db in mods[1:]:
+            if db["actions"].shape != ref["actions"].shape or set(db["rgb_obs"]) != set(ref["rgb_obs"]):
+                return False
+            if any(db["rgb_obs"][k].shape != ref["rgb_obs"][k].shape for k in ref["rgb_obs"]):
+                return False
+        return True
 
     def compute_kl_loss(self, pp_state: State, pr_state: State) -> torch.Tensor:
         """hulc2.py:444-466."""

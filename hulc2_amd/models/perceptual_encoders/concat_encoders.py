@@ -36,6 +36,8 @@ class ConcatEncoders(nn.Module):
         return self._latent_size
 
     def forward(self, imgs: Dict[str, torch.Tensor], depth_imgs: Dict[str, torch.Tensor], state_obs: torch.Tensor) -> torch.Tensor:
+        if isinstance(imgs, (list, tuple)):             # several modalities at once (Hulc2.training_step): see forward_multi
+            return self.forward_multi(imgs)
         rgb_static = imgs["rgb_static"]
         b, s, c, h, w = rgb_static.shape
         enc = self.rgb_static_encoder(rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
@@ -45,4 +47,17 @@ class ConcatEncoders(nn.Module):
             enc = torch.cat([enc, self.rgb_gripper_encoder(g.reshape(-1, c, h, w)).reshape(b, s, -1)], dim=-1)
         self.current_visual_embedding = enc.detach()   # detached: holding the graph across steps breaks HIP-graph capture
         self.current_state_obs = state_obs
+        return enc
+
+    def forward_multi(self, imgs_list) -> torch.Tensor:
+        """Several observation dicts of identical shapes (the modalities of one training step) through the shared encoders
+        in one pass: rows of the result are modality-major, (sum B, S, latent).  Same arithmetic per frame as `forward`."""
+        st = [im["rgb_static"] for im in imgs_list]
+        b, s, c, h, w = st[0].shape
+        enc = self.rgb_static_encoder([x.reshape(-1, c, h, w) for x in st]).reshape(len(st) * b, s, -1)
+        if self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list):
+            gr = [im["rgb_gripper"] for im in imgs_list]
+            _, _, c, h, w = gr[0].shape
+            enc = torch.cat([enc, self.rgb_gripper_encoder([x.reshape(-1, c, h, w) for x in gr]).reshape(len(gr) * b, s, -1)], dim=-1)
+        self.current_visual_embedding = enc.detach()
         return enc

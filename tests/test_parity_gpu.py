@@ -242,6 +242,28 @@ def test_decoder_segments_equal_separate_passes(dev, model, mode):
     close(g_both, dec.rnn.weight_hh_l1.grad.cpu().numpy(), 1e-3 if mode == "fp32" else 2e-2, "g whh1 (segments vs separate)")
 
 
+def test_modality_batching_equals_per_modality(dev, model, mode, monkeypatch):
+    """vis + lang through the shared networks in one pass == one pass per modality (losses and every gradient)"""
+    B, S = 2, 8
+    batch = syn.make_batch(77, B, S, device=dev)
+
+    def run():
+        zero(model)
+        total = model.training_step(batch, 0)
+        total.backward()
+        return total.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    t_b, g_b = run()
+    monkeypatch.setenv("HULC_NO_MODALITY_BATCHING", "1")
+    t_s, g_s = run()
+    monkeypatch.delenv("HULC_NO_MODALITY_BATCHING")
+    close(t_b, t_s.cpu().numpy(), 1e-5 if mode == "fp32" else 1e-3, "total loss (batched vs per modality)")
+    assert g_b.keys() == g_s.keys()
+    tol = 1e-3 if mode == "fp32" else 5e-2
+    for n in g_s:
+        close(g_b[n], g_s[n].cpu().numpy(), tol, f"g {n} (batched vs per modality)")
+
+
 def test_logistic_mixture_edges(dev):
     """every branch of the torch.where ladder of _logistic_loss (logistic_decoder_rnn.py:206-225)"""
     from hulc2_amd import functional as HF
@@ -296,8 +318,9 @@ def test_whole_training_step(dev, model, mode, B, S):
     close(model.logged["train/kl_loss"], fx["kl_loss"], t["loss"] * 5, "kl loss")
     close(model.logged["train/action_loss"], fx["action_loss"], t["loss"], "action loss")
     close(model.logged["train/lang_clip_loss"] / 3.0, fx["clip_loss"], t["loss"] * 5, "clip loss")
-    close(taps["emb"][0], fx["emb_vis"], t["act"] * 3, "perceptual emb vis")
-    close(taps["emb"][1], fx["emb_lang"], t["act"] * 3, "perceptual emb lang")
+    embs = torch.cat(list(taps["emb"]), dim=0)      # one batched call (rows modality-major) or one call per modality
+    close(embs[:B], fx["emb_vis"], t["act"] * 3, "perceptual emb vis")
+    close(embs[B:], fx["emb_lang"], t["act"] * 3, "perceptual emb lang")
     total.backward()
     names = [str(n) for n in fx["grad_names"]]
     P = dict(model.named_parameters())
