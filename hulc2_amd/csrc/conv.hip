@@ -28,6 +28,9 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
                             const long* cls_wtap, hipStream_t s);
+// LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
+int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
+                             int N, int H, int W, hipStream_t s);
 // LDS-band weight gradient (conv_wgrad_band.hip): same return convention
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, hipStream_t s);
@@ -451,6 +454,11 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
                                      cOH, cOW, cyo, cco, cw0, ctap, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
+    }
+    if (d->compute == HULC_BF16 && d->x_nchw && d->x_dtype == HULC_F32 && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 && d->stride == 4) {
+        rc = hulc_conv1_band_dispatch((const float*)x, w, d->w_dtype, g.ldw, bias, y, d->y_dtype, d->relu, d->N, d->H, d->W, (hipStream_t)stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(conv1 band)");
     }
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_fwd");

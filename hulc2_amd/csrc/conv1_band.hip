@@ -1,0 +1,165 @@
+// conv1_band.hip — forward of the first camera-encoder conv (NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4) from LDS bands.
+//
+// reference arithmetic: nn.Conv2d(3, 32, 8, stride=4) + ReLU, hulc2/models/perceptual_encoders/vision_network.py:37-39 and
+// vision_network_gripper.py:13.
+//
+// The layer is HBM-bound (30 GFLOP against 491 MB of fp32 frames + 157 MB of bf16 output per 1024 static frames); the
+// gather kernel re-reads every input element 4x from L2 in 32-byte pieces and converts it 4x.  Here a work unit (frame x band
+// of R output rows, full width) is copied ONCE into LDS as bf16 channel planes (flat 32-byte-per-lane copy, converted once,
+// next band prefetched into registers during the MFMAs), the 32 x 192 weight matrix lives in registers as A-operand
+// fragments, and a wave computes D[channel][pixel] for 32 consecutive output pixels per tile: the B fragment of k-step
+// (c, kh pair) is the 8 contiguous kw of the patch row — two aligned ds_read_b64, conflict-free across the 32 pixels.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+struct C1P {
+    const float* X; const void* Wt; const float* bias; void* Y;
+    int w_dtype, y_dtype, relu;
+    int Nimg, H, W, OH, OW, R;
+    long ldw;
+};
+
+template <int XCH>
+__global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
+    constexpr int NT = 512, C = 3, TH = 8, TW = 8, S = 4, K = C * TH * TW, KSTEPS = K / 16;   // 12 k-steps of (c, kh pair)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bands = (p.OH + p.R - 1) / p.R;
+    const int nunits = p.Nimg * bands;
+    const int rows_max = (p.R - 1) * S + TH;
+    const int PP = (rows_max * p.W + 7) / 8 * 8;                 // plane pitch (elements)
+
+    // ---- weights: 32 x 192 bf16 in LDS, row stride 400 B (conflict-free ds_read_b128 of the A-operand fragments: lane =
+    //      output channel r, 8 consecutive k of k-step ks at half h).  Registers stay under 128 -> two workgroups per CU.
+    constexpr int WROW = K * 2 + 16;
+    char* wlds = smem;
+    char* xlds = smem + 32 * WROW;
+    for (int id = tid; id < 32 * (K / 8); id += NT) {
+        const int row = id / (K / 8), ch = id % (K / 8);
+        Chunk8 c; chunk_load_contig(c, p.Wt, p.w_dtype, (long)row * p.ldw + ch * 8);
+        *(uint4*)(wlds + row * WROW + ch * 16) = make_uint4(pack_bf16x2(c.v[0], c.v[1]), pack_bf16x2(c.v[2], c.v[3]), pack_bf16x2(c.v[4], c.v[5]), pack_bf16x2(c.v[6], c.v[7]));
+    }
+
+    uint4 xpre[XCH];
+    auto unit_geom = [&](int unit, int& n, int& r0, int& R, int& rows) {
+        n = unit / bands; const int b = unit % bands;
+        r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + TH;
+    };
+    auto stage_load = [&](int unit) {
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int nflt = rows * p.W, items = (nflt + 7) / 8;
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+            const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
+            const long base = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W;
+            const long off = base + (inb ? (long)id * 8 : 0);
+            const float4 a = *(const float4*)(p.X + off);
+            const float4 b = *(const float4*)(p.X + (inb2 ? off + 4 : off));
+            xpre[j].x = inb ? pack_bf16x2(a.x, a.y) : 0u; xpre[j].y = inb ? pack_bf16x2(a.z, a.w) : 0u;
+            xpre[j].z = inb2 ? pack_bf16x2(b.x, b.y) : 0u; xpre[j].w = inb2 ? pack_bf16x2(b.z, b.w) : 0u;
+        }
+    };
+    auto stage_store = [&](int unit) {
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int items = (rows * p.W + 7) / 8;
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+            if (id < items) *(uint4*)(xlds + ((long)c * PP + id * 8) * 2) = xpre[j];
+        }
+    };
+
+    int unit = blockIdx.x;
+    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    __syncthreads();
+    for (; unit < nunits; unit += gridDim.x) {
+        const int next = unit + gridDim.x;
+        if (next < nunits) stage_load(next);
+
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int npix = R * p.OW, ntiles = (npix + 31) / 32;
+        for (int t = wave; t < ntiles; t += 8) {
+            const int q = t * 32 + r;
+            const int qc = q < npix ? q : npix - 1;
+            const int oy = qc / p.OW, ox = qc % p.OW;
+            const char* patch = xlds + ((oy * S) * p.W + ox * S + h * p.W) * 2;   // 8-byte aligned: ox*S*2 = 8*ox; lane half h = odd patch row
+            const char* wrow = wlds + r * WROW + h * 16;
+            f32x16_t acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int c = ks / 4, kh2 = (ks % 4) * 2;                     // patch row kh2 + h of channel c
+                const char* src = patch + ((long)c * PP + kh2 * p.W) * 2;
+                union { uint2 u[2]; bf16x8_t b; } x;
+                x.u[0] = *(const uint2*)src; x.u[1] = *(const uint2*)(src + 8);
+                const bf16x8_t wf = *(const bf16x8_t*)(wrow + ks * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x.b, acc, 0, 0, 0);
+            }
+            if (q < npix) {
+                const long yo = (((long)n * p.OH + r0) * p.OW + q) * 32;        // band pixels are contiguous in the NHWC output
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    // bias of this lane's channels (e&3) + 8(e>>2) + 4h: re-read per tile (L1-resident) rather than 16 live registers
+                    const float4 b4 = p.bias ? *(const float4*)(p.bias + 8 * g4 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
+                    if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    const int co = 8 * g4 + 4 * h;
+                    if (p.y_dtype == HULC_BF16) *(uint2*)((uint16_t*)p.Y + yo + co) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    else *(float4*)((float*)p.Y + yo + co) = make_float4(v0, v1, v2, v3);
+                }
+            }
+        }
+        __syncthreads();
+        if (next < nunits) stage_store(next);
+        __syncthreads();
+    }
+}
+
+template <int XCH>
+int launch_conv1(C1P& p, hipStream_t s) {
+    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return 32 * (192 * 2 + 16) + 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
+    auto fits = [&](int R) -> bool {
+        const long rows = (R - 1) * 4 + 8;
+        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512;
+    };
+    int R = p.OH;
+    while (R > 1 && !fits(R)) --R;
+    if (!fits(R)) return -1;
+    const int bands = (p.OH + R - 1) / R;
+    R = (p.OH + bands - 1) / bands;
+    p.R = R;
+    const int nunits = p.Nimg * bands;
+    const int slots = 512;                                       // two workgroups per CU (LDS <= 80 KB each)
+    const int per = (nunits + slots - 1) / slots;
+    const int grid = (nunits + per - 1) / per;
+    auto kern = conv1_band_kernel<XCH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
+        attr_set = true;
+    }
+    kern<<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    return 0;
+}
+
+}  // namespace
+
+// 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
+int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
+                             int N, int H, int W, hipStream_t s) {
+    if (getenv("HULC_NO_BAND_CONV1")) return 1;
+    if (W % 4 || ((uintptr_t)x % 16) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
+    C1P p;
+    p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
+    p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
+    const int rc = launch_conv1<6>(p, s);
+    if (rc == -1) return 1;
+    if (rc < 0) return hulc_fail(-8, "conv1 band: could not raise the dynamic LDS limit");
+    return 0;
+}
