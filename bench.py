@@ -28,21 +28,23 @@ sys.path.insert(0, str(ROOT))
 SEQ_FLOP_TRAIN = 14.13e9        # 3 x 4.710 GFLOP forward per play sequence
 PEAK_BF16 = 2.5e15              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32 = 157.3e12
+PEAK_HBM = 8.0e12               # HBM3E bytes/s (MI355X_MICROARCH.md)
 
 
-def conv_macs(N, H, W, Cin, Cout, K, stride):
-    oh, ow = (H - K) // stride + 1, (W - K) // stride + 1
-    return N * oh * ow * Cout * Cin * K * K
+# device kernel behind a timed entry point, where one entry-point shape maps to exactly one kernel instance
+PMC_KERNEL = {"rnn_wavefront": "rnn_wavefront_kernel<2048>(WaveP)"}
 
 
-def kernel_flops(key):
-    """algorithmic FLOPs of one launch, from its shape key (2 x MACs)"""
-    name = key[0]
-    if name == "gemm":
-        return 2.0 * key[1] * key[2] * key[3]
-    if name in ("conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_weight"):
-        return 2.0 * conv_macs(*key[1:])
-    return 0.0
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself; None when no committed measurement names the kernel."""
+    name = PMC_KERNEL.get(key[0])
+    files = sorted((ROOT / "profiles").glob("*_pmc_traffic.json"))
+    if not name or not files:
+        return None
+    rec = json.loads(files[-1].read_text()).get("kernels", {}).get(name)
+    return None if rec is None else round(rec["traffic_bytes"])
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -147,24 +149,31 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss)
 
-    # ---- roofline leg: per-launch HIP events over 3 more steps (outside the timed region) -------------
+    # ---- roofline leg: per-launch HIP events on the launch stream over 3 more eager steps (outside the timed region) ----
+    # The dominant kernel = the (entry point, shape) with the largest summed time.  Its bound is whichever roof needs longer for
+    # the launch's ALGORITHMIC work (kernels.py annotates flops = 2 x MACs and bytes = every operand / result touched once):
+    # bytes / 8 TB/s vs flops / dense MFMA peak.  achieved = that work / the measured average launch duration.
     kn.start_timing()
     for i in range(3):
         trainer.step(batch, i)
     table = kn.stop_timing()
-    total_ms = sum(t for _, t in table.values())
-    by_kind = {}
-    for key, (n, t) in table.items():
-        a = by_kind.setdefault(key[0], [0, 0.0, 0.0])
-        a[0] += n; a[1] += t; a[2] += kernel_flops(key) * n
-    dom_key, (dom_n, dom_t) = max(table.items(), key=lambda kv: kv[1][1])
-    dom_flops = kernel_flops(dom_key)
+    total_ms = sum(v[1] for v in table.values())
     peak = PEAK_BF16 if args.compute == "bf16" else PEAK_F32
-    achieved = dom_flops / (dom_t / dom_n * 1e-3) if dom_t > 0 else 0.0
+    dom_key, (dom_n, dom_t, dom_flops, dom_bytes) = max(table.items(), key=lambda kv: kv[1][1])
+    avg_s = dom_t / dom_n * 1e-3
+    hbm_bound = dom_bytes / PEAK_HBM >= dom_flops / peak
+    if hbm_bound:
+        rl = {"bound": "hbm", "achieved": round(dom_bytes / avg_s / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+              "frac": round(dom_bytes / avg_s / PEAK_HBM, 4)}
+    else:
+        rl = {"bound": "mfma", "achieved": round(dom_flops / avg_s / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+              "frac": round(dom_flops / avg_s / peak, 4)}
+    rl["traffic"] = pmc_traffic(dom_key)
     if args.breakdown and rank == 0:
-        for key, (n, t) in sorted(table.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("HULC_BREAKDOWN_ROWS", "25"))]:
-            f = kernel_flops(key)
-            print(f"  {t / 3:9.3f} ms/step  {n // 3:4d} launches  {f * n / max(t, 1e-9) / 1e9:9.1f} TFLOP/s  {key}", file=sys.stderr)
+        rows = int(os.environ.get("HULC_BREAKDOWN_ROWS", "25"))
+        for key, (n, t, f, b) in sorted(table.items(), key=lambda kv: -kv[1][1])[:rows]:
+            a = t / n * 1e-3
+            print(f"  {t / 3:9.3f} ms/step  {n // 3:4d} launches  {f / a / 1e12:8.1f} TFLOP/s  {b / a / 1e9:8.0f} GB/s  {key}", file=sys.stderr)
         print(f"  sum of kernel time: {total_ms / 3:.3f} ms/step", file=sys.stderr)
 
     seqs = 2 * args.batch * world * args.steps
@@ -180,11 +189,11 @@ def main():
                    "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
                    "final_loss": round(final_loss, 4)},
-        "roofline": {"bound": "mfma", "kernel": "/".join(str(k) for k in dom_key), "achieved": round(achieved / 1e12, 2),
-                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        "roofline": {**rl, "kernel": "/".join(str(k) for k in dom_key),
+                     "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_flops_per_launch": dom_flops,
                      "launches_per_step": dom_n // 3, "avg_launch_ms": round(dom_t / dom_n, 4),
                      "kernel_share_of_step": round(dom_t / max(total_ms, 1e-9), 3),
-                     "step_frac_of_peak": round(value / world * SEQ_FLOP_TRAIN / peak, 4),
+                     "step_frac_of_mfma_peak": round(value / world * SEQ_FLOP_TRAIN / peak, 4),
                      "gpu_kernel_ms_per_step": round(total_ms / 3, 3)},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -38,22 +38,27 @@ def start_timing() -> None:
 
 
 def stop_timing():
-    """-> {key: (launches, total_ms)}; synchronises the device."""
+    """-> {key: (launches, total_ms, flops_per_launch, bytes_per_launch)}; synchronises the device.  flops / bytes are the
+    ALGORITHMIC work of one launch (2 x MACs; each operand and the result touched once), 0 where not annotated."""
     global _timing
     rec, _timing = _timing or [], None
     torch.cuda.synchronize()
     out = {}
-    for key, e0, e1 in rec:
-        n, t = out.get(key, (0, 0.0))
-        out[key] = (n + 1, t + e0.elapsed_time(e1))
+    for key, e0, e1, fl, by in rec:
+        n, t, _, _ = out.get(key, (0, 0.0, 0.0, 0.0))
+        out[key] = (n + 1, t + e0.elapsed_time(e1), fl, by)
     return out
 
 
-class _Timed:
-    __slots__ = ("key", "e0")
+def _nbytes(*ts) -> float:
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
-    def __init__(self, key):
-        self.key = key
+
+class _Timed:
+    __slots__ = ("key", "e0", "flops", "bytes")
+
+    def __init__(self, key, flops=0.0, nbytes=0.0):
+        self.key, self.flops, self.bytes = key, flops, nbytes
 
     def __enter__(self):
         if _timing is not None:
@@ -64,7 +69,7 @@ class _Timed:
         if _timing is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _timing.append((self.key, self.e0, e1))
+            _timing.append((self.key, self.e0, e1, self.flops, self.bytes))
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -162,7 +167,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
     ws = _gemm_scratch(C.device)      # split-K slabs (stream-ordered reuse of one scratch buffer)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     d.seed_dev = step_state(C.device).data_ptr() if drop_p > 0.0 else None
-    with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor))):
+    esz = lambda t: t.element_size()
+    gbytes = M * K * esz(A) + N * K * esz(B) + M * N * esz(C) * (2 if accumulate else 1) \
+        + (M * N * esz(add) if add is not None and ld_add else 0) + (M * N * esz(mask) if mask is not None else 0)
+    with _Timed(("gemm", M, N, K, int(a_kmajor), int(b_kmajor)), 2.0 * M * N * K, float(gbytes)):
         _L.check(_L.load().hulc_gemm(ctypes.byref(d), ctypes.c_void_p(_stream())), "hulc_gemm")
     return C
 
@@ -186,7 +194,9 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc)."""
     _require_cuda(x, w2d, bias, y)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(y), _dt(w2d), relu, compute)
-    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride)):
+    oh, ow = conv_out_hw(H, W, KH, KW, stride)
+    macs = float(N) * oh * ow * Cout * Cin * KH * KW
+    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
         _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
                  "hulc_conv2d_fwd")
     return y
@@ -196,7 +206,9 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
     """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout]."""
     _require_cuda(dy, wt, dx, relu_src)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, False, _dt(dx), _dt(dy), _dt(wt), False, compute)
-    with _Timed(("conv2d_bwd_data", N, H, W, Cin, Cout, KH, stride)):
+    oh, ow = conv_out_hw(H, W, KH, KW, stride)
+    macs = float(N) * oh * ow * Cout * Cin * KH * KW
+    with _Timed(("conv2d_bwd_data", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(dy, wt, dx, relu_src)):
         _L.check(_L.load().hulc_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _p(relu_src),
                                                 ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_data")
     return dx
@@ -210,7 +222,9 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(dy), F32, False, compute)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    with _Timed(("conv2d_bwd_weight", N, H, W, Cin, Cout, KH, stride)):
+    oh, ow = conv_out_hw(H, W, KH, KW, stride)
+    macs = float(N) * oh * ow * Cout * Cin * KH * KW
+    with _Timed(("conv2d_bwd_weight", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, dy, dw, db)):
         _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                             ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
     return dw, db
@@ -222,7 +236,7 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
 _c = ctypes
 
 
-def _call(name, *args):
+def _call(name, *args, key=None, flops=0.0, nbytes=0.0):
     lib = _L.load()
     conv = []
     for a in args:
@@ -234,7 +248,7 @@ def _call(name, *args):
         else:
             conv.append(a)
     conv.append(_c.c_void_p(_stream()))
-    with _Timed((name,)):
+    with _Timed(key or (name,), flops, nbytes):
         _L.check(getattr(lib, name)(*conv), name)
 
 
@@ -287,7 +301,7 @@ def colsum(x, M, N, ld, out, accumulate=False):
     lib = _L.load()
     lib.hulc_colsum_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_colsum_workspace(_l(M), _i(N)), x.device)
-    _call("hulc_colsum", x, _i(_dt(x)), _l(M), _i(N), _l(ld), out, _i(accumulate), ws)
+    _call("hulc_colsum", x, _i(_dt(x)), _l(M), _i(N), _l(ld), out, _i(accumulate), ws, nbytes=float(M) * N * x.element_size())
 
 
 def seq_mean_fwd(x, y, B, S, D, scale=1.0):
@@ -352,7 +366,12 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     lib = _L.load()
     lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)
-    _call("hulc_rnn_wavefront", _c.byref(d), ws)
+    # algorithmic work: S wave steps of a (B x 2H) x (2H x 2H) product with one H x H block structurally zero; bytes: the
+    # three weight matrices once, per step the fp32 state row written + the bf16 copy written and read + add / masks read
+    flops = 2.0 * B * 3 * H * H * S
+    nbytes = 3.0 * H * H * 2 + S * B * (2 * H * 4 + 2 * 2 * H * 2 + (H * 4 if add1 is not None else 0)
+                                        + (H * 4 if mask1 is not None else 0) + (H * 4 if mask2 is not None else 0))
+    _call("hulc_rnn_wavefront", _c.byref(d), ws, key=("rnn_wavefront", S, B, H, int(bool(transposed))), flops=flops, nbytes=nbytes)
     return ws
 
 

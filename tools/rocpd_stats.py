@@ -32,5 +32,18 @@ def main(path):
     print(f"\ntotal kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
 
 
+def pmc(path):
+    """per-kernel average of every collected counter (view counters_collection): `python tools/rocpd_stats.py --pmc x.db`"""
+    c = sqlite3.connect(path)
+    rows = c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
+    rows.sort(key=lambda r: -r[3])
+    print(f"{'calls':>7} {'avg_value':>16} {'counter':>14}  kernel")
+    for name, ctr, n, v in rows:
+        print(f"{n:7d} {v / n:16.1f} {ctr:>14}  {short(name)}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[1] == "--pmc":
+        pmc(sys.argv[2])
+    else:
+        main(sys.argv[1])
