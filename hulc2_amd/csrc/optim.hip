@@ -68,6 +68,21 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     }
 }
 
+// transposed bf16 copies of 2-D weights, all in one launch: tile q = {src offset, rows, cols, tile row, tile col} (64 x 64 tiles);
+// dst holds W^T ([cols][rows]) at the same offset.  Lets the data-gradient GEMMs dX = dY W stream W k-major.
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                              const long* __restrict__ tiles) {
+    __shared__ uint16_t t[64][66];
+    const long* q = tiles + (long)blockIdx.x * 5;
+    const long off = q[0]; const int rows = (int)q[1], cols = (int)q[2], r0 = (int)q[3] * 64, c0 = (int)q[4] * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = src[off + (long)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < cols && r0 + tx < rows) dst[off + (long)(c0 + i) * rows + r0 + tx] = t[tx][i];
+}
+
 }  // namespace
 
 extern "C" int hulc_step_state_advance(unsigned long long* state, void* stream) {
@@ -95,4 +110,11 @@ extern "C" int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* 
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     cast_bf16_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, n);
     return hulc_check_launch("hulc_cast_f32_to_bf16");
+}
+
+extern "C" int hulc_transpose_bf16_tiles(const void* src, void* dst, const long* tiles, int ntiles, void* stream) {
+    if (!src || !dst || !tiles) return hulc_fail(-1, "hulc_transpose_bf16_tiles: null pointer");
+    if (ntiles <= 0) return 0;
+    transpose_tiles_kernel<<<(unsigned)ntiles, 256, 0, (hipStream_t)stream>>>((const uint16_t*)src, (uint16_t*)dst, tiles);
+    return hulc_check_launch("hulc_transpose_bf16_tiles");
 }

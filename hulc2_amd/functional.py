@@ -79,11 +79,11 @@ class MLPFn(torch.autograd.Function):
             grads[2 * i + 1] = None if sb is not None else db
             if i > 0 or need_x:
                 dinp = _f32(M, K, like=g)
+                wt = weight_operand(W, "t")                      # (K, N): the reduction index contiguous, like the forward pass
                 if i > 0 and relus[i - 1]:
-                    kn.gemm(g, weight_operand(W), dinp, M, K, N, g.stride(0), K, K, b_kmajor=False, mask=acts[i - 1], ld_mask=K,
-                            mask_scale=1.0 / (1.0 - drops[i - 1]))
+                    kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K, mask=acts[i - 1], ld_mask=K, mask_scale=1.0 / (1.0 - drops[i - 1]))
                 else:
-                    kn.gemm(g, weight_operand(W), dinp, M, K, N, g.stride(0), K, K, b_kmajor=False)
+                    kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K)
                 g = dinp
         dx = g.reshape(xshape) if need_x else None
         return (dx, None, None, None, *grads)
@@ -482,12 +482,13 @@ class DecoderRNNFn(torch.autograd.Function):
         kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
         if acc0:
             dw_ih0 = None
+        wih0_t = weight_operand(w_ih0, "t")                                         # (Kin, H): rows = input features, k-major
         dplan = torch.empty(B, P, **f32)
-        kn.gemm(dc, wih0, dplan, B, P, Hd, 2 * Hd, Kin, P, b_kmajor=False)
+        kn.gemm(dc, wih0_t, dplan, B, P, Hd, 2 * Hd, Hd, P)
         dgoal = torch.empty(B, G, **f32)
-        kn.gemm(dc, wih0[:, P + E:], dgoal, B, G, Hd, 2 * Hd, Kin, G, b_kmajor=False)
+        kn.gemm(dc, wih0_t[P + E:], dgoal, B, G, Hd, 2 * Hd, Hd, G)
         demb_t = torch.empty(S, B, E, **f32)
-        kn.gemm(d0, wih0[:, P:P + E], demb_t, M, E, Hd, 2 * Hd, Kin, E, b_kmajor=False)
+        kn.gemm(d0, wih0_t[P:P + E], demb_t, M, E, Hd, 2 * Hd, Hd, E)
         demb = torch.zeros(B, S, Etot, **f32)
         demb[:, :, lo:hi] = demb_t.permute(1, 0, 2)
         return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1)

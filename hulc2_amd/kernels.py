@@ -345,6 +345,11 @@ def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_mi
     return d
 
 
+def transpose_bf16_tiles(src, dst, tiles):
+    """tiles: int64 (ntiles, 5) device tensor {offset, rows, cols, tile row, tile col}"""
+    _call("hulc_transpose_bf16_tiles", src, dst, tiles, _i(tiles.shape[0]))
+
+
 def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1_step=0, ld_add1=0, bias1=(None, None), bias2=(None, None),
                   mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False):
     """Both RNN layers of one direction as one persistent kernel (csrc/rnn_wavefront.hip).  z0: view of the (zero) state row

@@ -15,12 +15,14 @@ from . import kernels as kn
 
 _cache: Dict[Tuple[int, Optional[str], int], Tuple[int, torch.Tensor, "weakref.ref"]] = {}
 _arena: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}   # id(param) -> (weakref(param), bf16 view into the shadow arena)
+_arena_t: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}  # id(param) -> (weakref(param), bf16 W^T view, refreshed by the trainer)
 _epoch = 0                                # bumped by optimizers that update parameters through raw pointers
 
 
 def clear() -> None:
     _cache.clear()
     _arena.clear()
+    _arena_t.clear()
 
 
 def bump_epoch() -> None:
@@ -34,6 +36,12 @@ def register_arena_view(param: torch.Tensor, view_bf16: torch.Tensor) -> None:
     """The native trainer keeps one flat bf16 arena that the Adam kernel refreshes in place."""
     key = id(param)
     _arena[key] = (weakref.ref(param, lambda _r, k=key: _arena.pop(k, None)), view_bf16)
+
+
+def register_arena_view_t(param: torch.Tensor, view_bf16_t: torch.Tensor) -> None:
+    """transposed bf16 shadow (cols, rows) kept fresh by the trainer (one hulc_transpose_bf16_tiles launch per step)"""
+    key = id(param)
+    _arena_t[key] = (weakref.ref(param, lambda _r, k=key: _arena_t.pop(k, None)), view_bf16_t)
 
 
 def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
@@ -59,8 +67,8 @@ def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tenso
     if not bf16:
         if layout in (None, "oihw_flat"):
             return _layout(base, layout) if layout else base
-    elif layout is None:
-        hit = _arena.get(id(w))
+    elif layout is None or layout == "t":
+        hit = (_arena if layout is None else _arena_t).get(id(w))
         if hit is not None and hit[0]() is w:       # ids are recycled: trust the entry only for the very same tensor object
             return hit[1]
     key = (id(w), layout, int(bf16))

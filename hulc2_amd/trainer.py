@@ -123,6 +123,26 @@ class ArenaTrainer:
                     shadow.register_arena_view(p, self.flat_bf16[off:off + n].view(p.shape))
         if self.flat_bf16 is not None:
             kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, total)
+        # transposed bf16 shadows of the nn.Linear weights (data-gradient GEMMs read W^T k-major); RNN and conv weights are
+        # consumed in place by their own kernels and stay out of the table
+        self.flat_bf16_t = self.tiles_t = None
+        if self.flat_bf16 is not None:
+            names = {id(p): n for n, p in model.named_parameters()}
+            tiles = []
+            for p, off in zip(self.params, self.offsets):
+                nm = names.get(id(p), "")
+                if p.dim() != 2 or "rnn.weight_hh" in nm or "rnn.weight_ih_l1" in nm or min(p.shape) < 8:
+                    continue
+                r, c = p.shape
+                tiles += [(off, r, c, i, j) for i in range((r + 63) // 64) for j in range((c + 63) // 64)]
+            if tiles:
+                self.flat_bf16_t = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+                self.tiles_t = torch.tensor(tiles, dtype=torch.int64, device=dev)
+                covered = {t[0] for t in tiles}
+                for p, off in zip(self.params, self.offsets):
+                    if off in covered:
+                        shadow.register_arena_view_t(p, self.flat_bf16_t[off:off + p.numel()].view(p.shape[1], p.shape[0]))
+                kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
         gradsink.clear()
@@ -145,6 +165,8 @@ class ArenaTrainer:
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,
                      step_state_dev=kn.step_state(self.dev))      # step count lives on the device (graph replay)
+        if self.tiles_t is not None:
+            kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
         shadow.bump_epoch()
 
     def _forward_backward(self, batch, batch_idx: int) -> torch.Tensor:

@@ -190,6 +190,10 @@ int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shad
  * step_state != NULL (the `step` argument is then ignored). */
 int hulc_step_state_advance(unsigned long long* state, void* stream);
 int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* Transposed bf16 shadows of the 2-D weights of the arena in one launch: tiles[q] = {element offset, rows, cols, tile row,
+ * tile col} over 64 x 64 tiles; dst + offset receives W^T ([cols][rows]).  The data-gradient GEMMs (dX = dY W of every
+ * nn.Linear) then read W k-major like the forward pass does. */
+int hulc_transpose_bf16_tiles(const void* src, void* dst, const long* tiles, int ntiles, void* stream);
 
 #ifdef __cplusplus
 }
