@@ -35,6 +35,7 @@ struct BandP {
     int OHmax, OWmax;               // largest class grid: defines the staged band
     int pad_y, pad_x;               // band origin: input row = oy*S + ty - pad_y
     int R;                          // output rows per work unit
+    int F;                          // > 1: a work unit is F whole frames (small maps; then R == OHmax)
     long x_sn, x_sy, x_sx;          // input element strides
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
@@ -52,7 +53,7 @@ HULC_DEVICE uint4 band_load_bits(const void* X, int dtype, long off) {
 }
 
 // C: input channels, NSET: weight sets (32 output channels each), TH x TW taps, S: input stride, MAXCH: band chunks/thread
-template <int C, int NSET, int TH, int TW, int S, int MAXCH>
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI>
 __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     const BandCls& cl = p.cls[set];
     const int Wb = (p.OWmax - 1) * S + TW;                  // band columns (padding included)
     const int bands = (p.OHmax + p.R - 1) / p.R;
-    const int nunits = p.Nimg * bands;
+    const int nunits = MULTI ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
 
     // ---- this wave's weight tile -> registers (A operand: lane = output channel row, 8 consecutive k)
     bf16x8_t wfrag[KSTEPS];
@@ -84,29 +85,32 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
     const int cc = tid % CPP;
     uint4 pre[MAXCH];
-    auto band_rows = [&](int unit, int& n, int& r0, int& R, int& rows) {
-        n = unit / bands; const int b = unit % bands;
-        r0 = b * p.R; R = (r0 + p.R <= p.OHmax) ? p.R : p.OHmax - r0; rows = (R - 1) * S + TH;
+    // unit -> first frame n, frames in the unit fu, first output row r0, output rows R, band rows per frame
+    auto band_rows = [&](int unit, int& n, int& fu, int& r0, int& R, int& rows) {
+        if (MULTI) { n = unit * p.F; fu = n + p.F <= p.Nimg ? p.F : p.Nimg - n; r0 = 0; R = p.OHmax; }
+        else { n = unit / bands; fu = 1; const int b = unit % bands; r0 = b * p.R; R = (r0 + p.R <= p.OHmax) ? p.R : p.OHmax - r0; }
+        rows = (R - 1) * S + TH;
     };
     auto stage_load = [&](int unit) {
-        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
-        const int iy0 = r0 * S - p.pad_y, npx = rows * Wb;
+        int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
+        const int iy0 = r0 * S - p.pad_y, fpx = rows * Wb, npx = fu * fpx;
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j) {
             const int px = tid / CPP + j * (NT / CPP);
-            const int pxc = px < npx ? px : 0;
+            int pxc = px < npx ? px : 0, f = 0;
+            if (MULTI) { f = pxc / fpx; pxc -= f * fpx; }
             const int br = pxc / Wb, bc = pxc % Wb;
             const int iy = iy0 + br, ix = bc - p.pad_x;
             const bool inb = px < npx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             // unconditional load from a clamped address, then select (no branch around the load)
-            const long off = inb ? (long)n * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
+            const long off = inb ? (long)(n + f) * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
             const uint4 t = band_load_bits(p.X, p.x_dtype, off);
             pre[j].x = inb ? t.x : 0u; pre[j].y = inb ? t.y : 0u; pre[j].z = inb ? t.z : 0u; pre[j].w = inb ? t.w : 0u;
         }
     };
     auto stage_store = [&](int unit) {
-        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
-        const int npx = rows * Wb;
+        int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
+        const int npx = fu * rows * Wb;
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j) {
             const int px = tid / CPP + j * (NT / CPP);
@@ -121,16 +125,18 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         const int next = unit + gridDim.x;
         if (next < nunits) stage_load(next);                 // in flight during the MFMA loop below
 
-        int n, r0, R, rows; band_rows(unit, n, r0, R, rows);
+        int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int Rc = r0 < cl.OH ? ((r0 + R <= cl.OH) ? R : cl.OH - r0) : 0;   // this class may have fewer rows/cols
-        const int npix = Rc * cl.OW;
+        const int fpix = Rc * cl.OW, npix = fu * fpix;
         const int ntile = (npix + 31) / 32;
         for (int tile = part; tile < ntile; tile += WPS) {
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
+            int f = 0;
+            if (MULTI) { f = q / fpix; q -= f * fpix; }
             const int oy = q / cl.OW, ox = q % cl.OW;
-            const char* a0 = band + ((oy * S) * Wb + ox * S) * PS + h * 16;
+            const char* a0 = band + ((f * rows + oy * S) * Wb + ox * S) * PS + h * 16;
             f32x16_t acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             }
             // ---- epilogue: lane = pixel; registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}
             if (live) {
-                const long off = cl.y_off + (long)n * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base + 4 * h;
+                const long off = cl.y_off + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // registers 4g..4g+3 hold channels co_base + 8g + 4h + {0..3}: one aligned float4 of the bias vector
@@ -192,20 +198,37 @@ int launch_band(BandP& p, hipStream_t s) {
     auto px_of = [&](int rr) { return (long)((rr - 1) * S + TH) * Wb; };
     while (R > 1 && (px_of(R) * PS > budget || px_of(R) > max_px)) --R;
     if (px_of(R) * PS > budget || px_of(R) > max_px) return -1;
-    const int bands = (p.OHmax + R - 1) / R;
-    R = (p.OHmax + bands - 1) / bands;                       // equal-ish bands
-    p.R = R;
-    if ((long)R * p.OWmax < 128) return -1;                  // tiny frames: one unit cannot feed 8 waves, the gather kernel is faster
-    const size_t lds = (size_t)px_of(R) * PS;
-    const int nunits = p.Nimg * bands;
-    const int grid = nunits < 256 ? nunits : 256;
-    auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-        attr_set = true;
+    int F = 1, nunits;
+    if (R == p.OHmax) {                                      // whole frames fit: pack several into one unit (small gripper maps)
+        while (F < p.Nimg && px_of(R) * (F + 1) * PS <= budget && px_of(R) * (F + 1) <= max_px) ++F;
+        nunits = (p.Nimg + F - 1) / F;
+    } else {
+        const int bands = (p.OHmax + R - 1) / R;
+        R = (p.OHmax + bands - 1) / bands;                   // equal-ish bands
+        nunits = p.Nimg * bands;
     }
-    kern<<<grid, 512, lds, s>>>(p);
+    p.R = R; p.F = F;
+    if ((long)F * R * p.OWmax < 128) return -1;              // a unit that cannot feed 8 waves: the gather kernel is faster
+    const size_t lds = (size_t)px_of(R) * F * PS;
+    const int per = (nunits + 255) / 256;                    // balanced persistent grid
+    const int grid = (nunits + per - 1) / per;
+    if (F > 1) {
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            attr_set = true;
+        }
+        kern<<<grid, 512, lds, s>>>(p);
+    } else {
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            attr_set = true;
+        }
+        kern<<<grid, 512, lds, s>>>(p);
+    }
     return 0;
 }
 
@@ -224,7 +247,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     BandP p;
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
-    p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1;
+    p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
     p.ldw = ldw; p.relu = relu;
     p.OHmax = 0; p.OWmax = 0;

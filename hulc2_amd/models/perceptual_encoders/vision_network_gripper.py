@@ -36,7 +36,9 @@ class VisionNetwork(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=False)     # (N, 7, 7, 64) NHWC
-        flat = a3.permute(0, 3, 1, 2).reshape(a3.shape[0], -1)              # Flatten order of the reference (C, H, W)
+        # Flatten order of the reference (C, H, W); one copy that also widens to fp32, so the 3136 -> 128 weight-gradient GEMM
+        # reads a row-major fp32 operand (16-byte micro-tile staging) instead of 2-byte strided bf16 loads
+        flat = a3.permute(0, 3, 1, 2).to(torch.float32, memory_format=torch.contiguous_format).reshape(a3.shape[0], -1)
         c = self.conv_model
         y = HF.mlp(flat, [(c[7].weight, c[7].bias, True), (self.fc1[0].weight, self.fc1[0].bias, True),
                           (self.fc2.weight, self.fc2.bias, False)])
