@@ -174,20 +174,24 @@ HULC_DEVICE float sub32_max(float v) {
     return v;
 }
 
-// out[0] = beta * (mix*KL + (1-mix)*KL) = beta*KL_mean (value), single workgroup, CLS == 32
-__global__ __launch_bounds__(1024) void cat_kl_fwd_kernel(const float* __restrict__ pp, const float* __restrict__ pr, int B, int G,
-                                                          float beta, float* __restrict__ out, float* __restrict__ kl_group) {
+// out[0] = beta * (mix*KL + (1-mix)*KL) = beta*KL_mean (value), CLS == 32: one 32-lane sub-wave per (row, category) group,
+// then a single workgroup sums the B*G group values in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void cat_kl_group_kernel(const float* __restrict__ pp, const float* __restrict__ pr, int NG,
+                                                           float* __restrict__ kl_group) {
+    const int lane = threadIdx.x & 31;
+    const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (g >= NG) return;
+    const float a = pr[(long)g * 32 + lane], b = pp[(long)g * 32 + lane];
+    const float ma = sub32_max(a), mb = sub32_max(b);
+    const float lp = a - (ma + logf(sub32_sum(expf(a - ma))));
+    const float lq = b - (mb + logf(sub32_sum(expf(b - mb))));
+    const float kl = sub32_sum(expf(lp) * (lp - lq));
+    if (lane == 0) kl_group[g] = kl;
+}
+__global__ __launch_bounds__(1024) void cat_kl_sum_kernel(const float* __restrict__ kl_group, int NG, int B, float beta, float* __restrict__ out) {
     __shared__ float sh[16];
-    const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5, nsub = blockDim.x >> 5;
     float acc = 0.f;
-    for (int g = sub; g < B * G; g += nsub) {
-        const float a = pr[(long)g * 32 + lane], b = pp[(long)g * 32 + lane];
-        const float ma = sub32_max(a), mb = sub32_max(b);
-        const float lp = a - (ma + logf(sub32_sum(expf(a - ma))));
-        const float lq = b - (mb + logf(sub32_sum(expf(b - mb))));
-        const float kl = sub32_sum(expf(lp) * (lp - lq));
-        if (lane == 0) { kl_group[g] = kl; acc += kl; }
-    }
+    for (int g = threadIdx.x; g < NG; g += blockDim.x) acc += kl_group[g];
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) out[0] = beta * acc / B;
 }
@@ -409,7 +413,8 @@ extern "C" int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const f
 extern "C" int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, float* out, float* kl_group, void* stream) {
     if (!pp || !pr || !out || !kl_group) return hulc_fail(-1, "hulc_cat_kl_fwd: null pointer");
     if (CLS != 32) return hulc_fail(-2, "hulc_cat_kl_fwd: class_size must be 32 (one 32-lane sub-wave per category)");
-    cat_kl_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pp, pr, B, G, beta, out, kl_group);
+    cat_kl_group_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, B * G, kl_group);
+    cat_kl_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kl_group, B * G, B, beta, out);
     return hulc_check_launch("hulc_cat_kl_fwd");
 }
 extern "C" int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int B, int G, int CLS, float beta, float mix,

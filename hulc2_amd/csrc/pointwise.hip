@@ -79,6 +79,92 @@ __global__ __launch_bounds__(256) void spatial_softmax_bwd_kernel(const void* __
     }
 }
 
+// ---- C == 64 fast path: a lane owns 8 channels of one position (one 16-byte bf16 / two 16-byte fp32 loads), 8 lanes cover a
+// position, a wave 8 positions per step; ONE pass over the frame with an online (running-max) softmax, partials merged across
+// the 8 position lanes by shuffles and across the 4 waves through LDS in a fixed order.
+struct SsmAcc { float m, s, sx, sy; };
+HULC_DEVICE void ssm_merge(SsmAcc& a, float m2, float s2, float sx2, float sy2) {
+    const float mn = fmaxf(a.m, m2);
+    const float c1 = a.m == -INFINITY ? 0.f : __expf(a.m - mn), c2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);   // empty partials weigh 0
+    a.s = a.s * c1 + s2 * c2; a.sx = a.sx * c1 + sx2 * c2; a.sy = a.sy * c1 + sy2 * c2; a.m = mn;
+}
+__global__ __launch_bounds__(256) void spatial_softmax_fwd64_kernel(const void* __restrict__ x, int x_dtype, int HW,
+                                                                    const float* __restrict__ xmap, const float* __restrict__ ymap,
+                                                                    const float* __restrict__ temperature, float* __restrict__ out,
+                                                                    float* __restrict__ stats) {
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 7, pl = lane >> 3;
+    const int n = blockIdx.x;
+    const float invT = 1.0f / temperature[0];
+    const long base = (long)n * HW * 64 + cg * 8;
+    SsmAcc a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j].m = -INFINITY; a[j].s = 0.f; a[j].sx = 0.f; a[j].sy = 0.f; }
+    for (int p = wave * 8 + pl; p < HW; p += 32) {
+        Chunk8 c; chunk_load_contig(c, x, x_dtype, base + (long)p * 64);
+        const float xm = xmap[p], ym = ymap[p];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = c.v[j] * invT;
+            const float mn = fmaxf(a[j].m, v);
+            const float sc = __expf(a[j].m - mn), e = __expf(v - mn);
+            a[j].s = a[j].s * sc + e; a[j].sx = a[j].sx * sc + e * xm; a[j].sy = a[j].sy * sc + e * ym; a[j].m = mn;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+            ssm_merge(a[j], __shfl_xor(a[j].m, o, 64), __shfl_xor(a[j].s, o, 64), __shfl_xor(a[j].sx, o, 64), __shfl_xor(a[j].sy, o, 64));
+        if (pl == 0) { red[wave][0][cg * 8 + j] = a[j].m; red[wave][1][cg * 8 + j] = a[j].s; red[wave][2][cg * 8 + j] = a[j].sx; red[wave][3][cg * 8 + j] = a[j].sy; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        SsmAcc t; t.m = red[0][0][lane]; t.s = red[0][1][lane]; t.sx = red[0][2][lane]; t.sy = red[0][3][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) ssm_merge(t, red[w][0][lane], red[w][1][lane], red[w][2][lane], red[w][3][lane]);
+        const float inv = 1.0f / t.s;
+        out[(long)n * 128 + 2 * lane] = t.sx * inv;
+        out[(long)n * 128 + 2 * lane + 1] = t.sy * inv;
+        stats[((long)n * 64 + lane) * 2] = t.m;
+        stats[((long)n * 64 + lane) * 2 + 1] = t.s;
+    }
+}
+__global__ __launch_bounds__(256) void spatial_softmax_bwd64_kernel(const void* __restrict__ x, int x_dtype, int HW,
+                                                                    const float* __restrict__ xmap, const float* __restrict__ ymap,
+                                                                    const float* __restrict__ temperature, const float* __restrict__ out,
+                                                                    const float* __restrict__ stats, const float* __restrict__ dout,
+                                                                    void* __restrict__ dx, int dx_dtype, int relu_mask) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 7, pl = lane >> 3;
+    const int n = blockIdx.x;
+    const float invT = 1.0f / temperature[0];
+    const long base = (long)n * HW * 64 + cg * 8;
+    float m[8], k[8], ex[8], ey[8], gx[8], gy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        m[j] = stats[((long)n * 64 + c) * 2]; k[j] = invT / stats[((long)n * 64 + c) * 2 + 1];
+        ex[j] = out[(long)n * 128 + 2 * c]; ey[j] = out[(long)n * 128 + 2 * c + 1];
+        gx[j] = dout[(long)n * 128 + 2 * c]; gy[j] = dout[(long)n * 128 + 2 * c + 1];
+    }
+    for (int p = wave * 8 + pl; p < HW; p += 32) {
+        Chunk8 c; chunk_load_contig(c, x, x_dtype, base + (long)p * 64);
+        const float xm = xmap[p], ym = ymap[p];
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g[j] = k[j] * __expf(c.v[j] * invT - m[j]) * (gx[j] * (xm - ex[j]) + gy[j] * (ym - ey[j]));
+            if (relu_mask && !(c.v[j] > 0.f)) g[j] = 0.f;
+        }
+        const long o = base + (long)p * 64;
+        if (dx_dtype == HULC_BF16) *(uint4*)((uint16_t*)dx + o) = make_uint4(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]), pack_bf16x2(g[4], g[5]), pack_bf16x2(g[6], g[7]));
+        else { ((float4*)((float*)dx + o))[0] = make_float4(g[0], g[1], g[2], g[3]); ((float4*)((float*)dx + o))[1] = make_float4(g[4], g[5], g[6], g[7]); }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension D <= 256 (one wave per row, up to 4 elements per lane)
 //   pre = x + dropout(o)   (o optional)   y = (pre - mean) * rstd * gamma + beta
@@ -482,7 +568,11 @@ extern "C" int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int H
                                         const float* temperature, float* out, float* stats, void* stream) {
     if (!x || !xmap || !ymap || !temperature || !out || !stats) return hulc_fail(-1, "hulc_spatial_softmax_fwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_fwd: C must be in 1..64 (lane = channel)");
-    spatial_softmax_fwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
+    const int esz = x_dtype == HULC_F32 ? 4 : 2;
+    if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0)
+        spatial_softmax_fwd64_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, HW, xmap, ymap, temperature, out, stats);
+    else
+        spatial_softmax_fwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
     return hulc_check_launch("hulc_spatial_softmax_fwd");
 }
 
@@ -491,7 +581,12 @@ extern "C" int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int H
                                         void* dx, int dx_dtype, int relu_mask, void* stream) {
     if (!x || !out || !stats || !dout || !dx) return hulc_fail(-1, "hulc_spatial_softmax_bwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_bwd: C must be in 1..64");
-    spatial_softmax_bwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats,
+    const int esz = x_dtype == HULC_F32 ? 4 : 2, dsz = dx_dtype == HULC_F32 ? 4 : 2;
+    if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0 && ((uintptr_t)dx % (8 * dsz)) == 0)
+        spatial_softmax_bwd64_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, HW, xmap, ymap, temperature, out, stats, dout, dx, dx_dtype,
+                                                                      relu_mask);
+    else
+        spatial_softmax_bwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats,
                                                                              dout, dx, dx_dtype, relu_mask);
     return hulc_check_launch("hulc_spatial_softmax_bwd");
 }
@@ -506,8 +601,10 @@ extern "C" int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, 
     return hulc_check_launch("hulc_layernorm_fwd");
 }
 
+// rows per workgroup: ~256 workgroups (one per CU) once there are enough rows, never fewer than 4 rows (one per wave)
+static int ln_bwd_rows_per_block(int R) { const int r = (R + 255) / 256; return r < 4 ? 4 : r; }
 extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
-    const int rpb = 32;
+    const int rpb = ln_bwd_rows_per_block(R);
     return (long)((R + rpb - 1) / rpb) * 2 * D * (long)sizeof(float);
 }
 
@@ -516,7 +613,7 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
                                   float* dgamma, float* dbeta, void* ws, void* stream) {
     if (!dy || !pre || !mean || !rstd || !gamma || !dpre || !dgamma || !dbeta || !ws) return hulc_fail(-1, "hulc_layernorm_bwd: null pointer");
     if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_bwd: D must be in 1..256");
-    const int rpb = 32, nb = (R + rpb - 1) / rpb;
+    const int rpb = ln_bwd_rows_per_block(R), nb = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, seed_dev, (float*)ws);
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
