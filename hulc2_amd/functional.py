@@ -346,6 +346,7 @@ def _rnn_persistent(B: int, Hd: int, state_dtype) -> bool:
     other geometries and the exact-fp32 mode use the per-step GEMMs.  HULC_NO_RNN_WAVEFRONT=1 forces the per-step path."""
     import os
     return (kn.get_compute() == "bf16" and Hd == 2048 and B <= 64 and state_dtype == torch.float32
+            and not kn.concurrent_streams()          # its device-wide barrier needs the GPU to itself (kernels.set_concurrent_streams)
             and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
 
 

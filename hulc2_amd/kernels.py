@@ -345,6 +345,21 @@ def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_mi
     return d
 
 
+# Kernels with a device-wide barrier (rnn_wavefront) need every workgroup co-resident: they must not share the GPU with
+# kernels on other streams (e.g. RCCL all-reduces overlapped with backward).  The trainer declares that situation here and
+# the recurrent decoder then takes its per-step GEMM path.
+_concurrent_streams = False
+
+
+def set_concurrent_streams(flag: bool) -> None:
+    global _concurrent_streams
+    _concurrent_streams = bool(flag)
+
+
+def concurrent_streams() -> bool:
+    return _concurrent_streams
+
+
 def transpose_bf16_tiles(src, dst, tiles):
     """tiles: int64 (ntiles, 5) device tensor {offset, rows, cols, tile row, tile col}"""
     _call("hulc_transpose_bf16_tiles", src, dst, tiles, _i(tiles.shape[0]))

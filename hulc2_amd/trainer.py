@@ -145,6 +145,8 @@ class ArenaTrainer:
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
+        # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
+        kn.set_concurrent_streams(dev.type == "cuda" and self.world > 1 and overlap)
         gradsink.clear()
         if dev.type == "cuda" and (self.world == 1 or not overlap):     # no per-parameter all-reduce hooks depend on AccumulateGrad
             for p, off in zip(self.params, self.offsets):

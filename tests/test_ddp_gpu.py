@@ -1,0 +1,81 @@
+"""Two data-parallel ranks sharing ONE MI355X (gloo transport on device tensors): the multi-process training paths of
+hulc2_amd/trainer.py on the GPU — eager bucketed all-reduce overlapped with backward, and hipGraph replay with the
+arena all-reduce between the two graphs (what bench.py runs with --gpus N; there the backend is "nccl" = RCCL, one GPU per
+rank).  Both ranks must stay bit-identical replicas.  Sharing a GPU between processes is exactly the situation the
+device-wide-barrier RNN kernel must not run in, so it is switched off here (HULC_NO_RNN_WAVEFRONT)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, graph, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HULC_NO_RNN_WAVEFRONT="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hulc2_amd import kernels as kn, synthetic as syn
+    from hulc2_amd.compat import instantiate
+    from hulc2_amd.config import default_model_config
+    from hulc2_amd.trainer import ArenaTrainer
+
+    kn.set_compute("bf16")
+    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    syn.fill_state_dict_(model.state_dict(), 42)
+    model.train()
+    tr = ArenaTrainer(model, lr=2e-4, overlap=not graph)
+    batch = syn.make_batch(100 + rank, 2, 8, device=dev)          # different data per rank
+    for db in batch.values():
+        db.pop("plan_idx", None)
+    losses = []
+    if graph:
+        tr.capture(batch)
+        for _ in range(3):
+            losses.append(float(tr.replay()))
+    else:
+        for i in range(3):
+            losses.append(float(tr.step(batch, i)))
+    torch.cuda.synchronize()
+    p = tr.flat_p.double()
+    mine = torch.stack([p.sum(), (p * p).sum()]).cpu()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok = all(torch.isfinite(torch.tensor(losses))) and torch.equal(both[0], both[1])
+    if rank == 0:
+        out.put((bool(ok), losses, [b.tolist() for b in both]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_stay_identical(graph):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok, losses, sums = q.get(timeout=5)
+    assert ok, f"replicas diverged or non-finite loss: losses {losses}, parameter checksums {sums}"

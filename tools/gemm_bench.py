@@ -3,7 +3,9 @@ sys.path.insert(0, '.')
 from hulc2_amd import kernels as kn
 dev = torch.device('cuda')
 kn.set_compute("bf16")
-shapes = [(2048, 2048, 2048, 0, 0), (2048, 2048, 32, 0, 0), (128, 3136, 1024, 0, 0), (128, 2048, 1024, 0, 0), (512, 128, 1024, 0, 0), (2048, 128, 1024, 0, 0),
+shapes = [(128, 128, 2048, 0, 0), (384, 128, 2048, 0, 0), (512, 128, 2048, 0, 0), (2048, 128, 2048, 0, 0), (128, 3136, 2048, 0, 0), (64, 512, 2048, 0, 0),
+          (2048, 128, 128, 1, 1), (2048, 2048, 128, 1, 1), (2048, 128, 2048, 1, 1), (2048, 3136, 128, 1, 1), (2048, 384, 128, 1, 1), (2048, 512, 128, 1, 1), (2048, 64, 512, 1, 1),
+          (2048, 2048, 2048, 0, 0), (2048, 2048, 32, 0, 0), (128, 3136, 1024, 0, 0), (128, 2048, 1024, 0, 0), (512, 128, 1024, 0, 0), (2048, 128, 1024, 0, 0),
           (1024, 128, 2048, 1, 0), (1024, 128, 384, 1, 0), (1024, 3136, 128, 1, 0), (1024, 2048, 128, 1, 1), (1024, 128, 2048, 1, 1)]
 for M, N, K, ak, bk in shapes:
     A = torch.randn((M, K) if ak else (K, M), device=dev)
