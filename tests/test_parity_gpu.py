@@ -264,6 +264,31 @@ def test_modality_batching_equals_per_modality(dev, model, mode, monkeypatch):
         close(g_b[n], g_s[n].cpu().numpy(), tol, f"g {n} (batched vs per modality)")
 
 
+def test_split_backward_equals_whole_backward(dev, model):
+    """backward stopped at the encoder output + encoder backward (the graph-mode split that overlaps the gradient all-reduce
+    with the conv backward) produces exactly the gradients of one whole backward"""
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.trainer import ArenaTrainer
+
+    kn.set_compute("bf16")
+    import copy
+    m = copy.deepcopy(model)
+    tr = ArenaTrainer(m, lr=0.0)
+    assert tr.enc_hi > tr.enc_lo and tr.enc_params
+    batch = syn.make_batch(91, 2, 8, device=dev)        # plan_idx injected, dropout 0: deterministic
+    tr._forward_backward(batch, 0)
+    whole = tr.flat_g.clone()
+    tr._forward_backward_head(batch, 0)
+    enc = slice(tr.enc_lo, tr.enc_hi)
+    assert float(tr.flat_g[enc].abs().max()) == 0.0, "encoder gradients must not exist before the encoder backward"
+    head = tr.flat_g.clone()
+    tr._backward_encoder()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.flat_g[:tr.enc_lo], head[:tr.enc_lo]) and torch.equal(tr.flat_g[tr.enc_hi:], head[tr.enc_hi:]), \
+        "the encoder backward must not touch the other gradients"
+    assert torch.equal(tr.flat_g, whole), "split backward differs from the whole backward"
+
+
 def test_logistic_mixture_edges(dev):
     """every branch of the torch.where ladder of _logistic_loss (logistic_decoder_rnn.py:206-225)"""
     from hulc2_amd import functional as HF
