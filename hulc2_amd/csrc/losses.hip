@@ -371,6 +371,67 @@ __global__ void world_to_tcp_kernel(const float* __restrict__ act, const float* 
     y[6] = a[6];
 }
 
+// tcp -> world frame (gripper_control.py:39-63): pos_w = R p, R_new = R * R(0.01*orn)^-1, orn_w = euler(R_new) - euler_obs, wrapped, x100
+__global__ void tcp_to_world_kernel(const float* __restrict__ act, const float* __restrict__ obs, int n, int obs_dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = act + (long)i * 7;
+    const float* o = obs + (long)i * obs_dim;
+    float R[3][3], Q[3][3];
+    euler_xyz(o[3], o[4], o[5], R);
+    euler_xyz(0.01f * a[3], 0.01f * a[4], 0.01f * a[5], Q);
+    float* y = out + (long)i * 7;
+    for (int r = 0; r < 3; ++r) y[r] = R[r][0] * a[0] + R[r][1] * a[1] + R[r][2] * a[2];
+    float M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = R[r][0] * Q[c][0] + R[r][1] * Q[c][1] + R[r][2] * Q[c][2];       // R Q^T (Q^-1 = Q^T)
+    float e[3] = {atan2f(-M[1][2], M[2][2]), asinf(fminf(fmaxf(M[0][2], -1.f), 1.f)), atan2f(-M[0][1], M[0][0])};
+    const float pi = 3.14159265358979323846f;
+    for (int r = 0; r < 3; ++r) {
+        float d = e[r] - o[3 + r];
+        if (d < -pi) d += 2 * pi;
+        if (d > pi) d -= 2 * pi;
+        y[3 + r] = d * 100.f;
+    }
+    y[6] = a[6];
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling from the logistic mixture (logistic_decoder_rnn.py:231-255): Gumbel-max over the mixtures, inverse-CDF draw from the
+// selected logistic, gripper = bounds[argmax].  One thread per (token, action dimension).  u_mix / u_inv (optional) inject the
+// raw uniforms torch.rand would have produced (parity tests); otherwise the counter RNG supplies them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mix_sample_kernel(MixP p, const float* __restrict__ u_mix, const float* __restrict__ u_inv,
+                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                         const float* __restrict__ gripper_bounds, float* __restrict__ act_out,
+                                                         long* __restrict__ idx_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)p.T * (p.A + 1)) return;
+    if (seed_dev) seed ^= seed_dev[0];
+    const int t = (int)(i / (p.A + 1)), a = (int)(i % (p.A + 1));
+    const float* row = p.y + (long)t * p.ld;
+    const int n = p.A * p.NM;
+    if (a == p.A) {                                                  // gripper command: first maximum of the two logits
+        const int g = row[3 * n + 1] > row[3 * n] ? 1 : 0;
+        act_out[(long)t * (p.A + 1) + p.A] = gripper_bounds[g];
+        return;
+    }
+    const float c = (float)(1e-5 - (1.0 - 1e-5)), r2 = (float)(1.0 - 1e-5);   // u = (r1 - r2) * rand + r2, as separate mul and add
+    int best = 0; float best_v = -INFINITY;
+    for (int k = 0; k < p.NM; ++k) {
+        const float raw = u_mix ? u_mix[((long)t * p.A + a) * p.NM + k] : hulc_uniform01(seed, (uint64_t)(((long)t * p.A + a) * p.NM + k));
+        const float u = __fadd_rn(__fmul_rn(c, raw), r2);
+        const float v = row[a * p.NM + k] - logf(-logf(u));
+        if (v > best_v) { best_v = v; best = k; }
+    }
+    const float mean = row[n + a * p.NM + best];
+    const float ls = fmaxf(row[2 * n + a * p.NM + best], p.log_scale_min);
+    const float raw = u_inv ? u_inv[(long)t * p.A + a] : hulc_uniform01(seed ^ 0x9E3779B97F4A7C15ull, (uint64_t)((long)t * p.A + a));
+    const float u = __fadd_rn(__fmul_rn(c, raw), r2);
+    act_out[(long)t * (p.A + 1) + a] = mean + expf(ls) * (logf(u) - logf(1.0f - u));
+    if (idx_out) idx_out[(long)t * p.A + a] = best;
+}
+
 MixP make_mix(const hulc_mix_desc* d, const float* y, const float* act) {
     MixP p;
     p.y = y; p.ld = d->ld; p.act = act; p.amin = d->act_min; p.amax = d->act_max;
@@ -460,4 +521,21 @@ extern "C" int hulc_world_to_tcp(const float* act, const float* robot_obs, int n
     if (obs_dim < 6) return hulc_fail(-2, "hulc_world_to_tcp: robot_obs needs the euler angles in columns 3:6");
     world_to_tcp_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(act, robot_obs, n, obs_dim, out);
     return hulc_check_launch("hulc_world_to_tcp");
+}
+
+extern "C" int hulc_tcp_to_world(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream) {
+    if (!act || !robot_obs || !out) return hulc_fail(-1, "hulc_tcp_to_world: null pointer");
+    if (obs_dim < 6) return hulc_fail(-2, "hulc_tcp_to_world: robot_obs needs the euler angles in columns 3:6");
+    tcp_to_world_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(act, robot_obs, n, obs_dim, out);
+    return hulc_check_launch("hulc_tcp_to_world");
+}
+
+extern "C" int hulc_mix_sample(const hulc_mix_desc* d, const float* y, const float* u_mix, const float* u_inv, unsigned long long seed,
+                               const unsigned long long* seed_dev, const float* gripper_bounds, float* act_out, long* idx_out, void* stream) {
+    if (!d || !y || !gripper_bounds || !act_out) return hulc_fail(-1, "hulc_mix_sample: null pointer");
+    if (d->T <= 0 || d->A <= 0 || d->n_mix <= 0 || d->ld < 3L * d->A * d->n_mix + 2) return hulc_fail(-2, "hulc_mix_sample: bad geometry");
+    MixP p = make_mix(d, y, nullptr);
+    const long n = (long)d->T * (d->A + 1);
+    mix_sample_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, u_mix, u_inv, seed, seed_dev, gripper_bounds, act_out, idx_out);
+    return hulc_check_launch("hulc_mix_sample");
 }

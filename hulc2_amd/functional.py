@@ -350,6 +350,65 @@ def _rnn_persistent(B: int, Hd: int, state_dtype) -> bool:
             and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
 
 
+def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, h0):
+    """Forward sweep shared by training (DecoderRNNFn) and inference (decoder_rnn_infer).  h0: None (zero initial state, the
+    training path) or (2, B, H) initial hidden states of the two layers (stateful `act`).  Returns the time-major state buffer
+    zbuf (S+2, B, 2H) with zbuf[t+1] = [h0_t | h1_{t-1}], the operands backward needs, and whether the persistent kernel ran."""
+    B, S, _ = emb.shape
+    Hd = w_hh0.shape[0]
+    P, G, E = plan.shape[1], goal.shape[1], hi - lo
+    plan, goal = _c(plan), _c(goal)
+    dev = emb.device
+    Kin = w_ih0.shape[1]
+    wih0 = weight_operand(w_ih0)
+    # per-sequence constant part c = plan Wp^T + goal Wg^T + b_ih0 (b_hh0 is added in the recurrent step)
+    c = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+    kn.gemm(plan, wih0, c, B, Hd, P, P, Kin, Hd, bias=b_ih0)
+    kn.gemm(goal, wih0[:, P + E:], c, B, Hd, G, G, Kin, Hd, accumulate=True)
+    emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
+    pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
+    kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
+    import os
+    # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
+    # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
+    zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
+    zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)                # zbuf[t+1] = [h0_t | h1_{t-1}]
+    if h0 is not None:                                                         # carried state: h0_{-1} and h1_{-1}
+        zbuf[0][:, :Hd] = h0[0]
+        zbuf[1][:, Hd:] = h0[1]
+    whh0 = weight_operand(w_hh0)
+    meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
+    persistent = h0 is None and _rnn_persistent(B, Hd, zdt)
+    if persistent:
+        # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
+        kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
+                         add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
+        return zbuf, plan, emb_t, goal, True, meta
+    w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
+    s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
+    s1.wait_stream(s0)
+    for t in range(S):
+        kn.gemm(zbuf[t][:, :Hd], whh0, zbuf[t + 1][:, :Hd], B, Hd, Hd, 2 * Hd, Hd, 2 * Hd, bias=b_hh0, add=pre0[t], ld_add=Hd, relu=True)
+        ev = torch.cuda.Event()
+        ev.record(s0)
+        with torch.cuda.stream(s1):
+            s1.wait_event(ev)
+            kn.gemm(zbuf[t + 1], w1cat, zbuf[t + 2][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, bias=b_ih1, add=b_hh1, ld_add=0,
+                    relu=True)
+    s0.wait_stream(s1)
+    return zbuf, plan, emb_t, goal, False, meta
+
+
+@torch.no_grad()
+def decoder_rnn_infer(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, h0=None):
+    """Inference forward of the decoder RNN (logistic_decoder_rnn.py:257-271 with h_0): -> (h1 (B,S,H), h_n (2,B,H))."""
+    zbuf, _, _, _, _, meta = _decoder_rnn_forward(plan, emb, goal, lo, hi, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, h0)
+    S, Hd = meta[1], meta[2]
+    h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()
+    h_n = torch.stack([zbuf[S][:, :Hd], zbuf[S + 1][:, Hd:]]).float()             # final states of layer 0 and layer 1
+    return h1, h_n
+
+
 class DecoderRNNFn(torch.autograd.Function):
     """2-layer ReLU RNN over x_t = [plan | emb_t[lo:hi] | goal], h_{-1} = 0  ->  h1 (B, S, H).
 
@@ -366,53 +425,14 @@ class DecoderRNNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
-        B, S, _ = emb.shape
-        Hd = w_hh0.shape[0]
-        P, G, E = plan.shape[1], goal.shape[1], hi - lo
-        plan, goal = _c(plan), _c(goal)
-        dev = emb.device
-        Kin = w_ih0.shape[1]
-        wih0 = weight_operand(w_ih0)
-        # per-sequence constant part c = plan Wp^T + goal Wg^T + b_ih0 (b_hh0 is added in the recurrent step)
-        c = torch.empty(B, Hd, dtype=torch.float32, device=dev)
-        kn.gemm(plan, wih0, c, B, Hd, P, P, Kin, Hd, bias=b_ih0)
-        kn.gemm(goal, wih0[:, P + E:], c, B, Hd, G, G, Kin, Hd, accumulate=True)
-        emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
-        pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
-        kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
-        import os
-        # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
-        # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
-        zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
-        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)                # zbuf[t+1] = [h0_t | h1_{t-1}]
-        whh0 = weight_operand(w_hh0)
-        ctx.persistent = _rnn_persistent(B, Hd, zdt)
-        if ctx.persistent:
-            # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
-            kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
-                             add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
-            h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()
-            ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
-            ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)
-            ctx.meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
-            return h1
-        w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
-        s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
-        s1.wait_stream(s0)
-        for t in range(S):
-            kn.gemm(zbuf[t][:, :Hd], whh0, zbuf[t + 1][:, :Hd], B, Hd, Hd, 2 * Hd, Hd, 2 * Hd, bias=b_hh0, add=pre0[t], ld_add=Hd, relu=True)
-            ev = torch.cuda.Event()
-            ev.record(s0)
-            with torch.cuda.stream(s1):
-                s1.wait_event(ev)
-                kn.gemm(zbuf[t + 1], w1cat, zbuf[t + 2][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, bias=b_ih1, add=b_hh1, ld_add=0,
-                        relu=True)
-        s0.wait_stream(s1)
-        h1 = zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()                  # (B, S, H) for the heads
+        zbuf, plan, emb_t, goal, persistent, meta = _decoder_rnn_forward(plan, emb, goal, lo, hi, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1,
+                                                                        b_ih1, b_hh1, None)
+        B, S, Hd = meta[0], meta[1], meta[2]
+        ctx.persistent = persistent
         ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
         ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)          # only their identity is needed (gradient sinks)
-        ctx.meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
-        return h1
+        ctx.meta = meta
+        return zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()                 # (B, S, H) for the heads
 
     @staticmethod
     def backward(ctx, dH1):
@@ -595,3 +615,25 @@ def world_to_tcp_frame(actions, robot_obs):
     out = torch.empty_like(actions)
     kn.world_to_tcp(_c(actions.float()), _c(robot_obs.float()), B * S, robot_obs.shape[-1], out)
     return out
+
+
+@torch.no_grad()
+def tcp_to_world_frame(actions: torch.Tensor, robot_obs: torch.Tensor) -> torch.Tensor:
+    """gripper_control.py:39-63 (sampled actions back to the world frame; no gradient, fp32 forced like the reference)."""
+    B, S, _ = actions.shape
+    out = torch.empty(B, S, 7, dtype=torch.float32, device=actions.device)
+    kn.tcp_to_world(_c(actions.float()), _c(robot_obs.float()), B * S, robot_obs.shape[-1], out)
+    return out
+
+
+@torch.no_grad()
+def mix_sample(y: torch.Tensor, A: int, n_mix: int, log_scale_min: float, gripper_bounds: torch.Tensor, seed: int,
+               u_mix: Optional[torch.Tensor] = None, u_inv: Optional[torch.Tensor] = None, return_idx: bool = False):
+    """LogisticDecoderRNN._sample on the fused head output y (T, >= 3*A*n_mix + 2) -> actions (T, A+1) [, mixture idx (T, A)]."""
+    y = _c(y)
+    T = y.shape[0]
+    act = torch.empty(T, A + 1, dtype=torch.float32, device=y.device)
+    idx = torch.empty(T, A, dtype=torch.int64, device=y.device) if return_idx else None
+    kn.mix_sample(y, y.stride(0), T, A, n_mix, log_scale_min, gripper_bounds, act, seed,
+                  None if u_mix is None else _c(u_mix.float()), None if u_inv is None else _c(u_inv.float()), idx)
+    return (act, idx) if return_idx else act

@@ -438,6 +438,17 @@ def world_to_tcp(act, robot_obs, n, obs_dim, out):
     _call("hulc_world_to_tcp", act, robot_obs, _i(n), _i(obs_dim), out)
 
 
+def tcp_to_world(act, robot_obs, n, obs_dim, out):
+    _call("hulc_tcp_to_world", act, robot_obs, _i(n), _i(obs_dim), out)
+
+
+def mix_sample(y, ld, T, A, n_mix, log_scale_min, gripper_bounds, act_out, seed, u_mix=None, u_inv=None, idx_out=None):
+    """LogisticDecoderRNN._sample; u_mix / u_inv inject the uniforms (parity tests), else the counter RNG on `seed`."""
+    d = _mix_desc(T, A, n_mix, 0, ld, log_scale_min, 0.0, gripper_bounds, gripper_bounds)
+    # validation / rollout run outside the training graphs: the caller advances `seed` itself, no device step word involved
+    _call("hulc_mix_sample", _c.byref(d), y, u_mix, u_inv, _u64(seed), None, gripper_bounds, act_out, idx_out)
+
+
 def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None):
     """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device."""
     _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),

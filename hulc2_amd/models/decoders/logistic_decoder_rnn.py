@@ -90,20 +90,78 @@ class LogisticDecoderRNN(ActionDecoder):
 
     def forward(self, latent_plan, perceptual_emb, latent_goal, h_0: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
-        if h_0 is not None:
-            raise NotImplementedError("stateful single-step decoding (inference `act`) is SURVEY.md §8 row f-1, not built yet")
+        """logistic_decoder_rnn.py:257-284 -> (logit_probs, log_scales, means, gripper_act, h_n).  With autograd enabled and no
+        h_0 this is the training recurrence (h_n carries only layer 1's final state: the fused recurrence does not export layer 0);
+        under torch.no_grad() or with a carried h_0 it is the inference sweep, which returns both final states."""
+        y, h_n = self._head_outputs(latent_plan, perceptual_emb, latent_goal, h_0)
+        return (*self._split_heads(y), h_n)
+
+    def _head_outputs(self, latent_plan, perceptual_emb, latent_goal, h_0=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """fused head output y (B, S, 184) and h_n (2, B, H)"""
         B, S = perceptual_emb.shape[0], perceptual_emb.shape[1]
-        h = self._rnn(latent_plan, perceptual_emb, latent_goal)
-        y = self._heads(h).reshape(B, S, -1)
+        if h_0 is not None or not torch.is_grad_enabled():
+            r = self.rnn
+            lo, hi = self.perceptual_emb_slice
+            h, h_n = HF.decoder_rnn_infer(latent_plan, perceptual_emb, latent_goal, lo, hi, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0,
+                                          r.bias_hh_l0, r.weight_ih_l1, r.weight_hh_l1, r.bias_ih_l1, r.bias_hh_l1, h_0)
+        else:
+            h = self._rnn(latent_plan, perceptual_emb, latent_goal)
+            h_n = torch.stack([h.new_zeros(B, h.shape[-1]), h[:, -1]])
+        return self._heads(h).reshape(B, S, -1), h_n
+
+    def _split_heads(self, y: torch.Tensor):
+        B, S = y.shape[0], y.shape[1]
         n = self.out_features * self.n_dist
         shp = (B, S, self.out_features, self.n_dist)
         logit_probs, means = y[..., :n].reshape(shp), y[..., n:2 * n].reshape(shp)
         log_scales = torch.clamp(y[..., 2 * n:3 * n], min=self.log_scale_min).reshape(shp)
-        h_n = torch.stack([h.new_zeros(B, h.shape[-1]), h[:, -1]])   # layer-0 final state is not exported by the fused recurrence
-        return logit_probs, log_scales, means, y[..., 3 * n:3 * n + 2], h_n
+        return logit_probs, log_scales, means, y[..., 3 * n:3 * n + 2]
 
-    def act(self, *a, **k):
-        raise NotImplementedError("inference sampling is SURVEY.md §8 row f-1 (next), not part of the training_step path")
+    # ---- validation / rollout (SURVEY.md §8 row f-1) ----------------------------------------------------
+    _sample_calls = 0
 
-    def loss_and_act(self, *a, **k):
-        raise NotImplementedError("validation sampling is SURVEY.md §8 row f-1 (next), not part of the training_step path")
+    def _sample(self, logit_probs, log_scales, means, gripper_act, u_mix=None, u_inv=None) -> torch.Tensor:
+        """logistic_decoder_rnn.py:231-255 (Gumbel-max over the mixtures + logistic inverse CDF + gripper argmax) as one kernel.
+        u_mix (B,S,A,n_mix) / u_inv (B,S,A): optional uniforms standing in for the reference's two torch.rand draws."""
+        B, S, A, M = means.shape
+        y = torch.cat([logit_probs.reshape(B * S, A * M), means.reshape(B * S, A * M), log_scales.reshape(B * S, A * M),
+                       gripper_act.reshape(B * S, 2)], dim=1)
+        return self._sample_heads(y, B, S, u_mix, u_inv)
+
+    injected_uniforms: Optional[list] = None      # parity tests: [(u_mix, u_inv), ...] consumed one pair per _sample call
+
+    def _sample_heads(self, y2d: torch.Tensor, B: int, S: int, u_mix=None, u_inv=None) -> torch.Tensor:
+        if u_mix is None and self.injected_uniforms:
+            u_mix, u_inv = self.injected_uniforms.pop(0)
+        LogisticDecoderRNN._sample_calls += 1                     # a fresh counter-RNG stream per call
+        seed = 0x5A3D1E00 + LogisticDecoderRNN._sample_calls
+        A = self.out_features
+        act = HF.mix_sample(y2d, A, self.n_dist, float(self.log_scale_min), self.gripper_bounds, seed,
+                            None if u_mix is None else u_mix.reshape(B * S, A, self.n_dist),
+                            None if u_inv is None else u_inv.reshape(B * S, A))
+        return act.reshape(B, S, A + 1)
+
+    @torch.no_grad()
+    def act(self, latent_plan, perceptual_emb, latent_goal, robot_obs) -> torch.Tensor:
+        """logistic_decoder_rnn.py:99-116: stateful decoding, the hidden state is carried across calls until clear_hidden_state()."""
+        B, S = perceptual_emb.shape[0], perceptual_emb.shape[1]
+        y, self.hidden_state = self._head_outputs(latent_plan, perceptual_emb, latent_goal,
+                                                  self.hidden_state if self.hidden_state is not None else self._zero_state(B, perceptual_emb))
+        pred = self._sample_heads(y.reshape(B * S, -1), B, S)
+        return HF.tcp_to_world_frame(pred, robot_obs) if self.gripper_control else pred
+
+    def _zero_state(self, B, like):
+        return torch.zeros(2, B, self.rnn.hidden_size, dtype=torch.float32, device=like.device)
+
+    @torch.no_grad()
+    def loss_and_act(self, latent_plan, perceptual_emb, latent_goal, actions, robot_obs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """logistic_decoder_rnn.py:82-97: validation loss and one sampled action sequence from the same head outputs."""
+        B, S = perceptual_emb.shape[0], perceptual_emb.shape[1]
+        y, _ = self._head_outputs(latent_plan, perceptual_emb, latent_goal, None)
+        y2d = y.reshape(B * S, -1)
+        pred = self._sample_heads(y2d, B, S)
+        acts = HF.world_to_tcp_frame(actions, robot_obs) if self.gripper_control else actions
+        loss = HF.MixLossFn.apply(y2d, acts.reshape(-1, acts.shape[-1]), self.action_min_bound[0, 0, :, 0].contiguous(),
+                                  self.action_max_bound[0, 0, :, 0].contiguous(), self.n_dist, self.num_classes,
+                                  float(self.log_scale_min), float(self.gripper_alpha), 1)[0]
+        return loss, (HF.tcp_to_world_frame(pred, robot_obs) if self.gripper_control else pred)

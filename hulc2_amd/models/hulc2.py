@@ -3,8 +3,8 @@
 Mirrors hulc2.models.hulc2.Hulc2 (reference hulc2/models/hulc2.py:27-508) for the training path: the same 16
 constructor arguments (un-instantiated configs, `_recursive_: false`), `setup_input_sizes`, `training_step`,
 `lmp_train`, `compute_kl_loss`, `clip_auxiliary_loss`, `configure_optimizers`, `set_kl_beta`, the same logged
-metric names and the same attribute names (hence state_dict keys).  Validation / rollout inference
-(`validation_step`, `step`, `reset`) is SURVEY.md §8 row f-1 and raises NotImplementedError for now.
+metric names and the same attribute names (hence state_dict keys); and for validation / rollout inference
+(SURVEY.md §8 row f-1): `lmp_val`, `validation_step`, `reset`, `step`, `predict_with_plan`, `get_pp_plan_vision/_lang`.
 
 Differences that do not change results:
   * the categorical plan sample can be injected through `dataset_batch["plan_idx"]` (parity tests); otherwise it
@@ -183,14 +183,119 @@ class Hulc2(LightningModule):
         im, tx = self.proj_vis_lang(seq_vis_feat, encoded_lang)
         return HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale)
 
-    # ---- outside the accelerated path ---------------------------------------------
-    def validation_step(self, batch, batch_idx):
-        raise NotImplementedError("validation_step (lmp_val + sampling) is SURVEY.md §8 row f-1: next, not built yet")
+    # ---- validation and rollout inference on the same kernels ------------------------
+    _plan_calls = 0
+
+    def _sample_plan(self, state: State, idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dist.sample_latent_plan(dist.get_dist(state)) (distributions.py:23-35, hulc2.py:287,302): a one-hot draw per category,
+        no gradient.  A fresh counter-RNG stream per call; `idx` injects the class indices (parity tests)."""
+        Hulc2._plan_calls += 1
+        with torch.no_grad():
+            plan, _ = self.dist.rsample_plan(state, seed=0xC0FFEE00 + Hulc2._plan_calls, idx=idx)
+        return plan
+
+    @torch.no_grad()
+    def lmp_val(self, perceptual_emb, latent_goal, actions, robot_obs, plan_idx_pp=None, plan_idx_pr=None):
+        """hulc2.py:247-334: plans sampled from the prior and the posterior, decoder loss + one sampled action sequence for each,
+        KL, per-dimension mean absolute errors and gripper success rates."""
+        def metrics(sample_act):
+            mae = torch.mean(torch.abs(sample_act[..., :-1] - actions[..., :-1]), 1)             # (batch, 6)
+            grip = torch.where(sample_act[..., -1] > 0, 1.0, -1.0)
+            return mae, torch.mean((actions[..., -1] == grip).float())
+
+        pp_state = self.plan_proposal(perceptual_emb[:, 0], latent_goal)
+        sampled_plan_pp = self._sample_plan(pp_state, plan_idx_pp)
+        action_loss_pp, sample_act_pp = self.action_decoder.loss_and_act(sampled_plan_pp, perceptual_emb, latent_goal, actions, robot_obs)
+        mae_pp, gripper_sr_pp = metrics(sample_act_pp)
+        pr_state, seq_feat = self.plan_recognition(perceptual_emb)
+        sampled_plan_pr = self._sample_plan(pr_state, plan_idx_pr)
+        action_loss_pr, sample_act_pr = self.action_decoder.loss_and_act(sampled_plan_pr, perceptual_emb, latent_goal, actions, robot_obs)
+        mae_pr, gripper_sr_pr = metrics(sample_act_pr)
+        kl_loss = self.compute_kl_loss(pp_state, pr_state)
+        return (sampled_plan_pp, action_loss_pp, sampled_plan_pr, action_loss_pr, kl_loss, mae_pp, mae_pr, gripper_sr_pp, gripper_sr_pr,
+                seq_feat)
+
+    @torch.no_grad()
+    def validation_step(self, batch: Dict[str, Dict], batch_idx: int) -> Dict[str, torch.Tensor]:
+        """hulc2.py:510-598: same logged names, returns the sampled plans and episode indices per modality."""
+        output = {}
+        val_total_act_loss_pp = None
+        for self.modality_scope, db in batch.items():
+            emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
+            latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
+            (plan_pp, act_loss_pp, plan_pr, act_loss_pr, kl_loss, mae_pp, mae_pr, grip_pp, grip_pr, seq_feat) = self.lmp_val(
+                emb, latent_goal, db["actions"], db["state_info"]["robot_obs"], db.get("plan_idx_pp"), db.get("plan_idx_pr"))
+            if "lang" in self.modality_scope and self.use_clip_auxiliary_loss:
+                self.log("val/val_pred_clip_loss", self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"]), sync_dist=True)
+            val_total_act_loss_pp = act_loss_pp if val_total_act_loss_pp is None else val_total_act_loss_pp + act_loss_pp
+            m = self.modality_scope
+            self.log(f"val_total_mae/{m}_total_mae_pr", mae_pr.mean(), sync_dist=True)
+            self.log(f"val_total_mae/{m}_total_mae_pp", mae_pp.mean(), sync_dist=True)
+            self.log(f"val_pos_mae/{m}_pos_mae_pr", mae_pr[..., :3].mean(), sync_dist=True)
+            self.log(f"val_pos_mae/{m}_pos_mae_pp", mae_pp[..., :3].mean(), sync_dist=True)
+            self.log(f"val_orn_mae/{m}_orn_mae_pr", mae_pr[..., 3:6].mean(), sync_dist=True)
+            self.log(f"val_orn_mae/{m}_orn_mae_pp", mae_pp[..., 3:6].mean(), sync_dist=True)
+            self.log(f"val_kl/{m}_kl_loss", kl_loss, sync_dist=True)
+            self.log(f"val_act/{m}_act_loss_pp", act_loss_pp, sync_dist=True)
+            self.log(f"val_act/{m}_act_loss_pr", act_loss_pr, sync_dist=True)
+            self.log(f"val_grip/{m}_grip_sr_pr", grip_pr, sync_dist=True)
+            self.log(f"val_grip/{m}_grip_sr_pp", grip_pp, sync_dist=True)
+            n_mod = len(getattr(getattr(getattr(self, "trainer", None), "datamodule", None), "modalities", None) or batch)
+            self.log("val_act/action_loss_pp", val_total_act_loss_pp / n_mod, sync_dist=True)
+            output[f"sampled_plan_pp_{m}"] = plan_pp
+            output[f"sampled_plan_pr_{m}"] = plan_pr
+            output[f"idx_{m}"] = db["idx"]
+        return output
 
     def reset(self):
+        """hulc2.py:600-606: call at the beginning of a rollout."""
         self.plan = None
         self.latent_goal = None
         self.rollout_step_counter = 0
 
     def step(self, obs, goal):
-        raise NotImplementedError("rollout inference is SURVEY.md §8 row f-1: next, not built yet")
+        """hulc2.py:608-628: one control step; a new plan is sampled from the prior every `replan_freq` steps."""
+        if self.rollout_step_counter % self.replan_freq == 0:
+            if "lang" in goal:
+                self.plan, self.latent_goal = self.get_pp_plan_lang(obs, goal)
+            else:
+                self.plan, self.latent_goal = self.get_pp_plan_vision(obs, goal)
+        action = self.predict_with_plan(obs, self.latent_goal, self.plan)
+        self.rollout_step_counter += 1
+        return action
+
+    @torch.no_grad()
+    def predict_with_plan(self, obs, latent_goal, sampled_plan):
+        """hulc2.py:630-652."""
+        emb = self.perceptual_encoder(obs["rgb_obs"], obs["depth_obs"], obs["robot_obs"])
+        return self.action_decoder.act(sampled_plan, emb, latent_goal, obs["robot_obs_raw"])
+
+    @torch.no_grad()
+    def get_pp_plan_vision(self, obs: dict, goal: dict):
+        """hulc2.py:654-683: current and goal frames as a 2-step sequence through the encoders, plan from the prior."""
+        assert len(obs["rgb_obs"]) == len(goal["rgb_obs"])
+        imgs = {k: torch.cat([v, goal["rgb_obs"][k]], dim=1) for k, v in obs["rgb_obs"].items()}     # (1, 2, C, H, W)
+        state = torch.cat([obs["robot_obs"], goal["robot_obs"]], dim=1) if "robot_obs" in obs and "robot_obs" in goal else None
+        emb = self.perceptual_encoder(imgs, {}, state)
+        latent_goal = self.visual_goal(emb[:, -1])
+        sampled_plan = self._sample_plan(self.plan_proposal(emb[:, 0], latent_goal))
+        self.action_decoder.clear_hidden_state()
+        return sampled_plan, latent_goal
+
+    @torch.no_grad()
+    def get_pp_plan_lang(self, obs: dict, goal: dict):
+        """hulc2.py:685-707."""
+        emb = self.perceptual_encoder(obs["rgb_obs"], obs["depth_obs"], obs["robot_obs"])
+        latent_goal = self.language_goal(goal["lang"])
+        sampled_plan = self._sample_plan(self.plan_proposal(emb[:, 0], latent_goal))
+        self.action_decoder.clear_hidden_state()
+        return sampled_plan, latent_goal
+
+    def on_train_epoch_start(self) -> None:
+        logger.info("Start training epoch %s", getattr(self, "current_epoch", "?"))
+
+    def on_train_epoch_end(self, unused=None) -> None:
+        logger.info("Finished training epoch %s", getattr(self, "current_epoch", "?"))
+
+    def on_validation_epoch_end(self) -> None:
+        logger.info("Finished validation epoch %s", getattr(self, "current_epoch", "?"))

@@ -155,6 +155,14 @@ int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* us
 /* Relative actions world -> tcp frame, act[n][7], robot_obs[n][obs_dim] (euler angles in 3:6),
  * gripper_control.py:16-36 (pytorch3d XYZ convention restated; parity unpinned). */
 int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
+/* inverse frame change for sampled actions, tcp_to_world_frame (gripper_control.py:39-63; without the NaN quaternion fallback) */
+int hulc_tcp_to_world(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
+/* LogisticDecoderRNN._sample (logistic_decoder_rnn.py:231-255) on the fused head output y (T rows: [logit_probs | means |
+ * log_scales | gripper 2], row stride d->ld): Gumbel-max over the n_mix mixtures, inverse-CDF draw from the selected logistic,
+ * gripper_bounds[argmax].  u_mix (T, A, n_mix) / u_inv (T, A): optional raw uniforms in [0,1) standing in for torch.rand
+ * (parity tests); NULL -> counter RNG on (seed ^ *seed_dev).  act_out (T, A+1); idx_out (T, A) selected mixture (optional). */
+int hulc_mix_sample(const hulc_mix_desc* d, const float* y, const float* u_mix, const float* u_inv, unsigned long long seed,
+                    const unsigned long long* seed_dev, const float* gripper_bounds, float* act_out, long* idx_out, void* stream);
 
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.

@@ -391,12 +391,71 @@ def gen_step(m, dist, flat, B, S):
          grad_names=np.array(names), grad_norms=np.array(norms), ck=ck, cv=cv, torch_version=torch.__version__, **res, **slices)
 
 
+def gen_inference(m, dist, flat):
+    """validation / rollout pieces: decoder forward with a carried hidden state, LogisticDecoderRNN._sample
+    and loss_and_act with the torch.rand draws recorded, and the lmp_val composition of hulc2.py:247-334 on the leaf modules."""
+    dec = m["action_decoder"]
+    B, S = 2, 3
+    with torch.no_grad():
+        plan = F.one_hot(torch.randint(0, 32, (B, 32), generator=g(SEED, "x.inf.idx")), 32).float().flatten(1)
+        emb = randn(SEED, "x.inf.emb", B, S, 128)
+        goal = randn(SEED, "x.inf.goal", B, 32)
+        h0 = randn(SEED, "x.inf.h0", 2, B, 2048).abs() * 0.2
+        lp, ls, mu, grip, h_n = dec(plan, emb, goal, h0)
+        save("decoder_state", seed=SEED, B=B, S=S, h0_checksum=float(h0.double().sum()), logit_probs=lp, log_scales=ls, means=mu, grip=grip,
+             h_n_s=h_n[:, :, ::16], h_n_sum=h_n.double().sum())
+
+        # _sample: the reference draws torch.rand(means.shape) then torch.rand(means.shape[:-1]) from the global generator
+        B, S = 2, 16
+        plan = F.one_hot(torch.randint(0, 32, (B, 32), generator=g(SEED, "x.smp.idx")), 32).float().flatten(1)
+        emb, goal = randn(SEED, "x.smp.emb", B, S, 128), randn(SEED, "x.smp.goal", B, 32)
+        lp, ls, mu, grip, _ = dec(plan, emb, goal)
+        lp = lp * 3.0                                           # spread the mixture logits so the Gumbel argmax is not a coin flip
+        torch.manual_seed(1234)
+        out = dec._sample(lp, ls, mu, grip)
+        torch.manual_seed(1234)
+        u_mix, u_inv = torch.rand(mu.shape), torch.rand(mu.shape[:-1])
+        r1, r2 = 1e-5, 1.0 - 1e-5
+        idx = torch.argmax(lp - torch.log(-torch.log((r1 - r2) * u_mix + r2)), -1)
+        save("decoder_sample", seed=SEED, logit_probs=lp, log_scales=ls, means=mu, grip=grip, u_mix=u_mix, u_inv=u_inv, actions=out,
+             mix_idx=idx.numpy().astype(np.int64), gripper_idx=grip.argmax(-1).numpy().astype(np.int64))
+
+        # lmp_val composition (hulc2.py:283-334) with injected plan samples and recorded uniforms
+        emb, goal = randn(SEED, "x.val.emb", B, S, 128), randn(SEED, "x.val.goal", B, 32)
+        acts = randu(SEED, "x.val.act", B, S, 7)
+        acts[..., 6] = (torch.rand(B, S, generator=g(SEED, "x.val.grip")) < 0.5).float() * 2 - 1
+        robot_obs = randn(SEED, "x.val.robot", B, S, 15)
+        idx_pp = torch.randint(0, 32, (B, 32), generator=g(SEED, "x.val.idx_pp"))
+        idx_pr = torch.randint(0, 32, (B, 32), generator=g(SEED, "x.val.idx_pr"))
+        pp_state = m["plan_proposal"](emb[:, 0], goal)
+        pr_state, seq_feat = m["plan_recognition"](emb)
+        res = {}
+        for tag, idx_, sd_ in (("pp", idx_pp, 4321), ("pr", idx_pr, 8765)):
+            plan = F.one_hot(idx_, 32).float().flatten(1)
+            torch.manual_seed(sd_)
+            loss, pred = dec.loss_and_act(plan, emb, goal, acts, robot_obs)            # :287-290 / :303-306
+            torch.manual_seed(sd_)
+            res[f"u_mix_{tag}"], res[f"u_inv_{tag}"] = torch.rand(B, S, 6, 10), torch.rand(B, S, 6)
+            mae = torch.mean(torch.nn.functional.l1_loss(pred[..., :-1], acts[..., :-1], reduction="none"), 1)   # :292-295
+            gd = pred[..., -1].clone()
+            mk = gd > 0
+            gd[mk] = 1
+            gd[~mk] = -1
+            res[f"loss_{tag}"], res[f"pred_{tag}"], res[f"mae_{tag}"] = loss, pred, mae
+            res[f"grip_sr_{tag}"] = torch.mean((acts[..., -1] == gd).float())                                # :297-302
+        kl = ref_kl(dist, pp_state.logit, pr_state.logit)
+        save("lmp_val", seed=SEED, B=B, S=S, idx_pp=idx_pp.numpy(), idx_pr=idx_pr.numpy(), acts=acts, kl=kl, seq_feat_s=seq_feat[:, ::64], **res)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
     m, dist, flat = build_reference_modules(R, SEED)
     print("reference leaf modules imported from", REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "inference":      # only the f-1 fixtures (the others are unchanged)
+        gen_inference(m, dist, flat)
+        return
     gen_vision(m, flat)
     gen_goal_and_proposal(m, flat)
     gen_plan_recognition(m, flat)
@@ -405,6 +464,7 @@ def main():
     gen_clip(m, flat)
     gen_step(m, dist, flat, 2, 16)
     gen_step(m, dist, flat, 2, 32)
+    gen_inference(m, dist, flat)
 
 
 if __name__ == "__main__":

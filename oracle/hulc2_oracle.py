@@ -185,35 +185,56 @@ def kl_loss(pp_logits: torch.Tensor, pr_logits: torch.Tensor, kl_beta: float, kl
 # ------------------------------------------------------------------------------------------------
 # action decoder: 2-layer ReLU RNN + discretised logistic mixture + gripper CE
 # ------------------------------------------------------------------------------------------------
-def relu_rnn(sd: SD, p: str, x: torch.Tensor, num_layers: int = 2) -> torch.Tensor:
-    """nn.RNN(nonlinearity='relu', batch_first=True), h0 = 0 (decoders/utils/rnn.py:5-14)."""
+def relu_rnn(sd: SD, p: str, x: torch.Tensor, num_layers: int = 2, h0: Optional[torch.Tensor] = None, return_state: bool = False):
+    """nn.RNN(nonlinearity='relu', batch_first=True); h0 (num_layers, B, H) or zeros (decoders/utils/rnn.py:5-14)."""
     B, S, _ = x.shape
     inp = x
+    finals = []
     for l in range(num_layers):
         w_ih, w_hh = sd[f"{p}weight_ih_l{l}"], sd[f"{p}weight_hh_l{l}"]
         b = sd[f"{p}bias_ih_l{l}"] + sd[f"{p}bias_hh_l{l}"]
-        h = torch.zeros(B, w_hh.shape[0], dtype=x.dtype)
+        h = torch.zeros(B, w_hh.shape[0], dtype=x.dtype) if h0 is None else h0[l]
         outs = []
         for t in range(S):
             h = F.relu(F.linear(inp[:, t], w_ih) + F.linear(h, w_hh) + b)
             outs.append(h)
+        finals.append(h)
         inp = torch.stack(outs, dim=1)
-    return inp
+    return (inp, torch.stack(finals)) if return_state else inp
 
 
 def decoder_forward(sd: SD, p: str, plan: torch.Tensor, emb: torch.Tensor, goal: torch.Tensor,
-                    emb_slice=(64, 128), n_mix: int = 10, log_scale_min: float = -7.0):
-    """LogisticDecoderRNN.forward, logistic_decoder_rnn.py:257-284."""
+                    emb_slice=(64, 128), n_mix: int = 10, log_scale_min: float = -7.0, h0: Optional[torch.Tensor] = None,
+                    return_state: bool = False):
+    """LogisticDecoderRNN.forward, logistic_decoder_rnn.py:257-284 (h0: the carried hidden state of `act`, :105-107)."""
     pe = emb[..., emb_slice[0]:emb_slice[1]]
     B, S = pe.shape[0], pe.shape[1]
     x = torch.cat([plan.unsqueeze(1).expand(-1, S, -1), pe, goal.unsqueeze(1).expand(-1, S, -1)], dim=-1)
-    h = relu_rnn(sd, p + "rnn.", x)
+    h, h_n = relu_rnn(sd, p + "rnn.", x, h0=h0, return_state=True)
     probs = F.linear(h, sd[p + "prob_fc.weight"], sd[p + "prob_fc.bias"])
     means = F.linear(h, sd[p + "mean_fc.weight"], sd[p + "mean_fc.bias"])
     log_scales = torch.clamp(F.linear(h, sd[p + "log_scale_fc.weight"], sd[p + "log_scale_fc.bias"]), min=log_scale_min)
     grip = F.linear(h, sd[p + "gripper_fc.weight"], sd[p + "gripper_fc.bias"])
     A = probs.shape[-1] // n_mix
-    return probs.view(B, S, A, n_mix), log_scales.view(B, S, A, n_mix), means.view(B, S, A, n_mix), grip
+    out = (probs.view(B, S, A, n_mix), log_scales.view(B, S, A, n_mix), means.view(B, S, A, n_mix), grip)
+    return (*out, h_n) if return_state else out
+
+
+def sample_actions(logit_probs, log_scales, means, grip, u_mix, u_inv, gripper_bounds=(-1.0, 1.0)):
+    """LogisticDecoderRNN._sample, logistic_decoder_rnn.py:231-255, with the two torch.rand draws passed in:
+    u_mix (B,S,A,n_mix) and u_inv (B,S,A) raw uniforms in [0,1).  Returns (actions (B,S,A+1), selected mixture index (B,S,A))."""
+    r1, r2 = 1e-5, 1.0 - 1e-5
+    temp = (r1 - r2) * u_mix + r2
+    temp = logit_probs - torch.log(-torch.log(temp))
+    argmax = torch.argmax(temp, -1)
+    dist = torch.eye(means.shape[-1], dtype=means.dtype)[argmax]
+    ls = (dist * log_scales).sum(dim=-1)
+    mu = (dist * means).sum(dim=-1)
+    scales = torch.exp(ls)
+    u = (r1 - r2) * u_inv + r2
+    actions = mu + scales * (torch.log(u) - torch.log(1.0 - u))
+    cmd = torch.tensor(gripper_bounds, dtype=means.dtype)[grip.argmax(dim=-1)]
+    return torch.cat([actions, cmd.unsqueeze(-1)], 2), argmax
 
 
 def logistic_loss(logit_probs, log_scales, means, actions, act_min=-1.0, act_max=1.0, num_classes=10,

@@ -268,3 +268,79 @@ def test_world_to_tcp_properties():
     assert torch.allclose(z[..., :3], act[..., :3], atol=1e-6)
     assert torch.allclose(z[..., 3:6], -act[..., 3:6], atol=1e-2)
     assert torch.equal(z[..., 6], act[..., 6])
+
+
+# ---- validation / rollout pieces --------------------------------------------------
+def _inference_inputs(seed, tag, B, S):
+    idx = torch.randint(0, 32, (B, 32), generator=syn._gen(seed, f"x.{tag}.idx"))
+    plan = torch.nn.functional.one_hot(idx, 32).float().flatten(1)
+    emb = torch.randn(B, S, 128, generator=syn._gen(seed, f"x.{tag}.emb"))
+    goal = torch.randn(B, 32, generator=syn._gen(seed, f"x.{tag}.goal"))
+    return plan, emb, goal
+
+
+def test_decoder_forward_with_carried_state(sd):
+    """LogisticDecoderRNN.forward(h_0) (the stateful `act` path, logistic_decoder_rnn.py:105-107,271)"""
+    fx = load("decoder_state")
+    seed, B, S = int(fx["seed"]), int(fx["B"]), int(fx["S"])
+    plan, emb, goal = _inference_inputs(seed, "inf", B, S)
+    h0 = torch.randn(2, B, 2048, generator=syn._gen(seed, "x.inf.h0")).abs() * 0.2
+    assert abs(float(h0.double().sum()) - float(fx["h0_checksum"])) < 1e-6
+    with torch.no_grad():
+        lp, ls, mu, grip, h_n = O.decoder_forward(sd, "action_decoder.", plan, emb, goal, h0=h0, return_state=True)
+    for a, k in ((lp, "logit_probs"), (ls, "log_scales"), (mu, "means"), (grip, "grip")):
+        close(a, fx[k], what=k)
+    close(h_n[:, :, ::16], fx["h_n_s"], what="h_n")
+    # three single-step calls carrying the state == one 3-step call
+    h = h0
+    outs = []
+    with torch.no_grad():
+        for t in range(S):
+            o = O.decoder_forward(sd, "action_decoder.", plan, emb[:, t:t + 1], goal, h0=h, return_state=True)
+            h = o[4]
+            outs.append(o[2])
+    close(torch.cat(outs, 1), fx["means"], what="means (stepwise)")
+
+
+def test_sample_actions_bit_exact_indices():
+    """LogisticDecoderRNN._sample with the recorded torch.rand draws: mixture / gripper indices bit-exact, actions to fp32 rounding"""
+    fx = load("decoder_sample")
+    t = {k: torch.tensor(fx[k]) for k in ("logit_probs", "log_scales", "means", "grip", "u_mix", "u_inv")}
+    act, idx = O.sample_actions(t["logit_probs"], t["log_scales"], t["means"], t["grip"], t["u_mix"], t["u_inv"])
+    assert np.array_equal(idx.numpy(), fx["mix_idx"])
+    assert np.array_equal(t["grip"].argmax(-1).numpy(), fx["gripper_idx"])
+    close(act, fx["actions"], 1e-6, "sampled actions")
+
+
+def test_lmp_val_composition(sd):
+    """hulc2.py:283-334 on the oracle: decoder losses, sampled actions (recorded uniforms), MAE, gripper success rate, KL"""
+    fx = load("lmp_val")
+    seed, B, S = int(fx["seed"]), int(fx["B"]), int(fx["S"])
+    emb = torch.randn(B, S, 128, generator=syn._gen(seed, "x.val.emb"))
+    goal = torch.randn(B, 32, generator=syn._gen(seed, "x.val.goal"))
+    acts = torch.tensor(fx["acts"])
+    with torch.no_grad():
+        pp = O.plan_proposal(sd, "plan_proposal.", emb[:, 0], goal)
+        pr, seq_feat = O.plan_recognition(sd, "plan_recognition.", emb)
+        close(seq_feat[:, ::64], fx["seq_feat_s"], what="seq_feat")
+        close(O.kl_loss(pp, pr, 0.01, 0.8), fx["kl"], what="kl")
+        for tag in ("pp", "pr"):
+            plan = torch.nn.functional.one_hot(torch.tensor(fx[f"idx_{tag}"]), 32).float().flatten(1)
+            lp, ls, mu, grip = O.decoder_forward(sd, "action_decoder.", plan, emb, goal)
+            close(O.decoder_loss(lp, ls, mu, grip, acts), fx[f"loss_{tag}"], what=f"loss {tag}")
+            pred, _ = O.sample_actions(lp, ls, mu, grip, torch.tensor(fx[f"u_mix_{tag}"]), torch.tensor(fx[f"u_inv_{tag}"]))
+            close(pred, fx[f"pred_{tag}"], 1e-4, f"pred {tag}")
+            mae = torch.mean(torch.abs(pred[..., :-1] - acts[..., :-1]), 1)
+            close(mae, fx[f"mae_{tag}"], 1e-4, f"mae {tag}")
+            sr = torch.mean((acts[..., -1] == torch.where(pred[..., -1] > 0, 1.0, -1.0)).float())
+            close(sr, fx[f"grip_sr_{tag}"], what=f"gripper sr {tag}")
+
+
+def test_tcp_world_round_trip():
+    """parity unpinned (pytorch3d): tcp_to_world_frame inverts world_to_tcp_frame (gripper_control.py:16-63)"""
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(3, 7, 7, generator=g) * 2 - 1
+    obs = torch.randn(3, 7, 15, generator=g)
+    obs[..., 3:6] = (torch.rand(3, 7, 3, generator=g) - 0.5) * 3.0
+    back = O.tcp_to_world_frame(O.world_to_tcp_frame(a, obs), obs)
+    assert (back - a).abs().max().item() < 2e-4
