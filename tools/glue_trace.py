@@ -1,0 +1,37 @@
+"""Where do the small torch kernels of a step come from?  Lists aten ops with their Python call sites."""
+import sys, torch, collections
+sys.path.insert(0, '.')
+from hulc2_amd import kernels as kn, synthetic as syn
+from hulc2_amd.compat import instantiate
+from hulc2_amd.config import default_model_config
+from hulc2_amd.trainer import ArenaTrainer
+from torch.profiler import profile, ProfilerActivity
+
+dev = torch.device("cuda", 0)
+kn.set_compute("bf16")
+m = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+syn.fill_state_dict_(m.state_dict(), 42)
+m.train()
+tr = ArenaTrainer(m, lr=2e-4)
+batch = syn.make_batch(42, 32, 32, device=dev)
+for db in batch.values():
+    db.pop("plan_idx", None)
+for i in range(2):
+    tr.step(batch, i)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    tr.step(batch, 2)
+torch.cuda.synchronize()
+want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::div", "aten::sum", "aten::clone",
+        "aten::contiguous", "aten::zeros", "aten::_to_copy", "aten::index", "aten::slice_backward", "aten::select_backward", "aten::stack", "aten::where",
+        "aten::abs", "aten::mean", "aten::neg", "aten::sub", "aten::expand", "aten::eq")
+rows = []
+for ev in prof.key_averages(group_by_stack_n=12):
+    if ev.key in want:
+        site = next((x for x in (ev.stack or []) if "hulc2_amd" in x or "bench" in x), (ev.stack or ["?"])[0])
+        rows.append((ev.count, ev.key, site.strip()[-110:]))
+agg = collections.Counter()
+for n, k, site in rows:
+    agg[(k, site)] += n
+for (k, site), n in sorted(agg.items(), key=lambda kv: -kv[1])[:80]:
+    print(f"{n:4d}  {k:20s} {site}")
