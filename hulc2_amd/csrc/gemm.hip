@@ -30,6 +30,7 @@ struct GemmP {
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
     const unsigned long long* seed_dev;   // optional device word xor-ed into drop_seed (graph-replay safe RNG stream)
+    float* rowsum; int rowsum_accumulate;  // optional: rowsum[m] (+)= sum_k A[m][k] (row-major A only): the bias gradient of a weight-gradient GEMM
 };
 
 // Load the 8-element k-chunk (row r, k0..k0+7) of an operand.
@@ -107,9 +108,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             c[0].v[j] = in_k ? v.x : 0.f; c[1].v[j] = in_k ? v.y : 0.f; c[2].v[j] = in_k ? v.z : 0.f; c[3].v[j] = in_k ? v.w : 0.f;
         }
     };
+    // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (before bf16 rounding)
+    const bool do_rowsum = !AK && p.rowsum != nullptr && blockIdx.y == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
     auto load_tiles = [&](int kt) {
         if (!AK && a_micro) {
-            if (tid < MTA) load_micro(ra, p.A, p.lda, m0 + (tid / NCH) * 4, kt * KT + (tid % NCH) * 8, p.K);
+            if (tid < MTA) {
+                load_micro(ra, p.A, p.lda, m0 + (tid / NCH) * 4, kt * KT + (tid % NCH) * 8, p.K);
+                if (do_rowsum) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rs[i] += ra[i].v[j];
+                }
+            }
         } else
 #pragma unroll
         for (int q = 0; q < A_PER; ++q) {
@@ -117,6 +129,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             if (A_CH % NT == 0 || id < A_CH) {
                 int r, ch; a_map(id, r, ch);
                 load_operand_chunk<AK>(ra[q], p.A, p.a_dtype, p.lda, p.M, p.K, m0 + r, kt * KT + ch * 8);
+                if (!AK && do_rowsum && m0 + r < p.M) {           // row = id % BM is the same for every q of a thread (NT % BM == 0)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rs[0] += ra[q].v[j];
+                }
             }
         }
         if (!BK && b_micro) {
@@ -179,6 +195,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
         if (kt + 1 < kt1) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+
+    if (do_rowsum) {
+        // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
+        float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
+        const bool acc_out = splitk == 1 && p.rowsum_accumulate;
+        if (a_micro) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);       // the NCH k-groups of a row group are adjacent lanes
+            if (tid < MTA && tid % NCH == 0) {
+                const int r0 = m0 + (tid / NCH) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
+            }
+        } else {
+            float* red = (float*)smem;                           // operand tiles are dead: NT floats of scratch
+            __syncthreads();
+            red[tid] = rs[0];
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float v = 0.f;
+                for (int t = tid; t < NT && t < A_CH; t += BM) v += red[t];
+                dst[m0 + tid] = acc_out ? dst[m0 + tid] + v : v;
+            }
+        }
     }
 
     if (splitk > 1) {   // raw partial sums; gemm_splitk_epilogue_kernel combines the slabs in a fixed order
@@ -333,6 +375,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __
 
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, const float* __restrict__ slabs, int splitk) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.rowsum && i < p.M) {                                   // fused bias gradient: row-sum slabs follow the C slabs
+        const float* rsl = slabs + (long)splitk * p.M * p.N;
+        float v = 0.f;
+        for (int s = 0; s < splitk; ++s) v += rsl[(long)s * p.M + i];
+        p.rowsum[i] = p.rowsum_accumulate ? p.rowsum[i] + v : v;
+    }
     if (i >= (long)p.M * p.N) return;
     const int m = (int)(i / p.N), n = (int)(i % p.N);
     float v = 0.f;
@@ -388,7 +436,7 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     const int nkt = (p.K + MmaTraits<CT>::KT - 1) / MmaTraits<CT>::KT;
     int splitk = 1;
     while (gx * gy * splitk < 192 && nkt / (splitk * 2) >= 8) splitk *= 2;
-    while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
+    while (splitk > 1 && (long)splitk * p.M * (p.N + 1) * 4 > ws_bytes) splitk /= 2;
     dim3 grid(gx, gy, splitk), block(WM * WN * 64);
     if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p, ws, splitk);
     else if (ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, true, false><<<grid, block, 0, s>>>(p, ws, splitk);
@@ -429,6 +477,8 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     p.relu = d->relu; p.accumulate = d->accumulate;
     p.alpha = d->alpha; p.mask_scale = d->mask_scale; p.drop_p = d->drop_p; p.drop_seed = d->drop_seed;
     p.seed_dev = d->seed_dev;
+    p.rowsum = d->rowsum_a; p.rowsum_accumulate = d->rowsum_accumulate;
+    if (p.rowsum && (d->a_kmajor || d->M <= 64)) return hulc_fail(-6, "hulc_gemm: rowsum_a needs a row-major A operand and M > 64 (tiled path)");
     hipStream_t s = (hipStream_t)stream;
     if (d->M <= 64) {
         if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);

@@ -71,10 +71,12 @@ class MLPFn(torch.autograd.Function):
             inp = x2 if i == 0 else acts[i - 1]
             sw, sb = gradsink.get(W), gradsink.get(params[2 * i + 1])
             dW = sw if sw is not None else _f32(N, K, like=g)
-            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False,
-                    accumulate=sw is not None)                                                                # dW (+)= g^T inp
             db = sb if sb is not None else _f32(N, like=g)
-            kn.colsum(g, M, N, g.stride(0), db, accumulate=sb is not None)
+            fused = kn.gemm_fuses_rowsum(N, False) and g.dtype == torch.float32     # bias gradient = row sums of g^T: same launch
+            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False,
+                    accumulate=sw is not None, rowsum=db if fused else None, rowsum_accumulate=sb is not None)    # dW (+)= g^T inp
+            if not fused:
+                kn.colsum(g, M, N, g.stride(0), db, accumulate=sb is not None)
             grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
             grads[2 * i + 1] = None if sb is not None else db
             if i > 0 or need_x:
@@ -470,27 +472,26 @@ class DecoderRNNFn(torch.autograd.Function):
         d1 = dbuf[1:S + 1]            # rows (t, b): [delta1_t | delta0_{t+1}]
         d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
         M = S * B
-        def wgrad(dlt, inp_rows, ncols, param):
-            """param.grad (+)= dlt^T inp_rows; straight into the gradient arena when the trainer registered a sink"""
-            sink = gradsink.get(param)
-            out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
-            kn.gemm(dlt, inp_rows, out, Hd, ncols, M, 2 * Hd, 2 * Hd, ncols, a_kmajor=False, b_kmajor=False, accumulate=sink is not None)
-            return None if sink is not None else out
+        fuse_b = kn.gemm_fuses_rowsum(Hd, False) and dbuf.dtype == torch.float32
 
-        def bgrad(dlt, param):
-            sink = gradsink.get(param)
-            out = sink if sink is not None else torch.empty(Hd, **f32)
-            kn.colsum(dlt, M, Hd, 2 * Hd, out, accumulate=sink is not None)
-            return None if sink is not None else out
+        def wgrad(dlt, inp_rows, ncols, param, bias):
+            """param.grad (+)= dlt^T inp_rows, bias.grad (+)= column sums of dlt (the row sums of the GEMM's A operand, fused into
+            the same launch); straight into the gradient arena when the trainer registered sinks"""
+            sink, bsink = gradsink.get(param), gradsink.get(bias)
+            out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
+            bout = bsink if bsink is not None else torch.empty(Hd, **f32)
+            kn.gemm(dlt, inp_rows, out, Hd, ncols, M, 2 * Hd, 2 * Hd, ncols, a_kmajor=False, b_kmajor=False, accumulate=sink is not None,
+                    rowsum=bout if fuse_b else None, rowsum_accumulate=bsink is not None)
+            if not fuse_b:
+                kn.colsum(dlt, M, Hd, 2 * Hd, bout, accumulate=bsink is not None)
+            return (None if sink is not None else out), (None if bsink is not None else bout)
 
         b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
-        # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}])
-        dw_ih1 = wgrad(d1, zbuf[1:S + 1], Hd, w_ih1)
-        dw_hh1 = wgrad(d1, zbuf[1:S + 1][:, :, Hd:], Hd, w_hh1)
-        db_ih1, db_hh1 = bgrad(d1, b_ih1), bgrad(d1, b_hh1)
-        # layer 0
-        dw_hh0 = wgrad(d0, zbuf[0:S], Hd, w_hh0)                                    # h0_{t-1} = zbuf[t][:, :H]
-        db_ih0, db_hh0 = bgrad(d0, b_ih0), bgrad(d0, b_hh0)
+        # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}]); both biases see delta1
+        dw_ih1, db_ih1 = wgrad(d1, zbuf[1:S + 1], Hd, w_ih1, b_ih1)
+        dw_hh1, db_hh1 = wgrad(d1, zbuf[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
+        # layer 0 (b_ih0's gradient rides on the embedding-column GEMM of dW_ih0 below)
+        dw_hh0, db_hh0 = wgrad(d0, zbuf[0:S], Hd, w_hh0, b_hh0)                     # h0_{t-1} = zbuf[t][:, :H]
         dcs = torch.empty(B, 2 * Hd, **f32)
         dc = dcs[:, Hd:]                                                            # (B, H) strided view, ld 2H
         kn.strided_seq_sum(d0, dc, B, S, Hd, 2 * Hd, B * 2 * Hd, 2 * Hd)            # dc = sum_t delta0_t
@@ -499,7 +500,14 @@ class DecoderRNNFn(torch.autograd.Function):
         dw_ih0 = s_ih0 if s_ih0 is not None else torch.empty(Hd, Kin, **f32)
         acc0 = s_ih0 is not None
         kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
-        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        sb_ih0 = gradsink.get(b_ih0)
+        db_ih0 = sb_ih0 if sb_ih0 is not None else torch.empty(Hd, **f32)
+        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
+                rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=sb_ih0 is not None)
+        if not fuse_b:
+            kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=sb_ih0 is not None)
+        if sb_ih0 is not None:
+            db_ih0 = None
         kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
         if acc0:
             dw_ih0 = None

@@ -145,7 +145,7 @@ def side_stream(device) -> "torch.cuda.Stream":
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=None, add=None, ld_add=0,
          mask=None, ld_mask=0, mask_scale=1.0, relu=False, accumulate=False, alpha=1.0, drop_p=0.0,
-         drop_seed=0, compute=None):
+         drop_seed=0, compute=None, rowsum=None, rowsum_accumulate=False):
     """C[M,N] = epi(alpha * A·B^T); see hulc_gemm in include/hulc2_amd.h."""
     _require_cuda(A, B, C, bias, add, mask)
     d = _L.GemmDesc()
@@ -167,6 +167,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=True, b_kmajor=True, bias=Non
     ws = _gemm_scratch(C.device)      # split-K slabs (stream-ordered reuse of one scratch buffer)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     d.seed_dev = step_state(C.device).data_ptr() if drop_p > 0.0 else None
+    d.rowsum_a, d.rowsum_accumulate = (rowsum.data_ptr() if rowsum is not None else None), int(rowsum_accumulate)
     esz = lambda t: t.element_size()
     gbytes = M * K * esz(A) + N * K * esz(B) + M * N * esz(C) * (2 if accumulate else 1) \
         + (M * N * esz(add) if add is not None and ld_add else 0) + (M * N * esz(mask) if mask is not None else 0)
@@ -358,6 +359,11 @@ def set_concurrent_streams(flag: bool) -> None:
 
 def concurrent_streams() -> bool:
     return _concurrent_streams
+
+
+def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
+    """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch for row-major A on the tiled path"""
+    return (not a_kmajor) and M > 64
 
 
 def transpose_bf16_tiles(src, dst, tiles):

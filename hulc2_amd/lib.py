@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("compute", ctypes.c_int),
         ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long),
         ("seed_dev", ctypes.c_void_p),
+        ("rowsum_a", ctypes.c_void_p), ("rowsum_accumulate", ctypes.c_int),
     ]
 
 

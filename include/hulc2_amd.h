@@ -48,6 +48,8 @@ typedef struct {
     int compute;
     void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K paths */
     const unsigned long long* seed_dev;   /* optional device word xor-ed into drop_seed (see hulc_step_state_advance) */
+    float* rowsum_a; int rowsum_accumulate;   /* optional, row-major A and M > 64 only: rowsum_a[m] (+)= sum_k A[m][k] in fp32 — with
+                                               * A = dY this is the bias gradient of the weight-gradient GEMM dW = dY^T X, fused */
 } hulc_gemm_desc;
 int hulc_gemm(const hulc_gemm_desc* d, void* stream);
 

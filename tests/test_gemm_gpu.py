@@ -138,3 +138,29 @@ def test_gemm_rejects_bad_calls(dev):
         kn.gemm(A, A, torch.zeros(8, 8, device=dev), 8, 8, 12, 12, 12, 8)   # K % 8 != 0
     with pytest.raises(HulcKernelError):
         kn.gemm(torch.zeros(8, 16), torch.zeros(8, 16), torch.zeros(8, 8), 8, 8, 16, 16, 16, 8)  # CPU tensors
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 2048), (128, 3136, 64), (200, 72, 520), (2048, 2048, 256), (68, 40, 33 * 8)])
+def test_gemm_fused_rowsum(dev, M, N, K, accumulate):
+    """rowsum_a: the bias gradient of a weight-gradient GEMM (row sums of the row-major A operand) from the same launch —
+    split-K and single-slice launches, aligned micro-tile staging and ragged edge tiles"""
+    from hulc2_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g).to(dev)            # [tokens][out features]  (dY)
+    B = torch.randn(K, N, generator=g).to(dev)            # [tokens][in features]   (X)
+    C = torch.zeros(M, N, device=dev)
+    r0 = torch.randn(M, generator=g).to(dev)
+    rs = r0.clone()
+    kn.gemm(A, B, C, M, N, K, M, N, N, a_kmajor=False, b_kmajor=False, rowsum=rs, rowsum_accumulate=accumulate)
+    torch.cuda.synchronize()
+    want = A.double().sum(0) + (r0.double() if accumulate else 0)
+    err = (rs.double() - want).abs().max().item()
+    assert err < 1e-5 * K ** 0.5 + 1e-5, f"rowsum max err {err:.3e}"
+    ref = A.to(torch.bfloat16).double().t() @ B.to(torch.bfloat16).double()
+    assert (C.double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-3, "the product itself is unchanged"
+    rs2 = r0.clone()
+    kn.gemm(A, B, C, M, N, K, M, N, N, a_kmajor=False, b_kmajor=False, rowsum=rs2, rowsum_accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert torch.equal(rs, rs2), "fixed summation order"
