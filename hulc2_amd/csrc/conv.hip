@@ -33,7 +33,7 @@ int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ld
                              int N, int H, int W, hipStream_t s);
 // LDS-band weight gradient (conv_wgrad_band.hip): same return convention
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
-                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, hipStream_t s);
+                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s);
 
 namespace {
 
@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 
 // out[r] = sum_p partial[p][r]: workgroup = 64 outputs x 16 P-slices (fixed slice boundaries and a fixed
 // combine order -> deterministic), so the P-long loop is 16x shorter and the grid is R/64 workgroups of 1024.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate) {
+// perm_c > 0: r = co*K + tap*perm_c + c is written at co*K + c*perm_taps + tap (forward k order -> the parameter's OIHW order)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate,
+                                                               int perm_c, int perm_taps) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long r = (long)blockIdx.x * 64 + lane;
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += red[w][lane];
-        out[r] = accumulate ? out[r] + t : t;
+        long o = r;
+        if (perm_c > 0) { const long K = (long)perm_c * perm_taps, co = r / K, k = r % K; o = co * K + (k % perm_c) * perm_taps + k / perm_c; }
+        out[o] = accumulate ? out[o] + t : t;
     }
 }
 
@@ -561,7 +565,7 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
     if (d->compute == HULC_BF16) {                           // LDS-band kernel (conv_wgrad_band.hip) for the geometries it covers
         const long wsb = hulc_conv2d_bwd_weight_workspace(d);
         const int brc = hulc_conv_wgrad_band_dispatch(d->x_nchw, d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, dy, d->y_dtype,
-                                                      d->N, d->H, d->W, dw, db, ws, wsb, (hipStream_t)stream);
+                                                      d->N, d->H, d->W, dw, db, ws, wsb, d->dw_oihw, d->dw_accumulate, (hipStream_t)stream);
         if (brc < 0) return brc;
         if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_weight(band)");
     }
@@ -589,7 +593,8 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
         if (d->Cout == 32) conv_wgrad_kernel<bf16_t, 1, 2><<<grid, 256, 0, s>>>(p); else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, 256, 0, s>>>(p);
     }
     const long R = (long)d->Cout * K;
-    reduce_partials_kernel<<<(unsigned)((R + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, (int)P, R, 0);
-    if (db) reduce_partials_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, (int)P, d->Cout, 0);
+    const int perm_c = (d->dw_oihw && !d->x_nchw) ? d->Cin : 0;
+    reduce_partials_kernel<<<(unsigned)((R + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, (int)P, R, d->dw_accumulate, perm_c, d->KH * d->KW);
+    if (db) reduce_partials_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, (int)P, d->Cout, d->dw_accumulate, 0, 0);
     return hulc_check_launch("hulc_conv2d_bwd_weight");
 }

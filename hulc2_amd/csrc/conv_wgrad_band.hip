@@ -256,7 +256,9 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
     }
 }
 
-__global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R) {
+// perm_c > 0: forward k order (tap, c) -> the parameter's OIHW order (c, tap); accumulate: add to the destination (gradient arena)
+__global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate,
+                                                            int perm_c, int perm_taps) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long rr = (long)blockIdx.x * 64 + lane;
@@ -271,12 +273,14 @@ __global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += red[w][lane];
-        out[rr] = t;
+        long o = rr;
+        if (perm_c > 0) { const long K = (long)perm_c * perm_taps, co = rr / K, k = rr % K; o = co * K + (k % perm_c) * perm_taps + k / perm_c; }
+        out[o] = accumulate ? out[o] + t : t;
     }
 }
 
 template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC>
-int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, hipStream_t s) {
+int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s) {
     constexpr int COUT = CT * 32, K = TH * TW * C;
     constexpr int PS = NCHW ? 2 : C * 2 + 16;
     const int Wb = p.W, Wp = Wb;
@@ -322,8 +326,8 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, hipSt
     }
     kern<<<grid, 512, (size_t)lds_of(R, F), s>>>(p);
     const long Rw = (long)COUT * K;
-    wband_reduce_kernel<<<(unsigned)((Rw + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, grid, Rw);
-    if (db) wband_reduce_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, grid, COUT);
+    wband_reduce_kernel<<<(unsigned)((Rw + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, (dw_oihw && !NCHW) ? C : 0, TH * TW);
+    if (db) wband_reduce_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, grid, COUT, accumulate, 0, 0);
     return 0;
 }
 
@@ -331,7 +335,7 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, hipSt
 
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error.  dw is [Cout][K] fp32 in the forward k order.
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
-                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, hipStream_t s) {
+                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s) {
     if (getenv("HULC_NO_BAND_WGRAD")) return 1;
     WBandP p;
     p.X = x; p.dY = dy; p.x_dtype = x_dtype; p.dy_dtype = dy_dtype;
@@ -340,10 +344,10 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     else { p.x_sn = (long)H * W * Cin; p.x_sy = (long)W * Cin; p.x_sx = Cin; p.x_sc = 1; }
     p.dy_sn = (long)p.OH * p.OW * Cout; p.dy_sy = (long)p.OW * Cout; p.dy_sx = Cout;
     int rc = 1;
-    if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1) rc = launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, s);
-    else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2) rc = launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, s);
+    if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1) rc = launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
+    else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2) rc = launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && x_dtype == HULC_F32)
-        rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, s);
+        rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else return 1;
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv wgrad band: could not raise the dynamic LDS limit");

@@ -83,6 +83,21 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __
         if (c0 + i < cols && r0 + tx < rows) dst[off + (long)(c0 + i) * rows + r0 + tx] = t[tx][i];
 }
 
+// conv weight repacks (fp32 OIHW parameter -> bf16 kernel layouts), one workgroup column per table entry
+__global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ table) {
+    const long* q = table + (long)blockIdx.y * 7;
+    const long so = q[0], d0 = q[1];
+    const int Cout = (int)q[2], Cin = (int)q[3], KH = (int)q[4], KW = (int)q[5], mode = (int)q[6];
+    const int n = Cout * Cin * KH * KW, taps = KH * KW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int o, c, t;                                      // destination index i -> (o, c, tap)
+        if (mode == 0) { o = i / (Cin * taps); c = (i / taps) % Cin; t = i % taps; }
+        else if (mode == 1) { o = i / (taps * Cin); t = (i / Cin) % taps; c = i % Cin; }
+        else { c = i / (taps * Cout); t = (i / Cout) % taps; o = i % Cout; }
+        dst[d0 + i] = f32_to_bf16_bits(src[so + ((long)o * Cin + c) * taps + t]);
+    }
+}
+
 }  // namespace
 
 extern "C" int hulc_step_state_advance(unsigned long long* state, void* stream) {
@@ -117,4 +132,11 @@ extern "C" int hulc_transpose_bf16_tiles(const void* src, void* dst, const long*
     if (ntiles <= 0) return 0;
     transpose_tiles_kernel<<<(unsigned)ntiles, 256, 0, (hipStream_t)stream>>>((const uint16_t*)src, (uint16_t*)dst, tiles);
     return hulc_check_launch("hulc_transpose_bf16_tiles");
+}
+
+extern "C" int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream) {
+    if (!src || !dst || !table) return hulc_fail(-1, "hulc_repack_conv_weights: null pointer");
+    if (n <= 0) return 0;
+    repack_conv_kernel<<<dim3(16, (unsigned)n), 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, table);
+    return hulc_check_launch("hulc_repack_conv_weights");
 }

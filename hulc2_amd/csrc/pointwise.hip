@@ -610,15 +610,15 @@ extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
 
 extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R,
                                   int D, float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
-                                  float* dgamma, float* dbeta, void* ws, void* stream) {
+                                  float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream) {
     if (!dy || !pre || !mean || !rstd || !gamma || !dpre || !dgamma || !dbeta || !ws) return hulc_fail(-1, "hulc_layernorm_bwd: null pointer");
     if (D > 256 || D <= 0) return hulc_fail(-2, "hulc_layernorm_bwd: D must be in 1..256");
     const int rpb = ln_bwd_rows_per_block(R), nb = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, seed_dev, (float*)ws);
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
-    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, 0);
-    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, 0);
+    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params);
+    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, accumulate_params);
     return hulc_check_launch("hulc_layernorm_bwd");
 }
 

@@ -137,6 +137,7 @@ class ConvStackFn(torch.autograd.Function):
             acts.append(y)
             inp, h, w_, cin = y, oh, ow, cout
         ctx.save_for_backward(acts[0], acts[1], acts[2], w2, w3, *xs)
+        ctx.conv_w, ctx.conv_b = ws, bs                   # identities for the gradient sinks
         ctx.meta = (dims, grad_premasked, Ns)
         return acts[2]
 
@@ -155,22 +156,19 @@ class ConvStackFn(torch.autograd.Function):
         grads_w, grads_b = [None] * 3, [None] * 3
         for li in (2, 1, 0):
             h, w_, cin, cout, k, s, nchw = dims[li]
-            if li == 0:                                  # per input tensor; partial gradients summed (tiny tensors)
-                dw = db = None
+            sw, sb = gradsink.get(ctx.conv_w[li]), gradsink.get(ctx.conv_b[li])
+            sunk = sw is not None and sb is not None      # the reduce pass writes OIHW straight into the gradient arena
+            dw = sw.view(cout, cin * k * k) if sunk else _f32(cout, cin * k * k, like=g)
+            db = sb if sunk else _f32(cout, like=g)
+            if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
-                for x, n in zip(xs, Ns):
-                    dwi, dbi = _f32(cout, cin * k * k, like=g), _f32(cout, like=g)
-                    kn.conv2d_bwd_weight(x, g[off:off + n], dwi, dbi, n, h, w_, cin, cout, k, k, s, nchw)
-                    dw, db = (dwi, dbi) if dw is None else (dw + dwi, db + dbi)
+                for j, (x, n) in enumerate(zip(xs, Ns)):
+                    kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk or j > 0)
                     off += n
             else:
-                inp = inputs[li]
-                dw = _f32(cout, cin * k * k, like=g)
-                db = _f32(cout, like=g)
-                kn.conv2d_bwd_weight(inp, g, dw, db, N, h, w_, cin, cout, k, k, s, nchw)
-            # back to the parameter's OIHW layout (dw is [Cout][kh][kw][cin] for NHWC layers)
-            grads_w[li] = dw.view(cout, cin, k, k) if nchw else dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
-            grads_b[li] = db
+                kn.conv2d_bwd_weight(inputs[li], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk)
+            grads_w[li] = None if sunk else dw.view(cout, cin, k, k)
+            grads_b[li] = None if sunk else db
             if li > 0:
                 inp = inputs[li]
                 wt = weight_operand(weights[li], "ihwo")
@@ -226,6 +224,7 @@ class LayerNormFn(torch.autograd.Function):
         pre = _f32(R, D, like=x2) if o2 is not None else None
         kn.layernorm_fwd(x2, o2, drop_p, seed, gamma, beta, eps, R, D, pre, y, mean, rstd)
         ctx.save_for_backward(pre if pre is not None else x2, mean, rstd, gamma)
+        ctx.beta = beta                                           # identity only (gradient sink lookup)
         ctx.meta = (x.shape, o is not None, drop_p, seed)
         return y.reshape(x.shape)
 
@@ -237,13 +236,15 @@ class LayerNormFn(torch.autograd.Function):
         dy2 = _c(dy.reshape(R, D))
         dpre = _f32(R, D, like=dy2)
         do = _f32(R, D, like=dy2) if (has_o and drop_p > 0) else None
-        dg, db = _f32(D, like=dy2), _f32(D, like=dy2)
-        kn.layernorm_bwd(dy2, pre, mean, rstd, gamma, R, D, dpre, do, drop_p, seed, dg, db)
+        sg, sb = gradsink.get(gamma), gradsink.get(ctx.beta)
+        sunk = sg is not None and sb is not None                  # straight into the gradient arena (no AccumulateGrad adds)
+        dg, db = (sg, sb) if sunk else (_f32(D, like=dy2), _f32(D, like=dy2))
+        kn.layernorm_bwd(dy2, pre, mean, rstd, gamma, R, D, dpre, do, drop_p, seed, dg, db, accumulate_params=sunk)
         dx = dpre.reshape(shape)
         d_o = None
         if has_o:
             d_o = (do if do is not None else dpre).reshape(shape)
-        return dx, d_o, dg, db, None, None, None
+        return dx, d_o, (None if sunk else dg), (None if sunk else db), None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

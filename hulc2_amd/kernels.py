@@ -215,12 +215,14 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
     return dx
 
 
-def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None):
-    """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC)."""
+def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None, dw_oihw=False, accumulate=False):
+    """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC).  dw_oihw: dw in the parameter's OIHW order (else the forward k order);
+    accumulate: add into dw / db (gradient arena sinks)."""
     _require_cuda(x, dy, dw, db)
     lib = _L.load()
     lib.hulc_conv2d_bwd_weight_workspace.restype = ctypes.c_long
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(dy), F32, False, compute)
+    d.dw_oihw, d.dw_accumulate = int(dw_oihw), int(accumulate)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
@@ -290,12 +292,12 @@ def layernorm_fwd(x, o, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, 
     _call("hulc_layernorm_fwd", x, o, _f(drop_p), _u64(seed), _sd(x, drop_p), gamma, beta, _f(eps), _i(R), _i(D), pre_out, y, mean, rstd)
 
 
-def layernorm_bwd(dy, pre, mean, rstd, gamma, R, D, dpre, do_out, drop_p, seed, dgamma, dbeta):
+def layernorm_bwd(dy, pre, mean, rstd, gamma, R, D, dpre, do_out, drop_p, seed, dgamma, dbeta, accumulate_params=False):
     lib = _L.load()
     lib.hulc_layernorm_bwd_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_layernorm_bwd_workspace(_i(R), _i(D)), dy.device)
     _call("hulc_layernorm_bwd", dy, pre, mean, rstd, gamma, _i(R), _i(D), dpre, do_out, _f(drop_p), _u64(seed), _sd(dy, drop_p), dgamma,
-          dbeta, ws)
+          dbeta, _i(accumulate_params), ws)
 
 
 def colsum(x, M, N, ld, out, accumulate=False):
@@ -364,6 +366,11 @@ def concurrent_streams() -> bool:
 def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
     """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch for row-major A on the tiled path"""
     return (not a_kmajor) and M > 64
+
+
+def repack_conv_weights(src_f32, dst_bf16, table):
+    """table: int64 (n, 7) device tensor {src offset, dst offset, Cout, Cin, KH, KW, mode} (mode 0 oihw_flat, 1 ohwi, 2 ihwo)"""
+    _call("hulc_repack_conv_weights", src_f32, dst_bf16, table, _i(table.shape[0]))
 
 
 def transpose_bf16_tiles(src, dst, tiles):

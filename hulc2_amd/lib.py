@@ -74,6 +74,7 @@ class ConvDesc(ctypes.Structure):
         ("x_dtype", ctypes.c_int), ("y_dtype", ctypes.c_int), ("w_dtype", ctypes.c_int),
         ("relu", ctypes.c_int),
         ("compute", ctypes.c_int),
+        ("dw_oihw", ctypes.c_int), ("dw_accumulate", ctypes.c_int),
     ]
 
 

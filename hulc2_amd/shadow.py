@@ -23,6 +23,7 @@ def clear() -> None:
     _cache.clear()
     _arena.clear()
     _arena_t.clear()
+    _arena_layout.clear()
 
 
 def bump_epoch() -> None:
@@ -42,6 +43,15 @@ def register_arena_view_t(param: torch.Tensor, view_bf16_t: torch.Tensor) -> Non
     """transposed bf16 shadow (cols, rows) kept fresh by the trainer (one hulc_transpose_bf16_tiles launch per step)"""
     key = id(param)
     _arena_t[key] = (weakref.ref(param, lambda _r, k=key: _arena_t.pop(k, None)), view_bf16_t)
+
+
+_arena_layout: Dict[Tuple[int, str], Tuple["weakref.ref", torch.Tensor]] = {}   # (id(param), layout) -> bf16 repack kept fresh by the trainer
+
+
+def register_layout_view(param: torch.Tensor, layout: str, view_bf16: torch.Tensor) -> None:
+    """conv-weight repack (oihw_flat / ohwi / ihwo) refreshed by the trainer's one-launch hulc_repack_conv_weights"""
+    key = (id(param), layout)
+    _arena_layout[key] = (weakref.ref(param, lambda _r, k=key: _arena_layout.pop(k, None)), view_bf16)
 
 
 def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
@@ -70,6 +80,10 @@ def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tenso
     elif layout is None or layout == "t":
         hit = (_arena if layout is None else _arena_t).get(id(w))
         if hit is not None and hit[0]() is w:       # ids are recycled: trust the entry only for the very same tensor object
+            return hit[1]
+    if bf16 and layout is not None:
+        hit = _arena_layout.get((id(w), layout))
+        if hit is not None and hit[0]() is w:
             return hit[1]
     key = (id(w), layout, int(bf16))
     ver = (w._version, _epoch)

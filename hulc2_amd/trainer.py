@@ -143,6 +143,25 @@ class ArenaTrainer:
                     if off in covered:
                         shadow.register_arena_view_t(p, self.flat_bf16_t[off:off + p.numel()].view(p.shape[1], p.shape[0]))
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+        # conv weights in their kernel layouts (OIHW flat for conv1, OHWI forward, IHWO data gradient): one repack launch per step
+        self.conv_shadow = self.conv_table = None
+        if self.flat_bf16 is not None:
+            rows, views, dst = [], [], 0
+            for p, off in zip(self.params, self.offsets):
+                if p.dim() != 4:
+                    continue
+                co, ci, kh, kw = p.shape
+                modes = [("oihw_flat", 0, (co, ci * kh * kw))] if ci < 8 else [("ohwi", 1, (co, kh * kw * ci)), ("ihwo", 2, (ci, kh, kw, co))]
+                for name, mode, shape in modes:
+                    rows.append((off, dst, co, ci, kh, kw, mode))
+                    views.append((p, name, dst, shape))
+                    dst += (p.numel() + 7) // 8 * 8
+            if rows:
+                self.conv_shadow = torch.zeros(dst, dtype=torch.bfloat16, device=dev)
+                self.conv_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+                for p, name, d0, shape in views:
+                    shadow.register_layout_view(p, name, self.conv_shadow[d0:d0 + p.numel()].view(shape))
+                kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
         # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
@@ -210,6 +229,8 @@ class ArenaTrainer:
                      step_state_dev=kn.step_state(self.dev))      # step count lives on the device (graph replay)
         if self.tiles_t is not None:
             kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+        if self.conv_table is not None:
+            kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         shadow.bump_epoch()
 
     def _forward_backward(self, batch, batch_idx: int) -> torch.Tensor:

@@ -67,6 +67,8 @@ typedef struct {
     int x_dtype, y_dtype, w_dtype;
     int relu;
     int compute;
+    int dw_oihw;        /* bwd_weight only: write dW in the parameter's OIHW order instead of the forward k order (NHWC layers) */
+    int dw_accumulate;  /* bwd_weight only: dW and db are added to the destination (gradient arena) instead of overwriting it */
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]
@@ -97,7 +99,8 @@ int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned lo
 long hulc_layernorm_bwd_workspace(int R, int D);
 int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
                        float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
-                       float* dgamma, float* dbeta, void* ws, void* stream);
+                       float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream);
+/* accumulate_params != 0: dgamma / dbeta are added to the destination (the gradient arena) instead of overwriting it */
 /* out[n] (+)= sum_m x[m*ld + n]: bias gradients of nn.Linear / position-embedding gradient. */
 long hulc_colsum_workspace(long M, int N);
 int hulc_colsum(const void* x, int x_dtype, long M, int N, long ld, float* out, int accumulate, void* ws, void* stream);
@@ -204,6 +207,10 @@ int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
  * tile col} over 64 x 64 tiles; dst + offset receives W^T ([cols][rows]).  The data-gradient GEMMs (dX = dY W of every
  * nn.Linear) then read W k-major like the forward pass does. */
 int hulc_transpose_bf16_tiles(const void* src, void* dst, const long* tiles, int ntiles, void* stream);
+/* All conv-weight repacks of a step in one launch: table[q] = {src offset (fp32 arena elements), dst offset (bf16 elements), Cout, Cin,
+ * KH, KW, mode}; mode 0 = OIHW flat (conv1 forward), 1 = OHWI (NHWC forward, k = (kh,kw,c)), 2 = IHWO (data gradient,
+ * rows = input channel, k = (kh,kw,cout)).  Replaces a permute copy + cast per layer and layout. */
+int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,3 +91,12 @@ def test_conv_bwd_weight(dev, compute, name, N, H, W, Cin, Cout, K, stride, nchw
     refb = dy.double().sum(dim=(0, 2, 3))
     errb = (db.double() - refb).abs().max().item()
     assert errb < 1e-4 * refb.abs().max().item() + 1e-3, f"{name}: db max err {errb:.3e}"
+    # gradient-arena form: the parameter's OIHW order, accumulated into the destination
+    base_w, base_b = torch.randn(Cout, Kd, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    dw2, db2 = base_w.clone(), base_b.clone()
+    kn.conv2d_bwd_weight(xin, dy.permute(0, 2, 3, 1).contiguous(), dw2, db2, N, H, W, Cin, Cout, K, K, stride, nchw,
+                         compute=kn._COMPUTE[compute], dw_oihw=True, accumulate=True)
+    torch.cuda.synchronize()
+    want = base_w.double() + ref.reshape(Cout, -1)
+    assert (dw2.double() - want).abs().max().item() < 1e-4 * scale + 1e-4, f"{name}: OIHW accumulated dW"
+    assert (db2.double() - (base_b.double() + refb)).abs().max().item() < 1e-4 * refb.abs().max().item() + 1e-3, f"{name}: accumulated db"
