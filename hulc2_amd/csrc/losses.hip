@@ -188,20 +188,25 @@ __global__ __launch_bounds__(256) void cat_kl_group_kernel(const float* __restri
     const float kl = sub32_sum(expf(lp) * (lp - lq));
     if (lane == 0) kl_group[g] = kl;
 }
-__global__ __launch_bounds__(1024) void cat_kl_sum_kernel(const float* __restrict__ kl_group, int NG, int B, float beta, float* __restrict__ out) {
+// one workgroup per segment (a modality of the batch): out[seg] = beta * mean over the segment's rows
+__global__ __launch_bounds__(1024) void cat_kl_sum_kernel(const float* __restrict__ kl_group, int NG_seg, int B_seg, float beta, float* __restrict__ out) {
     __shared__ float sh[16];
+    const float* kg = kl_group + (long)blockIdx.x * NG_seg;
     float acc = 0.f;
-    for (int g = threadIdx.x; g < NG; g += blockDim.x) acc += kl_group[g];
+    for (int g = threadIdx.x; g < NG_seg; g += blockDim.x) acc += kg[g];
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) out[0] = beta * acc / B;
+    if (threadIdx.x == 0) out[blockIdx.x] = beta * acc / B_seg;
 }
 
 __global__ __launch_bounds__(256) void cat_kl_bwd_kernel(const float* __restrict__ pp, const float* __restrict__ pr,
                                                          const float* __restrict__ kl_group, int B, int G, float beta, float mix,
-                                                         const float* __restrict__ gout, float* __restrict__ dpp, float* __restrict__ dpr) {
+                                                         const float* __restrict__ gout, int nseg, float* __restrict__ dpp, float* __restrict__ dpr) {
     const int lane = threadIdx.x & 31;
     const int g = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (g >= B * G) return;
+    const int Bs = B / nseg;                                      // rows per segment; gout[seg] is that segment's upstream gradient
+    gout += (g / G) / Bs;
+    B = Bs;
     const float a = pr[(long)g * 32 + lane], b = pp[(long)g * 32 + lane];
     const float ma = sub32_max(a), mb = sub32_max(b);
     const float lp = a - (ma + logf(sub32_sum(expf(a - ma))));
@@ -471,18 +476,20 @@ extern "C" int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const f
     return hulc_check_launch("hulc_mix_loss_bwd");
 }
 
-extern "C" int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, float* out, float* kl_group, void* stream) {
+extern "C" int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, int nseg, float* out, float* kl_group, void* stream) {
     if (!pp || !pr || !out || !kl_group) return hulc_fail(-1, "hulc_cat_kl_fwd: null pointer");
     if (CLS != 32) return hulc_fail(-2, "hulc_cat_kl_fwd: class_size must be 32 (one 32-lane sub-wave per category)");
+    if (nseg < 1 || B % nseg) return hulc_fail(-2, "hulc_cat_kl_fwd: the batch must split evenly into nseg segments");
     cat_kl_group_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, B * G, kl_group);
-    cat_kl_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kl_group, B * G, B, beta, out);
+    cat_kl_sum_kernel<<<nseg, 1024, 0, (hipStream_t)stream>>>(kl_group, B / nseg * G, B / nseg, beta, out);
     return hulc_check_launch("hulc_cat_kl_fwd");
 }
 extern "C" int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int B, int G, int CLS, float beta, float mix,
-                               const float* gout, float* dpp, float* dpr, void* stream) {
+                               const float* gout, int nseg, float* dpp, float* dpr, void* stream) {
     if (!pp || !pr || !kl_group || !gout || !dpp || !dpr) return hulc_fail(-1, "hulc_cat_kl_bwd: null pointer");
     if (CLS != 32) return hulc_fail(-2, "hulc_cat_kl_bwd: class_size must be 32");
-    cat_kl_bwd_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, kl_group, B, G, beta, mix, gout, dpp, dpr);
+    if (nseg < 1 || B % nseg) return hulc_fail(-2, "hulc_cat_kl_bwd: the batch must split evenly into nseg segments");
+    cat_kl_bwd_kernel<<<(B * G + 7) / 8, 256, 0, (hipStream_t)stream>>>(pp, pr, kl_group, B, G, beta, mix, gout, nseg, dpp, dpr);
     return hulc_check_launch("hulc_cat_kl_bwd");
 }
 extern "C" int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, const unsigned long long* seed_dev,

@@ -554,23 +554,24 @@ class CatKLFn(torch.autograd.Function):
     """KL balancing of hulc2.py:444-466 on (B, G*32) logits of prior (pp) and posterior (pr)."""
 
     @staticmethod
-    def forward(ctx, pp, pr, G: int, CLS: int, beta: float, mix: float):
+    def forward(ctx, pp, pr, G: int, CLS: int, beta: float, mix: float, nseg: int = 1):
+        """nseg > 1: the rows are nseg equal segments (modalities batched together) -> (nseg,) losses, each its own mean"""
         pp, pr = _c(pp), _c(pr)
         B = pp.shape[0]
-        out = _f32(1, like=pp)
+        out = _f32(nseg, like=pp)
         klg = _f32(B * G, like=pp)
-        kn.cat_kl_fwd(pp, pr, B, G, CLS, beta, out, klg)
+        kn.cat_kl_fwd(pp, pr, B, G, CLS, beta, out, klg, nseg)
         ctx.save_for_backward(pp, pr, klg)
-        ctx.meta = (B, G, CLS, beta, mix)
-        return out[0]
+        ctx.meta = (B, G, CLS, beta, mix, nseg)
+        return out[0] if nseg == 1 else out
 
     @staticmethod
     def backward(ctx, g):
         pp, pr, klg = ctx.saved_tensors
-        B, G, CLS, beta, mix = ctx.meta
+        B, G, CLS, beta, mix, nseg = ctx.meta
         dpp, dpr = torch.empty_like(pp), torch.empty_like(pr)
-        kn.cat_kl_bwd(pp, pr, klg, B, G, CLS, beta, mix, _c(g.reshape(1)), dpp, dpr)
-        return dpp, dpr, None, None, None, None
+        kn.cat_kl_bwd(pp, pr, klg, B, G, CLS, beta, mix, _c(g.reshape(nseg)), dpp, dpr, nseg)
+        return dpp, dpr, None, None, None, None, None
 
 
 class PlanSampleFn(torch.autograd.Function):

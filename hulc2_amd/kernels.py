@@ -422,12 +422,12 @@ def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scal
     _call("hulc_mix_loss_bwd", _c.byref(d), y, act, gout, dy, _l(ld_dy))
 
 
-def cat_kl_fwd(pp, pr, B, G, CLS, beta, out, kl_group):
-    _call("hulc_cat_kl_fwd", pp, pr, _i(B), _i(G), _i(CLS), _f(beta), out, kl_group)
+def cat_kl_fwd(pp, pr, B, G, CLS, beta, out, kl_group, nseg=1):
+    _call("hulc_cat_kl_fwd", pp, pr, _i(B), _i(G), _i(CLS), _f(beta), _i(nseg), out, kl_group)
 
 
-def cat_kl_bwd(pp, pr, kl_group, B, G, CLS, beta, mix, gout, dpp, dpr):
-    _call("hulc_cat_kl_bwd", pp, pr, kl_group, _i(B), _i(G), _i(CLS), _f(beta), _f(mix), gout, dpp, dpr)
+def cat_kl_bwd(pp, pr, kl_group, B, G, CLS, beta, mix, gout, dpp, dpr, nseg=1):
+    _call("hulc_cat_kl_bwd", pp, pr, kl_group, _i(B), _i(G), _i(CLS), _f(beta), _f(mix), gout, _i(nseg), dpp, dpr)
 
 
 def plan_sample_fwd(logits, idx_in, seed, NG, CLS, idx_out, plan):

@@ -55,8 +55,19 @@ class LogisticDecoderRNN(ActionDecoder):
         self.hidden_state = None
 
     # ---- hot path ----------------------------------------------------------------------------------
+    def fused_param_groups(self):
+        """Parameters the native trainer lays out contiguously so that the four heads are ONE (184, H) matrix / (184,) bias in the
+        arena (views, no per-step concat; their gradient lands in the same arena slice).  Order = the fused head layout."""
+        return [dict(attr="heads_w", params=[self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight],
+                     pad=2 * self.prob_fc.weight.shape[1], shape=(184, self.prob_fc.weight.shape[1])),
+                dict(attr="heads_b", params=[self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias], pad=2, shape=(184,))]
+
+    _fused = None      # {"heads_w": tensor view, "heads_b": tensor view} installed by ArenaTrainer
+
     def _heads(self, h: torch.Tensor) -> torch.Tensor:
         """(B,S,H) -> (B*S, 184): [logit_probs 60 | means 60 | log_scales 60 | gripper 2 | 2 zero pad columns]."""
+        if self._fused is not None:
+            return HF.mlp(h.reshape(-1, h.shape[-1]), [(self._fused["heads_w"], self._fused["heads_b"], False)])
         w = torch.cat([self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight,
                        self.prob_fc.weight.new_zeros(2, self.prob_fc.weight.shape[1])], dim=0)
         b = torch.cat([self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias,
@@ -81,7 +92,10 @@ class LogisticDecoderRNN(ActionDecoder):
         if n > 1 and len({p.shape[0] for p in plans}) > 1:          # unequal batches: fall back to separate passes
             return torch.cat([self.loss_segments([plans[i]], [embs[i]], [goals[i]], [actions[i]], [robot_obs[i]]) for i in range(n)])
         cat = (lambda ts: ts[0] if n == 1 else torch.cat(ts, dim=0))
-        plan, emb, goal, act, obs = cat(plans), cat(embs), cat(goals), cat(actions), cat(robot_obs)
+        return self.loss_stacked(cat(plans), cat(embs), cat(goals), cat(actions), cat(robot_obs), n)
+
+    def loss_stacked(self, plan, emb, goal, act, obs, n: int = 1) -> torch.Tensor:
+        """`loss_segments` on inputs that are already stacked on the batch axis (n equal segments, rows segment-major)"""
         y = self._heads(self._rnn(plan, emb, goal))
         acts = HF.world_to_tcp_frame(act, obs) if self.gripper_control else act
         return HF.MixLossFn.apply(y, acts.reshape(-1, acts.shape[-1]), self.action_min_bound[0, 0, :, 0].contiguous(),

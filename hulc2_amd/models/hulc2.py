@@ -98,25 +98,28 @@ class Hulc2(LightningModule):
         def acc(a, b):
             return b if a is None else a + b
 
-        # pass 1 — encoders, goal, prior/posterior, latent plan sample, KL (hulc2.py:380-386,228-237,242).  Modalities of
-        # identical shape go through the shared networks together (same per-row arithmetic, half the launches); the goal
-        # encoders, the plan sample and the KL stay per modality.
+        # encoders, goal, prior/posterior, latent plan sample, KL, decoder (hulc2.py:380-386,228-242).  Modalities of identical
+        # shape are stacked on the batch axis through every shared network (same per-row arithmetic, half the launches); only
+        # the goal encoders differ per modality, and every loss is still the mean over its own modality's rows.
         per = []
         mods = list(batch.items())
         if self._batchable(mods):
-            from hulc2_amd.utils.distributions import DiscState
             emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
             B = mods[0][1]["actions"].shape[0]
             embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
             goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
-            pp_all = self.plan_proposal(emb_all[:, 0], torch.cat(goals, dim=0))
+            goal_all = torch.cat(goals, dim=0)
+            pp_all = self.plan_proposal(emb_all[:, 0], goal_all)
             pr_all, seq_all = self.plan_recognition(emb_all)
+            # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality
+            idxs = [db.get("plan_idx") for _, db in mods]
+            idx_all = torch.cat(idxs, dim=0) if all(i is not None for i in idxs) else None
+            plan_all, _ = self.dist.rsample_plan(pr_all, seed=0xA11CE, idx=idx_all)
+            kls = self.dist.kl_balanced_segments(pp_all, pr_all, self.kl_beta, self.kl_balancing_mix, len(mods))
+            act_losses = self.action_decoder.loss_stacked(plan_all, emb_all, goal_all, torch.cat([db["actions"] for _, db in mods], dim=0),
+                                                          torch.cat([db["state_info"]["robot_obs"] for _, db in mods], dim=0), len(mods))
             for i, (self.modality_scope, db) in enumerate(mods):
-                sl = slice(i * B, (i + 1) * B)
-                pp_state, pr_state = DiscState(pp_all.logit[sl]), DiscState(pr_all.logit[sl])
-                site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
-                plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
-                per.append((self.modality_scope, db, embs[i], goals[i], seq_all[sl], plan, self.compute_kl_loss(pp_state, pr_state)))
+                per.append((self.modality_scope, db, None, goals[i], seq_all[i * B:(i + 1) * B], None, kls[i]))
         else:
             for self.modality_scope, db in mods:
                 emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
@@ -126,10 +129,10 @@ class Hulc2(LightningModule):
                 site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
                 plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
                 per.append((self.modality_scope, db, emb, latent_goal, seq_feat, plan, self.compute_kl_loss(pp_state, pr_state)))
-        # pass 2 — the action decoder sees all modalities at once (shared weights, independent sequences); it returns
-        # one loss per modality, each the mean over that modality's own tokens as in the reference (hulc2.py:239-241)
-        act_losses = self.action_decoder.loss_segments([p[5] for p in per], [p[2] for p in per], [p[3] for p in per],
-                                                       [p[1]["actions"] for p in per], [p[1]["state_info"]["robot_obs"] for p in per])
+            # the action decoder sees all modalities at once (shared weights, independent sequences); it returns one loss per
+            # modality, each the mean over that modality's own tokens as in the reference (hulc2.py:239-241)
+            act_losses = self.action_decoder.loss_segments([p[5] for p in per], [p[2] for p in per], [p[3] for p in per],
+                                                           [p[1]["actions"] for p in per], [p[1]["state_info"]["robot_obs"] for p in per])
         for i, (self.modality_scope, db, emb, latent_goal, seq_feat, plan, kl) in enumerate(per):
             act_loss = act_losses[i]
             mod_loss = act_loss + kl

@@ -103,10 +103,43 @@ class ArenaTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
-        self.offsets, total = [], 0
+        # arena order = registration order, except that modules may ask for groups of parameters to sit back to back
+        # (fused_param_groups: the decoder's four heads become one (184, H) matrix view).  Fused views receive their gradient
+        # through a sink only, so they exist only when sinks do (not with per-parameter all-reduce hooks).
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        use_sinks = dev.type == "cuda" and (self.world == 1 or not overlap)
+        groups = []
+        for mod in model.modules():                     # views installed by an earlier trainer die with its arena
+            if getattr(mod, "fused_param_groups", None) is not None:
+                mod._fused = None
+        if use_sinks:
+            for mod in model.modules():
+                fn = getattr(mod, "fused_param_groups", None)
+                if fn is not None:
+                    groups += [(mod, g) for g in fn() if all(p.requires_grad for p in g["params"])]
+        member = {id(p): gi for gi, (_, g) in enumerate(groups) for p in g["params"]}
+        order, placed, self.group_spans = [], set(), {}
         for p in self.params:
+            gi = member.get(id(p))
+            if gi is None:
+                order.append((p, None))
+            elif gi not in placed:
+                placed.add(gi)
+                order += [(q, gi) for q in groups[gi][1]["params"]]
+        self.params = [p for p, _ in order]
+        self.offsets, total = [], 0
+        for i, (p, gi) in enumerate(order):
             self.offsets.append(total)
-            total += (p.numel() + 7) // 8 * 8            # 16-byte alignment in both the fp32 and the bf16 arena
+            last_of_group = gi is not None and (i + 1 == len(order) or order[i + 1][1] != gi)
+            if gi is None:
+                total += (p.numel() + 7) // 8 * 8        # 16-byte alignment in both the fp32 and the bf16 arena
+            else:
+                if gi not in self.group_spans:
+                    self.group_spans[gi] = total
+                total += p.numel()                        # members tightly packed ...
+                if last_of_group:
+                    total = (total + groups[gi][1]["pad"] + 7) // 8 * 8   # ... then the group's zero padding
+        self._groups = groups
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -121,6 +154,20 @@ class ArenaTrainer:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 if self.flat_bf16 is not None and p.dim() == 2:
                     shadow.register_arena_view(p, self.flat_bf16[off:off + n].view(p.shape))
+        # fused group views: parameter view for the kernels, gradient view as its sink, bf16 shadow like any 2-D weight
+        self.fused = []
+        for gi, (mod, g) in enumerate(groups):
+            off, shape = self.group_spans[gi], tuple(g["shape"])
+            n = 1
+            for d in shape:
+                n *= d
+            pv, gv = self.flat_p[off:off + n].view(shape), self.flat_g[off:off + n].view(shape)
+            if mod._fused is None:
+                mod._fused = {}
+            mod._fused[g["attr"]] = pv
+            self.fused.append((pv, gv, off, shape))
+            if len(shape) == 2:
+                shadow.register_arena_view(pv, self.flat_bf16[off:off + n].view(shape))
         if self.flat_bf16 is not None:
             kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, total)
         # transposed bf16 shadows of the nn.Linear weights (data-gradient GEMMs read W^T k-major); RNN and conv weights are
@@ -128,20 +175,22 @@ class ArenaTrainer:
         self.flat_bf16_t = self.tiles_t = None
         if self.flat_bf16 is not None:
             names = {id(p): n for n, p in model.named_parameters()}
-            tiles = []
+            mats = []                                     # (tensor the kernels see, arena offset): single weights and fused groups
             for p, off in zip(self.params, self.offsets):
                 nm = names.get(id(p), "")
-                if p.dim() != 2 or "rnn.weight_hh" in nm or "rnn.weight_ih_l1" in nm or min(p.shape) < 8:
+                if p.dim() != 2 or "rnn.weight_hh" in nm or "rnn.weight_ih_l1" in nm or min(p.shape) < 8 or id(p) in member:
                     continue
-                r, c = p.shape
+                mats.append((p, off))
+            mats += [(pv, off) for pv, _, off, shape in self.fused if len(shape) == 2]
+            tiles = []
+            for t, off in mats:
+                r, c = t.shape
                 tiles += [(off, r, c, i, j) for i in range((r + 63) // 64) for j in range((c + 63) // 64)]
             if tiles:
                 self.flat_bf16_t = torch.zeros(total, dtype=torch.bfloat16, device=dev)
                 self.tiles_t = torch.tensor(tiles, dtype=torch.int64, device=dev)
-                covered = {t[0] for t in tiles}
-                for p, off in zip(self.params, self.offsets):
-                    if off in covered:
-                        shadow.register_arena_view_t(p, self.flat_bf16_t[off:off + p.numel()].view(p.shape[1], p.shape[0]))
+                for t, off in mats:
+                    shadow.register_arena_view_t(t, self.flat_bf16_t[off:off + t.numel()].view(t.shape[1], t.shape[0]))
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
         # conv weights in their kernel layouts (OIHW flat for conv1, OHWI forward, IHWO data gradient): one repack launch per step
         self.conv_shadow = self.conv_table = None
@@ -162,14 +211,15 @@ class ArenaTrainer:
                 for p, name, d0, shape in views:
                     shadow.register_layout_view(p, name, self.conv_shadow[d0:d0 + p.numel()].view(shape))
                 kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
         # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
         kn.set_concurrent_streams(dev.type == "cuda" and self.world > 1 and overlap)
         gradsink.clear()
-        if dev.type == "cuda" and (self.world == 1 or not overlap):     # no per-parameter all-reduce hooks depend on AccumulateGrad
+        if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
             for p, off in zip(self.params, self.offsets):
                 gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape))
+            for pv, gv, _, _ in self.fused:
+                gradsink.register(pv, gv)
         self.step_count = 0
         self.dev = dev
         self.graph_fb = self.graph_enc = self.graph_opt = None

@@ -54,3 +54,7 @@ class Distribution:
     def kl_balanced(self, pp_state: DiscState, pr_state: DiscState, kl_beta: float, mix: float) -> torch.Tensor:
         """Hulc2.compute_kl_loss (hulc2.py:444-466) in one kernel pair."""
         return HF.CatKLFn.apply(pp_state.logit, pr_state.logit, self.category_size, self.class_size, float(kl_beta), float(mix))
+
+    def kl_balanced_segments(self, pp_state: DiscState, pr_state: DiscState, kl_beta: float, mix: float, nseg: int) -> torch.Tensor:
+        """the same loss for nseg modalities stacked on the batch axis: (nseg,) values, each the mean over its own rows"""
+        return HF.CatKLFn.apply(pp_state.logit, pr_state.logit, self.category_size, self.class_size, float(kl_beta), float(mix), int(nseg))

@@ -141,11 +141,12 @@ typedef struct {
 long hulc_mix_loss_workspace(const hulc_mix_desc* d);
 int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out, void* ws, void* stream);
 int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const float* act, const float* gout, float* dy, long ld_dy, void* stream);
-/* KL-balanced categorical KL (hulc2.py:444-466): out[0] = beta * mean_b sum_g KL(post_g || prior_g);
- * bwd: dpp gets mix * d/d prior, dpr gets (1 - mix) * d/d posterior. pp/pr: [B][G*CLS], CLS == 32. */
-int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, float* out, float* kl_group, void* stream);
+/* KL-balanced categorical KL (hulc2.py:444-466): out[seg] = beta * mean over the segment's rows of sum_g KL(post_g || prior_g);
+ * the B rows are nseg equal segments (the modalities of a step batched together; nseg = 1: one mean over all rows).
+ * bwd: gout[seg] upstream; dpp gets mix * d/d prior, dpr gets (1 - mix) * d/d posterior. pp/pr: [B][G*CLS], CLS == 32. */
+int hulc_cat_kl_fwd(const float* pp, const float* pr, int B, int G, int CLS, float beta, int nseg, float* out, float* kl_group, void* stream);
 int hulc_cat_kl_bwd(const float* pp, const float* pr, const float* kl_group, int B, int G, int CLS, float beta, float mix,
-                    const float* gout, float* dpp, float* dpr, void* stream);
+                    const float* gout, int nseg, float* dpp, float* dpr, void* stream);
 /* Straight-through one-hot sample of each of NG categorical groups (distributions.py:23-27, hulc2.py:235-237):
  * plan = one_hot(idx); idx from idx_in (injected) or inverse-CDF sampling with the counter RNG. */
 int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long long seed, const unsigned long long* seed_dev,

@@ -19,19 +19,15 @@ for db in batch.values():
 for i in range(2):
     tr.step(batch, i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     tr.step(batch, 2)
 torch.cuda.synchronize()
-want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::div", "aten::sum", "aten::clone",
-        "aten::contiguous", "aten::zeros", "aten::_to_copy", "aten::index", "aten::slice_backward", "aten::select_backward", "aten::stack", "aten::where",
-        "aten::abs", "aten::mean", "aten::neg", "aten::sub", "aten::expand", "aten::eq")
-rows = []
-for ev in prof.key_averages(group_by_stack_n=12):
-    if ev.key in want:
-        site = next((x for x in (ev.stack or []) if "hulc2_amd" in x or "bench" in x), (ev.stack or ["?"])[0])
-        rows.append((ev.count, ev.key, site.strip()[-110:]))
+want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::div", "aten::sum",
+        "aten::_to_copy", "aten::index", "aten::stack", "aten::where", "aten::mean", "aten::neg", "aten::sub", "aten::eq", "aten::index_put_",
+        "aten::slice_backward", "aten::select_backward", "aten::masked_fill_", "aten::arange", "aten::expand")
 agg = collections.Counter()
-for n, k, site in rows:
-    agg[(k, site)] += n
-for (k, site), n in sorted(agg.items(), key=lambda kv: -kv[1])[:80]:
-    print(f"{n:4d}  {k:20s} {site}")
+for ev in prof.key_averages(group_by_input_shape=True):
+    if ev.key in want:
+        agg[(ev.key, str(ev.input_shapes)[:110])] += ev.count
+for (k, shp), n in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1])):
+    print(f"{n:4d}  {k:22s} {shp}")
