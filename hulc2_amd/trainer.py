@@ -222,6 +222,8 @@ class ArenaTrainer:
                 gradsink.register(pv, gv)
         self.step_count = 0
         self.dev = dev
+        if dev.type == "cuda":
+            kn.step_state(dev)[1] = 0               # the device-resident Adam step count starts with this trainer (the RNG word keeps walking)
         self.graph_fb = self.graph_enc = self.graph_opt = None
         self.static_loss = None
         # Split point for overlapping the gradient all-reduce with the tail of backward in graph mode: the camera encoders
