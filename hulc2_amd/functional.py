@@ -329,14 +329,54 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None
 
 
+class FFNFn(torch.autograd.Function):
+    """linear1 -> ReLU -> dropout -> linear2 of the transformer layer as one fused kernel per direction (csrc/ffn_fused.hip):
+    the (tokens x 2048) hidden activation never reaches HBM, backward recomputes it.  x (T, 128) fp32 -> f (T, 128) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, drop_p: float, seed: int):
+        x2 = _c(x.reshape(-1, x.shape[-1]))
+        T, D = x2.shape
+        FF = W1.shape[0]
+        f = _f32(T, D, like=x2)
+        kn.ffn_fwd(x2, weight_operand(W1), b1, weight_operand(W2), b2, T, D, FF, drop_p, seed, f)
+        ctx.save_for_backward(x2, W1, b1, W2, b2)
+        ctx.meta = (x.shape, T, D, FF, drop_p, seed)
+        return f.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, df):
+        x2, W1, b1, W2, b2 = ctx.saved_tensors
+        shape, T, D, FF, drop_p, seed = ctx.meta
+        df2 = _c(df.reshape(T, D))
+        sinks = [gradsink.get(t) for t in (W1, b1, W2, b2)]
+        sunk = all(s is not None for s in sinks)
+        dW1, db1, dW2, db2 = sinks if sunk else (_f32(FF, D, like=df2), _f32(FF, like=df2), _f32(D, FF, like=df2), _f32(D, like=df2))
+        dx = _f32(T, D, like=df2)
+        kn.ffn_bwd(x2, df2, weight_operand(W1), b1, weight_operand(W1, "t"), weight_operand(W2, "t"), T, D, FF, drop_p, seed, dx, dW1, db1, dW2,
+                   accumulate_params=sunk)
+        kn.colsum(df2, T, D, D, db2, accumulate=sunk)
+        g = (None, None, None, None) if sunk else (dW1, db1, dW2, db2)
+        return (dx.reshape(shape), *g, None, None)
+
+
+def _ffn_fused_ok(x, W1) -> bool:
+    import os
+    return (kn.get_compute() == "bf16" and x.shape[-1] == 128 and W1.shape[0] % 128 == 0 and x.dtype == torch.float32
+            and not os.environ.get("HULC_NO_FUSED_FFN"))
+
+
 def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: float, seed: int):
     """Post-norm nn.TransformerEncoderLayer (ReLU, eps 1e-5) on tokens x (B*S, E) — plan_recognition_net.py:115-117."""
     qkv = mlp(x, [(p["in_proj_weight"], p["in_proj_bias"], False)])
     att = AttentionFn.apply(qkv, B, S, nhead, drop_p, seed + 11)
     o = mlp(att, [(p["out_proj.weight"], p["out_proj.bias"], False)])
     x = add_layer_norm(x, o, p["norm1.weight"], p["norm1.bias"], 1e-5, drop_p, seed + 12)
-    ff = mlp(x, [(p["linear1.weight"], p["linear1.bias"], True), (p["linear2.weight"], p["linear2.bias"], False)],
-             drops=[drop_p, 0.0], seed=seed + 13)
+    if _ffn_fused_ok(x, p["linear1.weight"]):
+        ff = FFNFn.apply(x, p["linear1.weight"], p["linear1.bias"], p["linear2.weight"], p["linear2.bias"], float(drop_p), int(seed + 13))
+    else:
+        ff = mlp(x, [(p["linear1.weight"], p["linear1.bias"], True), (p["linear2.weight"], p["linear2.bias"], False)],
+                 drops=[drop_p, 0.0], seed=seed + 13)
     return add_layer_norm(x, ff, p["norm2.weight"], p["norm2.bias"], 1e-5, drop_p, seed + 15)
 
 

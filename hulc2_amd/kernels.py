@@ -368,6 +368,26 @@ def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
     return (not a_kmajor) and M > 64
 
 
+def _ffn_ws(T, FF, device):
+    lib = _L.load()
+    lib.hulc_ffn_workspace.restype = _c.c_long
+    return _ws(lib.hulc_ffn_workspace(_i(T), _i(FF)), device)
+
+
+def ffn_fwd(x, W1, b1, W2, b2, T, D, FF, drop_p, seed, f):
+    """fused transformer feed-forward block (csrc/ffn_fused.hip); W1 / W2 bf16"""
+    fl = 2.0 * 2 * T * D * FF
+    _call("hulc_ffn_fwd", x, W1, b1, W2, b2, _i(T), _i(D), _i(FF), _f(drop_p), _u64(seed), _sd(x, drop_p), f, _ffn_ws(T, FF, x.device),
+          key=("ffn_fwd", T, D, FF), flops=fl, nbytes=_nbytes(x, W1, W2, f))
+
+
+def ffn_bwd(x, df, W1, b1, W1T, W2T, T, D, FF, drop_p, seed, dx, dW1, db1, dW2, accumulate_params=False, dx_accumulate=False):
+    fl = 2.0 * 5 * T * D * FF                                  # recompute + two data-gradient + two weight-gradient products
+    _call("hulc_ffn_bwd", x, df, W1, b1, W1T, W2T, _i(T), _i(D), _i(FF), _f(drop_p), _u64(seed), _sd(x, drop_p), dx, _i(dx_accumulate),
+          dW1, db1, dW2, _i(accumulate_params), _ffn_ws(T, FF, x.device),
+          key=("ffn_bwd", T, D, FF), flops=fl, nbytes=_nbytes(x, df, W1, W1T, W2T, dx, dW1, dW2))
+
+
 def repack_conv_weights(src_f32, dst_bf16, table):
     """table: int64 (n, 7) device tensor {src offset, dst offset, Cout, Cin, KH, KW, mode} (mode 0 oihw_flat, 1 ohwi, 2 ihwo)"""
     _call("hulc_repack_conv_weights", src_f32, dst_bf16, table, _i(table.shape[0]))

@@ -170,6 +170,20 @@ int hulc_tcp_to_world(const float* act, const float* robot_obs, int n, int obs_d
 int hulc_mix_sample(const hulc_mix_desc* d, const float* y, const float* u_mix, const float* u_inv, unsigned long long seed,
                     const unsigned long long* seed_dev, const float* gripper_bounds, float* act_out, long* idx_out, void* stream);
 
+/* ---- transformer feed-forward block, fused (bf16 compute) ----------------------------------------------- */
+/* f = relu(x W1^T + b1) [dropout] W2^T + b2 of nn.TransformerEncoderLayer (plan_recognition_net.py:108-117), d_model 128,
+ * dim_feedforward FF (multiple of 128); the (T x FF) hidden activation stays on chip, backward recomputes it.
+ * x, f, df, dx: (T, 128) fp32; W1 [FF][128], W2 [128][FF] bf16; W1T = W1^T [128][FF], W2T = W2^T [FF][128] bf16.
+ * Dropout: counter RNG on (seed ^ *seed_dev, token*FF + unit), the stream hulc_gemm's epilogue uses for the unfused block.
+ * bwd: dx (+)= df-path input gradient; dW1 [FF][128], db1 [FF], dW2 [128][FF] (+)= when accumulate_params (db2 = column sums of df:
+ * hulc_colsum).  ws: hulc_ffn_workspace(T, FF) bytes. */
+long hulc_ffn_workspace(int T, int FF);
+int hulc_ffn_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int D, int FF, float drop_p,
+                 unsigned long long seed, const unsigned long long* seed_dev, float* f, void* ws, void* stream);
+int hulc_ffn_bwd(const float* x, const float* df, const void* W1, const float* b1, const void* W1T, const void* W2T, int T, int D, int FF,
+                 float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx, int dx_accumulate,
+                 float* dW1, float* db1, float* dW2, int accumulate_params, void* ws, void* stream);
+
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.
  * State rows z_t = [first half | second half] (B x 2H fp32, time-major, consecutive wave steps z_step elements apart,
