@@ -83,11 +83,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     // micro-tiles: eight 16-byte loads per thread give four complete k-chunks (an in-register transpose), instead of
     // 32 scalar loads.  lane -> (k-group fastest, row group) keeps the LDS chunk writes conflict-free and each load
     // instruction a set of 256-byte row segments.  A micro-tiles go to the first threads, B micro-tiles to the next.
-    constexpr int MTA = BM / 4 * NCH, MTB = BN / 4 * NCH;
-    constexpr int MICRO_B0 = (!AK && MTA + MTB <= NT) ? MTA : 0;          // first thread of the B micro-tiles
+    // Row-major bf16 operands (the recurrent decoder's weight gradients read the bf16 state copies) use 8(k) x 8(rows) micro-tiles:
+    // eight 16-byte loads, a 16-bit 8x8 transpose with v_perm, eight 16-byte LDS chunk writes.
+    constexpr int MTA = BM / 4 * NCH, MTB = BN / 4 * NCH;                 // fp32 micro-tiles per operand tile
+    constexpr int MTA16 = BM / 8 * NCH, MTB16 = BN / 8 * NCH;             // bf16 micro-tiles
+    constexpr bool IS_BF16 = sizeof(CT) == 2;
     const bool a_micro = !AK && p.a_dtype == HULC_F32 && p.lda % 4 == 0 && ((uintptr_t)p.A % 16) == 0 && m0 + BM <= p.M && m0 % 4 == 0;
     const bool b_micro = !BK && p.b_dtype == HULC_F32 && p.ldb % 4 == 0 && ((uintptr_t)p.B % 16) == 0 && n0 + BN <= p.N && n0 % 4 == 0;
-    Chunk8 ra[AK ? A_PER : (A_PER > 4 ? A_PER : 4)], rb[BK ? B_PER : (B_PER > 4 ? B_PER : 4)];
+    const bool a_micro16 = IS_BF16 && !AK && p.a_dtype == HULC_BF16 && p.lda % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && m0 + BM <= p.M;
+    const bool b_micro16 = IS_BF16 && !BK && p.b_dtype == HULC_BF16 && p.ldb % 8 == 0 && ((uintptr_t)p.B % 16) == 0 && n0 + BN <= p.N;
+    const int a_thr = a_micro16 ? MTA16 : (a_micro ? MTA : 0), b_thr = b_micro16 ? MTB16 : (b_micro ? MTB : 0);
+    const int MICRO_B0 = (a_thr + b_thr <= NT) ? a_thr : 0;                // first thread of the B micro-tiles
+    union Stage { Chunk8 c[4]; uint4 q[8]; };                             // fp32 micro-tile (4 chunks) or bf16 micro-tile (8 raw rows)
+    union StageA { Chunk8 c[AK ? A_PER : (A_PER > 4 ? A_PER : 4)]; uint4 q[8]; } sa;
+    union StageB { Chunk8 c[BK ? B_PER : (B_PER > 4 ? B_PER : 4)]; uint4 q[8]; } sb;
+    Chunk8* const ra = sa.c; Chunk8* const rb = sb.c;
     const int nkt_all = (p.K + KT - 1) / KT;
     const int kt_per = (nkt_all + splitk - 1) / splitk;            // blockIdx.z owns k tiles [kt0, kt1)
     const int kt0 = blockIdx.z * kt_per;
@@ -108,11 +118,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             c[0].v[j] = in_k ? v.x : 0.f; c[1].v[j] = in_k ? v.y : 0.f; c[2].v[j] = in_k ? v.z : 0.f; c[3].v[j] = in_k ? v.w : 0.f;
         }
     };
-    // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (before bf16 rounding)
+    auto load_micro16 = [&](uint4* q, const void* base, long ld, int row0, int k0, int K) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in_k = k0 + j < K;
+            const uint4 v = *(const uint4*)((const uint16_t*)base + (long)(in_k ? k0 + j : 0) * ld + row0);
+            q[j].x = in_k ? v.x : 0u; q[j].y = in_k ? v.y : 0u; q[j].z = in_k ? v.z : 0u; q[j].w = in_k ? v.w : 0u;
+        }
+    };
+    // 16-bit 8x8 transpose: chunk of row i = {q[0][i], ..., q[7][i]}; one v_perm per output dword
+    auto store_micro16 = [&](char* dst_rows, const uint4* q, int ch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned sel = (i & 1) ? 0x07060302u : 0x05040100u;
+            uint4 o;
+            const unsigned* w0 = (const unsigned*)&q[0];
+#define HULC_QW(j) (((const unsigned*)&q[j])[i >> 1])
+            o.x = __builtin_amdgcn_perm(HULC_QW(1), HULC_QW(0), sel);
+            o.y = __builtin_amdgcn_perm(HULC_QW(3), HULC_QW(2), sel);
+            o.z = __builtin_amdgcn_perm(HULC_QW(5), HULC_QW(4), sel);
+            o.w = __builtin_amdgcn_perm(HULC_QW(7), HULC_QW(6), sel);
+#undef HULC_QW
+            (void)w0;
+            *(uint4*)(dst_rows + i * HULC_ROWB + ch * 16) = o;
+        }
+    };
+    // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (fp32 operands: before
+    // bf16 rounding)
     const bool do_rowsum = !AK && p.rowsum != nullptr && blockIdx.y == 0;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_tiles = [&](int kt) {
-        if (!AK && a_micro) {
+        if (!AK && a_micro16) {
+            if (tid < MTA16) {
+                load_micro16(sa.q, p.A, p.lda, m0 + (tid / NCH) * 8, kt * KT + (tid % NCH) * 8, p.K);
+                if (do_rowsum) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned w[4] = {sa.q[j].x, sa.q[j].y, sa.q[j].z, sa.q[j].w};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) rs[i] += __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
+                    }
+                }
+            }
+        } else if (!AK && a_micro) {
             if (tid < MTA) {
                 load_micro(ra, p.A, p.lda, m0 + (tid / NCH) * 4, kt * KT + (tid % NCH) * 8, p.K);
                 if (do_rowsum) {
@@ -135,7 +183,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 }
             }
         }
-        if (!BK && b_micro) {
+        if (!BK && b_micro16) {
+            const int t = tid - MICRO_B0;
+            if (t >= 0 && t < MTB16) load_micro16(sb.q, p.B, p.ldb, n0 + (t / NCH) * 8, kt * KT + (t % NCH) * 8, p.K);
+        } else if (!BK && b_micro) {
             const int t = tid - MICRO_B0;
             if (t >= 0 && t < MTB) load_micro(rb, p.B, p.ldb, n0 + (t / NCH) * 4, kt * KT + (t % NCH) * 8, p.K);
         } else
@@ -151,7 +202,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     auto store_tiles = [&](int buf) {
         char* As = smem + buf * (BM + BN) * HULC_ROWB;
         char* Bs = As + BM * HULC_ROWB;
-        if (!AK && a_micro) {
+        if (!AK && a_micro16) {
+            if (tid < MTA16) store_micro16(As + (tid / NCH) * 8 * HULC_ROWB, sa.q, tid % NCH);
+        } else if (!AK && a_micro) {
             if (tid < MTA) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(As + ((tid / NCH) * 4 + i) * HULC_ROWB + (tid % NCH) * CHB, ra[i]);
@@ -165,7 +218,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
             }
         }
-        if (!BK && b_micro) {
+        if (!BK && b_micro16) {
+            const int t = tid - MICRO_B0;
+            if (t >= 0 && t < MTB16) store_micro16(Bs + (t / NCH) * 8 * HULC_ROWB, sb.q, t % NCH);
+        } else if (!BK && b_micro) {
             const int t = tid - MICRO_B0;
             if (t >= 0 && t < MTB) {
 #pragma unroll
@@ -201,7 +257,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
         float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
         const bool acc_out = splitk == 1 && p.rowsum_accumulate;
-        if (a_micro) {
+        if (a_micro16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);
+            if (tid < MTA16 && tid % NCH == 0) {
+                const int r0 = m0 + (tid / NCH) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
+            }
+        } else if (a_micro) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);       // the NCH k-groups of a row group are adjacent lanes

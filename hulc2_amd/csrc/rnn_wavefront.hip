@@ -27,7 +27,8 @@ namespace {
 
 struct WaveP {
     float* z; long z_step;                       // fp32 state rows: wave step tau reads z + tau*z_step, writes z + (tau+1)*z_step
-    uint16_t* zb;                                // bf16 copy of the state rows, one region per wave step: [S+2][B][2H]
+    uint16_t* zb;                                // bf16 copy of the state rows, [S+2][B][2H]: region r mirrors fp32 row r of the sweep
+    int zb_row0, zb_dir;                         // region read at wave step tau = zb_row0 + tau * zb_dir (0, +1 forward; S+1, -1 reversed)
     const uint16_t *wA, *wB1, *wB2;              // first (H x H), second k < H (H x H), second k >= H (H x H)
     long ldA, ldB1, ldB2; int tA, tB1, tB2;      // t: element (n, k) is w[k*ld + n] instead of w[n*ld + k]
     const float* add1; long add1_step, ld_add1;  // per-step external term of the first half (nullable)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
             } else if (p.mask2 && second_on) omask[rep] = p.mask2[(long)tau * p.mask2_step + (long)m * p.ld_mask2 + n];
         }
         if (tau > 0) {                                       // z_0 = 0: nothing to multiply
-            const uint16_t* a = p.zb + (long)tau * p.B * ldz;
+            const uint16_t* a = p.zb + (long)(p.zb_row0 + tau * p.zb_dir) * p.B * ldz;
             // the step's 32 fragment loads are independent of the MFMAs: the scheduler keeps as many in flight as registers allow
             bf16x8_t af[2][KPW][2];
 #pragma unroll
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 
         // ---- fixed-order sum over the 8 K slices + epilogue; 1024 outputs, 2 per thread
         float* zn = p.z + (long)(tau + 1) * p.z_step;
-        uint16_t* zbn = p.zb + (long)(tau + 1) * p.B * ldz;
+        uint16_t* zbn = p.zb + (long)(p.zb_row0 + (tau + 1) * p.zb_dir) * p.B * ldz;
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
             const int o = tid + rep * 512, t4 = o >> 8, e = o & 255, ct = t4 & 1;
@@ -237,7 +238,11 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.mask1 = d->mask1; p.mask1_step = d->mask1_step; p.ld_mask1 = d->ld_mask1;
     p.mask2 = d->mask2; p.mask2_step = d->mask2_step; p.ld_mask2 = d->ld_mask2;
     p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H;
-    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
+    p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
+    // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs
+    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess ||
+        hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)
+        return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
     rnn_wavefront_kernel<2048><<<2 * (2048 / 16), 512, 0, s>>>(p);
     return hulc_check_launch("hulc_rnn_wavefront");
 }

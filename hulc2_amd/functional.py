@@ -424,9 +424,9 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     persistent = h0 is None and _rnn_persistent(B, Hd, zdt)
     if persistent:
         # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
-        kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
-                         add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
-        return zbuf, plan, emb_t, goal, True, meta
+        z16 = kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
+                               add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
+        return zbuf, plan, emb_t, goal, z16, meta
     w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
     s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
     s1.wait_stream(s0)
@@ -439,7 +439,7 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
             kn.gemm(zbuf[t + 1], w1cat, zbuf[t + 2][:, Hd:], B, Hd, 2 * Hd, 2 * Hd, 2 * Hd, 2 * Hd, bias=b_ih1, add=b_hh1, ld_add=0,
                     relu=True)
     s0.wait_stream(s1)
-    return zbuf, plan, emb_t, goal, False, meta
+    return zbuf, plan, emb_t, goal, None, meta
 
 
 @torch.no_grad()
@@ -468,10 +468,11 @@ class DecoderRNNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
-        zbuf, plan, emb_t, goal, persistent, meta = _decoder_rnn_forward(plan, emb, goal, lo, hi, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1,
-                                                                        b_ih1, b_hh1, None)
+        zbuf, plan, emb_t, goal, z16, meta = _decoder_rnn_forward(plan, emb, goal, lo, hi, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1,
+                                                                 b_ih1, b_hh1, None)
         B, S, Hd = meta[0], meta[1], meta[2]
-        ctx.persistent = persistent
+        ctx.persistent = z16 is not None
+        ctx.z16 = z16                                      # bf16 mirror of zbuf written by the persistent kernel (weight-gradient operand)
         ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
         ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)          # only their identity is needed (gradient sinks)
         ctx.meta = meta
@@ -488,10 +489,10 @@ class DecoderRNNFn(torch.autograd.Function):
         dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
         if ctx.persistent:
             # reversed sweep: wave step s reads dbuf[S+1-s] (row S+1 = 0) and writes dbuf[S-s]; weights read transposed in place
-            kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
-                             add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
-                             mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
-                             mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd)
+            d16 = kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
+                                   add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
+                                   mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
+                                   mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd)
         else:
             whh1_t = weight_operand(w_hh1, "t")
             wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
@@ -512,8 +513,15 @@ class DecoderRNNFn(torch.autograd.Function):
             s0.wait_stream(s1)
         d1 = dbuf[1:S + 1]            # rows (t, b): [delta1_t | delta0_{t+1}]
         d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
+        # operands of the big weight-gradient GEMMs: the bf16 mirrors the persistent kernels left behind (half the bytes; the MFMA
+        # rounds to bf16 while staging anyway), else the fp32 buffers
+        import os
+        use16 = ctx.persistent and not os.environ.get("HULC_RNN_WGRAD_FP32")
+        zw = ctx.z16 if use16 else zbuf
+        d1w = d16[1:S + 1] if use16 else d1
+        d0w = d16[0:S][:, :, Hd:] if use16 else d0
         M = S * B
-        fuse_b = kn.gemm_fuses_rowsum(Hd, False) and dbuf.dtype == torch.float32
+        fuse_b = kn.gemm_fuses_rowsum(Hd, False)
 
         def wgrad(dlt, inp_rows, ncols, param, bias):
             """param.grad (+)= dlt^T inp_rows, bias.grad (+)= column sums of dlt (the row sums of the GEMM's A operand, fused into
@@ -529,10 +537,10 @@ class DecoderRNNFn(torch.autograd.Function):
 
         b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
         # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}]); both biases see delta1
-        dw_ih1, db_ih1 = wgrad(d1, zbuf[1:S + 1], Hd, w_ih1, b_ih1)
-        dw_hh1, db_hh1 = wgrad(d1, zbuf[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
+        dw_ih1, db_ih1 = wgrad(d1w, zw[1:S + 1], Hd, w_ih1, b_ih1)
+        dw_hh1, db_hh1 = wgrad(d1w, zw[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
         # layer 0 (b_ih0's gradient rides on the embedding-column GEMM of dW_ih0 below)
-        dw_hh0, db_hh0 = wgrad(d0, zbuf[0:S], Hd, w_hh0, b_hh0)                     # h0_{t-1} = zbuf[t][:, :H]
+        dw_hh0, db_hh0 = wgrad(d0w, zw[0:S], Hd, w_hh0, b_hh0)                      # h0_{t-1} = zbuf[t][:, :H]
         dcs = torch.empty(B, 2 * Hd, **f32)
         dc = dcs[:, Hd:]                                                            # (B, H) strided view, ld 2H
         kn.strided_seq_sum(d0, dc, B, S, Hd, 2 * Hd, B * 2 * Hd, 2 * Hd)            # dc = sum_t delta0_t
@@ -543,7 +551,7 @@ class DecoderRNNFn(torch.autograd.Function):
         kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
         sb_ih0 = gradsink.get(b_ih0)
         db_ih0 = sb_ih0 if sb_ih0 is not None else torch.empty(Hd, **f32)
-        kn.gemm(d0, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
+        kn.gemm(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
                 rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=sb_ih0 is not None)
         if not fuse_b:
             kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=sb_ih0 is not None)

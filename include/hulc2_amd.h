@@ -193,7 +193,8 @@ int hulc_ffn_bwd(const float* x, const float* df, const void* W1, const float* b
  *     second half (written for tau >= 1, zero at tau = 0):  f2( z_tau[:, :H] wB1^T + z_tau[:, H:] wB2^T + bias2a + bias2b )
  * f = keep where mask[tau] > 0 when a mask is given (backward: stored activations), else ReLU when relu != 0.
  * Weights are bf16, element (n, k) at w[n*ld + k] (t = 0) or w[k*ld + n] (t = 1); H must be 2048, B <= 64.
- * ws: hulc_rnn_wavefront_workspace(S, B, H) bytes.  A device-wide barrier separates wave steps: the stream must not run
+ * ws: hulc_rnn_wavefront_workspace(S, B, H) bytes; after the launch ws + 256 holds a bf16 mirror of the S+2 state rows (row r of
+ * the buffer the sweep walks, in buffer order for both directions) — the operands of the weight-gradient GEMMs at half the bytes.  A device-wide barrier separates wave steps: the stream must not run
  * another kernel concurrently; a barrier timeout writes NaN into the last state row instead of hanging. */
 typedef struct hulc_rnn_wave_desc {
     float* z; long z_step;

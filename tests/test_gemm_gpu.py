@@ -164,3 +164,27 @@ def test_gemm_fused_rowsum(dev, M, N, K, accumulate):
     kn.gemm(A, B, C, M, N, K, M, N, N, a_kmajor=False, b_kmajor=False, rowsum=rs2, rowsum_accumulate=accumulate)
     torch.cuda.synchronize()
     assert torch.equal(rs, rs2), "fixed summation order"
+
+
+@pytest.mark.parametrize("M,N,K,a16,b16", [(2048, 2048, 2048, True, True), (256, 128, 520, True, True), (128, 384, 96, True, False),
+                                           (256, 128, 64, False, True), (200, 136, 72, True, True)])
+def test_gemm_row_major_bf16_operands(dev, M, N, K, a16, b16):
+    """dW = dY^T X with bf16 row-major operands (the recurrent decoder reads the bf16 state copies): 8x8 micro-tile staging with
+    an in-register 16-bit transpose; ragged shapes take the scalar path.  Exact against float64 on the same bf16 values."""
+    from hulc2_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(K, M, generator=g).to(dev)
+    B = torch.randn(K, N, generator=g).to(dev)
+    A = A.to(torch.bfloat16) if a16 else A
+    B = B.to(torch.bfloat16) if b16 else B
+    C = torch.zeros(M, N, device=dev)
+    rs = torch.zeros(M, device=dev)
+    kn.gemm(A, B, C, M, N, K, M, N, N, a_kmajor=False, b_kmajor=False, rowsum=rs if M > 64 else None)
+    torch.cuda.synchronize()
+    ref = A.to(torch.bfloat16).double().t() @ B.to(torch.bfloat16).double()
+    err = (C.double() - ref).abs().max().item()
+    assert err < 1e-5 * K ** 0.5 * ref.abs().max().item() / max(K ** 0.5, 1) + 2e-3, f"max err {err:.3e}"
+    if M > 64:
+        want = A.double().sum(0)
+        assert (rs.double() - want).abs().max().item() < 1e-4 * K ** 0.5 + 1e-4
