@@ -30,10 +30,11 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             const long* cls_wtap, hipStream_t s);
 // LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, hipStream_t s);
+                             int N, int H, int W, int u8, int pad, const int* shift, hipStream_t s);
 // LDS-band weight gradient (conv_wgrad_band.hip): same return convention
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
-                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s);
+                                  int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
+                                  const int* shift, hipStream_t s);
 
 namespace {
 
@@ -459,11 +460,14 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
     }
-    if (d->compute == HULC_BF16 && d->x_nchw && d->x_dtype == HULC_F32 && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 && d->stride == 4) {
-        rc = hulc_conv1_band_dispatch((const float*)x, w, d->w_dtype, g.ldw, bias, y, d->y_dtype, d->relu, d->N, d->H, d->W, (hipStream_t)stream);
+    if (d->compute == HULC_BF16 && d->x_nchw && (d->x_dtype == HULC_F32 || d->x_u8_nhwc) && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 &&
+        d->stride == 4) {
+        rc = hulc_conv1_band_dispatch((const float*)x, w, d->w_dtype, g.ldw, bias, y, d->y_dtype, d->relu, d->N, d->H, d->W, d->x_u8_nhwc, d->aug_pad,
+                                      d->aug_shift, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(conv1 band)");
     }
+    if (d->x_u8_nhwc) return hulc_fail(-6, "hulc_conv2d_fwd: uint8 frames are consumed by the conv1 band kernel only (bf16 compute, 3 -> 32, 8x8 stride 4, W % 4 == 0)");
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_fwd");
 }
@@ -565,10 +569,12 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
     if (d->compute == HULC_BF16) {                           // LDS-band kernel (conv_wgrad_band.hip) for the geometries it covers
         const long wsb = hulc_conv2d_bwd_weight_workspace(d);
         const int brc = hulc_conv_wgrad_band_dispatch(d->x_nchw, d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, dy, d->y_dtype,
-                                                      d->N, d->H, d->W, dw, db, ws, wsb, d->dw_oihw, d->dw_accumulate, (hipStream_t)stream);
+                                                      d->N, d->H, d->W, dw, db, ws, wsb, d->dw_oihw, d->dw_accumulate, d->x_u8_nhwc, d->aug_pad,
+                                                      d->aug_shift, (hipStream_t)stream);
         if (brc < 0) return brc;
         if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_weight(band)");
     }
+    if (d->x_u8_nhwc) return hulc_fail(-6, "hulc_conv2d_bwd_weight: uint8 frames are consumed by the conv1 band kernel only");
     WgradP p; fill_gather(p.g, d);
     p.g.X = x; p.g.Wt = nullptr; p.g.bias = nullptr; p.g.Y = nullptr; p.g.mask = nullptr;
     p.dY = dy; p.dy_dtype = d->y_dtype;

@@ -84,6 +84,12 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _require_contiguous(**ts) -> None:
+    for name, t in ts.items():
+        if t is not None and not t.is_contiguous():
+            raise _L.HulcKernelError(f"{name} must be contiguous (the kernels take dense layouts; got strides {tuple(t.stride())})")
+
+
 def _require_cuda(*ts) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -191,10 +197,23 @@ def conv_out_hw(H, W, KH, KW, stride):
     return (H - KH) // stride + 1, (W - KW) // stride + 1
 
 
-def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None):
-    """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc)."""
-    _require_cuda(x, w2d, bias, y)
-    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(y), _dt(w2d), relu, compute)
+def _u8_frames(d, x, aug_shift, aug_pad):
+    """conv1 fed by uint8 NHWC frames: shift / scale / normalise happen while the kernel stages the band"""
+    if x.dtype != torch.uint8:
+        return
+    if aug_shift is not None and (aug_shift.dtype != torch.int32 or not aug_shift.is_contiguous() or aug_shift.numel() != 2 * d.N):
+        raise TypeError("aug_shift must be a contiguous int32 (N, 2) tensor of {sx, sy}")
+    d.x_u8_nhwc, d.aug_pad = 1, int(aug_pad)
+    d.aug_shift = aug_shift.data_ptr() if aug_shift is not None else None
+
+
+def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0):
+    """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
+    for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
+    _require_cuda(x, w2d, bias, y, aug_shift)
+    _require_contiguous(x=x, w2d=w2d, y=y)
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
+    _u8_frames(d, x, aug_shift, aug_pad)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
     macs = float(N) * oh * ow * Cout * Cin * KH * KW
     with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
@@ -215,14 +234,17 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
     return dx
 
 
-def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None, dw_oihw=False, accumulate=False):
+def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None, dw_oihw=False, accumulate=False,
+                      aug_shift=None, aug_pad=0):
     """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC).  dw_oihw: dw in the parameter's OIHW order (else the forward k order);
     accumulate: add into dw / db (gradient arena sinks)."""
     _require_cuda(x, dy, dw, db)
+    _require_contiguous(x=x, dy=dy, dw=dw)
     lib = _L.load()
     lib.hulc_conv2d_bwd_weight_workspace.restype = ctypes.c_long
-    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, _dt(x), _dt(dy), F32, False, compute)
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(dy), F32, False, compute)
     d.dw_oihw, d.dw_accumulate = int(dw_oihw), int(accumulate)
+    _u8_frames(d, x, aug_shift, aug_pad)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)

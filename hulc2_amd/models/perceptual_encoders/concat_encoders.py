@@ -30,6 +30,20 @@ class ConcatEncoders(nn.Module):
         self.state_decoder = None
         self.current_visual_embedding = None
         self.current_state_obs = None
+        # RandomShiftsAug pads of conf/datamodule/transforms/rand_shift.yaml:5,12 — used only when uint8 frames arrive together with
+        # per-frame shifts (the stored uint8 NHWC frames go straight into conv1)
+        self.aug_pad = {"rgb_static": 10, "rgb_gripper": 4}
+
+    @staticmethod
+    def _frames(imgs, key):
+        """-> (frames flattened over (B, S), shifts flattened or None, B, S).  fp32 (B,S,3,H,W) in [-1,1] as the reference's transforms
+        deliver them, or uint8 (B,S,H,W,3) as stored (+ optional imgs[key + "_shift"] (B,S,2) int32 {sx, sy})."""
+        x = imgs[key]
+        b, s = x.shape[0], x.shape[1]
+        if x.dtype == torch.uint8:
+            sh = imgs.get(key + "_shift")
+            return x.reshape(b * s, *x.shape[2:]), (None if sh is None else sh.reshape(b * s, 2)), b, s
+        return x.reshape(b * s, *x.shape[2:]), None, b, s
 
     @property
     def latent_size(self):
@@ -38,13 +52,11 @@ class ConcatEncoders(nn.Module):
     def forward(self, imgs: Dict[str, torch.Tensor], depth_imgs: Dict[str, torch.Tensor], state_obs: torch.Tensor) -> torch.Tensor:
         if isinstance(imgs, (list, tuple)):             # several modalities at once (Hulc2.training_step): see forward_multi
             return self.forward_multi(imgs)
-        rgb_static = imgs["rgb_static"]
-        b, s, c, h, w = rgb_static.shape
-        enc = self.rgb_static_encoder(rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
+        x, sh, b, s = self._frames(imgs, "rgb_static")
+        enc = self.rgb_static_encoder(x, sh, self.aug_pad["rgb_static"]).reshape(b, s, -1)
         if "rgb_gripper" in imgs and self.rgb_gripper_encoder is not None:
-            g = imgs["rgb_gripper"]
-            b, s, c, h, w = g.shape
-            enc = torch.cat([enc, self.rgb_gripper_encoder(g.reshape(-1, c, h, w)).reshape(b, s, -1)], dim=-1)
+            x, sh, b, s = self._frames(imgs, "rgb_gripper")
+            enc = torch.cat([enc, self.rgb_gripper_encoder(x, sh, self.aug_pad["rgb_gripper"]).reshape(b, s, -1)], dim=-1)
         self.current_visual_embedding = enc.detach()   # detached: holding the graph across steps breaks HIP-graph capture
         self.current_state_obs = state_obs
         return enc
@@ -52,12 +64,12 @@ class ConcatEncoders(nn.Module):
     def forward_multi(self, imgs_list) -> torch.Tensor:
         """Several observation dicts of identical shapes (the modalities of one training step) through the shared encoders
         in one pass: rows of the result are modality-major, (sum B, S, latent).  Same arithmetic per frame as `forward`."""
-        st = [im["rgb_static"] for im in imgs_list]
-        b, s, c, h, w = st[0].shape
-        enc = self.rgb_static_encoder([x.reshape(-1, c, h, w) for x in st]).reshape(len(st) * b, s, -1)
+        fr = [self._frames(im, "rgb_static") for im in imgs_list]
+        b, s = fr[0][2], fr[0][3]
+        enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"]).reshape(len(fr) * b, s, -1)
         if self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list):
-            gr = [im["rgb_gripper"] for im in imgs_list]
-            _, _, c, h, w = gr[0].shape
-            enc = torch.cat([enc, self.rgb_gripper_encoder([x.reshape(-1, c, h, w) for x in gr]).reshape(len(gr) * b, s, -1)], dim=-1)
+            fr = [self._frames(im, "rgb_gripper") for im in imgs_list]
+            enc = torch.cat([enc, self.rgb_gripper_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_gripper"]).reshape(len(fr) * b, s, -1)],
+                            dim=-1)
         self.current_visual_embedding = enc.detach()
         return enc

@@ -69,6 +69,13 @@ typedef struct {
     int compute;
     int dw_oihw;        /* bwd_weight only: write dW in the parameter's OIHW order instead of the forward k order (NHWC layers) */
     int dw_accumulate;  /* bwd_weight only: dW and db are added to the destination (gradient arena) instead of overwriting it */
+    /* conv1 fed by the frames as stored: x is uint8 NHWC [N][H][W][3]; the kernel applies, while staging,
+     * RandomShiftsAug (hulc2/utils/transforms.py:85-106: replicate-pad by aug_pad, integer shift aug_shift[n] = {sx, sy} in
+     * [0, 2*aug_pad]; NULL = no shift), ScaleImageTensor (/255, :8-19) and Normalize(0.5, 0.5) (conf/datamodule/transforms/
+     * rand_shift.yaml:7-10): value = (u8[clamp(y+sy-pad)][clamp(x+sx-pad)][c] / 255 - 0.5) / 0.5.  x_nchw must be 1 (k = (c,kh,kw)). */
+    int x_u8_nhwc;
+    int aug_pad;
+    const int* aug_shift;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

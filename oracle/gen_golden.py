@@ -391,6 +391,30 @@ def gen_step(m, dist, flat, B, S):
          grad_names=np.array(names), grad_norms=np.array(norms), ck=ck, cv=cv, torch_version=torch.__version__, **res, **slices)
 
 
+def gen_transforms():
+    """the reference's own RandomShiftsAug / ScaleImageTensor on uint8 frames (hulc2/utils/transforms.py); torchvision (absent here)
+    is only imported at module level there, so a name-only stub lets the file load — Normalize(0.5, 0.5) is restated as (x-0.5)/0.5."""
+    import importlib.util, types
+    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv); sys.modules.setdefault("torchvision.transforms", tvt)
+    spec = importlib.util.spec_from_file_location("_ref_transforms", REF / "hulc2" / "utils" / "transforms.py")
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    for tag, hw, pad, n in (("static", 200, 10, 2), ("gripper", 84, 4, 3)):
+        u8 = torch.randint(0, 256, (n, hw, hw, 3), generator=g(SEED, f"x.tf.{tag}"), dtype=torch.uint8)
+        x = u8.permute(0, 3, 1, 2)                                     # process_rgb: channels first
+        torch.manual_seed(77)
+        aug = T.RandomShiftsAug(pad)(x)
+        torch.manual_seed(77)
+        shift = torch.randint(0, 2 * pad + 1, size=(n, 1, 1, 2), dtype=torch.float32).reshape(n, 2).to(torch.int32)
+        y = T.ScaleImageTensor()(aug)
+        y = (y - 0.5) / 0.5                                            # torchvision.transforms.Normalize(mean=[0.5], std=[0.5])
+        val = (T.ScaleImageTensor()(x) - 0.5) / 0.5                    # validation pipeline: no shift
+        save(f"transforms_{tag}", seed=SEED, pad=pad, frames_u8=u8.numpy(), shift=shift.numpy(), train=y[:, :, ::3, ::3], val=val[:, :, ::3, ::3],
+             train_sum=y.double().sum(), val_sum=val.double().sum())
+
+
 def gen_inference(m, dist, flat):
     """validation / rollout pieces: decoder forward with a carried hidden state, LogisticDecoderRNN._sample
     and loss_and_act with the torch.rand draws recorded, and the lmp_val composition of hulc2.py:247-334 on the leaf modules."""
@@ -456,6 +480,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "inference":      # only the f-1 fixtures (the others are unchanged)
         gen_inference(m, dist, flat)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "transforms":     # only the f-2 fixtures
+        gen_transforms()
+        return
     gen_vision(m, flat)
     gen_goal_and_proposal(m, flat)
     gen_plan_recognition(m, flat)
@@ -465,6 +492,7 @@ def main():
     gen_step(m, dist, flat, 2, 16)
     gen_step(m, dist, flat, 2, 32)
     gen_inference(m, dist, flat)
+    gen_transforms()
 
 
 if __name__ == "__main__":

@@ -323,6 +323,34 @@ def tcp_to_world_frame(action: torch.Tensor, robot_obs: torch.Tensor) -> torch.T
 
 
 # ------------------------------------------------------------------------------------------------
+# input transforms of the training data pipeline: conf/datamodule/transforms/rand_shift.yaml:1-17
+# ------------------------------------------------------------------------------------------------
+def random_shifts_aug(x: torch.Tensor, pad: int, shift: torch.Tensor) -> torch.Tensor:
+    """RandomShiftsAug.forward, hulc2/utils/transforms.py:85-106, with the torch.randint draw passed in: shift (n, 2) integers
+    {sx, sy} in [0, 2*pad].  x (n, c, h, w), h == w."""
+    x = x.float()
+    n, c, h, w = x.size()
+    assert h == w
+    x = F.pad(x, (pad,) * 4, "replicate")
+    eps = 1.0 / (h + 2 * pad)
+    arange = torch.linspace(-1.0 + eps, 1.0 - eps, h + 2 * pad, dtype=x.dtype)[:h]
+    arange = arange.unsqueeze(0).repeat(h, 1).unsqueeze(2)
+    base_grid = torch.cat([arange, arange.transpose(1, 0)], dim=2).unsqueeze(0).repeat(n, 1, 1, 1)
+    sh = shift.reshape(n, 1, 1, 2).to(x.dtype) * (2.0 / (h + 2 * pad))
+    return F.grid_sample(x, base_grid + sh, padding_mode="zeros", align_corners=False)
+
+
+def frames_u8_to_input(frames_u8_nhwc: torch.Tensor, pad: int = 0, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stored uint8 (n, h, w, 3) frames -> the fp32 (n, 3, h, w) tensor in [-1, 1] the model sees: channels first
+    (hulc2/datasets/utils/episode_utils.py process_rgb), RandomShiftsAug (train only), ScaleImageTensor (transforms.py:8-19),
+    torchvision Normalize(mean 0.5, std 0.5) = (x - 0.5) / 0.5."""
+    x = frames_u8_nhwc.permute(0, 3, 1, 2)
+    x = random_shifts_aug(x, pad, shift) if shift is not None else x.float()
+    x = x.float().div(255)
+    return ((x - 0.5) / 0.5).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
 # CLIP-style auxiliary loss
 # ------------------------------------------------------------------------------------------------
 def clip_auxiliary_loss(sd: SD, seq_feat: torch.Tensor, goal: torch.Tensor, use: Optional[torch.Tensor]) -> torch.Tensor:

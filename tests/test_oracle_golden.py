@@ -344,3 +344,25 @@ def test_tcp_world_round_trip():
     obs[..., 3:6] = (torch.rand(3, 7, 3, generator=g) - 0.5) * 3.0
     back = O.tcp_to_world_frame(O.world_to_tcp_frame(a, obs), obs)
     assert (back - a).abs().max().item() < 2e-4
+
+
+# ---- input transforms -------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["static", "gripper"])
+def test_input_transforms(tag):
+    """uint8 NHWC frames -> model input: the reference's RandomShiftsAug (recorded torch.randint draw) + ScaleImageTensor + Normalize;
+    shifts are integers and must select exactly the pixels an integer crop of the replicate-padded frame selects (to grid_sample's
+    interpolation rounding)"""
+    fx = load(f"transforms_{tag}")
+    u8, shift, pad = torch.tensor(fx["frames_u8"]), torch.tensor(fx["shift"]), int(fx["pad"])
+    train = O.frames_u8_to_input(u8, pad, shift)
+    val = O.frames_u8_to_input(u8)
+    close(train[:, :, ::3, ::3], fx["train"], 1e-6, "train transform")
+    close(val[:, :, ::3, ::3], fx["val"], 1e-7, "val transform")
+    assert abs(float(train.double().sum()) - float(fx["train_sum"])) < 1e-3 and abs(float(val.double().sum()) - float(fx["val_sum"])) < 1e-6
+    n, h = u8.shape[0], u8.shape[1]
+    idx = torch.arange(h)
+    for i in range(n):                                      # integer-crop form used by the HIP kernels
+        sx, sy = int(shift[i, 0]), int(shift[i, 1])
+        yy, xx = (idx + sy - pad).clamp(0, h - 1), (idx + sx - pad).clamp(0, h - 1)
+        crop = (u8[i].permute(2, 0, 1).float()[:, yy][:, :, xx] / 255 - 0.5) / 0.5
+        assert (crop - train[i]).abs().max().item() < 1e-4, "grid_sample with integer shifts == integer crop (to interpolation rounding)"
