@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel time table to stderr")
+    ap.add_argument("--uint8-frames", action="store_true",
+                    help="feed uint8 NHWC frames + shift-augmentation offsets (SURVEY 8 row f-2) instead of transformed fp32 frames; "
+                         "a separate data format, not the headline configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,6 +122,14 @@ def main():
     batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev)
     for db in batch.values():
         db.pop("plan_idx", None)                            # benchmark samples the latent plan on-device
+    if args.uint8_frames:
+        g = torch.Generator().manual_seed(1234 + rank)
+        for db in batch.values():
+            obs = {}
+            for key, hw, pad in (("rgb_static", 200, 10), ("rgb_gripper", 84, 4)):
+                obs[key] = torch.randint(0, 256, (args.batch, args.seq_len, hw, hw, 3), generator=g, dtype=torch.uint8).to(dev)
+                obs[key + "_shift"] = torch.randint(0, 2 * pad + 1, (args.batch, args.seq_len, 2), generator=g, dtype=torch.int32).to(dev)
+            db["rgb_obs"] = obs
 
     def sync():
         if world > 1:
@@ -188,6 +199,8 @@ def main():
                                "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on",
                    "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
+                   "frames": "uint8 NHWC + RandomShiftsAug offsets, scaled/normalised while staging conv1" if args.uint8_frames
+                             else "fp32 NCHW, already transformed (the reference's dataloader output)",
                    "final_loss": round(final_loss, 4)},
         "roofline": {**rl, "kernel": "/".join(str(k) for k in dom_key),
                      "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_flops_per_launch": dom_flops,

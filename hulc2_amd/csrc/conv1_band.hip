@@ -11,6 +11,7 @@
 // (c, kh pair) is the 8 contiguous kw of the patch row — two aligned ds_read_b64, conflict-free across the 32 pixels.
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include "u8_frames.h"
 #include <stdlib.h>
 
 namespace {
@@ -22,23 +23,6 @@ struct C1P {
     long ldw;
     int u8, pad; const int* shift;     // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
 };
-
-// 8 consecutive band elements of channel c (flat index e0 over rows x W) from the uint8 NHWC frame: shift, clamp, scale, normalise
-HULC_DEVICE uint4 u8_band_chunk(const unsigned char* img, int H, int W, int c, int row0, int e0, int nflt, int sx, int sy, int pad) {
-    int rr = e0 / W, x = e0 - rr * W;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int yy = row0 + rr + sy - pad, xx = x + sx - pad;
-        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-        xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-        const float b = (float)img[((long)yy * W + xx) * 3 + c];
-        v[i] = e0 + i < nflt ? (b / 255.0f - 0.5f) / 0.5f : 0.f;
-        if (++x == W) { x = 0; ++rr; }
-    }
-    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-}
-
 
 template <int XCH>
 __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
@@ -70,15 +54,22 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     auto stage_load = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
+        if (p.u8) {                                        // uint8 NHWC frames: one chunk = 8 elements of all three planes
+            const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
+            const unsigned char* img = (const unsigned char*)p.X + (long)n * p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < XCH / C; ++i) {
+                const int id = tid + i * NT;
+                const bool inb = id < items;
+                u8_band_chunk3(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad,
+                               xpre[i], xpre[XCH / C + i], xpre[2 * (XCH / C) + i]);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
-            if (p.u8) {
-                const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-                xpre[j] = u8_band_chunk((const unsigned char*)p.X + (long)n * p.H * p.W * 3, p.H, p.W, c, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx, sy, p.pad);
-                continue;
-            }
             const long base = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W;
             const long off = base + (inb ? (long)id * 8 : 0);
             const float4 a = *(const float4*)((const float*)p.X + off);
@@ -177,7 +168,7 @@ int launch_conv1(C1P& p, hipStream_t s) {
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
                              int N, int H, int W, int u8, int pad, const int* shift, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
-    if (W % 4 || (!u8 && ((uintptr_t)x % 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
+    if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
     C1P p;
     p.u8 = u8; p.pad = pad; p.shift = shift;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;

@@ -18,6 +18,7 @@
 //   * the next unit's bands are prefetched into registers during the MFMA loop (single LDS buffer).
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include "u8_frames.h"
 #include <stdlib.h>
 
 namespace {
@@ -32,21 +33,6 @@ struct WBandP {
     float* partial_b;                 // [grid][Cout]
     int u8, pad; const int* shift;    // conv1 fed by uint8 NHWC frames: shift / scale / normalise applied while staging (see conv1_band.hip)
 };
-
-HULC_DEVICE uint4 u8_band_chunk_w(const unsigned char* img, int H, int W, int c, int row0, int e0, int nflt, int sx, int sy, int pad) {
-    int rr = e0 / W, x = e0 - rr * W;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int yy = row0 + rr + sy - pad, xx = x + sx - pad;
-        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-        xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-        const float b = (float)img[((long)yy * W + xx) * 3 + c];
-        v[i] = e0 + i < nflt ? (b / 255.0f - 0.5f) / 0.5f : 0.f;
-        if (++x == W) { x = 0; ++rr; }
-    }
-    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-}
 
 // C: input channels, CT: Cout / 32, TH x TW taps, S stride, NCHW: conv1 layout (k = (c, kh, kw), fp32 planes)
 template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC>
@@ -117,16 +103,21 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             // full-width bands: the band rows of one channel plane are contiguous in memory -> flat copy, item = 8 floats
             // (32 contiguous bytes per lane, every lane active: measured 1.3 - 1.7x faster than per-row maps)
             const int nflt = rows * p.W, items = (nflt + 7) / 8;
+            if (C == 3 && p.u8) {                          // uint8 NHWC frames: one chunk = 8 elements of all three planes
+                const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
+                const unsigned char* img = (const unsigned char*)p.X + (long)n * p.H * p.W * 3;
+#pragma unroll
+                for (int i = 0; i < XCH / 3; ++i) {
+                    const int id = tid + i * NT;
+                    const bool inb = id < items;
+                    u8_band_chunk3(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad,
+                                   xpre[i], xpre[(XCH / 3 + i) % XCH], xpre[(2 * (XCH / 3) + i) % XCH]);
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
                 const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
                 const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
-                if (p.u8) {
-                    const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-                    xpre[j] = u8_band_chunk_w((const unsigned char*)p.X + (long)n * p.H * p.W * 3, p.H, p.W, c, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx, sy,
-                                              p.pad);
-                    continue;
-                }
                 const long base = (long)n * p.x_sn + (long)c * p.x_sc + (long)(r0 * S) * p.x_sy;
                 const long off = base + (inb ? (long)id * 8 : 0);
                 const float4 a = *(const float4*)((const float*)p.X + off);
@@ -370,7 +361,7 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     int rc = 1;
     if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1) rc = launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2) rc = launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
-    else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || u8))
+    else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0)))
         rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else return 1;
     if (rc == -1) return 1;

@@ -1,0 +1,66 @@
+// u8_frames.h — staging of uint8 NHWC camera frames for the conv1 band kernels.
+//
+// reference arithmetic folded into the load: RandomShiftsAug (replicate-pad by `pad`, integer crop at (sx, sy)),
+// ScaleImageTensor (x / 255) and Normalize(0.5, 0.5) — hulc2/utils/transforms.py:8-19, 104-138.
+//
+// A thread turns 8 consecutive band elements (flat index over band rows x W) of ALL THREE channels into three uint4 of
+// bf16 plane data.  Each 4-pixel half reads its 12 source bytes as (at most) four aligned dwords of one source row — the
+// row clamp is one v_med3 per half, the column clamp only moves the 4-pixel window, realigned with v_alignbyte — instead of
+// 24 single-byte loads.  Halves whose window was clamped (the replicated border columns) pick their pixels with selects.
+//
+// (b / 255 - 0.5) / 0.5 is evaluated as fma(b, 2/255, -1): for all 256 byte values the two round to the same bf16 (checked
+// exhaustively, tests/test_oracle_golden.py::test_u8_normalise_fma_is_bf16_exact), and bf16 is what the bands hold.
+#pragma once
+#include "hulc_common.h"
+
+HULC_DEVICE void u8_half4(const unsigned char* img, int H, int W, int row, int x, int dx, int dy, bool live, uint32_t (&o)[3][2]) {
+    int yy = row + dy;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    const int xx0 = x + dx;
+    const int pw = xx0 < 0 ? 0 : (xx0 > W - 4 ? W - 4 : xx0);        // first pixel of the 4-pixel source window
+    const int d = xx0 - pw;                                           // != 0: some of the 4 elements are replicated border pixels
+    const int b0 = (yy * W + pw) * 3;                                 // < 2^31 for any camera frame
+    const int sh = b0 & 3;
+    const uint32_t* q = (const uint32_t*)(img + (b0 - sh));
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (live) { w0 = q[0]; w1 = q[1]; w2 = q[2]; if (sh) w3 = q[3]; }  // the fourth dword is only needed (and only in bounds) when sh > 0
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(w1, w0, sh), e1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
+                   e2 = __builtin_amdgcn_alignbyte(w3, w2, sh);       // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    float f[4][3];
+    f[0][0] = (float)(e0 & 0xff);         f[0][1] = (float)((e0 >> 8) & 0xff);  f[0][2] = (float)((e0 >> 16) & 0xff);
+    f[1][0] = (float)(e0 >> 24);          f[1][1] = (float)(e1 & 0xff);         f[1][2] = (float)((e1 >> 8) & 0xff);
+    f[2][0] = (float)((e1 >> 16) & 0xff); f[2][1] = (float)(e1 >> 24);          f[2][2] = (float)(e2 & 0xff);
+    f[3][0] = (float)((e2 >> 8) & 0xff);  f[3][1] = (float)((e2 >> 16) & 0xff); f[3][2] = (float)(e2 >> 24);
+    if (d != 0) {                                                     // element i <- window pixel clamp(i + d, 0, 3)
+        float g[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int j = i + d; j = j < 0 ? 0 : (j > 3 ? 3 : j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[i][c] = j == 0 ? f[0][c] : (j == 1 ? f[1][c] : (j == 2 ? f[2][c] : f[3][c]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[i][c] = g[i][c];
+    }
+    const float k = 2.0f / 255.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v0 = live ? __builtin_fmaf(f[0][c], k, -1.f) : 0.f, v1 = live ? __builtin_fmaf(f[1][c], k, -1.f) : 0.f;
+        const float v2 = live ? __builtin_fmaf(f[2][c], k, -1.f) : 0.f, v3 = live ? __builtin_fmaf(f[3][c], k, -1.f) : 0.f;
+        o[c][0] = pack_bf16x2(v0, v1); o[c][1] = pack_bf16x2(v2, v3);
+    }
+}
+
+// 8 band elements starting at flat index e0 (multiple of 8; W % 4 == 0 so a half never straddles a row); elements >= nflt are zero.
+HULC_DEVICE void u8_band_chunk3(const unsigned char* img, int H, int W, int row0, int e0, int nflt, int dx, int dy, uint4& p0, uint4& p1, uint4& p2) {
+    const int rr = e0 / W, x = e0 - rr * W;
+    const bool wrap = x + 4 >= W;
+    uint32_t a[3][2], b[3][2];
+    u8_half4(img, H, W, row0 + rr, x, dx, dy, e0 < nflt, a);
+    u8_half4(img, H, W, row0 + rr + (wrap ? 1 : 0), wrap ? 0 : x + 4, dx, dy, e0 + 4 < nflt, b);
+    p0 = make_uint4(a[0][0], a[0][1], b[0][0], b[0][1]);
+    p1 = make_uint4(a[1][0], a[1][1], b[1][0], b[1][1]);
+    p2 = make_uint4(a[2][0], a[2][1], b[2][0], b[2][1]);
+}

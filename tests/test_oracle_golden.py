@@ -366,3 +366,17 @@ def test_input_transforms(tag):
         yy, xx = (idx + sy - pad).clamp(0, h - 1), (idx + sx - pad).clamp(0, h - 1)
         crop = (u8[i].permute(2, 0, 1).float()[:, yy][:, :, xx] / 255 - 0.5) / 0.5
         assert (crop - train[i]).abs().max().item() < 1e-4, "grid_sample with integer shifts == integer crop (to interpolation rounding)"
+
+
+def test_u8_normalise_fma_is_bf16_exact():
+    """the kernels stage uint8 frames as bf16(fma(b, 2/255, -1)); the reference computes (b/255 - 0.5)/0.5 in fp32
+    (hulc2/utils/transforms.py:8-19 ScaleImageTensor + torchvision Normalize(0.5, 0.5)).  Identical bf16 for all 256 bytes."""
+    b = np.arange(256, dtype=np.float32)
+    exact = ((b / np.float32(255.0)) - np.float32(0.5)) / np.float32(0.5)
+    fma = (b.astype(np.float64) * np.float64(np.float32(2.0 / 255.0)) - 1.0).astype(np.float32)   # one rounding, as v_fma_f32
+
+    def bf16(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+
+    assert np.array_equal(bf16(exact), bf16(fma))
