@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--uint8-frames", action="store_true",
                     help="feed uint8 NHWC frames + shift-augmentation offsets (SURVEY 8 row f-2) instead of transformed fp32 frames; "
                          "a separate data format, not the headline configuration")
+    ap.add_argument("--episode-store", action="store_true",
+                    help="row f-2 end to end: an HBM-resident uint8 episode store per modality, every step draws new play windows "
+                         "(index rows, pad-by-repetition, shifts) and conv1 reads the store in place; separate from the headline configuration")
+    ap.add_argument("--store-frames", type=int, default=16384, help="frames in the synthetic episode store (141 KB each)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +135,34 @@ def main():
                 obs[key + "_shift"] = torch.randint(0, 2 * pad + 1, (args.batch, args.seq_len, 2), generator=g, dtype=torch.int32).to(dev)
             db["rgb_obs"] = obs
 
+    stores, draw = None, None
+    if args.episode_store:
+        import numpy as np
+        from hulc2_amd.datasets import DeviceEpisodeStore
+        g = torch.Generator().manual_seed(99 + rank)
+        n = args.store_frames
+        rgb = {"rgb_static": torch.randint(0, 256, (n, 200, 200, 3), generator=g, dtype=torch.uint8).to(dev),
+               "rgb_gripper": torch.randint(0, 256, (n, 84, 84, 3), generator=g, dtype=torch.uint8).to(dev)}
+        act = torch.rand(n, 7, generator=g) * 2 - 1
+        act[:, 6] = torch.where(act[:, 6] > 0, 1.0, -1.0)
+        obs = torch.randn(n, 15, generator=g)
+        obs[:, 3:6] = (torch.rand(n, 3, generator=g) * 2 - 1) * 3.14159 * 0.5
+        eps = [(a, min(a + 511, n - 1)) for a in range(0, n, 512)]           # 512-frame play episodes
+        lang_emb = torch.randn(64, 384, generator=g) * 0.05
+        # vision windows 20..32 (conf/datamodule/datasets/vision_dataset/vision_shm.yaml:5-6), language windows fixed at 32
+        stores = {"vis": DeviceEpisodeStore(rgb, act, obs, eps, 20, 32, device=dev, seed=rank)}
+        n_lang = len(DeviceEpisodeStore(rgb, act, obs, eps, 32, 32, device=dev))
+        stores["lang"] = DeviceEpisodeStore(stores["vis"].rgb, act, obs, eps, 32, 32, device=dev, seed=rank, lang_emb=lang_emb,
+                                            lang_lookup=np.random.RandomState(rank).randint(0, 64, n_lang))
+        sampler = np.random.RandomState(1000 + rank)
+
+        def draw():
+            for mod, st in stores.items():
+                fresh = st.batch(sampler.randint(0, len(st), args.batch))
+                fresh.pop("window_sizes")
+                batch[mod] = fresh                                            # same device buffers every step: graph replay sees the new windows
+        draw()
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -146,6 +178,12 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
     run_step = (lambda i: trainer.replay()) if use_graph else (lambda i: trainer.step(batch, i))
+    if draw is not None:
+        inner = run_step
+
+        def run_step(i):
+            draw()
+            return inner(i)
     for i in range(args.warmup):
         loss = run_step(i)
     sync()
@@ -199,7 +237,9 @@ def main():
                                "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on",
                    "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
-                   "frames": "uint8 NHWC + RandomShiftsAug offsets, scaled/normalised while staging conv1" if args.uint8_frames
+                   "frames": "HBM-resident uint8 episode store, new play windows (20..32 steps, padded by repetition) every step, conv1 reads "
+                             "the store through index rows" if args.episode_store
+                             else "uint8 NHWC + RandomShiftsAug offsets, scaled/normalised while staging conv1" if args.uint8_frames
                              else "fp32 NCHW, already transformed (the reference's dataloader output)",
                    "final_loss": round(final_loss, 4)},
         "roofline": {**rl, "kernel": "/".join(str(k) for k in dom_key),

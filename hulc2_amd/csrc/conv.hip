@@ -30,11 +30,11 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             const long* cls_wtap, hipStream_t s);
 // LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, hipStream_t s);
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s);
 // LDS-band weight gradient (conv_wgrad_band.hip): same return convention
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
-                                  const int* shift, hipStream_t s);
+                                  const int* shift, const int* fidx, hipStream_t s);
 
 namespace {
 
@@ -434,6 +434,7 @@ int validate(const hulc_conv_desc* d, const char* who) {
     if (log2_exact(inner) < 3) return hulc_fail(-4, "conv: inner run (KW for NCHW input, Cin for NHWC) must be a power of two >= 8");
     if (d->Cout != 32 && d->Cout != 64) return hulc_fail(-5, "conv: Cout must be 32 or 64");
     if (d->compute == HULC_F32 && (d->x_dtype != HULC_F32 || d->w_dtype != HULC_F32)) return hulc_fail(-6, "conv: f32 compute requires f32 operands");
+    if (d->frame_index && !d->x_u8_nhwc) return hulc_fail(-7, "conv: frame_index addresses a uint8 NHWC episode store (x_u8_nhwc = 1)");
     (void)who;
     return 0;
 }
@@ -463,7 +464,7 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     if (d->compute == HULC_BF16 && d->x_nchw && (d->x_dtype == HULC_F32 || d->x_u8_nhwc) && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 &&
         d->stride == 4) {
         rc = hulc_conv1_band_dispatch((const float*)x, w, d->w_dtype, g.ldw, bias, y, d->y_dtype, d->relu, d->N, d->H, d->W, d->x_u8_nhwc, d->aug_pad,
-                                      d->aug_shift, (hipStream_t)stream);
+                                      d->aug_shift, d->frame_index, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(conv1 band)");
     }
@@ -570,7 +571,7 @@ extern "C" int hulc_conv2d_bwd_weight(const hulc_conv_desc* d, const void* x, co
         const long wsb = hulc_conv2d_bwd_weight_workspace(d);
         const int brc = hulc_conv_wgrad_band_dispatch(d->x_nchw, d->Cin, d->Cout, d->KH, d->KW, d->stride, x, d->x_dtype, dy, d->y_dtype,
                                                       d->N, d->H, d->W, dw, db, ws, wsb, d->dw_oihw, d->dw_accumulate, d->x_u8_nhwc, d->aug_pad,
-                                                      d->aug_shift, (hipStream_t)stream);
+                                                      d->aug_shift, d->frame_index, (hipStream_t)stream);
         if (brc < 0) return brc;
         if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_weight(band)");
     }

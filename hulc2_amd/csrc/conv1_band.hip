@@ -21,7 +21,7 @@ struct C1P {
     int w_dtype, y_dtype, relu;
     int Nimg, H, W, OH, OW, R;
     long ldw;
-    int u8, pad; const int* shift;     // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
+    int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
 };
 
 template <int XCH>
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         if (p.u8) {                                        // uint8 NHWC frames: one chunk = 8 elements of all three planes
             const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-            const unsigned char* img = (const unsigned char*)p.X + (long)n * p.H * p.W * 3;
+            const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
 #pragma unroll
             for (int i = 0; i < XCH / C; ++i) {
                 const int id = tid + i * NT;
@@ -166,11 +166,11 @@ int launch_conv1(C1P& p, hipStream_t s) {
 
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, hipStream_t s) {
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
     C1P p;
-    p.u8 = u8; p.pad = pad; p.shift = shift;
+    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
     const int rc = launch_conv1<6>(p, s);

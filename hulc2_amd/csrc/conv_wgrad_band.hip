@@ -31,7 +31,7 @@ struct WBandP {
     long dy_sn, dy_sy, dy_sx;         // dY element strides (channels contiguous)
     float* partial_w;                 // [grid][Cout][K]
     float* partial_b;                 // [grid][Cout]
-    int u8, pad; const int* shift;    // conv1 fed by uint8 NHWC frames: shift / scale / normalise applied while staging (see conv1_band.hip)
+    int u8, pad; const int* shift; const int* fidx;   // conv1 fed by uint8 NHWC frames: shift / scale / normalise applied while staging (see conv1_band.hip)
 };
 
 // C: input channels, CT: Cout / 32, TH x TW taps, S stride, NCHW: conv1 layout (k = (c, kh, kw), fp32 planes)
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             const int nflt = rows * p.W, items = (nflt + 7) / 8;
             if (C == 3 && p.u8) {                          // uint8 NHWC frames: one chunk = 8 elements of all three planes
                 const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-                const unsigned char* img = (const unsigned char*)p.X + (long)n * p.H * p.W * 3;
+                const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
 #pragma unroll
                 for (int i = 0; i < XCH / 3; ++i) {
                     const int id = tid + i * NT;
@@ -349,10 +349,10 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error.  dw is [Cout][K] fp32 in the forward k order.
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
-                                  const int* shift, hipStream_t s) {
+                                  const int* shift, const int* fidx, hipStream_t s) {
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
-    p.u8 = u8; p.pad = pad; p.shift = shift;
+    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
     p.X = x; p.dY = dy; p.x_dtype = x_dtype; p.dy_dtype = dy_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - KH) / S + 1; p.OW = (W - KW) / S + 1; p.R = 1; p.F = 1;
     if (nchw) { p.x_sn = (long)Cin * H * W; p.x_sc = (long)H * W; p.x_sy = W; p.x_sx = 1; }

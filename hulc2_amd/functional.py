@@ -113,17 +113,18 @@ class ConvStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, grad_premasked: bool, aug, w1, b1, w2, b2, w3, b3, *xs):
-        """aug: None, or (pad, [shift_i or None per input]) for uint8 NHWC frame tensors (N_i, H, W, 3): conv1 applies
-        RandomShiftsAug / ScaleImageTensor / Normalize while staging."""
+        """aug: None, or (pad, [shift_i or None per input], [index_i or None per input]) for uint8 NHWC frame tensors (N_i, H, W, 3):
+        conv1 applies RandomShiftsAug / ScaleImageTensor / Normalize while staging.  With index_i the tensor is
+        the HBM-resident episode store and the batch frames are store frames index_i (windows padded by repeating an index)."""
         xs = [_c(x) for x in xs]
-        Ns = [x.shape[0] for x in xs]
+        pad, shifts, indices = (aug if aug is not None else (0, [None] * len(xs), [None] * len(xs)))
+        Ns = [x.shape[0] if ix is None else ix.numel() for x, ix in zip(xs, indices)]
         N = sum(Ns)
         u8 = xs[0].dtype == torch.uint8
         if u8:
             _, H, W, C = xs[0].shape
         else:
             _, C, H, W = xs[0].shape
-        pad, shifts = (aug if aug is not None else (0, [None] * len(xs)))
         ws, bs = (w1, w2, w3), (b1, b2, b3)
         acts, dims = [], []
         inp, h, w_, cin = None, H, W, C
@@ -135,8 +136,9 @@ class ConvStackFn(torch.autograd.Function):
             y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=xs[0].device)
             if li == 0:
                 off = 0
-                for x, n, sh in zip(xs, Ns, shifts):
-                    kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad)
+                for x, n, sh, ix in zip(xs, Ns, shifts, indices):
+                    kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
+                                  frame_index=ix)
                     off += n
             else:
                 kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
@@ -145,7 +147,7 @@ class ConvStackFn(torch.autograd.Function):
             inp, h, w_, cin = y, oh, ow, cout
         ctx.save_for_backward(acts[0], acts[1], acts[2], w2, w3, *xs)
         ctx.conv_w, ctx.conv_b = ws, bs                   # identities for the gradient sinks
-        ctx.aug = (pad, shifts)
+        ctx.aug = (pad, shifts, indices)
         ctx.meta = (dims, grad_premasked, Ns)
         return acts[2]
 
@@ -170,10 +172,10 @@ class ConvStackFn(torch.autograd.Function):
             db = sb if sunk else _f32(cout, like=g)
             if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
-                pad, shifts = ctx.aug
-                for j, (x, n, sh) in enumerate(zip(xs, Ns, shifts)):
+                pad, shifts, indices = ctx.aug
+                for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
                     kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk or j > 0,
-                                         aug_shift=sh, aug_pad=pad)
+                                         aug_shift=sh, aug_pad=pad, frame_index=ix)
                     off += n
             else:
                 kn.conv2d_bwd_weight(inputs[li], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk)
@@ -188,14 +190,17 @@ class ConvStackFn(torch.autograd.Function):
         return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], *([None] * len(xs)))
 
 
-def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None):
+def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, frame_index=None):
     """x: a frame tensor or a list of them (batched from conv1's output on); fp32 NCHW frames in [-1, 1], or uint8 NHWC frames as
-    stored, with aug_shifts (per tensor: (N, 2) int32 or None) and aug_pad applied inside conv1."""
+    stored, with aug_shifts (per tensor: (N, 2) int32 or None) and aug_pad applied inside conv1; frame_index (per tensor: int32 store
+    frame numbers or None) when x is the episode store itself."""
     xs = list(x) if isinstance(x, (list, tuple)) else [x]
     aug = None
     if xs[0].dtype == torch.uint8:
         sh = list(aug_shifts) if isinstance(aug_shifts, (list, tuple)) else [aug_shifts] * len(xs)
-        aug = (int(aug_pad), [None if t is None else _c(t.reshape(-1, 2).to(torch.int32)) for t in sh])
+        ix = list(frame_index) if isinstance(frame_index, (list, tuple)) else [frame_index] * len(xs)
+        aug = (int(aug_pad), [None if t is None else _c(t.reshape(-1, 2).to(torch.int32)) for t in sh],
+               [None if t is None else _c(t.reshape(-1).to(torch.int32)) for t in ix])
     return ConvStackFn.apply(grad_premasked, aug, *params, *xs)
 
 

@@ -197,23 +197,31 @@ def conv_out_hw(H, W, KH, KW, stride):
     return (H - KH) // stride + 1, (W - KW) // stride + 1
 
 
-def _u8_frames(d, x, aug_shift, aug_pad):
-    """conv1 fed by uint8 NHWC frames: shift / scale / normalise happen while the kernel stages the band"""
+def _u8_frames(d, x, aug_shift, aug_pad, frame_index=None):
+    """conv1 fed by uint8 NHWC frames: shift / scale / normalise happen while the kernel stages the band.
+    frame_index (N,) int32: x is the episode store and batch frame n is store frame frame_index[n]."""
     if x.dtype != torch.uint8:
+        if frame_index is not None:
+            raise TypeError("frame_index addresses a uint8 NHWC episode store")
         return
+    if frame_index is not None:
+        if frame_index.dtype != torch.int32 or not frame_index.is_contiguous() or frame_index.numel() != d.N:
+            raise TypeError("frame_index must be a contiguous int32 tensor with one store frame number per batch frame")
+        d.frame_index = frame_index.data_ptr()
     if aug_shift is not None and (aug_shift.dtype != torch.int32 or not aug_shift.is_contiguous() or aug_shift.numel() != 2 * d.N):
         raise TypeError("aug_shift must be a contiguous int32 (N, 2) tensor of {sx, sy}")
     d.x_u8_nhwc, d.aug_pad = 1, int(aug_pad)
     d.aug_shift = aug_shift.data_ptr() if aug_shift is not None else None
 
 
-def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0):
+def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
+               frame_index=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
     for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
-    _require_cuda(x, w2d, bias, y, aug_shift)
+    _require_cuda(x, w2d, bias, y, aug_shift, frame_index)
     _require_contiguous(x=x, w2d=w2d, y=y)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
-    _u8_frames(d, x, aug_shift, aug_pad)
+    _u8_frames(d, x, aug_shift, aug_pad, frame_index)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
     macs = float(N) * oh * ow * Cout * Cin * KH * KW
     with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
@@ -235,7 +243,7 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
 
 
 def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None, dw_oihw=False, accumulate=False,
-                      aug_shift=None, aug_pad=0):
+                      aug_shift=None, aug_pad=0, frame_index=None):
     """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC).  dw_oihw: dw in the parameter's OIHW order (else the forward k order);
     accumulate: add into dw / db (gradient arena sinks)."""
     _require_cuda(x, dy, dw, db)
@@ -244,7 +252,7 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     lib.hulc_conv2d_bwd_weight_workspace.restype = ctypes.c_long
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(dy), F32, False, compute)
     d.dw_oihw, d.dw_accumulate = int(dw_oihw), int(accumulate)
-    _u8_frames(d, x, aug_shift, aug_pad)
+    _u8_frames(d, x, aug_shift, aug_pad, frame_index)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
@@ -502,6 +510,25 @@ def mix_sample(y, ld, T, A, n_mix, log_scale_min, gripper_bounds, act_out, seed,
     d = _mix_desc(T, A, n_mix, 0, ld, log_scale_min, 0.0, gripper_bounds, gripper_bounds)
     # validation / rollout run outside the training graphs: the caller advances `seed` itself, no device step word involved
     _call("hulc_mix_sample", _c.byref(d), y, u_mix, u_inv, _u64(seed), None, gripper_bounds, act_out, idx_out)
+
+
+def window_index(starts, sizes, B, S, out):
+    """out (B, S) int32 = starts[b] + min(t, sizes[b] - 1): a padded play window as store frame numbers (base_dataset.py:94-112,149-154)"""
+    for t in (starts, sizes, out):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise TypeError("window_index: starts / sizes / out are contiguous int32 tensors")
+    _call("hulc_window_index", starts, sizes, _i(B), _i(S), out)
+    return out
+
+
+def window_rows(store, starts, sizes, B, S, out, zero_cols=(0, 0)):
+    """out (B, S, D) fp32 gathered from store (n, D); padded steps repeat the last row, columns [zero_cols) are zero-padded
+    (base_dataset.py:121-147 pad_sequence)"""
+    if store.dtype != torch.float32 or out.dtype != torch.float32 or starts.dtype != torch.int32 or sizes.dtype != torch.int32:
+        raise TypeError("window_rows: fp32 store / out, int32 starts / sizes")
+    _require_contiguous(store=store, out=out, starts=starts, sizes=sizes)
+    _call("hulc_window_rows", store, _i(store.shape[-1]), starts, sizes, _i(B), _i(S), _i(zero_cols[0]), _i(zero_cols[1]), out)
+    return out
 
 
 def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None):

@@ -36,14 +36,21 @@ class ConcatEncoders(nn.Module):
 
     @staticmethod
     def _frames(imgs, key):
-        """-> (frames flattened over (B, S), shifts flattened or None, B, S).  fp32 (B,S,3,H,W) in [-1,1] as the reference's transforms
-        deliver them, or uint8 (B,S,H,W,3) as stored (+ optional imgs[key + "_shift"] (B,S,2) int32 {sx, sy})."""
+        """-> (frames flattened over (B, S), shifts flattened or None, store frame numbers or None, B, S).  fp32 (B,S,3,H,W) in [-1,1]
+        as the reference's transforms deliver them, or uint8 (B,S,H,W,3) as stored (+ optional imgs[key + "_shift"] (B,S,2) int32
+        {sx, sy}), or the whole uint8 episode store (n_frames,H,W,3) with imgs[key + "_index"] (B,S) int32 naming the window frames
+        (hulc2_amd.datasets.DeviceEpisodeStore: nothing is gathered, conv1 reads the store in place)."""
         x = imgs[key]
+        ix = imgs.get(key + "_index")
+        if ix is not None:
+            b, s = ix.shape
+            sh = imgs.get(key + "_shift")
+            return x, (None if sh is None else sh.reshape(b * s, 2)), ix.reshape(b * s), b, s
         b, s = x.shape[0], x.shape[1]
         if x.dtype == torch.uint8:
             sh = imgs.get(key + "_shift")
-            return x.reshape(b * s, *x.shape[2:]), (None if sh is None else sh.reshape(b * s, 2)), b, s
-        return x.reshape(b * s, *x.shape[2:]), None, b, s
+            return x.reshape(b * s, *x.shape[2:]), (None if sh is None else sh.reshape(b * s, 2)), None, b, s
+        return x.reshape(b * s, *x.shape[2:]), None, None, b, s
 
     @property
     def latent_size(self):
@@ -52,11 +59,11 @@ class ConcatEncoders(nn.Module):
     def forward(self, imgs: Dict[str, torch.Tensor], depth_imgs: Dict[str, torch.Tensor], state_obs: torch.Tensor) -> torch.Tensor:
         if isinstance(imgs, (list, tuple)):             # several modalities at once (Hulc2.training_step): see forward_multi
             return self.forward_multi(imgs)
-        x, sh, b, s = self._frames(imgs, "rgb_static")
-        enc = self.rgb_static_encoder(x, sh, self.aug_pad["rgb_static"]).reshape(b, s, -1)
+        x, sh, ix, b, s = self._frames(imgs, "rgb_static")
+        enc = self.rgb_static_encoder(x, sh, self.aug_pad["rgb_static"], ix).reshape(b, s, -1)
         if "rgb_gripper" in imgs and self.rgb_gripper_encoder is not None:
-            x, sh, b, s = self._frames(imgs, "rgb_gripper")
-            enc = torch.cat([enc, self.rgb_gripper_encoder(x, sh, self.aug_pad["rgb_gripper"]).reshape(b, s, -1)], dim=-1)
+            x, sh, ix, b, s = self._frames(imgs, "rgb_gripper")
+            enc = torch.cat([enc, self.rgb_gripper_encoder(x, sh, self.aug_pad["rgb_gripper"], ix).reshape(b, s, -1)], dim=-1)
         self.current_visual_embedding = enc.detach()   # detached: holding the graph across steps breaks HIP-graph capture
         self.current_state_obs = state_obs
         return enc
@@ -65,11 +72,12 @@ class ConcatEncoders(nn.Module):
         """Several observation dicts of identical shapes (the modalities of one training step) through the shared encoders
         in one pass: rows of the result are modality-major, (sum B, S, latent).  Same arithmetic per frame as `forward`."""
         fr = [self._frames(im, "rgb_static") for im in imgs_list]
-        b, s = fr[0][2], fr[0][3]
-        enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"]).reshape(len(fr) * b, s, -1)
+        b, s = fr[0][3], fr[0][4]
+        enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"], [f[2] for f in fr]).reshape(len(fr) * b, s, -1)
         if self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list):
             fr = [self._frames(im, "rgb_gripper") for im in imgs_list]
-            enc = torch.cat([enc, self.rgb_gripper_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_gripper"]).reshape(len(fr) * b, s, -1)],
+            enc = torch.cat([enc, self.rgb_gripper_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_gripper"],
+                                                              [f[2] for f in fr]).reshape(len(fr) * b, s, -1)],
                             dim=-1)
         self.current_visual_embedding = enc.detach()
         return enc

@@ -34,8 +34,8 @@ class VisionNetwork(nn.Module):
         c = self.conv_model
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)
 
-    def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0) -> torch.Tensor:
-        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=False, aug_pad=aug_pad, aug_shifts=aug_shift)     # (N, 7, 7, 64) NHWC
+    def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0, frame_index=None) -> torch.Tensor:
+        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=False, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
         # Flatten order of the reference (C, H, W); one copy that also widens to fp32, so the 3136 -> 128 weight-gradient GEMM
         # reads a row-major fp32 operand (16-byte micro-tile staging) instead of 2-byte strided bf16 loads
         flat = a3.permute(0, 3, 1, 2).to(torch.float32, memory_format=torch.contiguous_format).reshape(a3.shape[0], -1)

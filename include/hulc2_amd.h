@@ -76,6 +76,10 @@ typedef struct {
     int x_u8_nhwc;
     int aug_pad;
     const int* aug_shift;
+    /* x_u8_nhwc only: batch frame n is frame frame_index[n] of x — x is then the HBM-resident episode store, not a gathered batch
+     * (hulc2/datasets/shm_dataset.py:101-118 reads its windows out of shared memory the same way; pad-by-repetition,
+     * base_dataset.py:150-155, is a repeated index).  NULL = frame n. */
+    const int* frame_index;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]
@@ -176,6 +180,17 @@ int hulc_tcp_to_world(const float* act, const float* robot_obs, int n, int obs_d
  * (parity tests); NULL -> counter RNG on (seed ^ *seed_dev).  act_out (T, A+1); idx_out (T, A) selected mixture (optional). */
 int hulc_mix_sample(const hulc_mix_desc* d, const float* y, const float* u_mix, const float* u_inv, unsigned long long seed,
                     const unsigned long long* seed_dev, const float* gripper_bounds, float* act_out, long* idx_out, void* stream);
+
+/* ---- play windows over the HBM-resident episode store ---------------------------------- */
+/* A window = `sizes[b]` consecutive store frames from `starts[b]`, padded to S steps (hulc2/datasets/base_dataset.py:94-112).
+ * hulc_window_index: index_out[b][t] = starts[b] + min(t, sizes[b] - 1) — pad_with_repetition (base_dataset.py:149-154) as a repeated
+ * index; feed it to hulc_conv_desc.frame_index so conv1 reads the store in place.
+ * hulc_window_rows: out (B, S, D) fp32 gathered from store (n_frames, D): padded steps repeat the last row, except columns
+ * [zero_lo, zero_hi) which are zero — relative actions pad with zeros in dims 0..5 and repeat the gripper dim (base_dataset.py:132-142);
+ * observations / state_info repeat everything (zero_lo = zero_hi = 0).  1 <= sizes[b] <= S; starts/sizes are device int32. */
+int hulc_window_index(const int* starts, const int* sizes, int B, int S, int* index_out, void* stream);
+int hulc_window_rows(const float* store, int D, const int* starts, const int* sizes, int B, int S, int zero_lo, int zero_hi,
+                     float* out, void* stream);
 
 /* ---- transformer feed-forward block, fused (bf16 compute) ----------------------------------------------- */
 /* f = relu(x W1^T + b1) [dropout] W2^T + b2 of nn.TransformerEncoderLayer (plan_recognition_net.py:108-117), d_model 128,

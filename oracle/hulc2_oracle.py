@@ -351,6 +351,71 @@ def frames_u8_to_input(frames_u8_nhwc: torch.Tensor, pad: int = 0, shift: Option
 
 
 # ------------------------------------------------------------------------------------------------
+# play windows: which frames a dataset index yields, and how a short window is padded  
+# PARITY UNPINNED for the validation hash only: pyhash (requirements.txt:12, no version) is absent here; FNV-1/32 with the hash
+# value starting at the seed (0) is restated from its published algorithm and anchored on pyhash's documented known answer
+# fnv1_32()("hello world") == 2805756500 (tests/test_oracle_golden.py).  Everything else is index arithmetic of the reference.
+# ------------------------------------------------------------------------------------------------
+def fnv1_32(text: str, seed: int = 0) -> int:
+    h = seed
+    for byte in text.encode("utf-8"):
+        h = ((h * 0x01000193) % (1 << 32)) ^ byte
+    return h
+
+
+def get_validation_window_size(idx: int, min_window_size: int, max_window_size: int) -> int:
+    """hulc2/datasets/base_dataset.py:26-28"""
+    window_range = max_window_size - min_window_size + 1
+    return min_window_size + fnv1_32(str(idx)) % window_range
+
+
+def episode_lookup(ep_start_end_ids, min_window_size: int):
+    """hulc2/datasets/utils/shared_memory_loader.py:67-73: (first frame, step inside the episode) of every window start"""
+    frames, steps = [], []
+    for start_idx, end_idx in ep_start_end_ids:
+        for j, idx in enumerate(range(int(start_idx), int(end_idx) + 1 - min_window_size)):
+            frames.append(idx)
+            steps.append(j)
+    return frames, steps
+
+
+def max_window_size_at(episode_counters, idx: int, min_window_size: int, max_window_size: int) -> int:
+    """hulc2/datasets/shm_dataset.py:77-95 — the part of get_window_size before the random / hashed draw"""
+    import numpy as np
+    episode_counters = np.asarray(episode_counters)
+    window_diff = max_window_size - min_window_size
+    if len(episode_counters) <= idx + window_diff:
+        return min_window_size + len(episode_counters) - idx - 1
+    if episode_counters[idx + window_diff] != episode_counters[idx] + window_diff:
+        expect = episode_counters[idx] + np.arange(window_diff + 1)
+        first_break = np.nonzero(episode_counters[idx : idx + window_diff + 1] - expect)[0][0]
+        return min(max_window_size, int(min_window_size + first_break - 1))
+    return max_window_size
+
+
+def pad_with_repetition(x: torch.Tensor, pad_size: int) -> torch.Tensor:
+    """hulc2/datasets/base_dataset.py:149-154"""
+    return torch.cat([x, x[-1:].expand(pad_size, *x.shape[1:])], dim=0) if pad_size > 0 else x
+
+
+def pad_with_zeros(x: torch.Tensor, pad_size: int) -> torch.Tensor:
+    """hulc2/datasets/base_dataset.py:156-163"""
+    return torch.cat([x, torch.zeros(pad_size, x.shape[-1], dtype=x.dtype)], dim=0) if pad_size > 0 else x
+
+
+def padded_window(frames_u8: Dict[str, torch.Tensor], rel_actions: torch.Tensor, robot_obs: torch.Tensor, start: int, size: int,
+                  max_window_size: int) -> Dict[str, torch.Tensor]:
+    """hulc2/datasets/base_dataset.py:94-147 for the npz / relative-action dataset (the CALVIN configuration): slice `size` steps
+    from `start`, then pad to max_window_size — observations repeat the last step, actions are zero except the repeated gripper dim"""
+    pad_size = max_window_size - size
+    out = {k: pad_with_repetition(v[start:start + size], pad_size) for k, v in frames_u8.items()}
+    a = rel_actions[start:start + size]
+    out["actions"] = torch.cat([pad_with_zeros(a[..., :-1], pad_size), pad_with_repetition(a[..., -1:], pad_size)], dim=-1)
+    out["robot_obs"] = pad_with_repetition(robot_obs[start:start + size], pad_size)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # CLIP-style auxiliary loss
 # ------------------------------------------------------------------------------------------------
 def clip_auxiliary_loss(sd: SD, seq_feat: torch.Tensor, goal: torch.Tensor, use: Optional[torch.Tensor]) -> torch.Tensor:
