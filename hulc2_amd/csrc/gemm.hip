@@ -496,11 +496,14 @@ template <typename CT, int TM, int TN, int WM, int WN>
 void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int gx = (p.M + BM - 1) / BM, gy = (p.N + BN - 1) / BN;
-    // few output tiles but a long reduction (dgrads into narrow layers, wgrads of narrow layers): split K over
-    // workgroups until ~256 exist, keeping >= 8 k-tiles per slice
+    // few output tiles but a long reduction (dgrads into narrow layers, wgrads of narrow layers): split K over workgroups.
+    // One workgroup per CU is latency-bound (a k-tile's loads are only covered by one tile of MFMAs): ~3 per CU (768) with >= 4
+    // k-tiles per slice measured best (tools/gemm_heur_sweep.sh: step 6.52 -> 6.20 ms together with the short-K rule below)
     const int nkt = (p.K + MmaTraits<CT>::KT - 1) / MmaTraits<CT>::KT;
     int splitk = 1;
-    while (gx * gy * splitk < 192 && nkt / (splitk * 2) >= 8) splitk *= 2;
+    static const int target = getenv("HULC_TILE_TARGET") ? atoi(getenv("HULC_TILE_TARGET")) : 768;
+    static const int minkt = getenv("HULC_TILE_MINKT") ? atoi(getenv("HULC_TILE_MINKT")) : 4;
+    while (gx * gy * splitk < target && nkt / (splitk * 2) >= minkt) splitk *= 2;
     while (splitk > 1 && (long)splitk * p.M * (p.N + 1) * 4 > ws_bytes) splitk /= 2;
     dim3 grid(gx, gy, splitk), block(WM * WN * 64);
     if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p, ws, splitk);
@@ -518,7 +521,10 @@ void launch_ct(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStre
     // tile choice: keep >= ~256 workgroups when the problem allows it (256 CUs); M <= 64 never gets here
     // (skinny path above).
     const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (blocks128 < 192) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, ws, ws_bytes, s);   // 64 x 64
+    // short reductions (K <= 256: weight gradients over 32 / 64 sequences, projections out of d_model = 128) are one or two k-tiles
+    // of latency followed by a 64 KB store per tile: 64 x 64 tiles give 4x the workgroups to overlap them
+    static const int smallk = getenv("HULC_TILE_SMALLK") ? atoi(getenv("HULC_TILE_SMALLK")) : 256;
+    if (blocks128 < 192 || p.K <= smallk) launch_cfg<CT, 1, 1, 2, 2>(p, ak, bk, ws, ws_bytes, s);   // 64 x 64
     else launch_cfg<CT, 2, 2, 2, 2>(p, ak, bk, ws, ws_bytes, s);                    // 128 x 128
 }
 
