@@ -16,18 +16,22 @@
 //     with the 8 waves splitting K, sums the 8 partial tiles through LDS in a fixed order (deterministic), applies the
 //     epilogue (bias / external add / ReLU or stored-activation mask) and writes fp32 (for the weight-gradient GEMMs) and
 //     bf16 (its own next operand, ping-pong) state;
-//   * wave steps are separated by a device-wide barrier (agent-scope release/acquire on one counter).  All 256 workgroups
+//   * wave steps are separated by a device-wide barrier (agent-scope counters, one per row half and XCD).  All 256 workgroups
 //     are co-resident (1 per CU by register footprint; the stream runs nothing else), the spin is bounded, and a timeout
 //     poisons the output with NaN instead of hanging the GPU.
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 #include <stdlib.h>
 
+#define RNN_CTR_STRIDE 1024                                   // unsigned words between barrier counters (4 KB)
+#define RNN_WS_HEADER (9 * RNN_CTR_STRIDE * 4)                // 8 barrier counters + the error word
+
 namespace {
 
 struct WaveP {
     float* z; long z_step;                       // fp32 state rows: wave step tau reads z + tau*z_step, writes z + (tau+1)*z_step
-    uint16_t* zb;                                // bf16 copy of the state rows, [S+2][B][2H]: region r mirrors fp32 row r of the sweep
+    uint16_t* zb;                                // bf16 mirror of the state rows, [S+2][B][2H] row-major (operand of the weight-gradient GEMMs)
+    uint16_t* xb;                                // the same values in the exchange layout the kernel itself reads, [S+2][2][H/8][64][8] (see below)
     int zb_row0, zb_dir;                         // region read at wave step tau = zb_row0 + tau * zb_dir (0, +1 forward; S+1, -1 reversed)
     const uint16_t *wA, *wB1, *wB2;              // first (H x H), second k < H (H x H), second k >= H (H x H)
     long ldA, ldB1, ldB2; int tA, tB1, tB2;      // t: element (n, k) is w[k*ld + n] instead of w[n*ld + k]
@@ -37,6 +41,7 @@ struct WaveP {
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
     unsigned* bar; int* err;
+    int dbg;                                     // timing experiments only (HULC_RNN_DBG): 1 = skip state loads + MFMAs, 2 = skip the barrier
 };
 
 // The bf16 state copy is the only data exchanged between workgroups inside the kernel.  Measured alternatives:
@@ -46,7 +51,10 @@ struct WaveP {
 //   * (this) every wave step writes its OWN region of the copy with write-through sc1 stores and readers use ordinary
 //     loads: a region's addresses are never cached before they are complete (first touch after the barrier; the caches
 //     start clean at kernel launch), so the 128 workgroups sharing a row half hit the XCD's L2 instead of memory.
-//     The workgroup -> (row half, column group) map keeps the four writers of every 128-byte line on one XCD.
+// Exchange layout: [region][state half][k / 8][row 0..63][8 values].  An MFMA A fragment is (row = lane % 16, 8 consecutive k
+// at k-block lane / 16): in a row-major copy the 16 lanes of a k-block sit 8 KB apart, every lane is its own tag lookup and the
+// 256 KB a workgroup reads per step took ~6 us (18 B/clk per CU).  Blocked, the 16 lanes read 256 contiguous bytes, an
+// instruction touches 8 full lines instead of 64 partial ones, and every 128-byte line has exactly one writer workgroup.
 HULC_DEVICE bf16x8_t load_state8(const uint16_t* p) { return *(const bf16x8_t*)p; }
 
 HULC_DEVICE bf16x8_t load_w(const uint16_t* w, long ld, int t, int n, int k) {
@@ -87,9 +95,6 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
         union { bf16x8_t b; uint4 u; } wc; wc.b = load_w(p.wB2, p.ldB2, p.tB2, n0 + i, k);
         wlds[wave][q][lane] = wc.u;                                          // read back only by this wave: no barrier needed
     }
-    int mrow[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { const int m = rowhalf * 32 + mt * 16 + i; mrow[mt] = m < p.B ? m : p.B - 1; }
     bool timed_out = false;
     // ---- this thread's two outputs per wave step (fixed): tile t4 = mt*2 + ct, accumulator element e
     int om[2], on[2]; float obias[2];
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
                 if (p.mask1 && first_on) omask[rep] = p.mask1[(long)tau * p.mask1_step + (long)m * p.ld_mask1 + n];
             } else if (p.mask2 && second_on) omask[rep] = p.mask2[(long)tau * p.mask2_step + (long)m * p.ld_mask2 + n];
         }
-        if (tau > 0) {                                       // z_0 = 0: nothing to multiply
-            const uint16_t* a = p.zb + (long)(p.zb_row0 + tau * p.zb_dir) * p.B * ldz;
+        if (tau > 0 && !(p.dbg & 1)) {                       // z_0 = 0: nothing to multiply
+            const uint16_t* a = p.xb + (long)(p.zb_row0 + tau * p.zb_dir) * 64 * ldz + (long)(rowhalf * 32 + i) * 8;
             // the step's 32 fragment loads are independent of the MFMAs: the scheduler keeps as many in flight as registers allow
             bf16x8_t af[2][KPW][2];
 #pragma unroll
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
                 for (int q = 0; q < KPW; ++q)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        af[hf][q][mt] = load_state8(a + (long)mrow[mt] * ldz + hf * H + (wave * KPW + q) * 32 + kb * 8);
+                        af[hf][q][mt] = load_state8(a + ((long)(hf * (H / 8) + (wave * KPW + q) * 4 + kb) * 64 + mt * 16) * 8);
 #pragma unroll
             for (int q = 0; q < KPW; ++q)
 #pragma unroll
@@ -158,6 +163,8 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
         // ---- fixed-order sum over the 8 K slices + epilogue; 1024 outputs, 2 per thread
         float* zn = p.z + (long)(tau + 1) * p.z_step;
         uint16_t* zbn = p.zb + (long)(p.zb_row0 + (tau + 1) * p.zb_dir) * p.B * ldz;
+        uint16_t* xbn = p.xb + (long)(p.zb_row0 + (tau + 1) * p.zb_dir) * 64 * ldz;
+        float vout[2]; bool vst[2];
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
             const int o = tid + rep * 512, t4 = o >> 8, e = o & 255, ct = t4 & 1;
@@ -165,37 +172,53 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[w][t4][e];
-            if (m >= p.B) continue;
             const bool on_ = ct == 0 ? first_on : second_on;
-            if (ct == 0 && !on_) continue;                               // last wave step: the first half is not produced
+            vst[rep] = m < p.B && !(ct == 0 && !on_);                    // last wave step: the first half is not produced
             v += oadd[rep] + obias[rep];
             if ((ct == 0 ? p.mask1 : p.mask2) != nullptr) v = omask[rep] > 0.f ? v : 0.f;
             else if (p.relu) v = fmaxf(v, 0.f);
             if (!on_) v = 0.f;                                           // wave step 0: the second half (h1_{-1}) is zero
-            zn[(long)m * ldz + ct * H + n] = v;
-            otile[m - rowhalf * 32][ct][n - n0] = f32_to_bf16_bits(v);
+            vout[rep] = v;
+            if (vst[rep]) otile[m - rowhalf * 32][ct][n - n0] = f32_to_bf16_bits(v);
         }
         __syncthreads();
-        if (tid < 128) {                                                     // 32 rows x 2 halves x 2 chunks of 8 columns = 128 16-byte stores
-            const int row = tid >> 2, ct = (tid >> 1) & 1, ch = tid & 1;
+        // the exchange copy first — it is all the other workgroups wait for; the fp32 rows and the row-major mirror are only read
+        // after the kernel and are stored behind the barrier arrival, off the critical path
+        uint4 v16 = make_uint4(0, 0, 0, 0); bool st16 = false; long off16 = 0;
+        if (tid < 128) {                                     // 32 rows x 2 halves x 2 chunks of 8 columns = 128 16-byte pieces
+            const int row = tid & 31, ct = tid >> 6, ch = (tid >> 5) & 1;
             const int m = rowhalf * 32 + row;
-            if (m < p.B && (ct == 1 || first_on)) {
-                const uint4 v = *(const uint4*)&otile[row][ct][ch * 8];
-                unsigned long long* dst = (unsigned long long*)(zbn + (long)m * ldz + ct * H + n0 + ch * 8);
-                __hip_atomic_store(dst, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st16 = m < p.B && (ct == 1 || first_on);
+            if (st16) {
+                v16 = *(const uint4*)&otile[row][ct][ch * 8];
+                off16 = (long)m * ldz + ct * H + n0 + ch * 8;
+                unsigned long long* dst = (unsigned long long*)(xbn + ((long)(ct * (H / 8) + n0 / 8 + ch) * 64 + m) * 8);
+                __hip_atomic_store(dst, (unsigned long long)v16.x | ((unsigned long long)v16.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, (unsigned long long)v16.z | ((unsigned long long)v16.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (tau == p.S) break;
+        const bool last = tau == p.S;
+        if (!last) {
+            // ---- device-wide barrier, arrival: everybody's z_{tau+1} is visible before anybody reads it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's coherent stores have been acknowledged
+            __syncthreads();
+            if (tid == 0 && !(p.dbg & 2)) __hip_atomic_fetch_add(p.bar + xcd * RNN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep)
+            if (vst[rep]) zn[(long)om[rep] * ldz + (((tid + rep * 512) >> 8) & 1) * H + on[rep]] = vout[rep];
+        if (st16) *(uint4*)(zbn + off16) = v16;                               // row-major mirror
+        if (last) break;
 
-        // ---- device-wide barrier: everybody's z_{tau+1} is visible before anybody reads it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's coherent stores have been acknowledged
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (unsigned)(tau + 1) * (unsigned)nblk;
+        if (tid < 4 && !(p.dbg & 2)) {
+            // The two row halves never exchange data, and a half lives on four XCDs (xcd parity = row half): one arrival counter per
+            // (half, XCD), 4 KB apart (separate memory channels); a workgroup adds to its own and lanes 0..3 each poll one of its
+            // half's four counters.  One counter for all 256 workgroups cost 13.4 us per wave step, one per half 11.1, this 10.5:
+            // same-address atomics and 256 pollers on one line serialise at the memory side.
+            const unsigned per = (unsigned)(nblk / 8) * (unsigned)(tau + 1);
+            const unsigned* bar = p.bar + ((xcd & 1) + 2 * tid) * RNN_CTR_STRIDE;
             long spins = 0;
-            while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1L << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
@@ -217,7 +240,9 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 
 }  // namespace
 
-extern "C" long hulc_rnn_wavefront_workspace(int S, int B, int H) { return 256 + (long)(S + 2) * B * 2 * H * 2; }
+extern "C" long hulc_rnn_wavefront_mirror_offset(void) { return RNN_WS_HEADER; }
+// header | row-major mirror (S+2, B, 2H) | exchange copy (S+2, 2, H/8, 64, 8)
+extern "C" long hulc_rnn_wavefront_workspace(int S, int B, int H) { return RNN_WS_HEADER + (long)(S + 2) * (B + 64) * 2 * H * 2; }
 
 // see include/hulc2_amd.h
 extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream) {
@@ -230,7 +255,8 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     hipStream_t s = (hipStream_t)stream;
     WaveP p;
     p.z = d->z; p.z_step = d->z_step;
-    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 64); p.zb = (uint16_t*)((char*)ws + 256);
+    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8 * RNN_CTR_STRIDE * 4); p.zb = (uint16_t*)((char*)ws + RNN_WS_HEADER);
+    p.xb = p.zb + (long)(d->S + 2) * d->B * 2 * d->H;
     p.wA = (const uint16_t*)d->wA; p.wB1 = (const uint16_t*)d->wB1; p.wB2 = (const uint16_t*)d->wB2;
     p.ldA = d->ldA; p.ldB1 = d->ldB1; p.ldB2 = d->ldB2; p.tA = d->tA; p.tB1 = d->tB1; p.tB2 = d->tB2;
     p.add1 = d->add1; p.add1_step = d->add1_step; p.ld_add1 = d->ld_add1;
@@ -238,10 +264,11 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.mask1 = d->mask1; p.mask1_step = d->mask1_step; p.ld_mask1 = d->ld_mask1;
     p.mask2 = d->mask2; p.mask2_step = d->mask2_step; p.ld_mask2 = d->ld_mask2;
     p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H;
+    p.dbg = getenv("HULC_RNN_DBG") ? atoi(getenv("HULC_RNN_DBG")) : 0;
     p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
     // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs
-    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess ||
-        hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)
+    if (hipMemsetAsync(ws, 0, RNN_WS_HEADER, s) != hipSuccess ||
+        hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)   // (exchange region 0 is never read: z_0 = 0 is skipped)
         return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
     rnn_wavefront_kernel<2048><<<2 * (2048 / 16), 512, 0, s>>>(p);
     return hulc_check_launch("hulc_rnn_wavefront");

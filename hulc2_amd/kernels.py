@@ -455,7 +455,9 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     nbytes = 3.0 * H * H * 2 + S * B * (2 * H * 4 + 2 * 2 * H * 2 + (H * 4 if add1 is not None else 0)
                                         + (H * 4 if mask1 is not None else 0) + (H * 4 if mask2 is not None else 0))
     _call("hulc_rnn_wavefront", _c.byref(d), ws, key=("rnn_wavefront", S, B, H, int(bool(transposed))), flops=flops, nbytes=nbytes)
-    return ws.view(torch.bfloat16)[128:128 + (S + 2) * B * 2 * H].view(S + 2, B, 2 * H)      # bf16 mirror of the S+2 state rows
+    lib.hulc_rnn_wavefront_mirror_offset.restype = ctypes.c_long
+    off = lib.hulc_rnn_wavefront_mirror_offset() // 2
+    return ws.view(torch.bfloat16)[off:off + (S + 2) * B * 2 * H].view(S + 2, B, 2 * H)      # bf16 mirror of the S+2 state rows
 
 
 def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):

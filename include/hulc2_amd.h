@@ -228,6 +228,7 @@ typedef struct hulc_rnn_wave_desc {
     int relu, S, B, H;
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
+long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */
 int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------- */
