@@ -24,14 +24,17 @@ struct C1P {
     int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
 };
 
-template <int XCH>
+// U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
+template <int XCH, bool U8>
 __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     constexpr int NT = 512, C = 3, TH = 8, TW = 8, S = 4, K = C * TH * TW, KSTEPS = K / 16;   // 12 k-steps of (c, kh pair)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int bands = (p.OH + p.R - 1) / p.R;
-    const int nunits = p.Nimg * bands;
+    // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
+    // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
+    const int nunits = ((p.Nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * bands;     // this workgroup's units
     const int rows_max = (p.R - 1) * S + TH;
     const int PP = (rows_max * p.W + 7) / 8 * 8;                 // plane pitch (elements)
 
@@ -46,23 +49,28 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         *(uint4*)(wlds + row * WROW + ch * 16) = make_uint4(pack_bf16x2(c.v[0], c.v[1]), pack_bf16x2(c.v[2], c.v[3]), pack_bf16x2(c.v[4], c.v[5]), pack_bf16x2(c.v[6], c.v[7]));
     }
 
-    uint4 xpre[XCH];
+    // the prefetched band stays RAW in registers (8 floats per item / the aligned dword windows of uint8 frames) and is converted in
+    // stage_store: any ALU use of a loaded value here would put the wait for the loads in front of the MFMA loop they overlap
+    float4 xraw[XCH][2];
     auto unit_geom = [&](int unit, int& n, int& r0, int& R, int& rows) {
-        n = unit / bands; const int b = unit % bands;
+        const int b = unit % bands;
+        n = blockIdx.x + (unit / bands) * gridDim.x;
         r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + TH;
     };
     auto stage_load = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
-        if (p.u8) {                                        // uint8 NHWC frames: one chunk = 8 elements of all three planes
+        if (U8) {                                          // uint8 NHWC frames: one item = 8 elements of all three planes
             const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
             const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
 #pragma unroll
             for (int i = 0; i < XCH / C; ++i) {
                 const int id = tid + i * NT;
                 const bool inb = id < items;
-                u8_band_chunk3(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad,
-                               xpre[i], xpre[XCH / C + i], xpre[2 * (XCH / C) + i]);
+                uint32_t raw[8];
+                u8_band_chunk3_load(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad, raw);
+                xraw[i][0] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+                xraw[i][1] = make_float4(__uint_as_float(raw[4]), __uint_as_float(raw[5]), __uint_as_float(raw[6]), __uint_as_float(raw[7]));
             }
             return;
         }
@@ -70,17 +78,34 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
-            const long base = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W;
-            const long off = base + (inb ? (long)id * 8 : 0);
-            const float4 a = *(const float4*)((const float*)p.X + off);
-            const float4 b = *(const float4*)((const float*)p.X + (inb2 ? off + 4 : off));
-            xpre[j].x = inb ? pack_bf16x2(a.x, a.y) : 0u; xpre[j].y = inb ? pack_bf16x2(a.z, a.w) : 0u;
-            xpre[j].z = inb2 ? pack_bf16x2(b.x, b.y) : 0u; xpre[j].w = inb2 ? pack_bf16x2(b.z, b.w) : 0u;
+            const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
+            xraw[j][0] = *(const float4*)((const float*)p.X + off);
+            xraw[j][1] = *(const float4*)((const float*)p.X + (inb2 ? off + 4 : off));
         }
     };
     auto stage_store = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
-        const int items = (rows * p.W + 7) / 8;
+        const int nflt = rows * p.W, items = (nflt + 7) / 8;
+        uint4 xpre[XCH];
+        if (U8) {
+            const int sx = p.shift ? p.shift[2 * n] : p.pad;
+#pragma unroll
+            for (int i = 0; i < XCH / C; ++i) {
+                const int id = tid + i * NT;
+                const bool inb = id < items;
+                const uint32_t raw[8] = {__float_as_uint(xraw[i][0].x), __float_as_uint(xraw[i][0].y), __float_as_uint(xraw[i][0].z), __float_as_uint(xraw[i][0].w),
+                                         __float_as_uint(xraw[i][1].x), __float_as_uint(xraw[i][1].y), __float_as_uint(xraw[i][1].z), __float_as_uint(xraw[i][1].w)};
+                u8_band_chunk3_convert(p.W, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, raw, xpre[i], xpre[XCH / C + i], xpre[2 * (XCH / C) + i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = tid + (j % (XCH / C)) * NT;
+                const bool inb2 = id * 8 + 8 <= nflt;
+                const float4 a = xraw[j][0], b = xraw[j][1];
+                xpre[j] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), inb2 ? pack_bf16x2(b.x, b.y) : 0u, inb2 ? pack_bf16x2(b.z, b.w) : 0u);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
@@ -88,11 +113,11 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         }
     };
 
-    int unit = blockIdx.x;
+    int unit = 0;
     if (unit < nunits) { stage_load(unit); stage_store(unit); }
     __syncthreads();
-    for (; unit < nunits; unit += gridDim.x) {
-        const int next = unit + gridDim.x;
+    for (; unit < nunits; ++unit) {
+        const int next = unit + 1;
         if (next < nunits) stage_load(next);
 
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
@@ -148,17 +173,17 @@ int launch_conv1(C1P& p, hipStream_t s) {
     const int bands = (p.OH + R - 1) / R;
     R = (p.OH + bands - 1) / bands;
     p.R = R;
-    const int nunits = p.Nimg * bands;
     const int slots = 512;                                       // two workgroups per CU (LDS <= 80 KB each)
-    const int per = (nunits + slots - 1) / slots;
-    const int grid = (nunits + per - 1) / per;
-    auto kern = conv1_band_kernel<XCH>;
+    const int per = (p.Nimg + slots - 1) / slots;                // frames per workgroup
+    const int grid = (p.Nimg + per - 1) / per;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
+        if (hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
         attr_set = true;
     }
-    kern<<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    if (p.u8) conv1_band_kernel<XCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    else conv1_band_kernel<XCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     return 0;
 }
 
@@ -173,7 +198,7 @@ int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ld
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
-    const int rc = launch_conv1<6>(p, s);
+    const int rc = launch_conv1<3>(p, s);
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv1 band: could not raise the dynamic LDS limit");
     return 0;

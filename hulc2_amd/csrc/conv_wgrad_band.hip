@@ -153,13 +153,9 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             uint4 v;
             const float keep = inb ? 1.f : 0.f;
             if (p.dy_dtype == HULC_BF16) {
+                // (the bias partial sums of bf16 gradients are taken in stage_store: touching the value here would wait for the load
+                // — and every load issued before it — ahead of the MFMA loop it is meant to overlap)
                 v = *(const uint4*)((const uint16_t*)p.dY + off);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += keep * __uint_as_float(w[e] << 16);
-                    bsum[2 * e + 1] += keep * __uint_as_float(w[e] & 0xffff0000u);
-                }
             } else {
                 const float4* qq = (const float4*)((const float*)p.dY + off);
                 const float4 a = qq[0], b = qq[1];
@@ -193,6 +189,10 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             const int q = tid / YCPP + j * (NT / YCPP);
             if (q < npad) {                                  // pixels in [npix, npad) carry zeros (ypre is zero there)
                 const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
+                if (p.dy_dtype == HULC_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint16_t bits = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
@@ -292,6 +292,273 @@ __global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// conv1 (3 -> 32 channels, 8x8 stride 4; fp32 NCHW frames or uint8 NHWC frames): phase-plane bands.
+// With channel planes as they are in memory, the B fragment of tap (c, kh, kw) — 8 consecutive output pixels, i.e. input columns
+// 4*ox + kw — is eight 2-byte LDS reads 8 bytes apart, and with the pixel-offset table the MFMA loop issued 11 LDS instructions per
+// MFMA: the kernel was LDS-issue-bound at ~3 TB/s of frames.  Here the band is de-interleaved while it is staged: plane phi of a row
+// holds columns phi, phi + 4, phi + 8, ... so that 8 consecutive output pixels of tap kw are the 8 consecutive elements
+// j = ox + kw / 4 of plane kw % 4.  Output pixels are enumerated per row in blocks of 8 (row padded to OWP = 8 * ceil(OW / 8) slots, dY^T
+// zero in the padding), a block's fragment is ONE aligned ds_read_b128 plus one ds_read_b32, shifted by one element with
+// v_alignbit for the taps kw >= 4.  Plane stride PSTR (multiple of 16 B with an odd number of 16-byte slots) makes the 16 distinct
+// (kh, phi) addresses of a ds_read_b128 lane group fall on 16 different bank quads.
+struct W1P {
+    const void* X; const void* dY; int dy_dtype;
+    int Nimg, H, W, OH, OW, OWP, R, PSTR, AT_ROW;
+    long dy_sn, dy_sy, dy_sx;
+    float* partial_w; float* partial_b;
+    int u8, pad; const int* shift; const int* fidx;
+    int dbg;
+};
+
+// U8: uint8 NHWC frames (else fp32 NCHW planes); dY is bf16 (other gradients dtypes take the generic kernel).  Both are compile-time so
+// that no join of two load paths makes the compiler wait for the prefetch early.
+template <int XCH, int YCH, bool U8>
+__global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
+    constexpr int NT = 512, C = 3, S = 4, K = 192, KTN = 6, YCPP = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bands = (p.OH + p.R - 1) / p.R;
+    // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
+    // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
+    const int nunits = ((p.Nimg - blockIdx.x + gridDim.x - 1) / gridDim.x) * bands;     // this workgroup's units
+    const int rows_max = (p.R - 1) * S + 8;
+    const int nbx = p.OWP / 8;                              // pixel blocks per output row
+    const int AT_ROW = p.AT_ROW;                            // dY^T row stride (bytes): an odd number of 16-byte slots
+    char* xband = smem;                                     // [c][row][phi][PSTR bytes]
+    const int xbytes = C * rows_max * 4 * p.PSTR;
+    char* at = smem + xbytes;                               // [32][AT_ROW]
+
+    // this lane's tap inside the wave's k tile: k = (c, kh, kw) = wave * 32 + r
+    const bool live = wave < KTN;
+    const int k = (live ? wave : 0) * 32 + r, kc = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
+    const int koff = ((kc * rows_max + kh) * 4 + (kw & 3)) * p.PSTR;
+    const unsigned ksh = (kw >> 2) * 16;                    // taps kw >= 4 read plane kw - 4 one element further
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    // zero once: the dY^T padding slots and the plane elements past W / 4 are read (times zero / as never-used taps) but never written
+    for (int o = tid * 16; o < xbytes + 32 * AT_ROW; o += NT * 16) *(uint4*)(smem + o) = make_uint4(0, 0, 0, 0);
+
+    // prefetched data stays RAW in registers (fp32 frames: 8 floats per item; uint8 frames: the aligned dword windows) and is
+    // converted in stage_store: any ALU use at load time would put the wait for the loads in front of the MFMA loop they overlap
+    float4 xraw[XCH][2]; uint4 ypre[YCH];
+    auto unit_geom = [&](int unit, int& n, int& r0, int& R, int& rows) {
+        const int b = unit % bands;
+        n = blockIdx.x + (unit / bands) * gridDim.x;
+        r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + 8;
+    };
+    auto stage_load = [&](int unit) {
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int nflt = rows * p.W, items = (nflt + 7) / 8;
+        if (U8) {                                          // uint8 NHWC frames: item = 8 elements of all three planes = 2 x (4 aligned dwords)
+            const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
+            const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < XCH / 3; ++i) {
+                const int id = tid + i * NT;
+                const bool inb = id < items;
+                uint32_t raw[8];
+                u8_band_chunk3_load(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad, raw);
+                xraw[i][0] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+                xraw[i][1] = make_float4(__uint_as_float(raw[4]), __uint_as_float(raw[5]), __uint_as_float(raw[6]), __uint_as_float(raw[7]));
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {                    // fp32 planes: the band rows of a channel are contiguous -> flat copy, 8 floats per item
+            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+            const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
+            const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
+            xraw[j][0] = *(const float4*)((const float*)p.X + off);
+            xraw[j][1] = *(const float4*)((const float*)p.X + (inb2 ? off + 4 : off));
+        }
+        const int npix = R * p.OW, ycc = tid % YCPP;
+#pragma unroll
+        for (int j = 0; j < YCH; ++j) {
+            const int q = tid / YCPP + j * (NT / YCPP);
+            const bool inb = q < npix;
+            // the output pixels of a band are contiguous in dY (dy_sy == OW * dy_sx)
+            const long off = (long)n * p.dy_sn + (long)r0 * p.dy_sy + (long)(inb ? q : 0) * p.dy_sx + ycc * 8;
+            const uint4 v = *(const uint4*)((const uint16_t*)p.dY + off);   // (bias partial sums are taken in stage_store, off the load path)
+            ypre[j] = v;
+        }
+    };
+    auto stage_store = [&](int unit) {
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int nflt = rows * p.W, items = (nflt + 7) / 8;
+        const bool w8 = (p.W & 7) == 0;                    // chunks never straddle a row and start at an even plane index
+        uint4 xpre[XCH];
+        if (U8) {
+            const int sx = p.shift ? p.shift[2 * n] : p.pad;
+#pragma unroll
+            for (int i = 0; i < XCH / 3; ++i) {
+                const int id = tid + i * NT;
+                const bool inb = id < items;
+                const uint32_t raw[8] = {__float_as_uint(xraw[i][0].x), __float_as_uint(xraw[i][0].y), __float_as_uint(xraw[i][0].z), __float_as_uint(xraw[i][0].w),
+                                         __float_as_uint(xraw[i][1].x), __float_as_uint(xraw[i][1].y), __float_as_uint(xraw[i][1].z), __float_as_uint(xraw[i][1].w)};
+                u8_band_chunk3_convert(p.W, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, raw, xpre[i], xpre[XCH / 3 + i], xpre[2 * (XCH / 3) + i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = tid + (j % (XCH / C)) * NT;
+                const bool inb2 = id * 8 + 8 <= nflt;
+                const float4 a = xraw[j][0], b = xraw[j][1];
+                xpre[j] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), inb2 ? pack_bf16x2(b.x, b.y) : 0u, inb2 ? pack_bf16x2(b.z, b.w) : 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+            if (id >= items || (p.dbg & 2)) continue;
+            const int e0 = id * 8, row = e0 / p.W, col = e0 - row * p.W;
+            const uint32_t w[4] = {xpre[j].x, xpre[j].y, xpre[j].z, xpre[j].w};          // columns col .. col + 7, two per dword
+            char* dst = xband + (long)((c * rows_max + row) * 4) * p.PSTR + (col >> 2) * 2;
+            if (w8) {                                      // plane phi gets columns col + phi and col + 4 + phi: elements j, j + 1
+                *(uint32_t*)(dst) = (w[0] & 0xffffu) | (w[2] << 16);
+                *(uint32_t*)(dst + p.PSTR) = (w[0] >> 16) | (w[2] & 0xffff0000u);
+                *(uint32_t*)(dst + 2 * p.PSTR) = (w[1] & 0xffffu) | (w[3] << 16);
+                *(uint32_t*)(dst + 3 * p.PSTR) = (w[1] >> 16) | (w[3] & 0xffff0000u);
+            } else {                                       // W % 8 == 4: the second quad may be the start of the next row
+                *(uint16_t*)(dst) = (uint16_t)w[0]; *(uint16_t*)(dst + p.PSTR) = (uint16_t)(w[0] >> 16);
+                *(uint16_t*)(dst + 2 * p.PSTR) = (uint16_t)w[1]; *(uint16_t*)(dst + 3 * p.PSTR) = (uint16_t)(w[1] >> 16);
+                if (e0 + 4 < nflt) {
+                    const bool wrap = col + 4 >= p.W;
+                    char* d2 = wrap ? xband + (long)((c * rows_max + row + 1) * 4) * p.PSTR : dst + 2;
+                    *(uint16_t*)(d2) = (uint16_t)w[2]; *(uint16_t*)(d2 + p.PSTR) = (uint16_t)(w[2] >> 16);
+                    *(uint16_t*)(d2 + 2 * p.PSTR) = (uint16_t)w[3]; *(uint16_t*)(d2 + 3 * p.PSTR) = (uint16_t)(w[3] >> 16);
+                }
+            }
+        }
+        const int npix = R * p.OW, ycc = tid % YCPP;
+#pragma unroll
+        for (int j = 0; j < YCH; ++j) {
+            const int q = tid / YCPP + j * (NT / YCPP);
+            if (q < npix && !(p.dbg & 4)) {
+                const int oy = q / p.OW, slot = oy * p.OWP + (q - oy * p.OW);
+                const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *(uint16_t*)(at + (ycc * 8 + e) * AT_ROW + slot * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+            }
+        }
+    };
+
+    int unit = 0;
+    __syncthreads();                                         // the zero fill precedes the first stage_store
+    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    __syncthreads();
+    for (; unit < nunits; ++unit) {
+        const int next = unit + 1;
+        if (next < nunits && !(p.dbg & 8)) stage_load(next);
+
+        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        if (live && !(p.dbg & 1)) {
+            const int nblk = R * nbx, nsteps = (nblk + 1) / 2;
+            int oy = 0, bx = h;                              // this lane half's pixel block: b = 2 * s + h
+            if (bx >= nbx) { bx -= nbx; ++oy; }
+            // one step = 16 pixel slots: dY^T fragment (ds_read_b128), X fragment (ds_read_b128 + ds_read_b32, realigned), one MFMA
+            auto fetch = [&](int st, uint4& a, uint4& w, uint32_t& w4) {
+                const bool valid = 2 * st + h < nblk;        // odd block count: the last step's second block does not exist
+                a = *(const uint4*)(at + r * AT_ROW + (2 * st + h) * 16);
+                if (!valid) a = make_uint4(0, 0, 0, 0);
+                const char* src = xband + koff + (valid ? oy : 0) * (S * 4) * p.PSTR + (valid ? bx : 0) * 16;
+                w = *(const uint4*)src;
+                w4 = *(const uint32_t*)(src + 16);
+                bx += 2;
+                if (bx >= nbx) { bx -= nbx; ++oy; }
+            };
+            auto mma = [&](f32x16_t& c, const uint4& a, const uint4& w, uint32_t w4) {
+                union { uint4 u; bf16x8_t b; } af; af.u = a;
+                union { uint32_t w[4]; bf16x8_t b; } x;
+                x.w[0] = __builtin_amdgcn_alignbit(w.y, w.x, ksh); x.w[1] = __builtin_amdgcn_alignbit(w.z, w.y, ksh);
+                x.w[2] = __builtin_amdgcn_alignbit(w.w, w.z, ksh); x.w[3] = __builtin_amdgcn_alignbit(w4, w.w, ksh);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, x.b, c, 0, 0, 0);
+            };
+            // software-pipelined: the next step's fragments are in flight while this step's MFMA issues (one accumulator: a second
+            // chain or deeper prefetch spills at the 128-VGPR budget of two workgroups per CU)
+            if (nsteps > 0) {
+                uint4 a0, w0; uint32_t e0;
+                fetch(0, a0, w0, e0);
+                for (int st = 1; st < nsteps; ++st) {
+                    uint4 a1, w1; uint32_t e1;
+                    fetch(st, a1, w1, e1);
+                    mma(acc, a0, w0, e0);
+                    a0 = a1; w0 = w1; e0 = e1;
+                }
+                mma(acc, a0, w0, e0);
+            }
+        }
+        __syncthreads();
+        if (next < nunits) stage_store(next);
+        __syncthreads();
+    }
+
+    // ---- slabs: dW partial [32][K] (lane = k column, register = channel row) and the bias partial
+    if (live) {
+        float* pw = p.partial_w + (long)blockIdx.x * 32 * K;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pw[(long)acc_row(e, lane) * K + k] = acc[e];
+    }
+    if (p.partial_b) {
+        float* red = (float*)smem;                            // bands are dead: reuse LDS, [NT][8] floats = 16 KB
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 32) {
+            const int ycc = tid / 8, e = tid % 8;
+            float sacc = 0.f;
+            for (int q = ycc; q < NT; q += YCPP) sacc += red[q * 8 + e];   // threads with tid % YCPP == ycc, fixed order
+            p.partial_b[(long)blockIdx.x * 32 + tid] = sacc;
+        }
+    }
+}
+
+int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, int accumulate, hipStream_t s) {
+    constexpr int XCH = 3, YCH = 2, K = 192;
+    if (p.W % 4) return -1;
+    p.OWP = (p.OW + 7) / 8 * 8;
+    p.PSTR = ((p.OWP + 2) * 2 + 15) / 16 * 16;
+    if (((p.PSTR / 16) & 1) == 0) p.PSTR += 16;
+    auto at_row = [&](int R) -> int { int a = R * p.OWP * 2 + 16; if (((a / 16) & 1) == 0) a += 16; return a; };
+    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + 32L * at_row(R) + 64; };
+    auto fits = [&](int R) -> bool {
+        const long rows = (R - 1) * 4 + 8;
+        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512 && (long)R * p.OW * 4 <= (long)YCH * 512;
+    };
+    int R = p.OH;
+    while (R > 1 && !fits(R)) --R;
+    if (!fits(R)) return -1;
+    const int bands = (p.OH + R - 1) / R;
+    R = (p.OH + bands - 1) / bands;
+    p.R = R; p.AT_ROW = at_row(R);
+    const int slots = 512;                                   // two workgroups per CU
+    const int per = (p.Nimg + slots - 1) / slots;            // frames per workgroup
+    const int grid = (p.Nimg + per - 1) / per;
+    if ((long)grid * 32 * (K + 1) * 4 > ws_bytes) return -1;
+    p.partial_w = (float*)ws;
+    p.partial_b = db ? p.partial_w + (long)grid * 32 * K : nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv1_wgrad_kernel<XCH, YCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv1_wgrad_kernel<XCH, YCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
+        attr_set = true;
+    }
+    if (p.u8) conv1_wgrad_kernel<XCH, YCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    else conv1_wgrad_kernel<XCH, YCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    const long Rw = 32L * K;
+    wband_reduce_kernel<<<(unsigned)((Rw + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, 0, 64);
+    if (db) wband_reduce_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, grid, 32, accumulate, 0, 0);
+    return 0;
+}
+
 template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC>
 int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s) {
     constexpr int COUT = CT * 32, K = TH * TW * C;
@@ -361,8 +628,17 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     int rc = 1;
     if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1) rc = launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2) rc = launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
-    else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0)))
-        rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
+    else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0))) {
+        if (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16) rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
+        else {
+            W1P q;
+            q.X = x; q.dY = dy; q.dy_dtype = dy_dtype; q.Nimg = N; q.H = H; q.W = W; q.OH = p.OH; q.OW = p.OW;
+            q.dy_sn = p.dy_sn; q.dy_sy = p.dy_sy; q.dy_sx = p.dy_sx;
+            q.u8 = u8; q.pad = pad; q.shift = shift; q.fidx = fidx;
+            q.dbg = getenv("HULC_W1_DBG") ? atoi(getenv("HULC_W1_DBG")) : 0;
+            rc = launch_conv1_wgrad(q, dw, db, ws, ws_bytes, accumulate, s);
+        }
+    }
     else return 1;
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv wgrad band: could not raise the dynamic LDS limit");

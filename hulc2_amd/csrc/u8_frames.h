@@ -64,3 +64,68 @@ HULC_DEVICE void u8_band_chunk3(const unsigned char* img, int H, int W, int row0
     p1 = make_uint4(a[1][0], a[1][1], b[1][0], b[1][1]);
     p2 = make_uint4(a[2][0], a[2][1], b[2][0], b[2][1]);
 }
+
+// ---- the same staging split in two: the LOAD half only issues the dword loads (results untouched, so a prefetch really stays in
+// flight behind other work), the CONVERT half redoes the cheap index arithmetic and turns the raw windows into plane data.
+HULC_DEVICE void u8_half4_load(const unsigned char* img, int H, int W, int row, int x, int dx, int dy, bool live, uint32_t* w) {
+    int yy = row + dy;
+    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+    const int xx0 = x + dx;
+    const int pw = xx0 < 0 ? 0 : (xx0 > W - 4 ? W - 4 : xx0);
+    const int b0 = (yy * W + pw) * 3, sh = b0 & 3;
+    const uint32_t* q = (const uint32_t*)(img + (live ? b0 - sh : 0));
+    w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
+    w[3] = q[(live && sh) ? 3 : 0];                              // the fourth dword is only in bounds (and only needed) when sh > 0
+}
+
+HULC_DEVICE void u8_half4_convert(int W, int x, int dx, bool live, const uint32_t* w, uint32_t (&o)[3][2]) {
+    const int xx0 = x + dx;
+    const int pw = xx0 < 0 ? 0 : (xx0 > W - 4 ? W - 4 : xx0);
+    const int d = xx0 - pw;
+    const int sh = (pw * 3) & 3;                                 // (yy * W * 3) is a multiple of 4 (W % 4 == 0)
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), e1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh),
+                   e2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
+    float f[4][3];
+    f[0][0] = (float)(e0 & 0xff);         f[0][1] = (float)((e0 >> 8) & 0xff);  f[0][2] = (float)((e0 >> 16) & 0xff);
+    f[1][0] = (float)(e0 >> 24);          f[1][1] = (float)(e1 & 0xff);         f[1][2] = (float)((e1 >> 8) & 0xff);
+    f[2][0] = (float)((e1 >> 16) & 0xff); f[2][1] = (float)(e1 >> 24);          f[2][2] = (float)(e2 & 0xff);
+    f[3][0] = (float)((e2 >> 8) & 0xff);  f[3][1] = (float)((e2 >> 16) & 0xff); f[3][2] = (float)(e2 >> 24);
+    if (d != 0) {
+        float g[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int j = i + d; j = j < 0 ? 0 : (j > 3 ? 3 : j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[i][c] = j == 0 ? f[0][c] : (j == 1 ? f[1][c] : (j == 2 ? f[2][c] : f[3][c]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[i][c] = g[i][c];
+    }
+    const float k = 2.0f / 255.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v0 = live ? __builtin_fmaf(f[0][c], k, -1.f) : 0.f, v1 = live ? __builtin_fmaf(f[1][c], k, -1.f) : 0.f;
+        const float v2 = live ? __builtin_fmaf(f[2][c], k, -1.f) : 0.f, v3 = live ? __builtin_fmaf(f[3][c], k, -1.f) : 0.f;
+        o[c][0] = pack_bf16x2(v0, v1); o[c][1] = pack_bf16x2(v2, v3);
+    }
+}
+
+HULC_DEVICE void u8_band_chunk3_load(const unsigned char* img, int H, int W, int row0, int e0, int nflt, int dx, int dy, uint32_t* raw) {
+    const int rr = e0 / W, x = e0 - rr * W;
+    const bool wrap = x + 4 >= W;
+    u8_half4_load(img, H, W, row0 + rr, x, dx, dy, e0 < nflt, raw);
+    u8_half4_load(img, H, W, row0 + rr + (wrap ? 1 : 0), wrap ? 0 : x + 4, dx, dy, e0 + 4 < nflt, raw + 4);
+}
+
+HULC_DEVICE void u8_band_chunk3_convert(int W, int e0, int nflt, int dx, const uint32_t* raw, uint4& p0, uint4& p1, uint4& p2) {
+    const int rr = e0 / W, x = e0 - rr * W;
+    const bool wrap = x + 4 >= W;
+    uint32_t a[3][2], b[3][2];
+    u8_half4_convert(W, x, dx, e0 < nflt, raw, a);
+    u8_half4_convert(W, wrap ? 0 : x + 4, dx, e0 + 4 < nflt, raw + 4, b);
+    p0 = make_uint4(a[0][0], a[0][1], b[0][0], b[0][1]);
+    p1 = make_uint4(a[1][0], a[1][1], b[1][0], b[1][1]);
+    p2 = make_uint4(a[2][0], a[2][1], b[2][0], b[2][1]);
+}
