@@ -85,6 +85,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
     const int cc = tid % CPP;
     uint4 pre[MAXCH];
+    unsigned pre_live = 0;               // bit j: chunk j of the prefetched band is inside the frame (else it is zero padding)
     // unit -> first frame n, frames in the unit fu, first output row r0, output rows R, band rows per frame
     auto band_rows = [&](int unit, int& n, int& fu, int& r0, int& R, int& rows) {
         if (MULTI) { n = unit * p.F; fu = n + p.F <= p.Nimg ? p.F : p.Nimg - n; r0 = 0; R = p.OHmax; }
@@ -104,8 +105,10 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             const bool inb = px < npx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             // unconditional load from a clamped address, then select (no branch around the load)
             const long off = inb ? (long)(n + f) * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
-            const uint4 t = band_load_bits(p.X, p.x_dtype, off);
-            pre[j].x = inb ? t.x : 0u; pre[j].y = inb ? t.y : 0u; pre[j].z = inb ? t.z : 0u; pre[j].w = inb ? t.w : 0u;
+            // the loaded value is not touched here (the select happens in stage_store): an ALU use would put the wait for the
+            // prefetch in front of the MFMA loop it overlaps
+            pre[j] = band_load_bits(p.X, p.x_dtype, off);
+            pre_live = j == 0 ? (inb ? 1u : 0u) : (pre_live | ((inb ? 1u : 0u) << j));
         }
     };
     auto stage_store = [&](int unit) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j) {
             const int px = tid / CPP + j * (NT / CPP);
-            if (px < npx) *(uint4*)(band + px * PS + cc * 16) = pre[j];
+            if (px < npx) *(uint4*)(band + px * PS + cc * 16) = ((pre_live >> j) & 1u) ? pre[j] : make_uint4(0, 0, 0, 0);
         }
     };
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                 bsum[0] += keep * a.x; bsum[1] += keep * a.y; bsum[2] += keep * a.z; bsum[3] += keep * a.w;
                 bsum[4] += keep * b.x; bsum[5] += keep * b.y; bsum[6] += keep * b.z; bsum[7] += keep * b.w;
             }
-            ypre[j].x = inb ? v.x : 0u; ypre[j].y = inb ? v.y : 0u; ypre[j].z = inb ? v.z : 0u; ypre[j].w = inb ? v.w : 0u;
+            ypre[j] = v;                                     // (pixels past npix are zeroed in stage_store, not here: see the note above)
         }
     };
     auto stage_store = [&](int unit) {
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
             const int q = tid / YCPP + j * (NT / YCPP);
-            if (q < npad) {                                  // pixels in [npix, npad) carry zeros (ypre is zero there)
-                const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
+            if (q < npad) {                                  // pixels in [npix, npad) carry zeros
+                const bool inb = q < npix;
+                const uint32_t w[4] = {inb ? ypre[j].x : 0u, inb ? ypre[j].y : 0u, inb ? ypre[j].z : 0u, inb ? ypre[j].w : 0u};
                 if (p.dy_dtype == HULC_BF16) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
