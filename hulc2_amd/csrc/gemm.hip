@@ -33,30 +33,67 @@ struct GemmP {
     float* rowsum; int rowsum_accumulate;  // optional: rowsum[m] (+)= sum_k A[m][k] (row-major A only): the bias gradient of a weight-gradient GEMM
 };
 
-// Load the 8-element k-chunk (row r, k0..k0+7) of an operand.
-//   KMAJOR : operand stored [rows][K], k contiguous   -> one or two 16-byte loads
-//   !KMAJOR: operand stored [K][rows], row contiguous -> 8 strided loads (coalesced across lanes)
-template <bool KMAJOR>
-HULC_DEVICE void load_operand_chunk(Chunk8& c, const void* base, int dtype, long ld, int rows, int K, int r, int k0) {
-    const bool in_k = k0 < K;
-    const int kc = in_k ? k0 : 0;  // branch-free: load from a clamped address, zero afterwards (see chunk_keep_if)
-    r = r < rows ? r : rows - 1;   // clamp: out-of-range rows are computed but never stored
+// Staging is split in two so that a prefetch really stays in flight behind the MFMAs of the current tile: the LOAD half only issues
+// global loads into registers (raw bits, addresses clamped to stay valid) and never touches a loaded value — any ALU use (bf16 -> f32
+// expansion, bounds select, a bias partial sum) would make the compiler wait for the load right there, in front of the MFMA loop, and
+// turn every k-tile into a full memory round trip; the FINISH half runs after the MFMAs, redoes the cheap index arithmetic, converts /
+// masks, and writes the LDS tile.
+//
+// The operand dtypes (DT) and the staging mode are template parameters: a run-time branch around a load makes hipcc wait for it at the
+// join, which is the same serialisation again.
+//
+// raw 8-element k-chunk (row r, k0..k0+7), held in the 8 dwords of a Chunk8 as bit patterns:
+//   KMAJOR (operand stored [rows][K], k contiguous): f32 -> 8 float bit patterns; bf16 -> 4 dwords of packed pairs (v[0..3])
+//   !KMAJOR (stored [K][rows]): element j's raw bits (f32 bits, or the bf16 bits zero-extended) in dword j — 8 strided loads, coalesced across lanes
+template <bool KMAJOR, int DT>
+HULC_DEVICE void load_operand_chunk_raw(Chunk8& c, const void* base, long ld, int rows, int K, int r, int k0) {
+    constexpr int dtype = DT;
+    const int kc = k0 < K ? k0 : 0;   // clamped (always valid) address; FINISH zeroes what lies past K
+    r = r < rows ? r : rows - 1;      // out-of-range rows are computed but never stored
     if (KMAJOR) {
-        chunk_load_contig(c, base, dtype, (long)r * ld + kc);
-        chunk_keep_if(c, in_k);
+        if (dtype == HULC_F32) {
+            const float4* q = (const float4*)((const float*)base + (long)r * ld + kc);
+            const float4 a = q[0], b = q[1];
+            c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w; c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
+        } else {
+            const uint4 u = *(const uint4*)((const uint16_t*)base + (long)r * ld + kc);
+            c.v[0] = __uint_as_float(u.x); c.v[1] = __uint_as_float(u.y); c.v[2] = __uint_as_float(u.z); c.v[3] = __uint_as_float(u.w);
+        }
     } else {
-        const int nvalid = in_k ? K - k0 : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int kk = (j < nvalid) ? kc + j : 0;
-            const float v = load_elem(base, dtype, (long)kk * ld + r);
-            c.v[j] = (j < nvalid) ? v : 0.f;
+            const int kk = kc + j < K ? kc + j : 0;
+            if (dtype == HULC_F32) c.v[j] = ((const float*)base)[(long)kk * ld + r];
+            else c.v[j] = __uint_as_float((unsigned)((const uint16_t*)base)[(long)kk * ld + r]);
         }
     }
 }
 
-template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK>
+template <bool KMAJOR, int DT>
+HULC_DEVICE void finish_operand_chunk(Chunk8& c, int K, int k0) {
+    constexpr int dtype = DT;
+    const int nvalid = k0 < K ? K - k0 : 0;               // k-major operands have K % 8 == 0: nvalid is 0 or >= 8
+    if (KMAJOR) {
+        if (dtype != HULC_F32) {
+            const unsigned u[4] = {__float_as_uint(c.v[0]), __float_as_uint(c.v[1]), __float_as_uint(c.v[2]), __float_as_uint(c.v[3])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c.v[2 * j] = __uint_as_float(u[j] << 16); c.v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+        }
+        chunk_keep_if(c, nvalid > 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = dtype == HULC_F32 ? c.v[j] : __uint_as_float(__float_as_uint(c.v[j]) << 16);
+            c.v[j] = j < nvalid ? v : 0.f;
+        }
+    }
+}
+
+// ADT / BDT: operand storage types (HULC_F32 / HULC_BF16).  MICRO (both operands row-major, tiles fully inside the matrices, aligned:
+// checked by the launcher): 8(k) x 4 / 8 x 8 micro-tile staging, see below.
+template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK, int ADT, int BDT, bool MICRO>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __restrict__ slabs, int splitk) {
+    static_assert(!MICRO || (!AK && !BK), "micro-tile staging is for row-major operands");
     using T = MmaTraits<CT>;
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -79,25 +116,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Row-major (reduction-major) fp32 operands — the weight-gradient GEMMs dW = dY^T X — are staged as 8(k) x 4(rows)
-    // micro-tiles: eight 16-byte loads per thread give four complete k-chunks (an in-register transpose), instead of
-    // 32 scalar loads.  lane -> (k-group fastest, row group) keeps the LDS chunk writes conflict-free and each load
-    // instruction a set of 256-byte row segments.  A micro-tiles go to the first threads, B micro-tiles to the next.
-    // Row-major bf16 operands (the recurrent decoder's weight gradients read the bf16 state copies) use 8(k) x 8(rows) micro-tiles:
-    // eight 16-byte loads, a 16-bit 8x8 transpose with v_perm, eight 16-byte LDS chunk writes.
-    constexpr int MTA = BM / 4 * NCH, MTB = BN / 4 * NCH;                 // fp32 micro-tiles per operand tile
-    constexpr int MTA16 = BM / 8 * NCH, MTB16 = BN / 8 * NCH;             // bf16 micro-tiles
-    constexpr bool IS_BF16 = sizeof(CT) == 2;
-    const bool a_micro = !AK && p.a_dtype == HULC_F32 && p.lda % 4 == 0 && ((uintptr_t)p.A % 16) == 0 && m0 + BM <= p.M && m0 % 4 == 0;
-    const bool b_micro = !BK && p.b_dtype == HULC_F32 && p.ldb % 4 == 0 && ((uintptr_t)p.B % 16) == 0 && n0 + BN <= p.N && n0 % 4 == 0;
-    const bool a_micro16 = IS_BF16 && !AK && p.a_dtype == HULC_BF16 && p.lda % 8 == 0 && ((uintptr_t)p.A % 16) == 0 && m0 + BM <= p.M;
-    const bool b_micro16 = IS_BF16 && !BK && p.b_dtype == HULC_BF16 && p.ldb % 8 == 0 && ((uintptr_t)p.B % 16) == 0 && n0 + BN <= p.N;
-    const int a_thr = a_micro16 ? MTA16 : (a_micro ? MTA : 0), b_thr = b_micro16 ? MTB16 : (b_micro ? MTB : 0);
-    const int MICRO_B0 = (a_thr + b_thr <= NT) ? a_thr : 0;                // first thread of the B micro-tiles
-    union Stage { Chunk8 c[4]; uint4 q[8]; };                             // fp32 micro-tile (4 chunks) or bf16 micro-tile (8 raw rows)
-    union StageA { Chunk8 c[AK ? A_PER : (A_PER > 4 ? A_PER : 4)]; uint4 q[8]; } sa;
-    union StageB { Chunk8 c[BK ? B_PER : (B_PER > 4 ? B_PER : 4)]; uint4 q[8]; } sb;
-    Chunk8* const ra = sa.c; Chunk8* const rb = sb.c;
+    // Row-major (reduction-major) operands — the weight-gradient GEMMs dW = dY^T X — are staged as micro-tiles (MICRO): a thread
+    // loads eight 16-byte rows (k0 .. k0+7) of 4 fp32 or 8 bf16 consecutive matrix rows and transposes them in registers into
+    // complete k-chunks (fp32: a renaming; bf16: a 16-bit 8x8 transpose with v_perm) instead of 32 / 64 scalar loads.
+    // lane -> (k-group fastest, row group) keeps the LDS chunk writes conflict-free.  A micro-tiles go to the first threads, B micro-tiles
+    // to the next; a thread's operand is chosen by SELECTS on the base / stride / row (no branch around the loads), spare threads
+    // repeat the last B tile's loads and skip the store.
+    constexpr int A_MR = ADT == HULC_F32 ? 4 : 8, B_MR = BDT == HULC_F32 ? 4 : 8;      // matrix rows per micro-tile
+    constexpr int MTA = BM / A_MR * NCH, MTB = BN / B_MR * NCH;
+    static_assert(!MICRO || MTA + MTB <= NT, "one micro-tile per thread");
+    Chunk8 ra[MICRO ? 1 : A_PER], rb[MICRO ? 1 : B_PER];
+    uint4 mq[MICRO ? 8 : 1];
     const int nkt_all = (p.K + KT - 1) / KT;
     const int kt_per = (nkt_all + splitk - 1) / splitk;            // blockIdx.z owns k tiles [kt0, kt1)
     const int kt0 = blockIdx.z * kt_per;
@@ -109,138 +138,143 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     auto a_map = [&](int id, int& r, int& ch) { if (AK) { r = id / NCH; ch = id % NCH; } else { r = id % BM; ch = id / BM; } };
     auto b_map = [&](int id, int& r, int& ch) { if (BK) { r = id / NCH; ch = id % NCH; } else { r = id % BN; ch = id / BN; } };
 
-    // 8 x 4 micro-tile: chunks c[i] (i = row within the group) from eight float4 rows of the source
-    auto load_micro = [&](Chunk8* c, const void* base, long ld, int row0, int k0, int K) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool in_k = k0 + j < K;
-            const float4 v = *(const float4*)((const float*)base + (long)(in_k ? k0 + j : 0) * ld + row0);
-            c[0].v[j] = in_k ? v.x : 0.f; c[1].v[j] = in_k ? v.y : 0.f; c[2].v[j] = in_k ? v.z : 0.f; c[3].v[j] = in_k ? v.w : 0.f;
-        }
-    };
-    auto load_micro16 = [&](uint4* q, const void* base, long ld, int row0, int k0, int K) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool in_k = k0 + j < K;
-            const uint4 v = *(const uint4*)((const uint16_t*)base + (long)(in_k ? k0 + j : 0) * ld + row0);
-            q[j].x = in_k ? v.x : 0u; q[j].y = in_k ? v.y : 0u; q[j].z = in_k ? v.z : 0u; q[j].w = in_k ? v.w : 0u;
-        }
-    };
+    // micro-tile role of this thread
+    const bool m_is_b = tid >= MTA;
+    const int m_t = m_is_b ? (tid - MTA < MTB ? tid - MTA : MTB - 1) : tid;
+    const bool m_live = tid < MTA + MTB;
+    // (row-group-fastest lanes — every load instruction a few full cache lines — measured: bf16 tiles unchanged, the LDS chunk writes
+    // then collide; fp32 tiles 115 -> 89 us at 2048^3, not taken because the fused row sums rely on the k-groups being adjacent lanes)
+    const int m_kg = m_t % NCH, m_rg = m_t / NCH;
+    const char* m_base = (const char*)(m_is_b ? p.B : p.A);
+    const long m_ld = m_is_b ? p.ldb : p.lda;
+    const int m_esz = (m_is_b ? BDT : ADT) == HULC_F32 ? 4 : 2;
+    // edge blocks: a micro-tile that would leave the matrix is moved back inside (its rows are computed twice and stored never)
+    const int m_row_want = m_is_b ? n0 + m_rg * B_MR : m0 + m_rg * A_MR;
+    const int m_row_max = m_is_b ? p.N - B_MR : p.M - A_MR;
+    const int m_row0 = m_row_want < m_row_max ? m_row_want : m_row_max;
+    const bool m_inside = m_row_want <= m_row_max;
+
+    // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (fp32 operands: before
+    // bf16 rounding)
+    const bool do_rowsum = !AK && p.rowsum != nullptr && blockIdx.y == 0;
+    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
     // 16-bit 8x8 transpose: chunk of row i = {q[0][i], ..., q[7][i]}; one v_perm per output dword
     auto store_micro16 = [&](char* dst_rows, const uint4* q, int ch) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const unsigned sel = (i & 1) ? 0x07060302u : 0x05040100u;
             uint4 o;
-            const unsigned* w0 = (const unsigned*)&q[0];
 #define HULC_QW(j) (((const unsigned*)&q[j])[i >> 1])
             o.x = __builtin_amdgcn_perm(HULC_QW(1), HULC_QW(0), sel);
             o.y = __builtin_amdgcn_perm(HULC_QW(3), HULC_QW(2), sel);
             o.z = __builtin_amdgcn_perm(HULC_QW(5), HULC_QW(4), sel);
             o.w = __builtin_amdgcn_perm(HULC_QW(7), HULC_QW(6), sel);
 #undef HULC_QW
-            (void)w0;
             *(uint4*)(dst_rows + i * HULC_ROWB + ch * 16) = o;
         }
     };
-    // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (fp32 operands: before
-    // bf16 rounding)
-    const bool do_rowsum = !AK && p.rowsum != nullptr && blockIdx.y == 0;
-    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto load_tiles = [&](int kt) {
-        if (!AK && a_micro16) {
-            if (tid < MTA16) {
-                load_micro16(sa.q, p.A, p.lda, m0 + (tid / NCH) * 8, kt * KT + (tid % NCH) * 8, p.K);
-                if (do_rowsum) {
+
+    auto load_tiles = [&](int kt) {                          // LOAD half: issues loads, touches no loaded value
+        if constexpr (MICRO) {
+            const int k0 = kt * KT + m_kg * 8;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const unsigned w[4] = {sa.q[j].x, sa.q[j].y, sa.q[j].z, sa.q[j].w};
+            for (int j = 0; j < 8; ++j)
+                mq[j] = *(const uint4*)(m_base + ((long)(k0 + j < p.K ? k0 + j : 0) * m_ld + m_row0) * m_esz);
+        } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) rs[i] += __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
-                    }
-                }
-            }
-        } else if (!AK && a_micro) {
-            if (tid < MTA) {
-                load_micro(ra, p.A, p.lda, m0 + (tid / NCH) * 4, kt * KT + (tid % NCH) * 8, p.K);
-                if (do_rowsum) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) rs[i] += ra[i].v[j];
-                }
-            }
-        } else
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            int id = tid + q * NT;
-            if (A_CH % NT == 0 || id < A_CH) {
+            for (int q = 0; q < A_PER; ++q) {
+                int id = tid + q * NT;
+                if (A_CH % NT != 0 && id >= A_CH) id = A_CH - 1;     // spare threads repeat the last chunk (no branch around the load)
                 int r, ch; a_map(id, r, ch);
-                load_operand_chunk<AK>(ra[q], p.A, p.a_dtype, p.lda, p.M, p.K, m0 + r, kt * KT + ch * 8);
-                if (!AK && do_rowsum && m0 + r < p.M) {           // row = id % BM is the same for every q of a thread (NT % BM == 0)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) rs[0] += ra[q].v[j];
-                }
+                load_operand_chunk_raw<AK, ADT>(ra[q], p.A, p.lda, p.M, p.K, m0 + r, kt * KT + ch * 8);
             }
-        }
-        if (!BK && b_micro16) {
-            const int t = tid - MICRO_B0;
-            if (t >= 0 && t < MTB16) load_micro16(sb.q, p.B, p.ldb, n0 + (t / NCH) * 8, kt * KT + (t % NCH) * 8, p.K);
-        } else if (!BK && b_micro) {
-            const int t = tid - MICRO_B0;
-            if (t >= 0 && t < MTB) load_micro(rb, p.B, p.ldb, n0 + (t / NCH) * 4, kt * KT + (t % NCH) * 8, p.K);
-        } else
 #pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            int id = tid + q * NT;
-            if (B_CH % NT == 0 || id < B_CH) {
+            for (int q = 0; q < B_PER; ++q) {
+                int id = tid + q * NT;
+                if (B_CH % NT != 0 && id >= B_CH) id = B_CH - 1;
                 int r, ch; b_map(id, r, ch);
-                load_operand_chunk<BK>(rb[q], p.B, p.b_dtype, p.ldb, p.N, p.K, n0 + r, kt * KT + ch * 8);
+                load_operand_chunk_raw<BK, BDT>(rb[q], p.B, p.ldb, p.N, p.K, n0 + r, kt * KT + ch * 8);
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt) {               // FINISH half for the tile loaded by load_tiles(kt)
         char* As = smem + buf * (BM + BN) * HULC_ROWB;
         char* Bs = As + BM * HULC_ROWB;
-        if (!AK && a_micro16) {
-            if (tid < MTA16) store_micro16(As + (tid / NCH) * 8 * HULC_ROWB, sa.q, tid % NCH);
-        } else if (!AK && a_micro) {
-            if (tid < MTA) {
+        if constexpr (MICRO) {
+            const int k0 = kt * KT + m_kg * 8;
+            uint4 q[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(As + ((tid / NCH) * 4 + i) * HULC_ROWB + (tid % NCH) * CHB, ra[i]);
+            for (int j = 0; j < 8; ++j) q[j] = k0 + j < p.K ? mq[j] : make_uint4(0, 0, 0, 0);
+            if (!m_live) return;
+            if (!m_is_b) {
+                if constexpr (ADT == HULC_F32) {
+                    Chunk8 c4[4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        c4[0].v[j] = __uint_as_float(q[j].x); c4[1].v[j] = __uint_as_float(q[j].y);
+                        c4[2].v[j] = __uint_as_float(q[j].z); c4[3].v[j] = __uint_as_float(q[j].w);
+                    }
+                    if (do_rowsum && m_inside) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) rs[i] += c4[i].v[j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(As + (m_rg * 4 + i) * HULC_ROWB + m_kg * CHB, c4[i]);
+                } else {
+                    if (do_rowsum && m_inside) {             // bf16 rows: the values ARE the unrounded inputs
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) rs[i] += __uint_as_float((i & 1) ? (w[i >> 1] & 0xffff0000u) : (w[i >> 1] << 16));
+                        }
+                    }
+                    store_micro16(As + m_rg * 8 * HULC_ROWB, q, m_kg);
+                }
+            } else {
+                if constexpr (BDT == HULC_F32) {
+                    Chunk8 c4[4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        c4[0].v[j] = __uint_as_float(q[j].x); c4[1].v[j] = __uint_as_float(q[j].y);
+                        c4[2].v[j] = __uint_as_float(q[j].z); c4[3].v[j] = __uint_as_float(q[j].w);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(Bs + (m_rg * 4 + i) * HULC_ROWB + m_kg * CHB, c4[i]);
+                } else store_micro16(Bs + m_rg * 8 * HULC_ROWB, q, m_kg);
             }
-        } else
+        } else {
 #pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            int id = tid + q * NT;
-            if (A_CH % NT == 0 || id < A_CH) {
-                int r, ch; a_map(id, r, ch);
-                chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
+            for (int q = 0; q < A_PER; ++q) {
+                const int id = tid + q * NT;
+                if (A_CH % NT == 0 || id < A_CH) {
+                    int r, ch; a_map(id, r, ch);
+                    finish_operand_chunk<AK, ADT>(ra[q], p.K, kt * KT + ch * 8);
+                    if (!AK && do_rowsum && m0 + r < p.M) {           // row = id % BM is the same for every q of a thread (NT % BM == 0)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rs[0] += ra[q].v[j];
+                    }
+                    chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
+                }
             }
-        }
-        if (!BK && b_micro16) {
-            const int t = tid - MICRO_B0;
-            if (t >= 0 && t < MTB16) store_micro16(Bs + (t / NCH) * 8 * HULC_ROWB, sb.q, t % NCH);
-        } else if (!BK && b_micro) {
-            const int t = tid - MICRO_B0;
-            if (t >= 0 && t < MTB) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) chunk_store_lds<CT>(Bs + ((t / NCH) * 4 + i) * HULC_ROWB + (t % NCH) * CHB, rb[i]);
-            }
-        } else
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            int id = tid + q * NT;
-            if (B_CH % NT == 0 || id < B_CH) {
-                int r, ch; b_map(id, r, ch);
-                chunk_store_lds<CT>(Bs + r * HULC_ROWB + ch * CHB, rb[q]);
+            for (int q = 0; q < B_PER; ++q) {
+                const int id = tid + q * NT;
+                if (B_CH % NT == 0 || id < B_CH) {
+                    int r, ch; b_map(id, r, ch);
+                    finish_operand_chunk<BK, BDT>(rb[q], p.K, kt * KT + ch * 8);
+                    chunk_store_lds<CT>(Bs + r * HULC_ROWB + ch * CHB, rb[q]);
+                }
             }
         }
     };
 
     if (kt0 < kt1) {
         load_tiles(kt0);
-        store_tiles(0);
+        store_tiles(0, kt0);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -249,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         const char* As = smem + buf * (BM + BN) * HULC_ROWB;
         const char* Bs = As + BM * HULC_ROWB;
         MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
-        if (kt + 1 < kt1) store_tiles(buf ^ 1);
+        if (kt + 1 < kt1) store_tiles(buf ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -257,20 +291,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
         float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
         const bool acc_out = splitk == 1 && p.rowsum_accumulate;
-        if (a_micro16) {
+        if (MICRO && ADT != HULC_F32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);
-            if (tid < MTA16 && tid % NCH == 0) {
+            if (tid < MTA && tid % NCH == 0 && m_inside) {
                 const int r0 = m0 + (tid / NCH) * 8;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
             }
-        } else if (a_micro) {
+        } else if (MICRO) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);       // the NCH k-groups of a row group are adjacent lanes
-            if (tid < MTA && tid % NCH == 0) {
+            if (tid < MTA && tid % NCH == 0 && m_inside) {
                 const int r0 = m0 + (tid / NCH) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
@@ -385,7 +419,7 @@ HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
     return v;
 }
 
-template <typename CT, int TM, bool AK, bool BK, int NW>
+template <typename CT, int TM, bool AK, bool BK, int NW, int ADT, int BDT>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw) {
     __shared__ float red[NW][TM][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,12 +441,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __
         for (int u = 0; u < UN; ++u) {
             const int k = k0 + u * 16 + h * 8;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (k < kend) load_operand_chunk<AK>(ca[u][i], p.A, p.a_dtype, p.lda, p.M, kend, i * 32 + r, k);
-                else chunk_zero(ca[u][i]);
-            }
-            if (k < kend) load_operand_chunk<BK>(cb[u], p.B, p.b_dtype, p.ldb, p.N, kend, n0 + r, k);
-            else chunk_zero(cb[u]);
+            for (int i = 0; i < TM; ++i) load_operand_chunk_raw<AK, ADT>(ca[u][i], p.A, p.lda, p.M, kend, i * 32 + r, k);
+            load_operand_chunk_raw<BK, BDT>(cb[u], p.B, p.ldb, p.N, kend, n0 + r, k);
+        }
+        // every load of the batch is issued before the first value is touched (no branch around a load, no conversion in between)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = k0 + u * 16 + h * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) finish_operand_chunk<AK, ADT>(ca[u][i], kend, k);
+            finish_operand_chunk<BK, BDT>(cb[u], kend, k);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -471,7 +509,15 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     int kw = (p.K + splitk * nw - 1) / (splitk * nw);
     kw = (kw + 15) / 16 * 16;
     dim3 grid(colblocks, splitk);
-#define HULC_SK(TMv, AKv, BKv, NWv) gemm_skinny_kernel<CT, TMv, AKv, BKv, NWv><<<grid, NWv * 64, 0, s>>>(p, ws, splitk, kw)
+    // operand layouts and storage types are template parameters (no run-time branch around a load, see load_operand_chunk_raw)
+#define HULC_SK_DT(TMv, AKv, BKv, NWv, ADTv, BDTv) gemm_skinny_kernel<CT, TMv, AKv, BKv, NWv, ADTv, BDTv><<<grid, NWv * 64, 0, s>>>(p, ws, splitk, kw)
+#define HULC_SK(TMv, AKv, BKv, NWv)                                                                         \
+    do {                                                                                                    \
+        if (sizeof(CT) == 4 || (p.a_dtype == HULC_F32 && p.b_dtype == HULC_F32)) HULC_SK_DT(TMv, AKv, BKv, NWv, HULC_F32, HULC_F32); \
+        else if (p.a_dtype == HULC_F32) HULC_SK_DT(TMv, AKv, BKv, NWv, HULC_F32, HULC_BF16);               \
+        else if (p.b_dtype == HULC_F32) HULC_SK_DT(TMv, AKv, BKv, NWv, HULC_BF16, HULC_F32);               \
+        else HULC_SK_DT(TMv, AKv, BKv, NWv, HULC_BF16, HULC_BF16);                                          \
+    } while (0)
     if (big) {
         if (ak && bk) HULC_SK(1, true, true, 16); else if (ak && !bk) HULC_SK(1, true, false, 16);
         else if (!ak && !bk) HULC_SK(1, false, false, 16); else HULC_SK(1, false, true, 16);
@@ -485,6 +531,7 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
         if (ak && bk) HULC_SK(2, true, true, 4); else if (ak && !bk) HULC_SK(2, true, false, 4);
         else if (!ak && !bk) HULC_SK(2, false, false, 4); else HULC_SK(2, false, true, 4);
     }
+#undef HULC_SK_DT
 #undef HULC_SK
     if (splitk > 1) {
         const long n = (long)p.M * p.N;
@@ -506,10 +553,28 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     while (gx * gy * splitk < target && nkt / (splitk * 2) >= minkt) splitk *= 2;
     while (splitk > 1 && (long)splitk * p.M * (p.N + 1) * 4 > ws_bytes) splitk /= 2;
     dim3 grid(gx, gy, splitk), block(WM * WN * 64);
-    if (ak && bk) gemm_kernel<CT, TM, TN, WM, WN, true, true><<<grid, block, 0, s>>>(p, ws, splitk);
-    else if (ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, true, false><<<grid, block, 0, s>>>(p, ws, splitk);
-    else if (!ak && !bk) gemm_kernel<CT, TM, TN, WM, WN, false, false><<<grid, block, 0, s>>>(p, ws, splitk);
-    else gemm_kernel<CT, TM, TN, WM, WN, false, true><<<grid, block, 0, s>>>(p, ws, splitk);
+    // operand layouts, storage types and the staging mode are template parameters (no run-time branch around a load)
+    const int adt = sizeof(CT) == 4 ? HULC_F32 : p.a_dtype, bdt = sizeof(CT) == 4 ? HULC_F32 : p.b_dtype;
+    const int amr = adt == HULC_F32 ? 4 : 8, bmr = bdt == HULC_F32 ? 4 : 8;
+    const bool micro = !ak && !bk && p.lda % amr == 0 && p.ldb % bmr == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.B % 16 == 0 &&
+                       p.M % amr == 0 && p.N % bmr == 0 && p.M >= amr && p.N >= bmr;
+#define HULC_GK(AKv, BKv, ADTv, BDTv, MICROv) gemm_kernel<CT, TM, TN, WM, WN, AKv, BKv, ADTv, BDTv, MICROv><<<grid, block, 0, s>>>(p, ws, splitk)
+#define HULC_GK_DT(AKv, BKv, MICROv)                                                              \
+    do {                                                                                          \
+        if (adt == HULC_F32 && bdt == HULC_F32) HULC_GK(AKv, BKv, HULC_F32, HULC_F32, MICROv);    \
+        else if constexpr (sizeof(CT) == 2) {                                                     \
+            if (adt == HULC_F32) HULC_GK(AKv, BKv, HULC_F32, HULC_BF16, MICROv);                  \
+            else if (bdt == HULC_F32) HULC_GK(AKv, BKv, HULC_BF16, HULC_F32, MICROv);             \
+            else HULC_GK(AKv, BKv, HULC_BF16, HULC_BF16, MICROv);                                 \
+        }                                                                                         \
+    } while (0)
+    if (ak && bk) HULC_GK_DT(true, true, false);
+    else if (ak && !bk) HULC_GK_DT(true, false, false);
+    else if (!ak && bk) HULC_GK_DT(false, true, false);
+    else if (micro) HULC_GK_DT(false, false, true);
+    else HULC_GK_DT(false, false, false);
+#undef HULC_GK_DT
+#undef HULC_GK
     if (splitk > 1) {
         const long n = (long)p.M * p.N;
         gemm_splitk_epilogue_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, ws, splitk);

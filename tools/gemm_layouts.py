@@ -3,13 +3,13 @@ sys.path.insert(0, '.')
 from hulc2_amd import kernels as kn
 dev = torch.device('cuda')
 kn.set_compute("bf16")
-def run(M,N,K,ak,bk,a16,b16):
+def run(M,N,K,ak,bk,a16,b16,seed=0):
     A = torch.randn((M, K) if ak else (K, M), device=dev)
     B = torch.randn((N, K) if bk else (K, N), device=dev)
     if a16: A = A.to(torch.bfloat16)
     if b16: B = B.to(torch.bfloat16)
     C = torch.zeros(M, N, device=dev)
-    f=lambda: kn.gemm(A, B, C, M, N, K, A.stride(0), B.stride(0), N, a_kmajor=bool(ak), b_kmajor=bool(bk), accumulate=True)
+    f=lambda: kn.gemm(A, B, C, M, N, K, A.stride(0), B.stride(0), N, a_kmajor=bool(ak), b_kmajor=bool(bk), accumulate=True, drop_seed=seed)
     for _ in range(5): f()
     torch.cuda.synchronize()
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
