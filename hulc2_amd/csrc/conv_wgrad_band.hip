@@ -271,11 +271,15 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 }
 
 // perm_c > 0: forward k order (tap, c) -> the parameter's OIHW order (c, tap); accumulate: add to the destination (gradient arena)
+// the workgroups past the weight rows (blockIdx.x >= nbw, optional) sum the bias partials: one launch for dW and db
 __global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, int accumulate,
-                                                            int perm_c, int perm_taps) {
+                                                            int perm_c, int perm_taps, int nbw = 1 << 30, const float* __restrict__ partial_b = nullptr,
+                                                            float* __restrict__ out_b = nullptr, long Rb = 0) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long rr = (long)blockIdx.x * 64 + lane;
+    int bx = blockIdx.x;
+    if (bx >= nbw) { bx -= nbw; partial = partial_b; out = out_b; R = Rb; perm_c = 0; }
+    const long rr = (long)bx * 64 + lane;
     const int per = (P + 15) / 16;
     const int q0 = sl * per, q1 = q0 + per < P ? q0 + per : P;
     float s = 0.f;
@@ -555,8 +559,8 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     if (p.u8) conv1_wgrad_kernel<XCH, YCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     else conv1_wgrad_kernel<XCH, YCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     const long Rw = 32L * K;
-    wband_reduce_kernel<<<(unsigned)((Rw + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, 0, 64);
-    if (db) wband_reduce_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, grid, 32, accumulate, 0, 0);
+    const int nbw = (int)((Rw + 63) / 64);
+    wband_reduce_kernel<<<nbw + (db ? 1 : 0), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, 0, 64, nbw, p.partial_b, db, 32);
     return 0;
 }
 
@@ -607,8 +611,9 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
     }
     kern<<<grid, 512, (size_t)lds_of(R, F), s>>>(p);
     const long Rw = (long)COUT * K;
-    wband_reduce_kernel<<<(unsigned)((Rw + 63) / 64), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, (dw_oihw && !NCHW) ? C : 0, TH * TW);
-    if (db) wband_reduce_kernel<<<1, 1024, 0, s>>>(p.partial_b, db, grid, COUT, accumulate, 0, 0);
+    const int nbw = (int)((Rw + 63) / 64);
+    wband_reduce_kernel<<<nbw + (db ? 1 : 0), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, (dw_oihw && !NCHW) ? C : 0, TH * TW, nbw, p.partial_b, db,
+                                                          COUT);
     return 0;
 }
 

@@ -320,9 +320,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     }
 }
 // out[r] (+)= sum_q partial[q*ld + r]: 64 columns x 16 row slices per workgroup, fixed summation order
+// blockIdx.y = 1 (optional second half of a launch): the same sum for partial + off1 into out1 — LayerNorm's dgamma | dbeta in one launch
 __global__ __launch_bounds__(1024) void reduce_rows_wide_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, long R, long ld,
-                                                                int accumulate) {
+                                                                int accumulate, long off1 = 0, float* __restrict__ out1 = nullptr) {
     __shared__ float red[16][64];
+    if (blockIdx.y == 1) { partial += off1; out = out1; }
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long rr = (long)blockIdx.x * 64 + lane;
     const int per = (P + 15) / 16;
@@ -617,8 +619,7 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
     hipStream_t s = (hipStream_t)stream;
     layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, do_out, drop_p, seed, seed_dev, (float*)ws);
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
-    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params);
-    reduce_rows_wide_kernel<<<(D + 63) / 64, 1024, 0, s>>>((const float*)ws + D, dbeta, nb, D, 2 * D, accumulate_params);
+    reduce_rows_wide_kernel<<<dim3((D + 63) / 64, 2), 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params, (long)D, dbeta);
     return hulc_check_launch("hulc_layernorm_bwd");
 }
 
