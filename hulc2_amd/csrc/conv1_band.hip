@@ -45,8 +45,7 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     char* xlds = smem + 32 * WROW;
     for (int id = tid; id < 32 * (K / 8); id += NT) {
         const int row = id / (K / 8), ch = id % (K / 8);
-        Chunk8 c; chunk_load_contig(c, p.Wt, p.w_dtype, (long)row * p.ldw + ch * 8);
-        *(uint4*)(wlds + row * WROW + ch * 16) = make_uint4(pack_bf16x2(c.v[0], c.v[1]), pack_bf16x2(c.v[2], c.v[3]), pack_bf16x2(c.v[4], c.v[5]), pack_bf16x2(c.v[6], c.v[7]));
+        *(uint4*)(wlds + row * WROW + ch * 16) = *(const uint4*)((const uint16_t*)p.Wt + (long)row * p.ldw + ch * 8);   // bf16 weights (dispatch checks)
     }
 
     // the prefetched band stays RAW in registers (8 floats per item / the aligned dword windows of uint8 frames) and is converted in
@@ -193,6 +192,7 @@ int launch_conv1(C1P& p, hipStream_t s) {
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
                              int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
+    if (w_dtype != HULC_BF16 || ((uintptr_t)w % 16) || ldw % 8) return u8 ? hulc_fail(-6, "conv1 band: bf16 weights, 16-byte aligned rows") : 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
     C1P p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;

@@ -43,17 +43,21 @@ struct BandP {
     BandCls cls[BAND_MAXCLS];
 };
 
-HULC_DEVICE uint4 band_load_bits(const void* X, int dtype, long off) {
-    if (dtype == HULC_BF16) return *(const uint4*)((const uint16_t*)X + off);
+// bf16 operands only (input band, weights, ReLU mask): a run-time dtype branch around a load makes hipcc wait for it at the join, which
+// turned the 32+ weight-fragment loads of a launch and the 10+ chunk loads of every prefetch into as many serial memory round trips.
+// Other storage types take the gather kernel in conv.hip.
+HULC_DEVICE uint4 band_load_bits(const void* X, long off) { return *(const uint4*)((const uint16_t*)X + off); }
+// XF32 instances (an fp32 gradient entering the gripper stack's conv3 data gradient): converted at load time, compile-time selected
+template <bool XF32>
+HULC_DEVICE uint4 band_load_x(const void* X, long off) {
+    if (!XF32) return band_load_bits(X, off);
     const float4* q = (const float4*)((const float*)X + off);
     const float4 a = q[0], c = q[1];
-    uint4 t;
-    t.x = pack_bf16x2(a.x, a.y); t.y = pack_bf16x2(a.z, a.w); t.z = pack_bf16x2(c.x, c.y); t.w = pack_bf16x2(c.z, c.w);
-    return t;
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(c.x, c.y), pack_bf16x2(c.z, c.w));
 }
 
 // C: input channels, NSET: weight sets (32 output channels each), TH x TW taps, S: input stride, MAXCH: band chunks/thread
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI>
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32>
 __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16;
@@ -78,9 +82,15 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         const int k0 = ks * 16 + h * 8;
         const int t = k0 / C, c0 = k0 % C;
         union { uint4 u; bf16x8_t b; } x;
-        x.u = band_load_bits(p.Wt, p.w_dtype, (cl.w_row0 + r) * p.ldw + cl.w_tap_off[t] + c0);
+        x.u = band_load_bits(p.Wt, (cl.w_row0 + r) * p.ldw + cl.w_tap_off[t] + c0);
         wfrag[ks] = x.b;
     }
+
+    // bias of this lane's 16 output channels (registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}), loaded once: a load inside the
+    // tile loop would have to wait, in order, for the whole prefetch issued before it
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = p.bias ? *(const float4*)(p.bias + cl.co_base + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
     const int cc = tid % CPP;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             const long off = inb ? (long)(n + f) * p.x_sn + (long)iy * p.x_sy + (long)ix * p.x_sx + cc * 8 : (long)n * p.x_sn;
             // the loaded value is not touched here (the select happens in stage_store): an ALU use would put the wait for the
             // prefetch in front of the MFMA loop it overlaps
-            pre[j] = band_load_bits(p.X, p.x_dtype, off);
+            pre[j] = band_load_x<XF32>(p.X, off);
             pre_live = j == 0 ? (inb ? 1u : 0u) : (pre_live | ((inb ? 1u : 0u) << j));
         }
     };
@@ -156,27 +166,18 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 const long off = cl.y_off + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    // registers 4g..4g+3 hold channels co_base + 8g + 4h + {0..3}: one aligned float4 of the bias vector
-                    const float4 bv = p.bias ? *(const float4*)(p.bias + cl.co_base + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 bv = bias4[g];
                     float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     if (p.mask) {
-                        if (p.mask_dtype == HULC_BF16) {
-                            const uint2 m = *(const uint2*)((const uint16_t*)p.mask + off + 8 * g);
-                            if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
-                            if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
-                            if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
-                            if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
-                        } else {
-                            const float4 m = *(const float4*)((const float*)p.mask + off + 8 * g);
-                            if (!(m.x > 0.f)) v[0] = 0.f;
-                            if (!(m.y > 0.f)) v[1] = 0.f;
-                            if (!(m.z > 0.f)) v[2] = 0.f;
-                            if (!(m.w > 0.f)) v[3] = 0.f;
-                        }
+                        const uint2 m = *(const uint2*)((const uint16_t*)p.mask + off + 8 * g);
+                        if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
                     }
                     if (p.y_dtype == HULC_BF16) {
                         uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     }
 }
 
-template <int C, int NSET, int TH, int TW, int S, int MAXCH>
-int launch_band(BandP& p, hipStream_t s) {
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32>
+int launch_band_x(BandP& p, hipStream_t s) {
     constexpr int PS = C * 2 + 16, CPP = C / 8;
     const int Wb = (p.OWmax - 1) * S + TW;
     const long budget = 160 * 1024 - 512;
@@ -216,7 +217,7 @@ int launch_band(BandP& p, hipStream_t s) {
     const int per = (nunits + 255) / 256;                    // balanced persistent grid
     const int grid = (nunits + per - 1) / per;
     if (F > 1) {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
@@ -224,7 +225,7 @@ int launch_band(BandP& p, hipStream_t s) {
         }
         kern<<<grid, 512, lds, s>>>(p);
     } else {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
@@ -233,6 +234,11 @@ int launch_band(BandP& p, hipStream_t s) {
         kern<<<grid, 512, lds, s>>>(p);
     }
     return 0;
+}
+
+template <int C, int NSET, int TH, int TW, int S, int MAXCH>
+int launch_band(BandP& p, hipStream_t s) {
+    return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false>(p, s);
 }
 
 }  // namespace
@@ -249,6 +255,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
     BandP p;
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
+    if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;

@@ -57,9 +57,12 @@ struct WaveP {
 // instruction touches 8 full lines instead of 64 partial ones, and every 128-byte line has exactly one writer workgroup.
 HULC_DEVICE bf16x8_t load_state8(const uint16_t* p) { return *(const bf16x8_t*)p; }
 
-HULC_DEVICE bf16x8_t load_w(const uint16_t* w, long ld, int t, int n, int k) {
+// T: element (n, k) is w[k*ld + n] instead of w[n*ld + k] — compile-time, so that the 24 fragment loads of a wave are issued back to
+// back (a run-time branch around a load makes hipcc wait for it at the join: 24 serial round trips at the start of every pass)
+template <bool T>
+HULC_DEVICE bf16x8_t load_w(const uint16_t* w, long ld, int n, int k) {
     union { uint4 u; bf16x8_t b; uint16_t h[8]; } x;
-    if (!t) x.u = *(const uint4*)(w + (long)n * ld + k);
+    if (!T) x.u = *(const uint4*)(w + (long)n * ld + k);
     else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x.h[j] = w[(long)(k + j) * ld + n];
@@ -67,7 +70,7 @@ HULC_DEVICE bf16x8_t load_w(const uint16_t* w, long ld, int t, int n, int k) {
     return x.b;
 }
 
-template <int H>
+template <int H, bool WT>
 __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
     constexpr int KS = H / 32;                   // k-steps (of 32) per half of the state row
     constexpr int KPW = KS / 8;                  // per wave
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 #pragma unroll
     for (int q = 0; q < KPW; ++q) {
         const int k = (wave * KPW + q) * 32 + kb * 8;
-        wfa[q] = load_w(p.wA, p.ldA, p.tA, n0 + i, k);
-        wfb[q] = load_w(p.wB1, p.ldB1, p.tB1, n0 + i, k);
-        union { bf16x8_t b; uint4 u; } wc; wc.b = load_w(p.wB2, p.ldB2, p.tB2, n0 + i, k);
+        wfa[q] = load_w<WT>(p.wA, p.ldA, n0 + i, k);
+        wfb[q] = load_w<WT>(p.wB1, p.ldB1, n0 + i, k);
+        union { bf16x8_t b; uint4 u; } wc; wc.b = load_w<WT>(p.wB2, p.ldB2, n0 + i, k);
         wlds[wave][q][lane] = wc.u;                                          // read back only by this wave: no barrier needed
     }
     bool timed_out = false;
@@ -270,6 +273,8 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     if (hipMemsetAsync(ws, 0, RNN_WS_HEADER, s) != hipSuccess ||
         hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)   // (exchange region 0 is never read: z_0 = 0 is skipped)
         return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
-    rnn_wavefront_kernel<2048><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    if (d->tA != d->tB1 || d->tA != d->tB2) return hulc_fail(-3, "hulc_rnn_wavefront: the three weight matrices share one layout (tA == tB1 == tB2)");
+    if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    else rnn_wavefront_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);
     return hulc_check_launch("hulc_rnn_wavefront");
 }
