@@ -35,11 +35,14 @@ def main(path):
 def pmc(path):
     """per-kernel average of every collected counter (view counters_collection): `python tools/rocpd_stats.py --pmc x.db`"""
     c = sqlite3.connect(path)
-    rows = c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
+    # one kernel instance serves several shapes (conv1 of the static and of the gripper camera): its launches are told apart by their
+    # LDS allocation and grid
+    rows = c.execute("select kernel_name, counter_name, count(*), sum(value), lds_block_size, grid_size from counters_collection "
+                     "group by kernel_name, counter_name, lds_block_size, grid_size").fetchall()
     rows.sort(key=lambda r: -r[3])
-    print(f"{'calls':>7} {'avg_value':>16} {'counter':>14}  kernel")
-    for name, ctr, n, v in rows:
-        print(f"{n:7d} {v / n:16.1f} {ctr:>14}  {short(name)}")
+    print(f"{'calls':>7} {'avg_value':>16} {'counter':>14} {'lds':>7} {'grid':>9}  kernel")
+    for name, ctr, n, v, lds, grid in rows:
+        print(f"{n:7d} {v / n:16.1f} {ctr:>14} {lds:7d} {grid:9d}  {short(name)}")
 
 
 if __name__ == "__main__":
