@@ -156,7 +156,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
 
     // fused bias gradient: the workgroups of the first column block also sum the A rows they stage (fp32 operands: before
     // bf16 rounding)
-    const bool do_rowsum = !AK && p.rowsum != nullptr && blockIdx.y == 0;
+    const bool do_rowsum = p.rowsum != nullptr && blockIdx.y == 0;
     float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // 16-bit 8x8 transpose: chunk of row i = {q[0][i], ..., q[7][i]}; one v_perm per output dword
@@ -253,9 +253,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 if (A_CH % NT == 0 || id < A_CH) {
                     int r, ch; a_map(id, r, ch);
                     finish_operand_chunk<AK, ADT>(ra[q], p.K, kt * KT + ch * 8);
-                    if (!AK && do_rowsum && m0 + r < p.M) {           // row = id % BM is the same for every q of a thread (NT % BM == 0)
+                    if (do_rowsum && m0 + r < p.M) {
+                        // row-major A: row = id % BM is the same for every q of a thread (NT % BM == 0) -> rs[0]; k-major A: chunk q
+                        // belongs to row id / NCH -> rs[q] (A_PER <= 8), the NCH chunks of a row sit in adjacent lanes
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) rs[0] += ra[q].v[j];
+                        for (int j = 0; j < 8; ++j) rs[AK ? q : 0] += ra[q].v[j];
                     }
                     chunk_store_lds<CT>(As + r * HULC_ROWB + ch * CHB, ra[q]);
                 }
@@ -291,7 +293,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
         float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
         const bool acc_out = splitk == 1 && p.rowsum_accumulate;
-        if (MICRO && ADT != HULC_F32) {
+        if (AK) {
+            static_assert(!AK || A_PER <= 8, "row sums of a k-major A: one accumulator per chunk slot");
+#pragma unroll
+            for (int q = 0; q < (AK ? A_PER : 0); ++q) {
+                for (int o = 1; o < NCH; o <<= 1) rs[q] += __shfl_xor(rs[q], o, 64);
+                const int id = tid + q * NT, r = id / NCH;
+                if ((A_CH % NT == 0 || id < A_CH) && id % NCH == 0 && m0 + r < p.M) dst[m0 + r] = acc_out ? dst[m0 + r] + rs[q] : rs[q];
+            }
+        } else if (MICRO && ADT != HULC_F32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 for (int o = 1; o < NCH; o <<= 1) rs[i] += __shfl_xor(rs[i], o, 64);
@@ -614,7 +624,7 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     p.alpha = d->alpha; p.mask_scale = d->mask_scale; p.drop_p = d->drop_p; p.drop_seed = d->drop_seed;
     p.seed_dev = d->seed_dev;
     p.rowsum = d->rowsum_a; p.rowsum_accumulate = d->rowsum_accumulate;
-    if (p.rowsum && (d->a_kmajor || d->M <= 64)) return hulc_fail(-6, "hulc_gemm: rowsum_a needs a row-major A operand and M > 64 (tiled path)");
+    if (p.rowsum && d->M <= 64) return hulc_fail(-6, "hulc_gemm: rowsum_a needs M > 64 (tiled path)");
     hipStream_t s = (hipStream_t)stream;
     if (d->M <= 64) {
         if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);

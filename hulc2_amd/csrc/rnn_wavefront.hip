@@ -31,6 +31,7 @@ namespace {
 struct WaveP {
     float* z; long z_step;                       // fp32 state rows: wave step tau reads z + tau*z_step, writes z + (tau+1)*z_step
     uint16_t* zb;                                // bf16 mirror of the state rows, [S+2][B][2H] row-major (operand of the weight-gradient GEMMs)
+    uint16_t* zt; long ld_t;                     // optional transposed mirror [2H][(S+2)*B] (token = region*B + row): k-major operand of the weight-gradient GEMMs
     uint16_t* xb;                                // the same values in the exchange layout the kernel itself reads, [S+2][2][H/8][64][8] (see below)
     int zb_row0, zb_dir;                         // region read at wave step tau = zb_row0 + tau * zb_dir (0, +1 forward; S+1, -1 reversed)
     const uint16_t *wA, *wB1, *wB2;              // first (H x H), second k < H (H x H), second k >= H (H x H)
@@ -211,6 +212,16 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
         for (int rep = 0; rep < 2; ++rep)
             if (vst[rep]) zn[(long)om[rep] * ldz + (((tid + rep * 512) >> 8) & 1) * H + on[rep]] = vout[rep];
         if (st16) *(uint4*)(zbn + off16) = v16;                               // row-major mirror
+        if (p.zt && tid < 128) {                                              // transposed mirror: (half, column, 8 rows) per thread
+            const int ct = tid >> 6, col = (tid >> 2) & 15, ch = tid & 3;
+            const int m = rowhalf * 32 + ch * 8;
+            if (m < p.B && (ct == 1 || first_on)) {                           // B % 8 == 0 (checked by the launcher)
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (unsigned)otile[ch * 8 + 2 * e][ct][col] | ((unsigned)otile[ch * 8 + 2 * e + 1][ct][col] << 16);
+                *(uint4*)(p.zt + (long)(ct * H + n0 + col) * p.ld_t + (long)(p.zb_row0 + (tau + 1) * p.zb_dir) * p.B + m) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
         if (last) break;
 
         if (tid < 4 && !(p.dbg & 2)) {
@@ -244,8 +255,9 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 }  // namespace
 
 extern "C" long hulc_rnn_wavefront_mirror_offset(void) { return RNN_WS_HEADER; }
-// header | row-major mirror (S+2, B, 2H) | exchange copy (S+2, 2, H/8, 64, 8)
-extern "C" long hulc_rnn_wavefront_workspace(int S, int B, int H) { return RNN_WS_HEADER + (long)(S + 2) * (B + 64) * 2 * H * 2; }
+// header | row-major mirror | exchange copy | transposed mirror (2H, (S+2)*B) when B % 8 == 0
+extern "C" long hulc_rnn_wavefront_mirror_t_offset(int S, int B, int H) { return B % 8 ? 0 : RNN_WS_HEADER + (long)(S + 2) * (B + 64) * 2 * H * 2; }
+extern "C" long hulc_rnn_wavefront_workspace(int S, int B, int H) { return RNN_WS_HEADER + (long)(S + 2) * (B + 64 + (B % 8 ? 0 : B)) * 2 * H * 2; }
 
 // see include/hulc2_amd.h
 extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream) {
@@ -260,6 +272,8 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.z = d->z; p.z_step = d->z_step;
     p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8 * RNN_CTR_STRIDE * 4); p.zb = (uint16_t*)((char*)ws + RNN_WS_HEADER);
     p.xb = p.zb + (long)(d->S + 2) * d->B * 2 * d->H;
+    p.zt = d->B % 8 ? nullptr : (uint16_t*)((char*)ws + hulc_rnn_wavefront_mirror_t_offset(d->S, d->B, d->H));
+    p.ld_t = (long)(d->S + 2) * d->B;
     p.wA = (const uint16_t*)d->wA; p.wB1 = (const uint16_t*)d->wB1; p.wB2 = (const uint16_t*)d->wB2;
     p.ldA = d->ldA; p.ldB1 = d->ldB1; p.ldB2 = d->ldB2; p.tA = d->tA; p.tB1 = d->tB1; p.tB2 = d->tB2;
     p.add1 = d->add1; p.add1_step = d->add1_step; p.ld_add1 = d->ld_add1;
@@ -273,6 +287,8 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     if (hipMemsetAsync(ws, 0, RNN_WS_HEADER, s) != hipSuccess ||
         hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)   // (exchange region 0 is never read: z_0 = 0 is skipped)
         return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
+    if (p.zt && hipMemset2DAsync(p.zt + (long)p.zb_row0 * d->B, (size_t)p.ld_t * 2, 0, (size_t)d->B * 2, (size_t)2 * d->H, s) != hipSuccess)
+        return hulc_fail(-9, "hulc_rnn_wavefront: could not zero the initial state of the transposed mirror");
     if (d->tA != d->tB1 || d->tA != d->tB2) return hulc_fail(-3, "hulc_rnn_wavefront: the three weight matrices share one layout (tA == tB1 == tB2)");
     if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
     else rnn_wavefront_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);

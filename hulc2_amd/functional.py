@@ -509,7 +509,7 @@ class DecoderRNNFn(torch.autograd.Function):
         dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
         if ctx.persistent:
             # reversed sweep: wave step s reads dbuf[S+1-s] (row S+1 = 0) and writes dbuf[S-s]; weights read transposed in place
-            d16 = kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
+            d16, d16t = kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
                                    add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
                                    mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
                                    mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd)
@@ -537,11 +537,25 @@ class DecoderRNNFn(torch.autograd.Function):
         # rounds to bf16 while staging anyway), else the fp32 buffers
         import os
         use16 = ctx.persistent and not os.environ.get("HULC_RNN_WGRAD_FP32")
-        zw = ctx.z16 if use16 else zbuf
+        z16, z16t = ctx.z16 if ctx.persistent else (None, None)
+        zw = z16 if use16 else zbuf
         d1w = d16[1:S + 1] if use16 else d1
         d0w = d16[0:S][:, :, Hd:] if use16 else d0
         M = S * B
         fuse_b = kn.gemm_fuses_rowsum(Hd, False)
+        # transposed mirrors (feature, token = row * B + b) make both operands of the three 2048^3 weight gradients k-major: 61 us instead
+        # of 99 us per GEMM (tools/gemm_layouts.py) — the row-major tiles need an in-register transpose while they are staged
+        use_t = use16 and z16t is not None and d16t is not None and not os.environ.get("HULC_RNN_WGRAD_ROWMAJOR")
+        ldt = (S + 2) * B
+
+        def wgrad_t(d_feat0, d_tok0, z_feat0, z_tok0, ncols, param, bias):
+            """the same as wgrad() on the transposed mirrors: rows of dT = delta features, rows of zT = input features, k = S*B tokens"""
+            sink, bsink = gradsink.get(param), gradsink.get(bias)
+            out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
+            bout = bsink if bsink is not None else torch.empty(Hd, **f32)
+            kn.gemm(d16t[d_feat0:, d_tok0 * B:], z16t[z_feat0:, z_tok0 * B:], out, Hd, ncols, M, ldt, ldt, ncols, a_kmajor=True, b_kmajor=True,
+                    accumulate=sink is not None, rowsum=bout, rowsum_accumulate=bsink is not None)
+            return (None if sink is not None else out), (None if bsink is not None else bout)
 
         def wgrad(dlt, inp_rows, ncols, param, bias):
             """param.grad (+)= dlt^T inp_rows, bias.grad (+)= column sums of dlt (the row sums of the GEMM's A operand, fused into
@@ -557,10 +571,15 @@ class DecoderRNNFn(torch.autograd.Function):
 
         b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
         # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}]); both biases see delta1
-        dw_ih1, db_ih1 = wgrad(d1w, zw[1:S + 1], Hd, w_ih1, b_ih1)
-        dw_hh1, db_hh1 = wgrad(d1w, zw[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
-        # layer 0 (b_ih0's gradient rides on the embedding-column GEMM of dW_ih0 below)
-        dw_hh0, db_hh0 = wgrad(d0w, zw[0:S], Hd, w_hh0, b_hh0)                      # h0_{t-1} = zbuf[t][:, :H]
+        if use_t:
+            dw_ih1, db_ih1 = wgrad_t(0, 1, 0, 1, Hd, w_ih1, b_ih1)                  # delta1 = d[1:S+1][:, :, :H], h0_t = z[1:S+1][:, :, :H]
+            dw_hh1, db_hh1 = wgrad_t(0, 1, Hd, 1, Hd, w_hh1, b_hh1)                 # h1_{t-1} = z[1:S+1][:, :, H:]
+            dw_hh0, db_hh0 = wgrad_t(Hd, 0, 0, 0, Hd, w_hh0, b_hh0)                 # delta0 = d[0:S][:, :, H:], h0_{t-1} = z[0:S][:, :, :H]
+        else:
+            dw_ih1, db_ih1 = wgrad(d1w, zw[1:S + 1], Hd, w_ih1, b_ih1)
+            dw_hh1, db_hh1 = wgrad(d1w, zw[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
+            # layer 0 (b_ih0's gradient rides on the embedding-column GEMM of dW_ih0 below)
+            dw_hh0, db_hh0 = wgrad(d0w, zw[0:S], Hd, w_hh0, b_hh0)                  # h0_{t-1} = zbuf[t][:, :H]
         dcs = torch.empty(B, 2 * Hd, **f32)
         dc = dcs[:, Hd:]                                                            # (B, H) strided view, ld 2H
         kn.strided_seq_sum(d0, dc, B, S, Hd, 2 * Hd, B * 2 * Hd, 2 * Hd)            # dc = sum_t delta0_t

@@ -394,8 +394,8 @@ def concurrent_streams() -> bool:
 
 
 def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
-    """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch for row-major A on the tiled path"""
-    return (not a_kmajor) and M > 64
+    """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch on the tiled path"""
+    return M > 64
 
 
 def _ffn_ws(T, FF, device):
@@ -456,8 +456,13 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
                                         + (H * 4 if mask1 is not None else 0) + (H * 4 if mask2 is not None else 0))
     _call("hulc_rnn_wavefront", _c.byref(d), ws, key=("rnn_wavefront", S, B, H, int(bool(transposed))), flops=flops, nbytes=nbytes)
     lib.hulc_rnn_wavefront_mirror_offset.restype = ctypes.c_long
+    lib.hulc_rnn_wavefront_mirror_t_offset.restype = ctypes.c_long
     off = lib.hulc_rnn_wavefront_mirror_offset() // 2
-    return ws.view(torch.bfloat16)[off:off + (S + 2) * B * 2 * H].view(S + 2, B, 2 * H)      # bf16 mirror of the S+2 state rows
+    w16 = ws.view(torch.bfloat16)
+    z16 = w16[off:off + (S + 2) * B * 2 * H].view(S + 2, B, 2 * H)
+    offt = lib.hulc_rnn_wavefront_mirror_t_offset(_i(S), _i(B), _i(H)) // 2
+    z16t = w16[offt:offt + (S + 2) * B * 2 * H].view(2 * H, (S + 2) * B) if offt else None     # (feature, token = row * B + b)
+    return z16, z16t      # bf16 mirror of the S+2 state rows
 
 
 def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):

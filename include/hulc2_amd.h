@@ -48,7 +48,7 @@ typedef struct {
     int compute;
     void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K paths */
     const unsigned long long* seed_dev;   /* optional device word xor-ed into drop_seed (see hulc_step_state_advance) */
-    float* rowsum_a; int rowsum_accumulate;   /* optional, row-major A and M > 64 only: rowsum_a[m] (+)= sum_k A[m][k] in fp32 — with
+    float* rowsum_a; int rowsum_accumulate;   /* optional, M > 64 only: rowsum_a[m] (+)= sum_k A[m][k] in fp32 — with
                                                * A = dY this is the bias gradient of the weight-gradient GEMM dW = dY^T X, fused */
 } hulc_gemm_desc;
 int hulc_gemm(const hulc_gemm_desc* d, void* stream);
@@ -229,6 +229,9 @@ typedef struct hulc_rnn_wave_desc {
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
 long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */
+/* byte offset of the TRANSPOSED bf16 mirror (2H, (S+2)*B), token = row_of_the_sweep * B + batch row — the k-major operand of the
+ * weight-gradient GEMMs dW = delta^T h (k = tokens contiguous); 0 when B % 8 != 0 (not produced) */
+long hulc_rnn_wavefront_mirror_t_offset(int S, int B, int H);
 int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------- */

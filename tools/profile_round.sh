@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/pk gpurun_out/pf gpurun_out/pw
+rocprofv3 --kernel-trace --stats -d gpurun_out/pk -o k -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > gpurun_out/pk.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pf -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pw -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pw.log 2>&1
+python3 bench.py > gpurun_out/bench_default.log 2>&1
+for d in pk pf pw; do f=$(find gpurun_out/$d -name "*.db" | head -1); echo $d $f; done
+python3 tools/rocpd_stats.py $(find gpurun_out/pk -name "*.db" | head -1) > gpurun_out/k_stats.txt
+python3 tools/rocpd_stats.py --pmc $(find gpurun_out/pf -name "*.db" | head -1) > gpurun_out/f_pmc.txt
+python3 tools/rocpd_stats.py --pmc $(find gpurun_out/pw -name "*.db" | head -1) > gpurun_out/w_pmc.txt
+rm -rf gpurun_out/pk gpurun_out/pf gpurun_out/pw
+tail -1 gpurun_out/bench_default.log | cut -c1-400
