@@ -435,13 +435,20 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
     # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
     zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
-    zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)                # zbuf[t+1] = [h0_t | h1_{t-1}]
+    persistent = h0 is None and _rnn_persistent(B, Hd, zdt)
+    if persistent:
+        # the persistent kernel writes every row it owns (rows 1..S+1, zeros included): only the initial row and the half of the last
+        # row it never produces are cleared, not 36 MB
+        zbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zdt, device=dev)            # zbuf[t+1] = [h0_t | h1_{t-1}]
+        zbuf[0].zero_()
+        zbuf[S + 1][:, :Hd].zero_()
+    else:
+        zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)
     if h0 is not None:                                                         # carried state: h0_{-1} and h1_{-1}
         zbuf[0][:, :Hd] = h0[0]
         zbuf[1][:, Hd:] = h0[1]
     whh0 = weight_operand(w_hh0)
     meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
-    persistent = h0 is None and _rnn_persistent(B, Hd, zdt)
     if persistent:
         # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
         z16 = kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
@@ -506,7 +513,12 @@ class DecoderRNNFn(torch.autograd.Function):
         Kin = w_ih0.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
         dH1_t = dH1.permute(1, 0, 2).contiguous()                                  # (S, B, H) time-major
-        dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)         # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
+        if ctx.persistent:                                                         # the kernel writes rows S..0; row S+1 is its zero start
+            dbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)
+            dbuf[S + 1].zero_()
+            dbuf[0][:, :Hd].zero_()
+        else:
+            dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)     # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
         if ctx.persistent:
             # reversed sweep: wave step s reads dbuf[S+1-s] (row S+1 = 0) and writes dbuf[S-s]; weights read transposed in place
             d16, d16t = kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
