@@ -40,6 +40,7 @@ struct BandP {
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
     int relu;
+    int dbg;                        // timing experiments (HULC_BAND_DBG): 1 = skip the MFMA tile loop, 2 = skip the prefetch loads, 4 = skip the LDS band stores
     BandCls cls[BAND_MAXCLS];
 };
 
@@ -136,13 +137,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     __syncthreads();
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits) stage_load(next);                 // in flight during the MFMA loop below
+        if (next < nunits && !(p.dbg & 2)) stage_load(next);  // in flight during the MFMA loop below
 
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int Rc = r0 < cl.OH ? ((r0 + R <= cl.OH) ? R : cl.OH - r0) : 0;   // this class may have fewer rows/cols
         const int fpix = Rc * cl.OW, npix = fu * fpix;
         const int ntile = (npix + 31) / 32;
-        for (int tile = part; tile < ntile; tile += WPS) {
+        for (int tile = part; tile < ((p.dbg & 1) ? 0 : ntile); tile += WPS) {
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
@@ -162,8 +163,41 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);   // D[channel][pixel]
             }
             // ---- epilogue: lane = pixel; registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}
-            if (live) {
-                const long off = cl.y_off + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base + 4 * h;
+            const long off0 = cl.y_off + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base;   // q is clamped: always valid
+            if (p.y_dtype == HULC_BF16) {
+                // bf16 outputs: the two lane halves of a pixel hold interleaved groups of 4 channels (8-byte pieces).  v_permlane32_swap
+                // trades the odd pieces of the lower half for the even pieces of the upper half: every lane then owns 8 consecutive
+                // channels — two 16-byte stores (and mask loads) per pixel instead of four 8-byte ones.
+                uint2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = bias4[g];
+                    float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    pk[g] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
+                    uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};                 // channels co_base + 16 gp + 8 h + {0..7}
+                    const long off = off0 + 16 * gp + 8 * h;
+                    if (p.mask) {
+                        const uint4 m = *(const uint4*)((const uint16_t*)p.mask + off);
+                        const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (!(__uint_as_float(mw[e] << 16) > 0.f)) o[e] &= 0xffff0000u;
+                            if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) o[e] &= 0x0000ffffu;
+                        }
+                    }
+                    if (live) *(uint4*)((uint16_t*)p.Y + off) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            } else if (live) {
+                const long off = off0 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = bias4[g];
@@ -179,15 +213,12 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                         if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
                         if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
                     }
-                    if (p.y_dtype == HULC_BF16) {
-                        uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)((uint16_t*)p.Y + off + 8 * g) = o;
-                    } else *(float4*)((float*)p.Y + off + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)((float*)p.Y + off + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
         __syncthreads();                                     // every wave is done reading this band
-        if (next < nunits) stage_store(next);
+        if (next < nunits && !(p.dbg & 4)) stage_store(next);
         __syncthreads();
     }
 }
@@ -257,6 +288,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
     if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
+    p.dbg = getenv("HULC_BAND_DBG") ? atoi(getenv("HULC_BAND_DBG")) : 0;
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
     p.ldw = ldw; p.relu = relu;
