@@ -42,7 +42,9 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     //      output channel r, 8 consecutive k of k-step ks at half h).  Registers stay under 128 -> two workgroups per CU.
     constexpr int WROW = K * 2 + 16;
     char* wlds = smem;
-    char* xlds = smem + 32 * WROW;
+    float* blds = (float*)(smem + 32 * WROW);                    // bias in LDS: a global load inside the tile loop would wait, in order, behind the prefetch
+    char* xlds = smem + 32 * WROW + 128;
+    if (tid < 32) blds[tid] = p.bias ? p.bias[tid] : 0.f;
     for (int id = tid; id < 32 * (K / 8); id += NT) {
         const int row = id / (K / 8), ch = id % (K / 8);
         *(uint4*)(wlds + row * WROW + ch * 16) = *(const uint4*)((const uint16_t*)p.Wt + (long)row * p.ldw + ch * 8);   // bf16 weights (dispatch checks)
@@ -139,17 +141,33 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
                 const bf16x8_t wf = *(const bf16x8_t*)(wrow + ks * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x.b, acc, 0, 0, 0);
             }
-            if (q < npix) {
-                const long yo = (((long)n * p.OH + r0) * p.OW + q) * 32;        // band pixels are contiguous in the NHWC output
+            {
+                const long yo = (((long)n * p.OH + r0) * p.OW + qc) * 32;       // band pixels are contiguous in the NHWC output (qc: clamped, always valid)
+                if (p.y_dtype == HULC_BF16) {
+                    // the two lane halves of a pixel hold interleaved groups of 4 channels: v_permlane32_swap gives every lane 8 consecutive
+                    // channels — two 16-byte stores per pixel instead of four 8-byte ones
+                    uint2 pk[4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    // bias of this lane's channels (e&3) + 8(e>>2) + 4h: re-read per tile (L1-resident) rather than 16 live registers
-                    const float4 b4 = p.bias ? *(const float4*)(p.bias + 8 * g4 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
-                    if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    const int co = 8 * g4 + 4 * h;
-                    if (p.y_dtype == HULC_BF16) *(uint2*)((uint16_t*)p.Y + yo + co) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                    else *(float4*)((float*)p.Y + yo + co) = make_float4(v0, v1, v2, v3);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 b4 = *(const float4*)(blds + 8 * g4 + 4 * h);
+                        float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        pk[g4] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    }
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
+                        if (q < npix) *(uint4*)((uint16_t*)p.Y + yo + 16 * gp + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    }
+                } else if (q < npix) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 b4 = *(const float4*)(blds + 8 * g4 + 4 * h);
+                        float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        *(float4*)((float*)p.Y + yo + 8 * g4 + 4 * h) = make_float4(v0, v1, v2, v3);
+                    }
                 }
             }
         }
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
 
 template <int XCH>
 int launch_conv1(C1P& p, hipStream_t s) {
-    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return 32 * (192 * 2 + 16) + 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
+    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return 32 * (192 * 2 + 16) + 128 + 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512;
