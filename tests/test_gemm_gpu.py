@@ -166,6 +166,28 @@ def test_gemm_fused_rowsum(dev, M, N, K, accumulate):
     assert torch.equal(rs, rs2), "fixed summation order"
 
 
+@pytest.mark.parametrize("a16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 2048), (200, 72, 520), (128, 2048, 64)])
+def test_gemm_fused_rowsum_kmajor(dev, M, N, K, a16):
+    """rowsum_a with a k-major A (the transposed bf16 mirrors of the recurrent decoder's weight gradients)"""
+    from hulc2_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = torch.randn(N, K, generator=g).to(dev).to(torch.bfloat16)
+    if a16:
+        A = A.to(torch.bfloat16)
+    C = torch.zeros(M, N, device=dev)
+    r0 = torch.randn(M, generator=g).to(dev)
+    rs = r0.clone()
+    kn.gemm(A, B, C, M, N, K, K, K, N, a_kmajor=True, b_kmajor=True, rowsum=rs, rowsum_accumulate=True)
+    torch.cuda.synchronize()
+    want = A.double().sum(1) + r0.double()
+    assert (rs.double() - want).abs().max().item() < 1e-5 * K ** 0.5 + 1e-5
+    ref = A.to(torch.bfloat16).double() @ B.double().t()
+    assert (C.double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("M,N,K,a16,b16", [(2048, 2048, 2048, True, True), (256, 128, 520, True, True), (128, 384, 96, True, False),
                                            (256, 128, 64, False, True), (200, 136, 72, True, True)])
 def test_gemm_row_major_bf16_operands(dev, M, N, K, a16, b16):

@@ -43,7 +43,7 @@ def _run(dev, B, S, persistent, seed=0):
     return h1.detach(), [t.grad for t in leaves]
 
 
-@pytest.mark.parametrize("B,S", [(3, 1), (5, 4), (64, 6), (33, 3)])
+@pytest.mark.parametrize("B,S", [(3, 1), (5, 4), (64, 6), (33, 3), (16, 5)])
 def test_wavefront_matches_per_step(dev, B, S):
     h_ref, g_ref = _run(dev, B, S, persistent=False)
     h, g = _run(dev, B, S, persistent=True)
@@ -62,3 +62,32 @@ def test_wavefront_deterministic(dev):
     assert torch.equal(h1, h2)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,transposed", [(64, False), (24, True)])
+def test_mirrors_agree_with_the_state_rows(dev, B, transposed):
+    """the row-major and the transposed bf16 mirror the kernel leaves behind are the bf16 rounding of its fp32 state rows"""
+    from hulc2_amd import kernels as kn
+
+    kn.set_compute("bf16")
+    S, H = 5, 2048
+    g = torch.Generator().manual_seed(B)
+    w = [((torch.rand(H, H, generator=g) * 2 - 1) * H ** -0.5).to(dev).to(torch.bfloat16) for _ in range(3)]
+    pre0 = torch.randn(S, B, H, generator=g).to(dev)
+    zbuf = torch.zeros(S + 2, B, 2 * H, device=dev)
+    if transposed:                                                   # the backward sweep: rows S+1 -> 0
+        z16, z16t = kn.rnn_wavefront(zbuf[S + 1], -B * 2 * H, S, B, H, w[0], w[1], w[2], True, add1=pre0[S - 1], add1_step=-B * H, ld_add1=H)
+    else:
+        z16, z16t = kn.rnn_wavefront(zbuf[0], B * 2 * H, S, B, H, w[0], w[1], w[2], False, add1=pre0, add1_step=B * H, ld_add1=H, relu=True)
+    torch.cuda.synchronize()
+    assert z16t is not None and tuple(z16t.shape) == (2 * H, (S + 2) * B)
+    lo, hi = (0, S) if transposed else (1, S + 1)                    # rows the sweep wrote completely
+    want = zbuf[lo:hi + 1].to(torch.bfloat16)
+    got, got_t = z16[lo:hi + 1].clone(), z16t.view(2 * H, S + 2, B).permute(1, 2, 0)[lo:hi + 1].clone()
+    skip = 0 if transposed else -1                                   # the half of the sweep's last row that is never produced (never read either)
+    for t in (want, got, got_t):
+        t[skip, :, :H] = 0
+    assert torch.equal(got, want)
+    assert torch.equal(got_t, got)
+    start = S + 1 if transposed else 0
+    assert not z16t.view(2 * H, S + 2, B)[:, start].any(), "initial state row of the transposed mirror is zero"
