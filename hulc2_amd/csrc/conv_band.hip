@@ -72,6 +72,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     const int r = lane & 31, h = lane >> 5;
     const int set = wave % NSET, part = wave / NSET;
     const BandCls& cl = p.cls[set];
+    // The class fields used inside the unit loop live in SGPRs: `set` comes from threadIdx, so p.cls[set] is a VECTOR load from the
+    // kernel-argument segment, and under register pressure the compiler re-issued those loads inside the loop — each one consumed at
+    // once, i.e. (vector memory returns in order) a wait for the whole prefetch in front of the MFMAs and in front of every store.
+    const int cl_OH = __builtin_amdgcn_readfirstlane(cl.OH), cl_OW = __builtin_amdgcn_readfirstlane(cl.OW);
+    const int cl_co = __builtin_amdgcn_readfirstlane(cl.co_base);
+    const long cl_yoff = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)cl.y_off >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cl.y_off));
     const int Wb = (p.OWmax - 1) * S + TW;                  // band columns (padding included)
     const int bands = (p.OHmax + p.R - 1) / p.R;
     const int nunits = MULTI ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
@@ -91,7 +98,12 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     // tile loop would have to wait, in order, for the whole prefetch issued before it
     float4 bias4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = p.bias ? *(const float4*)(p.bias + cl.co_base + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 4; ++g) bias4[g] = p.bias ? *(const float4*)(p.bias + cl_co + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // The resident operands are complete before the unit loop starts.  Without this the compiler keeps "weight fragment k may still be
+    // in flight" alive around the loop and guards MFMA k of EVERY tile with s_waitcnt vmcnt(31 - k): harmless for the weights, but the
+    // small counts also drain the prefetch issued just before the tile (vector memory returns in order).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) only
 
     // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
     const int cc = tid % CPP;
@@ -140,8 +152,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         if (next < nunits && !(p.dbg & 2)) stage_load(next);  // in flight during the MFMA loop below
 
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
-        const int Rc = r0 < cl.OH ? ((r0 + R <= cl.OH) ? R : cl.OH - r0) : 0;   // this class may have fewer rows/cols
-        const int fpix = Rc * cl.OW, npix = fu * fpix;
+        const int Rc = r0 < cl_OH ? ((r0 + R <= cl_OH) ? R : cl_OH - r0) : 0;   // this class may have fewer rows/cols
+        const int fpix = Rc * cl_OW, npix = fu * fpix;
         const int ntile = (npix + 31) / 32;
         for (int tile = part; tile < ((p.dbg & 1) ? 0 : ntile); tile += WPS) {
             int q = tile * 32 + r;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             if (!live) q = npix - 1;
             int f = 0;
             if (MULTI) { f = q / fpix; q -= f * fpix; }
-            const int oy = q / cl.OW, ox = q % cl.OW;
+            const int oy = q / cl_OW, ox = q % cl_OW;
             const char* a0 = band + ((f * rows + oy * S) * Wb + ox * S) * PS + h * 16;
             f32x16_t acc;
 #pragma unroll
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);   // D[channel][pixel]
             }
             // ---- epilogue: lane = pixel; registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}
-            const long off0 = cl.y_off + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl.co_base;   // q is clamped: always valid
+            const long off0 = cl_yoff + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl_co;   // q is clamped: always valid
             if (p.y_dtype == HULC_BF16) {
                 // bf16 outputs: the two lane halves of a pixel hold interleaved groups of 4 channels (8-byte pieces).  v_permlane32_swap
                 // trades the odd pieces of the lower half for the even pieces of the upper half: every lane then owns 8 consecutive
