@@ -36,7 +36,8 @@ struct WBandP {
 };
 
 // C: input channels, CT: Cout / 32, TH x TW taps, S stride, NCHW: conv1 layout (k = (c, kh, kw), fp32 planes)
-template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC>
+// PURE16: X and dY are bf16 (the benchmarked NHWC layers) — compile-time, so that no run-time dtype branch surrounds a prefetch load
+template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC, bool PURE16>
 __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p) {
     constexpr int NT = 512;
     constexpr int COUT = CT * 32;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                 const bool inb = px < npx;
                 const long off = (long)n * p.x_sn + (long)(r0 * S) * p.x_sy + (inb ? (long)px * p.x_sx + cc * 8 : 0);
                 uint4 v;
-                if (p.x_dtype == HULC_BF16) v = *(const uint4*)((const uint16_t*)p.X + off);
+                if (PURE16 || p.x_dtype == HULC_BF16) v = *(const uint4*)((const uint16_t*)p.X + off);
                 else {
                     const float4* q = (const float4*)((const float*)p.X + off);
                     const float4 a = q[0], b = q[1];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             const long off = (long)n * p.dy_sn + (long)r0 * p.dy_sy + (long)qc * p.dy_sx + ycc * 8;
             uint4 v;
             const float keep = inb ? 1.f : 0.f;
-            if (p.dy_dtype == HULC_BF16) {
+            if (PURE16 || p.dy_dtype == HULC_BF16) {
                 // (the bias partial sums of bf16 gradients are taken in stage_store: touching the value here would wait for the load
                 // — and every load issued before it — ahead of the MFMA loop it is meant to overlap)
                 v = *(const uint4*)((const uint16_t*)p.dY + off);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             if (q < npad) {                                  // pixels in [npix, npad) carry zeros
                 const bool inb = q < npix;
                 const uint32_t w[4] = {inb ? ypre[j].x : 0u, inb ? ypre[j].y : 0u, inb ? ypre[j].z : 0u, inb ? ypre[j].w : 0u};
-                if (p.dy_dtype == HULC_BF16) {
+                if (PURE16 || p.dy_dtype == HULC_BF16) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
                 }
@@ -566,7 +567,7 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     return 0;
 }
 
-template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC>
+template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC, bool PURE16 = false>
 int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, hipStream_t s) {
     constexpr int COUT = CT * 32, K = TH * TW * C;
     constexpr int PS = NCHW ? 2 : C * 2 + 16;
@@ -605,7 +606,7 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
     if ((long)grid * COUT * (K + 1) * 4 > ws_bytes) return -1;
     p.partial_w = (float*)ws;
     p.partial_b = db ? p.partial_w + (long)grid * COUT * K : nullptr;
-    auto kern = conv_wgrad_band_kernel<C, CT, TH, TW, S, NCHW, XCH, YCH, BPC>;
+    auto kern = conv_wgrad_band_kernel<C, CT, TH, TW, S, NCHW, XCH, YCH, BPC, PURE16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
@@ -635,8 +636,13 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     else { p.x_sn = (long)H * W * Cin; p.x_sy = (long)W * Cin; p.x_sx = Cin; p.x_sc = 1; }
     p.dy_sn = (long)p.OH * p.OW * Cout; p.dy_sy = (long)p.OW * Cout; p.dy_sx = Cout;
     int rc = 1;
-    if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1) rc = launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
-    else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2) rc = launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
+    const bool pure16 = x_dtype == HULC_BF16 && dy_dtype == HULC_BF16;
+    if (!nchw && Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && S == 1)
+        rc = pure16 ? launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1, true>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s)
+                    : launch_wband<64, 2, 3, 3, 1, false, 5, 4, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
+    else if (!nchw && Cin == 32 && Cout == 64 && KH == 4 && KW == 4 && S == 2)
+        rc = pure16 ? launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1, true>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s)
+                    : launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0))) {
         if (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16) rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
         else {
