@@ -162,12 +162,13 @@ def main():
         obs = torch.randn(n, 15, generator=g)
         obs[:, 3:6] = (torch.rand(n, 3, generator=g) * 2 - 1) * 3.14159 * 0.5
         eps = [(a, min(a + 511, n - 1)) for a in range(0, n, 512)]           # 512-frame play episodes
-        lang_emb = torch.randn(64, 384, generator=g) * 0.05
-        # vision windows 20..32 (conf/datamodule/datasets/vision_dataset/vision_shm.yaml:5-6), language windows fixed at 32
+        # vision windows 20..32 (conf/datamodule/datasets/vision_dataset/vision_shm.yaml:5-6); language windows 20..32 over 64-frame
+        # annotated spans in the auto_lang_ann.npy layout, aux-loss window 8 (lang_dataset/lang_shm.yaml:5-6,12)
         stores = {"vis": DeviceEpisodeStore(rgb, act, obs, eps, 20, 32, device=dev, seed=rank)}
-        n_lang = len(DeviceEpisodeStore(rgb, act, obs, eps, 32, 32, device=dev))
-        stores["lang"] = DeviceEpisodeStore(stores["vis"].rgb, act, obs, eps, 32, 32, device=dev, seed=rank, lang_emb=lang_emb,
-                                            lang_lookup=np.random.RandomState(rank).randint(0, 64, n_lang))
+        spans = [(a + 64 * j, a + 64 * j + 63) for a, b in eps for j in range(0, (b - a + 1) // 64, 2)]
+        lang_data = {"language": {"ann": [""] * len(spans), "task": [""] * len(spans),
+                                  "emb": (torch.randn(len(spans), 1, 384, generator=g) * 0.05).numpy()}, "info": {"indx": spans}}
+        stores["lang"] = DeviceEpisodeStore.from_language_annotations(stores["vis"].rgb, act, obs, lang_data, device=dev, seed=rank)
         sampler = np.random.RandomState(1000 + rank)
 
         def draw():

@@ -46,7 +46,7 @@ class DeviceEpisodeStore:
     def __init__(self, rgb: Dict[str, torch.Tensor], rel_actions: torch.Tensor, robot_obs: torch.Tensor, ep_start_end_ids,
                  min_window_size: int = 20, max_window_size: int = 32, pad: bool = True, validation: bool = False,
                  scene_obs: Optional[torch.Tensor] = None, lang_emb: Optional[torch.Tensor] = None,
-                 lang_lookup: Optional[Sequence[int]] = None, device=None, seed: int = 0):
+                 lang_lookup: Optional[Sequence[int]] = None, device=None, seed: int = 0, aux_lang_loss_window: int = 1):
         """rgb: {"rgb_static": (n, 200, 200, 3) uint8, "rgb_gripper": (n, 84, 84, 3) uint8} — the frames of all episodes back to
         back; rel_actions (n, 7), robot_obs (n, 15) [, scene_obs (n, 24)] fp32; ep_start_end_ids (E, 2): first / last store frame of
         each episode (inclusive, as ep_start_end_ids.npy).  lang_emb (n_ann, 384) + lang_lookup (one annotation per window start)
@@ -80,9 +80,45 @@ class DeviceEpisodeStore:
         self.lang_lookup = None if lang_lookup is None else np.asarray(lang_lookup, dtype=np.int64)
         if self.lang_lookup is not None and len(self.lang_lookup) != len(self.episode_lookup):
             raise ValueError("lang_lookup holds one annotation number per window start")
+        self.aux_lang_loss_window = aux_lang_loss_window
         self.np_rng = np.random.RandomState(seed)
         self.generator = torch.Generator().manual_seed(seed)
         self._buf: Dict[int, Dict] = {}
+
+    @classmethod
+    def from_language_annotations(cls, rgb, rel_actions, robot_obs, lang_data: Dict, frame0: int = 0, load_lang_embeddings: bool = True,
+                                  min_window_size: int = 20, max_window_size: int = 32, aux_lang_loss_window: int = 8, skip_frames: int = 1,
+                                  **kw) -> "DeviceEpisodeStore":
+        """The language dataset (file-format half): `lang_data` is the dict stored in
+        `<split>/lang_paraphrase-MiniLM-L3-v2/auto_lang_ann.npy` — {"language": {"ann": [...], "task": [...], "emb": (n, 1, 384)},
+        "info": {"indx": [(first, last), ...]}} with dataset frame numbers; `frame0` = dataset frame number of store frame 0.
+        Window starts / annotation lookup as hulc2/datasets/utils/shared_memory_loader.py:133-140 and npz_dataset.py:182-192 (every frame
+        of an annotated span that still has `min_window_size` frames after it), `use_for_aux_lang_loss` as shm_dataset.py:150-158,
+        conf/datamodule/datasets/lang_dataset/lang_shm.yaml:5-6,12 for the defaults.  Only the precomputed embeddings are supported
+        (`load_lang_embeddings: true`): sentences would need the SBERT encoder."""
+        if not load_lang_embeddings:
+            raise NotImplementedError("sentences need the SBERT encoder: set datamodule.datasets.lang_dataset.load_lang_embeddings=true "
+                                      "(the precomputed 'emb' entries of auto_lang_ann.npy are used)")
+        emb = torch.as_tensor(np.asarray(lang_data["language"]["emb"], dtype=np.float32))
+        emb = emb.reshape(emb.shape[0], -1)                              # (n, 1, 384) -> (n, 384): process_language squeezes
+        spans = [(int(a) - frame0, int(b) - frame0) for a, b in lang_data["info"]["indx"]]
+        self = cls(rgb, rel_actions, robot_obs, spans, min_window_size, max_window_size, lang_emb=emb,
+                   lang_lookup=None, aux_lang_loss_window=aux_lang_loss_window, **kw)
+        lookup, lang_lookup = [], []
+        for i, (a, b) in enumerate(spans):
+            for cnt, f in enumerate(range(a, b + 1 - min_window_size)):
+                if cnt % skip_frames == 0:
+                    lookup.append(f)
+                    lang_lookup.append(i)
+        self.episode_lookup = np.asarray(lookup, dtype=np.int64)
+        self.episode_counters = self.episode_lookup.copy()               # consecutive frames of one span <=> consecutive counters
+        self.lang_lookup = np.asarray(lang_lookup, dtype=np.int64)
+        return self
+
+    def use_for_aux_lang_loss(self, idx: int) -> bool:
+        """shm_dataset.py:150-158: true for the last `aux_lang_loss_window` window starts of an annotation"""
+        w = self.aux_lang_loss_window
+        return bool(idx + w < len(self.lang_lookup) and self.lang_lookup[idx] < self.lang_lookup[idx + w])
 
     def __len__(self) -> int:
         return len(self.episode_lookup)
@@ -121,6 +157,7 @@ class DeviceEpisodeStore:
                 b["scene_obs"] = torch.zeros(B, S, self.scene_obs.shape[1], device=dev)
             if self.lang_emb is not None:
                 b["lang"] = torch.zeros(B, self.lang_emb.shape[1], device=dev)
+                b["use_aux"] = torch.zeros(B, dtype=torch.bool, device=dev)
             self._buf[B] = b
         return self._buf[B]
 
@@ -158,5 +195,7 @@ class DeviceEpisodeStore:
             ann = torch.from_numpy(self.lang_lookup[idxs]).to(self.device)
             torch.index_select(self.lang_emb, 0, ann, out=buf["lang"])
             out["lang"] = buf["lang"]
-            out["use_for_aux_lang_loss"] = torch.ones(B, dtype=torch.bool, device=self.device)
+            use = np.asarray([self.use_for_aux_lang_loss(int(i)) for i in idxs])
+            buf["use_aux"].copy_(torch.from_numpy(use))
+            out["use_for_aux_lang_loss"] = buf["use_aux"]
         return out

@@ -393,6 +393,25 @@ def max_window_size_at(episode_counters, idx: int, min_window_size: int, max_win
     return max_window_size
 
 
+def language_lookup(indx, min_window_size: int, skip_frames: int = 1):
+    """hulc2/datasets/npz_dataset.py:182-192 (= shared_memory_loader.py:133-140 for skip_frames 1): window starts of the language
+    dataset and the annotation each belongs to; indx = lang_data["info"]["indx"]"""
+    episode_lookup, lang_lookup = [], []
+    for i, (start_idx, end_idx) in enumerate(indx):
+        cnt = 0
+        for idx in range(int(start_idx), int(end_idx) + 1 - min_window_size):
+            if cnt % skip_frames == 0:
+                lang_lookup.append(i)
+                episode_lookup.append(idx)
+            cnt += 1
+    return episode_lookup, lang_lookup
+
+
+def use_for_aux_lang_loss(lang_lookup, idx: int, aux_lang_loss_window: int) -> bool:
+    """hulc2/datasets/shm_dataset.py:150-158"""
+    return idx + aux_lang_loss_window < len(lang_lookup) and lang_lookup[idx] < lang_lookup[idx + aux_lang_loss_window]
+
+
 def pad_with_repetition(x: torch.Tensor, pad_size: int) -> torch.Tensor:
     """hulc2/datasets/base_dataset.py:149-154"""
     return torch.cat([x, x[-1:].expand(pad_size, *x.shape[1:])], dim=0) if pad_size > 0 else x

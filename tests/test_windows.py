@@ -70,6 +70,40 @@ def test_training_window_sizes_in_range():
     assert {fixed.get_window_size(i) for i in range(len(fixed))} == {32}
 
 
+def _lang_data(rng, ids, n_ann=7, span=64):
+    indx = []
+    for a, b in ids:
+        if b - a + 1 >= span and len(indx) < n_ann:
+            s0 = int(rng.integers(a, b + 2 - span))
+            indx.append((s0, s0 + span - 1))
+    g = torch.Generator().manual_seed(1)
+    emb = (torch.randn(len(indx), 1, 384, generator=g) * 0.05).numpy()
+    return {"language": {"ann": ["task"] * len(indx), "task": ["t"] * len(indx), "emb": emb}, "info": {"indx": indx}}
+
+
+def test_language_annotations_follow_the_reference_lookup():
+    """auto_lang_ann.npy layout -> window starts, annotation per start, use_for_aux_lang_loss (file-format half)"""
+    rng = np.random.default_rng(9)
+    ids, n = _episodes(rng, 5, lo=70, hi=120)
+    frame0 = 1000                                                      # dataset frame number of store frame 0
+    lang = _lang_data(rng, ids)
+    lang["info"]["indx"] = [(a + frame0, b + frame0) for a, b in lang["info"]["indx"]]
+    _, rgb, act, obs = _store(n, ids)
+    st = DeviceEpisodeStore.from_language_annotations(rgb, act, obs, lang, frame0=frame0, device="cpu", validation=True)
+    want_lookup, want_lang = O.language_lookup(lang["info"]["indx"], 20)
+    assert (st.episode_lookup + frame0).tolist() == want_lookup and st.lang_lookup.tolist() == want_lang
+    assert tuple(st.lang_emb.shape) == (len(lang["info"]["indx"]), 384)
+    flags = [st.use_for_aux_lang_loss(i) for i in range(len(st))]
+    assert flags == [O.use_for_aux_lang_loss(want_lang, i, 8) for i in range(len(st))]
+    per_ann = len(want_lang) // len(lang["info"]["indx"])              # 64 - 20 = 44 starts per annotation, the last 8 flagged (not the final one)
+    assert sum(flags) == 8 * (len(lang["info"]["indx"]) - 1) and per_ann == 44
+    for i in range(len(st)):                                          # windows stay inside their annotated span
+        a, b = lang["info"]["indx"][want_lang[i]]
+        assert want_lookup[i] + st.get_window_size(i) - 1 <= b or len(st) <= i + 12
+    with pytest.raises(NotImplementedError):
+        DeviceEpisodeStore.from_language_annotations(rgb, act, obs, lang, frame0=frame0, load_lang_embeddings=False, device="cpu")
+
+
 def test_bad_window_configuration_raises():
     with pytest.raises(ValueError):
         _store(40, [(0, 39)], min_window_size=33, max_window_size=32)
@@ -104,6 +138,23 @@ def test_device_windows_match_padded_windows(dev):
             got = out["rgb_obs"][k][out["rgb_obs"][k + "_index"][b].long()].cpu()
             assert torch.equal(got, want[k])
     assert "rgb_static_shift" not in out["rgb_obs"], "validation transforms have no RandomShiftsAug"
+
+
+@pytest.mark.gpu
+def test_language_batch_on_device(dev):
+    """batch() of a language store: the annotation's embedding row and the aux-loss flag of every window start"""
+    rng = np.random.default_rng(12)
+    ids, n = _episodes(rng, 4, lo=80, hi=130)
+    lang = _lang_data(rng, ids)
+    _, rgb, act, obs = _store(n, ids)
+    st = DeviceEpisodeStore.from_language_annotations(rgb, act, obs, lang, device=dev, validation=True)
+    idxs = [0, 35, 36, 43, 44, len(st) - 1]
+    out = st.batch(idxs)
+    torch.cuda.synchronize()
+    emb = torch.as_tensor(lang["language"]["emb"]).reshape(-1, 384)
+    assert torch.equal(out["lang"].cpu(), emb[st.lang_lookup[idxs]])
+    assert out["use_for_aux_lang_loss"].cpu().tolist() == [O.use_for_aux_lang_loss(st.lang_lookup.tolist(), i, 8) for i in idxs]
+    assert out["use_for_aux_lang_loss"].cpu().tolist()[1:3] == [False, True]
 
 
 @pytest.mark.gpu
