@@ -374,7 +374,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
                 const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
                 if (m >= p.M || !n_ok) continue;
                 float v = p.alpha * acc[i][j][e] + bv + addv[e];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // exact (erf) GELU
                 if (p.mask) v = maskv[e] > 0.f ? v * p.mask_scale : 0.f;
                 if (p.drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
                 store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, v + cold[e]);
@@ -421,7 +422,8 @@ HULC_DEVICE void frag_mma(const Frag<float>& a, const Frag<float>& b, f32x16_t& 
 HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
     float v = p.alpha * acc + (p.bias ? p.bias[n] : 0.f);
     if (p.add) v += load_elem(p.add, p.add_dtype, (long)m * p.ld_add + n);
-    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.relu == 1) v = fmaxf(v, 0.f);
+    else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     if (p.mask) v = load_elem(p.mask, p.mask_dtype, (long)m * p.ld_mask + n) > 0.f ? v * p.mask_scale : 0.f;
     if (p.drop_p > 0.f) v *= dropout_scale(p.drop_seed ^ (p.seed_dev ? p.seed_dev[0] : 0ull), (uint64_t)m * (uint64_t)p.N + n, p.drop_p);
     const long ci = (long)m * p.ldc + n;

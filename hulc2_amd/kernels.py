@@ -508,6 +508,31 @@ def world_to_tcp(act, robot_obs, n, obs_dim, out):
     _call("hulc_world_to_tcp", act, robot_obs, _i(n), _i(obs_dim), out)
 
 
+# ---- sentence encoder pieces (csrc/lang_encoder.hip) --------------------------------------------------------------
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, eps, T, S, D, out):
+    if ids.dtype != torch.int64 or not ids.is_contiguous():
+        raise TypeError("embed_ln_fwd: token ids are a contiguous int64 tensor")
+    _call("hulc_embed_ln_fwd", ids, word, pos, type0, gamma, beta, _f(eps), _i(T), _i(S), _i(D), out)
+    return out
+
+
+def ln_wide_fwd(x, add, gamma, beta, eps, R, D, y):
+    _call("hulc_ln_wide_fwd", x, add, gamma, beta, _f(eps), _i(R), _i(D), y)
+    return y
+
+
+def mha_masked_fwd(qkv, mask, B, S, nhead, hd, out):
+    if mask.dtype != torch.int32 or not mask.is_contiguous():
+        raise TypeError("mha_masked_fwd: the padding mask is a contiguous int32 (B, S) tensor")
+    _call("hulc_mha_masked_fwd", qkv, mask, _i(B), _i(S), _i(nhead), _i(hd), out)
+    return out
+
+
+def masked_mean_fwd(x, mask, B, S, D, out):
+    _call("hulc_masked_mean_fwd", x, mask, _i(B), _i(S), _i(D), out)
+    return out
+
+
 def tcp_to_world(act, robot_obs, n, obs_dim, out):
     _call("hulc_tcp_to_world", act, robot_obs, _i(n), _i(obs_dim), out)
 

@@ -47,6 +47,26 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
             t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
 
 
+def fill_bert_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
+    """The same recipe for a transformers BertModel state_dict (SURVEY §8 row f-3 parity fixtures): LayerNorm gains 1 + 0.1 N(0,1),
+    LayerNorm biases 0.1 N(0,1), embedding tables 0.5 N(0,1), dense weights U(+-2/sqrt(fan_in)) (sharp enough that the attention
+    softmax is not uniform), dense biases U(+-0.05).  Integer buffers (position_ids) are left untouched."""
+    for name, t in sd.items():
+        if not t.is_floating_point():
+            continue
+        g = _gen(seed, name)
+        leaf = name.rsplit(".", 1)[-1]
+        if "LayerNorm" in name:
+            r = torch.randn(t.shape, generator=g) * 0.1
+            t.copy_(r + 1.0 if leaf == "weight" else r)
+        elif "embeddings" in name:
+            t.copy_(torch.randn(t.shape, generator=g) * 0.5)
+        elif t.dim() >= 2:
+            t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (2.0 / math.sqrt(t.shape[1])))
+        else:
+            t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * 0.05)
+
+
 def checksum(sd: Dict[str, torch.Tensor]) -> Dict[str, float]:
     """Per-tensor (sum, abs-sum) in float64 — stored in fixtures to prove the recipe reproduced."""
     out = {}

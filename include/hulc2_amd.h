@@ -42,7 +42,7 @@ typedef struct {
     long lda, ldb, ldc, ld_add, ld_mask;
     int a_dtype, b_dtype, c_dtype, add_dtype, mask_dtype;
     int a_kmajor, b_kmajor;
-    int relu, accumulate;
+    int relu, accumulate;          /* relu: 0 = none, 1 = ReLU, 2 = exact (erf) GELU (the MiniLM feed-forward) */
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
     int compute;
@@ -191,6 +191,20 @@ int hulc_mix_sample(const hulc_mix_desc* d, const float* y, const float* u_mix, 
 int hulc_window_index(const int* starts, const int* sizes, int B, int S, int* index_out, void* stream);
 int hulc_window_rows(const float* store, int D, const int* starts, const int* sizes, int B, int S, int zero_lo, int zero_hi,
                      float* out, void* stream);
+
+/* ---- sentence encoder: paraphrase-MiniLM-L3-v2 = BERT (3 layers, hidden 384, 12 heads, GELU, eps 1e-12) + mean
+ * pooling, as sentence_transformers runs it for hulc2/affordance/models/language_encoders/sbert_lang_encoder.py:13-71 (frozen, inference
+ * only).  The dense layers are hulc_gemm (relu = 2 for the intermediate GELU); these are the pieces around them, all fp32 in/out. */
+/* out[t] = LayerNorm(word[ids[t]] + pos[t % S] + type0), T tokens of D <= 1024 features (BertEmbeddings) */
+int hulc_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type0, const float* gamma, const float* beta,
+                      float eps, int T, int S, int D, float* out, void* stream);
+/* y[r] = LayerNorm(x[r] + add[r]) over D <= 1024 (add may be NULL): BertSelfOutput / BertOutput */
+int hulc_ln_wide_fwd(const float* x, const float* add, const float* gamma, const float* beta, float eps, int R, int D, float* y, void* stream);
+/* multi-head self attention with a key padding mask: qkv (B*S, 3*nhead*hd) = [q | k | v], mask (B, S) int32 (1 = token), out (B*S, nhead*hd);
+ * softmax(q k^T / sqrt(hd) + (1 - mask) * finfo(float).min) v as BertSelfAttention; S <= 128, hd <= 64 */
+int hulc_mha_masked_fwd(const float* qkv, const int* mask, int B, int S, int nhead, int hd, float* out, void* stream);
+/* out[b] = sum_s mask[b][s] x[b][s] / max(sum_s mask[b][s], 1e-9): sentence_transformers' mean Pooling */
+int hulc_masked_mean_fwd(const float* x, const int* mask, int B, int S, int D, float* out, void* stream);
 
 /* ---- transformer feed-forward block, fused (bf16 compute) ----------------------------------------------- */
 /* f = relu(x W1^T + b1) [dropout] W2^T + b2 of nn.TransformerEncoderLayer (plan_recognition_net.py:108-117), d_model 128,

@@ -415,6 +415,32 @@ def gen_transforms():
              train_sum=y.double().sum(), val_sum=val.double().sum())
 
 
+def gen_minilm():
+    """the sentence encoder's arithmetic from transformers' own BertModel (the class sentence_transformers wraps for
+    paraphrase-MiniLM-L3-v2: 3 layers, hidden 384, 12 heads, intermediate 1536, GELU, eps 1e-12) with the seeded recipe of
+    hulc2_amd/synthetic.fill_bert_state_dict_, followed by mean pooling as sentence_transformers.models.Pooling defines it.  The trained
+    checkpoint and the tokenizer vocabulary are not available offline: token ids are random, padding is ragged."""
+    from transformers import BertConfig, BertModel
+    from hulc2_amd import synthetic as syn
+    cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=3, num_attention_heads=12, intermediate_size=1536,
+                     max_position_embeddings=512, hidden_act="gelu", layer_norm_eps=1e-12, attn_implementation="eager")
+    bert = BertModel(cfg, add_pooling_layer=False).eval()
+    sd = bert.state_dict()
+    syn.fill_bert_state_dict_(sd, SEED)
+    bert.load_state_dict(sd)
+    B, S = 6, 24
+    ids = torch.randint(0, 30522, (B, S), generator=g(SEED, "x.lm.ids"))
+    lens = torch.tensor([24, 17, 9, 24, 1, 13])
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    with torch.no_grad():
+        tok = bert(input_ids=ids, attention_mask=mask).last_hidden_state
+        mf = mask[:, :, None].float()
+        emb = (tok * mf).sum(1) / mf.sum(1).clamp(min=1e-9)            # sentence_transformers Pooling(mean)
+    ck, cv = zip(*[(k, float(v.double().sum())) for k, v in sd.items() if v.is_floating_point() and "word_embeddings" not in k])
+    save("minilm", seed=SEED, input_ids=ids.numpy(), attention_mask=mask.numpy(), tokens_s=tok[:, ::5, ::7], tokens_sum=tok.double().sum(),
+         sentence_embedding=emb, ck=np.array(ck), cv=np.array(cv), transformers_version=__import__("transformers").__version__)
+
+
 def gen_inference(m, dist, flat):
     """validation / rollout pieces: decoder forward with a carried hidden state, LogisticDecoderRNN._sample
     and loss_and_act with the torch.rand draws recorded, and the lmp_val composition of hulc2.py:247-334 on the leaf modules."""
@@ -474,6 +500,9 @@ def gen_inference(m, dist, flat):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "minilm":          # only the f-3 fixture (needs transformers, not the reference)
+        gen_minilm()
+        return
     R = import_reference()
     m, dist, flat = build_reference_modules(R, SEED)
     print("reference leaf modules imported from", REF)
@@ -493,6 +522,7 @@ def main():
     gen_step(m, dist, flat, 2, 32)
     gen_inference(m, dist, flat)
     gen_transforms()
+    gen_minilm()
 
 
 if __name__ == "__main__":

@@ -393,6 +393,35 @@ def max_window_size_at(episode_counters, idx: int, min_window_size: int, max_win
     return max_window_size
 
 
+def minilm_sentence_embedding(sd: SD, input_ids: torch.Tensor, attention_mask: torch.Tensor, p: str = "", num_layers: int = 3, nhead: int = 12,
+                              eps: float = 1e-12) -> torch.Tensor:
+    """paraphrase-MiniLM-L3-v2 as hulc2/affordance/models/language_encoders/sbert_lang_encoder.py:13-71 runs it: transformers'
+    BertModel (embeddings -> 3 x [self-attention, dense + LayerNorm, GELU feed-forward, dense + LayerNorm]) and sentence_transformers'
+    mean Pooling.  PARITY: those packages are un-vendored (requirements.txt:19, unpinned); the restatement is pinned against
+    transformers' own BertModel with seeded weights (oracle/gen_golden.py minilm -> tests/golden/minilm.npz), not against the
+    trained checkpoint, which is not available offline.  sd: BertModel state_dict keys under prefix p; input_ids / attention_mask (B, S)."""
+    F = torch.nn.functional
+    B, S = input_ids.shape
+    x = sd[p + "embeddings.word_embeddings.weight"][input_ids] + sd[p + "embeddings.token_type_embeddings.weight"][0]
+    x = x + sd[p + "embeddings.position_embeddings.weight"][:S]
+    D = x.shape[-1]
+    x = F.layer_norm(x, (D,), sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], eps)
+    hd = D // nhead
+    neg = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
+    for l in range(num_layers):
+        q = p + f"encoder.layer.{l}."
+        lin = lambda name, t: F.linear(t, sd[q + name + ".weight"], sd[q + name + ".bias"])
+        heads = lambda t: t.view(B, S, nhead, hd).transpose(1, 2)
+        qh, kh, vh = heads(lin("attention.self.query", x)), heads(lin("attention.self.key", x)), heads(lin("attention.self.value", x))
+        pr = torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5 + neg, dim=-1)
+        ctx = (pr @ vh).transpose(1, 2).reshape(B, S, D)
+        a = F.layer_norm(lin("attention.output.dense", ctx) + x, (D,), sd[q + "attention.output.LayerNorm.weight"], sd[q + "attention.output.LayerNorm.bias"], eps)
+        h = F.gelu(lin("intermediate.dense", a))
+        x = F.layer_norm(lin("output.dense", h) + a, (D,), sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"], eps)
+    m = attention_mask.to(x.dtype)[:, :, None]
+    return (x * m).sum(1) / m.sum(1).clamp(min=1e-9)
+
+
 def language_lookup(indx, min_window_size: int, skip_frames: int = 1):
     """hulc2/datasets/npz_dataset.py:182-192 (= shared_memory_loader.py:133-140 for skip_frames 1): window starts of the language
     dataset and the annotation each belongs to; indx = lang_data["info"]["indx"]"""

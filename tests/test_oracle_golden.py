@@ -380,3 +380,34 @@ def test_u8_normalise_fma_is_bf16_exact():
         return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
 
     assert np.array_equal(bf16(exact), bf16(fma))
+
+
+def test_minilm_oracle_matches_transformers_bert():
+    """the oracle's restatement of the sentence encoder (BertModel + mean pooling) against the fixture produced by
+    transformers' own BertModel with the seeded weight recipe (oracle/gen_golden.py minilm)"""
+    fx = dict(np.load(G / "minilm.npz", allow_pickle=True))
+    sd = _bert_sd(int(fx["seed"]))
+    for k, want in zip(fx["ck"], fx["cv"]):
+        assert abs(float(sd[str(k)].double().sum()) - float(want)) < 1e-6 * max(1.0, abs(float(want))), f"recipe drifted: {k}"
+    ids, mask = torch.tensor(fx["input_ids"]), torch.tensor(fx["attention_mask"])
+    emb = O.minilm_sentence_embedding(sd, ids, mask)
+    want = torch.tensor(fx["sentence_embedding"])
+    assert (emb - want).abs().max().item() < 2e-5 * want.abs().max().item() + 1e-6
+
+
+def _bert_sd(seed):
+    D, I = 384, 1536
+    shapes = {"embeddings.word_embeddings.weight": (30522, D), "embeddings.position_embeddings.weight": (512, D),
+              "embeddings.token_type_embeddings.weight": (2, D), "embeddings.LayerNorm.weight": (D,), "embeddings.LayerNorm.bias": (D,)}
+    for l in range(3):
+        q = f"encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            shapes[q + f"attention.self.{n}.weight"] = (D, D); shapes[q + f"attention.self.{n}.bias"] = (D,)
+        shapes[q + "attention.output.dense.weight"] = (D, D); shapes[q + "attention.output.dense.bias"] = (D,)
+        shapes[q + "attention.output.LayerNorm.weight"] = (D,); shapes[q + "attention.output.LayerNorm.bias"] = (D,)
+        shapes[q + "intermediate.dense.weight"] = (I, D); shapes[q + "intermediate.dense.bias"] = (I,)
+        shapes[q + "output.dense.weight"] = (D, I); shapes[q + "output.dense.bias"] = (D,)
+        shapes[q + "output.LayerNorm.weight"] = (D,); shapes[q + "output.LayerNorm.bias"] = (D,)
+    sd = {k: torch.empty(s) for k, s in shapes.items()}
+    syn.fill_bert_state_dict_(sd, seed)
+    return sd
