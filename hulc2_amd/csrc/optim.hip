@@ -72,9 +72,22 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 // dst holds W^T ([cols][rows]) at the same offset.  Lets the data-gradient GEMMs dX = dY W stream W k-major.
 __global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
                                                               const long* __restrict__ tiles) {
-    __shared__ uint16_t t[64][66];
+    __shared__ uint16_t t[64][68];
     const long* q = tiles + (long)blockIdx.x * 5;
     const long off = q[0]; const int rows = (int)q[1], cols = (int)q[2], r0 = (int)q[3] * 64, c0 = (int)q[4] * 64;
+    if (((rows | cols) & 3) == 0 && (off & 3) == 0) {
+        // 8-byte accesses: a lane moves 4 consecutive elements, a wave 4 tile rows (512 B per instruction instead of 128 B)
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;                 // 16 lanes x 4 columns, 16 row slots
+        for (int i = ty; i < 64; i += 16)
+            if (r0 + i < rows && c0 + 4 * tx < cols) *(uint2*)&t[i][4 * tx] = *(const uint2*)(src + off + (long)(r0 + i) * cols + c0 + 4 * tx);
+        __syncthreads();
+        for (int i = ty; i < 64; i += 16)
+            if (c0 + i < cols && r0 + 4 * tx < rows) {
+                const uint32_t lo = (uint32_t)t[4 * tx][i] | ((uint32_t)t[4 * tx + 1][i] << 16), hi = (uint32_t)t[4 * tx + 2][i] | ((uint32_t)t[4 * tx + 3][i] << 16);
+                *(uint2*)(dst + off + (long)(c0 + i) * rows + r0 + 4 * tx) = make_uint2(lo, hi);
+            }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4)
         if (r0 + i < rows && c0 + tx < cols) t[i][tx] = src[off + (long)(r0 + i) * cols + c0 + tx];
