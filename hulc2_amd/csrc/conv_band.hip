@@ -40,7 +40,6 @@ struct BandP {
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
     int relu;
-    int dbg;                        // timing experiments (HULC_BAND_DBG): 1 = skip the MFMA tile loop, 2 = skip the prefetch loads, 4 = skip the LDS band stores
     BandCls cls[BAND_MAXCLS];
 };
 
@@ -149,13 +148,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     __syncthreads();
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits && !(p.dbg & 2)) stage_load(next);  // in flight during the MFMA loop below
+        if (next < nunits) stage_load(next);                 // in flight during the MFMA loop below
 
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int Rc = r0 < cl_OH ? ((r0 + R <= cl_OH) ? R : cl_OH - r0) : 0;   // this class may have fewer rows/cols
         const int fpix = Rc * cl_OW, npix = fu * fpix;
         const int ntile = (npix + 31) / 32;
-        for (int tile = part; tile < ((p.dbg & 1) ? 0 : ntile); tile += WPS) {
+        for (int tile = part; tile < ntile; tile += WPS) {
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             }
         }
         __syncthreads();                                     // every wave is done reading this band
-        if (next < nunits && !(p.dbg & 4)) stage_store(next);
+        if (next < nunits) stage_store(next);
         __syncthreads();
     }
 }
@@ -300,7 +299,6 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
     if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
-    p.dbg = getenv("HULC_BAND_DBG") ? atoi(getenv("HULC_BAND_DBG")) : 0;
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
     p.ldw = ldw; p.relu = relu;

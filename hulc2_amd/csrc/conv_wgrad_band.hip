@@ -32,7 +32,6 @@ struct WBandP {
     float* partial_w;                 // [grid][Cout][K]
     float* partial_b;                 // [grid][Cout]
     int u8, pad; const int* shift; const int* fidx;   // conv1 fed by uint8 NHWC frames: shift / scale / normalise applied while staging (see conv1_band.hip)
-    int dbg;                                          // timing experiments (HULC_WG_DBG): 1 = no X fragment reads, 2 = no MFMA loop, 4 = no prefetch
 };
 
 // C: input channels, CT: Cout / 32, TH x TW taps, S stride, NCHW: conv1 layout (k = (c, kh, kw), fp32 planes)
@@ -216,10 +215,10 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
     __syncthreads();
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits && !(p.dbg & 4)) stage_load(next);
+        if (next < nunits) stage_load(next);
 
         int n, r0, R, rows, npix; unit_geom(unit, n, r0, R, rows, npix);
-        const int nsteps = (p.dbg & 2) ? 0 : (npix + 15) / 16;
+        const int nsteps = (npix + 15) / 16;
         for (int s = 0; s < nsteps; ++s) {
             const int m0 = s * 16 + h * 8;                   // this lane half's 8 pixels
             const int4 po0 = *(const int4*)(pixoff + m0), po1 = *(const int4*)(pixoff + m0 + 4);
@@ -233,7 +232,6 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                 union { uint32_t w[4]; bf16x8_t b; } x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (p.dbg & 1) { x.w[e] = 0x3f803f80u; continue; }
                     const uint32_t lo = *(const uint16_t*)(xband + po[2 * e] + koff[t]);
                     const uint32_t hi = *(const uint16_t*)(xband + po[2 * e + 1] + koff[t]);
                     x.w[e] = lo | (hi << 16);
@@ -422,7 +420,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
-            if (id >= items || (p.dbg & 2)) continue;
+            if (id >= items) continue;
             const int e0 = id * 8, row = e0 / p.W, col = e0 - row * p.W;
             const uint32_t w[4] = {xpre[j].x, xpre[j].y, xpre[j].z, xpre[j].w};          // columns col .. col + 7, two per dword
             char* dst = xband + (long)((c * rows_max + row) * 4) * p.PSTR + (col >> 2) * 2;
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
             const int q = tid / YCPP + j * (NT / YCPP);
-            if (q < npix && !(p.dbg & 4)) {
+            if (q < npix) {
                 const int oy = q / p.OW, slot = oy * p.OWP + (q - oy * p.OW);
                 const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
 #pragma unroll
@@ -629,7 +627,6 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
-    p.dbg = getenv("HULC_WG_DBG") ? atoi(getenv("HULC_WG_DBG")) : 0;
     p.X = x; p.dY = dy; p.x_dtype = x_dtype; p.dy_dtype = dy_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - KH) / S + 1; p.OW = (W - KW) / S + 1; p.R = 1; p.F = 1;
     if (nchw) { p.x_sn = (long)Cin * H * W; p.x_sc = (long)H * W; p.x_sy = W; p.x_sx = 1; }
