@@ -36,11 +36,11 @@ PEAK_HBM = 8.0e12               # HBM3E bytes/s (MI355X_MICROARCH.md)
 PMC_KERNEL = {
     ("conv2d_bwd_weight", 1024, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", 49472),
     ("conv2d_bwd_weight", 1024, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", 58176),
-    ("conv2d_fwd", 1024, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 36864),
-    ("conv2d_fwd", 1024, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 35040),
+    ("conv2d_fwd", 1024, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 36992),
+    ("conv2d_fwd", 1024, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 35168),
     ("conv2d_bwd_data", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<64, 4, 2, 2, 1, 12, false, false>", 97344),
     ("conv2d_fwd", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<32, 2, 4, 4, 2, 12, false, false>", 99840),
-    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1>", 141024),
+    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1, true>", 141024),
     ("rnn_wavefront", 32, 64, 2048, 1): ("rnn_wavefront_kernel<2048, true>", 101376),
     ("rnn_wavefront", 32, 64, 2048, 0): ("rnn_wavefront_kernel<2048, false>", 101376),
     ("hulc_adam_step",): ("adam_kernel", 0),
