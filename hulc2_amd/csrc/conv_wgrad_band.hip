@@ -54,12 +54,19 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
     const int nunits = p.F > 1 ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
     const int rows_max = (p.F - 1) * p.H + (p.R - 1) * S + TH;
     const int npix_max = (p.F * p.R * p.OW + 15) / 16 * 16;
-    const int AT_ROW = npix_max * 2 + 16;                 // dY^T row stride (bytes)
+    // TR (bf16 NHWC layers): both MFMA operands are fetched with ds_read_b64_tr_b16 — a 16-lane group hands in the addresses of a
+    // [4 pixels][16 channels] block (lane i: pixel i / 4, channels 4 (i % 4) .. + 3, any row stride) and lane i gets channel i of the 4
+    // pixels, i.e. 4 consecutive reduction indices (tools/probe/tr_probe.py pins this down).  dY stays in its natural [pixel][channel]
+    // layout (staged with 16-byte copies instead of eight 2-byte scatters per chunk) and the X fragment is two transpose reads through the
+    // pixel-offset table instead of eight 2-byte column reads.
+    constexpr bool TR = !NCHW && PURE16;
+    constexpr int DROW = COUT * 2 + 16;                   // TR: dY row stride (bytes), one row per output pixel
+    const int AT_ROW = TR ? 0 : npix_max * 2 + 16;        // dY^T row stride (bytes)
     char* xband = smem;
     const int PP = (rows_max * Wp + 7) / 8 * 8;           // NCHW plane pitch (elements)
     const int xbytes = NCHW ? C * PP * 2 : rows_max * Wb * PS;
     char* at = smem + (xbytes + 15) / 16 * 16;            // [COUT][AT_ROW]
-    int* pixoff = (int*)(at + COUT * AT_ROW);             // [npix_max] byte offset of each output pixel's patch origin
+    int* pixoff = (int*)(at + (TR ? npix_max * DROW : COUT * AT_ROW));   // [npix_max] byte offset of each output pixel's patch origin
 
     // ---- per-lane byte offset of this lane's k index inside a patch, for each k tile the wave owns
     int koff[MAXT]; bool kt_live[MAXT];
@@ -69,7 +76,10 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
         kt_live[t] = kt < KTN;
         const int k = (kt_live[t] ? kt : 0) * 32 + r;
         if (NCHW) { const int c = k / (TH * TW), kh = (k / TW) % TH, kw = k % TW; koff[t] = (c * PP + kh * Wp + kw) * 2; }
-        else { const int tap = k / C, c = k % C; koff[t] = ((tap / TW) * Wb + (tap % TW)) * PS + c * 2; }
+        else if (TR) {   // transpose read: this lane hands in channels cb + 4 (i % 4) .. + 3 of its group's 16, for pixel row i / 4
+            const int kb = (kt_live[t] ? kt : 0) * 32 + ((lane >> 4) & 1) * 16, tap = kb / C, cb = kb % C;
+            koff[t] = ((tap / TW) * Wb + (tap % TW)) * PS + (cb + (lane & 3) * 4) * 2;
+        } else { const int tap = k / C, c = k % C; koff[t] = ((tap / TW) * Wb + (tap % TW)) * PS + c * 2; }
     }
     f32x16_t acc[MAXT][CT];
 #pragma unroll
@@ -195,6 +205,8 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
                 }
+                if (TR) *(uint4*)(at + q * DROW + ycc * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+                else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint16_t bits = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
@@ -219,6 +231,32 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 
         int n, r0, R, rows, npix; unit_geom(unit, n, r0, R, rows, npix);
         const int nsteps = (npix + 15) / 16;
+        if (TR) {
+            typedef short v4s __attribute__((ext_vector_type(4)));
+            typedef v4s __attribute__((address_space(3))) * lds_v4s;
+            auto tr = [](const char* a) -> v4s { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)a); };
+            const int prow = (lane & 15) >> 2;                                  // pixel row of the 4 x 16 block this lane addresses
+            const char* abase = at + prow * DROW + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+            for (int s = 0; s < nsteps; ++s) {
+                const int m0 = s * 16 + h * 8;                                  // this lane half's 8 pixels
+                const int po0 = pixoff[m0 + prow], po1 = pixoff[m0 + 4 + prow];
+                bf16x8_t a[CT];
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    union { v4s v[2]; bf16x8_t b; } f;
+                    f.v[0] = tr(abase + m0 * DROW + i * 64); f.v[1] = tr(abase + (m0 + 4) * DROW + i * 64);
+                    a[i] = f.b;
+                }
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    if (!kt_live[t]) continue;                                  // wave-uniform
+                    union { v4s v[2]; bf16x8_t b; } x;
+                    x.v[0] = tr(xband + po0 + koff[t]); x.v[1] = tr(xband + po1 + koff[t]);
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
+                }
+            }
+        } else
         for (int s = 0; s < nsteps; ++s) {
             const int m0 = s * 16 + h * 8;                   // this lane half's 8 pixels
             const int4 po0 = *(const int4*)(pixoff + m0), po1 = *(const int4*)(pixoff + m0 + 4);
@@ -576,7 +614,8 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
         const int rows = (F - 1) * p.H + (R - 1) * S + TH;
         const long xb = NCHW ? (long)C * (((long)rows * Wp + 7) / 8 * 8) * 2 : (long)rows * Wb * PS;
         const long npad = ((long)F * R * p.OW + 15) / 16 * 16;
-        return (xb + 15) / 16 * 16 + (long)COUT * (npad * 2 + 16) + npad * 4 + 64;
+        const long dyb = (!NCHW && PURE16) ? npad * (COUT * 2 + 16) : (long)COUT * (npad * 2 + 16);
+        return (xb + 15) / 16 * 16 + dyb + npad * 4 + 64;
     };
     auto fits = [&](int R, int F) -> bool {
         const int rows = (F - 1) * p.H + (R - 1) * S + TH;
