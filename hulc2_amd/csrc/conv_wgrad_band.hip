@@ -369,10 +369,13 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
     const int nunits = ((p.Nimg - blockIdx.x + gridDim.x - 1) / gridDim.x) * bands;     // this workgroup's units
     const int rows_max = (p.R - 1) * S + 8;
     const int nbx = p.OWP / 8;                              // pixel blocks per output row
-    const int AT_ROW = p.AT_ROW;                            // dY^T row stride (bytes): an odd number of 16-byte slots
+    // dY in its natural layout, one 96-byte row (32 channels + pad) per pixel slot; the A fragment (lane = channel, 8 consecutive slots) is two
+    // ds_read_b64_tr_b16 (see the generic kernel above): no 2-byte transposing scatter while staging
+    constexpr int DR1 = 96;
+    const int nslots = p.R * p.OWP;
     char* xband = smem;                                     // [c][row][phi][PSTR bytes]
     const int xbytes = C * rows_max * 4 * p.PSTR;
-    char* at = smem + xbytes;                               // [32][AT_ROW]
+    char* at = smem + xbytes;                               // [nslots][DR1]
 
     // this lane's tap inside the wave's k tile: k = (c, kh, kw) = wave * 32 + r
     const bool live = wave < KTN;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     // zero once: the dY^T padding slots and the plane elements past W / 4 are read (times zero / as never-used taps) but never written
-    for (int o = tid * 16; o < xbytes + 32 * AT_ROW; o += NT * 16) *(uint4*)(smem + o) = make_uint4(0, 0, 0, 0);
+    for (int o = tid * 16; o < xbytes + nslots * DR1; o += NT * 16) *(uint4*)(smem + o) = make_uint4(0, 0, 0, 0);
 
     // prefetched data stays RAW in registers (fp32 frames: 8 floats per item; uint8 frames: the aligned dword windows) and is
     // converted in stage_store: any ALU use at load time would put the wait for the loads in front of the MFMA loop they overlap
@@ -487,9 +490,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
                 const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *(uint16_t*)(at + (ycc * 8 + e) * AT_ROW + slot * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+                *(uint4*)(at + slot * DR1 + ycc * 16) = ypre[j];
             }
         }
     };
@@ -510,7 +511,15 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
             // one step = 16 pixel slots: dY^T fragment (ds_read_b128), X fragment (ds_read_b128 + ds_read_b32, realigned), one MFMA
             auto fetch = [&](int st, uint4& a, uint4& w, uint32_t& w4) {
                 const bool valid = 2 * st + h < nblk;        // odd block count: the last step's second block does not exist
-                a = *(const uint4*)(at + r * AT_ROW + (2 * st + h) * 16);
+                {
+                    typedef short v4s __attribute__((ext_vector_type(4)));
+                    typedef v4s __attribute__((address_space(3))) * lds_v4s;
+                    const char* ab = at + ((2 * st + h) * 8 + ((lane & 15) >> 2)) * DR1 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+                    union { v4s v[2]; uint4 u; } f;
+                    f.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)ab);
+                    f.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)(ab + 4 * DR1));
+                    a = f.u;
+                }
                 if (!valid) a = make_uint4(0, 0, 0, 0);
                 const char* src = xband + koff + (valid ? oy : 0) * (S * 4) * p.PSTR + (valid ? bx : 0) * 16;
                 w = *(const uint4*)src;
@@ -572,7 +581,7 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     p.PSTR = ((p.OWP + 2) * 2 + 15) / 16 * 16;
     if (((p.PSTR / 16) & 1) == 0) p.PSTR += 16;
     auto at_row = [&](int R) -> int { int a = R * p.OWP * 2 + 16; if (((a / 16) & 1) == 0) a += 16; return a; };
-    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + 32L * at_row(R) + 64; };
+    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + (long)(R * p.OWP + 8) * 96 + 64; };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512 && (long)R * p.OW * 4 <= (long)YCH * 512;
