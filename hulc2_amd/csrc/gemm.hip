@@ -89,6 +89,40 @@ HULC_DEVICE void finish_operand_chunk(Chunk8& c, int K, int k0) {
     }
 }
 
+// bf16 tile product with both operands held in LDS as [k][rows] (the natural layout of a row-major operand): every fragment — lane = row,
+// 8 consecutive k — is two ds_read_b64_tr_b16 (a 16-lane group hands in a [4 k][16 rows] block, lane i gets row i of the 4 k; see
+// tools/probe/tr_probe.py).  a_tile / b_tile point at this wave's first row inside the tile, ra / rb are the k-row strides in bytes.
+template <int TM, int TN>
+HULC_DEVICE void mma_tile_bf16_tr(const char* a_tile, int ra, const char* b_tile, int rb, f32x16_t (&acc)[TM][TN], int lane) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef v4s __attribute__((address_space(3))) * lds_v4s;
+    auto tr = [](const char* q) -> v4s { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)q); };
+    const int krow = (lane >> 5) * 8 + ((lane & 15) >> 2), col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            union { v4s v[2]; bf16x8_t f; } x;
+            const char* q = a_tile + (ks * 16 + krow) * ra + col + i * 64;
+            x.v[0] = tr(q); x.v[1] = tr(q + 4 * ra);
+            a[i] = x.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            union { v4s v[2]; bf16x8_t f; } x;
+            const char* q = b_tile + (ks * 16 + krow) * rb + col + j * 64;
+            x.v[0] = tr(q); x.v[1] = tr(q + 4 * rb);
+            b[j] = x.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
 // ADT / BDT: operand storage types (HULC_F32 / HULC_BF16).  MICRO (both operands row-major, tiles fully inside the matrices, aligned:
 // checked by the launcher): 8(k) x 4 / 8 x 8 micro-tile staging, see below.
 template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK, int ADT, int BDT, bool MICRO>
@@ -125,8 +159,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     constexpr int A_MR = ADT == HULC_F32 ? 4 : 8, B_MR = BDT == HULC_F32 ? 4 : 8;      // matrix rows per micro-tile
     constexpr int MTA = BM / A_MR * NCH, MTB = BN / B_MR * NCH;
     static_assert(!MICRO || MTA + MTB <= NT, "one micro-tile per thread");
-    Chunk8 ra[MICRO ? 1 : A_PER], rb[MICRO ? 1 : B_PER];
-    uint4 mq[MICRO ? 8 : 1];
+    // TRT (bf16 MFMA): the row-major tiles are copied as they are — LDS holds [k][rows], the lanes of a load walk the contiguous row
+    // direction (full cache lines, every thread busy), and the MFMA fragments come out of ds_read_b64_tr_b16.  The micro-tile scheme
+    // (in-register transposes, half the threads idle, 64 tag lookups per load instruction) remains for the exact fp32 MFMA.
+    constexpr bool TRT = MICRO && sizeof(CT) == 2;
+    constexpr int RA_T = BM * 2 + 32, RB_T = BN * 2 + 32;          // [k] row strides: 4 consecutive k rows of a 32-byte column window hit distinct banks
+    static_assert(!TRT || KT * (RA_T + RB_T) <= (BM + BN) * HULC_ROWB, "the [k][rows] tiles fit the double buffer");
+    Chunk8 ra[(MICRO && !TRT) ? 1 : A_PER], rb[(MICRO && !TRT) ? 1 : B_PER];
+    uint4 mq[(MICRO && !TRT) ? 8 : 1];
     const int nkt_all = (p.K + KT - 1) / KT;
     const int kt_per = (nkt_all + splitk - 1) / splitk;            // blockIdx.z owns k tiles [kt0, kt1)
     const int kt0 = blockIdx.z * kt_per;
@@ -176,7 +216,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     };
 
     auto load_tiles = [&](int kt) {                          // LOAD half: issues loads, touches no loaded value
-        if constexpr (MICRO) {
+        if constexpr (TRT) {
+#pragma unroll
+            for (int q = 0; q < A_PER; ++q) {                // chunk id -> (k row, 8-row chunk): consecutive lanes walk the contiguous direction
+                const int id = tid + q * NT, kr = id / (BM / 8), mc = id % (BM / 8);
+                load_operand_chunk_raw<true, ADT>(ra[q], p.A, p.lda, p.K, p.M, kt * KT + kr, m0 + mc * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) {
+                const int id = tid + q * NT, kr = id / (BN / 8), nc = id % (BN / 8);
+                load_operand_chunk_raw<true, BDT>(rb[q], p.B, p.ldb, p.K, p.N, kt * KT + kr, n0 + nc * 8);
+            }
+        } else if constexpr (MICRO) {
             const int k0 = kt * KT + m_kg * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -201,7 +252,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
     auto store_tiles = [&](int buf, int kt) {               // FINISH half for the tile loaded by load_tiles(kt)
         char* As = smem + buf * (BM + BN) * HULC_ROWB;
         char* Bs = As + BM * HULC_ROWB;
-        if constexpr (MICRO) {
+        if constexpr (TRT) {
+            char* At = As; char* Bt = As + KT * RA_T;
+            auto put = [&](char* dst, Chunk8& c, int dt, bool live, bool sum) {
+                uint4 o;
+                if (dt == HULC_F32) {
+                    if (sum) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rs[j] += c.v[j];
+                    }
+                    o = make_uint4(pack_bf16x2(c.v[0], c.v[1]), pack_bf16x2(c.v[2], c.v[3]), pack_bf16x2(c.v[4], c.v[5]), pack_bf16x2(c.v[6], c.v[7]));
+                } else {
+                    o = make_uint4(__float_as_uint(c.v[0]), __float_as_uint(c.v[1]), __float_as_uint(c.v[2]), __float_as_uint(c.v[3]));
+                    if (sum) {
+                        const unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rs[j] += __uint_as_float((j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16));
+                    }
+                }
+                *(uint4*)dst = live ? o : make_uint4(0, 0, 0, 0);
+            };
+#pragma unroll
+            for (int q = 0; q < A_PER; ++q) {
+                const int id = tid + q * NT, kr = id / (BM / 8), mc = id % (BM / 8);
+                const bool live = kt * KT + kr < p.K;
+                put(At + kr * RA_T + mc * 16, ra[q], ADT, live, do_rowsum && live && m0 + mc * 8 < p.M);
+            }
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) {
+                const int id = tid + q * NT, kr = id / (BN / 8), nc = id % (BN / 8);
+                put(Bt + kr * RB_T + nc * 16, rb[q], BDT, kt * KT + kr < p.K, false);
+            }
+        } else if constexpr (MICRO) {
             const int k0 = kt * KT + m_kg * 8;
             uint4 q[8];
 #pragma unroll
@@ -284,7 +366,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         if (kt + 1 < kt1) load_tiles(kt + 1);
         const char* As = smem + buf * (BM + BN) * HULC_ROWB;
         const char* Bs = As + BM * HULC_ROWB;
-        MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        if constexpr (TRT) mma_tile_bf16_tr<TM, TN>(As + wm * TM * 64, RA_T, As + KT * RA_T + wn * TN * 64, RB_T, acc, lane);
+        else MmaTile<CT, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
         if (kt + 1 < kt1) store_tiles(buf ^ 1, kt + 1);
         __syncthreads();
     }
@@ -293,7 +376,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
         float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
         const bool acc_out = splitk == 1 && p.rowsum_accumulate;
-        if (AK) {
+        if (TRT) {
+            // a thread summed the 8 rows of its chunk column mc = tid % (BM / 8) over its k rows: fold the NT / (BM / 8) threads of a column
+            float* red = (float*)smem;                           // operand tiles are dead
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = rs[j];
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float v = 0.f;
+                for (int t = tid / 8; t < NT; t += BM / 8) v += red[t * 8 + (tid & 7)];
+                dst[m0 + tid] = acc_out ? dst[m0 + tid] + v : v;
+            }
+        } else if (AK) {
             static_assert(!AK || A_PER <= 8, "row sums of a k-major A: one accumulator per chunk slot");
 #pragma unroll
             for (int q = 0; q < (AK ? A_PER : 0); ++q) {
@@ -569,7 +664,8 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     const int adt = sizeof(CT) == 4 ? HULC_F32 : p.a_dtype, bdt = sizeof(CT) == 4 ? HULC_F32 : p.b_dtype;
     const int amr = adt == HULC_F32 ? 4 : 8, bmr = bdt == HULC_F32 ? 4 : 8;
     const bool micro = !ak && !bk && p.lda % amr == 0 && p.ldb % bmr == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.B % 16 == 0 &&
-                       p.M % amr == 0 && p.N % bmr == 0 && p.M >= amr && p.N >= bmr;
+                       p.M % amr == 0 && p.N % bmr == 0 && p.M >= amr && p.N >= bmr &&
+                       (sizeof(CT) == 4 || (p.M % 8 == 0 && p.N % 8 == 0));      // bf16 MFMA: 8-row chunks of the [k][rows] tiles
 #define HULC_GK(AKv, BKv, ADTv, BDTv, MICROv) gemm_kernel<CT, TM, TN, WM, WN, AKv, BKv, ADTv, BDTv, MICROv><<<grid, block, 0, s>>>(p, ws, splitk)
 #define HULC_GK_DT(AKv, BKv, MICROv)                                                              \
     do {                                                                                          \
