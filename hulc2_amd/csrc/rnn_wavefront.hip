@@ -272,7 +272,7 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.z = d->z; p.z_step = d->z_step;
     p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8 * RNN_CTR_STRIDE * 4); p.zb = (uint16_t*)((char*)ws + RNN_WS_HEADER);
     p.xb = p.zb + (long)(d->S + 2) * d->B * 2 * d->H;
-    p.zt = d->B % 8 ? nullptr : (uint16_t*)((char*)ws + hulc_rnn_wavefront_mirror_t_offset(d->S, d->B, d->H));
+    p.zt = (d->B % 8 || !d->mirror_t) ? nullptr : (uint16_t*)((char*)ws + hulc_rnn_wavefront_mirror_t_offset(d->S, d->B, d->H));
     p.ld_t = (long)(d->S + 2) * d->B;
     p.wA = (const uint16_t*)d->wA; p.wB1 = (const uint16_t*)d->wB1; p.wB2 = (const uint16_t*)d->wB2;
     p.ldA = d->ldA; p.ldB1 = d->ldB1; p.ldB2 = d->ldB2; p.tA = d->tA; p.tB1 = d->tB1; p.tB2 = d->tB2;

@@ -8,6 +8,8 @@ reference's nn.Linear / nn.Conv2d / nn.RNN layouts so state_dicts interchange.
 """
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import gradsink
@@ -381,7 +383,6 @@ class FFNFn(torch.autograd.Function):
 
 
 def _ffn_fused_ok(x, W1) -> bool:
-    import os
     return (kn.get_compute() == "bf16" and x.shape[-1] == 128 and W1.shape[0] % 128 == 0 and x.dtype == torch.float32
             and not os.environ.get("HULC_NO_FUSED_FFN"))
 
@@ -407,7 +408,6 @@ def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: fl
 def _rnn_persistent(B: int, Hd: int, state_dtype) -> bool:
     """the persistent wavefront kernel covers the benchmarked geometry (bf16 compute, H = 2048, <= 64 rows, fp32 state);
     other geometries and the exact-fp32 mode use the per-step GEMMs.  HULC_NO_RNN_WAVEFRONT=1 forces the per-step path."""
-    import os
     return (kn.get_compute() == "bf16" and Hd == 2048 and B <= 64 and state_dtype == torch.float32
             and not kn.concurrent_streams()          # its device-wide barrier needs the GPU to itself (kernels.set_concurrent_streams)
             and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
@@ -431,7 +431,6 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
     pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
     kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
-    import os
     # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
     # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
     zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
@@ -452,7 +451,8 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     if persistent:
         # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
         z16 = kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
-                               add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True)
+                               add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True,
+                               mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")))
         return zbuf, plan, emb_t, goal, z16, meta
     w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
     s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
@@ -524,7 +524,8 @@ class DecoderRNNFn(torch.autograd.Function):
             d16, d16t = kn.rnn_wavefront(dbuf[S + 1], -B * 2 * Hd, S, B, Hd, weight_operand(w_hh1), weight_operand(w_ih1), weight_operand(w_hh0), True,
                                    add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
                                    mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
-                                   mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd)
+                                   mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd,
+                                   mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")))
         else:
             whh1_t = weight_operand(w_hh1, "t")
             wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]
@@ -547,7 +548,6 @@ class DecoderRNNFn(torch.autograd.Function):
         d0 = dbuf[0:S][:, :, Hd:]     # rows (t, b): delta0_t   (strided view, ld 2H)
         # operands of the big weight-gradient GEMMs: the bf16 mirrors the persistent kernels left behind (half the bytes; the MFMA
         # rounds to bf16 while staging anyway), else the fp32 buffers
-        import os
         use16 = ctx.persistent and not os.environ.get("HULC_RNN_WGRAD_FP32")
         z16, z16t = ctx.z16 if ctx.persistent else (None, None)
         zw = z16 if use16 else zbuf
@@ -555,9 +555,10 @@ class DecoderRNNFn(torch.autograd.Function):
         d0w = d16[0:S][:, :, Hd:] if use16 else d0
         M = S * B
         fuse_b = kn.gemm_fuses_rowsum(Hd, False)
-        # transposed mirrors (feature, token = row * B + b) make both operands of the three 2048^3 weight gradients k-major: 61 us instead
-        # of 99 us per GEMM (tools/gemm_layouts.py) — the row-major tiles need an in-register transpose while they are staged
-        use_t = use16 and z16t is not None and d16t is not None and not os.environ.get("HULC_RNN_WGRAD_ROWMAJOR")
+        # transposed mirrors (HULC_RNN_WGRAD_TMIRROR=1: feature-major, k-major GEMM operands) were the faster operands while row-major
+        # tiles needed an in-register transpose (61 vs 99 us per GEMM); with the transpose-read tiles both layouts run 66-70 us and the
+        # default is the row-major mirror alone (no extra stores in the recurrent kernel)
+        use_t = use16 and z16t is not None and d16t is not None
         ldt = (S + 2) * B
 
         def wgrad_t(d_feat0, d_tok0, z_feat0, z_tok0, ncols, param, bias):

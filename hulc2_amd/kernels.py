@@ -429,7 +429,7 @@ def transpose_bf16_tiles(src, dst, tiles):
 
 
 def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1_step=0, ld_add1=0, bias1=(None, None), bias2=(None, None),
-                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False):
+                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False, mirror_t=False):
     """Both RNN layers of one direction as one persistent kernel (csrc/rnn_wavefront.hip).  z0: view of the (zero) state row
     wave step 0 reads; rows advance by z_step elements.  Weights are bf16 (H, H) matrices, `transposed` applies to all three."""
     for w in (wA, wB1, wB2):
@@ -446,6 +446,7 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     d.mask1, d.mask1_step, d.ld_mask1 = (mask1.data_ptr() if mask1 is not None else None), int(mask1_step), int(ld_mask1)
     d.mask2, d.mask2_step, d.ld_mask2 = (mask2.data_ptr() if mask2 is not None else None), int(mask2_step), int(ld_mask2)
     d.relu, d.S, d.B, d.H = int(relu), int(S), int(B), int(H)
+    d.mirror_t = int(bool(mirror_t))
     lib = _L.load()
     lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)
@@ -461,7 +462,7 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     w16 = ws.view(torch.bfloat16)
     z16 = w16[off:off + (S + 2) * B * 2 * H].view(S + 2, B, 2 * H)
     offt = lib.hulc_rnn_wavefront_mirror_t_offset(_i(S), _i(B), _i(H)) // 2
-    z16t = w16[offt:offt + (S + 2) * B * 2 * H].view(2 * H, (S + 2) * B) if offt else None     # (feature, token = row * B + b)
+    z16t = w16[offt:offt + (S + 2) * B * 2 * H].view(2 * H, (S + 2) * B) if (offt and mirror_t) else None     # (feature, token = row * B + b)
     return z16, z16t      # bf16 mirror of the S+2 state rows
 
 

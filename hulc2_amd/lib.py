@@ -90,7 +90,7 @@ class RnnWaveDesc(ctypes.Structure):
         ("bias1a", ctypes.c_void_p), ("bias1b", ctypes.c_void_p), ("bias2a", ctypes.c_void_p), ("bias2b", ctypes.c_void_p),
         ("mask1", ctypes.c_void_p), ("mask1_step", ctypes.c_long), ("ld_mask1", ctypes.c_long),
         ("mask2", ctypes.c_void_p), ("mask2_step", ctypes.c_long), ("ld_mask2", ctypes.c_long),
-        ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
+        ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int), ("mirror_t", ctypes.c_int),
     ]
 
 

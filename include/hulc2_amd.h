@@ -240,6 +240,7 @@ typedef struct hulc_rnn_wave_desc {
     const float* mask1; long mask1_step, ld_mask1;
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
+    int mirror_t;   /* also write the transposed bf16 mirror (hulc_rnn_wavefront_mirror_t_offset); needs B % 8 == 0 */
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
 long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */

@@ -56,6 +56,15 @@ def test_wavefront_matches_per_step(dev, B, S):
         assert e < 2e-2, f"grad {n}: rel L2 err {e:.3e}"     # ReLU-mask flips on bf16-level state differences
 
 
+def test_transposed_mirror_operands_give_the_same_gradients(dev, monkeypatch):
+    """HULC_RNN_WGRAD_TMIRROR=1: the weight gradients from the transposed mirrors (k-major GEMMs) against the default row-major ones"""
+    _, g0 = _run(dev, 64, 5, persistent=True, seed=2)
+    monkeypatch.setenv("HULC_RNN_WGRAD_TMIRROR", "1")
+    _, g1 = _run(dev, 64, 5, persistent=True, seed=2)
+    for a, b in zip(g0, g1):
+        assert ((a - b).norm() / b.norm().clamp_min(1e-12)).item() < 1e-5
+
+
 def test_wavefront_deterministic(dev):
     h1, g1 = _run(dev, 64, 8, persistent=True, seed=3)
     h2, g2 = _run(dev, 64, 8, persistent=True, seed=3)
@@ -76,9 +85,9 @@ def test_mirrors_agree_with_the_state_rows(dev, B, transposed):
     pre0 = torch.randn(S, B, H, generator=g).to(dev)
     zbuf = torch.zeros(S + 2, B, 2 * H, device=dev)
     if transposed:                                                   # the backward sweep: rows S+1 -> 0
-        z16, z16t = kn.rnn_wavefront(zbuf[S + 1], -B * 2 * H, S, B, H, w[0], w[1], w[2], True, add1=pre0[S - 1], add1_step=-B * H, ld_add1=H)
+        z16, z16t = kn.rnn_wavefront(zbuf[S + 1], -B * 2 * H, S, B, H, w[0], w[1], w[2], True, add1=pre0[S - 1], add1_step=-B * H, ld_add1=H, mirror_t=True)
     else:
-        z16, z16t = kn.rnn_wavefront(zbuf[0], B * 2 * H, S, B, H, w[0], w[1], w[2], False, add1=pre0, add1_step=B * H, ld_add1=H, relu=True)
+        z16, z16t = kn.rnn_wavefront(zbuf[0], B * 2 * H, S, B, H, w[0], w[1], w[2], False, add1=pre0, add1_step=B * H, ld_add1=H, relu=True, mirror_t=True)
     torch.cuda.synchronize()
     assert z16t is not None and tuple(z16t.shape) == (2 * H, (S + 2) * B)
     lo, hi = (0, S) if transposed else (1, S + 1)                    # rows the sweep wrote completely
