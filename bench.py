@@ -31,19 +31,19 @@ PEAK_F32 = 157.3e12
 PEAK_HBM = 8.0e12               # HBM3E bytes/s (MI355X_MICROARCH.md)
 
 
-# device kernel behind a timed (entry point, shape): kernel name prefix and LDS bytes of that launch in the committed --pmc passes
-# (one kernel instance serves several shapes; its launches are told apart by their LDS allocation)
+# device kernel behind a timed (entry point, shape): kernel name prefix in the committed --pmc passes.  One kernel instance serves the
+# static and the gripper camera (told apart in the passes by LDS size / grid): "max" = its launches with the larger traffic (static frames)
 PMC_KERNEL = {
-    ("conv2d_bwd_weight", 1024, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", 49472),
-    ("conv2d_bwd_weight", 1024, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", 58176),
-    ("conv2d_fwd", 1024, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 36992),
-    ("conv2d_fwd", 1024, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", 35168),
-    ("conv2d_bwd_data", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<64, 4, 2, 2, 1, 12, false, false>", 97344),
-    ("conv2d_fwd", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<32, 2, 4, 4, 2, 12, false, false>", 99840),
-    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1, true>", 141024),
-    ("rnn_wavefront", 32, 64, 2048, 1): ("rnn_wavefront_kernel<2048, true>", 101376),
-    ("rnn_wavefront", 32, 64, 2048, 0): ("rnn_wavefront_kernel<2048, false>", 101376),
-    ("hulc_adam_step",): ("adam_kernel", 0),
+    ("conv2d_bwd_weight", 1024, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "max"),
+    ("conv2d_bwd_weight", 1024, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "min"),
+    ("conv2d_fwd", 1024, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", "max"),
+    ("conv2d_fwd", 1024, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false>", "min"),
+    ("conv2d_bwd_data", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<64, 4, 2, 2, 1, 12, false, false>", "max"),
+    ("conv2d_fwd", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<32, 2, 4, 4, 2, 12, false, false>", "max"),
+    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1, true>", "max"),
+    ("rnn_wavefront", 32, 64, 2048, 1): ("rnn_wavefront_kernel<2048, true>", "max"),
+    ("rnn_wavefront", 32, 64, 2048, 0): ("rnn_wavefront_kernel<2048, false>", "max"),
+    ("hulc_adam_step",): ("adam_kernel", "max"),
 }
 
 
@@ -55,10 +55,10 @@ def pmc_traffic(key):
     files = sorted((ROOT / "profiles").glob("*_pmc_traffic.json"))
     if not want or not files:
         return None
-    for name, rec in json.loads(files[-1].read_text()).get("kernels", {}).items():
-        if name.startswith(want[0]) and f"@lds={want[1]} " in name + " ":
-            return round(rec["traffic_bytes"])
-    return None
+    hits = [rec["traffic_bytes"] for name, rec in json.loads(files[-1].read_text()).get("kernels", {}).items() if name.startswith(want[0])]
+    if not hits:
+        return None
+    return round(max(hits) if want[1] == "max" else min(hits))
 
 
 def cpu_baseline(seconds_budget=25.0):
