@@ -144,15 +144,27 @@ class DeviceEpisodeStore:
 
     # ---- base_dataset.py:94-147 on device ------------------------------------------------------------------------------
     def _buffers(self, B: int) -> Dict:
+        """Fixed device buffers of a batch of B windows.  Everything the host decides per step (window starts and sizes, dataset indices,
+        shift draws, annotation numbers, aux-loss flags) lives in ONE int32 block: it is filled in a pinned host mirror (two slots, so a
+        slot is never rewritten while its copy may still be in flight) and moved with one asynchronous copy — a pageable `copy_` per field
+        made the host wait for the previous step's GPU work every time."""
         if B not in self._buf:
             S, dev = self.max_window_size, self.device
-            i32 = dict(dtype=torch.int32, device=dev)
-            b = {"starts": torch.zeros(B, **i32), "sizes": torch.ones(B, **i32), "index": torch.zeros(B, S, **i32),
+            keys = sorted(self.rgb)
+            off, n = {}, 0
+            for name, cnt in [("idx64", 2 * B), ("starts", B), ("sizes", B), ("ann", B), ("use", B)] + [(k + "_shift", B * S * 2) for k in keys]:
+                off[name] = (n, cnt); n += cnt
+            blk = torch.zeros(n, dtype=torch.int32, device=dev)
+            view = lambda t, name: t[off[name][0]:off[name][0] + off[name][1]]
+            b = {"block": blk, "off": off, "slot": 0, "events": [None, None],
+                 "host": [torch.zeros(n, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(n, dtype=torch.int32) for _ in range(2)],
+                 "starts": view(blk, "starts"), "sizes": view(blk, "sizes"), "idx": view(blk, "idx64").view(torch.int64),
+                 "ann": view(blk, "ann"), "use": view(blk, "use"),
+                 "index": torch.zeros(B, S, dtype=torch.int32, device=dev),
                  "actions": torch.zeros(B, S, self.rel_actions.shape[1], device=dev),
-                 "robot_obs": torch.zeros(B, S, self.robot_obs.shape[1], device=dev),
-                 "idx": torch.zeros(B, dtype=torch.long, device=dev)}
-            for k in self.rgb:
-                b[k + "_shift"] = torch.zeros(B, S, 2, **i32)
+                 "robot_obs": torch.zeros(B, S, self.robot_obs.shape[1], device=dev)}
+            for k in keys:
+                b[k + "_shift"] = view(blk, k + "_shift").view(B, S, 2)
             if self.scene_obs is not None:
                 b["scene_obs"] = torch.zeros(B, S, self.scene_obs.shape[1], device=dev)
             if self.lang_emb is not None:
@@ -170,9 +182,28 @@ class DeviceEpisodeStore:
         if sizes.min() < 1 or sizes.max() > S:
             raise ValueError("window sizes must lie in [1, max_window_size]")
         buf = self._buffers(B)
-        buf["starts"].copy_(torch.from_numpy(self.episode_lookup[idxs].astype(np.int32)))
-        buf["sizes"].copy_(torch.from_numpy(sizes))
-        buf["idx"].copy_(torch.from_numpy(idxs))
+        slot = buf["slot"]; buf["slot"] = slot ^ 1
+        if buf["events"][slot] is not None:
+            buf["events"][slot].synchronize()                         # the copy that last read this host slot has finished (two steps ago)
+        host, off = buf["host"][slot], buf["off"]
+        hv = lambda name: host[off[name][0]:off[name][0] + off[name][1]]
+        hv("idx64").view(torch.int64).copy_(torch.from_numpy(idxs))
+        hv("starts").copy_(torch.from_numpy(self.episode_lookup[idxs].astype(np.int32)))
+        hv("sizes").copy_(torch.from_numpy(sizes))
+        with_shift = shifts is not None or not self.validation         # the validation transforms carry no RandomShiftsAug
+        if with_shift:
+            for k in self.rgb:
+                pad = self.AUG_PAD.get(k, 0)
+                if shifts is not None:
+                    hv(k + "_shift").copy_(shifts[k].reshape(-1).to(torch.int32))
+                else:
+                    torch.randint(0, 2 * pad + 1, (B * S * 2,), generator=self.generator, dtype=torch.int32, out=hv(k + "_shift"))
+        if self.lang_emb is not None:
+            hv("ann").copy_(torch.from_numpy(self.lang_lookup[idxs].astype(np.int32)))
+            hv("use").copy_(torch.from_numpy(np.asarray([self.use_for_aux_lang_loss(int(i)) for i in idxs], dtype=np.int32)))
+        buf["block"].copy_(host, non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event(); ev.record(); buf["events"][slot] = ev
         kn.window_index(buf["starts"], buf["sizes"], B, S, buf["index"])
         kn.window_rows(self.rel_actions, buf["starts"], buf["sizes"], B, S, buf["actions"], zero_cols=(0, self.rel_actions.shape[1] - 1))
         kn.window_rows(self.robot_obs, buf["starts"], buf["sizes"], B, S, buf["robot_obs"])
@@ -184,18 +215,13 @@ class DeviceEpisodeStore:
         for k, store in self.rgb.items():
             rgb_obs[k] = store
             rgb_obs[k + "_index"] = buf["index"]
-            if shifts is not None or not self.validation:              # the validation transforms carry no RandomShiftsAug
-                pad = self.AUG_PAD.get(k, 0)
-                sh = shifts[k] if shifts is not None else torch.randint(0, 2 * pad + 1, (B, S, 2), generator=self.generator, dtype=torch.int32)
-                buf[k + "_shift"].copy_(sh.reshape(B, S, 2))
+            if with_shift:
                 rgb_obs[k + "_shift"] = buf[k + "_shift"]
         out = {"rgb_obs": rgb_obs, "depth_obs": {}, "robot_obs": buf["robot_obs"], "actions": buf["actions"], "state_info": state_info,
                "idx": buf["idx"], "window_sizes": buf["sizes"]}
         if self.lang_emb is not None:
-            ann = torch.from_numpy(self.lang_lookup[idxs]).to(self.device)
-            torch.index_select(self.lang_emb, 0, ann, out=buf["lang"])
+            torch.index_select(self.lang_emb, 0, buf["ann"], out=buf["lang"])
+            torch.ne(buf["use"], 0, out=buf["use_aux"])
             out["lang"] = buf["lang"]
-            use = np.asarray([self.use_for_aux_lang_loss(int(i)) for i in idxs])
-            buf["use_aux"].copy_(torch.from_numpy(use))
             out["use_for_aux_lang_loss"] = buf["use_aux"]
         return out

@@ -19,7 +19,7 @@ for db in batch.values():
 for i in range(2):
     tr.step(batch, i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
     tr.step(batch, 2)
 torch.cuda.synchronize()
 want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::div", "aten::sum",
@@ -31,3 +31,13 @@ for ev in prof.key_averages(group_by_input_shape=True):
         agg[(ev.key, str(ev.input_shapes)[:110])] += ev.count
 for (k, shp), n in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1])):
     print(f"{n:4d}  {k:22s} {shp}")
+
+# ---- call sites (first frame inside hulc2_amd) of the ops that launch a kernel
+sites = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::cat", "aten::zero_", "aten::mul", "aten::div", "aten::index_select"):
+        fr = next((f for f in (ev.stack or []) if "hulc2_amd" in f), "?")
+        sites[(ev.name, fr.split("hulc2_amd/")[-1][:90])] += 1
+print("\ncall sites:")
+for (k, fr), n in sorted(sites.items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{n:4d}  {k:14s} {fr}")
