@@ -75,10 +75,12 @@ class MLPFn(torch.autograd.Function):
             dW = sw if sw is not None else _f32(N, K, like=g)
             db = sb if sb is not None else _f32(N, like=g)
             fused = kn.gemm_fuses_rowsum(N, False) and g.dtype == torch.float32     # bias gradient = row sums of g^T: same launch
+            acc_w = sw is not None and not gradsink.first_write(W)
+            acc_b = sb is not None and not gradsink.first_write(params[2 * i + 1])
             kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False,
-                    accumulate=sw is not None, rowsum=db if fused else None, rowsum_accumulate=sb is not None)    # dW (+)= g^T inp
+                    accumulate=acc_w, rowsum=db if fused else None, rowsum_accumulate=acc_b)    # dW (+)= g^T inp
             if not fused:
-                kn.colsum(g, M, N, g.stride(0), db, accumulate=sb is not None)
+                kn.colsum(g, M, N, g.stride(0), db, accumulate=acc_b)
             grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
             grads[2 * i + 1] = None if sb is not None else db
             if i > 0 or need_x:
@@ -172,15 +174,19 @@ class ConvStackFn(torch.autograd.Function):
             sunk = sw is not None and sb is not None      # the reduce pass writes OIHW straight into the gradient arena
             dw = sw.view(cout, cin * k * k) if sunk else _f32(cout, cin * k * k, like=g)
             db = sb if sunk else _f32(cout, like=g)
+            acc = sunk
+            if sunk:                                     # dW and db leave one launch: one flag for both
+                fw, fb = gradsink.first_write(ctx.conv_w[li]), gradsink.first_write(ctx.conv_b[li])
+                acc = not (fw and fb)
             if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
                 pad, shifts, indices = ctx.aug
                 for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
-                    kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk or j > 0,
+                    kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc or j > 0,
                                          aug_shift=sh, aug_pad=pad, frame_index=ix)
                     off += n
             else:
-                kn.conv2d_bwd_weight(inputs[li], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=sunk)
+                kn.conv2d_bwd_weight(inputs[li], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc)
             grads_w[li] = None if sunk else dw.view(cout, cin, k, k)
             grads_b[li] = None if sunk else db
             if li > 0:
@@ -261,7 +267,11 @@ class LayerNormFn(torch.autograd.Function):
         sg, sb = gradsink.get(gamma), gradsink.get(ctx.beta)
         sunk = sg is not None and sb is not None                  # straight into the gradient arena (no AccumulateGrad adds)
         dg, db = (sg, sb) if sunk else (_f32(D, like=dy2), _f32(D, like=dy2))
-        kn.layernorm_bwd(dy2, pre, mean, rstd, gamma, R, D, dpre, do, drop_p, seed, dg, db, accumulate_params=sunk)
+        acc = sunk
+        if sunk:
+            fg, fb = gradsink.first_write(gamma), gradsink.first_write(ctx.beta)
+            acc = not (fg and fb)
+        kn.layernorm_bwd(dy2, pre, mean, rstd, gamma, R, D, dpre, do, drop_p, seed, dg, db, accumulate_params=acc)
         dx = dpre.reshape(shape)
         d_o = None
         if has_o:
@@ -375,9 +385,13 @@ class FFNFn(torch.autograd.Function):
         sunk = all(s is not None for s in sinks)
         dW1, db1, dW2, db2 = sinks if sunk else (_f32(FF, D, like=df2), _f32(FF, like=df2), _f32(D, FF, like=df2), _f32(D, like=df2))
         dx = _f32(T, D, like=df2)
+        acc, acc_b2 = sunk, sunk
+        if sunk:
+            f = [gradsink.first_write(t) for t in (W1, b1, W2, b2)]
+            acc, acc_b2 = not all(f[:3]), not f[3]
         kn.ffn_bwd(x2, df2, weight_operand(W1), b1, weight_operand(W1, "t"), weight_operand(W2, "t"), T, D, FF, drop_p, seed, dx, dW1, db1, dW2,
-                   accumulate_params=sunk)
-        kn.colsum(df2, T, D, D, db2, accumulate=sunk)
+                   accumulate_params=acc)
+        kn.colsum(df2, T, D, D, db2, accumulate=acc_b2)
         g = (None, None, None, None) if sunk else (dW1, db1, dW2, db2)
         return (dx.reshape(shape), *g, None, None)
 
@@ -567,7 +581,8 @@ class DecoderRNNFn(torch.autograd.Function):
             out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
             bout = bsink if bsink is not None else torch.empty(Hd, **f32)
             kn.gemm(d16t[d_feat0:, d_tok0 * B:], z16t[z_feat0:, z_tok0 * B:], out, Hd, ncols, M, ldt, ldt, ncols, a_kmajor=True, b_kmajor=True,
-                    accumulate=sink is not None, rowsum=bout, rowsum_accumulate=bsink is not None)
+                    accumulate=sink is not None and not gradsink.first_write(param), rowsum=bout,
+                    rowsum_accumulate=bsink is not None and not gradsink.first_write(bias))
             return (None if sink is not None else out), (None if bsink is not None else bout)
 
         def wgrad(dlt, inp_rows, ncols, param, bias):
@@ -576,10 +591,11 @@ class DecoderRNNFn(torch.autograd.Function):
             sink, bsink = gradsink.get(param), gradsink.get(bias)
             out = sink if sink is not None else torch.empty(Hd, ncols, **f32)
             bout = bsink if bsink is not None else torch.empty(Hd, **f32)
-            kn.gemm(dlt, inp_rows, out, Hd, ncols, M, 2 * Hd, 2 * Hd, ncols, a_kmajor=False, b_kmajor=False, accumulate=sink is not None,
-                    rowsum=bout if fuse_b else None, rowsum_accumulate=bsink is not None)
+            acc_b = bsink is not None and not gradsink.first_write(bias)
+            kn.gemm(dlt, inp_rows, out, Hd, ncols, M, 2 * Hd, 2 * Hd, ncols, a_kmajor=False, b_kmajor=False,
+                    accumulate=sink is not None and not gradsink.first_write(param), rowsum=bout if fuse_b else None, rowsum_accumulate=acc_b)
             if not fuse_b:
-                kn.colsum(dlt, M, Hd, 2 * Hd, bout, accumulate=bsink is not None)
+                kn.colsum(dlt, M, Hd, 2 * Hd, bout, accumulate=acc_b)
             return (None if sink is not None else out), (None if bsink is not None else bout)
 
         b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
@@ -599,18 +615,19 @@ class DecoderRNNFn(torch.autograd.Function):
         wih0 = weight_operand(w_ih0)
         s_ih0 = gradsink.get(w_ih0)
         dw_ih0 = s_ih0 if s_ih0 is not None else torch.empty(Hd, Kin, **f32)
-        acc0 = s_ih0 is not None
+        acc0 = s_ih0 is not None and not gradsink.first_write(w_ih0)     # three GEMMs, each the only writer of its column slice
         kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
         sb_ih0 = gradsink.get(b_ih0)
         db_ih0 = sb_ih0 if sb_ih0 is not None else torch.empty(Hd, **f32)
+        acc_b0 = sb_ih0 is not None and not gradsink.first_write(b_ih0)
         kn.gemm(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
-                rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=sb_ih0 is not None)
+                rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=acc_b0)
         if not fuse_b:
-            kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=sb_ih0 is not None)
+            kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=acc_b0)
         if sb_ih0 is not None:
             db_ih0 = None
         kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
-        if acc0:
+        if s_ih0 is not None:                 # written straight into the gradient arena
             dw_ih0 = None
         wih0_t = weight_operand(w_ih0, "t")                                         # (Kin, H): rows = input features, k-major
         dplan = torch.empty(B, P, **f32)

@@ -29,3 +29,29 @@ def get(param: torch.Tensor) -> Optional[torch.Tensor]:
     if hit is not None and hit[0]() is param:
         return hit[1]
     return None
+
+
+# ---- first write of a step overwrites --------------------------------------------------------------------------------------------
+# A sink that is written exactly once per step does not need a zeroed arena slice nor a read-modify-write epilogue: the trainer turns
+# `overwrite mode` on once it has seen (in a first, fully zeroed step) which sinks the backward kernels write, stops zeroing those slices
+# and the writers ask first_write() whether they are the first contribution of the step.
+_written = set()
+_overwrite = False
+
+
+def begin_step(overwrite: bool) -> None:
+    global _overwrite
+    _written.clear()
+    _overwrite = bool(overwrite)
+
+
+def first_write(param: torch.Tensor) -> bool:
+    """marks the sink of `param` as written in this step; True when the caller may OVERWRITE it (first write, overwrite mode on)"""
+    k = id(param)
+    first = k not in _written
+    _written.add(k)
+    return first and _overwrite
+
+
+def written(param: torch.Tensor) -> bool:
+    return id(param) in _written

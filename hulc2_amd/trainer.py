@@ -15,6 +15,8 @@ backward -> DDP bucketed all-reduce -> Adam step).  Lightning is a third-party l
 """
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -268,13 +270,43 @@ class ArenaTrainer:
         g, emb.grad = emb.grad, None
         torch.autograd.backward(emb, grad_tensors=g, inputs=self.enc_params)
 
+    def _plan_partial_zero(self) -> None:
+        """After a fully zeroed step: the arena slices NOT written through a gradient sink are the only ones the next steps need zeroed
+        (autograd's `param.grad += g` lands there); sinks written by the backward kernels are overwritten by their first writer
+        (gradsink.first_write).  Neighbouring must-zero slices are merged across small written ones — zeroing a slice that is overwritten
+        later is harmless, one fill launch per slice is not."""
+        spans = []                                                 # arena ranges of fused groups whose single sink was written
+        for pv, gv, off, shape in self.fused:
+            if gradsink.written(pv):
+                spans.append((off, off + gv.numel()))
+        inside = lambda a, b: any(lo <= a and b <= hi for lo, hi in spans)
+        need = [(off, off + p.numel()) for p, off in zip(self.params, self.offsets)
+                if not (gradsink.written(p) or inside(off, off + p.numel()))]
+        merged = []
+        for a, b in sorted(need):
+            if merged and a - merged[-1][1] <= (1 << 18):          # gaps up to 1 MB of fp32 are cheaper to zero than another launch
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        self._zero_ranges = [(a, b) for a, b in merged]
+
+    _zero_ranges = None
+
     def zero_grad(self):
-        self.flat_g.zero_()
+        if self._zero_ranges is None or os.environ.get("HULC_FULL_ZERO_GRAD"):
+            self.flat_g.zero_()
+            gradsink.begin_step(False)
+        else:
+            for a, b in self._zero_ranges:
+                self.flat_g[a:b].zero_()
+            gradsink.begin_step(True)
         for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point at the arena
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
 
     def optimizer_step(self):
+        if self._zero_ranges is None and gradsink._sinks and not os.environ.get("HULC_FULL_ZERO_GRAD"):
+            self._plan_partial_zero()                              # the backward that just finished ran on a fully zeroed arena
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,

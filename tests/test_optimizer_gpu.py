@@ -109,3 +109,33 @@ def test_training_loop_tracks_oracle(dev, mode, tol):
     finally:
         kn.set_compute("bf16")
         kn.reset_step_state(dev)
+
+
+def test_first_write_overwrite_equals_zeroed_arena(dev, monkeypatch):
+    """From the second step on the trainer stops zeroing the gradient slices the backward kernels write (their first writer overwrites,
+    gradsink.first_write): parameters after 4 steps are bit-identical to a trainer that zeroes the whole arena every step."""
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.trainer import ArenaTrainer
+
+    kn.set_compute("bf16")
+    batch = syn.make_batch(5, 2, 8, device=dev)
+    finals, planned = [], []
+    for full in (True, False):
+        if full:
+            monkeypatch.setenv("HULC_FULL_ZERO_GRAD", "1")
+        else:
+            monkeypatch.delenv("HULC_FULL_ZERO_GRAD", raising=False)
+        m = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+        syn.fill_state_dict_(m.state_dict(), 21)
+        m.train()
+        tr = ArenaTrainer(m, lr=2e-4)
+        kn.reset_step_state(dev)
+        for i in range(4):
+            tr.step(batch, i)
+        torch.cuda.synchronize()
+        finals.append(tr.flat_p.clone())
+        planned.append(tr._zero_ranges)
+    assert planned[0] is None and planned[1] is not None
+    zeroed = sum(b - a for a, b in planned[1])
+    assert zeroed < 0.2 * finals[0].numel(), "most of the arena is written by sinks and no longer zeroed"
+    assert torch.equal(finals[0], finals[1])
