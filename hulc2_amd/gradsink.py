@@ -55,3 +55,7 @@ def first_write(param: torch.Tensor) -> bool:
 
 def written(param: torch.Tensor) -> bool:
     return id(param) in _written
+
+
+def written_ids() -> frozenset:
+    return frozenset(_written)

@@ -289,6 +289,9 @@ class ArenaTrainer:
             else:
                 merged.append([a, b])
         self._zero_ranges = [(a, b) for a, b in merged]
+        self._planned_written = gradsink.written_ids()
+        self._sink_slices = {id(p): (off, off + p.numel()) for p, off in zip(self.params, self.offsets)}
+        self._sink_slices.update({id(pv): (off, off + gv.numel()) for pv, gv, off, _ in self.fused})
 
     _zero_ranges = None
 
@@ -307,6 +310,12 @@ class ArenaTrainer:
     def optimizer_step(self):
         if self._zero_ranges is None and gradsink._sinks and not os.environ.get("HULC_FULL_ZERO_GRAD"):
             self._plan_partial_zero()                              # the backward that just finished ran on a fully zeroed arena
+        elif self._zero_ranges is not None:
+            # a sink the plan expects to be overwritten was not written by this backward (a branch of the model did not run): its slice
+            # still holds the previous step's gradient — the true gradient is zero
+            for k in self._planned_written - gradsink.written_ids():
+                a, b = self._sink_slices[k]
+                self.flat_g[a:b].zero_()
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,

@@ -113,7 +113,7 @@ def test_training_loop_tracks_oracle(dev, mode, tol):
 
 def test_first_write_overwrite_equals_zeroed_arena(dev, monkeypatch):
     """From the second step on the trainer stops zeroing the gradient slices the backward kernels write (their first writer overwrites,
-    gradsink.first_write): parameters after 4 steps are bit-identical to a trainer that zeroes the whole arena every step."""
+    gradsink.first_write): parameters after 4 steps plus one vision-only step (sinks the plan expects but nobody writes) are bit-identical to a trainer that zeroes the whole arena every step."""
     from hulc2_amd import kernels as kn
     from hulc2_amd.trainer import ArenaTrainer
 
@@ -132,6 +132,7 @@ def test_first_write_overwrite_equals_zeroed_arena(dev, monkeypatch):
         kn.reset_step_state(dev)
         for i in range(4):
             tr.step(batch, i)
+        tr.step({"vis": batch["vis"]}, 4)                              # a step in which the language-only parameters get no gradient at all
         torch.cuda.synchronize()
         finals.append(tr.flat_p.clone())
         planned.append(tr._zero_ranges)
