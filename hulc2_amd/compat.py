@@ -120,7 +120,8 @@ def install_as_hulc2() -> None:
     names = [
         "hulc2_amd", "hulc2_amd.models", "hulc2_amd.models.hulc2", "hulc2_amd.models.perceptual_encoders",
         "hulc2_amd.models.perceptual_encoders.concat_encoders", "hulc2_amd.models.perceptual_encoders.vision_network",
-        "hulc2_amd.models.perceptual_encoders.vision_network_gripper", "hulc2_amd.models.encoders",
+        "hulc2_amd.models.perceptual_encoders.vision_network_gripper", "hulc2_amd.models.perceptual_encoders.vision_r3m",
+        "hulc2_amd.models.encoders",
         "hulc2_amd.models.encoders.goal_encoders", "hulc2_amd.models.plan_encoders",
         "hulc2_amd.models.plan_encoders.plan_proposal_net", "hulc2_amd.models.plan_encoders.plan_recognition_net",
         "hulc2_amd.models.decoders", "hulc2_amd.models.decoders.action_decoder", "hulc2_amd.models.decoders.logistic_decoder_rnn",
@@ -130,4 +131,16 @@ def install_as_hulc2() -> None:
     for n in names:
         m = importlib.import_module(n)
         sys.modules["hulc2" + n[len("hulc2_amd"):]] = m
+    # conf/model/language_encoder/sbert.yaml:1 names the sentence encoder under the affordance package
+    import types
+    enc = importlib.import_module("hulc2_amd.models.language_encoders.sbert_lang_encoder")
+    chain = ("hulc2", "hulc2.affordance", "hulc2.affordance.models", "hulc2.affordance.models.language_encoders")
+    for parent, pkg in zip(chain, chain[1:]):
+        if pkg not in sys.modules:
+            mod = types.ModuleType(pkg)
+            mod.__path__ = []
+            sys.modules[pkg] = mod
+        setattr(sys.modules[parent], pkg.rsplit(".", 1)[1], sys.modules[pkg])
+    sys.modules[chain[-1] + ".sbert_lang_encoder"] = enc
+    sys.modules[chain[-1]].sbert_lang_encoder = enc
     _ = hulc2_amd

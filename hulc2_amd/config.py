@@ -56,3 +56,18 @@ def default_model_config(gripper_control: bool = True, dropout_p: float = 0.1, s
             "output_dim": 32, "proj_lang": True},
         "kl_beta": 0.01, "kl_balancing_mix": 0.8, "replan_freq": 30, "use_clip_auxiliary_loss": True, "clip_auxiliary_loss_beta": 3.0,
     })
+
+
+def real_world_model_config(dropout_p: float = 0.1) -> Config:
+    """conf/cfg_low_level_rw.yaml -> conf/model/real_world_hulc++.yaml (BASELINE configs[3]): static camera through the frozen R3M trunk
+    (conf/model/perceptual_encoder/rgb_static/r3m.yaml), the decoder sees the whole perceptual embedding and predicts world-frame actions
+    (conf/model/action_decoder/logistic_decoder_rnn_real_world.yaml:15,19), no CLIP auxiliary loss (real_world_hulc++.yaml:12,20);
+    language arrives as precomputed embeddings like the headline config (language_encoder = none)."""
+    cfg = default_model_config(gripper_control=False, dropout_p=dropout_p)
+    cfg["perceptual_encoder"]["rgb_static"] = Config.wrap({
+        "_target_": "hulc2.models.perceptual_encoders.vision_r3m.VisionR3M", "visual_features": 64, "freeze_backbone": True,
+        "resnet_model": "resnet18"})
+    cfg["action_decoder"]["perceptual_emb_slice"] = [0, 128]
+    cfg["proj_vis_lang"] = None
+    cfg["use_clip_auxiliary_loss"] = False
+    return cfg

@@ -41,8 +41,8 @@ namespace {
 #define HULC_MAX_TAPS 64
 
 struct GatherP {
-    const void* X; void* Y; const void* Wt; const float* bias; const void* mask;
-    int x_dtype, y_dtype, w_dtype, mask_dtype;
+    const void* X; void* Y; const void* Wt; const float* bias; const void* mask; const void* add;
+    int x_dtype, y_dtype, w_dtype, mask_dtype, add_dtype;
     int Nimg, OH, OW, Cout, H, W;
     long x_sn, x_sy, x_sx;
     long y_sn, y_sy, y_sx;
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
                 const long off = out_off[(wm * TM + i) * 32 + acc_row(e, lane)];
                 if (off < 0) continue;
                 float v = acc[i][j][e] + bv;
+                if (p.add) v += load_elem(p.add, p.add_dtype, off + n);       // residual branch of a ResNet block
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.mask) v = load_elem(p.mask, p.mask_dtype, off + n) > 0.f ? v * p.mask_scale : 0.f;
                 store_elem(p.Y, p.y_dtype, off + n, v);
@@ -445,7 +446,7 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     int rc = validate(d, "fwd"); if (rc) return rc;
     if (!x || !w || !y) return hulc_fail(-1, "hulc_conv2d_fwd: null pointer");
     GatherP g; fill_gather(g, d);
-    g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f;
+    g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = nullptr; g.add_dtype = HULC_F32;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
     if (d->compute == HULC_BF16 && !d->x_nchw && d->KH * d->KW <= 16 && d->Cout % 32 == 0 && d->Cout / 32 <= 4) {
@@ -471,6 +472,37 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     if (d->x_u8_nhwc) return hulc_fail(-6, "hulc_conv2d_fwd: uint8 frames are consumed by the conv1 band kernel only (bf16 compute, 3 -> 32, 8x8 stride 4, W % 4 == 0)");
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_fwd");
+}
+
+// Zero-padded convolution of the frozen ResNet trunk (VisionR3M): NHWC x, OHWI weights with the BatchNorm scale
+// folded in, bias = the folded shift, optional residual `add` (same shape / dtype as y) summed before the ReLU.
+extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const void* x, const void* w, const float* bias, const void* add, void* y,
+                                      void* stream) {
+    if (!d || !x || !w || !y) return hulc_fail(-1, "hulc_conv2d_padded_fwd: null pointer");
+    if (d->x_nchw || d->x_u8_nhwc) return hulc_fail(-7, "hulc_conv2d_padded_fwd: NHWC activations only");
+    if (d->N <= 0 || d->stride <= 0 || pad < 0 || d->H + 2 * pad < d->KH || d->W + 2 * pad < d->KW) return hulc_fail(-2, "hulc_conv2d_padded_fwd: bad geometry");
+    if (d->KH * d->KW > HULC_MAX_TAPS) return hulc_fail(-3, "hulc_conv2d_padded_fwd: too many taps");
+    if (log2_exact(d->Cin) < 3) return hulc_fail(-4, "hulc_conv2d_padded_fwd: Cin must be a power of two >= 8");
+    if (d->Cout % 32) return hulc_fail(-5, "hulc_conv2d_padded_fwd: Cout must be a multiple of 32");
+    if (d->compute == HULC_F32 && (d->x_dtype != HULC_F32 || d->w_dtype != HULC_F32)) return hulc_fail(-6, "hulc_conv2d_padded_fwd: f32 compute requires f32 operands");
+    GatherP g;
+    g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = add; g.add_dtype = d->y_dtype;
+    g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype; g.y_dtype = d->y_dtype; g.relu = d->relu;
+    g.Nimg = d->N; g.H = d->H; g.W = d->W; g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = pad > 0;
+    g.OH = (d->H + 2 * pad - d->KH) / d->stride + 1; g.OW = (d->W + 2 * pad - d->KW) / d->stride + 1;
+    g.x_sn = (long)d->H * d->W * d->Cin; g.x_sy = (long)d->W * d->Cin; g.x_sx = d->Cin;
+    g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
+    g.ntaps = d->KH * d->KW; g.inner_log2 = log2_exact(d->Cin);
+    for (int kh = 0; kh < d->KH; ++kh)
+        for (int kw = 0; kw < d->KW; ++kw) {
+            const int t = kh * d->KW + kw;
+            g.tap_dy[t] = kh - pad; g.tap_dx[t] = kw - pad;
+            g.tap_off[t] = (long)(kh - pad) * g.x_sy + (long)(kw - pad) * g.x_sx;
+            g.w_tap_off[t] = (long)t * d->Cin;
+        }
+    g.ldw = (long)g.ntaps << g.inner_log2;
+    if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
+    return hulc_check_launch("hulc_conv2d_padded_fwd");
 }
 
 // dX (NHWC [N][H][W][Cin]) from dY (NHWC [N][OH][OW][Cout]); wt = weights permuted to [Cin][KH][KW][Cout].
@@ -509,7 +541,7 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
             GatherP g;
-            g.X = dy; g.x_dtype = d->y_dtype; g.Wt = wt; g.w_dtype = d->w_dtype; g.bias = nullptr;
+            g.X = dy; g.x_dtype = d->y_dtype; g.Wt = wt; g.w_dtype = d->w_dtype; g.bias = nullptr; g.add = nullptr; g.add_dtype = HULC_F32;
             g.Nimg = d->N; g.H = OH; g.W = OW;                       // the gathered tensor is dY
             g.OH = (d->H - py + s - 1) / s; g.OW = (d->W - px + s - 1) / s;   // this class' sub-grid of dX
             if (g.OH <= 0 || g.OW <= 0) continue;

@@ -1,0 +1,82 @@
+// resnet.hip — the pieces of the frozen ResNet-18 trunk of VisionR3M that are not convolutions.
+//
+// reference behaviour: hulc2/models/perceptual_encoders/vision_r3m.py:8-32 runs `self.r3m(x)` under no_grad on frames in [0, 255]
+// (conf/datamodule/transforms/real_world_r3m.yaml:2-13).  `r3m` is an un-vendored submodule (parity unpinned); its public
+// forward is obs / 255 -> Normalize(ImageNet mean, std) -> torchvision resnet18 with fc = Identity.  The convolutions (BatchNorm folded
+// into weights + bias, residual add and ReLU in the epilogue) are hulc_conv2d_padded_fwd (conv.hip); this file holds the input
+// normalisation and the stem's max pool.  The global average pool is hulc_strided_seq_sum over the (H*W) axis.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+// x fp32 NCHW [N][3][H][W] in [0, 255] -> y NHWC [N][H][W][8]: channel c < 3 = (x / 255 - mean[c]) * inv_std[c], channels 3..7 zero
+// (8 channels make a pixel one aligned 16-byte bf16 chunk — the gather unit of the conv kernel; the stem's weights are zero there)
+__global__ __launch_bounds__(256) void r3m_normalize_kernel(const float* __restrict__ x, long HW, long total, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2, void* __restrict__ y, int y_dtype) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // pixel index over N*H*W
+    if (i >= total) return;
+    const long n = i / HW, p = i - n * HW;
+    const float* px = x + n * 3 * HW + p;
+    const float a = (px[0] / 255.f - m0) * s0, b = (px[HW] / 255.f - m1) * s1, c = (px[2 * HW] / 255.f - m2) * s2;
+    if (y_dtype == HULC_BF16) {
+        ((uint4*)y)[i] = make_uint4(pack_bf16x2(a, b), pack_bf16x2(c, 0.f), 0u, 0u);
+    } else {
+        float4* o = (float4*)y + 2 * i;
+        o[0] = make_float4(a, b, c, 0.f); o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// max pool k x k, stride s, padding p (padded positions never win: nn.MaxPool2d pads with -inf), NHWC, 8 channels per thread
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const void* __restrict__ x, int dtype, int H, int W, int C8, int OH, int OW, int k, int s,
+                                                           int pad, long total, void* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*OH*OW*C8
+    if (i >= total) return;
+    const int c8 = (int)(i % C8); long r = i / C8;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const long n = r / OH;
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * s - pad + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = ox * s - pad + kx;
+            if (ix < 0 || ix >= W) continue;
+            Chunk8 c;
+            chunk_load_contig(c, x, dtype, ((n * H + iy) * W + ix) * (long)C8 * 8 + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], c.v[e]);
+        }
+    }
+    const long o = i * 8;
+    if (dtype == HULC_BF16) {
+        *(uint4*)((uint16_t*)y + o) = make_uint4(pack_bf16x2(best[0], best[1]), pack_bf16x2(best[2], best[3]), pack_bf16x2(best[4], best[5]),
+                                                 pack_bf16x2(best[6], best[7]));
+    } else {
+        float4* q = (float4*)((float*)y + o);
+        q[0] = make_float4(best[0], best[1], best[2], best[3]); q[1] = make_float4(best[4], best[5], best[6], best[7]);
+    }
+}
+
+}  // namespace
+
+extern "C" int hulc_r3m_normalize(const float* x, int N, int H, int W, const float* mean3, const float* std3, void* y, int y_dtype, void* stream) {
+    if (!x || !mean3 || !std3 || !y) return hulc_fail(-1, "hulc_r3m_normalize: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return hulc_fail(-2, "hulc_r3m_normalize: bad shape");
+    const long HW = (long)H * W, total = HW * N;
+    r3m_normalize_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
+                                                                                          1.f / std3[1], 1.f / std3[2], y, y_dtype);
+    return hulc_check_launch("hulc_r3m_normalize");
+}
+
+extern "C" int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* y, void* stream) {
+    if (!x || !y) return hulc_fail(-1, "hulc_maxpool_nhwc: null pointer");
+    if (N <= 0 || C <= 0 || C % 8 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k || H + 2 * pad < k || W + 2 * pad < k)
+        return hulc_fail(-2, "hulc_maxpool_nhwc: bad geometry (C must be a multiple of 8, 2 * pad <= k)");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    const long total = (long)N * OH * OW * (C / 8);
+    maxpool_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, dtype, H, W, C / 8, OH, OW, k, stride, pad, total, y);
+    return hulc_check_launch("hulc_maxpool_nhwc");
+}

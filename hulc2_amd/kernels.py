@@ -230,6 +230,40 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
     return y
 
 
+def conv2d_padded_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, pad, relu=True, add=None, compute=None):
+    """y (NHWC) = [relu](conv_pad(x, w) + bias [+ add]): the convolutions of the frozen ResNet trunk (VisionR3M), BatchNorm folded into
+    w2d [Cout][KH*KW*Cin] / bias; add = the residual branch, shaped and typed like y."""
+    _require_cuda(x, w2d, bias, y, add)
+    _require_contiguous(x=x, w2d=w2d, y=y)
+    if add is not None and (add.dtype != y.dtype or add.shape != y.shape or not add.is_contiguous()):
+        raise TypeError("conv2d_padded_fwd: add must match y (shape, dtype, contiguous)")
+    d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, False, _dt(x), _dt(y), _dt(w2d), relu, compute)
+    oh, ow = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    macs = float(N) * oh * ow * Cout * Cin * KH * KW
+    with _Timed(("conv2d_padded_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y, add)):
+        _L.check(_L.load().hulc_conv2d_padded_fwd(ctypes.byref(d), _i(pad), _p(x), _p(w2d), _p(bias), _p(add), _p(y),
+                                                  ctypes.c_void_p(_stream())), "hulc_conv2d_padded_fwd")
+    return y
+
+
+def r3m_normalize(x, y, mean3, std3):
+    """x fp32 (N,3,H,W) in [0,255] -> y NHWC (N,H,W,8): ((x / 255) - mean) / std in channels 0..2, zeros in 3..7 (r3m's forward)."""
+    _require_cuda(x, y)
+    _require_contiguous(x=x, y=y)
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        raise TypeError("r3m_normalize: x must be fp32 (N, 3, H, W)")
+    n, _, h, w = x.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    _call("hulc_r3m_normalize", x, _i(n), _i(h), _i(w), m, sd, y, _i(_dt(y)))
+    return y
+
+
+def maxpool_nhwc(x, y, N, H, W, C, k, stride, pad):
+    _call("hulc_maxpool_nhwc", x, _i(_dt(x)), _i(N), _i(H), _i(W), _i(C), _i(k), _i(stride), _i(pad), y)
+    return y
+
+
 def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, compute=None):
     """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout]."""
     _require_cuda(dy, wt, dx, relu_src)

@@ -21,7 +21,9 @@ class ConcatEncoders(nn.Module):
                 raise NotImplementedError(f"{name} encoders are outside the accelerated path (cfg_low_level uses "
                                           "rgb_static + rgb_gripper only: conf/model/perceptual_encoder/gripper_cam.yaml)")
         self._latent_size = rgb_static["visual_features"] + (rgb_gripper["visual_features"] if rgb_gripper else 0)
-        self.rgb_static_encoder = instantiate(rgb_static)
+        # concat_encoders.py:34-37: the pretrained trunks are handed the device
+        needs_device = any(t in rgb_static["_target_"] for t in ("clip", "r3m"))
+        self.rgb_static_encoder = instantiate(rgb_static, device=device) if needs_device else instantiate(rgb_static)
         self.depth_static_encoder = None
         self.rgb_gripper_encoder = instantiate(rgb_gripper) if rgb_gripper else None
         self.depth_gripper_encoder = None

@@ -1,0 +1,183 @@
+"""Static-camera encoder with a frozen R3M ResNet trunk on MI355X kernels.
+
+Mirrors hulc2.models.perceptual_encoders.vision_r3m.VisionR3M (reference hulc2/models/perceptual_encoders/vision_r3m.py:8-32): same
+constructor kwargs, same state_dict keys (`r3m.convnet.*` named as torchvision names a ResNet, `fc1.*`, `fc2.*`), frames in [0, 255]
+(conf/datamodule/transforms/real_world_r3m.yaml:2-13), trunk under no_grad, two trainable linear layers behind it.
+
+What the trunk computes comes from `r3m`, an un-vendored submodule with downloaded weights (parity unpinned).  Restated from
+its public definition: obs / 255 -> Normalize(ImageNet mean, std) -> torchvision resnet18 (or 34) with fc = Identity, i.e. a (N, 512)
+feature; `self.r3m(x)` is called with the default obs_shape, so there is no resize / centre crop.  Without network access the constructor
+cannot download the weights: the trunk starts from torchvision's initialisation and takes its values from a checkpoint
+(`load_state_dict`) or from an r3m `model.pt` (`load_r3m_checkpoint`, or the HULC2_R3M_WEIGHTS environment variable).
+
+The trunk is frozen: BatchNorm uses its running statistics, folded into the convolution weights (scale) and bias (shift) once per
+parameter version, so a layer is one `hulc_conv2d_padded_fwd` launch with ReLU and the residual add in its epilogue.  (The reference leaves
+the trunk's mode to Lightning's `.train()` call, which would make BatchNorm normalise with batch statistics during training — a side
+effect of not calling `.eval()`, not something a frozen backbone is meant to do; this module keeps the frozen semantics in both modes.)
+"""
+import os
+from typing import List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from hulc2_amd import functional as HF
+from hulc2_amd import kernels as kn
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_STAGES = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+class BasicBlock(nn.Module):
+    """Parameter holder named like torchvision.models.resnet.BasicBlock (conv1, bn1, conv2, bn2, downsample.{0,1})."""
+
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+
+class ResNetTrunk(nn.Module):
+    """torchvision resnet18 / resnet34 without the classifier (r3m sets convnet.fc = Identity): parameters only."""
+
+    def __init__(self, name: str = "resnet18"):
+        super().__init__()
+        if name not in _STAGES:
+            raise NotImplementedError(f"VisionR3M trunk {name!r}: only the BasicBlock ResNets (resnet18, resnet34) are built "
+                                      "(conf/model/perceptual_encoder/rgb_static/r3m.yaml: resnet18)")
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for li, (n, cout) in enumerate(zip(_STAGES[name], (64, 128, 256, 512)), start=1):
+            blocks = []
+            for b in range(n):
+                blocks.append(BasicBlock(cin, cout, 2 if (b == 0 and li > 1) else 1))
+                cin = cout
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        for m in self.modules():            # torchvision's initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self.out_features = 512
+
+    def blocks(self) -> List[BasicBlock]:
+        return [b for li in range(1, 5) for b in getattr(self, f"layer{li}")]
+
+
+class R3M(nn.Module):
+    """`load_r3m(...).module` as the reference holds it: the only parameters are the trunk's (the language heads are stripped when r3m
+    loads a checkpoint with langweight = 0)."""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.convnet = ResNetTrunk(name)
+        self.outdim = self.convnet.out_features
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, cin_pad: int, wdtype: torch.dtype):
+    """conv + frozen BatchNorm -> (OHWI weight [Cout][KH*KW*Cin'] in wdtype, fp32 bias)."""
+    scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    w = conv.weight.float() * scale[:, None, None, None]                       # (O, I, KH, KW)
+    if cin_pad > w.shape[1]:
+        w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
+    w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(wdtype)
+    return w, (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+
+
+class VisionR3M(nn.Module):
+    def __init__(self, device: Union[str, torch.device, None], visual_features: int, resnet_model: str = "resnet18",
+                 freeze_backbone: bool = True):
+        super().__init__()
+        self.r3m = R3M(resnet_model)
+        for p in self.r3m.parameters():
+            p.requires_grad = False
+        if not freeze_backbone:
+            # vision_r3m.py:19-22 re-enables requires_grad on layer4, but the trunk still runs under no_grad (:25-26), so layer4 never
+            # receives a gradient; the flags are mirrored for optimizers that enumerate parameters.
+            for p in self.r3m.convnet.layer4.parameters():
+                p.requires_grad = True
+        self.fc1 = nn.Linear(self.r3m.outdim, 256)
+        self.fc2 = nn.Linear(256, visual_features)
+        self._folded = None
+        self._folded_key = None
+        path = os.environ.get("HULC2_R3M_WEIGHTS")
+        if path:
+            self.load_r3m_checkpoint(path)
+
+    # ---- weights -------------------------------------------------------------------------------------------------------------
+    def load_r3m_checkpoint(self, path: str) -> None:
+        """An r3m release `model.pt`: {"r3m": state_dict} with DataParallel's `module.` prefix; language heads ignored (r3m's
+        remove_language_head does the same when it loads the file)."""
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("r3m", sd)
+        own = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        own = {k: v for k, v in own.items() if k.startswith("convnet.") and not k.startswith("convnet.fc.")}
+        self.r3m.load_state_dict(own, strict=True)
+
+    def _trunk_tensors(self):
+        return list(self.r3m.convnet.parameters()) + [b for b in self.r3m.convnet.buffers() if b.dtype.is_floating_point]
+
+    def _fold_trunk(self):
+        ts = self._trunk_tensors()
+        wdtype = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
+        key = (wdtype, ts[0].device, tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+        if key != self._folded_key:
+            net = self.r3m.convnet
+            with torch.no_grad():
+                f = {"stem": _fold(net.conv1, net.bn1, 8, wdtype), "blocks": []}
+                for blk in net.blocks():
+                    f["blocks"].append((_fold(blk.conv1, blk.bn1, 0, wdtype), _fold(blk.conv2, blk.bn2, 0, wdtype),
+                                        _fold(blk.downsample[0], blk.downsample[1], 0, wdtype) if blk.downsample is not None else None,
+                                        blk.stride))
+            self._folded, self._folded_key = f, key
+        return self._folded
+
+    # ---- forward -------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def trunk_features(self, x: torch.Tensor) -> torch.Tensor:
+        """x (N, 3, H, W) fp32 in [0, 255] -> (N, 512) fp32: normalise, stem, max pool, the residual stages, global average pool."""
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise TypeError("VisionR3M expects fp32 (N, 3, H, W) frames in [0, 255] (conf/datamodule/transforms/real_world_r3m.yaml)")
+        f = self._fold_trunk()
+        adt = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
+        n, _, h, w = x.shape
+        dev = x.device
+
+        def conv(a, wb, hh, ww, cin, k, stride, pad, relu, add=None):
+            cout = wb[0].shape[0]
+            oh, ow = (hh + 2 * pad - k) // stride + 1, (ww + 2 * pad - k) // stride + 1
+            y = torch.empty((n, oh, ow, cout), dtype=adt, device=dev)
+            kn.conv2d_padded_fwd(a, wb[0], wb[1], y, n, hh, ww, cin, cout, k, k, stride, pad, relu=relu, add=add)
+            return y, oh, ow
+
+        a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), IMAGENET_MEAN, IMAGENET_STD)
+        a, h, w = conv(a, f["stem"], h, w, 8, 7, 2, 3, True)
+        ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        a = kn.maxpool_nhwc(a, torch.empty((n, ph, pw, 64), dtype=adt, device=dev), n, h, w, 64, 3, 2, 1)
+        h, w, c = ph, pw, 64
+        for c1, c2, ds, stride in f["blocks"]:
+            idn = a if ds is None else conv(a, ds, h, w, c, 1, stride, 0, False)[0]
+            o, oh, ow = conv(a, c1, h, w, c, 3, stride, 1, True)
+            c = c1[0].shape[0]
+            a, h, w = conv(o, c2, oh, ow, c, 3, 1, 1, True, add=idn)
+        feat = torch.empty((n, c), dtype=torch.float32, device=dev)
+        kn.strided_seq_sum(a, feat, n, h * w, c, h * w * c, c, c, 1.0 / (h * w))
+        return feat
+
+    def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]], aug_shift=None, aug_pad: int = 0, frame_index=None) -> torch.Tensor:
+        """x: (N, 3, H, W) fp32 in [0, 255], or one such tensor per modality of a step (rows of the result modality-major).  The real-world
+        transforms apply no shift augmentation to this camera, and the uint8 episode-store path belongs to the from-scratch CNN."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        for opt in (aug_shift, frame_index):
+            if opt is not None and any(o is not None for o in (opt if isinstance(opt, (list, tuple)) else [opt])):
+                raise NotImplementedError("VisionR3M takes fp32 frames in [0, 255]; shift augmentation / episode-store indices are not part "
+                                          "of the real-world static-camera transforms (conf/datamodule/transforms/real_world_r3m.yaml:2-13)")
+        feat = [self.trunk_features(t) for t in xs]
+        feat = feat[0] if len(feat) == 1 else torch.cat(feat, dim=0)
+        return HF.mlp(feat, [(self.fc1.weight, self.fc1.bias, True), (self.fc2.weight, self.fc2.bias, False)])

@@ -30,7 +30,16 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
             continue
         g = _gen(seed, name)
         leaf = name.rsplit(".", 1)[-1]
-        if name == "logit_scale":
+        if "r3m.convnet." in name:
+            # frozen ResNet trunk (VisionR3M): convolutions at torchvision's kaiming fan_out scale, BatchNorm with non-trivial affine
+            # parameters and running statistics so the folding is exercised (a variance must stay positive)
+            if t.dim() == 4:
+                t.copy_(torch.randn(t.shape, generator=g) * math.sqrt(2.0 / (t.shape[0] * t.shape[2] * t.shape[3])))
+            elif leaf in ("weight", "running_var"):
+                t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+            else:
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+        elif name == "logit_scale":
             t.fill_(math.log(1 / 0.07))
         elif ".ln." in name or ".norm1." in name or ".norm2." in name or ".layernorm." in name:
             r = torch.randn(t.shape, generator=g) * 0.1

@@ -206,6 +206,21 @@ int hulc_mha_masked_fwd(const float* qkv, const int* mask, int B, int S, int nhe
 /* out[b] = sum_s mask[b][s] x[b][s] / max(sum_s mask[b][s], 1e-9): sentence_transformers' mean Pooling */
 int hulc_masked_mean_fwd(const float* x, const int* mask, int B, int S, int D, float* out, void* stream);
 
+/* ---- frozen ResNet-18 trunk of VisionR3M ---------------------------------------- */
+/* hulc2/models/perceptual_encoders/vision_r3m.py:24-27 runs `self.r3m(x)` under no_grad on frames in [0, 255].  r3m (un-vendored
+ * submodule, parity unpinned — SURVEY §8c) computes obs / 255 -> Normalize(ImageNet) -> torchvision resnet18 with fc = Identity.
+ * hulc_r3m_normalize: x fp32 NCHW [N][3][H][W] -> y NHWC [N][H][W][8] (dtype y_dtype), channel c < 3 = (x / 255 - mean3[c]) / std3[c],
+ * channels 3..7 zero (one 16-byte bf16 chunk per pixel; the stem's weights are zero-padded to match).  mean3 / std3: HOST arrays.
+ * hulc_conv2d_padded_fwd: zero-padded convolution, NHWC x [N][H][W][Cin] (Cin a power of two >= 8), w [Cout][KH*KW*Cin] with the
+ * BatchNorm scale folded in, bias = the folded shift, y = [relu](conv + bias [+ add]) NHWC, add (optional residual) shaped and typed
+ * like y; Cout a multiple of 32; uses d->{N,H,W,Cin,Cout,KH,KW,stride,x_dtype,y_dtype,w_dtype,relu,compute}.
+ * hulc_maxpool_nhwc: nn.MaxPool2d(k, stride, pad) on NHWC (C % 8 == 0), same dtype in and out.
+ * The global average pool is hulc_strided_seq_sum over the H*W axis with scale 1 / (H*W). */
+int hulc_r3m_normalize(const float* x, int N, int H, int W, const float* mean3, const float* std3, void* y, int y_dtype, void* stream);
+int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const void* x, const void* w, const float* bias, const void* add, void* y,
+                           void* stream);
+int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* y, void* stream);
+
 /* ---- transformer feed-forward block, fused (bf16 compute) ----------------------------------------------- */
 /* f = relu(x W1^T + b1) [dropout] W2^T + b2 of nn.TransformerEncoderLayer (plan_recognition_net.py:108-117), d_model 128,
  * dim_feedforward FF (multiple of 128); the (T x FF) hidden activation stays on chip, backward recomputes it.

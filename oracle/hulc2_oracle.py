@@ -9,8 +9,9 @@ Pinning: every function below is checked in tests/test_oracle_golden.py against 
 tests/golden/ that were produced by importing the reference's own leaf modules in the build container
 (oracle/gen_golden.py).  Exceptions — `world_to_tcp_frame` follows pytorch3d (un-vendored, version
 unpinned in the reference's requirements.txt:23): PARITY UNPINNED, checked by properties only.
-SBERT (sentence-transformers, unpinned) and R3M (empty submodule) are outside the oracle: the path's
-language input is the (B,384) embedding.
+SBERT (sentence-transformers, unpinned) and R3M (empty submodule) are restated from their public definitions
+(`minilm_sentence_embedding`, `r3m_trunk_features`): PARITY UNPINNED against the reference's third-party code; MiniLM is
+pinned against transformers' BertModel, the ResNet trunk against torch's own nn layers (tests/test_oracle_golden.py).
 
 Each function cites the reference lines it follows.
 """
@@ -80,7 +81,10 @@ def vision_network_gripper(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 def concat_encoders(sd: SD, p: str, rgb_static: torch.Tensor, rgb_gripper: torch.Tensor) -> torch.Tensor:
     """ConcatEncoders.forward with proprio: none (concat_encoders.py:59-109)."""
     b, s, c, h, w = rgb_static.shape
-    e1 = vision_network_static(sd, p + "rgb_static_encoder.", rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
+    if p + "rgb_static_encoder.r3m.convnet.conv1.weight" in sd:      # rgb_static: r3m (vision_r3m.py:24-32), frames in [0, 255]
+        e1 = vision_r3m(sd, p + "rgb_static_encoder.", rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
+    else:
+        e1 = vision_network_static(sd, p + "rgb_static_encoder.", rgb_static.reshape(-1, c, h, w)).reshape(b, s, -1)
     b, s, c, h, w = rgb_gripper.shape
     e2 = vision_network_gripper(sd, p + "rgb_gripper_encoder.", rgb_gripper.reshape(-1, c, h, w)).reshape(b, s, -1)
     return torch.cat([e1, e2], dim=-1)
@@ -422,6 +426,40 @@ def minilm_sentence_embedding(sd: SD, input_ids: torch.Tensor, attention_mask: t
     return (x * m).sum(1) / m.sum(1).clamp(min=1e-9)
 
 
+def r3m_trunk_features(sd: SD, x: torch.Tensor, p: str = "r3m.convnet.", stages=(2, 2, 2, 2), eps: float = 1e-5) -> torch.Tensor:
+    """What `self.r3m(x)` of hulc2/models/perceptual_encoders/vision_r3m.py:24-27 returns for frames x (N,3,H,W) in [0, 255].
+    PARITY UNPINNED: `r3m` is an empty, un-vendored submodule (.gitmodules:4-6) and torchvision is absent here; this restates r3m's public
+    forward (obs / 255 -> Normalize(ImageNet) -> torchvision resnet18 with fc = Identity, no resize for the default obs_shape) with the
+    BatchNorm layers on their running statistics (frozen trunk).  sd: torchvision's ResNet parameter names under prefix p."""
+    mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+
+    def bn(t, q):
+        return F.batch_norm(t, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, eps)
+
+    t = (x / 255.0 - mean) / std
+    t = F.relu(bn(F.conv2d(t, sd[p + "conv1.weight"], None, 2, 3), p + "bn1"))
+    t = F.max_pool2d(t, 3, 2, 1)
+    for li, n in enumerate(stages, start=1):
+        for b in range(n):
+            q = p + f"layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            idn = t
+            if q + "downsample.0.weight" in sd:
+                idn = bn(F.conv2d(t, sd[q + "downsample.0.weight"], None, stride, 0), q + "downsample.1")
+            o = F.relu(bn(F.conv2d(t, sd[q + "conv1.weight"], None, stride, 1), q + "bn1"))
+            o = bn(F.conv2d(o, sd[q + "conv2.weight"], None, 1, 1), q + "bn2")
+            t = F.relu(o + idn)
+    return t.mean(dim=(2, 3))
+
+
+def vision_r3m(sd: SD, p: str, x: torch.Tensor, stages=(2, 2, 2, 2)) -> torch.Tensor:
+    """hulc2/models/perceptual_encoders/vision_r3m.py:24-32: frozen trunk (no_grad), flatten, relu(fc1), fc2."""
+    with torch.no_grad():
+        f = r3m_trunk_features(sd, x, p + "r3m.convnet.", stages)
+    return F.linear(F.relu(F.linear(f, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+
+
 def language_lookup(indx, min_window_size: int, skip_frames: int = 1):
     """hulc2/datasets/npz_dataset.py:182-192 (= shared_memory_loader.py:133-140 for skip_frames 1): window starts of the language
     dataset and the annotation each belongs to; indx = lang_data["info"]["indx"]"""
@@ -496,6 +534,11 @@ def lmp_train(sd: SD, emb, goal, actions, robot_obs, plan_idx, cfg) -> Dict[str,
     act_loss = decoder_loss(lp, ls, mu, grip, acts)
     kl = kl_loss(pp, pr, cfg.get("kl_beta", 0.01), cfg.get("kl_balancing_mix", 0.8))
     return dict(kl=kl, act=act_loss, total=act_loss + kl, pp=pp, pr=pr, seq_feat=seq_feat, plan=plan)
+
+
+def real_world_cfg() -> dict:
+    """conf/model/real_world_hulc++.yaml:12,20 + conf/model/action_decoder/logistic_decoder_rnn_real_world.yaml:15,19 (BASELINE configs[3])."""
+    return dict(gripper_control=False, emb_slice=(0, 128), use_clip_auxiliary_loss=False)
 
 
 def training_step(sd: SD, batch: Dict[str, Dict], cfg: Optional[dict] = None) -> Dict[str, torch.Tensor]:

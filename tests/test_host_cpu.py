@@ -97,3 +97,32 @@ def test_synthetic_recipe_is_order_independent():
     syn.fill_state_dict_(a, 3)
     syn.fill_state_dict_(b, 3)
     assert torch.equal(a["x.weight"], b["x.weight"]) and torch.equal(a["y.bias"], b["y.bias"])
+
+
+def test_real_world_config_resolves_r3m_encoder():
+    """cfg_low_level_rw (BASELINE configs[3]): `hulc2.models.perceptual_encoders.vision_r3m.VisionR3M` resolves here, its state_dict uses
+    torchvision's ResNet names under `r3m.convnet.` (what a reference checkpoint holds), the trunk is frozen, the decoder consumes the
+    whole perceptual embedding and there is no CLIP head."""
+    from hulc2_amd.config import real_world_model_config
+
+    install_as_hulc2()
+    import hulc2.models.perceptual_encoders.vision_r3m as ref_path
+    import hulc2.affordance.models.language_encoders.sbert_lang_encoder as sbert_path
+
+    m = instantiate(real_world_model_config())
+    enc = m.perceptual_encoder.rgb_static_encoder
+    assert type(enc) is ref_path.VisionR3M and hasattr(sbert_path, "SBertLang")
+    sd = enc.state_dict()
+    assert len(sd) == 124                                                    # torchvision resnet18 minus fc (120) + fc1, fc2
+    for k, shp in {"r3m.convnet.conv1.weight": (64, 3, 7, 7), "r3m.convnet.bn1.running_var": (64,), "r3m.convnet.layer1.0.conv1.weight": (64, 64, 3, 3),
+                   "r3m.convnet.layer2.0.downsample.0.weight": (128, 64, 1, 1), "r3m.convnet.layer2.0.downsample.1.num_batches_tracked": (),
+                   "r3m.convnet.layer4.1.bn2.bias": (512,), "fc1.weight": (256, 512), "fc2.weight": (64, 256)}.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert "r3m.convnet.layer1.0.downsample.0.weight" not in sd and not any(k.startswith("r3m.convnet.fc") for k in sd)
+    assert not any(p.requires_grad for p in enc.r3m.parameters())
+    assert sum(p.numel() for p in enc.r3m.parameters()) == 11_176_512         # torchvision resnet18 without its classifier
+    assert m.action_decoder.perceptual_emb_slice == (0, 128) and not m.action_decoder.gripper_control
+    assert not m.use_clip_auxiliary_loss and not hasattr(m, "proj_vis_lang") or m.proj_vis_lang is None
+    with pytest.raises(NotImplementedError):
+        from hulc2_amd.models.perceptual_encoders.vision_r3m import VisionR3M
+        VisionR3M(None, 64, resnet_model="resnet50")

@@ -411,3 +411,34 @@ def _bert_sd(seed):
     sd = {k: torch.empty(s) for k, s in shapes.items()}
     syn.fill_bert_state_dict_(sd, seed)
     return sd
+
+
+def test_r3m_trunk_oracle_matches_nn_layers():
+    """the functional restatement of r3m's trunk (normalise -> ResNet-18 without classifier -> global mean)
+    against the same network assembled from torch's own nn.Conv2d / nn.BatchNorm2d / nn.MaxPool2d layers in eval mode, and the
+    VisionR3M head (vision_r3m.py:28-32).  torchvision and r3m are absent here (parity unpinned); this pins the restatement's wiring —
+    strides, paddings, where the residual joins, the downsample branches."""
+    import torch.nn as nn
+
+    from hulc2_amd import synthetic as syn
+    from hulc2_amd.models.perceptual_encoders.vision_r3m import VisionR3M
+
+    m = VisionR3M(None, 64)
+    syn.fill_state_dict_(m.state_dict(), 5)
+    m.eval()
+    net = m.r3m.convnet
+    x = torch.rand(2, 3, 75, 100, generator=syn._gen(5, "r3m.x")) * 255
+    with torch.no_grad():
+        t = (x / 255 - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        t = nn.functional.max_pool2d(torch.relu(net.bn1(net.conv1(t))), 3, 2, 1)
+        for blk in net.blocks():
+            idn = t if blk.downsample is None else blk.downsample(t)
+            t = torch.relu(blk.bn2(blk.conv2(torch.relu(blk.bn1(blk.conv1(t))))) + idn)
+        want_f = torch.flatten(nn.functional.adaptive_avg_pool2d(t, 1), 1)
+        want = m.fc2(torch.relu(m.fc1(want_f)))
+        sd = m.state_dict()
+        got_f = O.r3m_trunk_features(sd, x)
+        got = O.vision_r3m(sd, "", x)
+    assert got_f.shape == (2, 512)
+    assert (got_f - want_f).abs().max().item() <= 1e-5 * want_f.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()

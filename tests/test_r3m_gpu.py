@@ -1,0 +1,165 @@
+"""GPU parity of the frozen R3M trunk (VisionR3M) against the CPU oracle.
+
+The reference's trunk arithmetic lives in the un-vendored `r3m` submodule (parity unpinned); the oracle restates its public
+definition (oracle/hulc2_oracle.py::r3m_trunk_features) and is itself pinned against torch's nn layers in tests/test_oracle_golden.py.
+
+Tolerances: fp32 compute 1e-3 of max-abs per tensor (20 chained convolutions; fp32 MFMA sums in a different order than the CPU);
+bf16 compute 5e-2 of max-abs for the 512 trunk features (activations are stored in bf16 between the 20 layers); gradients of the two
+trainable layers in relative L2 (1e-3 fp32, 0.15 bf16 — the bounds of tests/test_parity_gpu.py).
+"""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pytestmark = pytest.mark.gpu
+
+from hulc2_amd import kernels as kn  # noqa: E402
+from hulc2_amd import synthetic as syn  # noqa: E402
+from hulc2_amd.compat import instantiate  # noqa: E402
+from hulc2_amd.config import real_world_model_config  # noqa: E402
+from hulc2_amd.models.perceptual_encoders.vision_r3m import VisionR3M  # noqa: E402
+from oracle import hulc2_oracle as O  # noqa: E402
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def mode(request):
+    kn.set_compute(request.param)
+    yield request.param
+    kn.set_compute("bf16")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("geom", [
+    # N, H, W, Cin, Cout, K, stride, pad, relu, add
+    (3, 37, 50, 8, 64, 7, 2, 3, True, False),       # the stem (3 channels padded to 8)
+    (2, 38, 50, 64, 64, 3, 1, 1, True, True),        # layer1 second conv: residual + ReLU
+    (2, 38, 50, 64, 128, 3, 2, 1, True, False),      # layer2 first conv
+    (2, 38, 50, 64, 128, 1, 2, 0, False, False),     # downsample
+    (5, 5, 7, 512, 512, 3, 1, 1, True, True),        # layer4: 8 output-channel blocks, K = 4608
+    (1, 9, 9, 16, 32, 3, 1, 1, False, False),
+])
+def test_padded_conv_matches_torch(dev, mode, geom):
+    n, h, w, cin, cout, k, s, pad, relu, add = geom
+    g = syn._gen(7, f"padconv{geom}")
+    adt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x = torch.randn(n, cin, h, w, generator=g).to(adt).float()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(adt).float()
+    b = torch.randn(cout, generator=g) * 0.1
+    oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    r = torch.randn(n, cout, oh, ow, generator=g).to(adt).float() if add else None
+    ref = F.conv2d(x, wt, b, s, pad)
+    if add:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = torch.empty(n, oh, ow, cout, dtype=adt, device=dev)
+    kn.conv2d_padded_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev, adt), wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dev, adt),
+                         b.to(dev), y, n, h, w, cin, cout, k, k, s, pad, relu=relu,
+                         add=None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev, adt))
+    assert rel(y.float().permute(0, 3, 1, 2), ref) <= (1e-5 if mode == "fp32" else 1e-2)     # bf16: only the output rounding differs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_is_exact(dev, dtype):
+    g = syn._gen(3, "maxpool")
+    x = torch.randn(3, 64, 75, 100, generator=g).to(dtype)
+    ref = F.max_pool2d(x.float(), 3, 2, 1)
+    y = torch.empty(3, ref.shape[2], ref.shape[3], 64, dtype=dtype, device=dev)
+    kn.maxpool_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), y, 3, 75, 100, 64, 3, 2, 1)
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_normalize(dev):
+    g = syn._gen(5, "norm")
+    x = torch.rand(2, 3, 30, 44, generator=g) * 255
+    y = torch.empty(2, 30, 44, 8, dtype=torch.float32, device=dev)
+    kn.r3m_normalize(x.to(dev), y, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    ref = (x / 255 - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    assert rel(y[..., :3].permute(0, 3, 1, 2), ref) < 1e-6
+    assert (y[..., 3:] == 0).all()
+
+
+@pytest.fixture(scope="module")
+def net(dev):
+    m = VisionR3M(dev, 64).to(dev)
+    syn.fill_state_dict_(m.state_dict(), 11)
+    return m
+
+
+def test_trunk_and_head_match_oracle(dev, net, mode):
+    """150 x 200 frames (the size SURVEY §8d assigns to configs[3]) and a second, odd size: trunk features, encoder output and the
+    gradients of the two trainable layers."""
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for hw in ((150, 200), (97, 131)):
+        x = torch.rand(3, 3, *hw, generator=syn._gen(13, f"frames{hw}")) * 255
+        want_f = O.r3m_trunk_features(sd, x)
+        got_f = net.trunk_features(x.to(dev))
+        assert rel(got_f, want_f) <= (1e-3 if mode == "fp32" else 5e-2), hw
+    for p in net.parameters():
+        p.grad = None
+    out = net(x.to(dev))
+    r = torch.randn(out.shape, generator=syn._gen(13, "r"))
+    (out * r.to(dev)).sum().backward()
+    osd = {k: v.clone().requires_grad_(k.startswith("fc")) for k, v in sd.items()}
+    want = O.vision_r3m(osd, "", x)
+    (want * r).sum().backward()
+    tol = 1e-3 if mode == "fp32" else 5e-2
+    assert rel(out, want) <= tol
+    gtol = 1e-3 if mode == "fp32" else 0.15         # relative L2, the gradient bound of tests/test_parity_gpu.py (a ReLU unit of fc1 may flip in bf16)
+    for name in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+        gp = dict(net.named_parameters())[name].grad
+        assert gp is not None, name
+        want_g = osd[name].grad.double()
+        assert ((gp.double().cpu() - want_g).norm() / want_g.norm()).item() <= gtol, name
+    assert all(p.grad is None for p in net.r3m.parameters())          # the trunk is frozen (vision_r3m.py:14-16, 25-26)
+
+
+def test_folded_weights_follow_the_parameters(dev, net):
+    x = (torch.rand(2, 3, 64, 64, generator=syn._gen(1, "x")) * 255).to(dev)
+    a = net.trunk_features(x)
+    with torch.no_grad():
+        net.r3m.convnet.bn1.running_mean.add_(0.5)
+    b = net.trunk_features(x)
+    with torch.no_grad():
+        net.r3m.convnet.bn1.running_mean.sub_(0.5)
+    c = net.trunk_features(x)
+    assert not torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_real_world_training_step_matches_oracle(dev):
+    """cfg_low_level_rw (BASELINE configs[3]): R3M static camera in [0, 255], whole-embedding decoder input, world-frame actions, no CLIP
+    loss — one training_step against the oracle composed the same way, fp32 compute."""
+    kn.set_compute("fp32")
+    try:
+        cfg = real_world_model_config(dropout_p=0.0)
+        m = instantiate(cfg).to(dev)
+        syn.fill_state_dict_(m.state_dict(), 21)
+        m.train()
+        batch = syn.make_batch(21, 2, 16, static_hw=(150, 200))
+        for mod in batch.values():
+            mod["rgb_obs"]["rgb_static"] = (mod["rgb_obs"]["rgb_static"] + 1) * 127.5          # UpScaleImageTensor range
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        flat = {}
+        for name, db in batch.items():
+            flat[name] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
+                              robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+            if name == "lang":
+                flat[name].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
+        want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
+        got = m.training_step(syn._to(batch, dev), 0)
+        assert abs(got.item() - want.item()) <= 1e-3 * abs(want.item())
+        got.backward()
+        assert all(p.grad is None for p in m.perceptual_encoder.rgb_static_encoder.r3m.parameters())
+        assert m.perceptual_encoder.rgb_static_encoder.fc1.weight.grad is not None
+    finally:
+        kn.set_compute("bf16")
