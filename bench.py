@@ -114,6 +114,9 @@ def main():
                     help="row f-2 end to end: an HBM-resident uint8 episode store per modality, every step draws new play windows "
                          "(index rows, pad-by-repetition, shifts) and conv1 reads the store in place; separate from the headline configuration")
     ap.add_argument("--store-frames", type=int, default=16384, help="frames in the synthetic episode store (141 KB each)")
+    ap.add_argument("--real-world", action="store_true",
+                    help="secondary measurement, BASELINE configs[3] (cfg_low_level_rw): static camera 150x200 in [0,255] through the frozen R3M "
+                         "ResNet-18 trunk, whole-embedding decoder input, world-frame actions, no CLIP loss")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,18 +131,23 @@ def main():
 
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
-    from hulc2_amd.config import default_model_config
+    from hulc2_amd.config import default_model_config, real_world_model_config
     from hulc2_amd.trainer import ArenaTrainer
 
     kn.set_compute(args.compute)
-    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    if args.real_world and (args.uint8_frames or args.episode_store):
+        raise SystemExit("--real-world takes fp32 frames in [0,255] (conf/datamodule/transforms/real_world_r3m.yaml); the uint8 store feeds the CNN config")
+    cfg = real_world_model_config(dropout_p=0.1) if args.real_world else default_model_config(gripper_control=True, dropout_p=0.1)
+    model = instantiate(cfg).to(dev)
     syn.fill_state_dict_(model.state_dict(), 42)            # same weights on every rank
     model.train()
     use_graph = not args.no_graph
     trainer = ArenaTrainer(model, lr=2e-4, overlap=not use_graph)
-    batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev)
+    batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev, **({"static_hw": (150, 200)} if args.real_world else {}))
     for db in batch.values():
         db.pop("plan_idx", None)                            # benchmark samples the latent plan on-device
+        if args.real_world:                                 # UpScaleImageTensor: the R3M trunk takes [0, 255]
+            db["rgb_obs"]["rgb_static"] = (db["rgb_obs"]["rgb_static"] + 1) * 127.5
     if args.uint8_frames:
         g = torch.Generator().manual_seed(1234 + rank)
         for db in batch.values():
@@ -243,13 +251,20 @@ def main():
     seqs = 2 * args.batch * world * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = seqs / elapsed
+    # real-world config: frozen trunk forward only (1 167 MMAC per 150x200 frame, by closed form over the 20 convolutions) + 3x the trained part
+    seq_flop = (2 * 1167.0e6 * 32 + 3 * 2 * (237.37 + 59.24 + 15.01 + 4.78 + 492.2 + 0.15) * 1e6) if args.real_world else SEQ_FLOP_TRAIN
+    workload = ("BASELINE configs[3] (secondary): cfg_low_level_rw — static 150x200 in [0,255] through the frozen R3M ResNet-18 trunk (random "
+                "weights), gripper CNN 84x84, decoder on the whole embedding, world-frame actions, no CLIP loss, lang = random (B,384) embeddings"
+                if args.real_world else
+                "BASELINE configs[1]: synthetic CALVIN-shaped batch, Hulc2.training_step fwd+bwd+allreduce+Adam, "
+                "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on")
     out = {
-        "metric": "play-sequences/sec/node (seq_len=32, 200x200 RGB)",
+        "metric": "play-sequences/sec/node (seq_len=32, real-world cfg: R3M static 150x200)" if args.real_world
+                  else "play-sequences/sec/node (seq_len=32, 200x200 RGB)",
         "value": round(value, 2), "unit": "play-sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic CALVIN-shaped batch, Hulc2.training_step fwd+bwd+allreduce+Adam, "
-                               "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on",
+        "config": {"workload": workload,
                    "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
                    "frames": "HBM-resident uint8 episode store, new play windows (20..32 steps, padded by repetition) every step, conv1 reads "
@@ -261,7 +276,7 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_flops_per_launch": dom_flops,
                      "launches_per_step": dom_n // 3, "avg_launch_ms": round(dom_t / dom_n, 4),
                      "kernel_share_of_step": round(dom_t / max(total_ms, 1e-9), 3),
-                     "step_frac_of_mfma_peak": round(value / world * SEQ_FLOP_TRAIN / peak, 4),
+                     "step_frac_of_mfma_peak": round(value / world * seq_flop / peak, 4),
                      "gpu_kernel_ms_per_step": round(total_ms / 3, 3)},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

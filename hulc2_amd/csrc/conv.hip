@@ -185,12 +185,147 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
     }
 }
 
+// bf16-only variant for taps of >= 32 contiguous elements (every NHWC layer with Cin >= 32): the whole 32-wide k tile lies inside ONE
+// tap, so the tap's offsets are wave-uniform scalar loads, and the gathered 16-byte pieces stay untouched in registers between the global
+// load and the LDS write (zero padding is a select at store time) — the loads of tile kt+1 really are in flight during the MFMAs of
+// tile kt.  The generic kernel above converts every chunk to fp32 as it arrives, which puts the memory wait in front of the MFMAs.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int KT = 32, NCH = 4;
+    constexpr int A_PER = BM * NCH / NT, B_PER = BN * NCH / NT;
+    static_assert((BM * NCH) % NT == 0 && (BN * NCH) % NT == 0 && NT % NCH == 0, "tiles must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * HULC_ROWB];
+    __shared__ long out_off[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long Mtot = (long)p.Nimg * p.OH * p.OW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int nkt = (p.ntaps << p.inner_log2) / KT;
+    const int ch = tid % NCH, row0 = tid / NCH;                 // this thread's 16-byte piece of a tile row, rows row0 + q * NT / NCH
+
+    if (tid < BM) {
+        long m = m0 + tid;
+        if (m < Mtot) {
+            int ox = (int)(m % p.OW); long r = m / p.OW; int oy = (int)(r % p.OH); long n = r / p.OH;
+            out_off[tid] = n * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx;
+        } else out_off[tid] = -1;
+    }
+
+    long pbase[A_PER]; int iy0[A_PER], ix0[A_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) {
+        long m = m0 + row0 + q * (NT / NCH); if (m >= Mtot) m = Mtot - 1;
+        int ox = (int)(m % p.OW); long rr = m / p.OW; int oy = (int)(rr % p.OH); long n = rr / p.OH;
+        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride;
+        pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx + ch * 8;
+    }
+    long wbase[B_PER];
+#pragma unroll
+    for (int q = 0; q < B_PER; ++q) {
+        int n = n0 + row0 + q * (NT / NCH); n = n < p.Cout ? n : p.Cout - 1;
+        wbase[q] = (long)n * p.ldw + ch * 8;
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[A_PER], rb[B_PER];
+    unsigned keep = 0;
+    const int inner_mask = (1 << p.inner_log2) - 1;
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * KT;
+        const int t = k0 >> p.inner_log2, j0 = k0 & inner_mask;     // wave-uniform: scalar loads of the tap's offsets
+        const long toff = p.tap_off[t] + j0, woff = p.w_tap_off[t] + j0;
+        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        keep = 0;
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+            const bool in = !p.check_bounds || (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W);
+            ra[q] = *(const uint4*)((const uint16_t*)p.X + (in ? pbase[q] + toff : 0));
+            keep |= (in ? 1u : 0u) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) rb[q] = *(const uint4*)((const uint16_t*)p.Wt + wbase[q] + woff);
+    };
+    auto store_tiles = [&](int buf) {
+        char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        char* Bs = As + BM * HULC_ROWB;
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q)
+            *(uint4*)(As + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = ((keep >> q) & 1u) ? ra[q] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) *(uint4*)(Bs + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = rb[q];
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const char* As = smem + buf * (BM + BN) * HULC_ROWB;
+        const char* Bs = As + BM * HULC_ROWB;
+        MmaTile<bf16_t, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long off = out_off[(wm * TM + i) * 32 + acc_row(e, lane)];
+                if (off < 0) continue;
+                float v = acc[i][j][e] + bv;
+                if (p.add) v += load_elem(p.add, p.add_dtype, off + n);
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = load_elem(p.mask, p.mask_dtype, off + n) > 0.f ? v * p.mask_scale : 0.f;
+                store_elem(p.Y, p.y_dtype, off + n, v);
+            }
+    }
+}
+
+template <typename CT> bool launch_gather_raw(const GatherP&, hipStream_t) { return false; }
+template <> bool launch_gather_raw<bf16_t>(const GatherP& p, hipStream_t s) {
+    if (p.x_dtype != HULC_BF16 || p.w_dtype != HULC_BF16 || p.inner_log2 < 5 || p.Cout <= 32 || getenv("HULC_GATHER_GENERIC")) return false;
+    const long Mtot = (long)p.Nimg * p.OH * p.OW;
+    if (p.Cout % 128 == 0) {
+        dim3 grid((unsigned)((Mtot + 127) / 128), p.Cout / 128);
+        conv_gather_bf16_kernel<2, 2, 2, 2><<<grid, 256, 0, s>>>(p);
+    } else {
+        dim3 grid((unsigned)((Mtot + 127) / 128), (p.Cout + 63) / 64);
+        conv_gather_bf16_kernel<2, 1, 2, 2><<<grid, 256, 0, s>>>(p);
+    }
+    return true;
+}
+
 template <typename CT>
 void launch_gather(const GatherP& p, hipStream_t s) {
+    if (launch_gather_raw<CT>(p, s)) return;
     const long Mtot = (long)p.Nimg * p.OH * p.OW;
     if (p.Cout <= 32) {
         dim3 grid((unsigned)((Mtot + 127) / 128), 1);
         conv_gather_kernel<CT, 1, 1, 4, 1><<<grid, 256, 0, s>>>(p);
+    } else if (p.Cout % 128 == 0 && sizeof(CT) == 2 && !getenv("HULC_GATHER_N64")) {
+        // the ResNet trunk's wide layers: a 128 x 128 tile halves the LDS bytes per MFMA (each wave owns 64 x 64)
+        dim3 grid((unsigned)((Mtot + 127) / 128), p.Cout / 128);
+        conv_gather_kernel<CT, 2, 2, 2, 2><<<grid, 256, 0, s>>>(p);
     } else {
         dim3 grid((unsigned)((Mtot + 127) / 128), (p.Cout + 63) / 64);
         conv_gather_kernel<CT, 2, 1, 2, 2><<<grid, 256, 0, s>>>(p);
