@@ -27,7 +27,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
-                            const long* cls_wtap, hipStream_t s);
+                            const long* cls_wtap, const void* add, hipStream_t s);
 // LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
                              int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s);
@@ -48,6 +48,7 @@ struct GatherP {
     long y_sn, y_sy, y_sx;
     long ldw;
     int stride, ntaps, inner_log2, check_bounds;
+    int grid_kw, grid_pad;       // > 0: the taps are a dense KH x KW grid, tap t = (t / grid_kw - grid_pad, t % grid_kw - grid_pad), weights k-contiguous
     int relu; float mask_scale;
     int tap_dy[HULC_MAX_TAPS], tap_dx[HULC_MAX_TAPS];
     long tap_off[HULC_MAX_TAPS], w_tap_off[HULC_MAX_TAPS];
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
 // tap, so the tap's offsets are wave-uniform scalar loads, and the gathered 16-byte pieces stay untouched in registers between the global
 // load and the LDS write (zero padding is a select at store time) — the loads of tile kt+1 really are in flight during the MFMAs of
 // tile kt.  The generic kernel above converts every chunk to fp32 as it arrives, which puts the memory wait in front of the MFMAs.
-template <int TM, int TN, int WM, int WN>
+// UNI = false: taps narrower than the k tile (the stem: 8 channels per tap, 4 taps per tile) — the tap of a thread's piece is computed from the
+// dense KH x KW grid (p.grid_kw / p.grid_pad) instead of being looked up, and K may end inside a tile.
+template <int TM, int TN, int WM, int WN, bool UNI>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
     const long Mtot = (long)p.Nimg * p.OH * p.OW;
     const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int nkt = (p.ntaps << p.inner_log2) / KT;
+    const int K = p.ntaps << p.inner_log2;
+    const int nkt = (K + KT - 1) / KT;
     const int ch = tid % NCH, row0 = tid / NCH;                 // this thread's 16-byte piece of a tile row, rows row0 + q * NT / NCH
 
     if (tid < BM) {
@@ -222,36 +226,49 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
         long m = m0 + row0 + q * (NT / NCH); if (m >= Mtot) m = Mtot - 1;
         int ox = (int)(m % p.OW); long rr = m / p.OW; int oy = (int)(rr % p.OH); long n = rr / p.OH;
         iy0[q] = oy * p.stride; ix0[q] = ox * p.stride;
-        pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx + ch * 8;
+        pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx;
     }
     long wbase[B_PER];
 #pragma unroll
     for (int q = 0; q < B_PER; ++q) {
         int n = n0 + row0 + q * (NT / NCH); n = n < p.Cout ? n : p.Cout - 1;
-        wbase[q] = (long)n * p.ldw + ch * 8;
+        wbase[q] = (long)n * p.ldw;
     }
 
-    f32x16_t acc[TM][TN];
+    // MFMA roles swapped (A = weights, B = pixels): D[channel][pixel] leaves a lane with ONE pixel and groups of four consecutive
+    // channels, so the epilogue is 8-byte (bf16) / 16-byte (fp32) accesses with one output offset per lane
+    f32x16_t acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
     uint4 ra[A_PER], rb[B_PER];
     unsigned keep = 0;
+    bool kin = true;                                                 // UNI = false: this thread's piece of the tile is below K
     const int inner_mask = (1 << p.inner_log2) - 1;
     auto load_tiles = [&](int kt) {
-        const int k0 = kt * KT;
-        const int t = k0 >> p.inner_log2, j0 = k0 & inner_mask;     // wave-uniform: scalar loads of the tap's offsets
-        const long toff = p.tap_off[t] + j0, woff = p.w_tap_off[t] + j0;
-        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        long toff, woff; int dy, dx;
+        if (UNI) {
+            const int k0 = kt * KT;
+            const int t = k0 >> p.inner_log2, j0 = (k0 & inner_mask) + ch * 8;   // t is wave-uniform: scalar loads of the tap's offsets
+            toff = p.tap_off[t] + j0; woff = p.w_tap_off[t] + j0;
+            dy = p.tap_dy[t]; dx = p.tap_dx[t];
+        } else {
+            const int kc = kt * KT + ch * 8;
+            kin = kc < K;
+            const int kk = kin ? kc : 0;
+            const int t = kk >> p.inner_log2, kh = t / p.grid_kw;
+            dy = kh - p.grid_pad; dx = t - kh * p.grid_kw - p.grid_pad;
+            toff = (long)dy * p.x_sy + (long)dx * p.x_sx + (kk & inner_mask); woff = kk;
+        }
         keep = 0;
 #pragma unroll
         for (int q = 0; q < A_PER; ++q) {
             const int iy = iy0[q] + dy, ix = ix0[q] + dx;
-            const bool in = !p.check_bounds || (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W);
+            const bool in = kin && (!p.check_bounds || (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W));
             ra[q] = *(const uint4*)((const uint16_t*)p.X + (in ? pbase[q] + toff : 0));
             keep |= (in ? 1u : 0u) << q;
         }
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
         for (int q = 0; q < A_PER; ++q)
             *(uint4*)(As + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = ((keep >> q) & 1u) ? ra[q] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < B_PER; ++q) *(uint4*)(Bs + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = rb[q];
+        for (int q = 0; q < B_PER; ++q) *(uint4*)(Bs + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = kin ? rb[q] : make_uint4(0, 0, 0, 0);
     };
 
     load_tiles(0);
@@ -276,42 +293,61 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
         if (kt + 1 < nkt) load_tiles(kt + 1);
         const char* As = smem + buf * (BM + BN) * HULC_ROWB;
         const char* Bs = As + BM * HULC_ROWB;
-        MmaTile<bf16_t, TM, TN>::run(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        MmaTile<bf16_t, TN, TM>::run(Bs + wn * TN * 32 * HULC_ROWB, As + wm * TM * 32 * HULC_ROWB, acc, lane);
         if (kt + 1 < nkt) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
+    const int hh = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const long off = out_off[(wm * TM + i) * 32 + (lane & 31)];
+        if (off < 0) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + (wn * TN + j) * 32;              // Cout % 32 == 0: a 32-channel block is inside or outside as a whole
+            if (nb >= p.Cout) continue;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long off = out_off[(wm * TM + i) * 32 + acc_row(e, lane)];
-                if (off < 0) continue;
-                float v = acc[i][j][e] + bv;
-                if (p.add) v += load_elem(p.add, p.add_dtype, off + n);
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = load_elem(p.mask, p.mask_dtype, off + n) > 0.f ? v * p.mask_scale : 0.f;
-                store_elem(p.Y, p.y_dtype, off + n, v);
+            for (int g = 0; g < 4; ++g) {
+                const int c = nb + 8 * g + 4 * hh;               // registers 4g..4g+3 = channels c..c+3
+                float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                if (p.bias) { const float4 b = *(const float4*)(p.bias + c); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.add) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += load_elem(p.add, p.add_dtype, off + c + e);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = load_elem(p.mask, p.mask_dtype, off + c + e) > 0.f ? v[e] * p.mask_scale : 0.f;
+                }
+                if (p.y_dtype == HULC_BF16) *(uint2*)((uint16_t*)p.Y + off + c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                else *(float4*)((float*)p.Y + off + c) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        }
     }
 }
 
 template <typename CT> bool launch_gather_raw(const GatherP&, hipStream_t) { return false; }
 template <> bool launch_gather_raw<bf16_t>(const GatherP& p, hipStream_t s) {
-    if (p.x_dtype != HULC_BF16 || p.w_dtype != HULC_BF16 || p.inner_log2 < 5 || p.Cout <= 32 || getenv("HULC_GATHER_GENERIC")) return false;
+    if (p.x_dtype != HULC_BF16 || p.w_dtype != HULC_BF16 || p.Cout <= 32 || getenv("HULC_GATHER_GENERIC")) return false;
     const long Mtot = (long)p.Nimg * p.OH * p.OW;
-    if (p.Cout % 128 == 0) {
-        dim3 grid((unsigned)((Mtot + 127) / 128), p.Cout / 128);
-        conv_gather_bf16_kernel<2, 2, 2, 2><<<grid, 256, 0, s>>>(p);
-    } else {
-        dim3 grid((unsigned)((Mtot + 127) / 128), (p.Cout + 63) / 64);
-        conv_gather_bf16_kernel<2, 1, 2, 2><<<grid, 256, 0, s>>>(p);
-    }
+    const bool wide = p.Cout % 128 == 0;
+    // every wave owns 64 pixels x 64 channels (8 MFMAs per 32-wide k tile): 128 x 128 tiles for wide layers, 256 pixels x 64 channels else
+    const bool tall = !wide && p.Cout % 64 == 0 && Mtot >= 256 * 512 && !getenv("HULC_GATHER_M128");
+    dim3 grid((unsigned)((Mtot + (tall ? 255 : 127)) / (tall ? 256 : 128)), wide ? p.Cout / 128 : (p.Cout + 63) / 64);
+    if (p.inner_log2 >= 5) {
+        if (wide) conv_gather_bf16_kernel<2, 2, 2, 2, true><<<grid, 256, 0, s>>>(p);
+        else if (tall) conv_gather_bf16_kernel<2, 2, 4, 1, true><<<grid, 256, 0, s>>>(p);
+        else conv_gather_bf16_kernel<2, 1, 2, 2, true><<<grid, 256, 0, s>>>(p);
+    } else if (p.grid_kw > 0) {
+        if (wide) conv_gather_bf16_kernel<2, 2, 2, 2, false><<<grid, 256, 0, s>>>(p);
+        else if (tall) conv_gather_bf16_kernel<2, 2, 4, 1, false><<<grid, 256, 0, s>>>(p);
+        else conv_gather_bf16_kernel<2, 1, 2, 2, false><<<grid, 256, 0, s>>>(p);
+    } else return false;
     return true;
 }
 
@@ -536,7 +572,7 @@ void fill_gather(GatherP& g, const hulc_conv_desc* d) {
     g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype;
     g.Nimg = d->N; g.H = d->H; g.W = d->W;
     g.OH = (d->H - d->KH) / d->stride + 1; g.OW = (d->W - d->KW) / d->stride + 1;
-    g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = 0;
+    g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = 0; g.grid_kw = 0; g.grid_pad = 0;
     if (d->x_nchw) {   // k = (c, kh, kw): one tap per (c, kh), inner run = KW along x
         g.x_sn = (long)d->Cin * d->H * d->W; g.x_sy = d->W; g.x_sx = 1;
         g.ntaps = d->Cin * d->KH; g.inner_log2 = log2_exact(d->KW);
@@ -593,7 +629,7 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
         }
         rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                      y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
-                                     cOH, cOW, cyo, cco, cw0, ctap, (hipStream_t)stream);
+                                     cOH, cOW, cyo, cco, cw0, ctap, nullptr, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
     }
@@ -624,6 +660,7 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = add; g.add_dtype = d->y_dtype;
     g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype; g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.Nimg = d->N; g.H = d->H; g.W = d->W; g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = pad > 0;
+    g.grid_kw = d->KW; g.grid_pad = pad;
     g.OH = (d->H + 2 * pad - d->KH) / d->stride + 1; g.OW = (d->W + 2 * pad - d->KW) / d->stride + 1;
     g.x_sn = (long)d->H * d->W * d->Cin; g.x_sy = (long)d->W * d->Cin; g.x_sx = d->Cin;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
@@ -636,6 +673,20 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
             g.w_tap_off[t] = (long)t * d->Cin;
         }
     g.ldw = (long)g.ntaps << g.inner_log2;
+    // 64 -> 64, 3 x 3, stride 1 (ResNet layer1): the LDS-band kernel stages every input row once instead of gathering it nine times
+    if (d->compute == HULC_BF16 && d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->x_dtype == HULC_BF16 &&
+        d->y_dtype == HULC_BF16 && d->w_dtype == HULC_BF16 && !getenv("HULC_NO_BAND_PADDED")) {
+        int cOH[4], cOW[4], cco[4]; long cyo[4], cw0[4], ctap[4 * 16];
+        for (int c = 0; c < 2; ++c) {
+            cOH[c] = g.OH; cOW[c] = g.OW; cyo[c] = 0; cco[c] = 32 * c; cw0[c] = 32 * c;
+            for (int t = 0; t < 16; ++t) ctap[c * 16 + t] = t < 9 ? g.w_tap_off[t] : 0;
+        }
+        const int rc = hulc_conv_band_dispatch(64, 2, 3, 3, 1, x, d->x_dtype, d->N, d->H, d->W, pad, pad, g.x_sn, g.x_sy, g.x_sx, y, d->y_dtype, g.y_sn,
+                                               g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_BF16, d->relu, 2, cOH, cOW, cyo, cco, cw0, ctap,
+                                               add, (hipStream_t)stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return hulc_check_launch("hulc_conv2d_padded_fwd(band)");
+    }
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_padded_fwd");
 }
@@ -668,7 +719,7 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             const int brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
                                                     (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
                                                     (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
-                                                    nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, (hipStream_t)stream);
+                                                    nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, (hipStream_t)stream);
             if (brc < 0) return brc;
             if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_data(band)");
         }
@@ -680,7 +731,7 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             g.Nimg = d->N; g.H = OH; g.W = OW;                       // the gathered tensor is dY
             g.OH = (d->H - py + s - 1) / s; g.OW = (d->W - px + s - 1) / s;   // this class' sub-grid of dX
             if (g.OH <= 0 || g.OW <= 0) continue;
-            g.Cout = d->Cin; g.stride = 1; g.check_bounds = 1;
+            g.Cout = d->Cin; g.stride = 1; g.check_bounds = 1; g.grid_kw = 0; g.grid_pad = 0;
             g.x_sn = (long)OH * OW * d->Cout; g.x_sy = (long)OW * d->Cout; g.x_sx = d->Cout;
             g.inner_log2 = log2_exact(d->Cout);
             int t = 0;

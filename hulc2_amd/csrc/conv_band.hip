@@ -30,6 +30,7 @@ struct BandCls {
 };
 struct BandP {
     const void* X; void* Y; const void* Wt; const float* bias; const void* mask;
+    const void* add;                // optional residual (bf16, laid out like Y), summed before the ReLU: the ResNet trunk's block outputs
     int x_dtype, y_dtype, w_dtype, mask_dtype;
     int Nimg, H, W;                 // input tensor dims (NHWC, C = template)
     int OHmax, OWmax;               // largest class grid: defines the staged band
@@ -184,6 +185,11 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = bias4[g];
                     float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    if (p.add) {
+                        const uint2 a = *(const uint2*)((const uint16_t*)p.add + off0 + 8 * g + 4 * h);
+                        v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
+                        v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+                    }
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -292,11 +298,12 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
-                            const long* cls_wtap /* [ncls][16] */, hipStream_t s) {
+                            const long* cls_wtap /* [ncls][16] */, const void* add, hipStream_t s) {
     if (getenv("HULC_NO_BAND")) return 1;
     if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
     BandP p;
-    p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask;
+    p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask; p.add = add;
+    if (add && y_dtype != HULC_BF16) return 1;
     if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
