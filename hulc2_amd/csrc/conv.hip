@@ -48,6 +48,7 @@ struct GatherP {
     long y_sn, y_sy, y_sx;
     long ldw;
     int stride, ntaps, inner_log2, check_bounds;
+    int stride_x;                // output-x step in input positions (= stride except for the packed ResNet stem)
     int grid_kw, grid_pad;       // > 0: the taps are a dense KH x KW grid, tap t = (t / grid_kw - grid_pad, t % grid_kw - grid_pad), weights k-contiguous
     int relu; float mask_scale;
     int tap_dy[HULC_MAX_TAPS], tap_dx[HULC_MAX_TAPS];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
         int r = (tid + q * NT) / NCH;
         long m = m0 + r; if (m >= Mtot) m = Mtot - 1;
         int ox = (int)(m % p.OW); long rr = m / p.OW; int oy = (int)(rr % p.OH); long n = rr / p.OH;
-        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride;
+        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride_x;
         pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx;
     }
 
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
     for (int q = 0; q < A_PER; ++q) {
         long m = m0 + row0 + q * (NT / NCH); if (m >= Mtot) m = Mtot - 1;
         int ox = (int)(m % p.OW); long rr = m / p.OW; int oy = (int)(rr % p.OH); long n = rr / p.OH;
-        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride;
+        iy0[q] = oy * p.stride; ix0[q] = ox * p.stride_x;
         pbase[q] = n * p.x_sn + (long)iy0[q] * p.x_sy + (long)ix0[q] * p.x_sx;
     }
     long wbase[B_PER];
@@ -572,7 +573,7 @@ void fill_gather(GatherP& g, const hulc_conv_desc* d) {
     g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype;
     g.Nimg = d->N; g.H = d->H; g.W = d->W;
     g.OH = (d->H - d->KH) / d->stride + 1; g.OW = (d->W - d->KW) / d->stride + 1;
-    g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = 0; g.grid_kw = 0; g.grid_pad = 0;
+    g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = 0; g.grid_kw = 0; g.grid_pad = 0; g.stride_x = d->stride;
     if (d->x_nchw) {   // k = (c, kh, kw): one tap per (c, kh), inner run = KW along x
         g.x_sn = (long)d->Cin * d->H * d->W; g.x_sy = d->W; g.x_sx = 1;
         g.ntaps = d->Cin * d->KH; g.inner_log2 = log2_exact(d->KW);
@@ -660,7 +661,7 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = add; g.add_dtype = d->y_dtype;
     g.x_dtype = d->x_dtype; g.w_dtype = d->w_dtype; g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.Nimg = d->N; g.H = d->H; g.W = d->W; g.Cout = d->Cout; g.stride = d->stride; g.check_bounds = pad > 0;
-    g.grid_kw = d->KW; g.grid_pad = pad;
+    g.grid_kw = d->KW; g.grid_pad = pad; g.stride_x = d->stride;
     g.OH = (d->H + 2 * pad - d->KH) / d->stride + 1; g.OW = (d->W + 2 * pad - d->KW) / d->stride + 1;
     g.x_sn = (long)d->H * d->W * d->Cin; g.x_sy = (long)d->W * d->Cin; g.x_sx = d->Cin;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
@@ -689,6 +690,35 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
     }
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     return hulc_check_launch("hulc_conv2d_padded_fwd");
+}
+
+// The ResNet stem (7 x 7, stride 2, padding 3, 3 input channels) on the packed input hulc_r3m_normalize_packed writes: pixels of 4 bf16
+// channels (RGB + 0) inside a zero border, so TWO neighbouring pixels are one aligned 16-byte piece.  Seen as "double pixels" the stem is
+// a 7 x 4 convolution with stride (2, 1) and no bounds checks: K = 7 * 4 * 8 = 224 (seven 32-wide k tiles exactly) instead of the
+// 7 * 7 * 8 = 392 of the channel-padded NHWC8 form, and a pixel costs 8 gathered bytes instead of 16.
+extern "C" int hulc_r3m_packed_width(int W) { return 2 * ((W + 6 - 7) / 2) + 8; }
+
+extern "C" int hulc_r3m_stem_fwd(const void* xp, const void* w, const float* bias, void* y, int y_dtype, int N, int H, int W, int Cout, int relu,
+                                 void* stream) {
+    if (!xp || !w || !y) return hulc_fail(-1, "hulc_r3m_stem_fwd: null pointer");
+    if (N <= 0 || H < 1 || W < 1 || Cout % 64) return hulc_fail(-2, "hulc_r3m_stem_fwd: bad geometry (Cout must be a multiple of 64)");
+    const int Wp = hulc_r3m_packed_width(W), Hp = H + 6;
+    GatherP g;
+    g.X = xp; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = nullptr; g.add_dtype = HULC_F32;
+    g.x_dtype = HULC_BF16; g.w_dtype = HULC_BF16; g.y_dtype = y_dtype; g.relu = relu;
+    g.Nimg = N; g.H = Hp; g.W = Wp / 2; g.Cout = Cout; g.stride = 2; g.stride_x = 1; g.check_bounds = 0;
+    g.OH = (H + 6 - 7) / 2 + 1; g.OW = (W + 6 - 7) / 2 + 1;
+    g.x_sn = (long)Hp * Wp * 4; g.x_sy = (long)Wp * 4; g.x_sx = 8;
+    g.y_sn = (long)g.OH * g.OW * Cout; g.y_sy = (long)g.OW * Cout; g.y_sx = Cout;
+    g.ntaps = 28; g.inner_log2 = 3; g.grid_kw = 4; g.grid_pad = 0;
+    for (int t = 0; t < 28; ++t) {
+        g.tap_dy[t] = t / 4; g.tap_dx[t] = t % 4;
+        g.tap_off[t] = (long)(t / 4) * g.x_sy + (long)(t % 4) * g.x_sx;
+        g.w_tap_off[t] = (long)t * 8;
+    }
+    g.ldw = 224;
+    if (!launch_gather_raw<bf16_t>(g, (hipStream_t)stream)) launch_gather<bf16_t>(g, (hipStream_t)stream);
+    return hulc_check_launch("hulc_r3m_stem_fwd");
 }
 
 // dX (NHWC [N][H][W][Cin]) from dY (NHWC [N][OH][OW][Cout]); wt = weights permuted to [Cin][KH][KW][Cout].
@@ -731,7 +761,7 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
             g.Nimg = d->N; g.H = OH; g.W = OW;                       // the gathered tensor is dY
             g.OH = (d->H - py + s - 1) / s; g.OW = (d->W - px + s - 1) / s;   // this class' sub-grid of dX
             if (g.OH <= 0 || g.OW <= 0) continue;
-            g.Cout = d->Cin; g.stride = 1; g.check_bounds = 1; g.grid_kw = 0; g.grid_pad = 0;
+            g.Cout = d->Cin; g.stride = 1; g.check_bounds = 1; g.grid_kw = 0; g.grid_pad = 0; g.stride_x = 1;
             g.x_sn = (long)OH * OW * d->Cout; g.x_sy = (long)OW * d->Cout; g.x_sx = d->Cout;
             g.inner_log2 = log2_exact(d->Cout);
             int t = 0;

@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void r3m_normalize_kernel(const float* __restr
     }
 }
 
+// the same normalisation into the packed stem input: xp bf16 [N][H+6][Wp][4], pixel (y, x) at [y+3][x+3] = (R, G, B, 0), zero border
+__global__ __launch_bounds__(256) void r3m_normalize_packed_kernel(const float* __restrict__ x, int H, int W, int Wp, long total, float m0, float m1,
+                                                                   float m2, float s0, float s1, float s2, uint2* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // padded pixel index over N*(H+6)*Wp
+    if (i >= total) return;
+    const int xp = (int)(i % Wp); const long r = i / Wp;
+    const int yp = (int)(r % (H + 6)); const long n = r / (H + 6);
+    const int yy = yp - 3, xx = xp - 3;
+    uint2 o = make_uint2(0u, 0u);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const long HW = (long)H * W;
+        const float* px = x + n * 3 * HW + (long)yy * W + xx;
+        o = make_uint2(pack_bf16x2((px[0] / 255.f - m0) * s0, (px[HW] / 255.f - m1) * s1), pack_bf16x2((px[2 * HW] / 255.f - m2) * s2, 0.f));
+    }
+    y[i] = o;
+}
+
 // max pool k x k, stride s, padding p (padded positions never win: nn.MaxPool2d pads with -inf), NHWC, 8 channels per thread
 __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const void* __restrict__ x, int dtype, int H, int W, int C8, int OH, int OW, int k, int s,
                                                            int pad, long total, void* __restrict__ y) {
@@ -69,6 +86,16 @@ extern "C" int hulc_r3m_normalize(const float* x, int N, int H, int W, const flo
     r3m_normalize_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], 1.f / std3[0],
                                                                                           1.f / std3[1], 1.f / std3[2], y, y_dtype);
     return hulc_check_launch("hulc_r3m_normalize");
+}
+
+extern "C" int hulc_r3m_normalize_packed(const float* x, int N, int H, int W, const float* mean3, const float* std3, void* xp, void* stream) {
+    if (!x || !mean3 || !std3 || !xp) return hulc_fail(-1, "hulc_r3m_normalize_packed: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return hulc_fail(-2, "hulc_r3m_normalize_packed: bad shape");
+    const int Wp = hulc_r3m_packed_width(W);
+    const long total = (long)N * (H + 6) * Wp;
+    r3m_normalize_packed_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, H, W, Wp, total, mean3[0], mean3[1], mean3[2],
+                                                                                                  1.f / std3[0], 1.f / std3[1], 1.f / std3[2], (uint2*)xp);
+    return hulc_check_launch("hulc_r3m_normalize_packed");
 }
 
 extern "C" int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* y, void* stream) {

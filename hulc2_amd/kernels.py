@@ -259,6 +259,33 @@ def r3m_normalize(x, y, mean3, std3):
     return y
 
 
+def r3m_packed_width(W: int) -> int:
+    return int(_L.load().hulc_r3m_packed_width(int(W)))
+
+
+def r3m_normalize_packed(x, xp, mean3, std3):
+    """x fp32 (N,3,H,W) in [0,255] -> xp bf16 (N, H+6, r3m_packed_width(W), 4): normalised RGB + 0 inside a zero border (the stem's input)."""
+    _require_cuda(x, xp)
+    _require_contiguous(x=x, xp=xp)
+    n, _, h, w = x.shape
+    if x.dtype != torch.float32 or xp.dtype != torch.bfloat16 or tuple(xp.shape) != (n, h + 6, r3m_packed_width(w), 4):
+        raise TypeError("r3m_normalize_packed: x fp32 (N,3,H,W), xp bf16 (N, H+6, packed width, 4)")
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    _call("hulc_r3m_normalize_packed", x, _i(n), _i(h), _i(w), m, sd, xp)
+    return xp
+
+
+def r3m_stem_fwd(xp, w, bias, y, N, H, W, Cout, relu=True):
+    """the 7x7 stride-2 stem on the packed input: w bf16 (Cout, 7*8*4) = [o][kh][kw][c] with zeros at kw = 7 and c = 3; y NHWC."""
+    _require_contiguous(xp=xp, w=w, y=y)
+    oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    macs = float(N) * oh * ow * Cout * 147
+    _call("hulc_r3m_stem_fwd", xp, w, bias, y, _i(_dt(y)), _i(N), _i(H), _i(W), _i(Cout), _i(int(relu)),
+          key=("r3m_stem_fwd", N, H, W, Cout), flops=2 * macs, nbytes=_nbytes(xp, w, y))
+    return y
+
+
 def maxpool_nhwc(x, y, N, H, W, C, k, stride, pad):
     _call("hulc_maxpool_nhwc", x, _i(_dt(x)), _i(N), _i(H), _i(W), _i(C), _i(k), _i(stride), _i(pad), y)
     return y

@@ -131,6 +131,12 @@ class VisionR3M(nn.Module):
             net = self.r3m.convnet
             with torch.no_grad():
                 f = {"stem": _fold(net.conv1, net.bn1, 8, wdtype), "blocks": []}
+                if wdtype == torch.bfloat16:
+                    # packed stem (hulc_r3m_stem_fwd): [o][kh][kw -> 8][c -> 4], zeros at kw = 7 and c = 3
+                    w8, b = _fold(net.conv1, net.bn1, 4, torch.float32)
+                    w8 = w8.view(64, 7, 7, 4)
+                    w8 = torch.cat([w8, w8.new_zeros(64, 7, 1, 4)], dim=2).reshape(64, 224).contiguous().to(torch.bfloat16)
+                    f["stem_packed"] = (w8, b)
                 for blk in net.blocks():
                     f["blocks"].append((_fold(blk.conv1, blk.bn1, 0, wdtype), _fold(blk.conv2, blk.bn2, 0, wdtype),
                                         _fold(blk.downsample[0], blk.downsample[1], 0, wdtype) if blk.downsample is not None else None,
@@ -156,8 +162,15 @@ class VisionR3M(nn.Module):
             kn.conv2d_padded_fwd(a, wb[0], wb[1], y, n, hh, ww, cin, cout, k, k, stride, pad, relu=relu, add=add)
             return y, oh, ow
 
-        a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), IMAGENET_MEAN, IMAGENET_STD)
-        a, h, w = conv(a, f["stem"], h, w, 8, 7, 2, 3, True)
+        if "stem_packed" in f:
+            xp = kn.r3m_normalize_packed(x.contiguous(), torch.empty((n, h + 6, kn.r3m_packed_width(w), 4), dtype=adt, device=dev),
+                                         IMAGENET_MEAN, IMAGENET_STD)
+            oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            a = kn.r3m_stem_fwd(xp, f["stem_packed"][0], f["stem_packed"][1], torch.empty((n, oh, ow, 64), dtype=adt, device=dev), n, h, w, 64)
+            h, w = oh, ow
+        else:
+            a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), IMAGENET_MEAN, IMAGENET_STD)
+            a, h, w = conv(a, f["stem"], h, w, 8, 7, 2, 3, True)
         ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         a = kn.maxpool_nhwc(a, torch.empty((n, ph, pw, 64), dtype=adt, device=dev), n, h, w, 64, 3, 2, 1)
         h, w, c = ph, pw, 64

@@ -220,6 +220,13 @@ int hulc_r3m_normalize(const float* x, int N, int H, int W, const float* mean3, 
 int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const void* x, const void* w, const float* bias, const void* add, void* y,
                            void* stream);
 int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* y, void* stream);
+/* The stem (7x7, stride 2, padding 3, 3 -> Cout) on a packed input, bf16: hulc_r3m_normalize_packed writes xp [N][H+6][Wp][4] with
+ * Wp = hulc_r3m_packed_width(W), pixel (y, x) at [y+3][x+3] = normalised (R, G, B, 0), zero border; hulc_r3m_stem_fwd computes
+ * y NHWC [N][OH][OW][Cout] = [relu](conv + bias) from it with w [Cout][7][8][4] bf16 = the (BatchNorm-folded) stem weight as [o][kh][kw][c],
+ * zero at kw = 7 and c = 3: two neighbouring pixels are one aligned 16-byte piece, K = 224 instead of 392, no bounds checks. */
+int hulc_r3m_packed_width(int W);
+int hulc_r3m_normalize_packed(const float* x, int N, int H, int W, const float* mean3, const float* std3, void* xp, void* stream);
+int hulc_r3m_stem_fwd(const void* xp, const void* w, const float* bias, void* y, int y_dtype, int N, int H, int W, int Cout, int relu, void* stream);
 
 /* ---- transformer feed-forward block, fused (bf16 compute) ----------------------------------------------- */
 /* f = relu(x W1^T + b1) [dropout] W2^T + b2 of nn.TransformerEncoderLayer (plan_recognition_net.py:108-117), d_model 128,
