@@ -193,15 +193,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(GatherP p) {
 // tile kt.  The generic kernel above converts every chunk to fp32 as it arrives, which puts the memory wait in front of the MFMAs.
 // UNI = false: taps narrower than the k tile (the stem: 8 channels per tap, 4 taps per tile) — the tap of a thread's piece is computed from the
 // dense KH x KW grid (p.grid_kw / p.grid_pad) instead of being looked up, and K may end inside a tile.
-template <int TM, int TN, int WM, int WN, bool UNI>
+// KT: k-tile width.  Measured on the ResNet trunk's 128..512-channel layers (450-590 TFLOP/s with KT = 32, 64 x 64 per wave): KT = 64
+// is 7 % slower (73 KB of LDS per block), 128 x 64 per wave 35 % slower — 32 / <2,2,2,2> stays.
+template <int TA, int TB, int ROWB, int KS>
+HULC_DEVICE void mma_rows_bf16(const char* a_rows, const char* b_rows, f32x16_t (&acc)[TA][TB], int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_t a[TA], b[TB];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) a[i] = *(const bf16x8_t*)(a_rows + (i * 32 + r) * ROWB + (ks * 2 + h) * 16);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) b[j] = *(const bf16x8_t*)(b_rows + (j * 32 + r) * ROWB + (ks * 2 + h) * 16);
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int TM, int TN, int WM, int WN, bool UNI, int KT = 32>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int KT = 32, NCH = 4;
+    constexpr int NCH = KT / 8, ROWB = KT * 2 + 16;
     constexpr int A_PER = BM * NCH / NT, B_PER = BN * NCH / NT;
     static_assert((BM * NCH) % NT == 0 && (BN * NCH) % NT == 0 && NT % NCH == 0, "tiles must divide evenly");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * HULC_ROWB];
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];
     __shared__ long out_off[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,13 +296,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
         for (int q = 0; q < B_PER; ++q) rb[q] = *(const uint4*)((const uint16_t*)p.Wt + wbase[q] + woff);
     };
     auto store_tiles = [&](int buf) {
-        char* As = smem + buf * (BM + BN) * HULC_ROWB;
-        char* Bs = As + BM * HULC_ROWB;
+        char* As = smem + buf * (BM + BN) * ROWB;
+        char* Bs = As + BM * ROWB;
 #pragma unroll
         for (int q = 0; q < A_PER; ++q)
-            *(uint4*)(As + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = ((keep >> q) & 1u) ? ra[q] : make_uint4(0, 0, 0, 0);
+            *(uint4*)(As + (row0 + q * (NT / NCH)) * ROWB + ch * 16) = ((keep >> q) & 1u) ? ra[q] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < B_PER; ++q) *(uint4*)(Bs + (row0 + q * (NT / NCH)) * HULC_ROWB + ch * 16) = kin ? rb[q] : make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < B_PER; ++q) *(uint4*)(Bs + (row0 + q * (NT / NCH)) * ROWB + ch * 16) = kin ? rb[q] : make_uint4(0, 0, 0, 0);
     };
 
     load_tiles(0);
@@ -292,9 +311,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_bf16_kernel(GatherP p
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) load_tiles(kt + 1);
-        const char* As = smem + buf * (BM + BN) * HULC_ROWB;
-        const char* Bs = As + BM * HULC_ROWB;
-        MmaTile<bf16_t, TN, TM>::run(Bs + wn * TN * 32 * HULC_ROWB, As + wm * TM * 32 * HULC_ROWB, acc, lane);
+        const char* As = smem + buf * (BM + BN) * ROWB;
+        const char* Bs = As + BM * ROWB;
+        mma_rows_bf16<TN, TM, ROWB, KT / 16>(Bs + wn * TN * 32 * ROWB, As + wm * TM * 32 * ROWB, acc, lane);
         if (kt + 1 < nkt) store_tiles(buf ^ 1);
         __syncthreads();
     }
