@@ -163,3 +163,56 @@ def test_real_world_training_step_matches_oracle(dev):
         assert m.perceptual_encoder.rgb_static_encoder.fc1.weight.grad is not None
     finally:
         kn.set_compute("bf16")
+
+
+def test_shipped_real_world_config_with_sentence_encoder(dev):
+    """cfg_low_level_rw exactly as shipped: `language_encoder: sbert` (sentences in the batch, encoded inside the step, no gradient) on top of
+    the R3M static camera.  The WordPiece vocabulary is not available offline, so the tokenizer is a deterministic stand-in (word hash ->
+    id); everything behind it — MiniLM, language goal encoder, the rest of the step — is checked against the oracle, fp32 compute."""
+    import zlib
+
+    from tests.test_oracle_golden import _bert_sd
+
+    def tokenizer(sentences):
+        rows = [[101] + [1000 + zlib.crc32(w.encode()) % 20000 for w in s.split()] + [102] for s in sentences]
+        n = max(len(r) for r in rows)
+        ids = torch.tensor([r + [0] * (n - len(r)) for r in rows])
+        mask = torch.tensor([[1] * len(r) + [0] * (n - len(r)) for r in rows])
+        return {"input_ids": ids, "attention_mask": mask}
+
+    kn.set_compute("fp32")
+    try:
+        cfg = real_world_model_config(dropout_p=0.0)
+        cfg["language_encoder"] = type(cfg)({"_target_": "hulc2.affordance.models.language_encoders.sbert_lang_encoder.SBertLang",
+                                             "nlp_model": "paraphrase-MiniLM-L3-v2", "freeze_backbone": True})
+        from hulc2_amd.compat import install_as_hulc2
+        install_as_hulc2()
+        m = instantiate(cfg).to(dev)
+        syn.fill_state_dict_(m.state_dict(), 23)
+        bert = _bert_sd(23)
+        m.lang_encoder.load_bert_state_dict(bert)
+        m.lang_encoder.tokenizer = tokenizer
+        assert m.language_goal.lang_net is m.lang_encoder
+        m.train()
+        batch = syn.make_batch(23, 2, 16, static_hw=(150, 200))
+        for mod in batch.values():
+            mod["rgb_obs"]["rgb_static"] = (mod["rgb_obs"]["rgb_static"] + 1) * 127.5
+        sentences = ["push the red block to the left", "open the drawer"]
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        tok = tokenizer(sentences)
+        flat = {}
+        for name, db in batch.items():
+            flat[name] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
+                              robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+        flat["lang"].update(lang=O.minilm_sentence_embedding(bert, tok["input_ids"], tok["attention_mask"]),
+                            use_for_aux_lang_loss=batch["lang"]["use_for_aux_lang_loss"])
+        want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
+        gb = syn._to(batch, dev)
+        gb["lang"]["lang"] = sentences
+        got = m.training_step(gb, 0)
+        assert abs(got.item() - want.item()) <= 1e-3 * abs(want.item())
+        got.backward()
+        assert all(p.grad is None for p in m.lang_encoder.parameters())           # sbert_lang_encoder.py:41-54: no_grad + detach
+        assert m.language_goal.mlp[1].weight.grad is not None
+    finally:
+        kn.set_compute("bf16")
