@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restric
         int o, c, t;                                      // destination index i -> (o, c, tap)
         if (mode == 0) { o = i / (Cin * taps); c = (i / taps) % Cin; t = i % taps; }
         else if (mode == 1) { o = i / (taps * Cin); t = (i / Cin) % taps; c = i % Cin; }
-        else { c = i / (taps * Cout); t = (i / Cout) % taps; o = i % Cout; }
+        else if (mode == 2) { c = i / (taps * Cout); t = (i / Cout) % taps; o = i % Cout; }
+        else { t = i / (Cin * Cout); c = (i / Cout) % Cin; o = i % Cout; }     // mode 3: [tap][c][o], the transposed flatten-linear operand
         dst[d0 + i] = f32_to_bf16_bits(src[so + ((long)o * Cin + c) * taps + t]);
     }
 }

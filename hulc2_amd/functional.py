@@ -95,6 +95,62 @@ class MLPFn(torch.autograd.Function):
         return (dx, None, None, None, *grads)
 
 
+class FlattenLinearFn(torch.autograd.Function):
+    """relu(Linear(nn.Flatten(x_nchw))) computed on the NHWC activation a (N, H, W, C) as it lies in memory: the reference flattens
+    (C, H, W) (vision_network_gripper.py:16-17), so the weight's columns are reordered to (h, w, c) once per optimizer step
+    (weight_operand(W, "hwc")) instead of permuting 2048 x 3136 activations forward and their gradients backward.  The incoming ReLU of
+    `a` (conv3's) is applied to the returned gradient in the data-gradient GEMM's epilogue: da is already masked by (a > 0)."""
+
+    @staticmethod
+    def forward(ctx, a, W, b):
+        N = a.shape[0]
+        K = a[0].numel()
+        O = W.shape[0]
+        x2 = _c(a).reshape(N, K)
+        out = _f32(N, O, like=x2)
+        kn.gemm(x2, weight_operand(W, "hwc", chw=(a.shape[3], a.shape[1], a.shape[2])), out, N, O, K, K, K, O, bias=b, relu=True)
+        ctx.save_for_backward(x2, out, W, b)
+        ctx.ashape = a.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, out, W, b = ctx.saved_tensors
+        N, K = x2.shape
+        O = W.shape[0]
+        C = ctx.ashape[3]
+        g = _f32(N, O, like=out)
+        kn.relu_bwd(_c(dy), out, g, g.numel())
+        sw, sb = gradsink.get(W), gradsink.get(b)
+        dWh = _f32(O, K, like=g)                                   # (h, w, c) column order
+        db = sb if sb is not None else _f32(O, like=g)
+        acc_b = sb is not None and not gradsink.first_write(b)
+        fused = kn.gemm_fuses_rowsum(O, False)
+        kn.gemm(g, x2, dWh, O, K, N, O, K, K, a_kmajor=False, b_kmajor=False, rowsum=db if fused else None, rowsum_accumulate=acc_b)
+        if not fused:
+            kn.colsum(g, N, O, O, db, accumulate=acc_b)
+        src = dWh.view(O, K // C, C).transpose(1, 2)                # -> the parameter's (c, h*w) order
+        if sw is not None:
+            dst = sw.view(O, C, K // C)
+            if gradsink.first_write(W):
+                dst.copy_(src)
+            else:
+                dst.add_(src)
+            dW = None
+        else:
+            dW = src.reshape(O, K)
+        da = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(N, K, dtype=torch.float32, device=g.device)
+            kn.gemm(g, weight_operand(W, "hwc_t", chw=(C, ctx.ashape[1], ctx.ashape[2])), da, N, K, O, O, O, K, mask=x2, ld_mask=K, mask_scale=1.0)   # x (a > 0): conv3's ReLU
+            da = da.view(ctx.ashape)
+        return da, dW, (None if sb is not None else db)
+
+
+def flatten_linear_relu(a_nhwc, W, b):
+    return FlattenLinearFn.apply(a_nhwc, W, b)
+
+
 def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Optional[Sequence[float]] = None, seed: int = 0):
     """layers: [(weight, bias, relu), ...]; dropout (inverted, after the ReLU) per layer optional."""
     relus = tuple(bool(r) for _, _, r in layers)

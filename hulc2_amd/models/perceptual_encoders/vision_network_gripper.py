@@ -30,18 +30,20 @@ class VisionNetwork(nn.Module):
         self.fc2 = nn.Linear(512, visual_features)
         self.ln = nn.LayerNorm(visual_features)
 
+    def flatten_linears(self):
+        """(weight, (C, H, W)) of Linear layers behind nn.Flatten: the trainer keeps their (h, w, c)-ordered bf16 shadows fresh"""
+        return [(self.conv_model[7].weight, (64, 7, 7))]
+
     def conv_params(self):
         c = self.conv_model
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)
 
     def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0, frame_index=None) -> torch.Tensor:
-        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=False, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
-        # Flatten order of the reference (C, H, W); one copy that also widens to fp32, so the 3136 -> 128 weight-gradient GEMM
-        # reads a row-major fp32 operand (16-byte micro-tile staging) instead of 2-byte strided bf16 loads
-        flat = a3.permute(0, 3, 1, 2).to(torch.float32, memory_format=torch.contiguous_format).reshape(a3.shape[0], -1)
+        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
+        # nn.Flatten + Linear(3136, 128) + ReLU on the NHWC activation in place: the weight's columns are reordered, not the activations
         c = self.conv_model
-        y = HF.mlp(flat, [(c[7].weight, c[7].bias, True), (self.fc1[0].weight, self.fc1[0].bias, True),
-                          (self.fc2.weight, self.fc2.bias, False)])
+        y = HF.flatten_linear_relu(a3, c[7].weight, c[7].bias)
+        y = HF.mlp(y, [(self.fc1[0].weight, self.fc1[0].bias, True), (self.fc2.weight, self.fc2.bias, False)])
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)
 
     @staticmethod

@@ -54,7 +54,7 @@ def register_layout_view(param: torch.Tensor, layout: str, view_bf16: torch.Tens
     _arena_layout[key] = (weakref.ref(param, lambda _r, k=key: _arena_layout.pop(k, None)), view_bf16)
 
 
-def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
+def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
     if layout is None:
         return w
     if layout == "oihw_flat":          # conv1: k = (c, kh, kw) — the parameter itself, flattened
@@ -65,11 +65,15 @@ def _layout(w: torch.Tensor, layout: Optional[str]) -> torch.Tensor:
         return w.permute(1, 2, 3, 0)
     if layout == "t":                  # transposed 2-D weight: lets dX = dY W stream W k-major
         return w.t()
+    if layout in ("hwc", "hwc_t"):     # Linear behind nn.Flatten of a (C, H, W) map: columns reordered to the NHWC activation's (h, w, c)
+        c, h, w_ = chw
+        m = w.view(w.shape[0], c, h, w_).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        return m if layout == "hwc" else m.t()
     raise ValueError(layout)
 
 
 @torch.no_grad()
-def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tensor:
+def weight_operand(w: torch.Tensor, layout: Optional[str] = None, chw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
     """Tensor handed to the kernels for parameter `w`: fp32 (repacked if asked) in fp32 compute mode, a
     cached bf16 copy in bf16 mode."""
     bf16 = kn.get_compute() == "bf16"
@@ -90,7 +94,7 @@ def weight_operand(w: torch.Tensor, layout: Optional[str] = None) -> torch.Tenso
     hit = _cache.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
         return hit[1]
-    src = _layout(base, layout).contiguous()
+    src = _layout(base, layout, chw).contiguous()
     if bf16:
         out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
         kn.cast_f32_to_bf16(src, out, src.numel())

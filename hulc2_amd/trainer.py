@@ -198,11 +198,17 @@ class ArenaTrainer:
         self.conv_shadow = self.conv_table = None
         if self.flat_bf16 is not None:
             rows, views, dst = [], [], 0
+            flat_lin = {id(w): chw for m in model.modules() if hasattr(m, "flatten_linears") for w, chw in m.flatten_linears()}
             for p, off in zip(self.params, self.offsets):
-                if p.dim() != 4:
+                chw = flat_lin.get(id(p))
+                if p.dim() == 2 and chw is not None:          # Linear behind nn.Flatten of a (C, H, W) map (gripper encoder): NHWC column order
+                    co, (ci, kh, kw) = p.shape[0], chw
+                    modes = [("hwc", 1, (co, kh * kw * ci)), ("hwc_t", 3, (kh * kw * ci, co))]
+                elif p.dim() != 4:
                     continue
-                co, ci, kh, kw = p.shape
-                modes = [("oihw_flat", 0, (co, ci * kh * kw))] if ci < 8 else [("ohwi", 1, (co, kh * kw * ci)), ("ihwo", 2, (ci, kh, kw, co))]
+                else:
+                    co, ci, kh, kw = p.shape
+                    modes = [("oihw_flat", 0, (co, ci * kh * kw))] if ci < 8 else [("ohwi", 1, (co, kh * kw * ci)), ("ihwo", 2, (ci, kh, kw, co))]
                 for name, mode, shape in modes:
                     rows.append((off, dst, co, ci, kh, kw, mode))
                     views.append((p, name, dst, shape))
