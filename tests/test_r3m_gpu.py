@@ -216,3 +216,40 @@ def test_shipped_real_world_config_with_sentence_encoder(dev):
         assert m.language_goal.mlp[1].weight.grad is not None
     finally:
         kn.set_compute("bf16")
+
+
+def test_real_world_validation_and_rollout(dev):
+    """cfg_low_level_rw through validation_step (hulc2.py:594-598) and the batch-1 control loop reset / step (hulc2.py:600-628): the R3M
+    trunk under torch.no_grad(), frames in [0, 255], world-frame actions (no tcp transform), no CLIP head."""
+    m = instantiate(real_world_model_config(dropout_p=0.1)).to(dev)
+    syn.fill_state_dict_(m.state_dict(), 31)
+    m.eval()
+    B, S = 2, 8
+    batch = syn.make_batch(5, B, S, device=dev, static_hw=(150, 200))
+    for db in batch.values():
+        db.pop("plan_idx", None)
+        db["rgb_obs"]["rgb_static"] = (db["rgb_obs"]["rgb_static"] + 1) * 127.5
+    out = m.validation_step(batch, 0)
+    for mod in ("vis", "lang"):
+        assert out[f"sampled_plan_pp_{mod}"].shape == (B, 1024)
+        assert torch.equal(out[f"sampled_plan_pr_{mod}"].reshape(B, 32, 32).sum(-1), torch.ones(B, 32, device=dev))
+    for k in ("val_act/vis_act_loss_pp", "val_act/lang_act_loss_pr", "val_kl/lang_kl_loss", "val_total_mae/vis_total_mae_pr"):
+        assert torch.isfinite(torch.as_tensor(m.logged[k])).all(), k
+    m.replan_freq = 2
+    m.reset()
+    vis = batch["vis"]
+    goal = {"lang": batch["lang"]["lang"][:1]}
+    plans = []
+    for s in range(4):
+        obs = {"rgb_obs": {k: v[:1, s:s + 1] for k, v in vis["rgb_obs"].items()}, "depth_obs": {},
+               "robot_obs": vis["robot_obs"][:1, s:s + 1], "robot_obs_raw": vis["state_info"]["robot_obs"][:1, s:s + 1]}
+        a = m.step(obs, goal)
+        assert a.shape == (1, 1, 7) and torch.isfinite(a).all()
+        plans.append(m.plan.clone())
+    assert torch.equal(plans[0], plans[1]) and torch.equal(plans[2], plans[3])
+    # the encoder's batch-1 output equals its batched output on the same frame (no batch statistics anywhere in the frozen trunk)
+    enc = m.perceptual_encoder.rgb_static_encoder
+    x = vis["rgb_obs"]["rgb_static"].reshape(-1, 3, 150, 200)
+    with torch.no_grad():
+        full, one = enc(x), enc(x[3:4])
+    assert (full[3:4] - one).abs().max().item() <= 2e-2 * full.abs().max().item()
