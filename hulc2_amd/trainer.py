@@ -365,18 +365,20 @@ class ArenaTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
+        # world > 1: the process group's watchdog thread may touch the runtime while this thread captures; only this thread's calls are policed
+        mode = {"capture_error_mode": "thread_local"} if self.world > 1 else {}
         if self.world > 1 and self.enc_hi > self.enc_lo:
             # two graphs around the split point; replay() launches the big all-reduce between them on the comm stream
-            with torch.cuda.graph(self.graph_fb, stream=side):
+            with torch.cuda.graph(self.graph_fb, stream=side, **mode):
                 self.static_loss = self._forward_backward_head(batch, 0)
             self.graph_enc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_enc, pool=self.graph_fb.pool(), stream=side):
+            with torch.cuda.graph(self.graph_enc, pool=self.graph_fb.pool(), stream=side, **mode):
                 self._backward_encoder()
         else:
-            with torch.cuda.graph(self.graph_fb, stream=side):
+            with torch.cuda.graph(self.graph_fb, stream=side, **mode):
                 self.static_loss = self._forward_backward(batch, 0)
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), stream=side):
+        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), stream=side, **mode):
             self.optimizer_step()
         torch.cuda.synchronize()
 
