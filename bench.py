@@ -200,6 +200,10 @@ def main():
         except Exception as e:                              # noqa: BLE001 - report and fall back to eager launches
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
+        if world > 1:                                       # graph and eager modes issue different collectives: all ranks take the same one
+            ok = torch.tensor([1 if use_graph else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            use_graph = bool(ok.item())
     run_step = (lambda i: trainer.replay()) if use_graph else (lambda i: trainer.step(batch, i))
     if draw is not None:
         inner = run_step
