@@ -124,10 +124,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HULC_BENCH_BACKEND=gloo: functional check of the multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices;
+    # run it with HULC_NO_RNN_WAVEFRONT=1 — the device-wide-barrier kernel needs the GPU to itself).  The measured configuration is nccl (= RCCL).
+    backend = os.environ.get("HULC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
