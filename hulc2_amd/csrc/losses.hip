@@ -42,66 +42,68 @@ struct MixP {
 };
 
 // per (token, action dim): NLL and, when G != nullptr, gradients w.r.t. the 3*NM head outputs
+// per (token, action dim): NLL and, when GRAD, gradients w.r.t. the 3*NM head outputs — one LANE per mixture component: an item is a
+// group of 16 lanes (NM <= 16), the two log-sum-exps are butterfly reductions inside the group.  An item-per-thread form is one long dependent chain of ~40 transcendentals per thread and
+// only (T * 7) / 64 = 224 waves for the benchmark's 2048 tokens: 23 us forward, 30 us backward; spread over 16x the lanes it is latency-hidden.
+HULC_DEVICE float grp16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+HULC_DEVICE float grp16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 template <bool GRAD>
-HULC_DEVICE float mix_nll(const MixP& p, int t, int d, float gscale, float* dy_row) {
-    constexpr int MAXM = 16;
+HULC_DEVICE float mix_nll_lanes(const MixP& p, int t, int d, int i, float gscale, float* dy_row) {
     const float* row = p.y + (long)t * p.ld;
     const int NM = p.NM;
+    const bool on = i < NM;
+    const int ii = on ? i : 0;
     const float a = p.act[(long)t * (p.A + 1) + d];
     const float lo = p.amin[d], hi = p.amax[d];
     const float half = (hi - lo) * 0.5f / (float)(p.num_classes - 1);
     const float logc = logf((float)(p.num_classes - 1) * 0.5f);
-    float lp[MAXM], dmu[MAXM], dls[MAXM];
-    float lmax = -INFINITY;
-    for (int i = 0; i < NM; ++i) lmax = fmaxf(lmax, row[d * NM + i]);
-    float lsum = 0.f;
-    for (int i = 0; i < NM; ++i) lsum += expf(row[d * NM + i] - lmax);
-    const float llse = lmax + logf(lsum);
-    float m = -INFINITY;
-    for (int i = 0; i < NM; ++i) {
-        const float mu = row[p.A * NM + d * NM + i];
-        const float raw = row[2 * p.A * NM + d * NM + i];
-        const float ls = fmaxf(raw, p.log_scale_min);
-        const float inv = expf(-ls), c = a - mu;
-        const float plus = inv * (c + half), minn = inv * (c - half), mid = inv * c;
-        float v, gmu, gls;      // gmu = d logprob / d mu, gls = d logprob / d log_scale
-        if (a < lo + 1e-3f) {
-            v = plus - softplus_t(plus);
-            const float k = 1.f - sigmoid_f(plus);
-            gmu = -inv * k; gls = -plus * k;
-        } else if (a > hi - 1e-3f) {
-            v = -softplus_t(minn);
-            const float k = -sigmoid_f(minn);
-            gmu = -inv * k; gls = -minn * k;
+    const float logit = row[d * NM + ii];
+    const float lmax = grp16_max(on ? logit : -INFINITY);
+    const float llse = lmax + logf(grp16_sum(on ? expf(logit - lmax) : 0.f));
+    const float mu = row[p.A * NM + d * NM + ii];
+    const float raw = row[2 * p.A * NM + d * NM + ii];
+    const float ls = fmaxf(raw, p.log_scale_min);
+    const float inv = expf(-ls), c = a - mu;
+    const float plus = inv * (c + half), minn = inv * (c - half), mid = inv * c;
+    float v, gmu, gls;
+    if (a < lo + 1e-3f) {
+        v = plus - softplus_t(plus);
+        const float k = 1.f - sigmoid_f(plus);
+        gmu = -inv * k; gls = -plus * k;
+    } else if (a > hi - 1e-3f) {
+        v = -softplus_t(minn);
+        const float k = -sigmoid_f(minn);
+        gmu = -inv * k; gls = -minn * k;
+    } else {
+        const float sp = sigmoid_f(plus), sm = sigmoid_f(minn), delta = sp - sm;
+        if (delta > 1e-5f) {
+            v = logf(fmaxf(delta, 1e-12f));
+            const float dp = sp * (1.f - sp), dm = sm * (1.f - sm);
+            gmu = (-inv * dp + inv * dm) / delta;
+            gls = (-plus * dp + minn * dm) / delta;
         } else {
-            const float sp = sigmoid_f(plus), sm = sigmoid_f(minn), delta = sp - sm;
-            if (delta > 1e-5f) {
-                v = logf(fmaxf(delta, 1e-12f));
-                const float dp = sp * (1.f - sp), dm = sm * (1.f - sm);
-                gmu = (-inv * dp + inv * dm) / delta;
-                gls = (-plus * dp + minn * dm) / delta;
-            } else {
-                v = mid - ls - 2.f * softplus_t(mid) - logc;
-                const float k = 1.f - 2.f * sigmoid_f(mid);
-                gmu = -inv * k; gls = -mid * k - 1.f;
-            }
+            v = mid - ls - 2.f * softplus_t(mid) - logc;
+            const float k = 1.f - 2.f * sigmoid_f(mid);
+            gmu = -inv * k; gls = -mid * k - 1.f;
         }
-        if (raw < p.log_scale_min) gls = 0.f;                 // clamp(min) passes gradient only for raw >= min
-        lp[i] = v + (row[d * NM + i] - llse);
-        dmu[i] = gmu; dls[i] = gls;
-        m = fmaxf(m, lp[i]);
     }
-    float s = 0.f;
-    for (int i = 0; i < NM; ++i) s += expf(lp[i] - m);
-    const float lse = m + logf(s);
-    if (GRAD) {
-        for (int i = 0; i < NM; ++i) {
-            const float w = expf(lp[i] - lse);                           // responsibility
-            const float pi = expf(row[d * NM + i] - llse);
-            dy_row[d * NM + i] = -gscale * (w - pi);
-            dy_row[p.A * NM + d * NM + i] = -gscale * w * dmu[i];
-            dy_row[2 * p.A * NM + d * NM + i] = -gscale * w * dls[i];
-        }
+    if (raw < p.log_scale_min) gls = 0.f;
+    const float lp = v + (logit - llse);
+    const float m = grp16_max(on ? lp : -INFINITY);
+    const float lse = m + logf(grp16_sum(on ? expf(lp - m) : 0.f));
+    if (GRAD && on) {
+        const float w = expf(lp - lse), pi = expf(logit - llse);
+        dy_row[d * NM + i] = -gscale * (w - pi);
+        dy_row[p.A * NM + d * NM + i] = -gscale * w * gmu;
+        dy_row[2 * p.A * NM + d * NM + i] = -gscale * w * gls;
     }
     return -lse;
 }
@@ -113,12 +115,14 @@ HULC_DEVICE float mix_nll(const MixP& p, int t, int d, float gscale, float* dy_r
 __global__ __launch_bounds__(256) void mix_loss_partial_kernel(MixP p, int seg_tokens, int blocks_per_seg, float* __restrict__ partial) {
     __shared__ float sh[16];
     const int seg = blockIdx.x / blocks_per_seg, bl = blockIdx.x % blocks_per_seg;
-    const int w = bl * 256 + threadIdx.x;                  // item inside the segment
+    const int w = bl * 16 + (threadIdx.x >> 4), i = threadIdx.x & 15;     // item inside the segment (16 per workgroup), mixture lane
     float nll = 0.f, ce = 0.f;
     if (w < seg_tokens * (p.A + 1)) {
         const int t = seg * seg_tokens + w / (p.A + 1), d = w % (p.A + 1);
-        if (d < p.A) nll = mix_nll<false>(p, t, d, 0.f, nullptr);
-        else {
+        if (d < p.A) {
+            const float v = mix_nll_lanes<false>(p, t, d, i, 0.f, nullptr);
+            nll = i == 0 ? v : 0.f;
+        } else if (i == 0) {
             const float* g = p.y + (long)t * p.ld + 3 * p.A * p.NM;
             const float a = p.act[(long)t * (p.A + 1) + p.A];
             const int lbl = (a == -1.f) ? 0 : (int)a;
@@ -134,22 +138,23 @@ __global__ __launch_bounds__(256) void mix_loss_partial_kernel(MixP p, int seg_t
 __global__ __launch_bounds__(64) void mix_loss_final_kernel(const float* __restrict__ partial, int blocks_per_seg, int seg_tokens,
                                                             float gripper_alpha, float* __restrict__ out) {
     const int seg = blockIdx.x;
+    float nll = 0.f, ce = 0.f;                              // lane-strided partial sums, then one butterfly: a fixed order
+    for (int b = threadIdx.x; b < blocks_per_seg; b += 64) { nll += partial[2 * (seg * blocks_per_seg + b)]; ce += partial[2 * (seg * blocks_per_seg + b) + 1]; }
+    nll = wave_sum(nll); ce = wave_sum(ce);
     if (threadIdx.x != 0) return;
-    float nll = 0.f, ce = 0.f;
-    for (int b = 0; b < blocks_per_seg; ++b) { nll += partial[2 * (seg * blocks_per_seg + b)]; ce += partial[2 * (seg * blocks_per_seg + b) + 1]; }
     nll /= seg_tokens; ce /= seg_tokens;
     out[3 * seg] = nll + gripper_alpha * ce; out[3 * seg + 1] = nll; out[3 * seg + 2] = ce;
 }
 
 // gout[seg] scales segment seg's tokens
 __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(MixP p, int seg_tokens, const float* __restrict__ gout, float* __restrict__ dy, long ld_dy) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= p.T * (p.A + 1)) return;
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 4), i = threadIdx.x & 15;
+    if (w >= p.T * (p.A + 1)) return;                      // whole 16-lane groups leave together
     const int t = w / (p.A + 1), d = w % (p.A + 1);
     const float g = gout[t / seg_tokens] / seg_tokens;
     float* drow = dy + (long)t * ld_dy;
-    if (d < p.A) mix_nll<true>(p, t, d, g, drow);
-    else {
+    if (d < p.A) mix_nll_lanes<true>(p, t, d, i, g, drow);
+    else if (i == 0) {
         const float* gl = p.y + (long)t * p.ld + 3 * p.A * p.NM;
         const float a = p.act[(long)t * (p.A + 1) + p.A];
         const int lbl = (a == -1.f) ? 0 : (int)a;
@@ -456,12 +461,12 @@ static int mix_check(const hulc_mix_desc* d, const char* who) {
 extern "C" long hulc_mix_loss_workspace(const hulc_mix_desc* d) {
     if (!d || d->nseg < 1) return -1;
     const int items = (d->T / d->nseg) * (d->A + 1);
-    return (long)d->nseg * ((items + 255) / 256) * 2 * (long)sizeof(float);
+    return (long)d->nseg * ((items + 15) / 16) * 2 * (long)sizeof(float);     // 16 items (of 16 mixture lanes) per workgroup
 }
 extern "C" int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out, void* ws, void* stream) {
     if (!d || !y || !act || !out || !ws || !d->act_min || !d->act_max) return hulc_fail(-1, "hulc_mix_loss_fwd: null pointer");
     int rc = mix_check(d, "fwd"); if (rc) return rc;
-    const int seg_tokens = d->T / d->nseg, bps = (seg_tokens * (d->A + 1) + 255) / 256;
+    const int seg_tokens = d->T / d->nseg, bps = (seg_tokens * (d->A + 1) + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     mix_loss_partial_kernel<<<d->nseg * bps, 256, 0, s>>>(make_mix(d, y, act), seg_tokens, bps, (float*)ws);
     mix_loss_final_kernel<<<d->nseg, 64, 0, s>>>((const float*)ws, bps, seg_tokens, d->gripper_alpha, out);
@@ -472,7 +477,7 @@ extern "C" int hulc_mix_loss_bwd(const hulc_mix_desc* d, const float* y, const f
     if (!d || !y || !act || !gout || !dy) return hulc_fail(-1, "hulc_mix_loss_bwd: null pointer");
     int rc = mix_check(d, "bwd"); if (rc) return rc;
     const int n = d->T * (d->A + 1);
-    mix_loss_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(make_mix(d, y, act), d->T / d->nseg, gout, dy, ld_dy);
+    mix_loss_bwd_kernel<<<(n + 15) / 16, 256, 0, (hipStream_t)stream>>>(make_mix(d, y, act), d->T / d->nseg, gout, dy, ld_dy);
     return hulc_check_launch("hulc_mix_loss_bwd");
 }
 
