@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, graph, out):
+def _worker(rank, world, port, graph, out, real_world=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HULC_NO_RNN_WAVEFRONT="1")
     torch.cuda.set_device(0)
@@ -34,17 +34,19 @@ def _worker(rank, world, port, graph, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
-    from hulc2_amd.config import default_model_config
+    from hulc2_amd.config import default_model_config, real_world_model_config
     from hulc2_amd.trainer import ArenaTrainer
 
     kn.set_compute("bf16")
-    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    model = instantiate(real_world_model_config(dropout_p=0.1) if real_world else default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
     syn.fill_state_dict_(model.state_dict(), 42)
     model.train()
     tr = ArenaTrainer(model, lr=2e-4, overlap=not graph)
-    batch = syn.make_batch(100 + rank, 2, 8, device=dev)          # different data per rank
+    batch = syn.make_batch(100 + rank, 2, 8, device=dev, **({"static_hw": (150, 200)} if real_world else {}))          # different data per rank
     for db in batch.values():
         db.pop("plan_idx", None)
+        if real_world:                                                      # frozen R3M trunk: frames in [0, 255], its parameters are not in the arena
+            db["rgb_obs"]["rgb_static"] = (db["rgb_obs"]["rgb_static"] + 1) * 127.5
     losses = []
     if graph:
         tr.capture(batch)
@@ -64,14 +66,14 @@ def _worker(rank, world, port, graph, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_two_ranks_stay_identical(graph):
+@pytest.mark.parametrize("graph,real_world", [(False, False), (True, False), (True, True)])
+def test_two_ranks_stay_identical(graph, real_world):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, graph, q, real_world)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
