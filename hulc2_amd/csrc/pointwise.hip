@@ -10,6 +10,7 @@
 //   self-attention    : nn.MultiheadAttention inside the encoder layer (S <= 32, head_dim 16)
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -110,6 +111,77 @@ __global__ __launch_bounds__(256) void spatial_softmax_fwd64_kernel(const void* 
             const float mn = fmaxf(a[j].m, v);
             const float sc = __expf(a[j].m - mn), e = __expf(v - mn);
             a[j].s = a[j].s * sc + e; a[j].sx = a[j].sx * sc + e * xm; a[j].sy = a[j].sy * sc + e * ym; a[j].m = mn;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+            ssm_merge(a[j], __shfl_xor(a[j].m, o, 64), __shfl_xor(a[j].s, o, 64), __shfl_xor(a[j].sx, o, 64), __shfl_xor(a[j].sy, o, 64));
+        if (pl == 0) { red[wave][0][cg * 8 + j] = a[j].m; red[wave][1][cg * 8 + j] = a[j].s; red[wave][2][cg * 8 + j] = a[j].sx; red[wave][3][cg * 8 + j] = a[j].sy; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        SsmAcc t; t.m = red[0][0][lane]; t.s = red[0][1][lane]; t.sx = red[0][2][lane]; t.sy = red[0][3][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) ssm_merge(t, red[w][0][lane], red[w][1][lane], red[w][2][lane], red[w][3][lane]);
+        const float inv = 1.0f / t.s;
+        out[(long)n * 128 + 2 * lane] = t.sx * inv;
+        out[(long)n * 128 + 2 * lane + 1] = t.sy * inv;
+        stats[((long)n * 64 + lane) * 2] = t.m;
+        stats[((long)n * 64 + lane) * 2 + 1] = t.s;
+    }
+}
+// HW <= 448 (the 21 x 21 map of the static camera): a lane's 14 positions fit in registers, so the maximum is taken first and every element
+// costs ONE exponential instead of the two of the online form above (which is VALU-bound: 2.6 TB/s).  Same partials, same merge tree.
+template <bool BF16>
+__global__ __launch_bounds__(256) void spatial_softmax_fwd64_regs_kernel(const void* __restrict__ x, int HW, const float* __restrict__ xmap,
+                                                                         const float* __restrict__ ymap, const float* __restrict__ temperature,
+                                                                         float* __restrict__ out, float* __restrict__ stats) {
+    constexpr int IT = 14;
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 7, pl = lane >> 3;
+    const int n = blockIdx.x;
+    const float invT = 1.0f / temperature[0];
+    const long base = (long)n * HW * 64 + cg * 8;
+    float v[IT][8];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int p = wave * 8 + pl + 32 * k;
+        const bool on = p < HW;
+        const long off = base + (long)(on ? p : 0) * 64;
+        float c[8];
+        if (BF16) {
+            const uint4 r = *(const uint4*)((const uint16_t*)x + off);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[2 * j] = __uint_as_float(w[j] << 16); c[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        } else {
+            const float4* q = (const float4*)((const float*)x + off);
+            const float4 a0 = q[0], a1 = q[1];
+            c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[k][j] = on ? c[j] * invT : -INFINITY;
+    }
+    SsmAcc a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float m = v[0][j];                                   // position k = 0 exists for every lane (HW >= 32)
+#pragma unroll
+        for (int k = 1; k < IT; ++k) m = fmaxf(m, v[k][j]);
+        a[j].m = m; a[j].s = 0.f; a[j].sx = 0.f; a[j].sy = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int p = wave * 8 + pl + 32 * k;
+        const int pc = p < HW ? p : 0;
+        const float xm = xmap[pc], ym = ymap[pc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = __expf(v[k][j] - a[j].m);        // exp(-inf) = 0 for the positions past HW
+            a[j].s += e; a[j].sx += e * xm; a[j].sy += e * ym;
         }
     }
 #pragma unroll
@@ -571,7 +643,10 @@ extern "C" int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int H
     if (!x || !xmap || !ymap || !temperature || !out || !stats) return hulc_fail(-1, "hulc_spatial_softmax_fwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_fwd: C must be in 1..64 (lane = channel)");
     const int esz = x_dtype == HULC_F32 ? 4 : 2;
-    if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0)
+    if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0 && HW >= 32 && HW <= 448 && !getenv("HULC_SSM_ONLINE")) {
+        if (x_dtype == HULC_BF16) spatial_softmax_fwd64_regs_kernel<true><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
+        else spatial_softmax_fwd64_regs_kernel<false><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
+    } else if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0)
         spatial_softmax_fwd64_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, HW, xmap, ymap, temperature, out, stats);
     else
         spatial_softmax_fwd_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, N, HW, C, xmap, ymap, temperature, out, stats);
