@@ -322,8 +322,18 @@ __global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restr
     const int per = (P + 15) / 16;
     const int q0 = sl * per, q1 = q0 + per < P ? q0 + per : P;
     float s = 0.f;
-    if (rr < R)
-        for (int q = q0; q < q1; ++q) s += partial[(long)q * R + rr];
+    if (rr < R) {
+        // four independent loads per trip: with one load per trip every partial waited for its own memory round trip (12 us per launch)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int q = q0;
+        for (; q + 3 < q1; q += 4) {
+            const float a = partial[(long)q * R + rr], b = partial[(long)(q + 1) * R + rr], c = partial[(long)(q + 2) * R + rr],
+                        d = partial[(long)(q + 3) * R + rr];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; q < q1; ++q) s0 += partial[(long)q * R + rr];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[sl][lane] = s;
     __syncthreads();
     if (sl == 0 && rr < R) {
