@@ -257,24 +257,33 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(FfnP p, int ntiles) {
 }
 
 // dW1 [FF][128], dW2 [128][FF], db1 [FF] (+)= sum over the G token groups, fixed order
+// sum of G slabs at one offset, four independent loads per trip
+HULC_DEVICE float slab_sum(const float* __restrict__ base, long stride, int G) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        const float a = base[(long)g * stride], b = base[(long)(g + 1) * stride], c = base[(long)(g + 2) * stride], d = base[(long)(g + 3) * stride];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; g < G; ++g) s0 += base[(long)g * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void ffn_wgrad_reduce_kernel(FfnP p, int G, float* dW1, float* dW2, float* db1, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n1 = (long)p.FF * D, nslab = (long)(p.FF / HS) * HS * D;
     if (i < n1) {                                                            // dW1[(s*128 + j)][c]: slab index s*16384 + j*128 + c = i
-        float v = 0.f;
-        for (int g = 0; g < G; ++g) v += p.dw1_slab[(long)g * nslab + i];
+        const float v = slab_sum(p.dw1_slab + i, nslab, G);
         dW1[i] = accumulate ? dW1[i] + v : v;
     } else if (i < 2 * n1) {                                                 // dW2[n][s*128 + j]
         const long o = i - n1;
         const int n = (int)(o / p.FF), jj = (int)(o % p.FF), s = jj / HS, j = jj % HS;
         const long src = (long)s * HS * D + (long)n * HS + j;
-        float v = 0.f;
-        for (int g = 0; g < G; ++g) v += p.dw2_slab[(long)g * nslab + src];
+        const float v = slab_sum(p.dw2_slab + src, nslab, G);
         dW2[o] = accumulate ? dW2[o] + v : v;
     } else if (i < 2 * n1 + p.FF) {
         const long o = i - 2 * n1;
-        float v = 0.f;
-        for (int g = 0; g < G; ++g) v += p.db1_slab[(long)g * p.FF + o];
+        const float v = slab_sum(p.db1_slab + o, p.FF, G);
         db1[o] = accumulate ? db1[o] + v : v;
     }
 }

@@ -421,8 +421,16 @@ __global__ void seq_mean_fwd_kernel(const float* __restrict__ x, float* __restri
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * D) return;
     const int b = (int)(i / D), d = (int)(i % D);
-    float s = 0.f;
-    for (int t = 0; t < S; ++t) s += x[((long)b * S + t) * D + d];
+    // four independent loads per trip (a single accumulator chain waits for every load's round trip in turn)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* xb = x + (long)b * S * D + d;
+    int t = 0;
+    for (; t + 3 < S; t += 4) {
+        const float a = xb[(long)t * D], c = xb[(long)(t + 1) * D], e = xb[(long)(t + 2) * D], f = xb[(long)(t + 3) * D];
+        s0 += a; s1 += c; s2 += e; s3 += f;
+    }
+    for (; t < S; ++t) s0 += xb[(long)t * D];
+    const float s = (s0 + s1) + (s2 + s3);
     y[i] = scale * (s / S);
 }
 // y[b][d] = scale * sum_s x[b*stride_b + s*stride_s + d]  (any layout: time-major recurrent buffers, strided halves)
@@ -431,9 +439,16 @@ __global__ void strided_seq_sum_kernel(const void* __restrict__ x, int x_dtype, 
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * D) return;
     const int b = (int)(i / D), d = (int)(i % D);
-    float s = 0.f;
-    for (int t = 0; t < S; ++t) s += load_elem(x, x_dtype, (long)b * stride_b + (long)t * stride_s + d);
-    y[(long)b * ldy + d] = scale * s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long o = (long)b * stride_b + d;
+    int t = 0;
+    for (; t + 3 < S; t += 4) {
+        const float a = load_elem(x, x_dtype, o + (long)t * stride_s), c = load_elem(x, x_dtype, o + (long)(t + 1) * stride_s),
+                    e = load_elem(x, x_dtype, o + (long)(t + 2) * stride_s), f = load_elem(x, x_dtype, o + (long)(t + 3) * stride_s);
+        s0 += a; s1 += c; s2 += e; s3 += f;
+    }
+    for (; t < S; ++t) s0 += load_elem(x, x_dtype, o + (long)t * stride_s);
+    y[(long)b * ldy + d] = scale * ((s0 + s1) + (s2 + s3));
 }
 
 __global__ void seq_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int S, int D) {
