@@ -12,7 +12,8 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
-                                                   const unsigned long long* __restrict__ step_state) {
+                                                   const unsigned long long* __restrict__ step_state, const int* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag) return;    // an upstream kernel reported a fault (barrier timeout): keep the weights, the host raises
     if (step_state) {                       // bias corrections from the device-resident step count (graph replay)
         const float t = (float)step_state[1];
         bc1 = 1.f - powf(b1, t);
@@ -52,9 +53,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-__global__ void step_state_advance_kernel(unsigned long long* state) {
-    state[0] = state[0] * 6364136223846793005ull + 1442695040888963407ull;   // 64-bit LCG walk of the RNG word
-    state[1] += 1ull;                                                           // optimizer step count
+__global__ void step_state_advance_kernel(unsigned long long* state, int rng, int step) {
+    if (rng) state[0] = state[0] * 6364136223846793005ull + 1442695040888963407ull;   // 64-bit LCG walk of the RNG word
+    if (step) state[1] += 1ull;                                                         // optimizer step count
+}
+
+// bf16 -> fp32 (gradient payloads come back from a bf16 all-reduce), 8 elements per lane and trip
+__global__ __launch_bounds__(256) void cast_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 7 < n) {
+            const uint4 a = *(const uint4*)(src + i);
+            *(float4*)(dst + i) = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xFFFF0000u),
+                                              __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xFFFF0000u));
+            *(float4*)(dst + i + 4) = make_float4(__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xFFFF0000u),
+                                                  __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xFFFF0000u));
+        } else for (long k = i; k < n; ++k) dst[k] = __uint_as_float((uint32_t)src[k] << 16);
+    }
+}
+
+// dst[i] = sum_r src[r * chunk + i] in rank order r = 0..W-1, fp32 accumulation: the local reduction of the direct (all-to-all) gradient
+// all-reduce.  Every rank owns one chunk and sums the W contributions in the same order, so replicas stay bit-identical.
+template <bool BF16>
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const void* __restrict__ src_, int W, long chunk, void* __restrict__ dst_) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < chunk; i += stride) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (BF16) {
+            const uint16_t* src = (const uint16_t*)src_;
+            for (int r = 0; r < W; ++r) {
+                const uint2 v = *(const uint2*)(src + r * chunk + i);
+                a[0] += __uint_as_float(v.x << 16); a[1] += __uint_as_float(v.x & 0xFFFF0000u);
+                a[2] += __uint_as_float(v.y << 16); a[3] += __uint_as_float(v.y & 0xFFFF0000u);
+            }
+            uint2 o; o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
+            *(uint2*)((uint16_t*)dst_ + i) = o;
+        } else {
+            const float* src = (const float*)src_;
+            for (int r = 0; r < W; ++r) {
+                const float4 v = *(const float4*)(src + r * chunk + i);
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+            }
+            *(float4*)((float*)dst_ + i) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n) {
@@ -114,14 +156,35 @@ __global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int hulc_step_state_advance(unsigned long long* state, void* stream) {
+extern "C" int hulc_step_state_advance_words(unsigned long long* state, int rng, int step, void* stream) {
     if (!state) return hulc_fail(-1, "hulc_step_state_advance: null pointer");
-    step_state_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state);
+    step_state_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, rng, step);
     return hulc_check_launch("hulc_step_state_advance");
 }
 
+extern "C" int hulc_step_state_advance(unsigned long long* state, void* stream) { return hulc_step_state_advance_words(state, 1, 1, stream); }
+
+extern "C" int hulc_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream) {
+    if (!src || !dst) return hulc_fail(-1, "hulc_cast_bf16_to_f32: null pointer");
+    if (((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) return hulc_fail(-4, "hulc_cast_bf16_to_f32: misaligned");
+    long blocks = (n / 8 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    cast_f32_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)src, dst, n);
+    return hulc_check_launch("hulc_cast_bf16_to_f32");
+}
+
+extern "C" int hulc_sum_chunks(const void* src, int dtype, int W, long chunk, void* dst, void* stream) {
+    if (!src || !dst) return hulc_fail(-1, "hulc_sum_chunks: null pointer");
+    if (W < 1 || chunk < 0 || (chunk & 7)) return hulc_fail(-2, "hulc_sum_chunks: chunk must be a multiple of 8 elements, W >= 1");
+    if (((uintptr_t)src | (uintptr_t)dst) % 16) return hulc_fail(-4, "hulc_sum_chunks: misaligned");
+    if (chunk == 0) return 0;
+    long blocks = (chunk / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    if (dtype == HULC_BF16) sum_chunks_kernel<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, W, chunk, dst);
+    else sum_chunks_kernel<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(src, W, chunk, dst);
+    return hulc_check_launch("hulc_sum_chunks");
+}
+
 extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, void* stream) {
+                              float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag, void* stream) {
     if (!p || !g || !m || !v) return hulc_fail(-1, "hulc_adam_step: null pointer");
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return hulc_fail(-4, "hulc_adam_step: arenas must be 16-byte aligned");
     if (!step_state && step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
@@ -129,7 +192,7 @@ extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
-                                                                   bc1, bc2s, grad_scale, step_state);
+                                                                   bc1, bc2s, grad_scale, step_state, skip_flag);
     return hulc_check_launch("hulc_adam_step");
 }
 

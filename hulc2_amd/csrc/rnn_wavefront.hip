@@ -41,8 +41,8 @@ struct WaveP {
     const float* mask1; long mask1_step, ld_mask1;   // stored activations: output kept where mask > 0 (nullable)
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
-    unsigned* bar; int* err;
-    int dbg;                                     // timing experiments only (HULC_RNN_DBG): 1 = skip state loads + MFMAs, 2 = skip the barrier
+    unsigned* bar; int* err; int* err_sticky;
+    int dbg;                                     // experiments / tests only (HULC_RNN_DBG): 1 = skip state loads + MFMAs, 2 = skip the barrier, 4 = inject a barrier timeout
 };
 
 // The bf16 state copy is the only data exchanged between workgroups inside the kernel.  Measured alternatives:
@@ -234,7 +234,11 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
             long spins = 0;
             while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1L << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++spins > (1L << 22)) {
+                    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.err_sticky) __hip_atomic_store(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
         }
         __syncthreads();
@@ -242,6 +246,10 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
     }
     // a barrier timeout anywhere poisons the state so the failure is loud (NaN loss) instead of silent
     __syncthreads();
+    if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0) {        // fault injection (tests): behave as if the barrier had timed out
+        __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.err_sticky) __hip_atomic_store(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = true;
     if (timed_out) {
         float* zn = p.z + (long)(p.S + 1) * p.z_step;
@@ -280,7 +288,7 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.bias1a = d->bias1a; p.bias1b = d->bias1b; p.bias2a = d->bias2a; p.bias2b = d->bias2b;
     p.mask1 = d->mask1; p.mask1_step = d->mask1_step; p.ld_mask1 = d->ld_mask1;
     p.mask2 = d->mask2; p.mask2_step = d->mask2_step; p.ld_mask2 = d->ld_mask2;
-    p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H;
+    p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H; p.err_sticky = d->err_sticky;
     p.dbg = getenv("HULC_RNN_DBG") ? atoi(getenv("HULC_RNN_DBG")) : 0;
     p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
     // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs

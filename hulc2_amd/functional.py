@@ -475,10 +475,12 @@ def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: fl
 # action decoder recurrence: 2-layer ReLU RNN over [plan | emb_slice | goal]
 # reference: logistic_decoder_rnn.py:257-270 + decoders/utils/rnn.py:5-14
 # ------------------------------------------------------------------------------------------------
-def _rnn_persistent(B: int, Hd: int, state_dtype) -> bool:
-    """the persistent wavefront kernel covers the benchmarked geometry (bf16 compute, H = 2048, <= 64 rows, fp32 state);
+def _rnn_persistent(B: int, Hd: int, state_dtype, device) -> bool:
+    """the persistent wavefront kernel covers the benchmarked geometry (bf16 compute, H = 2048, <= 64 rows, fp32 state) on a whole
+    MI355X (its 256 workgroups must all be resident, one per CU: a CPX/DPX partition or a CU-masked device shows fewer CUs);
     other geometries and the exact-fp32 mode use the per-step GEMMs.  HULC_NO_RNN_WAVEFRONT=1 forces the per-step path."""
     return (kn.get_compute() == "bf16" and Hd == 2048 and B <= 64 and state_dtype == torch.float32
+            and kn.device_cu_count(device) >= 256
             and not kn.concurrent_streams()          # its device-wide barrier needs the GPU to itself (kernels.set_concurrent_streams)
             and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
 
@@ -504,7 +506,7 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
     # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
     zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
-    persistent = h0 is None and _rnn_persistent(B, Hd, zdt)
+    persistent = h0 is None and _rnn_persistent(B, Hd, zdt, dev)
     if persistent:
         # the persistent kernel writes every row it owns (rows 1..S+1, zeros included): only the initial row and the half of the last
         # row it never produces are cleared, not 36 MB

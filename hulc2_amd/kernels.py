@@ -117,12 +117,61 @@ def step_state(device) -> torch.Tensor:
     return t
 
 
-def advance_step_state(device) -> None:
-    _call("hulc_step_state_advance", step_state(device))
+_rng_fresh = {}
+_fault = {}
+
+
+def fault_word(device) -> torch.Tensor:
+    """Sticky device word the barrier kernel sets on a timeout (hulc_rnn_wave_desc.err_sticky).  While it is set the Adam kernel leaves the
+    weights alone; `check_faults` turns it into an exception."""
+    t = _fault.get(device)
+    if t is None:
+        t = _fault[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def check_faults(device) -> None:
+    """Host check of the fault word (synchronises the device: call it where a sync happens anyway — after a timed region, every N steps).
+    Raises HulcKernelError instead of letting a NaN loss propagate."""
+    t = _fault.get(device)
+    if t is not None and int(t.item()) != 0:
+        t.zero_()
+        raise _L.HulcKernelError(
+            "rnn_wavefront: device-wide barrier timed out — its 256 workgroups were not all resident (another kernel / process shared "
+            "the GPU, or the device is partitioned).  The optimizer update of that step was skipped.  Run with HULC_NO_RNN_WAVEFRONT=1 "
+            "to use the per-step GEMM path.")
+
+
+_cu_count = {}
+
+
+def device_cu_count(device) -> int:
+    n = _cu_count.get(device)
+    if n is None:
+        n = _cu_count[device] = torch.cuda.get_device_properties(device).multi_processor_count
+    return n
+
+
+def advance_step_state(device, rng: bool = True, step: bool = True) -> None:
+    """Walk the RNG word and / or bump the optimizer step count (one 1-thread kernel).  The native trainer advances both at the top of a
+    step and marks the RNG word fresh, so the `ensure_fresh_rng` inside Hulc2.training_step is then free."""
+    _call("hulc_step_state_advance_words", step_state(device), _i(rng), _i(step))
+    if rng:
+        _rng_fresh[device] = True
+
+
+def ensure_fresh_rng(device) -> None:
+    """Called by Hulc2.training_step in training mode: every call of the step draws new dropout masks and a new latent-plan sample, whoever
+    drives the loop (Lightning + any torch optimizer, or ArenaTrainer).  A trainer that already advanced the word for this step is honoured
+    once; the optimizer step count (word 1) is never touched here."""
+    if _rng_fresh.pop(device, False):
+        return
+    _call("hulc_step_state_advance_words", step_state(device), _i(1), _i(0))
 
 
 def reset_step_state(device, seed: int = 0x243F6A8885A308D3 >> 1, step: int = 0) -> None:
     step_state(device).copy_(torch.tensor([seed, step], dtype=torch.int64))
+    _rng_fresh.pop(device, None)
 
 
 
@@ -508,6 +557,7 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     d.mask2, d.mask2_step, d.ld_mask2 = (mask2.data_ptr() if mask2 is not None else None), int(mask2_step), int(ld_mask2)
     d.relu, d.S, d.B, d.H = int(relu), int(S), int(B), int(H)
     d.mirror_t = int(bool(mirror_t))
+    d.err_sticky = fault_word(z0.device).data_ptr()
     lib = _L.load()
     lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)
@@ -626,10 +676,22 @@ def window_rows(store, starts, sizes, B, S, out, zero_cols=(0, 0)):
 
 
 def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None):
-    """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device."""
+    """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device.  The update is skipped
+    on the device while the fault word is set (a barrier kernel timed out upstream) — check_faults() then raises on the host."""
     _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
-          step_state_dev, _f(grad_scale))
+          step_state_dev, _f(grad_scale), fault_word(p.device))
 
 
 def cast_f32_to_bf16(src, dst, n):
     _call("hulc_cast_f32_to_bf16", src, dst, _l(n))
+
+
+def cast_bf16_to_f32(src, dst, n):
+    _call("hulc_cast_bf16_to_f32", src, dst, _l(n))
+
+
+def sum_chunks(src, W, chunk, dst):
+    """dst (chunk,) = sum over the W rank chunks of src (W * chunk,), rank order, fp32 accumulation (direct gradient all-reduce)"""
+    if src.dtype != dst.dtype:
+        raise TypeError("sum_chunks: src and dst share a dtype")
+    _call("hulc_sum_chunks", src, _i(_dt(src)), _i(W), _l(chunk), dst)

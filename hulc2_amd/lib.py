@@ -91,6 +91,7 @@ class RnnWaveDesc(ctypes.Structure):
         ("mask1", ctypes.c_void_p), ("mask1_step", ctypes.c_long), ("ld_mask1", ctypes.c_long),
         ("mask2", ctypes.c_void_p), ("mask2_step", ctypes.c_long), ("ld_mask2", ctypes.c_long),
         ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int), ("mirror_t", ctypes.c_int),
+        ("err_sticky", ctypes.c_void_p),
     ]
 
 

@@ -58,9 +58,18 @@ class LogisticDecoderRNN(ActionDecoder):
     def fused_param_groups(self):
         """Parameters the native trainer lays out contiguously so that the four heads are ONE (184, H) matrix / (184,) bias in the
         arena (views, no per-step concat; their gradient lands in the same arena slice).  Order = the fused head layout."""
+        H = self.prob_fc.weight.shape[1]
+        rows, pad = self._head_rows()
         return [dict(attr="heads_w", params=[self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight],
-                     pad=2 * self.prob_fc.weight.shape[1], shape=(184, self.prob_fc.weight.shape[1])),
-                dict(attr="heads_b", params=[self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias], pad=2, shape=(184,))]
+                     pad=pad * H, shape=(rows + pad, H)),
+                dict(attr="heads_b", params=[self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias], pad=pad,
+                     shape=(rows + pad,))]
+
+    def _head_rows(self):
+        """(rows of the fused head matrix, zero rows appended so its width is a multiple of 8): 3 * out_features * n_dist + 2 gripper logits
+        — 182 + 2 for the configured 6 x 10 (conf/model/action_decoder/logistic_decoder_rnn_calvin.yaml), derived, not assumed"""
+        rows = 3 * self.out_features * self.n_dist + 2
+        return rows, (-rows) % 8
 
     _fused = None      # {"heads_w": tensor view, "heads_b": tensor view} installed by ArenaTrainer
 
@@ -68,10 +77,11 @@ class LogisticDecoderRNN(ActionDecoder):
         """(B,S,H) -> (B*S, 184): [logit_probs 60 | means 60 | log_scales 60 | gripper 2 | 2 zero pad columns]."""
         if self._fused is not None:
             return HF.mlp(h.reshape(-1, h.shape[-1]), [(self._fused["heads_w"], self._fused["heads_b"], False)])
+        pad = self._head_rows()[1]
         w = torch.cat([self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight,
-                       self.prob_fc.weight.new_zeros(2, self.prob_fc.weight.shape[1])], dim=0)
+                       self.prob_fc.weight.new_zeros(pad, self.prob_fc.weight.shape[1])], dim=0)
         b = torch.cat([self.prob_fc.bias, self.mean_fc.bias, self.log_scale_fc.bias, self.gripper_fc.bias,
-                       self.prob_fc.bias.new_zeros(2)], dim=0)
+                       self.prob_fc.bias.new_zeros(pad)], dim=0)
         return HF.mlp(h.reshape(-1, h.shape[-1]), [(w, b, False)])
 
     def _rnn(self, latent_plan, perceptual_emb, latent_goal) -> torch.Tensor:

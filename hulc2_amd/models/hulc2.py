@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from hulc2_amd import functional as HF
+from hulc2_amd import kernels as kn
 from hulc2_amd.compat import LightningModule, instantiate
 from hulc2_amd.utils.distributions import State
 
@@ -91,6 +92,12 @@ class Hulc2(LightningModule):
 
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
         """hulc2.py:336-442."""
+        if self.training:
+            # every training-mode call draws fresh dropout masks and a fresh latent-plan sample (the device RNG word, kernels.step_state),
+            # under any trainer: Lightning + a torch optimizer never touches that word, ArenaTrainer marks it fresh for this step itself
+            p0 = next(self.parameters())
+            if p0.is_cuda:
+                kn.ensure_fresh_rng(p0.device)
         kl_loss = action_loss = total_loss = lang_clip_loss = None
         batch_size: Dict[str, int] = {}
         total_bs = 0

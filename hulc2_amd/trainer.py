@@ -25,13 +25,99 @@ from . import kernels as kn
 from . import shadow
 
 
+class GradComm:
+    """Sums slices of the fp32 gradient arena over the ranks, in place (replaces the NCCL ring inside Lightning's DDPStrategy,
+    hulc2/training.py:72-75).
+
+      algo     "ring"   one dist.all_reduce per slice (RCCL picks the algorithm; on xGMI a ring is bound by ONE of the 7 links)
+               "direct" all_to_all_single -> local sum of the W contributions of this rank's chunk in rank order (hulc_sum_chunks, fp32
+                        accumulation) -> all_gather_into_tensor: every rank talks to every peer at once, so all 7 links carry 1/W of the
+                        payload each way; the result is bit-identical on all ranks (one rank reduces a chunk, everyone receives it)
+      payload  "fp32"   the arena slice as it is
+               "bf16"   rounded to bf16 for the wire (half the bytes), widened back into the arena afterwards; changes the arithmetic
+                        (gradients pick up one bf16 rounding, the sum of "direct" a second one), hence a switch
+    Defaults come from HULC_ALLREDUCE / HULC_GRAD_PAYLOAD (ring / fp32)."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, algo: Optional[str] = None, payload: Optional[str] = None, force: bool = False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.algo = algo or os.environ.get("HULC_ALLREDUCE", "ring")
+        self.payload = payload or os.environ.get("HULC_GRAD_PAYLOAD", "fp32")
+        if self.algo not in ("ring", "direct") or self.payload not in ("fp32", "bf16"):
+            raise ValueError(f"gradient all-reduce: algo {self.algo!r} (ring | direct), payload {self.payload!r} (fp32 | bf16)")
+        self.flat_grad = flat_grad
+        self.on_gpu = flat_grad.is_cuda
+        self._bufs = {}
+
+    def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = self._bufs[name] = torch.zeros(max(n, self.flat_grad.numel() + 8 * self.world), dtype=dtype, device=self.flat_grad.device)
+        return t[:n]
+
+    def reserve(self) -> None:
+        """allocate the staging buffers up front (before a hipGraph capture pins the allocator pools)"""
+        if not self.active or (self.algo == "ring" and self.payload == "fp32"):
+            return
+        dt = torch.bfloat16 if self.payload == "bf16" else torch.float32
+        self._buf("stage", 1, dt)
+        if self.algo == "direct":
+            self._buf("recv", 1, dt)
+            self._buf("mine", 1, dt)
+
+    def _narrow(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        if self.on_gpu and dst.dtype == torch.bfloat16:
+            kn.cast_f32_to_bf16(src, dst, src.numel())
+        else:
+            dst.copy_(src)
+
+    def _widen(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        if self.on_gpu and src.dtype == torch.bfloat16:
+            kn.cast_bf16_to_f32(src, dst, src.numel())
+        else:
+            dst.copy_(src)
+
+    def reduce(self, lo: int, hi: int, async_op: bool = False):
+        """flat_grad[lo:hi] <- sum over ranks, on the current stream.  Returns a work handle only for async_op (CPU ring/fp32 path)."""
+        view = self.flat_grad[lo:hi]
+        n = hi - lo
+        if n <= 0 or not self.active:
+            return None
+        if self.algo == "ring" and self.payload == "fp32":
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        dt = torch.bfloat16 if self.payload == "bf16" else torch.float32
+        if self.algo == "ring":
+            stage = self._buf("stage", n, dt)
+            self._narrow(view, stage)
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
+            self._widen(stage, view)
+            return None
+        W = self.world
+        chunk = ((n + W - 1) // W + 7) // 8 * 8
+        stage, recv, mine = self._buf("stage", chunk * W, dt), self._buf("recv", chunk * W, dt), self._buf("mine", chunk, dt)
+        self._narrow(view, stage[:n])
+        if chunk * W > n:
+            stage[n:].zero_()
+        dist.all_to_all_single(recv, stage, group=self.group)
+        if self.on_gpu:
+            kn.sum_chunks(recv, W, chunk, mine)
+        else:
+            mine.copy_(recv.view(W, chunk).float().sum(0))
+        dist.all_gather_into_tensor(stage, mine, group=self.group)
+        self._widen(stage[:n], view)
+        return None
+
+
 class GradBuckets:
     """Contiguous slices of the gradient arena reduced across ranks, overlapped with backward."""
 
     def __init__(self, params: List[torch.nn.Parameter], offsets: List[int], flat_grad: torch.Tensor, bucket_bytes: int,
-                 group=None, overlap: bool = True):
+                 group=None, overlap: bool = True, comm: Optional[GradComm] = None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = comm if comm is not None else GradComm(flat_grad, group)
+        self.world = self.comm.world
+        self.active = self.comm.active
         self.flat_grad = flat_grad
         self.on_gpu = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
@@ -56,7 +142,7 @@ class GradBuckets:
             self.members[b] += 1
         self.handles = []
         self.overlap = overlap
-        if self.world > 1 and overlap:
+        if self.active and overlap:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
@@ -67,13 +153,14 @@ class GradBuckets:
         self.handles = []
 
     def _launch(self, b):
-        view = self.flat_grad[b["lo"]:b["hi"]]
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self.comm.reduce(b["lo"], b["hi"])
         else:
-            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            h = self.comm.reduce(b["lo"], b["hi"], async_op=True)
+            if h is not None:
+                self.handles.append(h)
 
     def _hook(self, p):
         b = self.buckets[self.param_bucket[id(p)]]
@@ -83,10 +170,10 @@ class GradBuckets:
 
     def finish(self):
         """Flush buckets whose parameters produced no gradient this step, then join the comm stream."""
-        if self.world > 1 and not self.overlap:       # graph mode: one in-place all-reduce of the whole arena, same stream
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.active and not self.overlap:       # graph mode: one in-place all-reduce of the whole arena, same stream
+            self.comm.reduce(0, self.flat_grad.numel())
             return
-        if self.world > 1:
+        if self.active:
             for b in self.buckets:
                 if b["pending"] > 0:
                     b["pending"] = 0
@@ -100,7 +187,10 @@ class GradBuckets:
 
 class ArenaTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 bucket_mb: int = 32, group=None, overlap: bool = True):
+                 bucket_mb: int = 32, group=None, overlap: bool = True, comm_algo: Optional[str] = None, grad_payload: Optional[str] = None,
+                 force_comm: bool = False):
+        """force_comm: run the multi-rank control flow (split graphs, comm stream, collectives) even with a single rank in the process
+        group — how the RCCL path is exercised on a one-GPU box."""
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -109,7 +199,8 @@ class ArenaTrainer:
         # (fused_param_groups: the decoder's four heads become one (184, H) matrix view).  Fused views receive their gradient
         # through a sink only, so they exist only when sinks do (not with per-parameter all-reduce hooks).
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        use_sinks = dev.type == "cuda" and (self.world == 1 or not overlap)
+        self.multi = self.world > 1 or (force_comm and dist.is_initialized())
+        use_sinks = dev.type == "cuda" and (not self.multi or not overlap)
         groups = []
         for mod in model.modules():                     # views installed by an earlier trainer die with its arena
             if getattr(mod, "fused_param_groups", None) is not None:
@@ -219,9 +310,10 @@ class ArenaTrainer:
                 for p, name, d0, shape in views:
                     shadow.register_layout_view(p, name, self.conv_shadow[d0:d0 + p.numel()].view(shape))
                 kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
-        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap)
+        self.comm = GradComm(self.flat_g, group, comm_algo, grad_payload, force=force_comm)
+        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap, comm=self.comm)
         # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
-        kn.set_concurrent_streams(dev.type == "cuda" and self.world > 1 and overlap)
+        kn.set_concurrent_streams(dev.type == "cuda" and self.multi and overlap)
         gradsink.clear()
         if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
             for p, off in zip(self.params, self.offsets):
@@ -234,6 +326,7 @@ class ArenaTrainer:
             kn.step_state(dev)[1] = 0               # the device-resident Adam step count starts with this trainer (the RNG word keeps walking)
         self.graph_fb = self.graph_enc = self.graph_opt = None
         self.static_loss = None
+        model.register_load_state_dict_post_hook(self._after_model_load)
         # Split point for overlapping the gradient all-reduce with the tail of backward in graph mode: the camera encoders
         # are registered first (arena head, 0.75 M parameters) but their backward (the conv stack) is the LAST ~2 ms of a step,
         # while everything else (98 % of the gradient bytes) is complete once backward reaches the encoder output.
@@ -249,6 +342,63 @@ class ArenaTrainer:
             self.rest_params = [p for i, p in enumerate(self.params) if not enc[i]]
             model.perceptual_encoder.register_forward_hook(self._keep_encoder_output)
         self._emb = None
+
+    # ---- weights written from outside (checkpoint restore) and optimizer state ----------------------------------------------------
+    def refresh_shadows(self) -> None:
+        """Re-derive every kernel-side copy of the parameters from the fp32 arena: the bf16 shadow, its transposed tiles and the conv
+        repacks.  The Adam kernel keeps them fresh step by step; anything else that writes the parameters (model.load_state_dict —
+        Lightning restores weights AFTER the optimizer exists, hulc2/training.py:41-53,82 —, an external p.data.copy_) must be followed by
+        this call, else the next forward/backward runs on the old weights.  Installed as a load_state_dict post-hook on the model."""
+        if self.flat_bf16 is not None:
+            kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, self.total)
+            if self.tiles_t is not None:
+                kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+            if self.conv_table is not None:
+                kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
+        shadow.bump_epoch()
+
+    def _after_model_load(self, module, incompatible_keys) -> None:
+        for p, off in zip(self.params, self.offsets):         # a load that REPLACED .data (assign=True) would detach the arena: re-home it
+            if p.data_ptr() != self.flat_p.data_ptr() + off * 4:
+                with torch.no_grad():
+                    self.flat_p[off:off + p.numel()].copy_(p.reshape(-1))
+                    p.data = self.flat_p[off:off + p.numel()].view(p.shape)
+        self.refresh_shadows()
+
+    def state_dict(self) -> Dict:
+        """optimizer state in the reference's terms (a Lightning checkpoint carries torch.optim.Adam's exp_avg / exp_avg_sq / step per
+        parameter, hulc2.py:185-198): per-parameter tensors keyed by the model's parameter names, so the arena layout can change between
+        save and load; plus the device step words (Adam step count, RNG word)."""
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        st = {}
+        for p, off in zip(self.params, self.offsets):
+            n = p.numel()
+            st[names[id(p)]] = {"exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                                "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        words = kn.step_state(self.dev).tolist() if self.dev.type == "cuda" else [0, self.step_count]
+        return {"state": st, "step": int(self.step_count), "rng_word": int(words[0]), "device_step": int(words[1]),
+                "hparams": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        names = {n: p for n, p in self.model.named_parameters()}
+        index = {id(p): off for p, off in zip(self.params, self.offsets)}
+        missing = [n for n, p in names.items() if id(p) in index and n not in sd["state"]]
+        if missing:
+            raise KeyError(f"ArenaTrainer.load_state_dict: no optimizer state for {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        with torch.no_grad():
+            for n, rec in sd["state"].items():
+                p = names.get(n)
+                if p is None or id(p) not in index:
+                    continue
+                off, k = index[id(p)], p.numel()
+                self.exp_avg[off:off + k].copy_(rec["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(rec["exp_avg_sq"].reshape(-1))
+        self.step_count = int(sd["step"])
+        hp = sd.get("hparams", {})
+        self.lr, self.betas, self.eps, self.wd = hp.get("lr", self.lr), tuple(hp.get("betas", self.betas)), hp.get("eps", self.eps), hp.get("weight_decay", self.wd)
+        if self.dev.type == "cuda":
+            kn.reset_step_state(self.dev, seed=int(sd["rng_word"]), step=int(sd.get("device_step", sd["step"])))
+        self.refresh_shadows()
 
     def _keep_encoder_output(self, module, inputs, output):
         self._emb = output if (self._split_active and torch.is_tensor(output) and output.requires_grad) else None
@@ -345,7 +495,18 @@ class ArenaTrainer:
         loss = self._forward_backward(batch, batch_idx)
         self.buckets.finish()
         self.optimizer_step()
+        self._poll_faults()
         return loss
+
+    _fault_every = int(os.environ.get("HULC_FAULT_CHECK_EVERY", "64"))
+    _since_check = 0
+
+    def _poll_faults(self) -> None:
+        """every N steps (one device sync): a barrier-kernel timeout becomes an exception; the Adam kernel has skipped the faulty steps"""
+        self._since_check += 1
+        if self.dev.type == "cuda" and self._since_check >= self._fault_every:
+            self._since_check = 0
+            kn.check_faults(self.dev)
 
     # ---- hipGraph mode: the ~900 launches of a step are captured once and replayed ----------------------
     def capture(self, batch) -> None:
@@ -353,8 +514,9 @@ class ArenaTrainer:
         Between them the gradient arena is all-reduced eagerly when world > 1 (construct with overlap=False).
         Call after a few eager warm-up steps (allocator pools, lazy scratch buffers and kernels are then live)."""
         assert self.dev.type == "cuda"
-        if self.world > 1 and self.buckets.overlap:
+        if self.multi and self.buckets.overlap:
             raise RuntimeError("graph mode needs ArenaTrainer(overlap=False): bucket hooks cannot run inside a replayed graph")
+        self.comm.reserve()
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -366,8 +528,8 @@ class ArenaTrainer:
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
         # world > 1: the process group's watchdog thread may touch the runtime while this thread captures; only this thread's calls are policed
-        mode = {"capture_error_mode": "thread_local"} if self.world > 1 else {}
-        if self.world > 1 and self.enc_hi > self.enc_lo:
+        mode = {"capture_error_mode": "thread_local"} if self.multi else {}
+        if self.multi and self.enc_hi > self.enc_lo:
             # two graphs around the split point; replay() launches the big all-reduce between them on the comm stream
             with torch.cuda.graph(self.graph_fb, stream=side, **mode):
                 self.static_loss = self._forward_backward_head(batch, 0)
@@ -390,12 +552,14 @@ class ArenaTrainer:
             comm.wait_stream(cur)
             with torch.cuda.stream(comm):
                 for lo, hi in ((0, self.enc_lo), (self.enc_hi, self.total)):
-                    if hi > lo:
-                        dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.buckets.group)
+                    self.comm.reduce(lo, hi)
             self.graph_enc.replay()
-            dist.all_reduce(self.flat_g[self.enc_lo:self.enc_hi], op=dist.ReduceOp.SUM, group=self.buckets.group)
+            comm.wait_stream(cur)                    # the small encoder slice follows on the SAME stream: the staging buffers of the
+            with torch.cuda.stream(comm):            # bf16 / direct modes are shared, two reduces must never run concurrently
+                self.comm.reduce(self.enc_lo, self.enc_hi)
             cur.wait_stream(comm)
         else:
             self.buckets.finish()
         self.graph_opt.replay()
+        self._poll_faults()
         return self.static_loss

@@ -263,6 +263,8 @@ typedef struct hulc_rnn_wave_desc {
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
     int mirror_t;   /* also write the transposed bf16 mirror (hulc_rnn_wavefront_mirror_t_offset); needs B % 8 == 0 */
+    int* err_sticky; /* optional device word set to 1 on a barrier timeout and never cleared by the kernels: the host polls it
+                      * (and hulc_adam_step skips its update while it is set) so a timeout ends the job instead of feeding NaN to Adam */
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
 long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */
@@ -275,13 +277,22 @@ int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream);
 /* torch.optim.Adam semantics (hulc2.py:185-198, conf/model/optimizer/adam.yaml) over a flat fp32 arena;
  * bf16_shadow (optional) receives the updated weights rounded to bf16 for the MFMA kernels. */
 int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, void* stream);
+                   float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                   void* stream);   /* skip_flag (optional device word): non-zero = leave parameters and moments untouched (kernel fault upstream) */
 /* Device-resident step state {rng word, optimizer step count}: advanced by one kernel per training step so that
  * a captured hipGraph replays with fresh dropout masks / plan samples and the right Adam bias correction.
  * RNG kernels xor state[0] into their site seed (seed_dev = state); hulc_adam_step reads state[1] when
  * step_state != NULL (the `step` argument is then ignored). */
 int hulc_step_state_advance(unsigned long long* state, void* stream);
+/* the same with the two words advanced separately: Hulc2.training_step (hulc2.py:336) walks the RNG word whenever it runs in training
+ * mode (under Lightning too), the native trainer alone bumps the optimizer step count (its Adam bias correction) */
+int hulc_step_state_advance_words(unsigned long long* state, int rng, int step, void* stream);
 int hulc_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* Gradient all-reduce helpers of the data-parallel path (replaces the NCCL ring inside Lightning's DDPStrategy, hulc2/training.py:72-75;
+ * SURVEY §8e): bf16 payloads widen back to the fp32 arena; the direct algorithm (all-to-all -> local sum -> all-gather, every xGMI link
+ * busy at once) sums the W rank contributions of this rank's chunk in rank order with fp32 accumulation. */
+int hulc_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
+int hulc_sum_chunks(const void* src, int dtype, int W, long chunk, void* dst, void* stream);
 /* Transposed bf16 shadows of the 2-D weights of the arena in one launch: tiles[q] = {element offset, rows, cols, tile row,
  * tile col} over 64 x 64 tiles; dst + offset receives W^T ([cols][rows]).  The data-gradient GEMMs (dX = dY W of every
  * nn.Linear) then read W k-major like the forward pass does. */

@@ -86,3 +86,79 @@ def test_bucket_layout_is_contiguous_and_covers_arena():
         assert b <= c
     covered = sum(b - a for a, b in spans)
     assert covered >= sum(p.numel() for p in tr.params)
+
+
+def _comm_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hulc2_amd.trainer import GradComm
+
+    n = 1003                                               # not a multiple of 8 * world: exercises the zero-padded tail chunk
+    res = {}
+    for algo in ("ring", "direct"):
+        for payload in ("fp32", "bf16"):
+            g = torch.Generator().manual_seed(7)
+            base = [torch.randn(n, generator=g) for _ in range(world)]          # every rank can rebuild every rank's gradients
+            arena = base[rank].clone()
+            comm = GradComm(arena, None, algo, payload)
+            comm.reserve()
+            comm.reduce(5, n - 3)                          # an interior slice: the elements outside must stay untouched
+            want = arena.clone()
+            if payload == "fp32":
+                want[5:n - 3] = sum(b[5:n - 3] for b in base)
+                tol = 1e-6
+            else:                                          # one bf16 rounding of the inputs (+ one of the sum for "direct")
+                want[5:n - 3] = sum(b[5:n - 3].bfloat16().float() for b in base)
+                tol = 4e-2
+            inside = torch.allclose(arena[5:n - 3], want[5:n - 3], atol=tol, rtol=tol)
+            outside = torch.equal(arena[:5], base[rank][:5]) and torch.equal(arena[n - 3:], base[rank][n - 3:])
+            gathered = [torch.empty_like(arena) for _ in range(world)]
+            dist.all_gather(gathered, arena)
+            same = all(torch.equal(gathered[0][5:n - 3], t[5:n - 3]) for t in gathered)     # replicas bit-identical after the reduce
+            res[(algo, payload)] = (inside, outside, same)
+    if rank == 0:
+        out.put(res)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_algorithms_world2():
+    """ring / direct (all-to-all + fixed-order local sum + all-gather) x fp32 / bf16 payload: same sums, untouched neighbours, identical replicas"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = q.get(timeout=5)
+    assert len(res) == 4
+    for key, flags in res.items():
+        assert all(flags), f"{key}: (sum correct, neighbours untouched, replicas identical) = {flags}"
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` from a plain shell starts N rank processes; --dry-run = rendezvous only, no GPU"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["rank_sum"] == 3.0
+
+
+def test_bench_launcher_propagates_rank_failure():
+    """a failing rank ends the job with a non-zero exit code (here: no GPU in this container -> every rank refuses to run)"""
+    import subprocess
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a machine without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HULC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]

@@ -82,7 +82,7 @@ def test_abi_library_exports_every_declared_symbol():
     so = ctypes.CDLL(str(lib.lib_path()))
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, missing
-    assert so.hulc_abi_version() == 1
+    assert so.hulc_abi_version() == 2
 
 
 def test_product_never_imports_oracle():
@@ -126,3 +126,97 @@ def test_real_world_config_resolves_r3m_encoder():
     with pytest.raises(NotImplementedError):
         from hulc2_amd.models.perceptual_encoders.vision_r3m import VisionR3M
         VisionR3M(None, 64, resnet_model="resnet50")
+
+
+# ---- the C structs of include/hulc2_amd.h against their ctypes mirrors and the binding shown in INTEGRATION.md ----------------------------
+_C2CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "unsigned long long": ctypes.c_ulonglong}
+
+
+def _parse_struct(text: str, name: str):
+    """-> [(field, ctypes type)] of `typedef struct name { ... } name;` — handles `const T *a, *b;`, `T a, b;`, `T* a; long b, c;` on one line"""
+    end = re.search(r"\}\s*" + name + r"\s*;", text)
+    assert end, f"struct {name} not found"
+    start = text.rfind("typedef struct", 0, end.start())
+    body = re.sub(r"/\*.*?\*/", "", text[text.index("{", start) + 1:end.start()], flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m2 = re.match(r"(?:const\s+)?(unsigned long long|void|float|int|long|unsigned)\s*(.*)$", decl, re.S)
+        assert m2, decl
+        base, rest = m2.group(1), m2.group(2)
+        for item in rest.split(","):
+            item = item.strip()
+            ptr = "*" in item
+            fields.append((item.replace("*", "").strip(), ctypes.c_void_p if ptr else _C2CT[base]))
+    return fields
+
+
+@pytest.mark.parametrize("cname,pyname", [("hulc_gemm_desc", "GemmDesc"), ("hulc_conv_desc", "ConvDesc"), ("hulc_rnn_wave_desc", "RnnWaveDesc"),
+                                          ("hulc_mix_desc", "MixDesc")])
+def test_ctypes_structures_mirror_the_header(cname, pyname):
+    """field count, order, names and C types of every descriptor struct == its ctypes.Structure in hulc2_amd/lib.py: a field added on one
+    side only makes the kernel read past the caller's struct (the INTEGRATION.md stub was 3 fields short)"""
+    from hulc2_amd import lib
+    header = (ROOT / "include" / "hulc2_amd.h").read_text()
+    want = _parse_struct(header, cname)
+    got = [(n, t) for n, t in getattr(lib, pyname)._fields_]
+    assert [n for n, _ in got] == [n for n, _ in want], (cname, [n for n, _ in got], [n for n, _ in want])
+    for (n, tg), (_, tw) in zip(got, want):
+        assert tg is tw, (cname, n, tg, tw)
+
+
+def test_integration_doc_binding_lists_every_gemm_field():
+    """INTEGRATION.md shows the ctypes binding a maintainer would write; its GemmDesc must carry all fields of hulc_gemm_desc in order"""
+    from hulc2_amd import lib
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    m = re.search(r"class GemmDesc\(ctypes\.Structure\):(.*?)\n```", doc, re.S)
+    assert m, "INTEGRATION.md no longer shows the GemmDesc binding"
+    names = re.findall(r'\("([A-Za-z_0-9]+)",\s*ctypes\.', m.group(1))
+    assert names == [n for n, _ in lib.GemmDesc._fields_], (names, [n for n, _ in lib.GemmDesc._fields_])
+    assert "raise `NotImplementedError`" not in doc or "validation" not in doc.split("raise `NotImplementedError`")[0][-200:]
+
+
+def test_fused_heads_follow_the_configured_mixture_count():
+    """the fused head layout is derived from out_features x n_mixtures, not assumed to be 6 x 10"""
+    from hulc2_amd.models.decoders.logistic_decoder_rnn import LogisticDecoderRNN
+    for n_mix, out in ((10, 7), (5, 7), (3, 4)):
+        dec = LogisticDecoderRNN(perceptual_features=128, latent_goal_features=32, plan_features=1024, n_mixtures=n_mix, hidden_size=64,
+                                 out_features=out, log_scale_min=-7.0, act_max_bound=[1.0] * out, act_min_bound=[-1.0] * out, dataset_dir="",
+                                 load_action_bounds=False, num_classes=10, gripper_alpha=1.0, perceptual_emb_slice=[64, 128],
+                                 policy_rnn_dropout_p=0.0, num_layers=2, rnn_model="rnn_decoder", gripper_control=False, discrete_gripper=True)
+        for g in dec.fused_param_groups():
+            members = sum(p.numel() for p in g["params"])
+            n = 1
+            for d in g["shape"]:
+                n *= d
+            assert members + g["pad"] == n, (n_mix, out, g["attr"])              # the view spans exactly the members + the zero padding
+            assert g["shape"][0] % 8 == 0 and g["shape"][0] - (3 * (out - 1) * n_mix + 2) == (-(3 * (out - 1) * n_mix + 2)) % 8
+
+
+def test_trainer_optimizer_state_roundtrip_and_reload_hook():
+    """ArenaTrainer.state_dict / load_state_dict carry exp_avg / exp_avg_sq / step by parameter NAME, and a model.load_state_dict
+    after the trainer exists keeps the parameters inside the arena (the post-hook re-derives the kernel-side shadows on the GPU)"""
+    from hulc2_amd.trainer import ArenaTrainer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 2))
+    tr = ArenaTrainer(m)
+    tr.exp_avg.normal_()
+    tr.exp_avg_sq.uniform_()
+    tr.step_count = 17
+    sd = tr.state_dict()
+    assert set(sd["state"]) == {n for n, _ in m.named_parameters()} and sd["step"] == 17
+    m2 = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 2))
+    tr2 = ArenaTrainer(m2)
+    tr2.load_state_dict(sd)
+    assert tr2.step_count == 17
+    for p, off in zip(tr2.params, tr2.offsets):                                  # (alignment padding between parameters carries no state)
+        sl = slice(off, off + p.numel())
+        assert torch.equal(tr2.exp_avg[sl], tr.exp_avg[sl]) and torch.equal(tr2.exp_avg_sq[sl], tr.exp_avg_sq[sl])
+    m2.load_state_dict(m.state_dict())                                           # weights restored AFTER the trainer was built
+    for p, off in zip(tr2.params, tr2.offsets):
+        assert p.data_ptr() == tr2.flat_p.data_ptr() + 4 * off
+    assert all(torch.equal(a, b) for a, b in zip(m2.parameters(), m.parameters()))
+    with pytest.raises(KeyError):
+        tr2.load_state_dict({**sd, "state": {k: v for k, v in list(sd["state"].items())[:-1]}})
