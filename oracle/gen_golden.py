@@ -13,7 +13,8 @@ imported leaf modules in the order of hulc2.py:379-442 / :200-245 / :444-466 / :
 Parameters and inputs are a pure function of (name, seed) — hulc2_amd/synthetic.py — so fixtures carry
 seeds, checksums, outputs and selected gradients only.
 
-usage: python oracle/gen_golden.py
+usage: python oracle/gen_golden.py            regenerate every fixture into tests/golden/
+       python oracle/gen_golden.py --check    regenerate into a temp dir and diff against the committed fixtures
 """
 import sys
 import types
@@ -397,10 +398,15 @@ def gen_transforms():
     import importlib.util, types
     tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
     tv.transforms = tvt
+    mine = [k for k in ("torchvision", "torchvision.transforms") if k not in sys.modules]
     sys.modules.setdefault("torchvision", tv); sys.modules.setdefault("torchvision.transforms", tvt)
-    spec = importlib.util.spec_from_file_location("_ref_transforms", REF / "hulc2" / "utils" / "transforms.py")
-    T = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(T)
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_transforms", REF / "hulc2" / "utils" / "transforms.py")
+        T = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(T)
+    finally:
+        for k in mine:                 # the name-only stub must not outlive the import: transformers probes torchvision.__spec__ later
+            sys.modules.pop(k, None)
     for tag, hw, pad, n in (("static", 200, 10, 2), ("gripper", 84, 4, 3)):
         u8 = torch.randint(0, 256, (n, hw, hw, 3), generator=g(SEED, f"x.tf.{tag}"), dtype=torch.uint8)
         x = u8.permute(0, 3, 1, 2)                                     # process_rgb: channels first
@@ -497,6 +503,56 @@ def gen_inference(m, dist, flat):
         save("lmp_val", seed=SEED, B=B, S=S, idx_pp=idx_pp.numpy(), idx_pr=idx_pr.numpy(), acts=acts, kl=kl, seq_feat_s=seq_feat[:, ::64], **res)
 
 
+def check() -> int:
+    """`python oracle/gen_golden.py --check`: regenerate every fixture into a temporary directory from the reference's modules and compare
+    with the committed tests/golden/*.npz array by array (exact for integer arrays, max-abs difference for floats).  0 = all identical."""
+    import tempfile
+    global OUT
+    committed = OUT
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = Path(tmp)
+        sys.argv = sys.argv[:1]
+        main()
+        OUT = committed
+        made = sorted(Path(tmp).glob("*.npz"))
+        for f in made:
+            ref = committed / f.name
+            if not ref.exists():
+                print(f"  {f.name}: NOT COMMITTED")
+                bad += 1
+                continue
+            a, b = np.load(f, allow_pickle=False), np.load(ref, allow_pickle=False)
+            worst = 0.0
+            for k in sorted(set(a.files) | set(b.files)):
+                if k not in a.files or k not in b.files:
+                    print(f"  {f.name}[{k}]: present on one side only")
+                    bad += 1
+                    continue
+                if k == "torch_version":
+                    continue
+                x, y = a[k], b[k]
+                if x.shape != y.shape or x.dtype != y.dtype:
+                    print(f"  {f.name}[{k}]: {x.dtype}{x.shape} vs {y.dtype}{y.shape}")
+                    bad += 1
+                elif x.dtype.kind in "fc":
+                    d = float(np.max(np.abs(x.astype(np.float64) - y.astype(np.float64)))) if x.size else 0.0
+                    worst = max(worst, d)
+                    if d != 0.0:
+                        print(f"  {f.name}[{k}]: max abs diff {d:.3e}")
+                        bad += 1
+                elif not np.array_equal(x, y):
+                    print(f"  {f.name}[{k}]: integer / string arrays differ")
+                    bad += 1
+            print(f"  {f.name}: {'identical' if worst == 0.0 else 'DIFFERS'} ({len(a.files)} arrays)")
+        missing = sorted(p.name for p in committed.glob("*.npz") if not (Path(tmp) / p.name).exists())
+        for n in missing:
+            print(f"  {n}: committed but no longer generated")
+        bad += len(missing)
+    print("fixtures reproduce bit for bit" if bad == 0 else f"{bad} mismatches")
+    return 1 if bad else 0
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -526,4 +582,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(check())
     main()
