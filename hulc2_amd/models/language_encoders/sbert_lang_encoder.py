@@ -7,10 +7,14 @@ BertModel (3 layers, hidden 384, 12 heads, GELU, LayerNorm eps 1e-12) + mean Poo
   -> hulc_gemm -> hulc_ln_wide_fwd] -> hulc_masked_mean_fwd,
 frozen and inference-only as in the reference (`freeze_backbone=True`).
 
-What is NOT here: the trained checkpoint and the WordPiece vocabulary (no network in the build image).  `load_bert_state_dict` takes a
-transformers BertModel state_dict (sentence_transformers' `0.auto_model.` prefix is stripped); `encode` takes sentences only when a
-tokenizer callable was given, `encode_tokens` takes token ids + attention mask directly.  Parity is pinned on the arithmetic
-(tests/golden/minilm.npz from transformers' own BertModel with seeded weights), not on the checkpoint."""
+`encode(list[str])` tokenises inside the module like the reference (sbert_lang_encoder.py:38-62: length-sort, tokenize, forward, un-sort)
+with the WordPiece tokenizer of wordpiece.py (token ids bit-exact against transformers' BertTokenizer, tests/golden/wordpiece.npz).
+
+What is NOT here: the trained checkpoint and its vocab.txt (no network in the build image).  They are read from a checkpoint directory —
+`nlp_model` given as a path, $HULC2_SBERT_DIR, or the local sentence-transformers / huggingface cache — never downloaded; without one the
+weights stay zero until `load_bert_state_dict` (a transformers BertModel state_dict, sentence_transformers' `0.auto_model.` prefix
+stripped) and `encode` needs `tokenizer=`.  Parity is pinned on the arithmetic (tests/golden/minilm.npz from transformers' own BertModel
+with seeded weights) and on the token ids, not on the checkpoint."""
 from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
@@ -18,7 +22,10 @@ from typing import Callable, Dict, List, Optional
 import torch
 from torch import nn
 
+import numpy as np
+
 from ... import kernels as kn
+from .wordpiece import WordPieceTokenizer, find_checkpoint_dir
 
 
 class SBertLang(nn.Module):
@@ -27,7 +34,9 @@ class SBertLang(nn.Module):
     def __init__(self, nlp_model: str = "paraphrase-MiniLM-L3-v2", freeze_backbone: bool = True,
                  tokenizer: Optional[Callable[[List[str]], Dict[str, torch.Tensor]]] = None) -> None:
         super().__init__()
-        if nlp_model != "paraphrase-MiniLM-L3-v2":
+        import os
+        ckpt_dir = find_checkpoint_dir(nlp_model)
+        if os.path.basename(os.path.normpath(nlp_model)).replace("sentence-transformers_", "") != "paraphrase-MiniLM-L3-v2":
             raise NotImplementedError(f"{nlp_model}: only paraphrase-MiniLM-L3-v2 (conf/model/language_encoder/sbert.yaml) is built")
         if not freeze_backbone:
             raise NotImplementedError("the sentence encoder is inference-only (the reference trains with freeze_backbone=True)")
@@ -42,6 +51,25 @@ class SBertLang(nn.Module):
                 setattr(self, f"l{l}_{name}", z(*shape))
         self.text_fc = nn.Linear(D, 1024)
         self._w16: Dict[str, torch.Tensor] = {}
+        self.checkpoint_dir = ckpt_dir
+        if ckpt_dir is not None:
+            self.load_checkpoint_dir(ckpt_dir)
+
+    def load_checkpoint_dir(self, root: str) -> None:
+        """a sentence-transformers checkpoint directory: vocab.txt -> the tokenizer (unless one was injected), model.safetensors /
+        pytorch_model.bin (top level or 0_Transformer/) -> the BertModel weights"""
+        import os
+        if self.tokenizer is None:
+            self.tokenizer = WordPieceTokenizer.from_checkpoint_dir(root, max_length=128)
+        for sub in ("", "0_Transformer"):
+            st, pt = os.path.join(root, sub, "model.safetensors"), os.path.join(root, sub, "pytorch_model.bin")
+            if os.path.isfile(st):
+                from safetensors.torch import load_file
+                self.load_bert_state_dict(load_file(st))
+                return
+            if os.path.isfile(pt):
+                self.load_bert_state_dict(torch.load(pt, map_location="cpu", weights_only=True))
+                return
 
     # ---- weights ---------------------------------------------------------------------------------------------------------
     def load_bert_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
@@ -98,12 +126,17 @@ class SBertLang(nn.Module):
         return kn.masked_mean_fwd(x, mask, B, S, D, f(B, D))
 
     def encode(self, sentences: List[str], normalize_embeddings: bool = False) -> torch.Tensor:
+        """sbert_lang_encoder.py:31-62: sort by text length (longest first), tokenize, forward, undo the sort, stack"""
         if self.tokenizer is None:
-            raise NotImplementedError("no tokenizer: the WordPiece vocabulary of paraphrase-MiniLM-L3-v2 is not shipped; pass "
+            raise NotImplementedError("no tokenizer: vocab.txt of paraphrase-MiniLM-L3-v2 is not shipped and no checkpoint directory was found "
+                                      "(nlp_model=<dir>, $HULC2_SBERT_DIR, or the local sentence-transformers cache); pass "
                                       "tokenizer=callable(sentences) -> {'input_ids', 'attention_mask'} or call encode_tokens()")
-        feats = self.tokenizer(sentences)
+        order = np.argsort([-len(sen) for sen in sentences])                 # SentenceTransformer._text_length of a str = len(str)
+        feats = self.tokenizer([sentences[i] for i in order])
         emb = self.encode_tokens(feats["input_ids"], feats["attention_mask"])
-        return torch.nn.functional.normalize(emb, p=2, dim=1) if normalize_embeddings else emb
+        if normalize_embeddings:
+            emb = torch.nn.functional.normalize(emb, p=2, dim=1)
+        return emb[torch.as_tensor(np.argsort(order), device=emb.device)]
 
     def forward(self, x: List[str]) -> torch.Tensor:
         return self.encode(x)

@@ -447,6 +447,56 @@ def gen_minilm():
          sentence_embedding=emb, ck=np.array(ck), cv=np.array(cv), transformers_version=__import__("transformers").__version__)
 
 
+WORDPIECE_SENTENCES = [
+    "push the red block to the left", "Lift the BLUE block from the sliding cabinet!", "turn on the led light", "open the drawer, then close it.",
+    "  rotate   the pink block\t90 degrees\nto the right  ", "don't stack: un-stack the blocks (carefully)...", "café déjà-vu naïve ÅNGSTRÖM İstanbul",
+    "grasp 3 blocks & 12 lightbulbs @ 100% speed", "", "   ", "supercalifragilisticexpialidocious" * 4, "move\u00a0the\u2003slider\u200b left\x00\x07 now",
+    "推 the 红色 block 左", "the robot 🤖 pushes ☃ blocks", "place [SEP] the block [MASK] in [CLS] the [UNK] drawer [PAD]", "e\u0301clair and e\u0301\u0323x",
+    "unaffordable unpushable blockishness", "slide_the-door/left\\right|now", "«quoted» “text” — dash… ¿qué?", "ß ǅ ﬁ ﬀ", "\ufffdbroken\ufffd",
+    " ".join(["pick up the block and put it in the drawer"] * 20), "x" * 100, "y" * 101, "a.b.c.d", "Lift\rthe\x0bblock\x0cnow\x85ok",
+]
+
+
+def wordpiece_vocab():
+    """a small synthetic BERT-style vocabulary (the real vocab.txt is a download): specials at the ids bert-base-uncased uses relative to
+    each other, single characters, their continuation forms, CALVIN-annotation words and a handful of sub-word pieces"""
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(5)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    chars = list("abcdefghijklmnopqrstuvwxyz0123456789") + list("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~") + ["推", "红", "色", "«", "»", "—", "…", "¿", "ß", "“", "”"]
+    toks += chars + ["##" + c for c in chars if c.isalnum()]
+    words = ("the a to of and in it on off up then now from left right push pull lift turn open close rotate slide place grasp move stack "
+             "pick put red blue pink block blocks drawer cabinet slider sliding led light lightbulb lightbulbs door robot degrees speed "
+             "carefully text quoted dash que cafe deja vu naive angstrom istanbul eclair ex broken ok un don t").split()
+    toks += words
+    toks += ["##s", "##es", "##ing", "##ed", "##ly", "##able", "##ness", "##ish", "##stack", "##push", "##afford", "##bulb", "##bulbs", "##light",
+             "super", "##cali", "##fragilistic", "##expiali", "##docious", "block##", "##00", "10", "12", "90", "100", "ss", "fi", "ff", "dz", "##z"]
+    seen, out = set(), []
+    for t in toks:
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    return out
+
+
+def gen_wordpiece():
+    """row a8 / f-3, tokenizer half: token ids of transformers' own BertTokenizer (the class sentence-transformers' Transformer.tokenize drives,
+    sbert_lang_encoder.py:45) on a synthetic vocabulary — padding=True, truncation='longest_first', max_length=128, sentences stripped first"""
+    from transformers import BertTokenizer
+    vocab = wordpiece_vocab()
+    OUT.mkdir(parents=True, exist_ok=True)
+    (OUT / "wordpiece_vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    tok = BertTokenizer(vocab={t: i for i, t in enumerate(vocab)}, do_lower_case=True)
+    sents = [s.strip() for s in WORDPIECE_SENTENCES]
+    enc = tok(sents, padding=True, truncation="longest_first", return_tensors="np", max_length=128)
+    save("wordpiece", sentences=np.array(WORDPIECE_SENTENCES), input_ids=enc["input_ids"].astype(np.int64),
+         attention_mask=enc["attention_mask"].astype(np.int64), token_type_ids=enc["token_type_ids"].astype(np.int64),
+         transformers_version=transformers_version())
+
+
+def transformers_version():
+    import transformers
+    return transformers.__version__
+
+
 def gen_inference(m, dist, flat):
     """validation / rollout pieces: decoder forward with a carried hidden state, LogisticDecoderRNN._sample
     and loss_and_act with the torch.rand draws recorded, and the lmp_val composition of hulc2.py:247-334 on the leaf modules."""
@@ -559,6 +609,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "minilm":          # only the f-3 fixture (needs transformers, not the reference)
         gen_minilm()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "wordpiece":       # only the tokenizer fixture (needs transformers, not the reference)
+        gen_wordpiece()
+        return
     R = import_reference()
     m, dist, flat = build_reference_modules(R, SEED)
     print("reference leaf modules imported from", REF)
@@ -579,6 +632,7 @@ def main():
     gen_inference(m, dist, flat)
     gen_transforms()
     gen_minilm()
+    gen_wordpiece()
 
 
 if __name__ == "__main__":

@@ -72,3 +72,35 @@ def test_pieces_against_the_oracle(dev):
     out = enc2(["a", "b"])
     assert tuple(out.shape) == (2, 384)
     assert tuple(enc2.encode_text(["a", "b"])[0].shape) == (2, 1024)
+
+
+def test_encode_sentences_from_a_checkpoint_directory(dev, tmp_path):
+    """`model/language_encoder=sbert` as shipped: SBertLang(nlp_model) finds vocab.txt + model.safetensors in a checkpoint directory,
+    `encode(list[str])` tokenises inside the module (length sort -> WordPiece -> forward -> un-sort, sbert_lang_encoder.py:38-62) and
+    equals the oracle on the token ids transformers' BertTokenizer produced for the same sentences (tests/golden/wordpiece.npz)."""
+    import numpy as np
+    from safetensors.torch import save_file
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.models.language_encoders import SBertLang
+
+    G = ROOT / "tests" / "golden"
+    fx = np.load(G / "wordpiece.npz", allow_pickle=False)
+    sents = [str(s) for s in fx["sentences"]]
+    root = tmp_path / "paraphrase-MiniLM-L3-v2"
+    root.mkdir()
+    (root / "vocab.txt").write_text((G / "wordpiece_vocab.txt").read_text())
+    sd = _bert_sd(9)
+    save_file({("0.auto_model." + k): v.contiguous() for k, v in sd.items()}, str(root / "model.safetensors"))
+    kn.set_compute("fp32")
+    try:
+        enc = SBertLang(nlp_model=str(root)).to(dev)
+        emb = enc(sents).cpu()                                                     # forward(list[str]) == encode
+        ids, mask = torch.tensor(fx["input_ids"]), torch.tensor(fx["attention_mask"])
+        want = O.minilm_sentence_embedding(sd, ids, mask)
+        assert tuple(emb.shape) == (len(sents), 384)
+        # row i of the output belongs to sentence i (the length sort is undone); padding to the batch maximum does not change a row
+        assert (emb - want).abs().max().item() < 2e-4 * want.abs().max().item()
+        one = enc([sents[3]]).cpu()
+        assert (one[0] - want[3]).abs().max().item() < 2e-4 * want.abs().max().item()
+    finally:
+        kn.set_compute("bf16")
