@@ -324,7 +324,7 @@ static int ffn_check(int T, int Dm, int FF, const char* who) {
 // see include/hulc2_amd.h
 extern "C" int hulc_ffn_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int Dm, int FF, float drop_p,
                             unsigned long long seed, const unsigned long long* seed_dev, float* f, void* ws, void* stream) {
-    if (!x || !W1 || !b1 || !W2 || !b2 || !f || !ws) return hulc_fail(-1, "hulc_ffn_fwd: null pointer");
+    if (!x || !W1 || !b1 || !W2 || !b2 || !ws) return hulc_fail(-1, "hulc_ffn_fwd: null pointer");
     if (int rc = ffn_check(T, Dm, FF, "hulc_ffn_fwd: needs d_model 128 and dim_feedforward a multiple of 128")) return rc;
     FfnP p = {};
     p.x = x; p.W1 = (const uint16_t*)W1; p.W2 = (const uint16_t*)W2; p.b1 = b1; p.b2 = b2; p.T = T; p.FF = FF;
@@ -332,14 +332,14 @@ extern "C" int hulc_ffn_fwd(const float* x, const void* W1, const float* b1, con
     hipStream_t s = (hipStream_t)stream;
     ffn_fwd_kernel<<<dim3((T + TT - 1) / TT, FF / HS), 512, 0, s>>>(p);
     const long n = (long)T * D;
-    ffn_slice_sum_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(p.f_slab, f, FF / HS, n, 0);
+    if (f) ffn_slice_sum_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(p.f_slab, f, FF / HS, n, 0);
     return hulc_check_launch("hulc_ffn_fwd");
 }
 
 extern "C" int hulc_ffn_bwd(const float* x, const float* df, const void* W1, const float* b1, const void* W1T, const void* W2T, int T, int Dm, int FF,
                             float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx, int dx_accumulate,
                             float* dW1, float* db1, float* dW2, int accumulate_params, void* ws, void* stream) {
-    if (!x || !df || !W1 || !b1 || !W1T || !W2T || !dx || !dW1 || !db1 || !dW2 || !ws) return hulc_fail(-1, "hulc_ffn_bwd: null pointer");
+    if (!x || !df || !W1 || !b1 || !W1T || !W2T || !dW1 || !db1 || !dW2 || !ws) return hulc_fail(-1, "hulc_ffn_bwd: null pointer");
     if (int rc = ffn_check(T, Dm, FF, "hulc_ffn_bwd: needs d_model 128 and dim_feedforward a multiple of 128")) return rc;
     const int ns = FF / HS, G = ffn_groups(T), ntiles = (T + TT - 1) / TT;
     FfnP p = {};
@@ -359,7 +359,7 @@ extern "C" int hulc_ffn_bwd(const float* x, const float* df, const void* W1, con
     }
     ffn_bwd_kernel<<<dim3(G, ns), 512, lds, s>>>(p, ntiles);
     const long n = (long)T * D;
-    ffn_slice_sum_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(p.dx_slab, dx, ns, n, dx_accumulate);
+    if (dx) ffn_slice_sum_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(p.dx_slab, dx, ns, n, dx_accumulate);
     const long nr = 2L * FF * D + FF;
     ffn_wgrad_reduce_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, s>>>(p, G, dW1, dW2, db1, accumulate_params);
     return hulc_check_launch("hulc_ffn_bwd");

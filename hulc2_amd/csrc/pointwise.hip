@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int R, int D,
                                                             float* __restrict__ pre_out, float* __restrict__ y,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int n_o = 1, long o_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             float t = x[i];
             if (o) {
                 float ov = o[i];
+                for (int sl = 1; sl < n_o; ++sl) ov += o[(long)sl * o_stride + i];     // o given as partial slabs (fused feed-forward slices), fixed order
                 if (drop_p > 0.f) ov *= dropout_scale(seed, (uint64_t)i, drop_p);
                 t += ov;
             }
@@ -693,6 +695,16 @@ extern "C" int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, 
     return hulc_check_launch("hulc_layernorm_fwd");
 }
 
+extern "C" int hulc_layernorm_slab_fwd(const float* x, const float* o, int n_o, long o_stride, float drop_p, unsigned long long seed,
+                                       const unsigned long long* seed_dev, const float* gamma, const float* beta, float eps, int R, int D,
+                                       float* pre_out, float* y, float* mean, float* rstd, void* stream) {
+    if (!x || !o || !gamma || !beta || !y || !mean || !rstd || !pre_out) return hulc_fail(-1, "hulc_layernorm_slab_fwd: null pointer");
+    if (D > 256 || D <= 0 || n_o < 1) return hulc_fail(-2, "hulc_layernorm_slab_fwd: D must be in 1..256, n_o >= 1");
+    layernorm_fwd_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, o, drop_p, seed, seed_dev, gamma, beta, eps, R, D, pre_out, y, mean, rstd,
+                                                                        n_o, o_stride);
+    return hulc_check_launch("hulc_layernorm_slab_fwd");
+}
+
 // rows per workgroup: ~256 workgroups (one per CU) once there are enough rows, never fewer than 4 rows (one per wave)
 static int ln_bwd_rows_per_block(int R) { const int r = (R + 255) / 256; return r < 4 ? 4 : r; }
 extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
@@ -711,6 +723,14 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
     reduce_rows_wide_kernel<<<dim3((D + 63) / 64, 2), 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params, (long)D, dbeta);
     return hulc_check_launch("hulc_layernorm_bwd");
+}
+
+// partial (P, 2, D) rows of [dgamma | dbeta] partial sums (hulc_txl_attn_bwd's ln_partial) -> dgamma, dbeta; fixed summation order
+extern "C" int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, float* dbeta, int accumulate, void* stream) {
+    if (!partial || !dgamma || !dbeta) return hulc_fail(-1, "hulc_ln_partial_reduce: null pointer");
+    if (P < 1 || D < 1) return hulc_fail(-2, "hulc_ln_partial_reduce: bad geometry");
+    reduce_rows_wide_kernel<<<dim3((D + 63) / 64, 2), 1024, 0, (hipStream_t)stream>>>(partial, dgamma, P, D, 2 * D, accumulate, (long)D, dbeta);
+    return hulc_check_launch("hulc_ln_partial_reduce");
 }
 
 static long colsum_row_blocks(long M, int N) {

@@ -452,6 +452,91 @@ class FFNFn(torch.autograd.Function):
         return (dx.reshape(shape), *g, None, None)
 
 
+def _sink_or_new(param, shape, like):
+    """-> (tensor the kernels write, accumulate flag, None-or-tensor to hand back to autograd)"""
+    sk = gradsink.get(param)
+    if sk is None:
+        t = _f32(*shape, like=like)
+        return t, False, t
+    return sk.view(*shape), not gradsink.first_write(param), None
+
+
+class TxlLayerFn(torch.autograd.Function):
+    """One post-norm nn.TransformerEncoderLayer (plan_recognition_net.py:115-117) on tokens x (B*S, 128), bf16 compute, as
+         forward : hulc_txl_attn_fwd (in_proj + MFMA attention + out_proj + residual + dropout + LayerNorm1, one workgroup per sequence)
+                   -> hulc_ffn_fwd (hidden-slice partials) -> hulc_layernorm_slab_fwd (slice sum + residual + dropout + LayerNorm2)
+         backward: hulc_layernorm_bwd -> hulc_ffn_bwd (dx left as slice partials) -> hulc_txl_attn_bwd (sums them, LayerNorm1 backward,
+                   attention / projection data gradients) -> two weight-gradient GEMMs over all tokens + the small reductions.
+    Autograd sees one node per layer: no gradient fan-in adds, no intermediate tensors between the kernels."""
+
+    NP = 12
+
+    @staticmethod
+    def forward(ctx, x, B: int, S: int, H: int, drop_p: float, seed: int, w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2):
+        x2 = _c(x.reshape(B * S, x.shape[-1]))
+        T, E = x2.shape
+        FF = w1.shape[0]
+        keep = torch.is_grad_enabled()
+        y1 = _f32(T, E, like=x2)
+        pre1, mean1, rstd1 = (_f32(T, E, like=x2), _f32(T, like=x2), _f32(T, like=x2)) if keep else (None, None, None)
+        ctxb = torch.empty(T, E, dtype=torch.bfloat16, device=x2.device) if keep else None
+        kn.txl_attn_fwd(x2, weight_operand(w_in), b_in, weight_operand(w_out), b_out, g1, be1, 1e-5, B, S, H, drop_p, seed + 11, seed + 12,
+                        y1, pre1, mean1, rstd1, ctxb)
+        ws = kn.ffn_fwd(y1, weight_operand(w1), b1, weight_operand(w2), b2, T, E, FF, drop_p, seed + 13, None)
+        y2, pre2, mean2, rstd2 = _f32(T, E, like=x2), _f32(T, E, like=x2), _f32(T, like=x2), _f32(T, like=x2)
+        kn.layernorm_slab_fwd(y1, ws, FF // 128, T * E, drop_p, seed + 15, g2, be2, 1e-5, T, E, pre2, y2, mean2, rstd2)
+        if keep:
+            ctx.save_for_backward(x2, y1, pre1, mean1, rstd1, ctxb, pre2, mean2, rstd2, w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2)
+            ctx.meta = (B, S, H, drop_p, seed, x.shape)
+        return y2.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, y1, pre1, mean1, rstd1, ctxb, pre2, mean2, rstd2, w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2) = ctx.saved_tensors
+        B, S, H, drop_p, seed, xshape = ctx.meta
+        T, E = x2.shape
+        FF = w1.shape[0]
+        dy2 = _c(dy.reshape(T, E))
+        like = dy2
+        outs = {}
+
+        def sink(name, param, shape):
+            t, acc, ret = _sink_or_new(param, shape, like)
+            outs[name] = ret
+            return t, acc
+        # LayerNorm2 backward: dpre2 = gradient of y1 through the residual, df = gradient of the feed-forward output
+        dpre2 = _f32(T, E, like=like)
+        df = _f32(T, E, like=like) if drop_p > 0 else dpre2
+        (dg2, a1), (db2n, a2) = sink("g2", g2, (E,)), sink("be2", be2, (E,))
+        kn.layernorm_bwd(dy2, pre2, mean2, rstd2, g2, T, E, dpre2, df if drop_p > 0 else None, drop_p, seed + 15, dg2, db2n, accumulate_params=a1 or a2)
+        # feed-forward backward: weight gradients complete, input gradient left as FF / 128 slice partials
+        (dW1, c1), (db1, c2), (dW2, c3), (db2, c4) = sink("w1", w1, (FF, E)), sink("b1", b1, (FF,)), sink("w2", w2, (E, FF)), sink("b2", b2, (E,))
+        ws = kn.ffn_bwd(y1, df, weight_operand(w1), b1, weight_operand(w1, "t"), weight_operand(w2, "t"), T, E, FF, drop_p, seed + 13, None, dW1, db1,
+                        dW2, accumulate_params=c1 or c2 or c3)
+        kn.colsum(df, T, E, E, db2, accumulate=c4)
+        # attention half backward
+        dx = _f32(T, E, like=like)
+        d_o = torch.empty(T, E, dtype=torch.bfloat16, device=like.device)
+        dqkv = torch.empty(T, 3 * E, dtype=torch.bfloat16, device=like.device)
+        lnp = _f32(B, 2, E, like=like)
+        kn.txl_attn_bwd(x2, weight_operand(w_in), weight_operand(w_in, "t"), weight_operand(w_out, "t"), b_in, g1, 1e-5, B, S, H, drop_p, seed + 11,
+                        seed + 12, pre1, mean1, rstd1, dpre2, ws, FF // 128, T * E, dx, d_o, dqkv, lnp)
+        (dg1, e1), (db1n, e2) = sink("g1", g1, (E,)), sink("be1", be1, (E,))
+        kn.ln_partial_reduce(lnp, B, E, dg1, db1n, accumulate=e1 or e2)
+        # weight gradients of the two projections over all tokens; the row sums of the left operand are the bias gradients
+        (dWin, f1), (dbin, f2) = sink("w_in", w_in, (3 * E, E)), sink("b_in", b_in, (3 * E,))
+        kn.gemm(dqkv, x2, dWin, 3 * E, E, T, 3 * E, E, E, a_kmajor=False, b_kmajor=False, accumulate=f1, rowsum=dbin, rowsum_accumulate=f2)
+        (dWo, h1), (dbo, h2) = sink("w_out", w_out, (E, E)), sink("b_out", b_out, (E,))
+        kn.gemm(d_o, ctxb, dWo, E, E, T, E, E, E, a_kmajor=False, b_kmajor=False, accumulate=h1, rowsum=dbo, rowsum_accumulate=h2)
+        g = [outs[k] for k in ("w_in", "b_in", "w_out", "b_out", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2")]
+        return (dx.reshape(xshape), None, None, None, None, None, *g)
+
+
+def _txl_fused_ok(x, p: dict, S: int, nhead: int) -> bool:
+    return (kn.get_compute() == "bf16" and x.shape[-1] == 128 and nhead == 8 and 1 <= S <= 32 and p["linear1.weight"].shape[0] % 128 == 0
+            and x.dtype == torch.float32 and not os.environ.get("HULC_NO_FUSED_TXL") and not os.environ.get("HULC_NO_FUSED_FFN"))
+
+
 def _ffn_fused_ok(x, W1) -> bool:
     return (kn.get_compute() == "bf16" and x.shape[-1] == 128 and W1.shape[0] % 128 == 0 and x.dtype == torch.float32
             and not os.environ.get("HULC_NO_FUSED_FFN"))
@@ -459,6 +544,10 @@ def _ffn_fused_ok(x, W1) -> bool:
 
 def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: float, seed: int):
     """Post-norm nn.TransformerEncoderLayer (ReLU, eps 1e-5) on tokens x (B*S, E) — plan_recognition_net.py:115-117."""
+    if _txl_fused_ok(x, p, S, nhead):
+        return TxlLayerFn.apply(x, B, S, nhead, float(drop_p), int(seed), p["in_proj_weight"], p["in_proj_bias"], p["out_proj.weight"],
+                                p["out_proj.bias"], p["linear1.weight"], p["linear1.bias"], p["linear2.weight"], p["linear2.bias"],
+                                p["norm1.weight"], p["norm1.bias"], p["norm2.weight"], p["norm2.bias"])
     qkv = mlp(x, [(p["in_proj_weight"], p["in_proj_bias"], False)])
     att = AttentionFn.apply(qkv, B, S, nhead, drop_p, seed + 11)
     o = mlp(att, [(p["out_proj.weight"], p["out_proj.bias"], False)])

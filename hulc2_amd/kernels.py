@@ -515,17 +515,76 @@ def _ffn_ws(T, FF, device):
 
 
 def ffn_fwd(x, W1, b1, W2, b2, T, D, FF, drop_p, seed, f):
-    """fused transformer feed-forward block (csrc/ffn_fused.hip); W1 / W2 bf16"""
+    """fused transformer feed-forward block (csrc/ffn_fused.hip); W1 / W2 bf16.  f = None: the FF / 128 hidden-slice partials are left
+    unsummed in the returned workspace ((FF / 128, T, 128) fp32 at its start) for a consumer that sums them (layernorm_slab_fwd)."""
     fl = 2.0 * 2 * T * D * FF
-    _call("hulc_ffn_fwd", x, W1, b1, W2, b2, _i(T), _i(D), _i(FF), _f(drop_p), _u64(seed), _sd(x, drop_p), f, _ffn_ws(T, FF, x.device),
+    ws = _ffn_ws(T, FF, x.device)
+    _call("hulc_ffn_fwd", x, W1, b1, W2, b2, _i(T), _i(D), _i(FF), _f(drop_p), _u64(seed), _sd(x, drop_p), f, ws,
           key=("ffn_fwd", T, D, FF), flops=fl, nbytes=_nbytes(x, W1, W2, f))
+    return ws
 
 
 def ffn_bwd(x, df, W1, b1, W1T, W2T, T, D, FF, drop_p, seed, dx, dW1, db1, dW2, accumulate_params=False, dx_accumulate=False):
     fl = 2.0 * 5 * T * D * FF                                  # recompute + two data-gradient + two weight-gradient products
+    ws = _ffn_ws(T, FF, x.device)                              # dx = None: the slice partials of dx stay at the start of ws
     _call("hulc_ffn_bwd", x, df, W1, b1, W1T, W2T, _i(T), _i(D), _i(FF), _f(drop_p), _u64(seed), _sd(x, drop_p), dx, _i(dx_accumulate),
-          dW1, db1, dW2, _i(accumulate_params), _ffn_ws(T, FF, x.device),
+          dW1, db1, dW2, _i(accumulate_params), ws,
           key=("ffn_bwd", T, D, FF), flops=fl, nbytes=_nbytes(x, df, W1, W1T, W2T, dx, dW1, dW2))
+    return ws
+
+
+def layernorm_slab_fwd(x, o_slabs, n_o, o_stride, drop_p, seed, gamma, beta, eps, R, D, pre_out, y, mean, rstd):
+    """y = LayerNorm(x + dropout(sum of the n_o partial slabs)) — slice sum + residual + norm in one launch"""
+    _call("hulc_layernorm_slab_fwd", x, o_slabs, _i(n_o), _l(o_stride), _f(drop_p), _u64(seed), _sd(x, drop_p), gamma, beta, _f(eps), _i(R), _i(D),
+          pre_out, y, mean, rstd)
+
+
+def ln_partial_reduce(partial, P, D, dgamma, dbeta, accumulate=False):
+    """partial (P, 2, D): rows of [dgamma | dbeta] partial sums -> the two parameter gradients, fixed order, one launch"""
+    _call("hulc_ln_partial_reduce", partial, _i(P), _i(D), dgamma, dbeta, _i(accumulate))
+
+
+def _txl_desc(x, Wqkv, bqkv, gamma, B, S, H, drop_p, seed_attn, seed_ln, eps):
+    d = _L.TxlAttnDesc()
+    _require_cuda(x, Wqkv, bqkv, gamma)
+    d.x, d.Wqkv, d.bqkv, d.gamma = x.data_ptr(), Wqkv.data_ptr(), bqkv.data_ptr(), gamma.data_ptr()
+    d.eps, d.B, d.S, d.H, d.E = float(eps), int(B), int(S), int(H), int(x.shape[-1])
+    d.drop_p, d.seed_attn, d.seed_ln = float(drop_p), int(seed_attn) & 0xFFFFFFFFFFFFFFFF, int(seed_ln) & 0xFFFFFFFFFFFFFFFF
+    d.seed_dev = step_state(x.device).data_ptr() if drop_p > 0.0 else None
+    return d
+
+
+def txl_attn_fwd(x, Wqkv, bqkv, Wo, bo, gamma, beta, eps, B, S, H, drop_p, seed_attn, seed_ln, y, pre=None, mean=None, rstd=None, ctx=None):
+    """attention half of the post-norm transformer layer, one launch (csrc/txl_fused.hip); Wqkv / Wo bf16"""
+    for t in (Wqkv, Wo):
+        if t.dtype != torch.bfloat16:
+            raise _L.HulcKernelError("txl_attn_fwd: weights are the bf16 shadows (bf16 compute mode)")
+    _require_contiguous(x=x, Wqkv=Wqkv, Wo=Wo, y=y)
+    _require_cuda(Wo, bo, beta, y, pre, mean, rstd, ctx)
+    d = _txl_desc(x, Wqkv, bqkv, gamma, B, S, H, drop_p, seed_attn, seed_ln, eps)
+    d.Wo, d.bo, d.beta, d.y = Wo.data_ptr(), bo.data_ptr(), beta.data_ptr(), y.data_ptr()
+    d.pre, d.mean, d.rstd = [t.data_ptr() if t is not None else None for t in (pre, mean, rstd)]
+    d.ctx = ctx.data_ptr() if ctx is not None else None
+    T, E = B * S, x.shape[-1]
+    fl = 2.0 * T * E * 4 * E + 2.0 * 2 * B * H * S * S * (E // H)
+    _call("hulc_txl_attn_fwd", _c.byref(d), key=("txl_attn_fwd", B, S), flops=fl, nbytes=_nbytes(x, Wqkv, Wo, y, pre, ctx))
+
+
+def txl_attn_bwd(x, Wqkv, WqkvT, WoT, bqkv, gamma, eps, B, S, H, drop_p, seed_attn, seed_ln, pre, mean, rstd, dy, dy_slab, n_slab,
+                 slab_stride, dx, d_o, dqkv, ln_partial):
+    for t in (Wqkv, WqkvT, WoT):
+        if t.dtype != torch.bfloat16:
+            raise _L.HulcKernelError("txl_attn_bwd: weights are the bf16 shadows (bf16 compute mode)")
+    _require_contiguous(x=x, Wqkv=Wqkv, WqkvT=WqkvT, WoT=WoT, dy=dy, dx=dx, d_o=d_o, dqkv=dqkv, pre=pre)
+    _require_cuda(WqkvT, WoT, pre, mean, rstd, dy, dy_slab, dx, d_o, dqkv, ln_partial)
+    d = _txl_desc(x, Wqkv, bqkv, gamma, B, S, H, drop_p, seed_attn, seed_ln, eps)
+    d.WqkvT, d.WoT = WqkvT.data_ptr(), WoT.data_ptr()
+    d.pre, d.mean, d.rstd, d.dy = pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr()
+    d.dy_slab, d.n_slab, d.slab_stride = (dy_slab.data_ptr() if dy_slab is not None else None), int(n_slab), int(slab_stride)
+    d.dx, d.d_o, d.dqkv, d.ln_partial = dx.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(), ln_partial.data_ptr()
+    T, E = B * S, x.shape[-1]
+    fl = 2.0 * T * E * (2 * E + 5 * E + 3 * E) + 2.0 * 10 * B * H * S * S * (E // H)
+    _call("hulc_txl_attn_bwd", _c.byref(d), key=("txl_attn_bwd", B, S), flops=fl, nbytes=_nbytes(x, Wqkv, WqkvT, WoT, dy, dx, d_o, dqkv, pre))
 
 
 def repack_conv_weights(src_f32, dst_bf16, table):

@@ -102,3 +102,25 @@ class MixDesc(ctypes.Structure):
         ("log_scale_min", ctypes.c_float), ("gripper_alpha", ctypes.c_float),
         ("act_min", ctypes.c_void_p), ("act_max", ctypes.c_void_p),
     ]
+
+
+class TxlAttnDesc(ctypes.Structure):
+    """mirror of hulc_txl_attn_desc (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("Wqkv", ctypes.c_void_p), ("Wo", ctypes.c_void_p), ("WqkvT", ctypes.c_void_p), ("WoT", ctypes.c_void_p),
+        ("bqkv", ctypes.c_void_p), ("bo", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+        ("eps", ctypes.c_float),
+        ("B", ctypes.c_int), ("S", ctypes.c_int), ("H", ctypes.c_int), ("E", ctypes.c_int),
+        ("drop_p", ctypes.c_float),
+        ("seed_attn", ctypes.c_ulonglong), ("seed_ln", ctypes.c_ulonglong),
+        ("seed_dev", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("pre", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+        ("ctx", ctypes.c_void_p),
+        ("dy", ctypes.c_void_p), ("dy_slab", ctypes.c_void_p),
+        ("n_slab", ctypes.c_int),
+        ("slab_stride", ctypes.c_long),
+        ("dx", ctypes.c_void_p),
+        ("d_o", ctypes.c_void_p), ("dqkv", ctypes.c_void_p),
+        ("ln_partial", ctypes.c_void_p),
+    ]

@@ -170,8 +170,19 @@ class GradBuckets:
 
     def finish(self):
         """Flush buckets whose parameters produced no gradient this step, then join the comm stream."""
-        if self.active and not self.overlap:       # graph mode: one in-place all-reduce of the whole arena, same stream
-            self.comm.reduce(0, self.flat_grad.numel())
+        if self.active and not self.overlap:       # graph mode, eager step: one in-place all-reduce of the whole arena
+            # Always on the comm stream, never on the caller's: ProcessGroupNCCL records the work's end event on the stream the collective
+            # runs on, and its watchdog thread keeps querying that event for a while after the work is done.  capture() runs its warm-up
+            # steps on the very stream it captures next — an event of that stream queried during capture is hipErrorCapturedEvent and the
+            # watchdog aborts the process (found by the first RCCL run on hardware, round 2).
+            if self.on_gpu:
+                cur = torch.cuda.current_stream()
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm.reduce(0, self.flat_grad.numel())
+                cur.wait_stream(self.comm_stream)
+            else:
+                self.comm.reduce(0, self.flat_grad.numel())
             return
         if self.active:
             for b in self.buckets:

@@ -107,6 +107,11 @@ int hulc_spatial_softmax_bwd(const void* x, int x_dtype, int N, int HW, int C, c
 int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
                        const float* gamma, const float* beta, float eps, int R, int D, float* pre_out, float* y, float* mean,
                        float* rstd, void* stream);
+/* the same with the residual branch given as n_o partial slabs o[s] (R x D each, o_stride elements apart) summed in order before the
+ * dropout: the hidden-slice partials hulc_ffn_fwd leaves in its workspace (f == NULL) — slice sum + residual + LayerNorm in one launch */
+int hulc_layernorm_slab_fwd(const float* x, const float* o, int n_o, long o_stride, float drop_p, unsigned long long seed,
+                            const unsigned long long* seed_dev, const float* gamma, const float* beta, float eps, int R, int D,
+                            float* pre_out, float* y, float* mean, float* rstd, void* stream);
 long hulc_layernorm_bwd_workspace(int R, int D);
 int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
                        float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
@@ -234,13 +239,50 @@ int hulc_r3m_stem_fwd(const void* xp, const void* w, const float* bias, void* y,
  * x, f, df, dx: (T, 128) fp32; W1 [FF][128], W2 [128][FF] bf16; W1T = W1^T [128][FF], W2T = W2^T [FF][128] bf16.
  * Dropout: counter RNG on (seed ^ *seed_dev, token*FF + unit), the stream hulc_gemm's epilogue uses for the unfused block.
  * bwd: dx (+)= df-path input gradient; dW1 [FF][128], db1 [FF], dW2 [128][FF] (+)= when accumulate_params (db2 = column sums of df:
- * hulc_colsum).  ws: hulc_ffn_workspace(T, FF) bytes. */
+ * hulc_colsum).  ws: hulc_ffn_workspace(T, FF) bytes.  f == NULL (fwd) / dx == NULL (bwd): skip the pass that sums the FF / 128
+ * hidden-slice partials; they stay at the start of ws as [FF / 128][T][128] fp32 (b2 rides in slice 0) for a consumer that sums them
+ * itself (hulc_layernorm_slab_fwd, hulc_txl_attn_bwd). */
 long hulc_ffn_workspace(int T, int FF);
 int hulc_ffn_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int D, int FF, float drop_p,
                  unsigned long long seed, const unsigned long long* seed_dev, float* f, void* ws, void* stream);
 int hulc_ffn_bwd(const float* x, const float* df, const void* W1, const float* b1, const void* W1T, const void* W2T, int T, int D, int FF,
                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx, int dx_accumulate,
                  float* dW1, float* db1, float* dW2, int accumulate_params, void* ws, void* stream);
+
+/* ---- transformer layer, attention half, fused (bf16 compute) ----------------------------------------------- */
+/* y1 = LayerNorm1(x + dropout(out_proj(MHA(x)))) of the post-norm nn.TransformerEncoderLayer behind PlanRecognitionTransformersNetwork
+ * (hulc2/models/plan_encoders/plan_recognition_net.py:108-121; d_model E = 128, H = 8 heads of 16, S <= 32 tokens per sequence) as ONE
+ * launch: workgroup = sequence, wave = 2 heads; in_proj, QK^T (one 32x32x16 MFMA per head), softmax + dropout in registers, PV,
+ * out_proj, residual + dropout + LayerNorm.  Rows of x are tokens b*S + s.  Weights bf16: Wqkv [3E][E] (in_proj_weight), Wo [E][E];
+ * the backward also reads their transposes WqkvT [E][3E], WoT [E][E].
+ * fwd : writes y (T, E) fp32 and, when pre != NULL, what backward needs: pre (T, E) fp32 = x + dropout(o), mean / rstd (T), and
+ *       ctx (T, E) bf16 (attention output before out_proj: operand of the out_proj weight gradient).
+ * bwd : dy (T, E) fp32 [+ n_slab partials dy_slab[s] (T, E) fp32, slab_stride elements apart, summed in order: the hidden-slice
+ *       input gradients of hulc_ffn_bwd] -> dx (T, E) fp32 (gradient of x through both the residual and the attention branch),
+ *       d_o (T, E) bf16 and dqkv (T, 3E) bf16 (left operands of the weight-gradient GEMMs dWo = d_o^T ctx, dWqkv = dqkv^T x, whose
+ *       row sums are the bias gradients) and ln_partial (B, 2, E) fp32 = per-sequence {dgamma, dbeta} sums (hulc_colsum finishes them).
+ * Dropout streams are those of hulc_attention_fwd (seed_attn) and hulc_layernorm_fwd (seed_ln): the unfused kernels give the same masks. */
+typedef struct hulc_txl_attn_desc {
+    const float* x;
+    const void *Wqkv, *Wo, *WqkvT, *WoT;
+    const float *bqkv, *bo, *gamma, *beta;
+    float eps;
+    int B, S, H, E;
+    float drop_p;
+    unsigned long long seed_attn, seed_ln;
+    const unsigned long long* seed_dev;
+    float *y, *pre, *mean, *rstd;
+    void* ctx;
+    const float *dy, *dy_slab;
+    int n_slab;
+    long slab_stride;
+    float* dx;
+    void *d_o, *dqkv;
+    float* ln_partial;
+} hulc_txl_attn_desc;
+int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, float* dbeta, int accumulate, void* stream);
+int hulc_txl_attn_fwd(const hulc_txl_attn_desc* d, void* stream);
+int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.

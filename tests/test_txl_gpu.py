@@ -1,0 +1,113 @@
+"""Fused transformer layer (csrc/txl_fused.hip: in_proj + MFMA attention + out_proj + residual + LayerNorm in one launch per direction,
+feed-forward slice sums folded into the neighbouring kernels) against
+  (a) a plain PyTorch fp32 nn.TransformerEncoderLayer — the reference's own layer class (plan_recognition_net.py:115-117) — dropout off,
+  (b) the unfused HIP kernel chain on the same counter-RNG streams, dropout on (identical masks by construction).
+Tolerances are bf16's (the fused kernel rounds q, k, v, P and ctx to bf16 as MFMA operands): stated per assertion."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pytestmark = pytest.mark.gpu
+
+from hulc2_amd import functional as HF, kernels as kn  # noqa: E402
+
+
+def _layer(dev, seed, p_drop):
+    torch.manual_seed(seed)
+    m = torch.nn.TransformerEncoderLayer(128, 8, dim_feedforward=2048, dropout=p_drop)
+    with torch.no_grad():
+        for q in m.parameters():                       # non-trivial biases and LayerNorm parameters
+            if q.dim() == 1:
+                q.add_(torch.randn_like(q) * 0.1)
+    return m
+
+
+def _params(m):
+    return {"in_proj_weight": m.self_attn.in_proj_weight, "in_proj_bias": m.self_attn.in_proj_bias,
+            "out_proj.weight": m.self_attn.out_proj.weight, "out_proj.bias": m.self_attn.out_proj.bias,
+            "linear1.weight": m.linear1.weight, "linear1.bias": m.linear1.bias, "linear2.weight": m.linear2.weight, "linear2.bias": m.linear2.bias,
+            "norm1.weight": m.norm1.weight, "norm1.bias": m.norm1.bias, "norm2.weight": m.norm2.weight, "norm2.bias": m.norm2.bias}
+
+
+def _run(m, x, r, B, S, p_drop, seed, fused):
+    for q in m.parameters():
+        q.grad = None
+    x = x.clone().requires_grad_(True)
+    if fused:
+        os.environ.pop("HULC_NO_FUSED_TXL", None)
+    else:
+        os.environ["HULC_NO_FUSED_TXL"] = "1"
+    try:
+        y = HF.transformer_encoder_layer(x.reshape(B * S, 128), _params(m), B, S, 8, p_drop, seed)
+    finally:
+        os.environ.pop("HULC_NO_FUSED_TXL", None)
+    (y * r.reshape(B * S, 128)).sum().backward()
+    return y.detach().reshape(B, S, 128), x.grad.detach(), {k: v.grad.detach().clone() for k, v in _params(m).items()}
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("B,S", [(5, 32), (3, 16), (2, 7), (64, 32)])
+def test_fused_layer_matches_torch_fp32(dev, B, S):
+    kn.set_compute("bf16")
+    ref = _layer(dev, 1, 0.0)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, S, 128, generator=g)
+    r = torch.randn(B, S, 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr.transpose(0, 1)).transpose(0, 1)                  # the reference runs (S, B, E), batch_first=False
+    (yr * r).sum().backward()
+    want = {k: v.grad.clone() for k, v in _params(ref).items()}
+    m = _layer(dev, 1, 0.0).to(dev)
+    got_y, got_dx, got = _run(m, x.to(dev), r.to(dev), B, S, 0.0, 77, fused=True)
+    unf_y, unf_dx, unf = _run(m, x.to(dev), r.to(dev), B, S, 0.0, 77, fused=False)
+    e_f, e_u = _rel(got_y, yr.detach()), _rel(unf_y, yr.detach())
+    print(f"B={B} S={S} y: fused {e_f:.2e} unfused {e_u:.2e}")
+    assert e_f < 1.5e-2, e_f                                       # relative L2, bf16 operands (measured ~4e-3)
+    e_f, e_u = _rel(got_dx, xr.grad), _rel(unf_dx, xr.grad)
+    print(f"  dx: fused {e_f:.2e} unfused {e_u:.2e}")
+    assert e_f < 3e-2, e_f
+    for k in want:
+        e_f, e_u = _rel(got[k], want[k]), _rel(unf[k], want[k])
+        print(f"  {k}: fused {e_f:.2e} unfused {e_u:.2e}")
+        assert e_f < 4e-2 and e_f < max(3 * e_u, 2e-2), (k, e_f, e_u)
+
+
+@pytest.mark.parametrize("B,S", [(4, 32), (3, 20)])
+def test_fused_layer_matches_unfused_kernels_under_dropout(dev, B, S):
+    """same dropout streams -> same masks: the two HIP paths differ by bf16 rounding only"""
+    kn.set_compute("bf16")
+    kn.reset_step_state(dev)
+    m = _layer(dev, 3, 0.1).to(dev)
+    g = torch.Generator().manual_seed(4)
+    x, r = torch.randn(B, S, 128, generator=g).to(dev), torch.randn(B, S, 128, generator=g).to(dev)
+    fy, fdx, fg = _run(m, x, r, B, S, 0.1, 1234, fused=True)
+    uy, udx, ug = _run(m, x, r, B, S, 0.1, 1234, fused=False)
+    assert _rel(fy, uy) < 1.5e-2 and _rel(fdx, udx) < 3e-2, (_rel(fy, uy), _rel(fdx, udx))
+    for k in fg:
+        assert _rel(fg[k], ug[k]) < 4e-2, (k, _rel(fg[k], ug[k]))
+    fy2, _, _ = _run(m, x, r, B, S, 0.1, 1235, fused=True)      # another site seed: other masks
+    assert not torch.equal(fy, fy2)
+    fy3, fdx3, _ = _run(m, x, r, B, S, 0.1, 1234, fused=True)    # bit-reproducible
+    assert torch.equal(fy, fy3) and torch.equal(fdx, fdx3)
+
+
+def test_padded_rows_do_not_leak(dev):
+    """S < 32: tokens of the NEXT sequence must not influence a sequence (keys >= S are masked, rows >= S never stored)"""
+    kn.set_compute("bf16")
+    m = _layer(dev, 5, 0.0).to(dev)
+    g = torch.Generator().manual_seed(6)
+    x, r = torch.randn(3, 11, 128, generator=g).to(dev), torch.randn(3, 11, 128, generator=g).to(dev)
+    y, dx, _ = _run(m, x, r, 3, 11, 0.0, 9, fused=True)
+    x2 = x.clone()
+    x2[1:] = torch.randn_like(x2[1:])
+    y2, dx2, _ = _run(m, x2, r, 3, 11, 0.0, 9, fused=True)
+    assert torch.equal(y[0], y2[0]) and torch.equal(dx[0], dx2[0])
