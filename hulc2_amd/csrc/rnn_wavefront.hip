@@ -260,6 +260,23 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
     }
 }
 
+// zero the barrier header and the bf16 mirror of the initial state row: a kernel, not hipMemsetAsync, so that a captured hipGraph holds
+// nothing but kernel nodes with plain pointer arguments (a captured hipMemsetAsync node
+// was found to leave the barrier header un-zeroed on later replays once other allocations ran in between: NaN from replay 2 on, round 2;
+// HULC_RNN_MEMSET=1 restores the memset calls to reproduce it)
+__global__ __launch_bounds__(256) void rnn_prep_kernel(uint4* __restrict__ a, long na, uint4* __restrict__ b, long nb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (i < na) a[i] = z;
+    if (i < nb) b[i] = z;
+}
+
+// rows x width bf16 elements at row pitch `pitch` <- 0 (initial-state column block of the transposed mirror)
+__global__ __launch_bounds__(256) void rnn_zero2d_kernel(uint16_t* __restrict__ dst, long pitch, int width, int rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)rows * width) dst[(i / width) * pitch + i % width] = 0;
+}
+
 }  // namespace
 
 extern "C" long hulc_rnn_wavefront_mirror_offset(void) { return RNN_WS_HEADER; }
@@ -292,11 +309,21 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.dbg = getenv("HULC_RNN_DBG") ? atoi(getenv("HULC_RNN_DBG")) : 0;
     p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
     // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs
-    if (hipMemsetAsync(ws, 0, RNN_WS_HEADER, s) != hipSuccess ||
-        hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)   // (exchange region 0 is never read: z_0 = 0 is skipped)
-        return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
-    if (p.zt && hipMemset2DAsync(p.zt + (long)p.zb_row0 * d->B, (size_t)p.ld_t * 2, 0, (size_t)d->B * 2, (size_t)2 * d->H, s) != hipSuccess)
-        return hulc_fail(-9, "hulc_rnn_wavefront: could not zero the initial state of the transposed mirror");
+    static const bool use_memset = getenv("HULC_RNN_MEMSET") != nullptr;
+    if (use_memset) {
+        if (hipMemsetAsync(ws, 0, RNN_WS_HEADER, s) != hipSuccess ||
+            hipMemsetAsync(p.zb + (long)p.zb_row0 * d->B * 2 * d->H, 0, (size_t)d->B * 2 * d->H * 2, s) != hipSuccess)   // (exchange region 0 is never read: z_0 = 0 is skipped)
+            return hulc_fail(-9, "hulc_rnn_wavefront: could not reset the barrier words");
+    } else {
+        if ((uintptr_t)ws % 16 || RNN_WS_HEADER % 16) return hulc_fail(-4, "hulc_rnn_wavefront: workspace must be 16-byte aligned");
+        const long na = RNN_WS_HEADER / 16, nb = (long)d->B * 2 * d->H * 2 / 16;
+        const long n = na > nb ? na : nb;
+        rnn_prep_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((uint4*)ws, na, (uint4*)(p.zb + (long)p.zb_row0 * d->B * 2 * d->H), nb);
+    }
+    if (p.zt) {
+        const long n = 2L * d->H * d->B;
+        rnn_zero2d_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p.zt + (long)p.zb_row0 * d->B, p.ld_t, d->B, 2 * d->H);
+    }
     if (d->tA != d->tB1 || d->tA != d->tB2) return hulc_fail(-3, "hulc_rnn_wavefront: the three weight matrices share one layout (tA == tB1 == tB2)");
     if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
     else rnn_wavefront_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);

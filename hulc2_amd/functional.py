@@ -476,7 +476,7 @@ class TxlLayerFn(torch.autograd.Function):
         x2 = _c(x.reshape(B * S, x.shape[-1]))
         T, E = x2.shape
         FF = w1.shape[0]
-        keep = torch.is_grad_enabled()
+        keep = any(ctx.needs_input_grad)               # (grad mode is off inside Function.forward: ask which inputs want gradients)
         y1 = _f32(T, E, like=x2)
         pre1, mean1, rstd1 = (_f32(T, E, like=x2), _f32(T, like=x2), _f32(T, like=x2)) if keep else (None, None, None)
         ctxb = torch.empty(T, E, dtype=torch.bfloat16, device=x2.device) if keep else None

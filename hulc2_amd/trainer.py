@@ -539,8 +539,8 @@ class ArenaTrainer:
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
         # world > 1: the process group's watchdog thread may touch the runtime while this thread captures; only this thread's calls are policed
-        mode = {"capture_error_mode": "thread_local"} if self.multi else {}
-        if self.multi and self.enc_hi > self.enc_lo:
+        mode = {"capture_error_mode": os.environ.get("HULC_CAPTURE_MODE", "thread_local")} if self.multi else {}
+        if self.multi and self.enc_hi > self.enc_lo and not os.environ.get("HULC_NO_SPLIT_GRAPH"):
             # two graphs around the split point; replay() launches the big all-reduce between them on the comm stream
             with torch.cuda.graph(self.graph_fb, stream=side, **mode):
                 self.static_loss = self._forward_backward_head(batch, 0)

@@ -20,3 +20,16 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _error_budget_context(request):
+    """names the running test for tests/errbudget.py (measured-error bounds per (test, tensor))"""
+    from tests import errbudget
+    errbudget.current = request.node.nodeid.split("tests/")[-1]
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import errbudget
+    errbudget.dump()

@@ -1,0 +1,41 @@
+"""Measured-error budget of the parity tests ("parity of the benchmarked mode, stated as numbers").
+
+Every comparison of the GPU parity tests has a flat tolerance (what the arithmetic type allows) AND a recorded measurement: the error
+this build produced on an MI355X for that exact (test, tensor), committed as tests/golden/error_budget.json.  The assertion bound is
+min(flat tolerance, 1.5 x recorded): a kernel change that doubles an error fails even when the result still sits inside the flat bf16
+bound.  The kernels are bit-reproducible (fixed summation orders), so the recorded values reproduce exactly on the same build.
+
+Recording: HULC_RECORD_ERRORS=1 python -m pytest tests -m gpu   -> gpurun_out/error_budget.json (copy it over the committed file)."""
+import json
+import os
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+FILE = ROOT / "tests" / "golden" / "error_budget.json"
+RECORD = bool(os.environ.get("HULC_RECORD_ERRORS"))
+_loaded = json.loads(FILE.read_text()) if FILE.exists() else {}
+_rec = {}
+current = "?"
+
+
+def limit(what: str, ratio: float, flat: float) -> float:
+    """-> the bound `ratio` (error / scale) must meet for tensor `what` of the running test; records the measurement when asked to"""
+    key = f"{current}::{what}"
+    if RECORD:
+        _rec[key] = max(_rec.get(key, 0.0), float(ratio))
+        return flat
+    got = _loaded.get(key)
+    return flat if got is None else min(flat, 1.5 * got + 1e-7)
+
+
+def measured(what: str):
+    return _loaded.get(f"{current}::{what}")
+
+
+def dump() -> None:
+    if RECORD and _rec:
+        out = ROOT / "gpurun_out" / "error_budget.json"
+        out.parent.mkdir(exist_ok=True)
+        merged = dict(_loaded)
+        merged.update(_rec)
+        out.write_text(json.dumps(dict(sorted(merged.items())), indent=0))

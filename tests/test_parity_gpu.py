@@ -21,6 +21,7 @@ sys.path.insert(0, str(ROOT))
 pytestmark = pytest.mark.gpu
 
 from hulc2_amd import synthetic as syn  # noqa: E402
+from tests import errbudget  # noqa: E402
 from hulc2_amd.compat import instantiate  # noqa: E402
 from hulc2_amd.config import default_model_config  # noqa: E402
 
@@ -41,7 +42,8 @@ def close(a, b, rtol, what):
         err, scale = (a - b).norm().item(), b.norm().item() + 1e-12
     else:                                             # activations / losses: max-abs relative to max-abs
         err, scale = (a - b).abs().max().item(), b.abs().max().item() + 1e-12
-    assert err <= rtol * scale + 1e-6, f"{what}: err {err:.3e} > {rtol:g} * scale {scale:.3e} (ratio {err / scale:.2e})"
+    lim = errbudget.limit(what, err / scale, rtol)     # min(flat tolerance, 1.5 x the error recorded for this (test, tensor))
+    assert err <= lim * scale + 1e-6, f"{what}: err {err:.3e} > {lim:g} * scale {scale:.3e} (ratio {err / scale:.2e}, flat tolerance {rtol:g})"
 
 
 @pytest.fixture(scope="module")
@@ -367,6 +369,71 @@ def test_whole_training_step(dev, model, mode, B, S):
     close(P["perceptual_encoder.rgb_gripper_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_gripper"], max(t["grad"] * 2, 6e-3), "g conv1 gripper")
     close(P["plan_recognition.position_embeddings.weight"].grad, fx["g_pos"], t["grad"] * 2, "g pos")
     close(P["action_decoder.gripper_fc.weight"].grad, fx["g_grip_w"], t["grad"] * 2, "g gripper_fc")
+
+
+def _oracle_batch(raw):
+    ob = {}
+    for m, db in raw.items():
+        ob[m] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
+                     robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+        if m == "lang":
+            ob[m].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
+    return ob
+
+
+@pytest.mark.parametrize("B,S", [(2, 16), (32, 32)])
+def test_benchmarked_config_against_oracle(dev, B, S):
+    """The configuration bench.py measures — gripper_control ON (tcp-frame actions), bf16 compute — at B=2,S=16 and at BASELINE's full size
+    (B=32 per modality, S=32: configs[1]), against the CPU oracle run live on the same seeded batch (dropout off, injected plan indices):
+    the four losses, the perceptual embeddings and the gradient of EVERY parameter (relative L2).  VERDICT r01: the fixture-pinned
+    whole step had gripper_control off, and the full size was only property-checked."""
+    from hulc2_amd import kernels as kn, param_spec
+    from oracle import hulc2_oracle as O
+
+    kn.set_compute("bf16")
+    t = TOL["bf16"]
+    seed = 321
+    m = instantiate(default_model_config(gripper_control=True, dropout_p=0.0)).to(dev)
+    syn.fill_state_dict_(m.state_dict(), seed)
+    m.train()
+    batch = syn.make_batch(seed, B, S, device=dev)
+    taps = []
+    h = m.perceptual_encoder.register_forward_hook(lambda mod, i, o: taps.append(o))
+    total = m.training_step(batch, 0)
+    h.remove()
+    total.backward()
+    torch.cuda.synchronize()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthreads))                       # the oracle oversubscribes badly on a 128-core host
+    try:
+        sd = {k: torch.empty(s) for k, s in param_spec.trainable_shapes().items()}
+        syn.fill_state_dict_(sd, seed)
+        for v in sd.values():
+            v.requires_grad_(True)
+        out = O.training_step(sd, _oracle_batch(syn.make_batch(seed, B, S)), dict(gripper_control=True))
+        out["total_loss"].backward()
+    finally:
+        torch.set_num_threads(nthreads)
+    close(total, out["total_loss"], t["loss"], "total loss")
+    close(m.logged["train/kl_loss"], out["kl_loss"], t["loss"] * 5, "kl loss")
+    close(m.logged["train/action_loss"], out["action_loss"], t["loss"], "action loss")
+    close(m.logged["train/lang_clip_loss"] / 3.0, out["clip_loss"], t["loss"] * 5, "clip loss")
+    embs = torch.cat(taps, dim=0)
+    close(embs[:B], out["emb_vis"], t["act"] * 3, "perceptual emb vis")
+    close(embs[B:], out["emb_lang"], t["act"] * 3, "perceptual emb lang")
+    P = dict(m.named_parameters())
+    for n, ref in sd.items():
+        if ref.grad is None:
+            assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0, n
+            continue
+        # contrastive head at tiny batch: see test_whole_training_step
+        lim = 0.6 if (B == 2 and (n.startswith("proj_vis_lang") or n == "logit_scale")) else t["grad"] * 2
+        if n == "logit_scale":
+            got, want = P[n].grad.reshape(1), ref.grad.reshape(1)
+            rel = (got.cpu() - want).abs().item() / (want.abs().item() + 1e-12)
+            assert rel <= errbudget.limit("g " + n, rel, lim), (n, rel)
+        else:
+            close(P[n].grad, ref.grad, lim, "g " + n)
 
 
 def test_world_to_tcp_matches_oracle(dev):

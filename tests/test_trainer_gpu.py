@@ -146,3 +146,31 @@ def test_bench_exits_nonzero_on_barrier_timeout():
                         "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "barrier timed out" in r.stderr, r.stderr[-2000:]
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_graph_replay_is_immune_to_eager_work_between_replays(dev):
+    """Regression (round 2): a hipMemsetAsync captured inside the recurrent kernel's launcher left the barrier header stale on later
+    replays as soon as anything else allocated / filled memory between two replays (NaN from the second replay on) — exactly what an
+    RCCL all-reduce or a data loader does.  Replays interleaved with NaN-filled scratch allocations must reproduce the undisturbed run
+    bit for bit."""
+    def run(disturb):
+        kn.reset_step_state(dev)
+        m = _model(dev, 13, 0.1)
+        tr = ArenaTrainer(m, overlap=False)
+        batch = _batch(dev, 13, B=4, S=16, sampled=True)
+        for i in range(2):
+            tr.step(batch, i)
+        tr.capture(batch)
+        out = []
+        for _ in range(4):
+            out.append(float(tr.replay()))
+            if disturb:
+                torch.cuda.synchronize()
+                junk = [torch.full((n,), float("nan"), device=dev) for n in (1, 100, 5000, 100000, 4 * 10**6) for _ in range(6)]
+                del junk
+        torch.cuda.synchronize()
+        return out, tr.flat_p.clone()
+    a, pa = run(False)
+    b, pb = run(True)
+    assert all(x == x for x in b), b
+    assert a == b and torch.equal(pa, pb), (a, b)

@@ -14,7 +14,8 @@ syn.fill_state_dict_(m.state_dict(), 42)
 m.train()
 net = m.plan_recognition
 FLOP_TOKEN = 3 * 2 * 2 * 598016.0          # fwd + bwd (= 3x fwd), 2 layers, 2 FLOP per MAC
-for B in (64, 512, 4096):
+import os
+for B in ([int(v) for v in os.environ["HULC_TXL_SIZES"].split(",")] if os.environ.get("HULC_TXL_SIZES") else (64, 512, 4096)):
     emb = torch.randn(B, 32, 128, device=dev, requires_grad=True)
     def step():
         for p in net.parameters():
