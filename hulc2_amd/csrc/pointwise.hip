@@ -263,7 +263,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             float t = x[i];
             if (o) {
                 float ov = o[i];
-                for (int sl = 1; sl < n_o; ++sl) ov += o[(long)sl * o_stride + i];     // o given as partial slabs (fused feed-forward slices), fixed order
+                {   // o given as partial slabs (fused feed-forward slices), fixed order; four independent loads per trip
+                    int sl = 1;
+                    for (; sl + 3 < n_o; sl += 4) {
+                        const float a0 = o[(long)sl * o_stride + i], a1 = o[(long)(sl + 1) * o_stride + i], a2 = o[(long)(sl + 2) * o_stride + i],
+                                    a3 = o[(long)(sl + 3) * o_stride + i];
+                        ov += a0; ov += a1; ov += a2; ov += a3;
+                    }
+                    for (; sl < n_o; ++sl) ov += o[(long)sl * o_stride + i];
+                }
                 if (drop_p > 0.f) ov *= dropout_scale(seed, (uint64_t)i, drop_p);
                 t += ov;
             }

@@ -108,13 +108,32 @@ __global__ __launch_bounds__(256) void txl_attn_fwd_kernel(TxlP p) {
     // transposed q / k tiles D[col][token] (lane <-> token), plain v tile D[token][col] (lane <-> column)
     f32x16_t qT = zero16(), kT = zero16(), v = zero16();
     {
+        // every weight fragment of the three projections is requested before the first MFMA (one memory round trip, not 24)
         const uint16_t* wq = p.Wqkv + (long)(32 * w + r) * E + hf * 8;
+        bf16x8_t fq[8], fk[8], fv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { fq[ks] = ldg16(wq + ks * 16); fk[ks] = ldg16(wq + (long)E * E + ks * 16); fv[ks] = ldg16(wq + 2L * E * E + ks * 16); }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8_t fq = ldg16(wq + ks * 16), fk = ldg16(wq + (long)E * E + ks * 16), fv = ldg16(wq + 2L * E * E + ks * 16);
-            qT = MFMA(fq, xf[ks], qT);
-            kT = MFMA(fk, xf[ks], kT);
-            v = MFMA(xf[ks], fv, v);
+            qT = MFMA(fq[ks], xf[ks], qT);
+            kT = MFMA(fk[ks], xf[ks], kT);
+            v = MFMA(xf[ks], fv[ks], v);
+        }
+    }
+    // operands of the later phases that do not depend on anything computed here: requested now, consumed behind the barriers
+    bf16x8_t wof[8];
+    {
+        const uint16_t* wo = p.Wo + (long)(32 * w + r) * E + 4 * hf;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) wof[kk] = ldg_split(wo + 32 * (kk >> 1) + 16 * (kk & 1));
+    }
+    float4 xres[4], bov[4], gmv[4], btv[4];
+    {
+        const float* xr0 = p.x + (tok0 + (r < S ? r : 0)) * E + 32 * w + 4 * hf;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xres[g] = *(const float4*)(xr0 + 8 * g); bov[g] = *(const float4*)(p.bo + 32 * w + 4 * hf + 8 * g);
+            gmv[g] = *(const float4*)(p.gamma + 32 * w + 4 * hf + 8 * g); btv[g] = *(const float4*)(p.beta + 32 * w + 4 * hf + 8 * g);
         }
     }
     add_row_vec(qT, p.bqkv + 32 * w, hf, 0.25f);           // (q + bq) / sqrt(16)
@@ -159,21 +178,17 @@ __global__ __launch_bounds__(256) void txl_attn_fwd_kernel(TxlP p) {
     __syncthreads();
     // out_proj for output features 32w..32w+31: D[feature][token] = Wo (columns in fragment order) x ctx^T
     f32x16_t o = zero16();
-    {
-        const uint16_t* wo = p.Wo + (long)(32 * w + r) * E + 4 * hf;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            Frag f; f.u = cs[(kk * 2 + hf) * 32 + r];
-            o = MFMA(ldg_split(wo + 32 * (kk >> 1) + 16 * (kk & 1)), f.b, o);
-        }
+    for (int kk = 0; kk < 8; ++kk) {
+        Frag f; f.u = cs[(kk * 2 + hf) * 32 + r];
+        o = MFMA(wof[kk], f.b, o);
     }
     // residual + dropout + LayerNorm over the 128 features of token r (spread over 4 waves x 2 lane halves x 16 registers)
-    const float* xr = p.x + (tok0 + (r < S ? r : 0)) * E + 32 * w + 4 * hf;
     float pre[16];
     float s1 = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float4 xv = *(const float4*)(xr + 8 * g), bv = *(const float4*)(p.bo + 32 * w + 4 * hf + 8 * g);
+        const float4 xv = xres[g], bv = bov[g];
         const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ba[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void txl_attn_fwd_kernel(TxlP p) {
         float* pr = p.pre ? p.pre + (tok0 + r) * E + 32 * w + 4 * hf : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 gv = *(const float4*)(p.gamma + 32 * w + 4 * hf + 8 * g), bt = *(const float4*)(p.beta + 32 * w + 4 * hf + 8 * g);
+            const float4 gv = gmv[g], bt = btv[g];
             float4 out;
             out.x = (pre[4 * g] - mean) * rstd * gv.x + bt.x; out.y = (pre[4 * g + 1] - mean) * rstd * gv.y + bt.y;
             out.z = (pre[4 * g + 2] - mean) * rstd * gv.z + bt.z; out.w = (pre[4 * g + 3] - mean) * rstd * gv.w + bt.w;
@@ -232,6 +247,13 @@ __global__ __launch_bounds__(256) void txl_attn_bwd_kernel(TxlP p) {
     const bool live = r < S;
     const long tok = tok0 + (live ? r : 0);
 
+    // Wo^T fragments (consumed behind the first barriers) are requested before anything else
+    bf16x8_t wotf[8];
+    {
+        const uint16_t* wt = p.WoT + (long)(32 * w + r) * E + 4 * hf;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) wotf[kk] = ldg_split(wt + 32 * (kk >> 1) + 16 * (kk & 1));
+    }
     // ---- LayerNorm1 backward in the (lane <-> token, registers <-> features 32w + arow) layout
     float dpre[16];
     {
@@ -239,13 +261,34 @@ __global__ __launch_bounds__(256) void txl_attn_bwd_kernel(TxlP p) {
         const float mean = p.mean[tok], rstd = p.rstd[tok];
         float g[16], xh[16], dyv[16];
         float s1 = 0.f, s2 = 0.f;
+        // dy + the partial slabs: all loads of a trip are issued before any is consumed (4 slabs x 4 pieces in flight; a one-load-per-trip
+        // accumulation chain cost 64 serial memory round trips here: 40 us per launch)
+        float4 dsum[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) dsum[q4] = *(const float4*)(p.dy + off + 8 * q4);
+        {
+            int sl = 0;
+            for (; sl + 3 < p.n_slab; sl += 4) {
+                float4 t[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) t[u][q4] = *(const float4*)(p.dy_slab + (long)(sl + u) * p.slab_stride + off + 8 * q4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) { dsum[q4].x += t[u][q4].x; dsum[q4].y += t[u][q4].y; dsum[q4].z += t[u][q4].z; dsum[q4].w += t[u][q4].w; }
+            }
+            for (; sl < p.n_slab; ++sl)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 a = *(const float4*)(p.dy_slab + (long)sl * p.slab_stride + off + 8 * q4);
+                    dsum[q4].x += a.x; dsum[q4].y += a.y; dsum[q4].z += a.z; dsum[q4].w += a.w;
+                }
+        }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            float4 d = *(const float4*)(p.dy + off + 8 * q4);
-            for (int sl = 0; sl < p.n_slab; ++sl) {
-                const float4 a = *(const float4*)(p.dy_slab + (long)sl * p.slab_stride + off + 8 * q4);
-                d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
-            }
+            const float4 d = dsum[q4];
             const float4 pv = *(const float4*)(p.pre + off + 8 * q4), gm = *(const float4*)(p.gamma + 32 * w + 4 * hf + 8 * q4);
             const float da[4] = {d.x, d.y, d.z, d.w}, pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
@@ -284,33 +327,31 @@ __global__ __launch_bounds__(256) void txl_attn_bwd_kernel(TxlP p) {
         for (int i = 0; i < 32; ++i) acc += lt[w][hf][r][i];
         p.ln_partial[((long)b * 2 + hf) * E + 32 * w + r] = acc;
     }
+    // operands of the projection recompute: independent of the exchange, requested before the barrier
+    bf16x8_t xf[8], fq[8], fk[8], fv[8];
+    load_x_frags(xf, p.x, tok0, r, hf, S);
+    {
+        const uint16_t* wq = p.Wqkv + (long)(32 * w + r) * E + hf * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { fq[ks] = ldg16(wq + ks * 16); fk[ks] = ldg16(wq + (long)E * E + ks * 16); fv[ks] = ldg16(wq + 2L * E * E + ks * 16); }
+    }
     __syncthreads();
 
     // ---- dctx = d_o Wo in both orientations, for this wave's 32 context columns
     f32x16_t dcT = zero16(), dc = zero16();     // dcT: lane <-> token, registers <-> column;  dc: lane <-> column, registers <-> token
-    {
-        const uint16_t* wt = p.WoT + (long)(32 * w + r) * E + 4 * hf;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            Frag f; f.u = dos[(kk * 2 + hf) * 32 + r];
-            const bf16x8_t wf = ldg_split(wt + 32 * (kk >> 1) + 16 * (kk & 1));
-            dcT = MFMA(wf, f.b, dcT);
-            dc = MFMA(f.b, wf, dc);
-        }
+    for (int kk = 0; kk < 8; ++kk) {
+        Frag f; f.u = dos[(kk * 2 + hf) * 32 + r];
+        dcT = MFMA(wotf[kk], f.b, dcT);
+        dc = MFMA(f.b, wotf[kk], dc);
     }
     // ---- recompute the projections (both orientations where both are consumed)
-    bf16x8_t xf[8];
-    load_x_frags(xf, p.x, tok0, r, hf, S);
     f32x16_t qT = zero16(), kT = zero16(), vT = zero16(), qn = zero16(), kn = zero16();
-    {
-        const uint16_t* wq = p.Wqkv + (long)(32 * w + r) * E + hf * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8_t fq = ldg16(wq + ks * 16), fk = ldg16(wq + (long)E * E + ks * 16), fv = ldg16(wq + 2L * E * E + ks * 16);
-            qT = MFMA(fq, xf[ks], qT); qn = MFMA(xf[ks], fq, qn);
-            kT = MFMA(fk, xf[ks], kT); kn = MFMA(xf[ks], fk, kn);
-            vT = MFMA(fv, xf[ks], vT);
-        }
+    for (int ks = 0; ks < 8; ++ks) {
+        qT = MFMA(fq[ks], xf[ks], qT); qn = MFMA(xf[ks], fq[ks], qn);
+        kT = MFMA(fk[ks], xf[ks], kT); kn = MFMA(xf[ks], fk[ks], kn);
+        vT = MFMA(fv[ks], xf[ks], vT);
     }
     add_row_vec(qT, p.bqkv + 32 * w, hf, 0.25f);
     add_row_vec(kT, p.bqkv + E + 32 * w, hf, 1.f);
@@ -395,16 +436,20 @@ __global__ __launch_bounds__(256) void txl_attn_bwd_kernel(TxlP p) {
             }
         }
     }
-    __syncthreads();
-    // ---- dx^T [feature][token] = Wqkv^T (columns in fragment order) x dqkv^T, + the residual path
-    f32x16_t ax = zero16();
+    // Wqkv^T fragments (columns in fragment order): requested before the barrier they are consumed behind
+    bf16x8_t wtf[24];
     {
         const uint16_t* wt = p.WqkvT + (long)(32 * w + r) * 3 * E + 4 * hf;
 #pragma unroll
-        for (int kk = 0; kk < 24; ++kk) {
-            Frag f; f.u = dqs[(kk * 2 + hf) * 32 + r];
-            ax = MFMA(ldg_split(wt + E * (kk >> 3) + 32 * ((kk & 7) >> 1) + 16 * (kk & 1)), f.b, ax);
-        }
+        for (int kk = 0; kk < 24; ++kk) wtf[kk] = ldg_split(wt + E * (kk >> 3) + 32 * ((kk & 7) >> 1) + 16 * (kk & 1));
+    }
+    __syncthreads();
+    // ---- dx^T [feature][token] = Wqkv^T x dqkv^T, + the residual path
+    f32x16_t ax = zero16();
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) {
+        Frag f; f.u = dqs[(kk * 2 + hf) * 32 + r];
+        ax = MFMA(wtf[kk], f.b, ax);
     }
     if (live) {
         float* dst = p.dx + (tok0 + r) * E + 32 * w + 4 * hf;

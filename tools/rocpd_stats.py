@@ -45,8 +45,34 @@ def pmc(path):
         print(f"{n:7d} {v / n:16.1f} {ctr:>14} {lds:7d} {grid:9d}  {short(name)}")
 
 
+def mfma(path):
+    """MFMA utilisation per kernel from one pass with SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE:
+         util %   = 100 x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)     (the gfx94x MfmaUtil formula rocprofv3 falls back to)
+         TFLOP/s  = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16 / (GRBM_GUI_ACTIVE / 2.4 GHz)           (counter unit: 512 FLOP)
+       `python tools/rocpd_stats.py --mfma x.db`"""
+    c = sqlite3.connect(path)
+    rows = c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
+    per = {}
+    for name, ctr, n, v in rows:
+        d = per.setdefault(name, {"n": 0})
+        d[ctr] = v
+        d["n"] = max(d["n"], n)
+    tot_busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in per.values())
+    tot_act = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in per.values())
+    tot_mops = sum(d.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) for d in per.values())
+    print(f"# all kernels: MFMA busy {tot_busy:.3e} cycles over GRBM_GUI_ACTIVE {tot_act:.3e} -> utilisation {100 * tot_busy / max(tot_act * 1024, 1):.2f} % of the "
+          f"1024 SIMD matrix pipes; {512 * tot_mops / 1e12:.3f} TFLOP counted ({512 * tot_mops / max(tot_act / 2.4e9, 1e-12) / 1e12:.1f} TFLOP/s at 2.4 GHz)")
+    print(f"{'calls':>7} {'gui_active/launch':>18} {'mfma_busy/launch':>17} {'mfma_util_%':>11} {'bf16_TFLOP/s':>12} {'sq_busy/launch':>15}  kernel")
+    for name, d in sorted(per.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+        n, act, busy = d["n"], d.get("GRBM_GUI_ACTIVE", 0), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+        mops, sqb = d.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), d.get("SQ_BUSY_CYCLES", 0)
+        print(f"{n:7d} {act / n:18.0f} {busy / n:17.0f} {100 * busy / max(act * 1024, 1):11.2f} {512 * mops / max(act / 2.4e9, 1e-12) / 1e12:12.1f} {sqb / n:15.0f}  {short(name)}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--pmc":
+    if len(sys.argv) > 2 and sys.argv[1] == "--mfma":
+        mfma(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "--pmc":
         pmc(sys.argv[2])
     else:
         main(sys.argv[1])
