@@ -703,6 +703,8 @@ void launch_ct(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStre
 
 }  // namespace
 
+int hulc_gemm_tn128_try(const hulc_gemm_desc* d, hipStream_t s);   // gemm_tn128.hip
+
 extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return hulc_fail(-1, "hulc_gemm: null operand");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return hulc_fail(-2, "hulc_gemm: non-positive dimension");
@@ -724,6 +726,11 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     p.rowsum = d->rowsum_a; p.rowsum_accumulate = d->rowsum_accumulate;
     if (p.rowsum && d->M <= 64) return hulc_fail(-6, "hulc_gemm: rowsum_a needs M > 64 (tiled path)");
     hipStream_t s = (hipStream_t)stream;
+    if (!getenv("HULC_NO_GEMM_TN128")) {          // large row-major x row-major bf16 products (the recurrent weight gradients): 128-deep k-steps
+        const int took = hulc_gemm_tn128_try(d, s);
+        if (took < 0) return took;
+        if (took) return hulc_check_launch("hulc_gemm");
+    }
     if (d->M <= 64) {
         if (d->compute == HULC_F32) launch_skinny<float>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);
         else launch_skinny<bf16_t>(p, d->a_kmajor, d->b_kmajor, (float*)d->ws, d->ws ? d->ws_bytes : 0, s);

@@ -1,0 +1,170 @@
+// gemm_tn128.hip — the large weight-gradient GEMM  C[M][N] (+)= sum_k A[k][m] B[k][n]  with both operands row-major bf16 and the reduction
+// index OUTER (k = token): dW = delta^T h of the recurrent decoder (three 2048 x 2048 x 2048 products per step; reference:
+// nn.RNN's weight gradients, hulc2/models/decoders/utils/rnn.py:5-14 through autograd).
+//
+// The generic tiled kernel (gemm.hip) spends one barrier pair per 32-deep k-tile: 8 MFMAs per wave between synchronisations, 10 % of the
+// matrix pipe at 2048^3 (66 us).  Here a k-step is 128 deep:
+//   * workgroup tile 128 x 128, 4 waves of 64 x 64 (2 x 2 accumulators of 32 x 32), 256 workgroups at 2048^2 = one per CU;
+//   * LDS holds the operand tiles as they lie in memory, [k][128 columns] (row stride 288 B: the four k rows a ds_read_b64_tr_b16 group
+//     touches fall on distinct banks), fragments come out of ds_read_b64_tr_b16 (lane = column, 8 consecutive k);
+//   * two LDS stages (2 x 72 KB): the next k-step's 16-byte loads are issued into registers before the 32 MFMAs of the current one and
+//     written to the other stage behind them — one barrier per k-step, loads never waited for in front of the MFMAs;
+//   * epilogue: fp32 store or accumulate; the first column block also sums its A tile columns in fp32 (the bias gradient, fixed order).
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+constexpr int BT = 128;                 // tile edge (output rows, columns) and k-step depth
+constexpr int RST = BT * 2 + 32;        // LDS row stride of a [k][128] bf16 tile (288 B)
+constexpr int TILE_B = BT * RST;        // bytes per operand tile
+
+struct TnP {
+    const uint16_t* A; const uint16_t* B; float* C;
+    long lda, ldb, ldc;
+    int M, N, K;
+    int accumulate;
+    float* rowsum; int rowsum_accumulate;
+};
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef v4s __attribute__((address_space(3))) * lds_v4s;
+HULC_DEVICE v4s tr_read(const char* q) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)q); }
+
+// one workgroup per CU (147 KB of LDS): tell the register allocator that one wave per SIMD is the plan — with dynamic LDS it otherwise
+// budgets 128 VGPRs for two, spills the prefetched tile to scratch and waits for the loads in front of the MFMAs (61 us instead of ...)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_tn128_kernel(TnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [stage][A tile | B tile]
+    __shared__ float rsum[16][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // neighbouring workgroups share an A panel (blockIdx.x fastest = columns): both panels of a tile row stay in one XCD's L2 for a while
+    const int n0 = blockIdx.x * BT, m0 = blockIdx.y * BT;
+    const int kr0 = tid >> 4, mc = tid & 15;                          // this thread's chunk: k rows kr0 + 16 q, columns 8 mc .. 8 mc + 7
+    const uint16_t* ga = p.A + (long)kr0 * p.lda + m0 + mc * 8;
+    const uint16_t* gb = p.B + (long)kr0 * p.ldb + n0 + mc * 8;
+    const bool do_rowsum = p.rowsum != nullptr && blockIdx.x == 0;
+    float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // the staging registers are sixteen NAMED values touched only by straight-line, unconditional code: as arrays (or behind a lambda or a
+    // condition) hipcc kept part of them in scratch memory and waited for each load right where it was issued
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define TN_LD1(q, kt_) ra##q = *(const uint4*)(ga + ((long)(kt_) * BT + 16 * q) * p.lda); rb##q = *(const uint4*)(gb + ((long)(kt_) * BT + 16 * q) * p.ldb);
+#define TN_LOAD(kt_) TN_LD1(0, kt_) TN_LD1(1, kt_) TN_LD1(2, kt_) TN_LD1(3, kt_) TN_LD1(4, kt_) TN_LD1(5, kt_) TN_LD1(6, kt_) TN_LD1(7, kt_)
+#define TN_SUM1(w_, sum_)                                                                                              \
+    rs[0] += (sum_) * __uint_as_float(w_.x << 16); rs[1] += (sum_) * __uint_as_float(w_.x & 0xffff0000u);             \
+    rs[2] += (sum_) * __uint_as_float(w_.y << 16); rs[3] += (sum_) * __uint_as_float(w_.y & 0xffff0000u);             \
+    rs[4] += (sum_) * __uint_as_float(w_.z << 16); rs[5] += (sum_) * __uint_as_float(w_.z & 0xffff0000u);             \
+    rs[6] += (sum_) * __uint_as_float(w_.w << 16); rs[7] += (sum_) * __uint_as_float(w_.w & 0xffff0000u);
+#define TN_ST1(q, At_, Bt_) *(uint4*)(At_ + (kr0 + 16 * q) * RST + mc * 16) = ra##q; *(uint4*)(Bt_ + (kr0 + 16 * q) * RST + mc * 16) = rb##q;
+#define TN_STORE(stage_)                                                                                               \
+    {                                                                                                                  \
+        char* At_ = smem + (stage_) * 2 * TILE_B;                                                                      \
+        char* Bt_ = At_ + TILE_B;                                                                                      \
+        TN_ST1(0, At_, Bt_) TN_ST1(1, At_, Bt_) TN_ST1(2, At_, Bt_) TN_ST1(3, At_, Bt_)                                \
+        TN_ST1(4, At_, Bt_) TN_ST1(5, At_, Bt_) TN_ST1(6, At_, Bt_) TN_ST1(7, At_, Bt_)                                \
+    }
+    const int nkt = p.K / BT;
+    TN_LOAD(0)
+    TN_STORE(0)
+    __syncthreads();
+    const int krow = (lane >> 5) * 8 + ((lane & 15) >> 2), col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = kt + 1 < nkt ? kt + 1 : kt;                    // last trip: reloads its own tile (never consumed), no branch
+        TN_LOAD(ktn)                                                   // in flight behind the MFMAs below ...
+        __builtin_amdgcn_sched_barrier(0);                             // ... pinned: the scheduler otherwise sinks the loads to their use
+        const char* At = smem + cur * 2 * TILE_B + wm * 64 * 2;
+        const char* Bt = smem + cur * 2 * TILE_B + TILE_B + wn * 64 * 2;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {                               // 16 k per step
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                union { v4s v[2]; bf16x8_t f; } x;
+                const char* q = At + (ks * 16 + krow) * RST + col + i * 64;
+                x.v[0] = tr_read(q); x.v[1] = tr_read(q + 4 * RST);
+                a[i] = x.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                union { v4s v[2]; bf16x8_t f; } x;
+                const char* q = Bt + (ks * 16 + krow) * RST + col + j * 64;
+                x.v[0] = tr_read(q); x.v[1] = tr_read(q + 4 * RST);
+                b[j] = x.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_rowsum) {      // bias gradient: column sums of the CURRENT A tile, read back from LDS — never from the staging registers (any
+                              // arithmetic on a prefetched value is hoisted to the load and turns the prefetch into a wait)
+            const char* Ac = smem + cur * 2 * TILE_B;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 w_ = *(const uint4*)(Ac + (kr0 + 16 * q) * RST + mc * 16);
+                TN_SUM1(w_, 1.f)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TN_STORE(cur ^ 1)                                              // the other stage: its last readers passed the previous barrier
+        __syncthreads();
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(e, lane);
+                float* dst = p.C + (long)m * p.ldc + n;
+                *dst = p.accumulate ? *dst + acc[i][j][e] : acc[i][j][e];
+            }
+        }
+    if (do_rowsum) {                                                   // 16 k-row groups per column chunk, summed in a fixed order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rsum[kr0][mc * 8 + j] = rs[j];
+        __syncthreads();
+        if (tid < BT) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += rsum[g][tid];
+            float* dst = p.rowsum + m0 + tid;
+            *dst = p.rowsum_accumulate ? *dst + s : s;
+        }
+    }
+}
+
+}  // namespace
+
+// internal entry used by hulc_gemm (gemm.hip): returns 1 when the shape was taken, 0 when the generic kernel must run, < 0 on error
+int hulc_gemm_tn128_try(const hulc_gemm_desc* d, hipStream_t s) {
+    if (d->compute != HULC_BF16 || d->a_kmajor || d->b_kmajor || d->a_dtype != HULC_BF16 || d->b_dtype != HULC_BF16 || d->c_dtype != HULC_F32) return 0;
+    if (d->bias || d->add || d->mask || d->relu || d->alpha != 1.0f || d->drop_p > 0.f) return 0;
+    if (d->M % BT || d->N % BT || d->K % BT || d->M < 512 || d->N < 512 || d->K < 512) return 0;
+    if (((uintptr_t)d->A | (uintptr_t)d->B) % 16 || d->lda % 8 || d->ldb % 8) return 0;
+    TnP p;
+    p.A = (const uint16_t*)d->A; p.B = (const uint16_t*)d->B; p.C = (float*)d->C;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.M = d->M; p.N = d->N; p.K = d->K;
+    p.accumulate = d->accumulate; p.rowsum = d->rowsum_a; p.rowsum_accumulate = d->rowsum_accumulate;
+    static bool attr = false;
+    const size_t lds = (size_t)4 * TILE_B;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)gemm_tn128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * BT * 4) != hipSuccess)
+            return hulc_fail(-8, "hulc_gemm: could not raise the dynamic LDS limit (tn128)");
+        attr = true;
+    }
+    gemm_tn128_kernel<<<dim3(d->N / BT, d->M / BT), 256, lds, s>>>(p);
+    return 1;
+}

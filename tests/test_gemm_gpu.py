@@ -210,3 +210,37 @@ def test_gemm_row_major_bf16_operands(dev, M, N, K, a16, b16):
     if M > 64:
         want = A.double().sum(0)
         assert (rs.double() - want).abs().max().item() < 1e-4 * K ** 0.5 + 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,accumulate", [(1024, 512, 640, False), (512, 2048, 1024, True)])
+def test_gemm_tn128_strided_views_and_accumulate(dev, M, N, K, accumulate):
+    """the 128-deep k-step kernel (csrc/gemm_tn128.hip) on what the recurrent decoder hands it: column slices of wider bf16 row-major
+    buffers (lda / ldb = twice the width), output overwritten or accumulated, fused bias gradient; an asymmetric product so that a
+    transposed result cannot pass; identical to the generic kernel (HULC_NO_GEMM_TN128) up to fp32 summation order"""
+    import os
+    from hulc2_amd import kernels as kn
+
+    kn.set_compute("bf16")
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    Aw = torch.randn(K, 2 * M, generator=g).to(dev).to(torch.bfloat16)
+    Bw = torch.randn(K, 2 * N, generator=g).to(dev).to(torch.bfloat16)
+    A, B = Aw[:, M:], Bw[:, :N]
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    rs0 = torch.randn(M, generator=g).to(dev)
+
+    def run():
+        C, rs = C0.clone(), rs0.clone()
+        kn.gemm(A, B, C, M, N, K, 2 * M, 2 * N, N, a_kmajor=False, b_kmajor=False, accumulate=accumulate, rowsum=rs, rowsum_accumulate=accumulate)
+        torch.cuda.synchronize()
+        return C, rs
+    C, rs = run()
+    ref = A.double().t() @ B.double() + (C0.double() if accumulate else 0)
+    assert (C.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item() + 1e-4
+    want = A.double().sum(0) + (rs0.double() if accumulate else 0)
+    assert (rs.double() - want).abs().max().item() < 1e-4 * K ** 0.5 + 1e-4
+    os.environ["HULC_NO_GEMM_TN128"] = "1"
+    try:
+        C2, rs2 = run()
+    finally:
+        del os.environ["HULC_NO_GEMM_TN128"]
+    assert (C - C2).abs().max().item() < 1e-4 * ref.abs().max().item()

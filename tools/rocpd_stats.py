@@ -47,8 +47,11 @@ def pmc(path):
 
 def mfma(path):
     """MFMA utilisation per kernel from one pass with SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE:
-         util %   = 100 x SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)     (the gfx94x MfmaUtil formula rocprofv3 falls back to)
-         TFLOP/s  = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16 / (GRBM_GUI_ACTIVE / 2.4 GHz)           (counter unit: 512 FLOP)
+         util %   = 100 x SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 256 CUs x 4 SIMDs)     (the gfx94x MfmaUtil formula rocprofv3 falls back to)
+         TFLOP/s  = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16 / (cycles / 2.4 GHz)           (counter unit: 512 FLOP)
+       with cycles = GRBM_GUI_ACTIVE / 8: rocprofv3 reports the counter summed over the 8 XCDs (checked against kernel durations: the
+       conv3 forward launch shows 2.66 M "active" = 8 x 332 k cycles = 138 us, its traced duration under the counter pass).  A dispatch
+       under --pmc carries ~10 us of serialisation, so small kernels read low; the big kernels' numbers match FLOPs / traced time.
        `python tools/rocpd_stats.py --mfma x.db`"""
     c = sqlite3.connect(path)
     rows = c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
@@ -58,13 +61,13 @@ def mfma(path):
         d[ctr] = v
         d["n"] = max(d["n"], n)
     tot_busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in per.values())
-    tot_act = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in per.values())
+    tot_act = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in per.values()) / 8.0
     tot_mops = sum(d.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) for d in per.values())
-    print(f"# all kernels: MFMA busy {tot_busy:.3e} cycles over GRBM_GUI_ACTIVE {tot_act:.3e} -> utilisation {100 * tot_busy / max(tot_act * 1024, 1):.2f} % of the "
+    print(f"# all kernels: MFMA busy {tot_busy:.3e} cycles over {tot_act:.3e} active cycles (GRBM_GUI_ACTIVE / 8 XCDs) -> utilisation {100 * tot_busy / max(tot_act * 1024, 1):.2f} % of the "
           f"1024 SIMD matrix pipes; {512 * tot_mops / 1e12:.3f} TFLOP counted ({512 * tot_mops / max(tot_act / 2.4e9, 1e-12) / 1e12:.1f} TFLOP/s at 2.4 GHz)")
-    print(f"{'calls':>7} {'gui_active/launch':>18} {'mfma_busy/launch':>17} {'mfma_util_%':>11} {'bf16_TFLOP/s':>12} {'sq_busy/launch':>15}  kernel")
+    print(f"{'calls':>7} {'cycles/launch':>18} {'mfma_busy/launch':>17} {'mfma_util_%':>11} {'bf16_TFLOP/s':>12} {'sq_busy/launch':>15}  kernel")
     for name, d in sorted(per.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
-        n, act, busy = d["n"], d.get("GRBM_GUI_ACTIVE", 0), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+        n, act, busy = d["n"], d.get("GRBM_GUI_ACTIVE", 0) / 8.0, d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
         mops, sqb = d.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), d.get("SQ_BUSY_CYCLES", 0)
         print(f"{n:7d} {act / n:18.0f} {busy / n:17.0f} {100 * busy / max(act * 1024, 1):11.2f} {512 * mops / max(act / 2.4e9, 1e-12) / 1e12:12.1f} {sqb / n:15.0f}  {short(name)}")
 
