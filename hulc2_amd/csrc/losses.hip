@@ -39,7 +39,16 @@ struct MixP {
     const float* amin; const float* amax;   // [A]
     int T, A, NM, num_classes;
     float log_scale_min, gripper_alpha;
+    int tm_B, nseg;                 // tm_B > 0: rows are time-major (row = step * tm_B + batch row) and a segment is a block of tm_B / nseg batch rows
 };
+
+// physical row of token j (0 .. seg_tokens) of segment seg
+HULC_DEVICE int mix_row(const MixP& p, int seg, int j, int seg_tokens) {
+    if (p.tm_B == 0) return seg * seg_tokens + j;
+    const int bs = p.tm_B / p.nseg;
+    return (j / bs) * p.tm_B + seg * bs + j % bs;
+}
+HULC_DEVICE int mix_seg_of_row(const MixP& p, int t, int seg_tokens) { return p.tm_B == 0 ? t / seg_tokens : (t % p.tm_B) / (p.tm_B / p.nseg); }
 
 // per (token, action dim): NLL and, when G != nullptr, gradients w.r.t. the 3*NM head outputs
 // per (token, action dim): NLL and, when GRAD, gradients w.r.t. the 3*NM head outputs — one LANE per mixture component: an item is a
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void mix_loss_partial_kernel(MixP p, int seg_t
     const int w = bl * 16 + (threadIdx.x >> 4), i = threadIdx.x & 15;     // item inside the segment (16 per workgroup), mixture lane
     float nll = 0.f, ce = 0.f;
     if (w < seg_tokens * (p.A + 1)) {
-        const int t = seg * seg_tokens + w / (p.A + 1), d = w % (p.A + 1);
+        const int t = mix_row(p, seg, w / (p.A + 1), seg_tokens), d = w % (p.A + 1);
         if (d < p.A) {
             const float v = mix_nll_lanes<false>(p, t, d, i, 0.f, nullptr);
             nll = i == 0 ? v : 0.f;
@@ -151,10 +160,11 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(MixP p, int seg_token
     const int w = blockIdx.x * 16 + (threadIdx.x >> 4), i = threadIdx.x & 15;
     if (w >= p.T * (p.A + 1)) return;                      // whole 16-lane groups leave together
     const int t = w / (p.A + 1), d = w % (p.A + 1);
-    const float g = gout[t / seg_tokens] / seg_tokens;
+    const float g = gout[mix_seg_of_row(p, t, seg_tokens)] / seg_tokens;
     float* drow = dy + (long)t * ld_dy;
     if (d < p.A) mix_nll_lanes<true>(p, t, d, i, g, drow);
     else if (i == 0) {
+        for (int c = 3 * p.A * p.NM + 2; c < ld_dy; ++c) drow[c] = 0.f;      // pad columns of the fused head output carry no gradient
         const float* gl = p.y + (long)t * p.ld + 3 * p.A * p.NM;
         const float a = p.act[(long)t * (p.A + 1) + p.A];
         const int lbl = (a == -1.f) ? 0 : (int)a;
@@ -447,6 +457,7 @@ MixP make_mix(const hulc_mix_desc* d, const float* y, const float* act) {
     p.y = y; p.ld = d->ld; p.act = act; p.amin = d->act_min; p.amax = d->act_max;
     p.T = d->T; p.A = d->A; p.NM = d->n_mix; p.num_classes = d->num_classes;
     p.log_scale_min = d->log_scale_min; p.gripper_alpha = d->gripper_alpha;
+    p.tm_B = d->time_major_B; p.nseg = d->nseg < 1 ? 1 : d->nseg;
     return p;
 }
 
@@ -455,6 +466,8 @@ MixP make_mix(const hulc_mix_desc* d, const float* y, const float* act) {
 static int mix_check(const hulc_mix_desc* d, const char* who) {
     if (d->n_mix > 16 || d->n_mix <= 0) return hulc_fail(-2, "hulc_mix_loss: n_mix must be in 1..16");
     if (d->nseg < 1 || d->T % d->nseg != 0) return hulc_fail(-3, "hulc_mix_loss: T must split into nseg equal segments");
+    if (d->time_major_B < 0 || (d->time_major_B > 0 && (d->T % d->time_major_B || d->time_major_B % d->nseg)))
+        return hulc_fail(-3, "hulc_mix_loss: time-major rows need T % B == 0 and B % nseg == 0");
     (void)who;
     return 0;
 }
@@ -526,6 +539,37 @@ extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsign
     if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128 and D == 32");
     clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, nullptr, gout, dim, dtx, dscale);
     return hulc_check_launch("hulc_clip_loss_bwd");
+}
+
+// total = (sum_m act[m] + sum_m kl[m]) / n + beta * clip  — the scalar tail of Hulc2.training_step (hulc2.py:400-430) as one launch per
+// direction (a dozen 0-dim torch kernels otherwise).  out = {total, kl mean, action mean, beta * clip, per-modality act + kl ...}
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ kls, const float* __restrict__ acts, const float* __restrict__ clip, int n, float beta,
+                                        float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sk = 0.f, sa = 0.f, st = 0.f;
+    for (int m = 0; m < n; ++m) { const float t = acts[m] + kls[m]; out[4 + m] = t; sk += kls[m]; sa += acts[m]; st += t; }
+    float total = st / n;
+    const float wc = clip ? beta * clip[0] : 0.f;
+    if (clip) total = total + wc;
+    out[0] = total; out[1] = sk / n; out[2] = sa / n; out[3] = wc;
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, int n, float beta, float* __restrict__ dkls, float* __restrict__ dacts,
+                                        float* __restrict__ dclip) {
+    const int m = threadIdx.x;
+    if (m < n) { dkls[m] = g[0] / n; dacts[m] = g[0] / n; }
+    if (m == 0 && dclip) dclip[0] = g[0] * beta;
+}
+extern "C" int hulc_loss_combine_fwd(const float* kls, const float* acts, const float* clip, int n, float beta, float* out, void* stream) {
+    if (!kls || !acts || !out) return hulc_fail(-1, "hulc_loss_combine_fwd: null pointer");
+    if (n < 1 || n > 64) return hulc_fail(-2, "hulc_loss_combine_fwd: 1..64 modalities");
+    loss_combine_fwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(kls, acts, clip, n, beta, out);
+    return hulc_check_launch("hulc_loss_combine_fwd");
+}
+extern "C" int hulc_loss_combine_bwd(const float* g, int n, float beta, float* dkls, float* dacts, float* dclip, void* stream) {
+    if (!g || !dkls || !dacts) return hulc_fail(-1, "hulc_loss_combine_bwd: null pointer");
+    if (n < 1 || n > 64) return hulc_fail(-2, "hulc_loss_combine_bwd: 1..64 modalities");
+    loss_combine_bwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(g, n, beta, dkls, dacts, dclip);
+    return hulc_check_launch("hulc_loss_combine_bwd");
 }
 
 extern "C" int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream) {

@@ -214,6 +214,6 @@ extern "C" int hulc_transpose_bf16_tiles(const void* src, void* dst, const long*
 extern "C" int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream) {
     if (!src || !dst || !table) return hulc_fail(-1, "hulc_repack_conv_weights: null pointer");
     if (n <= 0) return 0;
-    repack_conv_kernel<<<dim3(16, (unsigned)n), 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, table);
+    repack_conv_kernel<<<dim3(128, (unsigned)n), 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, table);
     return hulc_check_launch("hulc_repack_conv_weights");
 }

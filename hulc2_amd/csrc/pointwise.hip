@@ -733,6 +733,58 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
     return hulc_check_launch("hulc_layernorm_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// fan-out of the perceptual embedding emb (N, S, D) to its four consumers in Hulc2.training_step (hulc2.py:380-387 / :228-231): the
+// prior sees emb[:, 0], the visual goal encoder emb[:n_last, -1], the posterior all of it, the action decoder the column slice [lo, hi)
+// — handed over time-major (S, N, hi - lo), the order the recurrent kernel consumes.  Forward: the three small gathers in one launch.
+// Backward: the four gradients merged in one launch (autograd's select / slice backward + three accumulate adds were nine).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emb_fanout_fwd_kernel(const float* __restrict__ emb, int N, int S, int D, int n_last, int lo, int hi,
+                                                             float* __restrict__ e0, float* __restrict__ elast, float* __restrict__ edec_t) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = hi - lo;
+    const long n_dec = (long)S * N * E, n0 = (long)N * D, nl = (long)n_last * D;
+    if (i < n_dec) {
+        const int c = (int)(i % E); const long sn = i / E; const int n = (int)(sn % N), st = (int)(sn / N);
+        edec_t[i] = emb[((long)n * S + st) * D + lo + c];
+    } else if (i < n_dec + n0) {
+        const long j = i - n_dec; const int c = (int)(j % D), n = (int)(j / D);
+        e0[j] = emb[((long)n * S) * D + c];
+    } else if (i < n_dec + n0 + nl) {
+        const long j = i - n_dec - n0; const int c = (int)(j % D), n = (int)(j / D);
+        elast[j] = emb[((long)n * S + S - 1) * D + c];
+    }
+}
+__global__ __launch_bounds__(256) void emb_fanin_bwd_kernel(const float* __restrict__ g_rec, const float* __restrict__ g0, const float* __restrict__ g_last,
+                                                            const float* __restrict__ g_dec_t, int N, int S, int D, int n_last, int lo, int hi,
+                                                            float* __restrict__ demb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * S * D) return;
+    const int c = (int)(i % D); const long ns = i / D; const int st = (int)(ns % S), n = (int)(ns / S);
+    float v = g_rec ? g_rec[i] : 0.f;
+    if (g0 && st == 0) v += g0[(long)n * D + c];
+    if (g_last && st == S - 1 && n < n_last) v += g_last[(long)n * D + c];
+    if (g_dec_t && c >= lo && c < hi) v += g_dec_t[((long)st * N + n) * (hi - lo) + c - lo];
+    demb[i] = v;
+}
+
+extern "C" int hulc_emb_fanout_fwd(const float* emb, int N, int S, int D, int n_last, int lo, int hi, float* e0, float* elast, float* edec_t,
+                                   void* stream) {
+    if (!emb || !e0 || !edec_t || (n_last > 0 && !elast)) return hulc_fail(-1, "hulc_emb_fanout_fwd: null pointer");
+    if (N < 1 || S < 1 || lo < 0 || hi > D || lo >= hi || n_last < 0 || n_last > N) return hulc_fail(-2, "hulc_emb_fanout_fwd: bad geometry");
+    const long n = (long)S * N * (hi - lo) + (long)N * D + (long)n_last * D;
+    emb_fanout_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(emb, N, S, D, n_last, lo, hi, e0, elast, edec_t);
+    return hulc_check_launch("hulc_emb_fanout_fwd");
+}
+extern "C" int hulc_emb_fanin_bwd(const float* g_rec, const float* g0, const float* g_last, const float* g_dec_t, int N, int S, int D, int n_last,
+                                  int lo, int hi, float* demb, void* stream) {
+    if (!demb) return hulc_fail(-1, "hulc_emb_fanin_bwd: null pointer");
+    if (N < 1 || S < 1 || lo < 0 || hi > D || lo >= hi || n_last < 0 || n_last > N) return hulc_fail(-2, "hulc_emb_fanin_bwd: bad geometry");
+    const long n = (long)N * S * D;
+    emb_fanin_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(g_rec, g0, g_last, g_dec_t, N, S, D, n_last, lo, hi, demb);
+    return hulc_check_launch("hulc_emb_fanin_bwd");
+}
+
 // partial (P, 2, D) rows of [dgamma | dbeta] partial sums (hulc_txl_attn_bwd's ln_partial) -> dgamma, dbeta; fixed summation order
 extern "C" int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, float* dbeta, int accumulate, void* stream) {
     if (!partial || !dgamma || !dbeta) return hulc_fail(-1, "hulc_ln_partial_reduce: null pointer");

@@ -42,6 +42,7 @@ struct WaveP {
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
     unsigned* bar; int* err; int* err_sticky;
+    const float* add1c; long ld_add1c;           // per-row constant of the first half, the same at every step (nullable): folded into the bias term
     int dbg;                                     // experiments / tests only (HULC_RNN_DBG): 1 = skip state loads + MFMAs, 2 = skip the barrier, 4 = inject a barrier timeout
 };
 
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
         const float* ba = (t4 & 1) ? p.bias2a : p.bias1a;
         const float* bb = (t4 & 1) ? p.bias2b : p.bias1b;
         obias[rep] = (ba ? ba[on[rep]] : 0.f) + (bb ? bb[on[rep]] : 0.f);
+        if (!(t4 & 1) && p.add1c) obias[rep] += p.add1c[(long)(om[rep] < p.B ? om[rep] : p.B - 1) * p.ld_add1c + on[rep]];
     }
 
     for (int tau = 0; tau <= p.S; ++tau) {
@@ -306,6 +308,7 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.mask1 = d->mask1; p.mask1_step = d->mask1_step; p.ld_mask1 = d->ld_mask1;
     p.mask2 = d->mask2; p.mask2_step = d->mask2_step; p.ld_mask2 = d->ld_mask2;
     p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H; p.err_sticky = d->err_sticky;
+    p.add1c = d->add1c; p.ld_add1c = d->ld_add1c;
     p.dbg = getenv("HULC_RNN_DBG") ? atoi(getenv("HULC_RNN_DBG")) : 0;
     p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
     // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs

@@ -42,7 +42,8 @@ class MLPFn(torch.autograd.Function):
     def forward(ctx, x, relus: Tuple[bool, ...], drops: Tuple[float, ...], seed: int, *params):
         L = len(relus)
         assert len(params) == 2 * L and not relus[-1], "chain must end with a plain Linear"
-        x2 = _c(x.reshape(-1, x.shape[-1]))
+        # a 2-D input with unit inner stride is consumed in place (row stride = lda): the recurrent decoder hands in a column slice
+        x2 = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else _c(x.reshape(-1, x.shape[-1]))
         M = x2.shape[0]
         acts: List[torch.Tensor] = []
         inp = x2
@@ -574,11 +575,15 @@ def _rnn_persistent(B: int, Hd: int, state_dtype, device) -> bool:
             and not os.environ.get("HULC_NO_RNN_WAVEFRONT"))
 
 
-def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, h0):
+def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, h0, emb_tm: bool = False):
     """Forward sweep shared by training (DecoderRNNFn) and inference (decoder_rnn_infer).  h0: None (zero initial state, the
     training path) or (2, B, H) initial hidden states of the two layers (stateful `act`).  Returns the time-major state buffer
     zbuf (S+2, B, 2H) with zbuf[t+1] = [h0_t | h1_{t-1}], the operands backward needs, and whether the persistent kernel ran."""
-    B, S, _ = emb.shape
+    # emb_tm: `emb` already IS the decoder's column slice in time-major order, (S, B, hi - lo) (EmbFanoutFn)
+    if emb_tm:
+        S, B, _ = emb.shape
+    else:
+        B, S, _ = emb.shape
     Hd = w_hh0.shape[0]
     P, G, E = plan.shape[1], goal.shape[1], hi - lo
     plan, goal = _c(plan), _c(goal)
@@ -589,9 +594,15 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     c = torch.empty(B, Hd, dtype=torch.float32, device=dev)
     kn.gemm(plan, wih0, c, B, Hd, P, P, Kin, Hd, bias=b_ih0)
     kn.gemm(goal, wih0[:, P + E:], c, B, Hd, G, G, Kin, Hd, accumulate=True)
-    emb_t = emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
-    pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
-    kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
+    emb_t = _c(emb) if emb_tm else emb[:, :, lo:hi].permute(1, 0, 2).contiguous()                   # (S, B, E) time-major
+    zdt0 = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
+    persistent0 = h0 is None and _rnn_persistent(B, Hd, zdt0, dev)
+    if persistent0:       # the per-sequence constant c enters the recurrent kernel as its own (step-independent) term: no (S, B, H) expand
+        pre0 = torch.empty(S, B, Hd, dtype=torch.float32, device=dev)
+        kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd)
+    else:
+        pre0 = c.unsqueeze(0).expand(S, B, Hd).contiguous()
+        kn.gemm(emb_t, wih0[:, P:P + E], pre0, S * B, Hd, E, E, Kin, Hd, accumulate=True)
     # state kept fp32: a bf16 state halves the step traffic but the big reduction-major wgrad GEMMs over it then run on
     # 2-byte strided loads and lose more than the steps gain (tools/decoder_bench.py: 3.07 ms fp32 vs 3.69 ms bf16)
     zdt = _act_dtype() if os.environ.get("HULC_RNN_STATE_BF16") else torch.float32
@@ -608,12 +619,12 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
         zbuf[0][:, :Hd] = h0[0]
         zbuf[1][:, Hd:] = h0[1]
     whh0 = weight_operand(w_hh0)
-    meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2])
+    meta = (B, S, Hd, P, G, E, lo, hi, emb.shape[2], emb_tm)
     if persistent:
         # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
         z16 = kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
                                add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True,
-                               mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")))
+                               mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")), add1c=c)
         return zbuf, plan, emb_t, goal, z16, meta
     w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
     s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
@@ -655,25 +666,32 @@ class DecoderRNNFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+    def forward(ctx, plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, time_major_out: bool = False,
+                emb_tm: bool = False):
+        """time_major_out: return h1 as the (S*B, H) column slice of the state buffer it already lies in (row = step * B + batch row, row
+        stride 2H) instead of a (B, S, H) copy; the incoming gradient then has the same time-major row order.
+        emb_tm: `emb` is the (S, B, hi - lo) time-major slice itself; its gradient comes back in the same layout."""
         zbuf, plan, emb_t, goal, z16, meta = _decoder_rnn_forward(plan, emb, goal, lo, hi, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1,
-                                                                 b_ih1, b_hh1, None)
+                                                                 b_ih1, b_hh1, None, emb_tm)
         B, S, Hd = meta[0], meta[1], meta[2]
+        ctx.time_major = bool(time_major_out)
         ctx.persistent = z16 is not None
         ctx.z16 = z16                                      # bf16 mirror of zbuf written by the persistent kernel (weight-gradient operand)
         ctx.save_for_backward(plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1)
         ctx.biases = (b_ih0, b_hh0, b_ih1, b_hh1)          # only their identity is needed (gradient sinks)
         ctx.meta = meta
+        if time_major_out:
+            return zbuf[2:S + 2].view(S * B, 2 * Hd)[:, Hd:]                       # (S*B, H) view, row stride 2H
         return zbuf[2:S + 2, :, Hd:].permute(1, 0, 2).contiguous()                 # (B, S, H) for the heads
 
     @staticmethod
     def backward(ctx, dH1):
         plan, emb_t, goal, zbuf, w_ih0, w_hh0, w_ih1, w_hh1 = ctx.saved_tensors
-        B, S, Hd, P, G, E, lo, hi, Etot = ctx.meta
+        B, S, Hd, P, G, E, lo, hi, Etot, emb_tm = ctx.meta
         dev = dH1.device
         Kin = w_ih0.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
-        dH1_t = dH1.permute(1, 0, 2).contiguous()                                  # (S, B, H) time-major
+        dH1_t = _c(dH1).view(S, B, Hd) if ctx.time_major else dH1.permute(1, 0, 2).contiguous()     # (S, B, H) time-major
         if ctx.persistent:                                                         # the kernel writes rows S..0; row S+1 is its zero start
             dbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)
             dbuf[S + 1].zero_()
@@ -783,9 +801,62 @@ class DecoderRNNFn(torch.autograd.Function):
         kn.gemm(dc, wih0_t[P + E:], dgoal, B, G, Hd, 2 * Hd, Hd, G)
         demb_t = torch.empty(S, B, E, **f32)
         kn.gemm(d0, wih0_t[P:P + E], demb_t, M, E, Hd, 2 * Hd, Hd, E)
-        demb = torch.zeros(B, S, Etot, **f32)
-        demb[:, :, lo:hi] = demb_t.permute(1, 0, 2)
-        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1)
+        if emb_tm:
+            demb = demb_t
+        else:
+            demb = torch.zeros(B, S, Etot, **f32)
+            demb[:, :, lo:hi] = demb_t.permute(1, 0, 2)
+        return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1, None, None)
+
+
+class EmbFanoutFn(torch.autograd.Function):
+    """emb (N, S, D) -> (emb[:, 0], emb[:n_last, -1], emb, emb[:, :, lo:hi] time-major (S, N, hi-lo)): the four views Hulc2.training_step
+    hands to the prior, the visual goal encoder, the posterior and the action decoder (hulc2.py:380-387).  One gather launch forward,
+    one merge launch backward (csrc/pointwise.hip: emb_fanout_fwd / emb_fanin_bwd)."""
+
+    @staticmethod
+    def forward(ctx, emb, n_last: int, lo: int, hi: int):
+        emb = _c(emb)
+        N, S, D = emb.shape
+        e0, elast = _f32(N, D, like=emb), _f32(max(n_last, 1), D, like=emb)
+        edec = _f32(S, N, hi - lo, like=emb)
+        kn.emb_fanout_fwd(emb, N, S, D, n_last, lo, hi, e0, elast if n_last > 0 else None, edec)
+        ctx.meta = (N, S, D, n_last, lo, hi)
+        return e0, elast[:n_last], emb.view_as(emb), edec
+
+    @staticmethod
+    def backward(ctx, g0, glast, grec, gdec):
+        N, S, D, n_last, lo, hi = ctx.meta
+        like = next(g for g in (g0, glast, grec, gdec) if g is not None)
+        demb = _f32(N, S, D, like=like)
+        c = lambda t: None if t is None else _c(t)
+        kn.emb_fanin_bwd(c(grec), c(g0), c(glast) if n_last > 0 else None, c(gdec), N, S, D, n_last, lo, hi, demb)
+        return demb, None, None, None
+
+
+class LossCombineFn(torch.autograd.Function):
+    """(kl_loss[m], action_loss[m], clip) -> total (0-dim), logs (3 + n) = {kl mean, action mean, beta * clip, per-modality totals}; hulc2.py:400-430.
+    Only `total` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, kls, acts, clip, beta: float):
+        kls, acts = _c(kls), _c(acts)
+        n = kls.numel()
+        out = _f32(4 + n, like=kls)
+        kn.loss_combine_fwd(kls, acts, None if clip is None else clip.reshape(1), n, beta, out)
+        ctx.meta = (n, beta, clip is not None)
+        total, logs = out[0], out[1:]                      # two outputs (views of one buffer made here): no select-backward nodes later
+        ctx.mark_non_differentiable(logs)
+        return total, logs
+
+    @staticmethod
+    def backward(ctx, g, _glogs):
+        n, beta, has_clip = ctx.meta
+        g = _c(g.reshape(1))
+        dk, da = _f32(n, like=g), _f32(n, like=g)
+        dc = _f32(1, like=g) if has_clip else None
+        kn.loss_combine_bwd(g, n, beta, dk, da, dc)          # g[0] = d total (the other outputs are logged values, detached by the caller)
+        return dk, da, (dc.reshape(()) if has_clip else None), None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -796,22 +867,24 @@ class MixLossFn(torch.autograd.Function):
     mean over its own T/nseg tokens (nseg = 1: the reference's single mean; nseg = 2: vis and lang batched together)."""
 
     @staticmethod
-    def forward(ctx, y, act, act_min, act_max, n_mix: int, num_classes: int, log_scale_min: float, gripper_alpha: float, nseg: int = 1):
+    def forward(ctx, y, act, act_min, act_max, n_mix: int, num_classes: int, log_scale_min: float, gripper_alpha: float, nseg: int = 1,
+                time_major_B: int = 0):
+        """time_major_B > 0: the rows of y / act are time-major (row = step * B + batch row, the order the recurrent kernel produces)"""
         y, act = _c(y), _c(act)
         T, A = act.shape[0], act.shape[1] - 1
         out = _f32(nseg, 3, like=y)
         cfg = (T, A, n_mix, num_classes, y.stride(0), log_scale_min, gripper_alpha)
-        kn.mix_loss_fwd(y, act, out, *cfg, act_min, act_max, nseg=nseg)
+        kn.mix_loss_fwd(y, act, out, *cfg, act_min, act_max, nseg=nseg, time_major_B=time_major_B)
         ctx.save_for_backward(y, act, act_min, act_max)
-        ctx.cfg, ctx.nseg = cfg, nseg
+        ctx.cfg, ctx.nseg, ctx.tmb = cfg, nseg, time_major_B
         return out[:, 0].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         y, act, act_min, act_max = ctx.saved_tensors
-        dy = torch.zeros_like(y)           # pad columns (beyond 3*A*n_mix + 2) must carry zero gradient
-        kn.mix_loss_bwd(y, act, _c(g.reshape(ctx.nseg)), dy, dy.stride(0), *ctx.cfg, act_min, act_max, nseg=ctx.nseg)
-        return dy, None, None, None, None, None, None, None, None
+        dy = torch.empty_like(y)           # the kernel writes every column (pad columns beyond 3*A*n_mix + 2 as zeros)
+        kn.mix_loss_bwd(y, act, _c(g.reshape(ctx.nseg)), dy, dy.stride(0), *ctx.cfg, act_min, act_max, nseg=ctx.nseg, time_major_B=ctx.tmb)
+        return dy, None, None, None, None, None, None, None, None, None
 
 
 class CatKLFn(torch.autograd.Function):

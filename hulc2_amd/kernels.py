@@ -479,9 +479,10 @@ def attention_bwd(qkv, probs, dout, dqkv, B, S, H, head_dim, drop_p, seed):
     _call("hulc_attention_bwd", qkv, probs, dout, dqkv, _i(B), _i(S), _i(H), _i(head_dim), _f(drop_p), _u64(seed), _sd(qkv, drop_p))
 
 
-def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
+def _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1, time_major_B=0):
     d = _L.MixDesc()
     d.T, d.A, d.n_mix, d.num_classes, d.ld, d.nseg = T, A, n_mix, num_classes, ld, nseg
+    d.time_major_B = int(time_major_B)
     d.log_scale_min, d.gripper_alpha = log_scale_min, gripper_alpha
     _require_cuda(act_min, act_max)
     d.act_min, d.act_max = act_min.data_ptr(), act_max.data_ptr()
@@ -598,7 +599,7 @@ def transpose_bf16_tiles(src, dst, tiles):
 
 
 def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1_step=0, ld_add1=0, bias1=(None, None), bias2=(None, None),
-                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False, mirror_t=False):
+                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False, mirror_t=False, add1c=None):
     """Both RNN layers of one direction as one persistent kernel (csrc/rnn_wavefront.hip).  z0: view of the (zero) state row
     wave step 0 reads; rows advance by z_step elements.  Weights are bf16 (H, H) matrices, `transposed` applies to all three."""
     for w in (wA, wB1, wB2):
@@ -617,6 +618,7 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     d.relu, d.S, d.B, d.H = int(relu), int(S), int(B), int(H)
     d.mirror_t = int(bool(mirror_t))
     d.err_sticky = fault_word(z0.device).data_ptr()
+    d.add1c, d.ld_add1c = (add1c.data_ptr(), add1c.stride(0)) if add1c is not None else (None, 0)
     lib = _L.load()
     lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)
@@ -636,17 +638,18 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     return z16, z16t      # bf16 mirror of the S+2 state rows
 
 
-def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
-    """out: (nseg, 3) = {total, nll_mean, ce_mean} per segment of T / nseg tokens."""
-    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg)
+def mix_loss_fwd(y, act, out, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1, time_major_B=0):
+    """out: (nseg, 3) = {total, nll_mean, ce_mean} per segment of T / nseg tokens (time_major_B: see hulc_mix_desc)."""
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg, time_major_B)
     lib = _L.load()
     lib.hulc_mix_loss_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_mix_loss_workspace(_c.byref(d)), y.device)
     _call("hulc_mix_loss_fwd", _c.byref(d), y, act, out, ws)
 
 
-def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1):
-    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg)
+def mix_loss_bwd(y, act, gout, dy, ld_dy, T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg=1, time_major_B=0):
+    """writes every column of dy (the pad columns beyond 3 * A * n_mix + 2 as zeros)"""
+    d = _mix_desc(T, A, n_mix, num_classes, ld, log_scale_min, gripper_alpha, act_min, act_max, nseg, time_major_B)
     _call("hulc_mix_loss_bwd", _c.byref(d), y, act, gout, dy, _l(ld_dy))
 
 
@@ -673,6 +676,22 @@ def clip_loss_fwd(im, tx, use, logit_scale, M, D, out):
 
 def clip_loss_bwd(im, tx, use, logit_scale, M, D, gout, dim, dtx, dscale):
     _call("hulc_clip_loss_bwd", im, tx, use, logit_scale, _i(M), _i(D), gout, dim, dtx, dscale)
+
+
+def loss_combine_fwd(kls, acts, clip, n, beta, out):
+    _call("hulc_loss_combine_fwd", kls, acts, clip, _i(n), _f(beta), out)
+
+
+def loss_combine_bwd(g, n, beta, dkls, dacts, dclip):
+    _call("hulc_loss_combine_bwd", g, _i(n), _f(beta), dkls, dacts, dclip)
+
+
+def emb_fanout_fwd(emb, N, S, D, n_last, lo, hi, e0, elast, edec_t):
+    _call("hulc_emb_fanout_fwd", emb, _i(N), _i(S), _i(D), _i(n_last), _i(lo), _i(hi), e0, elast, edec_t)
+
+
+def emb_fanin_bwd(g_rec, g0, g_last, g_dec_t, N, S, D, n_last, lo, hi, demb):
+    _call("hulc_emb_fanin_bwd", g_rec, g0, g_last, g_dec_t, _i(N), _i(S), _i(D), _i(n_last), _i(lo), _i(hi), demb)
 
 
 def world_to_tcp(act, robot_obs, n, obs_dim, out):

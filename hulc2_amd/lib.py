@@ -92,6 +92,7 @@ class RnnWaveDesc(ctypes.Structure):
         ("mask2", ctypes.c_void_p), ("mask2_step", ctypes.c_long), ("ld_mask2", ctypes.c_long),
         ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int), ("mirror_t", ctypes.c_int),
         ("err_sticky", ctypes.c_void_p),
+        ("add1c", ctypes.c_void_p), ("ld_add1c", ctypes.c_long),
     ]
 
 
@@ -101,6 +102,7 @@ class MixDesc(ctypes.Structure):
         ("ld", ctypes.c_long),
         ("log_scale_min", ctypes.c_float), ("gripper_alpha", ctypes.c_float),
         ("act_min", ctypes.c_void_p), ("act_max", ctypes.c_void_p),
+        ("time_major_B", ctypes.c_int),
     ]
 
 

@@ -84,11 +84,11 @@ class LogisticDecoderRNN(ActionDecoder):
                        self.prob_fc.bias.new_zeros(pad)], dim=0)
         return HF.mlp(h.reshape(-1, h.shape[-1]), [(w, b, False)])
 
-    def _rnn(self, latent_plan, perceptual_emb, latent_goal) -> torch.Tensor:
+    def _rnn(self, latent_plan, perceptual_emb, latent_goal, time_major: bool = False, emb_tm: bool = False) -> torch.Tensor:
         r = self.rnn
         lo, hi = self.perceptual_emb_slice
         return HF.DecoderRNNFn.apply(latent_plan, perceptual_emb, latent_goal, lo, hi, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0,
-                                     r.bias_hh_l0, r.weight_ih_l1, r.weight_hh_l1, r.bias_ih_l1, r.bias_hh_l1)
+                                     r.bias_hh_l0, r.weight_ih_l1, r.weight_hh_l1, r.bias_ih_l1, r.bias_hh_l1, time_major, emb_tm)
 
     def loss(self, latent_plan, perceptual_emb, latent_goal, actions, robot_obs) -> torch.Tensor:
         return self.loss_segments([latent_plan], [perceptual_emb], [latent_goal], [actions], [robot_obs])[0]
@@ -104,13 +104,18 @@ class LogisticDecoderRNN(ActionDecoder):
         cat = (lambda ts: ts[0] if n == 1 else torch.cat(ts, dim=0))
         return self.loss_stacked(cat(plans), cat(embs), cat(goals), cat(actions), cat(robot_obs), n)
 
-    def loss_stacked(self, plan, emb, goal, act, obs, n: int = 1) -> torch.Tensor:
-        """`loss_segments` on inputs that are already stacked on the batch axis (n equal segments, rows segment-major)"""
-        y = self._heads(self._rnn(plan, emb, goal))
+    def loss_stacked(self, plan, emb, goal, act, obs, n: int = 1, emb_tm: bool = False) -> torch.Tensor:
+        """`loss_segments` on inputs that are already stacked on the batch axis (n equal segments, rows segment-major).
+        emb_tm: `emb` is the decoder's embedding slice in time-major order (S, B, hi - lo), as EmbFanoutFn hands it over."""
+        # training path: everything after the recurrence stays in the time-major row order the recurrent kernel leaves behind (row = step * B
+        # + batch row): the heads read h1 in place, the loss maps rows to modality segments itself — no (B, S, 2048) transposes either way
+        B, S = (emb.shape[1], emb.shape[0]) if emb_tm else (emb.shape[0], emb.shape[1])
+        y = self._heads(self._rnn(plan, emb, goal, time_major=True, emb_tm=emb_tm))  # (S*B, heads)
         acts = HF.world_to_tcp_frame(act, obs) if self.gripper_control else act
-        return HF.MixLossFn.apply(y, acts.reshape(-1, acts.shape[-1]), self.action_min_bound[0, 0, :, 0].contiguous(),
+        acts_t = acts.transpose(0, 1).contiguous().reshape(S * B, acts.shape[-1])  # 7 floats per token
+        return HF.MixLossFn.apply(y, acts_t, self.action_min_bound[0, 0, :, 0].contiguous(),
                                   self.action_max_bound[0, 0, :, 0].contiguous(), self.n_dist, self.num_classes,
-                                  float(self.log_scale_min), float(self.gripper_alpha), n)
+                                  float(self.log_scale_min), float(self.gripper_alpha), n, B)
 
     def forward(self, latent_plan, perceptual_emb, latent_goal, h_0: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

@@ -109,22 +109,35 @@ class Hulc2(LightningModule):
         # shape are stacked on the batch axis through every shared network (same per-row arithmetic, half the launches); only
         # the goal encoders differ per modality, and every loss is still the mean over its own modality's rows.
         per = []
+        kl_stacked = None
         mods = list(batch.items())
         if self._batchable(mods):
             emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
             B = mods[0][1]["actions"].shape[0]
-            embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
-            goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
+            # the embedding's four consumers get their views from one fan-out node (one gather launch forward, ONE merge launch backward
+            # instead of autograd's select / slice backward fills and three accumulate adds): emb[:, 0] -> prior, emb[:B, -1] of a leading
+            # vision modality -> visual goal encoder, emb -> posterior, emb[..., lo:hi] time-major -> action decoder
+            vis_first = "lang" not in mods[0][0] and all("lang" in sc for sc, _ in mods[1:])
+            lo, hi = self.action_decoder.perceptual_emb_slice
+            fan = vis_first and emb_all.is_cuda
+            if fan:
+                emb0, emb_last, emb_rec, emb_dec_t = HF.EmbFanoutFn.apply(emb_all, B, lo, hi)
+                goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(emb_last) for scope, db in mods]
+            else:
+                embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
+                emb0, emb_rec = emb_all[:, 0], emb_all
+                goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
             goal_all = torch.cat(goals, dim=0)
-            pp_all = self.plan_proposal(emb_all[:, 0], goal_all)
-            pr_all, seq_all = self.plan_recognition(emb_all)
+            pp_all = self.plan_proposal(emb0, goal_all)
+            pr_all, seq_all = self.plan_recognition(emb_rec)
             # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality
             idxs = [db.get("plan_idx") for _, db in mods]
             idx_all = torch.cat(idxs, dim=0) if all(i is not None for i in idxs) else None
             plan_all, _ = self.dist.rsample_plan(pr_all, seed=0xA11CE, idx=idx_all)
-            kls = self.dist.kl_balanced_segments(pp_all, pr_all, self.kl_beta, self.kl_balancing_mix, len(mods))
-            act_losses = self.action_decoder.loss_stacked(plan_all, emb_all, goal_all, torch.cat([db["actions"] for _, db in mods], dim=0),
-                                                          torch.cat([db["state_info"]["robot_obs"] for _, db in mods], dim=0), len(mods))
+            kls = kl_stacked = self.dist.kl_balanced_segments(pp_all, pr_all, self.kl_beta, self.kl_balancing_mix, len(mods))
+            act_losses = self.action_decoder.loss_stacked(plan_all, emb_dec_t if fan else emb_all, goal_all,
+                                                          torch.cat([db["actions"] for _, db in mods], dim=0),
+                                                          torch.cat([db["state_info"]["robot_obs"] for _, db in mods], dim=0), len(mods), emb_tm=fan)
             for i, (self.modality_scope, db) in enumerate(mods):
                 per.append((self.modality_scope, db, None, goals[i], seq_all[i * B:(i + 1) * B], None, kls[i]))
         else:
@@ -140,28 +153,31 @@ class Hulc2(LightningModule):
             # modality, each the mean over that modality's own tokens as in the reference (hulc2.py:239-241)
             act_losses = self.action_decoder.loss_segments([p[5] for p in per], [p[2] for p in per], [p[3] for p in per],
                                                            [p[1]["actions"] for p in per], [p[1]["state_info"]["robot_obs"] for p in per])
+        # the scalar tail (hulc2.py:400-430) is one launch per direction: total = (sum act + sum kl) / n + beta * clip
         for i, (self.modality_scope, db, emb, latent_goal, seq_feat, plan, kl) in enumerate(per):
-            act_loss = act_losses[i]
-            mod_loss = act_loss + kl
             if "lang" in self.modality_scope:
                 batch_size["aux_lang"] = db["actions"].shape[0]
                 if self.use_clip_auxiliary_loss:
                     lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"]))
-            kl_loss, action_loss, total_loss = acc(kl_loss, kl), acc(action_loss, act_loss), acc(total_loss, mod_loss)
             bs = db["actions"].shape[0]
             batch_size[self.modality_scope] = bs
             total_bs += bs
-            self.log(f"train/kl_loss_scaled_{self.modality_scope}", kl, on_step=False, on_epoch=True, batch_size=bs)
-            self.log(f"train/action_loss_{self.modality_scope}", act_loss, on_step=False, on_epoch=True, batch_size=bs)
-            self.log(f"train/total_loss_{self.modality_scope}", mod_loss, on_step=False, on_epoch=True, batch_size=bs)
         n = len(batch)
-        total_loss, kl_loss, action_loss = total_loss / n, kl_loss / n, action_loss / n
-        if self.use_clip_auxiliary_loss and lang_clip_loss is not None:
-            total_loss = total_loss + self.clip_auxiliary_loss_beta * lang_clip_loss
-            self.log("train/lang_clip_loss", self.clip_auxiliary_loss_beta * lang_clip_loss, on_step=False, on_epoch=True,
+        kl_vec = kl_stacked if kl_stacked is not None else torch.stack([p[6].reshape(()) for p in per])
+        act_vec = act_losses if act_losses.dim() == 1 else act_losses.reshape(-1)
+        clip_term = lang_clip_loss if (self.use_clip_auxiliary_loss and lang_clip_loss is not None) else None
+        total_loss, logs = HF.LossCombineFn.apply(kl_vec, act_vec, clip_term, float(self.clip_auxiliary_loss_beta))
+        kl_d, act_d = kl_vec.detach(), act_vec.detach()
+        for i, (scope, db, *_rest) in enumerate(per):
+            bs = db["actions"].shape[0]
+            self.log(f"train/kl_loss_scaled_{scope}", kl_d[i], on_step=False, on_epoch=True, batch_size=bs)
+            self.log(f"train/action_loss_{scope}", act_d[i], on_step=False, on_epoch=True, batch_size=bs)
+            self.log(f"train/total_loss_{scope}", logs[3 + i], on_step=False, on_epoch=True, batch_size=bs)
+        if clip_term is not None:
+            self.log("train/lang_clip_loss", logs[2], on_step=False, on_epoch=True,
                      batch_size=batch_size.get("aux_lang", 1), sync_dist=True)
-        self.log("train/kl_loss", kl_loss, on_step=False, on_epoch=True, batch_size=total_bs)
-        self.log("train/action_loss", action_loss, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/kl_loss", logs[0], on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/action_loss", logs[1], on_step=False, on_epoch=True, batch_size=total_bs)
         self.log("train/total_loss", total_loss, on_step=False, on_epoch=True, batch_size=total_bs)
         return total_loss
 

@@ -153,6 +153,8 @@ typedef struct {
     long ld;
     float log_scale_min, gripper_alpha;
     const float* act_min; const float* act_max;   /* device [A] */
+    int time_major_B;   /* 0: rows are batch-major, segment seg = rows [seg T/nseg, (seg+1) T/nseg); B > 0: rows are time-major (row = step * B +
+                         * batch row, what the recurrent kernel leaves behind) and segment seg = batch rows [seg B/nseg, (seg+1) B/nseg) of every step */
 } hulc_mix_desc;
 long hulc_mix_loss_workspace(const hulc_mix_desc* d);
 int hulc_mix_loss_fwd(const hulc_mix_desc* d, const float* y, const float* act, float* out, void* ws, void* stream);
@@ -174,6 +176,16 @@ int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* us
                        float* out, void* stream);
 int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
                        const float* gout, float* dim, float* dtx, float* dscale, void* stream);
+/* The scalar tail of Hulc2.training_step (hulc2.py:400-430): total = (sum_m action_loss[m] + sum_m kl_loss[m]) / n + beta * clip (clip may be
+ * NULL).  out (4 + n) = {total, kl mean, action mean, beta * clip, action_loss[m] + kl_loss[m] ...}: everything the step logs.  bwd: g = d total. */
+int hulc_loss_combine_fwd(const float* kls, const float* acts, const float* clip, int n, float beta, float* out, void* stream);
+int hulc_loss_combine_bwd(const float* g, int n, float beta, float* dkls, float* dacts, float* dclip, void* stream);
+/* Fan-out of the perceptual embedding emb (N, S, D) to its consumers (hulc2.py:380-387, :228-231): e0 (N, D) = emb[:, 0] (prior),
+ * elast (n_last, D) = emb[:n_last, -1] (visual goal encoder), edec_t (S, N, hi - lo) = emb[:, :, lo:hi] time-major (action decoder,
+ * logistic_decoder_rnn.py:262-266); the posterior reads emb itself.  bwd: demb = g_rec + the three scattered gradients (any may be NULL). */
+int hulc_emb_fanout_fwd(const float* emb, int N, int S, int D, int n_last, int lo, int hi, float* e0, float* elast, float* edec_t, void* stream);
+int hulc_emb_fanin_bwd(const float* g_rec, const float* g0, const float* g_last, const float* g_dec_t, int N, int S, int D, int n_last, int lo, int hi,
+                       float* demb, void* stream);
 /* Relative actions world -> tcp frame, act[n][7], robot_obs[n][obs_dim] (euler angles in 3:6),
  * gripper_control.py:16-36 (pytorch3d XYZ convention restated; parity unpinned). */
 int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
@@ -307,6 +319,8 @@ typedef struct hulc_rnn_wave_desc {
     int mirror_t;   /* also write the transposed bf16 mirror (hulc_rnn_wavefront_mirror_t_offset); needs B % 8 == 0 */
     int* err_sticky; /* optional device word set to 1 on a barrier timeout and never cleared by the kernels: the host polls it
                       * (and hulc_adam_step skips its update while it is set) so a timeout ends the job instead of feeding NaN to Adam */
+    const float* add1c; long ld_add1c;   /* optional (B x H, row stride ld_add1c): a per-row term of the first half that is the same at every
+                                          * wave step — the plan / goal part of the layer-0 input projection, constant over a sequence */
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
 long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */
