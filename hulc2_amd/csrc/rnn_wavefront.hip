@@ -266,11 +266,16 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 // nothing but kernel nodes with plain pointer arguments (a captured hipMemsetAsync node
 // was found to leave the barrier header un-zeroed on later replays once other allocations ran in between: NaN from replay 2 on, round 2;
 // HULC_RNN_MEMSET=1 restores the memset calls to reproduce it)
-__global__ __launch_bounds__(256) void rnn_prep_kernel(uint4* __restrict__ a, long na, uint4* __restrict__ b, long nb) {
+__global__ __launch_bounds__(256) void rnn_prep_kernel(uint4* __restrict__ a, long na, uint4* __restrict__ b, long nb, float4* __restrict__ z0, long nz0,
+                                                       float* __restrict__ zl, int B, int H) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     if (i < na) a[i] = z;
     if (i < nb) b[i] = z;
+    // the fp32 state rows the sweep reads but never writes: the initial row (B x 2H) and the FIRST half of the last row (its second half is
+    // the sweep's final output) — were four torch fill launches per step
+    if (z0 && i < nz0) z0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zl && i < (long)B * H / 4) { const long e = i * 4; *(float4*)(zl + (e / H) * 2 * H + e % H) = make_float4(0.f, 0.f, 0.f, 0.f); }
 }
 
 // rows x width bf16 elements at row pitch `pitch` <- 0 (initial-state column block of the transposed mirror)
@@ -320,8 +325,12 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     } else {
         if ((uintptr_t)ws % 16 || RNN_WS_HEADER % 16) return hulc_fail(-4, "hulc_rnn_wavefront: workspace must be 16-byte aligned");
         const long na = RNN_WS_HEADER / 16, nb = (long)d->B * 2 * d->H * 2 / 16;
-        const long n = na > nb ? na : nb;
-        rnn_prep_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((uint4*)ws, na, (uint4*)(p.zb + (long)p.zb_row0 * d->B * 2 * d->H), nb);
+        const long nz0 = d->zero_edges ? (long)d->B * 2 * d->H / 4 : 0;
+        long n = na > nb ? na : nb;
+        if (nz0 > n) n = nz0;
+        float* zlast = d->zero_edges ? d->z + (long)(d->S + 1) * d->z_step : nullptr;       // row S+1 of the sweep
+        rnn_prep_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((uint4*)ws, na, (uint4*)(p.zb + (long)p.zb_row0 * d->B * 2 * d->H), nb,
+                                                                  d->zero_edges ? (float4*)d->z : nullptr, nz0, zlast, d->B, d->H);
     }
     if (p.zt) {
         const long n = 2L * d->H * d->B;

@@ -610,9 +610,7 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
     if persistent:
         # the persistent kernel writes every row it owns (rows 1..S+1, zeros included): only the initial row and the half of the last
         # row it never produces are cleared, not 36 MB
-        zbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zdt, device=dev)            # zbuf[t+1] = [h0_t | h1_{t-1}]
-        zbuf[0].zero_()
-        zbuf[S + 1][:, :Hd].zero_()
+        zbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zdt, device=dev)            # zbuf[t+1] = [h0_t | h1_{t-1}]; edges cleared by the launcher
     else:
         zbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zdt, device=dev)
     if h0 is not None:                                                         # carried state: h0_{-1} and h1_{-1}
@@ -624,7 +622,7 @@ def _decoder_rnn_forward(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0,
         # both layers, all S steps: one persistent kernel with register-resident weights (csrc/rnn_wavefront.hip)
         z16 = kn.rnn_wavefront(zbuf[0], B * 2 * Hd, S, B, Hd, whh0, weight_operand(w_ih1), weight_operand(w_hh1), False,
                                add1=pre0, add1_step=B * Hd, ld_add1=Hd, bias1=(b_hh0, None), bias2=(b_ih1, b_hh1), relu=True,
-                               mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")), add1c=c)
+                               mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")), add1c=c, zero_edges=True)
         return zbuf, plan, emb_t, goal, z16, meta
     w1cat = weight_operand(torch.cat([w_ih1.detach(), w_hh1.detach()], dim=1))   # (H, 2H) = [W_ih1 | W_hh1]
     s0, s1 = torch.cuda.current_stream(dev), kn.side_stream(dev)
@@ -693,9 +691,7 @@ class DecoderRNNFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         dH1_t = _c(dH1).view(S, B, Hd) if ctx.time_major else dH1.permute(1, 0, 2).contiguous()     # (S, B, H) time-major
         if ctx.persistent:                                                         # the kernel writes rows S..0; row S+1 is its zero start
-            dbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)
-            dbuf[S + 1].zero_()
-            dbuf[0][:, :Hd].zero_()
+            dbuf = torch.empty(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)     # edges (row S+1, first half of row 0) cleared by the launcher
         else:
             dbuf = torch.zeros(S + 2, B, 2 * Hd, dtype=zbuf.dtype, device=dev)     # dbuf[t+1][:, :H] = delta1_t, dbuf[t][:, H:] = delta0_t
         if ctx.persistent:
@@ -704,7 +700,7 @@ class DecoderRNNFn(torch.autograd.Function):
                                    add1=dH1_t[S - 1], add1_step=-B * Hd, ld_add1=Hd,
                                    mask1=zbuf[S + 1][:, Hd:], mask1_step=-B * 2 * Hd, ld_mask1=2 * Hd,
                                    mask2=zbuf[S + 1][:, :Hd], mask2_step=-B * 2 * Hd, ld_mask2=2 * Hd,
-                                   mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")))
+                                   mirror_t=bool(os.environ.get("HULC_RNN_WGRAD_TMIRROR")), zero_edges=True)
         else:
             whh1_t = weight_operand(w_hh1, "t")
             wb0 = weight_operand(torch.cat([w_ih1.detach().t(), w_hh0.detach().t()], dim=1))   # (H, 2H) = [W_ih1^T | W_hh0^T]

@@ -599,7 +599,7 @@ def transpose_bf16_tiles(src, dst, tiles):
 
 
 def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1_step=0, ld_add1=0, bias1=(None, None), bias2=(None, None),
-                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False, mirror_t=False, add1c=None):
+                  mask1=None, mask1_step=0, ld_mask1=0, mask2=None, mask2_step=0, ld_mask2=0, relu=False, mirror_t=False, add1c=None, zero_edges=False):
     """Both RNN layers of one direction as one persistent kernel (csrc/rnn_wavefront.hip).  z0: view of the (zero) state row
     wave step 0 reads; rows advance by z_step elements.  Weights are bf16 (H, H) matrices, `transposed` applies to all three."""
     for w in (wA, wB1, wB2):
@@ -619,6 +619,7 @@ def rnn_wavefront(z0, z_step, S, B, H, wA, wB1, wB2, transposed, add1=None, add1
     d.mirror_t = int(bool(mirror_t))
     d.err_sticky = fault_word(z0.device).data_ptr()
     d.add1c, d.ld_add1c = (add1c.data_ptr(), add1c.stride(0)) if add1c is not None else (None, 0)
+    d.zero_edges = int(bool(zero_edges))
     lib = _L.load()
     lib.hulc_rnn_wavefront_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_rnn_wavefront_workspace(_i(S), _i(B), _i(H)), z0.device)

@@ -93,6 +93,7 @@ class RnnWaveDesc(ctypes.Structure):
         ("relu", ctypes.c_int), ("S", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int), ("mirror_t", ctypes.c_int),
         ("err_sticky", ctypes.c_void_p),
         ("add1c", ctypes.c_void_p), ("ld_add1c", ctypes.c_long),
+        ("zero_edges", ctypes.c_int),
     ]
 
 

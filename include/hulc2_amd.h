@@ -321,6 +321,8 @@ typedef struct hulc_rnn_wave_desc {
                       * (and hulc_adam_step skips its update while it is set) so a timeout ends the job instead of feeding NaN to Adam */
     const float* add1c; long ld_add1c;   /* optional (B x H, row stride ld_add1c): a per-row term of the first half that is the same at every
                                           * wave step — the plan / goal part of the layer-0 input projection, constant over a sequence */
+    int zero_edges;   /* also clear the two fp32 pieces the sweep reads / exposes without writing: row 0 (the zero initial state) and the first
+                       * half of row S+1 — the caller then hands in an uninitialised buffer */
 } hulc_rnn_wave_desc;
 long hulc_rnn_wavefront_workspace(int S, int B, int H);
 long hulc_rnn_wavefront_mirror_offset(void);   /* byte offset of the bf16 state mirror (S+2, B, 2H) inside ws */
