@@ -252,8 +252,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # HULC_BENCH_BACKEND=gloo: functional check of the multi-rank control flow on a box with fewer GPUs than ranks (ranks then share devices;
-    # run it with HULC_NO_RNN_WAVEFRONT=1 — the device-wide-barrier kernel needs the GPU to itself).  The measured configuration is nccl (= RCCL).
+    # the device-wide-barrier kernels need the GPU to themselves and are switched off then).  The measured configuration is nccl (= RCCL).
     backend = os.environ.get("HULC_BENCH_BACKEND", "nccl")
+    if backend != "nccl" and world > torch.cuda.device_count():
+        os.environ["HULC_NO_RNN_WAVEFRONT"] = os.environ["HULC_NO_MLP_CHAIN"] = "1"
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

@@ -1,0 +1,241 @@
+// mlp_chain.hip — a whole stack of Linear(+ReLU) layers on M <= 64 rows as ONE persistent launch (bf16 MFMA, fp32 accumulate).
+//
+// reference arithmetic: the per-sequence MLPs of the policy — PlanProposalNetwork.fc_model + fc_state (plan_proposal_net.py:26-47),
+// Visual/LanguageGoalEncoder.mlp (goal_encoders.py:21-34,53-71), ProjVisLang (proj_vis_lang.py:10-21), the posterior's fc -> fc_state
+// (plan_recognition_net.py:122-123,144-148) — and, with W^T and the stored activations as masks, the data-gradient chain of their backward.
+//
+// At 64 rows a 2048 x 2048 layer is 0.5 GFLOP and 8 MB of weights: as its own launch it costs ~10 us + a ~5 us split-K epilogue, all of it
+// latency.  Here the launch is paid once per chain:
+//   * 256 workgroups, one 16-column output tile of the current layer each (N / 16 tiles; idle workgroups still join the barriers);
+//     4 waves split K, 16x16x32 MFMA tiles, a fixed-order LDS reduction, bias / ReLU / mask epilogue;
+//   * the tile's weight fragments are requested BEFORE the wait for the previous layer (weights depend on nothing), so the barrier wait
+//     hides their HBM latency;
+//   * layer outputs are exchanged through L2 as bf16 in the blocked layout [k / 8][64 rows][8] (the 16 lanes of an MFMA k-block read 256
+//     contiguous bytes), every layer into its OWN region, written with device-scope write-through stores and read with plain loads only
+//     after the grid barrier (one arrival counter per XCD, 4 KB apart) — the exchange protocol of rnn_wavefront.hip;
+//   * every layer's fp32 output also goes to its caller-visible buffer (what autograd saves / returns).
+// Like the recurrent kernel it needs all its workgroups resident (one per CU): a barrier timeout sets the sticky fault word.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int CH_MAXL = 8;
+constexpr int CH_CTR_STRIDE = 1024;                 // unsigned words between the 8 arrival counters (4 KB)
+constexpr long CH_HEADER = 9L * CH_CTR_STRIDE * 4;   // 8 counters + the error word
+
+struct ChLayer {
+    const uint16_t* W; long ldw;        // bf16 [N][K], k contiguous
+    const float* bias;                  // [N] or null
+    const float* mask; long ld_mask; float mask_scale;   // out = mask > 0 ? v * mask_scale : 0   (data-gradient chain) or null
+    float* out; long ld_out;            // fp32 [M][N]
+    int N, K, relu;
+    long xb_off;                        // element offset of this layer's OUTPUT exchange region inside xb
+};
+struct ChainP {
+    ChLayer L[CH_MAXL];
+    int nl, M;
+    const float* x0; long ld_x0;        // layer 0 input, fp32 [M][K0]
+    uint16_t* xb;
+    unsigned* bar; int* err; int* err_sticky;
+};
+
+union F8 { uint4 u; bf16x8_t b; };
+HULC_DEVICE constexpr int s_of(int bi, int q, int ab) { return bi * ab + q; }
+
+__global__ __launch_bounds__(64) void chain_prep_kernel(uint4* __restrict__ hdr, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hdr[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// one layer for this workgroup's column tile; KSW = k-steps (of 32) per wave, K padded up to 128 * KSW
+template <int KSW>
+HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool first, const uint16_t* __restrict__ xin, float (*red)[64][16], int tid, bool& timed_out,
+                             int nwg) {
+    const ChLayer& c = p.L[l];
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int ntile = c.N / 16;
+    const bool active = tile < ntile;
+    const int n0 = (active ? tile : 0) * 16;
+    // ---- weight fragments of this wave's k range: requested before the wait on the previous layer
+    F8 wf[KSW];
+    {
+        const uint16_t* wrow = c.W + (long)(n0 + r) * c.ldw;
+#pragma unroll
+        for (int s = 0; s < KSW; ++s) {
+            const int k = (wave * KSW + s) * 32 + g * 8;
+            wf[s].u = *(const uint4*)(wrow + (k < c.K ? k : 0));            // clamped (always valid) address; the matching A fragment is zero
+        }
+    }
+    // ---- wait for the previous layer's outputs (all workgroups)
+    if (!first) {
+        if (tid < 8) {
+            const unsigned want = (unsigned)(nwg / 8) * (unsigned)l;
+            const unsigned* bar = p.bar + tid * CH_CTR_STRIDE;
+            long spins = 0;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1L << 22)) {
+                    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.err_sticky) __hip_atomic_fetch_or(p.err_sticky, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // bit 1 = mlp_chain
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        asm volatile("" ::: "memory");
+    }
+    // ---- products: 4 row tiles of 16, this wave's k-steps.  The A fragments are fetched a batch of k-steps ahead of the MFMAs that consume them
+    // (two register sets): left to itself the compiler loads one k-step, waits a full L2 round trip, multiplies, and repeats — 16 round trips
+    // per 2048-deep layer (16 us per layer measured)
+    f32x4_t acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int MT = (p.M + 15) / 16;
+    constexpr int AB = KSW >= 32 ? 2 : (KSW >= 4 ? 4 : KSW);            // k-steps per batch
+    constexpr int NB = KSW / AB;
+    static_assert(KSW % AB == 0, "batches tile the k range");
+    F8 af[2][AB][4];
+    auto load_batch = [&](F8 (&dst)[AB][4], int bi) {
+#pragma unroll
+        for (int q = 0; q < AB; ++q) {
+            const int k = (wave * KSW + bi * AB + q) * 32 + g * 8;
+            const bool kin = k < c.K;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = mt * 16 + r;
+                if (first) {                                                       // fp32 row-major input
+                    const float* src = p.x0 + (long)(m < p.M ? m : p.M - 1) * p.ld_x0 + (kin ? k : 0);
+                    const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+                    dst[q][mt].u = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+                } else {
+                    dst[q][mt].u = *(const uint4*)(xin + ((long)((kin ? k : 0) / 8) * 64 + m) * 8);
+                }
+            }
+        }
+    };
+    if (active) {
+        load_batch(af[0], 0);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+            if (bi + 1 < NB) load_batch(af[(bi + 1) & 1], bi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < AB; ++q) {
+                const int k = (wave * KSW + bi * AB + q) * 32 + g * 8;
+                const bool kin = k < c.K;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    F8 a = af[bi & 1][q][mt];
+                    if (!kin) a.u = make_uint4(0u, 0u, 0u, 0u);
+                    if (mt < MT) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, wf[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- fixed-order reduction over the 4 waves + epilogue: 64 x 16 outputs, 4 per thread
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][mt * 16 + g * 4 + e][r] = acc[mt][e];
+    __syncthreads();
+    if (active) {
+        const int m = tid >> 2, n4 = (tid & 3) * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (red[0][m][n4 + j] + red[1][m][n4 + j]) + (red[2][m][n4 + j] + red[3][m][n4 + j]);
+        const int mc = m < p.M ? m : p.M - 1;
+        if (c.bias) {
+            const float4 b = *(const float4*)(c.bias + n0 + n4);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (c.mask) {
+            const float4 mk = *(const float4*)(c.mask + (long)mc * c.ld_mask + n0 + n4);
+            v[0] = mk.x > 0.f ? v[0] * c.mask_scale : 0.f; v[1] = mk.y > 0.f ? v[1] * c.mask_scale : 0.f;
+            v[2] = mk.z > 0.f ? v[2] * c.mask_scale : 0.f; v[3] = mk.w > 0.f ? v[3] * c.mask_scale : 0.f;
+        } else if (c.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (m < p.M) *(float4*)(c.out + (long)m * c.ld_out + n0 + n4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (l + 1 < p.nl && m < p.M) {           // exchange copy for the next layer: [n / 8][64][8] bf16, device-scope write-through
+            uint16_t* dst = p.xb + c.xb_off + ((long)((n0 + n4) / 8) * 64 + m) * 8 + (n4 & 7);
+            const unsigned long long bits = (unsigned long long)pack_bf16x2(v[0], v[1]) | ((unsigned long long)pack_bf16x2(v[2], v[3]) << 32);
+            __hip_atomic_store((unsigned long long*)dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (l + 1 < p.nl) {                          // arrival: everybody's outputs acknowledged before anybody may read them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.bar + (blockIdx.x & 7) * CH_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __syncthreads();
+    }
+    (void)timed_out;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_chain_kernel(ChainP p) {
+    __shared__ float red[4][64][16];
+    const int tid = threadIdx.x;
+    bool timed_out = false;
+    const int nwg = gridDim.x, tile = blockIdx.x;                         // N <= 16 * gridDim: at most one tile per workgroup and layer
+    for (int l = 0; l < p.nl; ++l) {
+        const int ksw = (p.L[l].K + 127) / 128;
+        const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : nullptr;
+        switch (ksw) {
+            case 1: chain_layer<1>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 2: chain_layer<2>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 3: chain_layer<3>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 4: chain_layer<4>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 8: chain_layer<8>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 16: chain_layer<16>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            default: chain_layer<32>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d) {
+    if (!d || d->nl < 1 || d->nl > CH_MAXL) return 0;
+    long elems = 0;
+    for (int l = 0; l + 1 < d->nl; ++l) elems += (long)d->layers[l].N * 64;
+    return CH_HEADER + elems * 2 + 64;
+}
+
+// see include/hulc2_amd.h
+extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream) {
+    if (!d || !ws || !d->x0) return hulc_fail(-1, "hulc_mlp_chain: null pointer");
+    if (d->nl < 1 || d->nl > CH_MAXL) return hulc_fail(-2, "hulc_mlp_chain: 1..8 layers");
+    if (d->M < 1 || d->M > 64) return hulc_fail(-2, "hulc_mlp_chain: 1 <= M <= 64 rows");
+    if ((uintptr_t)ws % 16 || (uintptr_t)d->x0 % 16 || d->ld_x0 % 4) return hulc_fail(-4, "hulc_mlp_chain: workspace / input must be 16-byte aligned");
+    ChainP p = {};
+    p.nl = d->nl; p.M = d->M; p.x0 = d->x0; p.ld_x0 = d->ld_x0;
+    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8L * CH_CTR_STRIDE * 4); p.err_sticky = err_sticky;
+    p.xb = (uint16_t*)((char*)ws + CH_HEADER);
+    long off = 0;
+    int kin = d->K0;
+    for (int l = 0; l < d->nl; ++l) {
+        const hulc_mlp_chain_layer& s = d->layers[l];
+        if (!s.W || !s.out) return hulc_fail(-1, "hulc_mlp_chain: null layer operand");
+        if (l == 0 && kin > 512) return hulc_fail(-3, "hulc_mlp_chain: the fp32 input is gathered row by row: K0 <= 512 (wider inputs take hulc_gemm)");
+        if (s.N < 16 || s.N % 16 || s.N > 4096 || kin < 8 || kin % 8 || kin > 4096 || s.ldw % 8 || (uintptr_t)s.W % 16 || s.ld_out % 4 || (uintptr_t)s.out % 16)
+            return hulc_fail(-3, "hulc_mlp_chain: N must be a multiple of 16, K a multiple of 8 and <= 4096, operands 16-byte aligned");
+        const int ksw = (kin + 127) / 128;
+        if (!(ksw == 1 || ksw == 2 || ksw == 3 || ksw == 4 || ksw == 8 || ksw == 16 || ksw == 32))
+            return hulc_fail(-3, "hulc_mlp_chain: K must round up to 128 x {1, 2, 3, 4, 8, 16, 32}");
+        if (s.bias && (uintptr_t)s.bias % 16) return hulc_fail(-4, "hulc_mlp_chain: bias must be 16-byte aligned");
+        if (s.mask && ((uintptr_t)s.mask % 16 || s.ld_mask % 4)) return hulc_fail(-4, "hulc_mlp_chain: mask must be 16-byte aligned");
+        ChLayer& c = p.L[l];
+        c.W = (const uint16_t*)s.W; c.ldw = s.ldw; c.bias = s.bias; c.mask = s.mask; c.ld_mask = s.ld_mask; c.mask_scale = s.mask_scale;
+        c.out = s.out; c.ld_out = s.ld_out; c.N = s.N; c.K = kin; c.relu = s.relu; c.xb_off = off;
+        off += (long)s.N * 64;
+        kin = s.N;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    chain_prep_kernel<<<(unsigned)((CH_HEADER / 16 + 63) / 64), 64, 0, st>>>((uint4*)ws, CH_HEADER / 16);
+    mlp_chain_kernel<<<256, 256, 0, st>>>(p);
+    return hulc_check_launch("hulc_mlp_chain");
+}

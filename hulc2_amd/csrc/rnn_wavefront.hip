@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1L << 22)) {
                     __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (p.err_sticky) __hip_atomic_store(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (p.err_sticky) __hip_atomic_fetch_or(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // bit 0 = rnn_wavefront
                     break;
                 }
             }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
     __syncthreads();
     if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0) {        // fault injection (tests): behave as if the barrier had timed out
         __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p.err_sticky) __hip_atomic_store(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.err_sticky) __hip_atomic_fetch_or(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // bit 0 = rnn_wavefront
     }
     if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = true;
     if (timed_out) {

@@ -46,8 +46,14 @@ class MLPFn(torch.autograd.Function):
         x2 = x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else _c(x.reshape(-1, x.shape[-1]))
         M = x2.shape[0]
         acts: List[torch.Tensor] = []
+        widths = [params[2 * i].shape[0] for i in range(L)]
+        chain = (L >= 2 and not any(d > 0 for d in drops) and x2.dtype == torch.float32 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+                 and kn.mlp_chain_ok(M, x2.shape[1], widths, x2.device))
+        if chain:      # the whole stack as one persistent launch (csrc/mlp_chain.hip): no per-layer launch, no split-K epilogues
+            acts = [_f32(M, n, like=x2) for n in widths]
+            kn.mlp_chain(x2, [(weight_operand(params[2 * i]), params[2 * i + 1], relus[i], None, 1.0, acts[i]) for i in range(L)], M)
         inp = x2
-        for i in range(L):
+        for i in range(L if not chain else 0):
             W, b = params[2 * i], params[2 * i + 1]
             N, K = W.shape
             out = _f32(M, N, like=x2)
@@ -57,6 +63,7 @@ class MLPFn(torch.autograd.Function):
             inp = out
         ctx.save_for_backward(x2, *acts[:-1], *params)
         ctx.meta = (relus, drops, seed, L, x.shape)
+        ctx.chain = chain
         return acts[-1].reshape(*x.shape[:-1], acts[-1].shape[-1])
 
     @staticmethod
@@ -68,7 +75,23 @@ class MLPFn(torch.autograd.Function):
         M = g.shape[0]
         grads = [None] * (2 * L)
         need_x = ctx.needs_input_grad[0]
+        # data-gradient chain  g_{i-1} = (g_i W_i) * (act_{i-1} > 0)  as one persistent launch when the forward took that path
+        gs = {L - 1: g}
+        lo_layer = 0 if need_x else 1                       # lowest layer whose input gradient is wanted
+        n_chain = L - lo_layer
+        ks = [x2.shape[1]] + [params[2 * i].shape[0] for i in range(L - 1)]      # input width of layer i
+        if (ctx.chain and n_chain >= 2 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0
+                and kn.mlp_chain_ok(M, g.shape[1], [ks[i] for i in range(L - 1, lo_layer - 1, -1)], g.device)):
+            layers = []
+            for i in range(L - 1, lo_layer - 1, -1):
+                out = _f32(M, ks[i], like=g)
+                masked = i > 0 and relus[i - 1]
+                layers.append((weight_operand(params[2 * i], "t"), None, False, acts[i - 1] if masked else None,
+                               1.0 / (1.0 - drops[i - 1]) if masked else 1.0, out))
+                gs[i - 1] = out
+            kn.mlp_chain(g, layers, M)
         for i in range(L - 1, -1, -1):
+            g = gs[i] if i in gs else g
             W = params[2 * i]
             N, K = W.shape
             inp = x2 if i == 0 else acts[i - 1]
@@ -84,6 +107,8 @@ class MLPFn(torch.autograd.Function):
                 kn.colsum(g, M, N, g.stride(0), db, accumulate=acc_b)
             grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
             grads[2 * i + 1] = None if sb is not None else db
+            if (i - 1) in gs:
+                continue                                       # produced by the chain launch
             if i > 0 or need_x:
                 dinp = _f32(M, K, like=g)
                 wt = weight_operand(W, "t")                      # (K, N): the reduction index contiguous, like the forward pass
@@ -91,7 +116,8 @@ class MLPFn(torch.autograd.Function):
                     kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K, mask=acts[i - 1], ld_mask=K, mask_scale=1.0 / (1.0 - drops[i - 1]))
                 else:
                     kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K)
-                g = dinp
+                gs[i - 1] = dinp
+        g = gs.get(-1, g)
         dx = g.reshape(xshape) if need_x else None
         return (dx, None, None, None, *grads)
 

@@ -134,12 +134,14 @@ def check_faults(device) -> None:
     """Host check of the fault word (synchronises the device: call it where a sync happens anyway — after a timed region, every N steps).
     Raises HulcKernelError instead of letting a NaN loss propagate."""
     t = _fault.get(device)
-    if t is not None and int(t.item()) != 0:
+    w = int(t.item()) if t is not None else 0
+    if w != 0:
         t.zero_()
+        who = [n for b, n in ((1, "rnn_wavefront (HULC_NO_RNN_WAVEFRONT=1 selects the per-step GEMM path)"),
+                              (2, "mlp_chain (HULC_NO_MLP_CHAIN=1 selects the per-layer GEMM path)")) if w & b]
         raise _L.HulcKernelError(
-            "rnn_wavefront: device-wide barrier timed out — its 256 workgroups were not all resident (another kernel / process shared "
-            "the GPU, or the device is partitioned).  The optimizer update of that step was skipped.  Run with HULC_NO_RNN_WAVEFRONT=1 "
-            "to use the per-step GEMM path.")
+            "device-wide barrier timed out in " + " and ".join(who) + " — the kernel's 256 workgroups were not all resident (another "
+            "kernel / process shared the GPU, or the device is partitioned).  The optimizer update of that step was skipped.")
 
 
 _cu_count = {}
@@ -507,6 +509,48 @@ def concurrent_streams() -> bool:
 def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
     """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch on the tiled path"""
     return M > 64
+
+
+def mlp_chain_ok(M: int, K0: int, widths, device) -> bool:
+    """shapes hulc_mlp_chain takes (include/hulc2_amd.h) on a whole MI355X with nothing else sharing the GPU"""
+    import os
+    if os.environ.get("HULC_NO_MLP_CHAIN") or _compute_mode != BF16 or concurrent_streams() or device_cu_count(device) < 256:
+        return False
+    if not (1 <= M <= 64) or not (1 <= len(widths) <= 8) or K0 > 512:      # (the fp32 input is gathered row by row: narrow inputs only)
+        return False
+    k = K0
+    for n in widths:
+        if n < 16 or n % 16 or n > 4096 or k < 8 or k % 8 or k > 4096 or (k + 127) // 128 not in (1, 2, 3, 4, 8, 16, 32):
+            return False
+        k = n
+    return True
+
+
+def mlp_chain(x0, layers, M):
+    """layers: [(W bf16 [N][K] k-major, bias fp32 or None, relu flag, mask fp32 (M, N) or None, mask_scale, out fp32 (M, N))]; one persistent
+    launch (csrc/mlp_chain.hip).  x0 fp32 (M, K0), unit inner stride."""
+    d = _L.MlpChainDesc()
+    d.nl, d.M, d.K0 = len(layers), int(M), int(x0.shape[1])
+    _require_cuda(x0)
+    d.x0, d.ld_x0 = x0.data_ptr(), x0.stride(0)
+    flops, nbytes, k = 0.0, float(x0.numel() * 4), x0.shape[1]
+    for i, (W, bias, relu, mask, mscale, out) in enumerate(layers):
+        if W.dtype != torch.bfloat16 or W.stride(1) != 1:
+            raise _L.HulcKernelError("mlp_chain: weights are bf16 k-major shadows")
+        _require_cuda(W, bias, mask, out)
+        e = d.layers[i]
+        e.W, e.ldw = W.data_ptr(), W.stride(0)
+        e.bias = bias.data_ptr() if bias is not None else None
+        e.mask, e.ld_mask, e.mask_scale = (mask.data_ptr(), mask.stride(0), float(mscale)) if mask is not None else (None, 0, 1.0)
+        e.out, e.ld_out, e.N, e.relu = out.data_ptr(), out.stride(0), int(W.shape[0]), int(bool(relu))
+        flops += 2.0 * M * W.shape[0] * k
+        nbytes += W.shape[0] * k * 2 + M * W.shape[0] * 4
+        k = W.shape[0]
+    lib = _L.load()
+    lib.hulc_mlp_chain_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_mlp_chain_workspace(_c.byref(d)), x0.device)
+    _call("hulc_mlp_chain", _c.byref(d), ws, fault_word(x0.device), key=("mlp_chain", M, int(x0.shape[1])) + tuple(int(l[0].shape[0]) for l in layers),
+          flops=flops, nbytes=nbytes)
 
 
 def _ffn_ws(T, FF, device):

@@ -127,3 +127,23 @@ class TxlAttnDesc(ctypes.Structure):
         ("d_o", ctypes.c_void_p), ("dqkv", ctypes.c_void_p),
         ("ln_partial", ctypes.c_void_p),
     ]
+
+
+class MlpChainLayer(ctypes.Structure):
+    """mirror of hulc_mlp_chain_layer (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("W", ctypes.c_void_p), ("ldw", ctypes.c_long),
+        ("bias", ctypes.c_void_p),
+        ("mask", ctypes.c_void_p), ("ld_mask", ctypes.c_long), ("mask_scale", ctypes.c_float),
+        ("out", ctypes.c_void_p), ("ld_out", ctypes.c_long),
+        ("N", ctypes.c_int), ("relu", ctypes.c_int),
+    ]
+
+
+class MlpChainDesc(ctypes.Structure):
+    """mirror of hulc_mlp_chain_desc (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("nl", ctypes.c_int), ("M", ctypes.c_int), ("K0", ctypes.c_int),
+        ("x0", ctypes.c_void_p), ("ld_x0", ctypes.c_long),
+        ("layers", MlpChainLayer * 8),
+    ]

@@ -296,6 +296,29 @@ int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, fl
 int hulc_txl_attn_fwd(const hulc_txl_attn_desc* d, void* stream);
 int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 
+/* ---- a stack of Linear(+ReLU) layers on M <= 64 rows as one persistent launch (bf16 compute) -------------------------------------- */
+/* y_l = f_l(y_{l-1} W_l^T + b_l), l = 0 .. nl-1 (nl <= 8): the per-sequence MLPs of the policy — PlanProposalNetwork (plan_proposal_net.py:
+ * 26-47), the goal encoders (goal_encoders.py:21-34,53-71), ProjVisLang (proj_vis_lang.py:10-21), the posterior's fc -> fc_state
+ * (plan_recognition_net.py:122-123,144-148) — and, with W = the transposed weights and mask = the stored activations, the data-gradient
+ * chain of their backward (f_l = keep where mask > 0, scaled by mask_scale).  x0: fp32 (M, K0) row-major; W_l: bf16 [N_l][K_l] with
+ * K_l = N_{l-1}; every layer's fp32 output goes to out_l (M, N_l).  N_l: multiple of 16, <= 4096; K: multiple of 8 rounding up to
+ * 128 x {1, 2, 3, 4, 8, 16, 32}.  256 workgroups meet at a device-wide barrier between layers: the stream must not run another kernel
+ * concurrently; a barrier timeout ORs bit 1 (value 2) into *err_sticky (see hulc_rnn_wave_desc.err_sticky).  ws: hulc_mlp_chain_workspace(d) bytes. */
+typedef struct hulc_mlp_chain_layer {
+    const void* W; long ldw;
+    const float* bias;
+    const float* mask; long ld_mask; float mask_scale;
+    float* out; long ld_out;
+    int N, relu;
+} hulc_mlp_chain_layer;
+typedef struct hulc_mlp_chain_desc {
+    int nl, M, K0;
+    const float* x0; long ld_x0;
+    hulc_mlp_chain_layer layers[8];
+} hulc_mlp_chain_desc;
+long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d);
+int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream);
+
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.
  * State rows z_t = [first half | second half] (B x 2H fp32, time-major, consecutive wave steps z_step elements apart,
@@ -317,7 +340,7 @@ typedef struct hulc_rnn_wave_desc {
     const float* mask2; long mask2_step, ld_mask2;
     int relu, S, B, H;
     int mirror_t;   /* also write the transposed bf16 mirror (hulc_rnn_wavefront_mirror_t_offset); needs B % 8 == 0 */
-    int* err_sticky; /* optional device word set to 1 on a barrier timeout and never cleared by the kernels: the host polls it
+    int* err_sticky; /* optional device word: bit 0 (value 1) is OR-ed in on a barrier timeout and never cleared by the kernels: the host polls it
                       * (and hulc_adam_step skips its update while it is set) so a timeout ends the job instead of feeding NaN to Adam */
     const float* add1c; long ld_add1c;   /* optional (B x H, row stride ld_add1c): a per-row term of the first half that is the same at every
                                           * wave step — the plan / goal part of the layer-0 input projection, constant over a sequence */

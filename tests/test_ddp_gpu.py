@@ -2,7 +2,7 @@
 hulc2_amd/trainer.py on the GPU — eager bucketed all-reduce overlapped with backward, and hipGraph replay with the
 arena all-reduce between the two graphs (what bench.py runs with --gpus N; there the backend is "nccl" = RCCL, one GPU per
 rank).  Both ranks must stay bit-identical replicas.  Sharing a GPU between processes is exactly the situation the
-device-wide-barrier RNN kernel must not run in, so it is switched off here (HULC_NO_RNN_WAVEFRONT)."""
+device-wide-barrier RNN kernel must not run in, so those are switched off here (HULC_NO_RNN_WAVEFRONT, HULC_NO_MLP_CHAIN)."""
 import os
 import socket
 import sys
@@ -28,7 +28,7 @@ def _free_port():
 
 def _worker(rank, world, port, graph, out, real_world=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HULC_NO_RNN_WAVEFRONT="1")
+                      HULC_NO_RNN_WAVEFRONT="1", HULC_NO_MLP_CHAIN="1")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -101,7 +101,7 @@ def test_bench_gpus_flag_starts_two_ranks():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq-len", "8", "--no-cpu-baseline", "--no-secondary"],
-                  {"HULC_BENCH_BACKEND": "gloo", "HULC_NO_RNN_WAVEFRONT": "1"})
+                  {"HULC_BENCH_BACKEND": "gloo", "HULC_NO_RNN_WAVEFRONT": "1", "HULC_NO_MLP_CHAIN": "1"})   # two ranks share one GPU: no device-wide barrier kernels
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]        # finite
 

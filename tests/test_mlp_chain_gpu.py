@@ -1,0 +1,104 @@
+"""The persistent MLP-chain kernel (csrc/mlp_chain.hip) against (a) fp64 torch on bf16-rounded operands' own arithmetic bound and (b) the
+per-layer GEMM path of the same Function (HULC_NO_MLP_CHAIN=1) — forward values, input gradient, every weight / bias gradient — on the
+shapes the policy uses: the prior (160 -> 4 x 2048 -> 1024, 64 rows), the goal encoders (128 / 384 -> 2048 -> 2048 -> 32, 32 rows), the
+contrastive projections (4096 -> 128 -> 32, 32 -> 128 -> 32) and ragged row counts."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pytestmark = pytest.mark.gpu
+
+from hulc2_amd import functional as HF, kernels as kn  # noqa: E402
+
+SHAPES = [(64, (160, 2048, 2048, 2048, 2048, 1024)), (32, (128, 2048, 2048, 32)), (32, (384, 2048, 2048, 32)), (32, (4096, 128, 32)),
+          (32, (32, 128, 32)), (5, (160, 2048, 1024)), (2, (128, 2048, 2048, 32)), (17, (384, 64, 48))]
+
+
+def _run(M, dims, seed, chain, need_x=True):
+    torch.manual_seed(seed)
+    ws = [torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])]
+    x, r = torch.randn(M, dims[0]), torch.randn(M, dims[-1])
+    dev = torch.device("cuda", 0)
+    import copy
+    wsd = [copy.deepcopy(l).to(dev) for l in ws]
+    xd = x.to(dev).requires_grad_(need_x)
+    if chain:
+        os.environ.pop("HULC_NO_MLP_CHAIN", None)
+    else:
+        os.environ["HULC_NO_MLP_CHAIN"] = "1"
+    try:
+        y = HF.mlp(xd, [(l.weight, l.bias, i < len(wsd) - 1) for i, l in enumerate(wsd)])
+        (y * r.to(dev)).sum().backward()
+    finally:
+        os.environ.pop("HULC_NO_MLP_CHAIN", None)
+    torch.cuda.synchronize()
+    return y.detach(), (xd.grad if need_x else None), [l.weight.grad for l in wsd], [l.bias.grad for l in wsd], (ws, x, r)
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("M,dims", SHAPES)
+def test_chain_matches_per_layer_gemms(dev, M, dims):
+    kn.set_compute("bf16")
+    if not kn.mlp_chain_ok(M, dims[0], list(dims[1:]), dev):
+        pytest.skip("shape not taken by the chain kernel on this device")
+    yc, dxc, dWc, dbc, _ = _run(M, dims, 7, chain=True)
+    yg, dxg, dWg, dbg, (ws, x, r) = _run(M, dims, 7, chain=False)
+    # forward: both paths round operands to bf16 and accumulate in fp32 — they differ by summation order and by the bf16 rounding of the
+    # exchanged hidden activations (the GEMM path rounds them while staging, the chain when it stores them): same values, 1e-3 class
+    assert _rel(yc, yg) < 4e-3, _rel(yc, yg)
+    # against fp32 torch: the bf16 error of the stack (3e-3 per layer, grows with depth; ReLU sign flips dominate the gradients)
+    h = x.clone().requires_grad_(True)
+    t = h
+    for i, l in enumerate(ws):
+        t = l(t)
+        if i < len(ws) - 1:
+            t = torch.relu(t)
+    (t * r).sum().backward()
+    e_c, e_g = _rel(yc, t.detach()), _rel(yg, t.detach())
+    assert e_c < max(1.5 * e_g, 6e-3), (e_c, e_g)
+    e_c, e_g = _rel(dxc, h.grad), _rel(dxg, h.grad)
+    assert e_c < max(1.6 * e_g, 2e-2), ("dx", e_c, e_g)
+    for i, l in enumerate(ws):
+        e_c, e_g = _rel(dWc[i], l.weight.grad), _rel(dWg[i], l.weight.grad)
+        assert e_c < max(1.6 * e_g, 2e-2), ("dW", i, e_c, e_g)
+        e_c, e_g = _rel(dbc[i], l.bias.grad), _rel(dbg[i], l.bias.grad)
+        assert e_c < max(1.6 * e_g, 2e-2), ("db", i, e_c, e_g)
+
+
+def test_chain_is_deterministic_and_skips_dx_when_not_needed(dev):
+    kn.set_compute("bf16")
+    M, dims = 64, (160, 2048, 2048, 1024)
+    if not kn.mlp_chain_ok(M, dims[0], list(dims[1:]), dev):
+        pytest.skip("chain kernel not available")
+    a = _run(M, dims, 3, chain=True)
+    b = _run(M, dims, 3, chain=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(p, q) for p, q in zip(a[2], b[2]))
+    c = _run(M, dims, 3, chain=True, need_x=False)
+    assert torch.equal(a[0], c[0]) and all(torch.equal(p, q) for p, q in zip(a[2], c[2])) and c[1] is None
+
+
+def test_chain_rows_do_not_mix(dev):
+    """rows are independent samples: changing one input row changes only that output row (the 64-row exchange layout is per row)"""
+    kn.set_compute("bf16")
+    dims = (128, 2048, 2048, 32)
+    if not kn.mlp_chain_ok(33, dims[0], list(dims[1:]), dev):
+        pytest.skip("chain kernel not available")
+    torch.manual_seed(0)
+    ws = [torch.nn.Linear(a, b).to(dev) for a, b in zip(dims[:-1], dims[1:])]
+    x = torch.randn(33, dims[0], device=dev)
+    layers = [(l.weight, l.bias, i < len(ws) - 1) for i, l in enumerate(ws)]
+    with torch.no_grad():
+        y1 = HF.mlp(x, layers)
+        x2 = x.clone()
+        x2[20] += 1.0
+        y2 = HF.mlp(x2, layers)
+    same = [i for i in range(33) if torch.equal(y1[i], y2[i])]
+    assert same == [i for i in range(33) if i != 20]
