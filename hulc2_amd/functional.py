@@ -98,13 +98,11 @@ class MLPFn(torch.autograd.Function):
             sw, sb = gradsink.get(W), gradsink.get(params[2 * i + 1])
             dW = sw if sw is not None else _f32(N, K, like=g)
             db = sb if sb is not None else _f32(N, like=g)
-            fused = kn.gemm_fuses_rowsum(N, False) and g.dtype == torch.float32     # bias gradient = row sums of g^T: same launch
             acc_w = sw is not None and not gradsink.first_write(W)
             acc_b = sb is not None and not gradsink.first_write(params[2 * i + 1])
-            kn.gemm(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, a_kmajor=False, b_kmajor=False,
-                    accumulate=acc_w, rowsum=db if fused else None, rowsum_accumulate=acc_b)    # dW (+)= g^T inp
-            if not fused:
-                kn.colsum(g, M, N, g.stride(0), db, accumulate=acc_b)
+            # dW (+)= g^T inp, db (+)= column sums of g: part of the pass's grouped weight-gradient launch when both land in the arena
+            kn.wgrad(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, accumulate=acc_w, rowsum=db, rowsum_accumulate=acc_b,
+                     defer=sw is not None and sb is not None)
             grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
             grads[2 * i + 1] = None if sb is not None else db
             if (i - 1) in gs:
@@ -552,9 +550,11 @@ class TxlLayerFn(torch.autograd.Function):
         kn.ln_partial_reduce(lnp, B, E, dg1, db1n, accumulate=e1 or e2)
         # weight gradients of the two projections over all tokens; the row sums of the left operand are the bias gradients
         (dWin, f1), (dbin, f2) = sink("w_in", w_in, (3 * E, E)), sink("b_in", b_in, (3 * E,))
-        kn.gemm(dqkv, x2, dWin, 3 * E, E, T, 3 * E, E, E, a_kmajor=False, b_kmajor=False, accumulate=f1, rowsum=dbin, rowsum_accumulate=f2)
+        kn.wgrad(dqkv, x2, dWin, 3 * E, E, T, 3 * E, E, E, accumulate=f1, rowsum=dbin, rowsum_accumulate=f2,
+                 defer=outs["w_in"] is None and outs["b_in"] is None)
         (dWo, h1), (dbo, h2) = sink("w_out", w_out, (E, E)), sink("b_out", b_out, (E,))
-        kn.gemm(d_o, ctxb, dWo, E, E, T, E, E, E, a_kmajor=False, b_kmajor=False, accumulate=h1, rowsum=dbo, rowsum_accumulate=h2)
+        kn.wgrad(d_o, ctxb, dWo, E, E, T, E, E, E, accumulate=h1, rowsum=dbo, rowsum_accumulate=h2,
+                 defer=outs["w_out"] is None and outs["b_out"] is None)
         g = [outs[k] for k in ("w_in", "b_in", "w_out", "b_out", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2")]
         return (dx.reshape(xshape), None, None, None, None, None, *g)
 
@@ -803,17 +803,21 @@ class DecoderRNNFn(torch.autograd.Function):
         s_ih0 = gradsink.get(w_ih0)
         dw_ih0 = s_ih0 if s_ih0 is not None else torch.empty(Hd, Kin, **f32)
         acc0 = s_ih0 is not None and not gradsink.first_write(w_ih0)     # three GEMMs, each the only writer of its column slice
-        kn.gemm(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        kn.wgrad(dc, plan, dw_ih0, Hd, P, B, 2 * Hd, P, Kin, accumulate=acc0, defer=s_ih0 is not None)
         sb_ih0 = gradsink.get(b_ih0)
         db_ih0 = sb_ih0 if sb_ih0 is not None else torch.empty(Hd, **f32)
         acc_b0 = sb_ih0 is not None and not gradsink.first_write(b_ih0)
-        kn.gemm(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
-                rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=acc_b0)
-        if not fuse_b:
-            kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=acc_b0)
+        if kn.wgrad_group_ok(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin):
+            kn.wgrad(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, accumulate=acc0, rowsum=db_ih0, rowsum_accumulate=acc_b0,
+                     defer=s_ih0 is not None and sb_ih0 is not None)
+        else:
+            kn.gemm(d0w, emb_t, dw_ih0[:, P:P + E], Hd, E, M, 2 * Hd, E, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0,
+                    rowsum=db_ih0 if fuse_b else None, rowsum_accumulate=acc_b0)
+            if not fuse_b:
+                kn.colsum(d0, M, Hd, 2 * Hd, db_ih0, accumulate=acc_b0)
         if sb_ih0 is not None:
             db_ih0 = None
-        kn.gemm(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, a_kmajor=False, b_kmajor=False, accumulate=acc0)
+        kn.wgrad(dc, goal, dw_ih0[:, P + E:], Hd, G, B, 2 * Hd, G, Kin, accumulate=acc0, defer=s_ih0 is not None)
         if s_ih0 is not None:                 # written straight into the gradient arena
             dw_ih0 = None
         wih0_t = weight_operand(w_ih0, "t")                                         # (Kin, H): rows = input features, k-major

@@ -553,6 +553,96 @@ def mlp_chain(x0, layers, M):
           flops=flops, nbytes=nbytes)
 
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients: collected during a backward pass, one grouped launch at its end (csrc/wgrad_group.hip)
+# ------------------------------------------------------------------------------------------------
+_wg_pending = {}        # device -> list of (A, B, C, rowsum, M, N, K, lda, ldb, ldc, accumulate, rowsum_accumulate)
+_wg_ws = {}             # (device, stream) -> workspace (counters zeroed once, left zero by every launch)
+_wg_armed = set()
+
+
+def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc) -> bool:
+    """shapes hulc_wgrad_group takes; the three 2048^3 products of the recurrent decoder stay on their own kernel (gemm_tn128)"""
+    import os
+    if _compute_mode != BF16 or os.environ.get("HULC_NO_WGRAD_GROUP"):
+        return False
+    if K % 32 or M % 8 or N % 8 or C.dtype != torch.float32 or A.dtype not in (torch.float32, torch.bfloat16) \
+            or B.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    if min(M, N, K) >= 512 and M % 128 == 0 and N % 128 == 0 and K % 128 == 0 and A.dtype == B.dtype == torch.bfloat16:
+        return False
+    ea, eb = (4 if A.dtype == torch.float32 else 8), (4 if B.dtype == torch.float32 else 8)
+    return lda % ea == 0 and ldb % eb == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and C.data_ptr() % 4 == 0
+
+
+def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False):
+    """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
+    destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
+    when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
+    if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc):
+        fused = rowsum is not None and gemm_fuses_rowsum(M, False) and A.dtype == torch.float32
+        gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, accumulate=accumulate,
+             rowsum=rowsum if fused else None, rowsum_accumulate=rowsum_accumulate)
+        if rowsum is not None and not fused:
+            colsum(A, K, M, lda, rowsum, accumulate=rowsum_accumulate)
+        return True
+    _require_cuda(A, B, C, rowsum)
+    dev = C.device
+    q = _wg_pending.setdefault(dev, [])
+    mine = {C.data_ptr()} | ({rowsum.data_ptr()} if rowsum is not None else set())
+    if any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
+        wgrad_flush(dev)                    # a second writer of the same destination: keep the order
+        q = _wg_pending.setdefault(dev, [])
+    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate)))
+    if not defer:
+        wgrad_flush(dev)
+    elif dev not in _wg_armed:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: (_wg_armed.discard(d), wgrad_flush(d)))
+            _wg_armed.add(dev)
+        except RuntimeError:               # not inside a backward pass
+            wgrad_flush(dev)
+    return True
+
+
+def wgrad_reset(device) -> None:
+    """drop products left behind by a backward pass that raised (start of a trainer step)"""
+    _wg_pending.pop(device, None)
+    _wg_armed.discard(device)
+
+
+def wgrad_flush(device=None) -> None:
+    """issue the pending weight-gradient products (all devices when device is None)"""
+    for dev in ([device] if device is not None else list(_wg_pending)):
+        q = _wg_pending.pop(dev, None)
+        if not q:
+            continue
+        n = len(q)
+        items = (_L.WgradItem * n)()
+        flops = nbytes = 0.0
+        for it, (A, B, C, rs, M, N, K, lda, ldb, ldc, acc, racc) in zip(items, q):
+            it.A, it.B, it.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+            it.rowsum = rs.data_ptr() if rs is not None else None
+            it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, lda, ldb, ldc
+            it.a_dtype, it.b_dtype = _dt(A), _dt(B)
+            it.accumulate, it.rowsum_accumulate = int(acc), int(racc)
+            flops += 2.0 * M * N * K
+            nbytes += K * M * A.element_size() + K * N * B.element_size() + M * N * 4 * (2 if acc else 1)
+        lib = _L.load()
+        lib.hulc_wgrad_group_workspace.restype = _c.c_long
+        need = int(lib.hulc_wgrad_group_workspace(items, _i(n)))
+        with torch.cuda.device(dev):
+            key = (dev, _stream())
+            ws = _wg_ws.get(key)
+            if ws is None or ws.numel() * 4 < need:
+                ws = torch.zeros((need + (8 << 20)) // 4, dtype=torch.float32, device=dev)
+                if not torch.cuda.is_current_stream_capturing():      # (memory of a graph's pool must not outlive the graph in this cache)
+                    _wg_ws[key] = ws
+            with _Timed(("wgrad_group", n), flops, nbytes):
+                _L.check(lib.hulc_wgrad_group(items, _i(n), _c.c_void_p(ws.data_ptr()), _l(ws.numel() * 4), _c.c_void_p(_stream())),
+                         "hulc_wgrad_group")
+
+
 def _ffn_ws(T, FF, device):
     lib = _L.load()
     lib.hulc_ffn_workspace.restype = _c.c_long

@@ -129,6 +129,17 @@ class TxlAttnDesc(ctypes.Structure):
     ]
 
 
+class WgradItem(ctypes.Structure):
+    """mirror of hulc_wgrad_item (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("rowsum", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int),
+        ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int),
+        ("accumulate", ctypes.c_int), ("rowsum_accumulate", ctypes.c_int),
+    ]
+
+
 class MlpChainLayer(ctypes.Structure):
     """mirror of hulc_mlp_chain_layer (include/hulc2_amd.h)"""
     _fields_ = [

@@ -420,6 +420,7 @@ class ArenaTrainer:
         """forward + backward down to the encoder output: every gradient outside the camera encoders is final afterwards"""
         shadow.bump_epoch()
         kn.advance_step_state(self.dev)
+        kn.wgrad_reset(self.dev)
         self.zero_grad()
         self._split_active = True
         try:
@@ -430,12 +431,14 @@ class ArenaTrainer:
         if emb is None:
             raise RuntimeError("split backward: the perceptual encoder was not called exactly through its module (no output captured)")
         torch.autograd.backward(loss, inputs=[emb] + self.rest_params)
+        kn.wgrad_flush(self.dev)                     # (autograd's end-of-pass callback already issued it: no-op unless the pass was cut short)
         return loss.detach()
 
     def _backward_encoder(self) -> None:
         emb, self._emb = self._emb, None
         g, emb.grad = emb.grad, None
         torch.autograd.backward(emb, grad_tensors=g, inputs=self.enc_params)
+        kn.wgrad_flush(self.dev)
 
     def _plan_partial_zero(self) -> None:
         """After a fully zeroed step: the arena slices NOT written through a gradient sink are the only ones the next steps need zeroed
@@ -496,9 +499,11 @@ class ArenaTrainer:
     def _forward_backward(self, batch, batch_idx: int) -> torch.Tensor:
         shadow.bump_epoch()                    # every repack/shadow is re-made inside this step (and inside a capture)
         kn.advance_step_state(self.dev)        # fresh dropout / plan-sample stream, step count + 1
+        kn.wgrad_reset(self.dev)
         self.zero_grad()
         loss = self.model.training_step(batch, batch_idx)
         loss.backward()
+        kn.wgrad_flush(self.dev)
         return loss.detach()
 
     def step(self, batch, batch_idx: int = 0) -> torch.Tensor:

@@ -319,6 +319,25 @@ typedef struct hulc_mlp_chain_desc {
 long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d);
 int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream);
 
+/* ---- all small weight gradients of a backward pass in one launch (csrc/wgrad_group.hip) ------------------- */
+/* For every item i:  C[M][N] (+)= sum_k A[k][m] B[k][n]  and, when rowsum != NULL,  rowsum[m] (+)= sum_k A[k][m]  — the weight and bias
+ * gradient of an nn.Linear (A = gradient of its output, B = its input, both row-major with the token index k outer; reference: what
+ * autograd computes for plan_proposal_net.py:26-47, goal_encoders.py:21-34,53-71, plan_recognition_net.py:115-148, vision_network.py:43-47,
+ * logistic_decoder_rnn.py:81-84).  bf16 MFMA with fp32 accumulation (fp32 operands are rounded to bf16 as hulc_gemm does; the bias sums use
+ * the unrounded values); split-K partials are summed in slice order, the result does not depend on scheduling.  M, N multiples of 8,
+ * K a multiple of 32, operand rows 16-byte aligned.  Two items of one call must not write the same C / rowsum.
+ * ws: hulc_wgrad_group_workspace(items, n) bytes whose first 256 KiB (tile counters) were zero before the FIRST use of the buffer; every
+ * launch leaves them zero again. */
+typedef struct hulc_wgrad_item {
+    const void* A; const void* B; float* C; float* rowsum;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_dtype, b_dtype;            /* HULC_F32 / HULC_BF16 */
+    int accumulate, rowsum_accumulate;
+} hulc_wgrad_item;
+long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n);
+int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream);
+
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.
  * State rows z_t = [first half | second half] (B x 2H fp32, time-major, consecutive wave steps z_step elements apart,

@@ -154,7 +154,8 @@ def _parse_struct(text: str, name: str):
 
 
 @pytest.mark.parametrize("cname,pyname", [("hulc_gemm_desc", "GemmDesc"), ("hulc_conv_desc", "ConvDesc"), ("hulc_rnn_wave_desc", "RnnWaveDesc"),
-                                          ("hulc_mix_desc", "MixDesc")])
+                                          ("hulc_mix_desc", "MixDesc"), ("hulc_txl_attn_desc", "TxlAttnDesc"), ("hulc_wgrad_item", "WgradItem"),
+                                          ("hulc_mlp_chain_layer", "MlpChainLayer")])
 def test_ctypes_structures_mirror_the_header(cname, pyname):
     """field count, order, names and C types of every descriptor struct == its ctypes.Structure in hulc2_amd/lib.py: a field added on one
     side only makes the kernel read past the caller's struct (the INTEGRATION.md stub was 3 fields short)"""

@@ -72,8 +72,20 @@ def mfma(path):
         print(f"{n:7d} {act / n:18.0f} {busy / n:17.0f} {100 * busy / max(act * 1024, 1):11.2f} {512 * mops / max(act / 2.4e9, 1e-12) / 1e12:12.1f} {sqb / n:15.0f}  {short(name)}")
 
 
+def listing(path, pattern):
+    """every dispatch whose kernel name contains `pattern`, in launch order: `python tools/rocpd_stats.py --list PATTERN x.db`"""
+    c = sqlite3.connect(path)
+    rows = c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                     "on d.kernel_id = s.id order by d.start").fetchall()
+    for name, st, en, grid in rows:
+        if pattern in name:
+            print(f"{(en - st) / 1e3:10.2f} us  grid {grid:8d}  {short(name)[:80]}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--mfma":
+    if len(sys.argv) > 3 and sys.argv[1] == "--list":
+        listing(sys.argv[3], sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "--mfma":
         mfma(sys.argv[2])
     elif len(sys.argv) > 2 and sys.argv[1] == "--pmc":
         pmc(sys.argv[2])
