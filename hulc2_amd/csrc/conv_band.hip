@@ -94,11 +94,10 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         wfrag[ks] = x.b;
     }
 
-    // bias of this lane's 16 output channels (registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}), loaded once: a load inside the
-    // tile loop would have to wait, in order, for the whole prefetch issued before it
-    float4 bias4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = p.bias ? *(const float4*)(p.bias + cl_co + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // bias of this set's 32 output channels: in LDS (the lane's 16 values would occupy 16 of the 256 VGPRs the weight tile, the prefetched
+    // band and the fragment read-ahead compete for); read back per tile behind the MFMA loop
+    __shared__ float sbias[BAND_MAXCLS * 32];
+    if (tid < NSET * 32) sbias[tid] = p.bias ? p.bias[p.cls[tid >> 5].co_base + (tid & 31)] : 0.f;
 
     // The resident operands are complete before the unit loop starts.  Without this the compiler keeps "weight fragment k may still be
     // in flight" alive around the loop and guards MFMA k of EVERY tile with s_waitcnt vmcnt(31 - k): harmless for the weights, but the
@@ -166,13 +165,26 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             f32x16_t acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
+            // pixel fragments are read RD k-steps ahead of the MFMA that consumes them: left to the compiler (256 VGPRs in use) every
+            // MFMA waited for the one ds_read_b128 issued just before it — an LDS round trip (~250 cycles with 8 waves reading) per
+            // 32-cycle MFMA, 21-27 % of the matrix pipe
+            constexpr int RD = KSTEPS <= 16 ? 8 : 4;            // (the 2 x 2-tap data-gradient classes keep 64 weight registers: room for 8)
+            auto frag = [&](int ks) {
                 const int k0 = ks * 16;
                 const int t = k0 / C, c0 = k0 % C;
                 const int ty = t / TW, tx = t % TW;
-                const bf16x8_t px = *(const bf16x8_t*)(a0 + (ty * Wb + tx) * PS + c0 * 2);
+                return *(const bf16x8_t*)(a0 + (ty * Wb + tx) * PS + c0 * 2);
+            };
+            bf16x8_t pf[RD];
+#pragma unroll
+            for (int i = 0; i < RD; ++i) pf[i] = frag(i);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const bf16x8_t px = pf[ks % RD];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);   // D[channel][pixel]
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + RD < KSTEPS) pf[ks % RD] = frag(ks + RD);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- epilogue: lane = pixel; registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}
             const long off0 = cl_yoff + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx + cl_co;   // q is clamped: always valid
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 uint2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = bias4[g];
+                    const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
                     float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
                     if (p.add) {
                         const uint2 a = *(const uint2*)((const uint16_t*)p.add + off0 + 8 * g + 4 * h);
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 const long off = off0 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = bias4[g];
+                    const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
                     float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
                     if (p.relu) {
 #pragma unroll
@@ -244,7 +256,7 @@ template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32>
 int launch_band_x(BandP& p, hipStream_t s) {
     constexpr int PS = C * 2 + 16, CPP = C / 8;
     const int Wb = (p.OWmax - 1) * S + TW;
-    const long budget = 160 * 1024 - 512;
+    const long budget = 160 * 1024 - 1024;                   // (512 B of static LDS: the bias table)
     const long max_px = (long)MAXCH * (512 / CPP);           // pixels one register-staged band can hold
     int R = p.OHmax;
     auto px_of = [&](int rr) { return (long)((rr - 1) * S + TH) * Wb; };
@@ -268,7 +280,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
         auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32>;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
             attr_set = true;
         }
         kern<<<grid, 512, lds, s>>>(p);
@@ -276,7 +288,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
         auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32>;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
             attr_set = true;
         }
         kern<<<grid, 512, lds, s>>>(p);

@@ -36,7 +36,7 @@ struct ChLayer {
 struct ChainP {
     ChLayer L[CH_MAXL];
     int nl, M;
-    const float* x0; long ld_x0;        // layer 0 input, fp32 [M][K0]
+    const uint16_t* x0b;                // layer 0 input, bf16 blocked (chain_prep_kernel)
     uint16_t* xb;
     unsigned* bar; int* err; int* err_sticky;
 };
@@ -44,9 +44,23 @@ struct ChainP {
 union F8 { uint4 u; bf16x8_t b; };
 HULC_DEVICE constexpr int s_of(int bi, int q, int ab) { return bi * ab + q; }
 
-__global__ __launch_bounds__(64) void chain_prep_kernel(uint4* __restrict__ hdr, long n) {
+// before the chain: zero the barrier header, and lay the fp32 input out the way every later layer finds its input — bf16, blocked
+// [k / 8][64 rows][8] (rows >= M and columns >= K0 zero).  Read by the chain's 256 workgroups as 16-byte pieces; gathering the fp32 rows
+// inside the chain kernel instead cost 256 x M x K0 x 4 bytes of strided L2 reads (74 us for a 4096-wide input).
+__global__ __launch_bounds__(256) void chain_prep_kernel(uint4* __restrict__ hdr, long nhdr, const float* __restrict__ x0, long ld_x0, int M, int K0,
+                                                          uint4* __restrict__ x0b, long nchunk) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hdr[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < nhdr) hdr[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < nchunk) {
+        const int m = (int)(i & 63), k = (int)(i >> 6) * 8;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (m < M && k < K0) {                                             // K0 is a multiple of 8
+            const float* src = x0 + (long)m * ld_x0 + k;
+            const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+            o = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+        }
+        x0b[i] = o;
+    }
 }
 
 // one layer for this workgroup's column tile; KSW = k-steps (of 32) per wave, K padded up to 128 * KSW
@@ -105,13 +119,7 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool first, const
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = mt * 16 + r;
-                if (first) {                                                       // fp32 row-major input
-                    const float* src = p.x0 + (long)(m < p.M ? m : p.M - 1) * p.ld_x0 + (kin ? k : 0);
-                    const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
-                    dst[q][mt].u = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
-                } else {
-                    dst[q][mt].u = *(const uint4*)(xin + ((long)((kin ? k : 0) / 8) * 64 + m) * 8);
-                }
+                dst[q][mt].u = *(const uint4*)(xin + ((long)((kin ? k : 0) / 8) * 64 + m) * 8);
             }
         }
     };
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nwg = gridDim.x, tile = blockIdx.x;                         // N <= 16 * gridDim: at most one tile per workgroup and layer
     for (int l = 0; l < p.nl; ++l) {
         const int ksw = (p.L[l].K + 127) / 128;
-        const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : nullptr;
+        const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : p.x0b;
         switch (ksw) {
             case 1: chain_layer<1>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
             case 2: chain_layer<2>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
@@ -202,7 +210,7 @@ extern "C" long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d) {
     if (!d || d->nl < 1 || d->nl > CH_MAXL) return 0;
     long elems = 0;
     for (int l = 0; l + 1 < d->nl; ++l) elems += (long)d->layers[l].N * 64;
-    return CH_HEADER + elems * 2 + 64;
+    return CH_HEADER + elems * 2 + 64 + ((long)(d->K0 + 7) / 8) * 64 * 16;     // header, exchange regions, the blocked input
 }
 
 // see include/hulc2_amd.h
@@ -212,7 +220,7 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
     if (d->M < 1 || d->M > 64) return hulc_fail(-2, "hulc_mlp_chain: 1 <= M <= 64 rows");
     if ((uintptr_t)ws % 16 || (uintptr_t)d->x0 % 16 || d->ld_x0 % 4) return hulc_fail(-4, "hulc_mlp_chain: workspace / input must be 16-byte aligned");
     ChainP p = {};
-    p.nl = d->nl; p.M = d->M; p.x0 = d->x0; p.ld_x0 = d->ld_x0;
+    p.nl = d->nl; p.M = d->M;
     p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8L * CH_CTR_STRIDE * 4); p.err_sticky = err_sticky;
     p.xb = (uint16_t*)((char*)ws + CH_HEADER);
     long off = 0;
@@ -220,7 +228,6 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
     for (int l = 0; l < d->nl; ++l) {
         const hulc_mlp_chain_layer& s = d->layers[l];
         if (!s.W || !s.out) return hulc_fail(-1, "hulc_mlp_chain: null layer operand");
-        if (l == 0 && kin > 512) return hulc_fail(-3, "hulc_mlp_chain: the fp32 input is gathered row by row: K0 <= 512 (wider inputs take hulc_gemm)");
         if (s.N < 16 || s.N % 16 || s.N > 4096 || kin < 8 || kin % 8 || kin > 4096 || s.ldw % 8 || (uintptr_t)s.W % 16 || s.ld_out % 4 || (uintptr_t)s.out % 16)
             return hulc_fail(-3, "hulc_mlp_chain: N must be a multiple of 16, K a multiple of 8 and <= 4096, operands 16-byte aligned");
         const int ksw = (kin + 127) / 128;
@@ -235,7 +242,10 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
         kin = s.N;
     }
     hipStream_t st = (hipStream_t)stream;
-    chain_prep_kernel<<<(unsigned)((CH_HEADER / 16 + 63) / 64), 64, 0, st>>>((uint4*)ws, CH_HEADER / 16);
+    p.x0b = p.xb + ((off - (long)d->layers[d->nl - 1].N * 64 + 7) / 8) * 8;          // behind the exchange regions of layers 0 .. nl-2
+    const long nchunk = ((long)(d->K0 + 7) / 8) * 64, nhdr = CH_HEADER / 16;
+    const long nthr = nchunk > nhdr ? nchunk : nhdr;
+    chain_prep_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>((uint4*)ws, nhdr, d->x0, d->ld_x0, d->M, d->K0, (uint4*)p.x0b, nchunk);
     mlp_chain_kernel<<<256, 256, 0, st>>>(p);
     return hulc_check_launch("hulc_mlp_chain");
 }

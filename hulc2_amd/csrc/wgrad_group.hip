@@ -33,6 +33,7 @@ struct Item {
     int flags;                            // bit 0 A fp32, bit 1 B fp32, bit 2 accumulate into C, bit 3 accumulate into rowsum
     int tn, ksplit, kper;                 // tiles along N, slices of K, k-steps per slice
     int ctr0;                             // first counter
+    int perm;                             // > 0: product column n is stored at column (n % perm) * (N / perm) + n / perm
     long slab0;                           // first slab
 };
 struct GroupP { int first[MAX_ITEMS]; Item it[MAX_ITEMS]; int n, total; unsigned* ctr; float* slabs; };   // first[j]: first work item of problem j (INT_MAX: unused)
@@ -166,6 +167,8 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
         if (tid < T) bsum = ((red[T * (T + 1) + tid] + red[T * (T + 1) + T + tid]) + red[T * (T + 1) + 2 * T + tid]) + red[T * (T + 1) + 3 * T + tid];
     }
     const int nloc = wn * 32 + (lane & 31);
+    const int nn = n0 + nloc;
+    const int ncol = it.perm > 0 ? (nn % it.perm) * (it.N / it.perm) + nn / it.perm : nn;   // (h, w, c) -> (c, h, w) weight columns of a flattened conv map
     if (it.ksplit == 1) {
         const bool accum = it.flags & 4;
         if (n0 + nloc < it.N) {
@@ -173,7 +176,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 32 + acc_row(e, lane);
                 if (m < it.M) {
-                    float* dst = it.C + (long)m * it.ldc + n0 + nloc;
+                    float* dst = it.C + (long)m * it.ldc + ncol;
                     *dst = accum ? *dst + acc[e] : acc[e];
                 }
             }
@@ -223,7 +226,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 32 + acc_row(e, lane);
                 if (m < it.M) {
-                    float* dst = it.C + (long)m * it.ldc + n0 + nloc;
+                    float* dst = it.C + (long)m * it.ldc + ncol;
                     *dst = accum ? *dst + acc[e] : acc[e];
                 }
             }
@@ -281,6 +284,7 @@ int check_item(const hulc_wgrad_item& d) {
         return hulc_fail(-2, "hulc_wgrad_group: operands are fp32 or bf16");
     if (d.lda % ea || d.ldb % eb || ((uintptr_t)d.A | (uintptr_t)d.B) % 16) return hulc_fail(-2, "hulc_wgrad_group: operand rows must be 16-byte aligned");
     if (d.lda < d.M || d.ldb < d.N || d.ldc < d.N || !d.A || !d.B || !d.C) return hulc_fail(-2, "hulc_wgrad_group: bad leading dimension or null operand");
+    if (d.col_perm < 0 || (d.col_perm > 0 && d.N % d.col_perm)) return hulc_fail(-2, "hulc_wgrad_group: col_perm must divide N");
     return 0;
 }
 
@@ -321,7 +325,7 @@ extern "C" int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, l
             it.M = d.M; it.N = d.N; it.K = d.K; it.lda = d.lda; it.ldb = d.ldb; it.ldc = d.ldc;
             it.flags = (d.a_dtype == HULC_F32 ? 1 : 0) | (d.b_dtype == HULC_F32 ? 2 : 0) | (d.accumulate ? 4 : 0) | (d.rowsum_accumulate ? 8 : 0);
             p.first[j] = first; it.tn = pl.tn; it.ksplit = pl.ksplit; it.kper = pl.kper;
-            it.ctr0 = ctr; it.slab0 = slab;
+            it.ctr0 = ctr; it.slab0 = slab; it.perm = d.col_perm;
             first += pl.tiles * pl.ksplit;
             if (pl.ksplit > 1) { ctr += pl.tiles; slab += (long)pl.tiles * pl.ksplit; }
         }

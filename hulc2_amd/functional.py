@@ -147,29 +147,37 @@ class FlattenLinearFn(torch.autograd.Function):
         g = _f32(N, O, like=out)
         kn.relu_bwd(_c(dy), out, g, g.numel())
         sw, sb = gradsink.get(W), gradsink.get(b)
-        dWh = _f32(O, K, like=g)                                   # (h, w, c) column order
-        db = sb if sb is not None else _f32(O, like=g)
-        acc_b = sb is not None and not gradsink.first_write(b)
-        fused = kn.gemm_fuses_rowsum(O, False)
-        kn.gemm(g, x2, dWh, O, K, N, O, K, K, a_kmajor=False, b_kmajor=False, rowsum=db if fused else None, rowsum_accumulate=acc_b)
-        if not fused:
-            kn.colsum(g, N, O, O, db, accumulate=acc_b)
-        src = dWh.view(O, K // C, C).transpose(1, 2)                # -> the parameter's (c, h*w) order
-        if sw is not None:
-            dst = sw.view(O, C, K // C)
-            if gradsink.first_write(W):
-                dst.copy_(src)
-            else:
-                dst.add_(src)
-            dW = None
+        if sw is not None and sb is not None and kn.wgrad_group_ok(g, x2, sw, O, K, N, O, K, K):
+            # straight into the arena with the parameter's (c, h*w) column order: one item of the pass's grouped weight-gradient launch
+            kn.wgrad(g, x2, sw.view(O, K), O, K, N, O, K, K, accumulate=not gradsink.first_write(W), rowsum=sb,
+                     rowsum_accumulate=not gradsink.first_write(b), defer=True, col_perm=C)
+            dW = db = None
         else:
-            dW = src.reshape(O, K)
+            dWh = _f32(O, K, like=g)                                   # (h, w, c) column order
+            db = sb if sb is not None else _f32(O, like=g)
+            acc_b = sb is not None and not gradsink.first_write(b)
+            fused = kn.gemm_fuses_rowsum(O, False)
+            kn.gemm(g, x2, dWh, O, K, N, O, K, K, a_kmajor=False, b_kmajor=False, rowsum=db if fused else None, rowsum_accumulate=acc_b)
+            if not fused:
+                kn.colsum(g, N, O, O, db, accumulate=acc_b)
+            src = dWh.view(O, K // C, C).transpose(1, 2)                # -> the parameter's (c, h*w) order
+            if sw is not None:
+                dst = sw.view(O, C, K // C)
+                if gradsink.first_write(W):
+                    dst.copy_(src)
+                else:
+                    dst.add_(src)
+                dW = None
+            else:
+                dW = src.reshape(O, K)
+            if sb is not None:
+                db = None
         da = None
         if ctx.needs_input_grad[0]:
             da = torch.empty(N, K, dtype=torch.float32, device=g.device)
             kn.gemm(g, weight_operand(W, "hwc_t", chw=(C, ctx.ashape[1], ctx.ashape[2])), da, N, K, O, O, O, K, mask=x2, ld_mask=K, mask_scale=1.0)   # x (a > 0): conv3's ReLU
             da = da.view(ctx.ashape)
-        return da, dW, (None if sb is not None else db)
+        return da, dW, db
 
 
 def flatten_linear_relu(a_nhwc, W, b):

@@ -516,7 +516,7 @@ def mlp_chain_ok(M: int, K0: int, widths, device) -> bool:
     import os
     if os.environ.get("HULC_NO_MLP_CHAIN") or _compute_mode != BF16 or concurrent_streams() or device_cu_count(device) < 256:
         return False
-    if not (1 <= M <= 64) or not (1 <= len(widths) <= 8) or K0 > 512:      # (the fp32 input is gathered row by row: narrow inputs only)
+    if not (1 <= M <= 64) or not (1 <= len(widths) <= 8):
         return False
     k = K0
     for n in widths:
@@ -575,11 +575,13 @@ def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc) -> bool:
     return lda % ea == 0 and ldb % eb == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and C.data_ptr() % 4 == 0
 
 
-def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False):
+def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False, col_perm=0):
     """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
     destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
     when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
     if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc):
+        if col_perm:
+            raise _L.HulcKernelError("wgrad: col_perm needs the grouped kernel (check wgrad_group_ok first)")
         fused = rowsum is not None and gemm_fuses_rowsum(M, False) and A.dtype == torch.float32
         gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, accumulate=accumulate,
              rowsum=rowsum if fused else None, rowsum_accumulate=rowsum_accumulate)
@@ -593,7 +595,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     if any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
         wgrad_flush(dev)                    # a second writer of the same destination: keep the order
         q = _wg_pending.setdefault(dev, [])
-    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate)))
+    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm)))
     if not defer:
         wgrad_flush(dev)
     elif dev not in _wg_armed:
@@ -620,12 +622,13 @@ def wgrad_flush(device=None) -> None:
         n = len(q)
         items = (_L.WgradItem * n)()
         flops = nbytes = 0.0
-        for it, (A, B, C, rs, M, N, K, lda, ldb, ldc, acc, racc) in zip(items, q):
+        for it, (A, B, C, rs, M, N, K, lda, ldb, ldc, acc, racc, *rest) in zip(items, q):
             it.A, it.B, it.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
             it.rowsum = rs.data_ptr() if rs is not None else None
             it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, lda, ldb, ldc
             it.a_dtype, it.b_dtype = _dt(A), _dt(B)
             it.accumulate, it.rowsum_accumulate = int(acc), int(racc)
+            it.col_perm = rest[0] if rest else 0
             flops += 2.0 * M * N * K
             nbytes += K * M * A.element_size() + K * N * B.element_size() + M * N * 4 * (2 if acc else 1)
         lib = _L.load()

@@ -300,7 +300,8 @@ int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 /* y_l = f_l(y_{l-1} W_l^T + b_l), l = 0 .. nl-1 (nl <= 8): the per-sequence MLPs of the policy — PlanProposalNetwork (plan_proposal_net.py:
  * 26-47), the goal encoders (goal_encoders.py:21-34,53-71), ProjVisLang (proj_vis_lang.py:10-21), the posterior's fc -> fc_state
  * (plan_recognition_net.py:122-123,144-148) — and, with W = the transposed weights and mask = the stored activations, the data-gradient
- * chain of their backward (f_l = keep where mask > 0, scaled by mask_scale).  x0: fp32 (M, K0) row-major; W_l: bf16 [N_l][K_l] with
+ * chain of their backward (f_l = keep where mask > 0, scaled by mask_scale).  x0: fp32 (M, K0 <= 4096) row-major (a first small launch
+ * rounds it to bf16 in the layout the layers exchange their outputs in); W_l: bf16 [N_l][K_l] with
  * K_l = N_{l-1}; every layer's fp32 output goes to out_l (M, N_l).  N_l: multiple of 16, <= 4096; K: multiple of 8 rounding up to
  * 128 x {1, 2, 3, 4, 8, 16, 32}.  256 workgroups meet at a device-wide barrier between layers: the stream must not run another kernel
  * concurrently; a barrier timeout ORs bit 1 (value 2) into *err_sticky (see hulc_rnn_wave_desc.err_sticky).  ws: hulc_mlp_chain_workspace(d) bytes. */
@@ -334,6 +335,8 @@ typedef struct hulc_wgrad_item {
     int lda, ldb, ldc;
     int a_dtype, b_dtype;            /* HULC_F32 / HULC_BF16 */
     int accumulate, rowsum_accumulate;
+    int col_perm;                    /* > 0: column n of the product is stored at column (n % col_perm) * (N / col_perm) + n / col_perm — the
+                                      * (h, w, c) -> (c, h, w) order of a Linear that follows nn.Flatten on an NHWC map (vision_network_gripper.py:16-17) */
 } hulc_wgrad_item;
 long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n);
 int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream);

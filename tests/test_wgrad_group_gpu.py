@@ -107,6 +107,22 @@ def test_second_writer_of_a_destination_keeps_order():
     assert (C.double() - (w1 + w2)).abs().max().item() < 2e-3 and (rs.double() - (r1 + r2)).abs().max().item() < 2e-3
 
 
+def test_column_permutation_of_a_flattened_map():
+    """col_perm = C: the product's (h*w, c) columns land in the parameter's (c, h*w) order (vision_network_gripper.py:16-17)"""
+    dev = _dev()
+    M, HW, C, K = 128, 49, 64, 2048
+    N = HW * C
+    A, B = _problem(M, N, K, dev, False, False)
+    A, B = A.contiguous(), B.contiguous()
+    out = torch.full((M, N), float("nan"), device=dev)
+    rs = torch.empty(M, device=dev)
+    kn.wgrad(A, B, out, M, N, K, M, N, N, rowsum=rs, col_perm=C)
+    torch.cuda.synchronize()
+    want, _ = _ref(A, B)
+    want = want.view(M, HW, C).transpose(1, 2).reshape(M, N)
+    assert (out.double() - want).abs().max().item() < 4e-3
+
+
 def test_rejected_shapes_take_the_gemm_path():
     dev = _dev()
     M, N, K = 60, 100, 48                              # not multiples of 8 / 32

@@ -1,43 +1,72 @@
-"""Where do the small torch kernels of a step come from?  Lists aten ops with their Python call sites."""
-import sys, torch, collections
-sys.path.insert(0, '.')
-from hulc2_amd import kernels as kn, synthetic as syn
-from hulc2_amd.compat import instantiate
-from hulc2_amd.config import default_model_config
-from hulc2_amd.trainer import ArenaTrainer
-from torch.profiler import profile, ProfilerActivity
+#!/usr/bin/env python3
+"""Which Python lines launch the framework (aten / runtime-copy) kernels of a training step?  Runs eager steps of the benchmark
+configuration under torch.profiler with stacks and prints, per kernel-launching aten op, the launches per step and the innermost
+hulc2_amd frames that issued them.   usage (GPU box): python tools/glue_trace.py [--steps 2]"""
+import collections
+import sys
+from pathlib import Path
 
-dev = torch.device("cuda", 0)
-kn.set_compute("bf16")
-m = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
-syn.fill_state_dict_(m.state_dict(), 42)
-m.train()
-tr = ArenaTrainer(m, lr=2e-4)
-batch = syn.make_batch(42, 32, 32, device=dev)
-for db in batch.values():
-    db.pop("plan_idx", None)
-for i in range(2):
-    tr.step(batch, i)
-torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
-    tr.step(batch, 2)
-torch.cuda.synchronize()
-want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::div", "aten::sum",
-        "aten::_to_copy", "aten::index", "aten::stack", "aten::where", "aten::mean", "aten::neg", "aten::sub", "aten::eq", "aten::index_put_",
-        "aten::slice_backward", "aten::select_backward", "aten::masked_fill_", "aten::arange", "aten::expand")
-agg = collections.Counter()
-for ev in prof.key_averages(group_by_input_shape=True):
-    if ev.key in want:
-        agg[(ev.key, str(ev.input_shapes)[:110])] += ev.count
-for (k, shp), n in sorted(agg.items(), key=lambda kv: (kv[0][0], -kv[1])):
-    print(f"{n:4d}  {k:22s} {shp}")
+import torch
 
-# ---- call sites (first frame inside hulc2_amd) of the ops that launch a kernel
-sites = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::cat", "aten::zero_", "aten::mul", "aten::div", "aten::index_select"):
-        fr = next((f for f in (ev.stack or []) if "hulc2_amd" in f), "?")
-        sites[(ev.name, fr.split("hulc2_amd/")[-1][:90])] += 1
-print("\ncall sites:")
-for (k, fr), n in sorted(sites.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{n:4d}  {k:14s} {fr}")
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from hulc2_amd import kernels as kn, synthetic as syn  # noqa: E402
+from hulc2_amd.compat import instantiate  # noqa: E402
+from hulc2_amd.config import default_model_config  # noqa: E402
+from hulc2_amd.trainer import ArenaTrainer  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 2
+    dev = torch.device("cuda", 0)
+    kn.set_compute("bf16")
+    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    syn.fill_state_dict_(model.state_dict(), 42)
+    model.train()
+    trainer = ArenaTrainer(model, lr=2e-4, overlap=False)
+    batch = syn.make_batch(42, 32, 32, device=dev)
+    for db in batch.values():
+        db.pop("plan_idx", None)
+    for i in range(3):
+        trainer.step(batch, i)
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for i in range(steps):
+            trainer.step(batch, 3 + i)
+        torch.cuda.synchronize()
+    # CPU-side aten ops that own device kernels: attribute to the innermost repo frame
+    rows = collections.Counter()
+    for ev in prof.events():
+        if not ev.name.startswith("aten::") or not ev.kernels:
+            continue
+        if any(k.name.startswith("aten::") for k in ev.cpu_children if k.kernels):
+            continue                                                        # count the leaf op only
+        frames = [f for f in (ev.stack or []) if "hulc2_amd" in f or "bench" in f]
+        where = " <- ".join(f.split("/root/repo/")[-1].split("repo/")[-1] for f in frames[:2]) or "(autograd engine / no repo frame)"
+        for k in ev.kernels:
+            rows[(ev.name, k.name[:60], where)] += 1
+    total = 0
+    for (op, kname, where), n in sorted(rows.items(), key=lambda kv: -kv[1]):
+        total += n
+        print(f"{n / steps:6.1f}/step  {op:28s} {kname:60s} {where}")
+    print(f"total {total / steps:.1f} aten-launched kernels per step")
+    # runtime copies / memsets (not kernels of an aten op): name, count, and the CPU op that was running when they were issued
+    mem = collections.Counter()
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CUDA and ("Memcpy" in ev.name or "Memset" in ev.name):
+            mem[ev.name] += 1
+    for name, n in mem.most_common():
+        print(f"{n / steps:6.1f}/step  {name}")
+    cpu = collections.Counter()
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CPU and any(t in ev.name for t in ("hipMemcpy", "hipMemset", "aten::_to_copy", "aten::to", "aten::item",
+                                                                                          "aten::_local_scalar_dense", "aten::scalar_tensor", "aten::tensor")):
+            par = ev.cpu_parent.name if ev.cpu_parent is not None else "-"
+            cpu[(ev.name, par)] += 1
+    for (name, par), n in cpu.most_common(40):
+        print(f"{n / steps:6.1f}/step  {name:32s} inside {par}")
+
+
+if __name__ == "__main__":
+    main()
