@@ -126,7 +126,7 @@ HULC_DEVICE void mma_tile_bf16_tr(const char* a_tile, int ra, const char* b_tile
 // ADT / BDT: operand storage types (HULC_F32 / HULC_BF16).  MICRO (both operands row-major, tiles fully inside the matrices, aligned:
 // checked by the launcher): 8(k) x 4 / 8 x 8 micro-tile staging, see below.
 template <typename CT, int TM, int TN, int WM, int WN, bool AK, bool BK, int ADT, int BDT, bool MICRO>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __restrict__ slabs, int splitk) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __restrict__ slabs, int splitk, unsigned* __restrict__ tile_ctr) {
     static_assert(!MICRO || (!AK && !BK), "micro-tile staging is for row-major operands");
     using T = MmaTraits<CT>;
     constexpr int NT = WM * WN * 64;
@@ -376,6 +376,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
         // partial row sums of this K slice -> rowsum slab [splitk][M] behind the C slabs (split K) or straight to the output
         float* dst = splitk > 1 ? slabs + (long)splitk * p.M * p.N + (long)blockIdx.z * p.M : p.rowsum;
         const bool acc_out = splitk == 1 && p.rowsum_accumulate;
+        // split K: the partials are picked up by another workgroup of this launch (the last one to arrive at the tile): agent-scope stores
+        auto put_rs = [&](float* q, float v) {
+            if (splitk > 1) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *q = acc_out ? *q + v : v;
+        };
         if (TRT) {
             // a thread summed the 8 rows of its chunk column mc = tid % (BM / 8) over its k rows: fold the NT / (BM / 8) threads of a column
             float* red = (float*)smem;                           // operand tiles are dead
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             if (tid < BM && m0 + tid < p.M) {
                 float v = 0.f;
                 for (int t = tid / 8; t < NT; t += BM / 8) v += red[t * 8 + (tid & 7)];
-                dst[m0 + tid] = acc_out ? dst[m0 + tid] + v : v;
+                put_rs(dst + m0 + tid, v);
             }
         } else if (AK) {
             static_assert(!AK || A_PER <= 8, "row sums of a k-major A: one accumulator per chunk slot");
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             for (int q = 0; q < (AK ? A_PER : 0); ++q) {
                 for (int o = 1; o < NCH; o <<= 1) rs[q] += __shfl_xor(rs[q], o, 64);
                 const int id = tid + q * NT, r = id / NCH;
-                if ((A_CH % NT == 0 || id < A_CH) && id % NCH == 0 && m0 + r < p.M) dst[m0 + r] = acc_out ? dst[m0 + r] + rs[q] : rs[q];
+                if ((A_CH % NT == 0 || id < A_CH) && id % NCH == 0 && m0 + r < p.M) put_rs(dst + m0 + r, rs[q]);
             }
         } else if (MICRO && ADT != HULC_F32) {
 #pragma unroll
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             if (tid < MTA && tid % NCH == 0 && m_inside) {
                 const int r0 = m0 + (tid / NCH) * 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
+                for (int i = 0; i < 8; ++i) put_rs(dst + r0 + i, rs[i]);
             }
         } else if (MICRO) {
 #pragma unroll
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             if (tid < MTA && tid % NCH == 0 && m_inside) {
                 const int r0 = m0 + (tid / NCH) * 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[r0 + i] = acc_out ? dst[r0 + i] + rs[i] : rs[i];
+                for (int i = 0; i < 4; ++i) put_rs(dst + r0 + i, rs[i]);
             }
         } else {
             float* red = (float*)smem;                           // operand tiles are dead: NT floats of scratch
@@ -422,12 +427,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
             if (tid < BM && m0 + tid < p.M) {
                 float v = 0.f;
                 for (int t = tid; t < NT && t < A_CH; t += BM) v += red[t];
-                dst[m0 + tid] = acc_out ? dst[m0 + tid] + v : v;
+                put_rs(dst + m0 + tid, v);
             }
         }
     }
 
-    if (splitk > 1) {   // raw partial sums; gemm_splitk_epilogue_kernel combines the slabs in a fixed order
+    if (splitk > 1) {
+        // Raw partial sums go to this slice's slab; the workgroup that arrives LAST at the tile's counter sums all slabs in slice order
+        // (the result does not depend on who that is) and runs the epilogue below — no second launch.  The slabs travel as agent-scope
+        // atomic (write-through / L2-bypassing) accesses: they are written and read by different XCDs inside one launch.
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -437,10 +445,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p, float* __res
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
-                    if (m < p.M) slabs[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][e];
+                    if (m < p.M) __hip_atomic_store(slabs + ((long)blockIdx.z * p.M + m) * p.N + n, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
         }
-        return;
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's partials are acknowledged ...
+        __syncthreads();                                          // ... and so are the workgroup's
+        if (tid == 0) {
+            unsigned* c = tile_ctr + blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(splitk - 1);
+            if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // zero again for the next launch
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const int nc = n < p.N ? n : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int z = 0; z < splitk; ++z) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + (wm * TM + i) * 32 + acc_row(e, lane);
+                        const int mc = m < p.M ? m : 0;
+                        acc[i][j][e] += __hip_atomic_load(slabs + ((long)z * p.M + mc) * p.N + nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        if (do_rowsum && tid < BM && m0 + tid < p.M) {
+            const float* rsl = slabs + (long)splitk * p.M * p.N;
+            float v = 0.f;
+            for (int z = 0; z < splitk; ++z) v += __hip_atomic_load(rsl + (long)z * p.M + m0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.rowsum[m0 + tid] = p.rowsum_accumulate ? p.rowsum[m0 + tid] + v : v;
+        }
     }
 
     // epilogue: lane owns column n = lane & 31 of each tile; each accumulator register is one row.  All reads of the
@@ -601,6 +644,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, cons
 
 // K slices: waves first (up to 16 per workgroup: combined through LDS in the same launch, epilogue fused),
 // then workgroups (fp32 slabs + epilogue kernel) until ~256 workgroups exist; every wave keeps >= 64 k.
+constexpr long HULC_GEMM_CTR_BYTES = 16384;      // 4096 tile counters at the head of hulc_gemm_desc.ws
+
 template <typename CT>
 void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStream_t s) {
     const int colblocks = (p.N + 31) / 32;
@@ -612,6 +657,8 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     const int min_kw = 64;   // measured (tools/rnn_bench.py): more, shorter K slices win even with the extra epilogue launch
     while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= min_kw) splitk *= 2;
     if (force) splitk = atoi(force);
+    ws = ws ? ws + HULC_GEMM_CTR_BYTES / 4 : ws;                 // (the head of the workspace holds the tiled kernel's counters)
+    ws_bytes = ws_bytes > HULC_GEMM_CTR_BYTES ? ws_bytes - HULC_GEMM_CTR_BYTES : 0;
     while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
     int kw = (p.K + splitk * nw - 1) / (splitk * nw);
     kw = (kw + 15) / 16 * 16;
@@ -658,7 +705,11 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     static const int target = getenv("HULC_TILE_TARGET") ? atoi(getenv("HULC_TILE_TARGET")) : 768;
     static const int minkt = getenv("HULC_TILE_MINKT") ? atoi(getenv("HULC_TILE_MINKT")) : 4;
     while (gx * gy * splitk < target && nkt / (splitk * 2) >= minkt) splitk *= 2;
-    while (splitk > 1 && (long)splitk * p.M * (p.N + 1) * 4 > ws_bytes) splitk /= 2;
+    // workspace: [HULC_GEMM_CTR_BYTES of tile counters (zero between launches) | split-K slabs + row-sum slabs]
+    unsigned* ctr = (unsigned*)ws;
+    ws = ws ? ws + HULC_GEMM_CTR_BYTES / 4 : ws;
+    ws_bytes = ws_bytes > HULC_GEMM_CTR_BYTES ? ws_bytes - HULC_GEMM_CTR_BYTES : 0;
+    while (splitk > 1 && ((long)splitk * p.M * (p.N + 1) * 4 > ws_bytes || (long)gx * gy * 4 > HULC_GEMM_CTR_BYTES)) splitk /= 2;
     dim3 grid(gx, gy, splitk), block(WM * WN * 64);
     // operand layouts, storage types and the staging mode are template parameters (no run-time branch around a load)
     const int adt = sizeof(CT) == 4 ? HULC_F32 : p.a_dtype, bdt = sizeof(CT) == 4 ? HULC_F32 : p.b_dtype;
@@ -666,7 +717,7 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     const bool micro = !ak && !bk && p.lda % amr == 0 && p.ldb % bmr == 0 && (uintptr_t)p.A % 16 == 0 && (uintptr_t)p.B % 16 == 0 &&
                        p.M % amr == 0 && p.N % bmr == 0 && p.M >= amr && p.N >= bmr &&
                        (sizeof(CT) == 4 || (p.M % 8 == 0 && p.N % 8 == 0));      // bf16 MFMA: 8-row chunks of the [k][rows] tiles
-#define HULC_GK(AKv, BKv, ADTv, BDTv, MICROv) gemm_kernel<CT, TM, TN, WM, WN, AKv, BKv, ADTv, BDTv, MICROv><<<grid, block, 0, s>>>(p, ws, splitk)
+#define HULC_GK(AKv, BKv, ADTv, BDTv, MICROv) gemm_kernel<CT, TM, TN, WM, WN, AKv, BKv, ADTv, BDTv, MICROv><<<grid, block, 0, s>>>(p, ws, splitk, ctr)
 #define HULC_GK_DT(AKv, BKv, MICROv)                                                              \
     do {                                                                                          \
         if (adt == HULC_F32 && bdt == HULC_F32) HULC_GK(AKv, BKv, HULC_F32, HULC_F32, MICROv);    \
@@ -683,10 +734,7 @@ void launch_cfg(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStr
     else HULC_GK_DT(false, false, false);
 #undef HULC_GK_DT
 #undef HULC_GK
-    if (splitk > 1) {
-        const long n = (long)p.M * p.N;
-        gemm_splitk_epilogue_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, ws, splitk);
-    }
+    // (split K: the last workgroup to arrive at a tile sums the slabs and runs the epilogue inside the same launch)
 }
 
 template <typename CT>

@@ -36,7 +36,8 @@ struct ChLayer {
 struct ChainP {
     ChLayer L[CH_MAXL];
     int nl, M;
-    const uint16_t* x0b;                // layer 0 input, bf16 blocked (chain_prep_kernel)
+    const float* x0; long ld_x0; int K0;    // layer 0 input, fp32 [M][K0] ...
+    uint16_t* x0b;                      // ... and its bf16 blocked copy (chain_stage_input)
     uint16_t* xb;
     unsigned* bar; int* err; int* err_sticky;
 };
@@ -44,28 +45,32 @@ struct ChainP {
 union F8 { uint4 u; bf16x8_t b; };
 HULC_DEVICE constexpr int s_of(int bi, int q, int ab) { return bi * ab + q; }
 
-// before the chain: zero the barrier header, and lay the fp32 input out the way every later layer finds its input — bf16, blocked
-// [k / 8][64 rows][8] (rows >= M and columns >= K0 zero).  Read by the chain's 256 workgroups as 16-byte pieces; gathering the fp32 rows
-// inside the chain kernel instead cost 256 x M x K0 x 4 bytes of strided L2 reads (74 us for a 4096-wide input).
-__global__ __launch_bounds__(256) void chain_prep_kernel(uint4* __restrict__ hdr, long nhdr, const float* __restrict__ x0, long ld_x0, int M, int K0,
-                                                          uint4* __restrict__ x0b, long nchunk) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nhdr) hdr[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (i < nchunk) {
+// stage 0 of the chain (all workgroups): lay the fp32 input out the way every later layer finds its input — bf16, blocked
+// [k / 8][64 rows][8] (rows >= M and columns >= K0 zero), written through to memory like the layers' exchange copies.  Each of the chain's
+// 256 workgroups then reads it as 16-byte pieces; gathering the fp32 rows directly cost 256 x M x K0 x 4 bytes of strided L2 reads
+// (74 us for a 4096-wide input).
+HULC_DEVICE void chain_stage_input(const ChainP& p, int tid, int nwg) {
+    const long nchunk = ((long)(p.K0 + 7) / 8) * 64;
+    for (long i = (long)blockIdx.x * 256 + tid; i < nchunk; i += (long)nwg * 256) {
         const int m = (int)(i & 63), k = (int)(i >> 6) * 8;
         uint4 o = make_uint4(0u, 0u, 0u, 0u);
-        if (m < M && k < K0) {                                             // K0 is a multiple of 8
-            const float* src = x0 + (long)m * ld_x0 + k;
+        if (m < p.M && k < p.K0) {                                         // K0 is a multiple of 8
+            const float* src = p.x0 + (long)m * p.ld_x0 + k;
             const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
             o = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
         }
-        x0b[i] = o;
+        unsigned long long* dst = (unsigned long long*)(p.x0b + i * 8);
+        __hip_atomic_store(dst, (unsigned long long)o.x | ((unsigned long long)o.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, (unsigned long long)o.z | ((unsigned long long)o.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(p.bar + (blockIdx.x & 7) * CH_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one layer for this workgroup's column tile; KSW = k-steps (of 32) per wave, K padded up to 128 * KSW
 template <int KSW>
-HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool first, const uint16_t* __restrict__ xin, float (*red)[64][16], int tid, bool& timed_out,
+HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const uint16_t* __restrict__ xin, float (*red)[64][16], int tid, bool& timed_out,
                              int nwg) {
     const ChLayer& c = p.L[l];
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -82,10 +87,10 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool first, const
             wf[s].u = *(const uint4*)(wrow + (k < c.K ? k : 0));            // clamped (always valid) address; the matching A fragment is zero
         }
     }
-    // ---- wait for the previous layer's outputs (all workgroups)
-    if (!first) {
+    // ---- wait for the previous stage's outputs (all workgroups): stage 0 = the input copy, stage l = layer l - 1
+    {
         if (tid < 8) {
-            const unsigned want = (unsigned)(nwg / 8) * (unsigned)l;
+            const unsigned want = (unsigned)(nwg / 8) * (unsigned)(l + 1);
             const unsigned* bar = p.bar + tid * CH_CTR_STRIDE;
             long spins = 0;
             while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -99,6 +104,16 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool first, const
         }
         __syncthreads();
         asm volatile("" ::: "memory");
+        // behind the LAST wait of the launch nobody looks at the arrival counters again: the workgroup that gets here last puts them
+        // (and the count of workgroups that got here) back to zero — the header is clean for the next launch without a memset / prep launch
+        if (last && tid == 0) {
+            unsigned* done = p.bar + 8 * CH_CTR_STRIDE + 16;
+            if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1)) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) __hip_atomic_store(p.bar + x * CH_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     // ---- products: 4 row tiles of 16, this wave's k-steps.  The A fragments are fetched a batch of k-steps ahead of the MFMAs that consume them
     // (two register sets): left to itself the compiler loads one k-step, waits a full L2 round trip, multiplies, and repeats — 16 round trips
@@ -189,17 +204,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x;
     bool timed_out = false;
     const int nwg = gridDim.x, tile = blockIdx.x;                         // N <= 16 * gridDim: at most one tile per workgroup and layer
+    chain_stage_input(p, tid, nwg);
     for (int l = 0; l < p.nl; ++l) {
         const int ksw = (p.L[l].K + 127) / 128;
         const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : p.x0b;
         switch (ksw) {
-            case 1: chain_layer<1>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            case 2: chain_layer<2>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            case 3: chain_layer<3>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            case 4: chain_layer<4>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            case 8: chain_layer<8>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            case 16: chain_layer<16>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
-            default: chain_layer<32>(p, l, tile, l == 0, xin, red, tid, timed_out, nwg); break;
+            case 1: chain_layer<1>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            case 2: chain_layer<2>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            case 3: chain_layer<3>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            case 4: chain_layer<4>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            case 8: chain_layer<8>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            case 16: chain_layer<16>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            default: chain_layer<32>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
         }
     }
 }
@@ -220,7 +236,7 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
     if (d->M < 1 || d->M > 64) return hulc_fail(-2, "hulc_mlp_chain: 1 <= M <= 64 rows");
     if ((uintptr_t)ws % 16 || (uintptr_t)d->x0 % 16 || d->ld_x0 % 4) return hulc_fail(-4, "hulc_mlp_chain: workspace / input must be 16-byte aligned");
     ChainP p = {};
-    p.nl = d->nl; p.M = d->M;
+    p.nl = d->nl; p.M = d->M; p.x0 = d->x0; p.ld_x0 = d->ld_x0; p.K0 = d->K0;
     p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8L * CH_CTR_STRIDE * 4); p.err_sticky = err_sticky;
     p.xb = (uint16_t*)((char*)ws + CH_HEADER);
     long off = 0;
@@ -243,9 +259,6 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
     }
     hipStream_t st = (hipStream_t)stream;
     p.x0b = p.xb + ((off - (long)d->layers[d->nl - 1].N * 64 + 7) / 8) * 8;          // behind the exchange regions of layers 0 .. nl-2
-    const long nchunk = ((long)(d->K0 + 7) / 8) * 64, nhdr = CH_HEADER / 16;
-    const long nthr = nchunk > nhdr ? nchunk : nhdr;
-    chain_prep_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>((uint4*)ws, nhdr, d->x0, d->ld_x0, d->M, d->K0, (uint4*)p.x0b, nchunk);
     mlp_chain_kernel<<<256, 256, 0, st>>>(p);
     return hulc_check_launch("hulc_mlp_chain");
 }

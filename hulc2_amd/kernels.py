@@ -137,6 +137,7 @@ def check_faults(device) -> None:
     w = int(t.item()) if t is not None else 0
     if w != 0:
         t.zero_()
+        _chain_ws.clear()                 # (a timed-out chain leaves its barrier counters non-zero: fresh workspaces)
         who = [n for b, n in ((1, "rnn_wavefront (HULC_NO_RNN_WAVEFRONT=1 selects the per-step GEMM path)"),
                               (2, "mlp_chain (HULC_NO_MLP_CHAIN=1 selects the per-layer GEMM path)")) if w & b]
         raise _L.HulcKernelError(
@@ -182,7 +183,7 @@ def _gemm_scratch(device) -> torch.Tensor:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     t = _scratch.get(key)
     if t is None:
-        t = _scratch[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)   # 32 MiB
+        t = _scratch[key] = torch.zeros(8 << 20, dtype=torch.float32, device=device)   # 32 MiB; the head holds hulc_gemm's tile counters (zero between launches)
     return t
 
 
@@ -526,6 +527,9 @@ def mlp_chain_ok(M: int, K0: int, widths, device) -> bool:
     return True
 
 
+_chain_ws = {}
+
+
 def mlp_chain(x0, layers, M):
     """layers: [(W bf16 [N][K] k-major, bias fp32 or None, relu flag, mask fp32 (M, N) or None, mask_scale, out fp32 (M, N))]; one persistent
     launch (csrc/mlp_chain.hip).  x0 fp32 (M, K0), unit inner stride."""
@@ -548,7 +552,15 @@ def mlp_chain(x0, layers, M):
         k = W.shape[0]
     lib = _L.load()
     lib.hulc_mlp_chain_workspace.restype = _c.c_long
-    ws = _ws(lib.hulc_mlp_chain_workspace(_c.byref(d)), x0.device)
+    # persistent workspace per (device, stream): its header (barrier counters) is zero before the first launch and every launch leaves it
+    # zero; check_faults drops the cache after a barrier timeout (the one case that leaves counts behind)
+    need = int(lib.hulc_mlp_chain_workspace(_c.byref(d)))
+    key = (x0.device, _stream())
+    ws = _chain_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros(max(need, 4 << 20) // 4 + 1, dtype=torch.float32, device=x0.device)
+        if not torch.cuda.is_current_stream_capturing():
+            _chain_ws[key] = ws
     _call("hulc_mlp_chain", _c.byref(d), ws, fault_word(x0.device), key=("mlp_chain", M, int(x0.shape[1])) + tuple(int(l[0].shape[0]) for l in layers),
           flops=flops, nbytes=nbytes)
 

@@ -46,7 +46,8 @@ typedef struct {
     float alpha, mask_scale, drop_p;
     unsigned long long drop_seed;
     int compute;
-    void* ws; long ws_bytes;   /* optional fp32 scratch for the split-K paths */
+    void* ws; long ws_bytes;   /* optional scratch for the split-K paths: the first 16 KiB are tile counters that must be ZERO before the
+                                * first use of the buffer (every launch leaves them zero), fp32 slabs follow; not shared by concurrent streams */
     const unsigned long long* seed_dev;   /* optional device word xor-ed into drop_seed (see hulc_step_state_advance) */
     float* rowsum_a; int rowsum_accumulate;   /* optional, M > 64 only: rowsum_a[m] (+)= sum_k A[m][k] in fp32 — with
                                                * A = dY this is the bias gradient of the weight-gradient GEMM dW = dY^T X, fused */
@@ -300,11 +301,13 @@ int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 /* y_l = f_l(y_{l-1} W_l^T + b_l), l = 0 .. nl-1 (nl <= 8): the per-sequence MLPs of the policy — PlanProposalNetwork (plan_proposal_net.py:
  * 26-47), the goal encoders (goal_encoders.py:21-34,53-71), ProjVisLang (proj_vis_lang.py:10-21), the posterior's fc -> fc_state
  * (plan_recognition_net.py:122-123,144-148) — and, with W = the transposed weights and mask = the stored activations, the data-gradient
- * chain of their backward (f_l = keep where mask > 0, scaled by mask_scale).  x0: fp32 (M, K0 <= 4096) row-major (a first small launch
+ * chain of their backward (f_l = keep where mask > 0, scaled by mask_scale).  x0: fp32 (M, K0 <= 4096) row-major (the launch's first stage
  * rounds it to bf16 in the layout the layers exchange their outputs in); W_l: bf16 [N_l][K_l] with
  * K_l = N_{l-1}; every layer's fp32 output goes to out_l (M, N_l).  N_l: multiple of 16, <= 4096; K: multiple of 8 rounding up to
  * 128 x {1, 2, 3, 4, 8, 16, 32}.  256 workgroups meet at a device-wide barrier between layers: the stream must not run another kernel
- * concurrently; a barrier timeout ORs bit 1 (value 2) into *err_sticky (see hulc_rnn_wave_desc.err_sticky).  ws: hulc_mlp_chain_workspace(d) bytes. */
+ * concurrently; a barrier timeout ORs bit 1 (value 2) into *err_sticky (see hulc_rnn_wave_desc.err_sticky).  ws: hulc_mlp_chain_workspace(d) bytes
+ * whose first 36 KiB (barrier counters) were ZERO before the first use of the buffer; every launch that does not time out leaves them zero,
+ * so one buffer serves all launches of a stream (a single launch, no memset). */
 typedef struct hulc_mlp_chain_layer {
     const void* W; long ldw;
     const float* bias;

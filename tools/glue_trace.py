@@ -51,6 +51,14 @@ def main():
         total += n
         print(f"{n / steps:6.1f}/step  {op:28s} {kname:60s} {where}")
     print(f"total {total / steps:.1f} aten-launched kernels per step")
+    allk = collections.Counter()
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in ev.name and "Memset" not in ev.name:
+            nm = ev.name.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
+            allk[nm[:90]] += 1
+    print(f"ALL device kernels: {sum(allk.values()) / steps:.1f} per step")
+    for name, n in allk.most_common(60):
+        print(f"{n / steps:6.1f}/step  {name}")
     # runtime copies / memsets (not kernels of an aten op): name, count, and the CPU op that was running when they were issued
     mem = collections.Counter()
     for ev in prof.events():
