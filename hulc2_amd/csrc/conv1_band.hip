@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int bands = (p.OH + p.R - 1) / p.R;
+    const float inv_OW = fast_rcp(p.OW);
     // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
     // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
     const int nunits = ((p.Nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * bands;     // this workgroup's units
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         for (int t = wave; t < ntiles; t += 8) {
             const int q = t * 32 + r;
             const int qc = q < npix ? q : npix - 1;
-            const int oy = qc / p.OW, ox = qc % p.OW;
+            const int oy = fast_div(qc, inv_OW), ox = qc - oy * p.OW;
             const char* patch = xlds + ((oy * S) * p.W + ox * S + h * p.W) * 2;   // 8-byte aligned: ox*S*2 = 8*ox; lane half h = odd patch row
             const char* wrow = wlds + r * WROW + h * 16;
             f32x16_t acc;

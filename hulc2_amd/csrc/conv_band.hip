@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     const long cl_yoff = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)cl.y_off >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cl.y_off));
     const int Wb = (p.OWmax - 1) * S + TW;                  // band columns (padding included)
+    const float inv_Wb = __builtin_amdgcn_rcpf((float)Wb), inv_OW = __builtin_amdgcn_rcpf((float)cl_OW);
     const int bands = (p.OHmax + p.R - 1) / p.R;
     const int nunits = MULTI ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
 
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         for (int j = 0; j < MAXCH; ++j) {
             const int px = tid / CPP + j * (NT / CPP);
             int pxc = px < npx ? px : 0, f = 0;
-            if (MULTI) { f = pxc / fpx; pxc -= f * fpx; }
-            const int br = pxc / Wb, bc = pxc % Wb;
+            if (MULTI) { f = fast_div(pxc, __builtin_amdgcn_rcpf((float)fpx)); pxc -= f * fpx; }
+            const int br = fast_div(pxc, inv_Wb), bc = pxc - br * Wb;
             const int iy = iy0 + br, ix = bc - p.pad_x;
             const bool inb = px < npx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             // unconditional load from a clamped address, then select (no branch around the load)
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             const bool live = q < npix;
             if (!live) q = npix - 1;
             int f = 0;
-            if (MULTI) { f = q / fpix; q -= f * fpix; }
-            const int oy = q / cl_OW, ox = q % cl_OW;
+            if (MULTI) { f = fast_div(q, __builtin_amdgcn_rcpf((float)fpix)); q -= f * fpix; }
+            const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
             const char* a0 = band + ((f * rows + oy * S) * Wb + ox * S) * PS + h * 16;
             f32x16_t acc;
 #pragma unroll

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
     const int Wb = p.W;                                   // bands hold full input rows: staging is a contiguous copy (no index division)
     const int Wp = Wb;                                    // NCHW plane row pitch (elements)
     const int bands = (p.OH + p.R - 1) / p.R;
+    const float inv_OW = fast_rcp(p.OW);
     const int nunits = p.F > 1 ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
     const int rows_max = (p.F - 1) * p.H + (p.R - 1) * S + TH;
     const int npix_max = (p.F * p.R * p.OW + 15) / 16 * 16;
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
         }
         for (int q = tid; q < npad; q += NT) {               // patch origin of every output pixel of the band
             const int qc = q < npix ? q : npix - 1;
-            const int ppf = R * p.OW, f = qc / ppf, qq = qc % ppf;
-            const int oy = qq / p.OW, ox = qq % p.OW;
+            const int ppf = R * p.OW, f = fast_div(qc, fast_rcp(ppf)), qq = qc - f * ppf;
+            const int oy = fast_div(qq, inv_OW), ox = qq - oy * p.OW;
             pixoff[q] = NCHW ? ((oy * S) * Wp + ox * S) * 2 : ((f * p.H + oy * S) * Wb + ox * S) * PS;
         }
     };
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int bands = (p.OH + p.R - 1) / p.R;
+    const float inv_OW = fast_rcp(p.OW), inv_W = fast_rcp(p.W);
     // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
     // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
     const int nunits = ((p.Nimg - blockIdx.x + gridDim.x - 1) / gridDim.x) * bands;     // this workgroup's units
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             if (id >= items) continue;
-            const int e0 = id * 8, row = e0 / p.W, col = e0 - row * p.W;
+            const int e0 = id * 8, row = fast_div(e0, inv_W), col = e0 - row * p.W;
             const uint32_t w[4] = {xpre[j].x, xpre[j].y, xpre[j].z, xpre[j].w};          // columns col .. col + 7, two per dword
             char* dst = xband + (long)((c * rows_max + row) * 4) * p.PSTR + (col >> 2) * 2;
             if (w8) {                                      // plane phi gets columns col + phi and col + 4 + phi: elements j, j + 1
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         for (int j = 0; j < YCH; ++j) {
             const int q = tid / YCPP + j * (NT / YCPP);
             if (q < npix) {
-                const int oy = q / p.OW, slot = oy * p.OWP + (q - oy * p.OW);
+                const int oy = fast_div(q, inv_OW), slot = oy * p.OWP + (q - oy * p.OW);
                 const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }

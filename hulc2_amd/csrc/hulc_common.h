@@ -199,6 +199,14 @@ template <int TM, int TN> struct MmaTile<float, TM, TN> {
 };
 
 // accumulator element (reg) of a 32x32 tile -> row inside the tile; the column is lane & 31.
+// x / d for 0 <= x < 2^20 with inv = v_rcp_f32(d) (1 ulp): exact — (x + 0.5) / d is at least 0.5 / d away from an integer, the error of the
+// product is below x / d x 2^-22, i.e. below that margin for every x < 2^20 — three VALU ops instead of the ~25 of an integer division.  The conv
+// band staging plans divide by a band / map width for every 16-byte chunk of every unit (500 VALU instructions per wave and unit before the
+// first MFMA of conv3).
+HULC_DEVICE int fast_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+HULC_DEVICE float fast_rcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
+
 HULC_DEVICE int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ---------------------------------------------------------------------------------------------
