@@ -41,6 +41,7 @@ struct BandP {
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
     int relu;
+    int dbg;                        // timing experiments (HULC_BAND_DBG): 1 skip the MFMA loop, 2 skip the output stores, 4 skip band staging
     BandCls cls[BAND_MAXCLS];
 };
 
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     __syncthreads();
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits) stage_load(next);                 // in flight during the MFMA loop below
+        if (next < nunits && !(p.dbg & 4)) stage_load(next);                 // in flight during the MFMA loop below
 
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int Rc = r0 < cl_OH ? ((r0 + R <= cl_OH) ? R : cl_OH - r0) : 0;   // this class may have fewer rows/cols
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             bf16x8_t pf[RD];
 #pragma unroll
             for (int i = 0; i < RD; ++i) pf[i] = frag(i);
+            if (!(p.dbg & 1))
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const bf16x8_t px = pf[ks % RD];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                             if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) o[e] &= 0x0000ffffu;
                         }
                     }
-                    if (live) *(uint4*)((uint16_t*)p.Y + off) = make_uint4(o[0], o[1], o[2], o[3]);
+                    if (live && !(p.dbg & 2)) *(uint4*)((uint16_t*)p.Y + off) = make_uint4(o[0], o[1], o[2], o[3]);
                 }
             } else if (live) {
                 const long off = off0 + 4 * h;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             }
         }
         __syncthreads();                                     // every wave is done reading this band
-        if (next < nunits) stage_store(next);
+        if (next < nunits && !(p.dbg & 4)) stage_store(next);
         __syncthreads();
     }
 }
@@ -322,6 +324,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;
     p.x_sn = x_sn; p.x_sy = x_sy; p.x_sx = x_sx; p.y_sn = y_sn; p.y_sy = y_sy; p.y_sx = y_sx;
     p.ldw = ldw; p.relu = relu;
+    { static const char* e = getenv("HULC_BAND_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.OHmax = 0; p.OWmax = 0;
     for (int c = 0; c < ncls; ++c) {
         p.cls[c].OH = cls_OH[c]; p.cls[c].OW = cls_OW[c]; p.cls[c].y_off = cls_yoff[c]; p.cls[c].co_base = cls_cobase[c];
