@@ -56,6 +56,25 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
             t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
 
 
+def fill_affordance_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
+    """The recipe for the affordance model's trainable part (language-fused U-Net decoder, segmentation head, depth
+    head, text_fc): convolution / linear weights U(+-1/sqrt(fan_in)), biases U(+-0.05), BatchNorm gains 1 + 0.1 N(0,1) and shifts
+    0.1 N(0,1) (4-D weights mark a convolution, a 1-D `.1.weight` / `.1.bias` inside a Conv2dReLU is its BatchNorm); running statistics
+    and counters are left at their initial values."""
+    for name, t in sd.items():
+        if not t.is_floating_point() or "running_" in name:
+            continue
+        g = _gen(seed, name)
+        leaf = name.rsplit(".", 1)[-1]
+        if t.dim() >= 2:
+            t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) / math.sqrt(t[0].numel()))
+        elif ".conv1.1." in name or ".conv2.1." in name:                      # nn.BatchNorm2d of a Conv2dReLU
+            r = torch.randn(t.shape, generator=g) * 0.1
+            t.copy_(r + 1.0 if leaf == "weight" else r)
+        else:
+            t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * 0.05)
+
+
 def fill_bert_state_dict_(sd: Dict[str, torch.Tensor], seed: int) -> None:
     """The same recipe for a transformers BertModel state_dict (SURVEY §8 row f-3 parity fixtures): LayerNorm gains 1 + 0.1 N(0,1),
     LayerNorm biases 0.1 N(0,1), embedding tables 0.5 N(0,1), dense weights U(+-2/sqrt(fan_in)) (sharp enough that the attention

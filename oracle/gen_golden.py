@@ -492,6 +492,115 @@ def gen_wordpiece():
          transformers_version=transformers_version())
 
 
+def import_affordance_reference():
+    """the affordance model's leaf modules by file path (SURVEY §8 row f-4): unet_decoder.py, fusion.py and losses.py need torch only;
+    depth_gaussian.py imports torchvision.models, the dataset transforms (cv2, torchvision) and the CLIP text encoder at module level without
+    using them in DepthEstimationGaussian — name-only stubs let the file load and are removed again."""
+    import importlib.util, types
+    A = REF / "hulc2" / "affordance"
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    ud = load("_ref_unet_decoder", A / "models" / "core" / "unet_decoder.py")
+    fu = load("_ref_fusion", A / "models" / "core" / "fusion.py")
+    lo = load("_ref_aff_losses", A / "utils" / "losses.py")
+    stubs = {}
+    for n in ("torchvision", "torchvision.models", "torchvision.transforms", "cv2", "hulc2.utils.img_utils",
+              "hulc2.affordance", "hulc2.affordance.datasets", "hulc2.affordance.models", "hulc2.affordance.models.language_encoders",
+              "hulc2.affordance.models.language_encoders.clip_lang_encoder"):
+        if n not in sys.modules:
+            stubs[n] = sys.modules[n] = types.ModuleType(n)
+    if "hulc2" not in sys.modules:
+        stubs["hulc2"] = _stub_pkg("hulc2", REF / "hulc2")
+    if "hulc2.utils" not in sys.modules:
+        stubs["hulc2.utils"] = _stub_pkg("hulc2.utils", REF / "hulc2" / "utils")
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].Normalize = object           # base class of an unused transform defined in the file
+    sys.modules["hulc2.utils.img_utils"].pixel_after_pad = sys.modules["hulc2.utils.img_utils"].resize_pixel = None
+    sys.modules["hulc2.affordance.models.language_encoders.clip_lang_encoder"].CLIPLang = None
+    try:
+        sys.modules["hulc2.affordance.datasets.transforms"] = load("hulc2.affordance.datasets.transforms", A / "datasets" / "transforms.py")
+        stubs["hulc2.affordance.datasets.transforms"] = True
+        dg = load("_ref_depth_gaussian", A / "models" / "depth" / "depth_gaussian.py")
+    finally:
+        for k in stubs:                 # name-only stubs must not outlive the import (transformers probes torchvision.__spec__ later)
+            sys.modules.pop(k, None)
+    return ud, fu, lo, dg
+
+
+class _Cfg(dict):
+    """the two access styles the reference uses on its DictConfig: cfg["lang_fusion_type"] and cfg.normalized"""
+    __getattr__ = dict.__getitem__
+
+
+def build_affordance_reference(seed: int, enc_hw: int):
+    """the trainable part of PixelAffLangDetector in its shipped variant (conf/affordance/aff_detection/r3m.yaml): what
+    R3M._build_decoder (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:52-69), SBertLang.text_fc
+    (language_encoders/sbert_lang_encoder.py:19) and DepthEstimationGaussian._build_decoder (models/depth/depth_gaussian.py:56-65) create"""
+    ud, fu, lo, dg = import_affordance_reference()
+    dec_ch = (512, 256, 128, 64, 32)
+    net = torch.nn.ModuleDict({
+        "text_fc": torch.nn.Linear(384, 1024),
+        "decoder": ud.UnetLangFusionDecoder(fusion_module=fu.names["mult"], lang_embed_dim=1024, encoder_channels=(3, 64, 64, 128, 256, 512),
+                                            decoder_channels=dec_ch, n_blocks=len(dec_ch)),
+        "segmentation_head": torch.nn.Conv2d(dec_ch[-1], 1, kernel_size=3, padding=1),
+        "depth_stream": dg.DepthEstimationGaussian((512, enc_hw, enc_hw), 1, _Cfg(lang_fusion_type="mult", normalized=True,
+                                                                                  depth_norm_values={"mean": 0.0, "std": 1.0})),
+    })
+    syn.fill_affordance_state_dict_(net.state_dict(), seed)
+    return net, lo
+
+
+def gen_affordance():
+    """One training step of the affordance model's trainable part on given trunk features (the frozen R3M trunk is third-party and absent:
+    its five feature maps are the inputs, like the (B, 384) sentence embedding is for SBERT).  Follows R3M.forward
+    (r3m_rn18.py:78-94), AffDepthLangFusionPixel.forward (lang_fusion/aff_lang_depth_pixel.py:98-129), PixelAffLangDetector.criterion
+    (pixel_aff_lang_detector.py:122-171) with loss_weights aff 0.1 / depth 0.9 (conf/affordance/train_affordance.yaml:31-33), train mode
+    (BatchNorm batch statistics)."""
+    B, HW = 2, 64
+    net, lo = build_affordance_reference(SEED, HW // 32)
+    net.train()
+    sizes = ((64, HW // 4), (64, HW // 4), (128, HW // 8), (256, HW // 16), (512, HW // 32))        # stem, layer1 .. layer4 of ResNet-18
+    feats = [torch.relu(randn(SEED, f"x.aff.f{i}", B, c, h, h)) for i, (c, h) in enumerate(sizes)]
+    img = randn(SEED, "x.aff.img", B, 3, HW, HW)
+    emb = randn(SEED, "x.aff.emb", B, 384) * 0.5
+    p0 = torch.stack([torch.randint(0, HW, (B,), generator=g(SEED, "x.aff.p0y")), torch.randint(0, HW, (B,), generator=g(SEED, "x.aff.p0x"))], 1)
+    gt_depth = randn(SEED, "x.aff.depth", B)
+    l_enc = net["text_fc"](emb)
+    dec = net["decoder"](l_enc, img, *feats)
+    aff = net["segmentation_head"](dec)                                  # (B, 1, H, W)
+    logits = aff.permute(0, 2, 3, 1).reshape(B, -1)
+    (dist, mu, sigma), _ = net["depth_stream"](feats[-1], (l_enc, None, None))
+    label = torch.zeros(B, HW, HW)
+    label[torch.arange(B), p0[:, 0], p0[:, 1]] = 1
+    aff_loss = lo.cross_entropy_with_logits(logits, label.reshape(B, -1))
+    depth_loss = net["depth_stream"].loss((dist, mu, sigma), gt_depth.unsqueeze(-1))
+    loss = 0.1 * aff_loss + 0.9 * depth_loss
+    loss.backward()
+    out = dict(seed=SEED, B=B, HW=HW, emb=emb, p0=p0.to(torch.int32), gt_depth=gt_depth, loss=loss, aff_loss=aff_loss, depth_loss=depth_loss,
+               logits_sub=logits[:, ::37], mu=mu, sigma=sigma, dec_sub=dec[:, :, ::5, ::7], l_enc_sub=l_enc[:, ::16],
+               torch_version=np.array(torch.__version__))
+    for i, f in enumerate(feats):
+        out[f"feat{i}"] = f
+    for name, p in net.named_parameters():
+        if p.grad is not None:                                           # (blocks 3 and 4 own a lang_proj the forward never uses)
+            out["gnorm." + name] = p.grad.norm()
+    for name in ("decoder.blocks.0.conv1.0.weight", "decoder.blocks.4.conv2.0.weight", "segmentation_head.weight", "text_fc.weight"):
+        out["grad." + name] = net.get_parameter(name).grad.flatten()[::97][:512]
+    for name in ("decoder.blocks.0.conv1.1.weight", "decoder.blocks.0.conv1.1.bias", "decoder.blocks.3.conv2.1.weight", "decoder.blocks.0.lang_proj.bias",
+                 "depth_stream.depth_mu.weight", "depth_stream.fc3.bias", "segmentation_head.bias"):
+        out["grad." + name] = net.get_parameter(name).grad.flatten()
+    sd = net.state_dict()
+    out["bn_mean.b0c1"] = sd["decoder.blocks.0.conv1.1.running_mean"]
+    out["bn_var.b4c2"] = sd["decoder.blocks.4.conv2.1.running_var"]
+    save("affordance_step_B2_64", **out)
+
+
 def transformers_version():
     import transformers
     return transformers.__version__
@@ -612,6 +721,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "wordpiece":       # only the tokenizer fixture (needs transformers, not the reference)
         gen_wordpiece()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "affordance":      # only the f-4 fixture
+        gen_affordance()
+        return
     R = import_reference()
     m, dist, flat = build_reference_modules(R, SEED)
     print("reference leaf modules imported from", REF)
@@ -631,6 +743,7 @@ def main():
     gen_step(m, dist, flat, 2, 32)
     gen_inference(m, dist, flat)
     gen_transforms()
+    gen_affordance()
     gen_minilm()
     gen_wordpiece()
 

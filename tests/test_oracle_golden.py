@@ -442,3 +442,39 @@ def test_r3m_trunk_oracle_matches_nn_layers():
     assert got_f.shape == (2, 512)
     assert (got_f - want_f).abs().max().item() <= 1e-5 * want_f.abs().max().item()
     assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+def test_affordance_step():
+    """row f-4: the affordance model's trainable part (oracle/affordance_oracle.py) against a step of the reference's own
+    UnetLangFusionDecoder + segmentation head + DepthEstimationGaussian + cross_entropy_with_logits (gen_golden.py::gen_affordance):
+    losses, logits, depth distribution, decoder output, every gradient norm, gradient slices, BatchNorm running statistics"""
+    from oracle import affordance_oracle as A
+    g = load("affordance_step_B2_64")
+    B, HW = int(g["B"]), int(g["HW"])
+    sd = {k: torch.empty(s) for k, s in A.trainable_shapes(HW // 32).items()}
+    syn.fill_affordance_state_dict_(sd, int(g["seed"]))
+    for v in sd.values():
+        v.requires_grad_(True)
+    feats = [torch.as_tensor(g[f"feat{i}"]) for i in range(5)]
+    stats = []
+    out = A.training_step(sd, feats, torch.as_tensor(g["emb"]), torch.as_tensor(g["p0"]), torch.as_tensor(g["gt_depth"]), HW, stats=stats)
+    out["loss"].backward()
+    for k in ("loss", "aff_loss", "depth_loss", "mu", "sigma"):
+        close(out[k], g[k], what=k)
+    close(out["logits"][:, ::37], g["logits_sub"], what="logits")
+    close(out["dec"][:, :, ::5, ::7], g["dec_sub"], what="decoder output")
+    close(out["l_enc"][:, ::16], g["l_enc_sub"], what="l_enc")
+    seen = 0
+    for k in g:
+        if k.startswith("gnorm."):
+            close(sd[k[6:]].grad.norm(), g[k], rtol=1e-4, what=k)
+            seen += 1
+        elif k.startswith("grad."):
+            gr = sd[k[5:]].grad.flatten()
+            close(gr[::97][:512] if g[k].shape[0] == 512 and gr.numel() > 512 * 97 - 96 else (gr if gr.numel() == g[k].shape[0] else gr[::97][:512]), g[k], rtol=1e-4, what=k)
+    assert seen == 50
+    unused = [k for k, v in sd.items() if v.grad is None]
+    assert sorted(unused) == sorted(f"decoder.blocks.{i}.lang_proj.{n}" for i in (3, 4) for n in ("weight", "bias"))
+    # BatchNorm2d bookkeeping (momentum 0.1 from mean 0 / var 1, unbiased batch variance)
+    close(0.1 * stats[0][0], g["bn_mean.b0c1"], rtol=1e-4, what="running_mean of block 0 conv1")
+    close(0.9 + 0.1 * stats[9][1], g["bn_var.b4c2"], rtol=1e-4, what="running_var of block 4 conv2")
