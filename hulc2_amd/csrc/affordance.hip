@@ -1,0 +1,324 @@
+// affordance.hip — the pointwise / reduction kernels of the affordance model's trainable part on padded-grid
+// activations (layout: gridconv.hip).  Reference: Conv2dReLU's BatchNorm2d (batch statistics) + ReLU and DecoderBlock.forward
+// (language fusion, nearest up-sampling, skip concatenation) of hulc2/affordance/models/core/unet_decoder.py:6-80 with FusionMult
+// (core/fusion.py:40-47,64-73), cross_entropy_with_logits (utils/losses.py:6-13) as PixelAffLangDetector.criterion applies it
+// (pixel_aff_lang_detector.py:122-145), and their autograd backward.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+HULC_DEVICE bool grid_interior(int r, int H, int W) {
+    const int Wp = W + 2, PP = (H + 2) * Wp;
+    const int rem = r % PP, yy = rem / Wp, xx = rem - yy * Wp;
+    return yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+}
+
+// ---- fixed-order sum of partial rows: out[c] = sum_b part[b][c], one thread per column, four loads in flight ------------------------------
+HULC_DEVICE float sum_partials(const float* part, int nb, long ld, int c) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nb; b += 4) {
+        const float x0 = part[(long)b * ld + c], x1 = part[(long)(b + 1) * ld + c], x2 = part[(long)(b + 2) * ld + c], x3 = part[(long)(b + 3) * ld + c];
+        a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+    }
+    for (; b < nb; ++b) a0 += part[(long)b * ld + c];
+    return (a0 + a1) + (a2 + a3);
+}
+
+// BatchNorm2d, training mode: partial sums (sum y, sum y^2 over the interior rows; gridconv's epilogue) -> bn[0..3][C] = mean, rstd,
+// scale = gamma rstd, shift = beta - mean scale; running statistics updated with momentum 0.1 and the unbiased variance (nn.BatchNorm2d)
+__global__ void grid_bn_finalize_kernel(const float* __restrict__ part, int nb, int C, float count, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ bn,
+                                        float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = sum_partials(part, nb, 2L * C, c), s2 = sum_partials(part + C, nb, 2L * C, c);
+    const float mean = s1 / count;
+    float var = s2 / count - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + eps), scale = gamma[c] * rstd;
+    bn[c] = mean; bn[C + c] = rstd; bn[2 * C + c] = scale; bn[3 * C + c] = beta[c] - mean * scale;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / (count - 1.f));
+}
+
+// out = interior ? relu(y scale + shift) : 0 — a thread handles 8 channels of one grid row
+__global__ void grid_bn_relu_fwd_kernel(const uint16_t* __restrict__ y, long ldy, const float* __restrict__ bn, int R, int H, int W, int C,
+                                        uint16_t* __restrict__ out, long ldo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = C / 8;
+    if (i >= (long)R * cpr) return;
+    const int r = (int)(i / cpr), c0 = (int)(i % cpr) * 8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (grid_interior(r, H, W)) {
+        const uint4 v = *(const uint4*)(y + (long)r * ldy + c0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = fmaxf(__uint_as_float(w[e] << 16) * bn[2 * C + c0 + 2 * e] + bn[3 * C + c0 + 2 * e], 0.f);
+            const float b = fmaxf(__uint_as_float(w[e] & 0xffff0000u) * bn[2 * C + c0 + 2 * e + 1] + bn[3 * C + c0 + 2 * e + 1], 0.f);
+            q[e] = pack_bf16x2(a, b);
+        }
+        o = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    *(uint4*)(out + (long)r * ldo + c0) = o;
+}
+
+// backward, pass 1: per channel  s1 = sum dY, s2 = sum dY xhat  with dY = dOut where out > 0 (the ReLU), xhat = (y - mean) rstd; a workgroup
+// sums 256 grid rows x 64 channels (lane = channel, 4 waves = row slices), partial rows [block][2][C]
+__global__ __launch_bounds__(256) void grid_bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dout, long ldd, const uint16_t* __restrict__ out, long ldo,
+                                                                      const uint16_t* __restrict__ y, long ldy, const float* __restrict__ bn, int R, int C,
+                                                                      float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < C;                                    // (C = 32: half the lanes idle)
+    const float mean = cok ? bn[c] : 0.f, rstd = cok ? bn[C + c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const int r0 = blockIdx.x * 256;
+    for (int k = sl; k < 256; k += 4) {
+        const int r = r0 + k;
+        if (r >= R || !cok) break;
+        const float o = bf16_bits_to_f32(out[(long)r * ldo + c]);
+        const float d = o > 0.f ? bf16_bits_to_f32(dout[(long)r * ldd + c]) : 0.f;          // border rows: out == 0
+        const float xh = (bf16_bits_to_f32(y[(long)r * ldy + c]) - mean) * rstd;
+        s1 += d; s2 += d * xh;
+    }
+    red[0][sl][lane] = s1; red[1][sl][lane] = s2;
+    __syncthreads();
+    if (sl == 0 && cok) {
+        part[((long)blockIdx.x * 2) * C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        part[((long)blockIdx.x * 2 + 1) * C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+// the two sums, once: sums[0][C] = s1 (= dbeta), sums[1][C] = s2 (= dgamma), also written / accumulated into the parameter gradients
+__global__ void grid_bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = sum_partials(part, nb, 2L * C, c), s2 = sum_partials(part + C, nb, 2L * C, c);
+    sums[c] = s1; sums[C + c] = s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+}
+
+// backward, pass 2: dZ = interior ? gamma rstd (dY - s1 / M - xhat s2 / M) : 0
+__global__ void grid_bn_relu_bwd_apply_kernel(const uint16_t* __restrict__ dout, long ldd, const uint16_t* __restrict__ out, long ldo,
+                                              const uint16_t* __restrict__ y, long ldy, const float* __restrict__ bn, const float* __restrict__ sums,
+                                              float inv_count, int R, int H, int W, int C, uint16_t* __restrict__ dz, long ldz) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = C / 8;
+    if (i >= (long)R * cpr) return;
+    const int r = (int)(i / cpr), c0 = (int)(i % cpr) * 8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (grid_interior(r, H, W)) {
+        const uint4 vd = *(const uint4*)(dout + (long)r * ldd + c0), vo = *(const uint4*)(out + (long)r * ldo + c0), vy = *(const uint4*)(y + (long)r * ldy + c0);
+        const uint32_t wd[4] = {vd.x, vd.y, vd.z, vd.w}, wo[4] = {vo.x, vo.y, vo.z, vo.w}, wy[4] = {vy.x, vy.y, vy.z, vy.w};
+        uint32_t q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float res[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 2 * e + h;
+                const float ov = h ? __uint_as_float(wo[e] & 0xffff0000u) : __uint_as_float(wo[e] << 16);
+                const float dv = h ? __uint_as_float(wd[e] & 0xffff0000u) : __uint_as_float(wd[e] << 16);
+                const float yv = h ? __uint_as_float(wy[e] & 0xffff0000u) : __uint_as_float(wy[e] << 16);
+                const float d = ov > 0.f ? dv : 0.f;
+                const float xh = (yv - bn[c]) * bn[C + c];
+                res[h] = bn[2 * C + c] * (d - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+            }
+            q[e] = pack_bf16x2(res[0], res[1]);
+        }
+        o = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    *(uint4*)(dz + (long)r * ldz + c0) = o;
+}
+
+// ---- DecoderBlock input: [nearest-up-sampled (x * g) | skip] on the output grid --------------------------------------------------------
+// x: (N, Hi, Wi, Cx) bf16 with element strides (xsn, xsy, xsx) — a grid tensor's interior or a plain NHWC trunk map; g: (N, Cx) fp32 or null
+// (FusionMult: x * lang_proj(l)[:, :, None, None]); skip: (N, Ho, Wo, Cs) bf16 strided likewise or null; out: grid (N, Ho, Wo) rows of Cx + Cs
+__global__ void grid_upcat_fwd_kernel(const uint16_t* __restrict__ x, long xsn, long xsy, long xsx, const float* __restrict__ g,
+                                      const uint16_t* __restrict__ skip, long ssn, long ssy, long ssx, int N, int Ho, int Wo, int s, int Cx, int Cs,
+                                      uint16_t* __restrict__ out) {
+    const int Ct = Cx + Cs, cpr = Ct / 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Wp = Wo + 2, PP = (Ho + 2) * Wp;
+    const long R = (long)N * PP;
+    if (i >= R * cpr) return;
+    const int r = (int)(i / cpr), c0 = (int)(i % cpr) * 8;
+    const int n = r / PP, rem = r - n * PP, yy = rem / Wp, xx = rem - yy * Wp;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (yy >= 1 && yy <= Ho && xx >= 1 && xx <= Wo) {
+        const int yo = yy - 1, xo = xx - 1;
+        if (c0 < Cx) {
+            const uint4 v = *(const uint4*)(x + (long)n * xsn + (long)(yo / s) * xsy + (long)(xo / s) * xsx + c0);
+            if (g) {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    q[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * g[(long)n * Cx + c0 + 2 * e], __uint_as_float(w[e] & 0xffff0000u) * g[(long)n * Cx + c0 + 2 * e + 1]);
+                o = make_uint4(q[0], q[1], q[2], q[3]);
+            } else o = v;
+        } else {
+            o = *(const uint4*)(skip + (long)n * ssn + (long)yo * ssy + (long)xo * ssx + (c0 - Cx));
+        }
+    }
+    *(uint4*)(out + (long)r * Ct + c0) = o;
+}
+
+// backward of the x branch: dsmall[n, yi, xi, c] = g[n, c] * sum over the s x s block of dX (grid rows, first Cx of ldd channels), written as a
+// grid tensor (N, Hi, Wi) of Cx channels (borders zeroed by a separate fill: this kernel writes interior rows only); dg[n, c] = sum over pixels of
+// x[n, yi, xi, c] * block sum.  Workgroup = (n, 64 channels, pixel tile pt of npt); 4 waves = pixel slices; dg needs npt == 1.
+__global__ __launch_bounds__(256) void grid_upcat_bwd_kernel(const uint16_t* __restrict__ dX, long ldd, const uint16_t* __restrict__ x, long xsn, long xsy, long xsx,
+                                                             const float* __restrict__ g, int Hi, int Wi, int s, int Cx, uint16_t* __restrict__ dsmall,
+                                                             float* __restrict__ dg, int accumulate_dg) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int n = blockIdx.x, c = blockIdx.y * 64 + lane, pt = blockIdx.z, npt = gridDim.z;
+    const int Ho = Hi * s, Wo = Wi * s, Wpo = Wo + 2, PPo = (Ho + 2) * Wpo, Wpi = Wi + 2, PPi = (Hi + 2) * Wpi;
+    const float gv = g ? g[(long)n * Cx + c] : 1.f;
+    float acc = 0.f;
+    const int npx = Hi * Wi, per = (npx + npt - 1) / npt, p0 = pt * per, p1 = min(p0 + per, npx);
+    for (int px = p0 + sl; px < p1; px += 4) {
+        const int yi = px / Wi, xi = px - yi * Wi;
+        float bs = 0.f;
+        for (int a = 0; a < s; ++a)
+            for (int b = 0; b < s; ++b)
+                bs += bf16_bits_to_f32(dX[((long)n * PPo + (long)(yi * s + a + 1) * Wpo + (xi * s + b + 1)) * ldd + c]);
+        if (dsmall) dsmall[((long)n * PPi + (long)(yi + 1) * Wpi + (xi + 1)) * Cx + c] = f32_to_bf16_bits(bs * gv);
+        if (dg) acc += bs * bf16_bits_to_f32(x[(long)n * xsn + (long)yi * xsy + (long)xi * xsx + c]);
+    }
+    if (dg) {
+        red[sl][lane] = acc;
+        __syncthreads();
+        if (sl == 0) {
+            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            float* dst = dg + (long)n * Cx + c;
+            *dst = accumulate_dg ? *dst + t : t;
+        }
+    }
+}
+
+// ---- pixel cross-entropy over the H x W logits of an image -----------------------------------------------------------------------------
+// logit0: fp32 per grid row (gridconv's out0).  lse[n] = log sum exp over the interior rows; loss = -(1 / (N H W)) sum_n (logit[p0_n] - lse[n])
+__global__ __launch_bounds__(1024) void pixel_ce_fwd_kernel(const float* __restrict__ logit0, const int* __restrict__ p0, int H, int W, float* __restrict__ lse,
+                                                            float* __restrict__ picked) {
+    __shared__ float red[16];
+    const int n = blockIdx.x, tid = threadIdx.x, Wp = W + 2, PP = (H + 2) * Wp;
+    const float* lg = logit0 + (long)n * PP;
+    float m = -3.0e38f;
+    for (int i = tid; i < H * W; i += 1024) { const int y = i / W, x = i - y * W; m = fmaxf(m, lg[(y + 1) * Wp + x + 1]); }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    float mm = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < H * W; i += 1024) { const int y = i / W, x = i - y * W; s += __expf(lg[(y + 1) * Wp + x + 1] - mm); }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        lse[n] = mm + logf(t);
+        picked[n] = lg[(p0[2 * n] + 1) * Wp + p0[2 * n + 1] + 1];
+    }
+}
+// dlogit = upstream * (softmax - onehot) / (N H W) into channel 0 of a grid tensor of C channels (the others and the borders zero)
+__global__ void pixel_ce_bwd_kernel(const float* __restrict__ logit0, const int* __restrict__ p0, const float* __restrict__ lse, const float* __restrict__ upstream,
+                                    int N, int H, int W, int C, uint16_t* __restrict__ dz) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Wp = W + 2, PP = (H + 2) * Wp, cpr = C / 8;
+    if (i >= (long)N * PP * cpr) return;
+    const int r = (int)(i / cpr), ck = (int)(i % cpr);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (ck == 0) {
+        const int n = r / PP, rem = r - n * PP, yy = rem / Wp, xx = rem - yy * Wp;
+        if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+            float d = __expf(logit0[r] - lse[n]);
+            if (yy - 1 == p0[2 * n] && xx - 1 == p0[2 * n + 1]) d -= 1.f;
+            d *= upstream[0] / ((float)N * H * W);
+            o.x = pack_bf16x2(d, 0.f);
+        }
+    }
+    *(uint4*)(dz + (long)r * C + ck * 8) = o;
+}
+
+}  // namespace
+
+// ---- C ABI (include/hulc2_amd.h) ---------------------------------------------------------------------------------------------------------
+extern "C" int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum,
+                                     float* bn, float* run_mean, float* run_var, void* stream) {
+    if (!part || !gamma || !beta || !bn || C <= 0 || nb <= 0 || count < 2) return hulc_fail(-1, "hulc_grid_bn_finalize: bad argument");
+    grid_bn_finalize_kernel<<<(C + 63) / 64, 64, 0, (hipStream_t)stream>>>(part, nb, C, (float)count, gamma, beta, eps, momentum, bn, run_mean, run_var);
+    return hulc_check_launch("hulc_grid_bn_finalize");
+}
+
+extern "C" int hulc_grid_bn_relu_fwd(const void* y, long ldy, const float* bn, int N, int H, int W, int C, void* out, long ldo, void* stream) {
+    if (!y || !bn || !out || C % 8 || ldy % 8 || ldo % 8) return hulc_fail(-1, "hulc_grid_bn_relu_fwd: bad argument");
+    const long R = (long)N * (H + 2) * (W + 2), n = R * (C / 8);
+    grid_bn_relu_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const uint16_t*)y, ldy, bn, (int)R, H, W, C, (uint16_t*)out, ldo);
+    return hulc_check_launch("hulc_grid_bn_relu_fwd");
+}
+
+extern "C" long hulc_grid_bn_bwd_workspace(int N, int H, int W, int C) {
+    const long R = (long)N * (H + 2) * (W + 2);
+    return (((R + 255) / 256) * 2 * C + 2 * C) * (long)sizeof(float);
+}
+
+extern "C" int hulc_grid_bn_relu_bwd(const void* dout, long ldd, const void* out, long ldo, const void* y, long ldy, const float* bn, int N, int H, int W,
+                                     int C, void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream) {
+    if (!dout || !out || !y || !bn || !dz || !ws || C % 8) return hulc_fail(-1, "hulc_grid_bn_relu_bwd: bad argument (C must be a multiple of 8)");
+    const long R = (long)N * (H + 2) * (W + 2);
+    const int nb = (int)((R + 255) / 256);
+    float* part = (float*)ws;
+    float* sums = part + (long)nb * 2 * C;
+    hipStream_t s = (hipStream_t)stream;
+    grid_bn_relu_bwd_reduce_kernel<<<dim3(nb, (C + 63) / 64), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, (int)R, C, part);
+    grid_bn_bwd_sums_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, nb, C, sums, dgamma, dbeta, accumulate_params);
+    const long n = R * (C / 8);
+    grid_bn_relu_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, sums,
+                                                                             1.0f / ((float)N * H * W), (int)R, H, W, C, (uint16_t*)dz, ldz);
+    return hulc_check_launch("hulc_grid_bn_relu_bwd");
+}
+
+extern "C" int hulc_grid_upcat_fwd(const void* x, long xsn, long xsy, long xsx, const float* g, const void* skip, long ssn, long ssy, long ssx, int N, int Ho,
+                                   int Wo, int s, int Cx, int Cs, void* out, void* stream) {
+    if (!x || !out || Cx % 8 || Cs % 8 || s < 1 || Ho % s || Wo % s || (Cs && !skip)) return hulc_fail(-1, "hulc_grid_upcat_fwd: bad argument");
+    const long n = (long)N * (Ho + 2) * (Wo + 2) * ((Cx + Cs) / 8);
+    grid_upcat_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, xsn, xsy, xsx, g, (const uint16_t*)skip, ssn, ssy, ssx, N, Ho,
+                                                                                        Wo, s, Cx, Cs, (uint16_t*)out);
+    return hulc_check_launch("hulc_grid_upcat_fwd");
+}
+
+extern "C" int hulc_grid_upcat_bwd(const void* dX, long ldd, const void* x, long xsn, long xsy, long xsx, const float* g, int N, int Hi, int Wi, int s, int Cx,
+                                   void* dsmall, float* dg, int accumulate_dg, void* stream) {
+    if (!dX || Cx % 64 || (dg && !x) || (!dsmall && !dg)) return hulc_fail(-1, "hulc_grid_upcat_bwd: bad argument (Cx must be a multiple of 64)");
+    int npt = 1;
+    if (!dg) { while ((long)N * (Cx / 64) * npt < 512 && npt * 64 < Hi * Wi) npt *= 2; }
+    grid_upcat_bwd_kernel<<<dim3(N, Cx / 64, npt), 256, 0, (hipStream_t)stream>>>((const uint16_t*)dX, ldd, (const uint16_t*)x, xsn, xsy, xsx, g, Hi, Wi, s, Cx,
+                                                                                  (uint16_t*)dsmall, dg, accumulate_dg);
+    return hulc_check_launch("hulc_grid_upcat_bwd");
+}
+
+extern "C" int hulc_pixel_ce_fwd(const float* logit0, const int* p0, int N, int H, int W, float* lse, float* picked, void* stream) {
+    if (!logit0 || !p0 || !lse || !picked) return hulc_fail(-1, "hulc_pixel_ce_fwd: null pointer");
+    pixel_ce_fwd_kernel<<<N, 1024, 0, (hipStream_t)stream>>>(logit0, p0, H, W, lse, picked);
+    return hulc_check_launch("hulc_pixel_ce_fwd");
+}
+
+extern "C" int hulc_pixel_ce_bwd(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, int C, void* dz, void* stream) {
+    if (!logit0 || !p0 || !lse || !upstream || !dz || C % 8) return hulc_fail(-1, "hulc_pixel_ce_bwd: bad argument");
+    const long n = (long)N * (H + 2) * (W + 2) * (C / 8);
+    pixel_ce_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(logit0, p0, lse, upstream, N, H, W, C, (uint16_t*)dz);
+    return hulc_check_launch("hulc_pixel_ce_bwd");
+}

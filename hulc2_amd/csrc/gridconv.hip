@@ -1,0 +1,164 @@
+// gridconv.hip — the zero-padded 3 x 3, stride-1 convolutions of the affordance model's U-Net decoder as a shifted GEMM
+// on a PADDED GRID.  Reference: Conv2dReLU / DecoderBlock of hulc2/affordance/models/core/unet_decoder.py:6-80 (nn.Conv2d(k = 3, padding = 1,
+// bias = False) + BatchNorm2d + ReLU), the segmentation head of visual_lang_encoders/r3m_rn18.py:64-69, and autograd's data gradient of both.
+//
+// Layout: an activation map (N, H, W, C) lives as rows of C bf16 channels on the grid (N, H + 2, W + 2) — pixel (n, y, x) is grid row
+// n (H + 2)(W + 2) + (y + 1)(W + 2) + (x + 1), the border rows are ZERO, and W + 3 zero guard rows precede and follow the tensor.  Then
+//     Y[r][co] = sum over taps t = (dy, dx) and ci of  X[r + dy (W + 2) + dx][ci] * Wt[co][t * Cin + ci]
+// for every interior row r with no bounds test at all: a tap is a constant row offset, the padding is the zero border, and the same kernel
+// computes the data gradient (flipped taps, transposed weights: prepared by the host).  The weight gradient is nine products
+// dW_t = dY^T X[. + off_t] over the grid rows — items of the grouped weight-gradient launch (wgrad_group.hip), the zero border of dY silencing
+// the rows that are not pixels.  The price is (H + 2)(W + 2) / (H W) - 1 extra rows: 31 % at 14 x 14, 7 % at 56 x 56, 2 % at 224 x 224.
+//
+// Kernel: workgroup tile 128 grid rows x BN output channels (BN = 128 / 64 / 32), 4 waves, 32 x 32 x 16 bf16 MFMA, k-steps of 32 channels of
+// one tap, operand tiles [row][32 k] in LDS with 80-byte rows (conflict-free ds_read_b128, as gemm.hip), register prefetch of the next k-step
+// behind the MFMAs, two LDS stages.  Epilogue: bf16 store with the border rows forced to zero (the output is a grid tensor again), optional
+// per-channel partial sums of y and y^2 over the interior rows from the fp32 accumulators (BatchNorm batch statistics, reduced in a fixed
+// order by hulc_grid_bn_finalize), optional fp32 copy of channel 0 + bias (the one-channel segmentation head).
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+
+namespace {
+
+constexpr int GC_BM = 128;
+
+struct GcP {
+    const uint16_t* X; long ldx;
+    const uint16_t* Wt; long ldw;
+    uint16_t* Y; long ldy;
+    float* out0; const float* bias;
+    float* stats;
+    int R, H, W, Cin, Cout;
+};
+
+template <int WN, int TN>
+__global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
+    constexpr int WM = 4 / WN, TM = GC_BM / (WM * 32), BN = WN * TN * 32;
+    constexpr int B_PER = (BN * 4 + 255) / 256;                    // 16-byte chunks of the B tile per thread
+    __shared__ __attribute__((aligned(16))) char smem[2 * (GC_BM + BN) * HULC_ROWB];
+    __shared__ float sred[2][WM][BN];
+    __shared__ unsigned char rowok[GC_BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r0 = blockIdx.x * GC_BM, n0 = blockIdx.y * BN;
+    const int Wp = p.W + 2, PP = (p.H + 2) * Wp;
+    if (tid < GC_BM) {
+        const int r = r0 + tid, rem = r % PP, yy = rem / Wp, xx = rem - yy * Wp;
+        rowok[tid] = (r < p.R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W) ? 1 : 0;
+    }
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int kpt = p.Cin / 32, nk = 9 * kpt;                      // k-steps per tap, in all
+    // this thread's chunks: A rows (tid >> 2) and (tid >> 2) + 64, chunk tid & 3; B rows likewise
+    const int ch = tid & 3;
+    int ar[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int r = r0 + (tid >> 2) + q * 64; ar[q] = r < p.R ? r : p.R - 1; }
+    uint4 ra0, ra1, rb0, rb1;
+    rb0 = rb1 = make_uint4(0u, 0u, 0u, 0u);
+    auto tap_off = [&](int t) { return (t / 3 - 1) * Wp + (t % 3 - 1); };
+#define GC_LOAD(ks_)                                                                                                   \
+    {                                                                                                                  \
+        const int t_ = (ks_) / kpt, c0_ = ((ks_) - t_ * kpt) * 32 + ch * 8, off_ = tap_off(t_);                        \
+        ra0 = *(const uint4*)(p.X + (long)(ar[0] + off_) * p.ldx + c0_);                                               \
+        ra1 = *(const uint4*)(p.X + (long)(ar[1] + off_) * p.ldx + c0_);                                               \
+        const long kb_ = (long)t_ * p.Cin + c0_;                                                                       \
+        if (B_PER == 2 || tid < BN * 4) rb0 = *(const uint4*)(p.Wt + (long)(n0 + (tid >> 2)) * p.ldw + kb_);           \
+        if (B_PER == 2) rb1 = *(const uint4*)(p.Wt + (long)(n0 + (tid >> 2) + 64) * p.ldw + kb_);                      \
+    }
+#define GC_STORE(stage_)                                                                                               \
+    {                                                                                                                  \
+        char* As_ = smem + (stage_) * (GC_BM + BN) * HULC_ROWB;                                                        \
+        char* Bs_ = As_ + GC_BM * HULC_ROWB;                                                                           \
+        *(uint4*)(As_ + (tid >> 2) * HULC_ROWB + ch * 16) = ra0;                                                       \
+        *(uint4*)(As_ + ((tid >> 2) + 64) * HULC_ROWB + ch * 16) = ra1;                                                \
+        if (B_PER == 2 || tid < BN * 4) *(uint4*)(Bs_ + (tid >> 2) * HULC_ROWB + ch * 16) = rb0;                       \
+        if (B_PER == 2) *(uint4*)(Bs_ + ((tid >> 2) + 64) * HULC_ROWB + ch * 16) = rb1;                                \
+    }
+    GC_LOAD(0)
+    GC_STORE(0)
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        const int nx = ks + 1 < nk ? ks + 1 : ks;                  // last trip reloads its own tile into the other stage: nobody reads it
+        GC_LOAD(nx)
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = smem + cur * (GC_BM + BN) * HULC_ROWB;
+        const char* Bs = As + GC_BM * HULC_ROWB;
+        mma_tile_bf16<TM, TN>(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        GC_STORE(cur ^ 1)
+        __syncthreads();
+    }
+#undef GC_LOAD
+#undef GC_STORE
+    // ---- epilogue
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wm * TM + i) * 32 + acc_row(e, lane);
+                const int r = r0 + row;
+                const bool ok = rowok[row] != 0;
+                const float v = ok ? acc[i][j][e] : 0.f;
+                s1[j] += v; s2[j] += v * v;
+                if (r < p.R) {
+                    if (p.Y) p.Y[(long)r * p.ldy + n] = f32_to_bf16_bits(v);
+                    if (p.out0 && n == 0) p.out0[r] = ok ? v + (p.bias ? p.bias[0] : 0.f) : 0.f;
+                }
+            }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (lane < 32) { sred[0][wm][(wn * TN + j) * 32 + lane] = s1[j]; sred[1][wm][(wn * TN + j) * 32 + lane] = s2[j]; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += sred[0][w][tid]; b += sred[1][w][tid]; }
+            p.stats[((long)blockIdx.x * 2) * p.Cout + n0 + tid] = a;
+            p.stats[((long)blockIdx.x * 2 + 1) * p.Cout + n0 + tid] = b;
+        }
+    }
+}
+
+}  // namespace
+
+// see include/hulc2_amd.h
+extern "C" long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout) {
+    const long R = (long)N * (H + 2) * (W + 2);
+    return ((R + GC_BM - 1) / GC_BM) * 2 * Cout * (long)sizeof(float);
+}
+
+extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, float* stats,
+                                float* out0, const float* bias0, void* stream) {
+    if (!x || !wt || (!y && !out0)) return hulc_fail(-1, "hulc_gridconv3x3: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % 32 || Cin <= 0 || Cout % 32 || Cout <= 0) return hulc_fail(-2, "hulc_gridconv3x3: Cin and Cout must be positive multiples of 32");
+    if (ldx % 8 || ldx < Cin || (y && (ldy < Cout)) || (uintptr_t)x % 16 || (uintptr_t)wt % 16) return hulc_fail(-3, "hulc_gridconv3x3: rows must be 16-byte aligned");
+    const long R = (long)N * (H + 2) * (W + 2);
+    if (R >= (1L << 31) / 2) return hulc_fail(-2, "hulc_gridconv3x3: grid too large");
+    GcP p;
+    p.X = (const uint16_t*)x; p.ldx = ldx; p.Wt = (const uint16_t*)wt; p.ldw = 9L * Cin; p.Y = (uint16_t*)y; p.ldy = ldy;
+    p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    const unsigned gx = (unsigned)((R + GC_BM - 1) / GC_BM);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout % 128 == 0) gridconv_kernel<2, 2><<<dim3(gx, Cout / 128), 256, 0, s>>>(p);
+    else if (Cout % 64 == 0) gridconv_kernel<1, 2><<<dim3(gx, Cout / 64), 256, 0, s>>>(p);
+    else gridconv_kernel<1, 1><<<dim3(gx, Cout / 32), 256, 0, s>>>(p);
+    return hulc_check_launch("hulc_gridconv3x3");
+}

@@ -23,7 +23,7 @@ namespace {
 constexpr int T = 64;                     // tile edge and k-step
 constexpr int RS = T * 2 + 16;            // LDS row stride of a [k][64] bf16 tile (144 B: the 4 k rows of a transposing read on distinct banks)
 constexpr int TILE_B = T * RS;            // 9216 B
-constexpr int MAX_ITEMS = 40;             // per launch (kernel-argument space: 40 x 88 + 40 x 4 bytes of the 4 KB)
+constexpr int MAX_ITEMS = 38;             // per launch (kernel-argument space: 38 x 96 + 38 x 4 bytes of the 4 KB)
 constexpr int SLAB = T * T + T;           // floats per partial slab (even): the tile, then its 64 bias-gradient partials
 constexpr int CTR_WORDS = 65536;          // counters at the head of the workspace
 
@@ -34,6 +34,7 @@ struct Item {
     int tn, ksplit, kper;                 // tiles along N, slices of K, k-steps per slice
     int ctr0;                             // first counter
     int perm;                             // > 0: product column n is stored at column (n % perm) * (N / perm) + n / perm
+    int cmul;                             // otherwise: at column n * cmul
     long slab0;                           // first slab
 };
 struct GroupP { int first[MAX_ITEMS]; Item it[MAX_ITEMS]; int n, total; unsigned* ctr; float* slabs; };   // first[j]: first work item of problem j (INT_MAX: unused)
@@ -168,7 +169,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
     }
     const int nloc = wn * 32 + (lane & 31);
     const int nn = n0 + nloc;
-    const int ncol = it.perm > 0 ? (nn % it.perm) * (it.N / it.perm) + nn / it.perm : nn;   // (h, w, c) -> (c, h, w) weight columns of a flattened conv map
+    const int ncol = it.perm > 0 ? (nn % it.perm) * (it.N / it.perm) + nn / it.perm : nn * it.cmul;   // (h, w, c) -> (c, h, w) weight columns of a flattened conv map
     if (it.ksplit == 1) {
         const bool accum = it.flags & 4;
         if (n0 + nloc < it.N) {
@@ -283,7 +284,7 @@ int check_item(const hulc_wgrad_item& d) {
     if ((d.a_dtype != HULC_F32 && d.a_dtype != HULC_BF16) || (d.b_dtype != HULC_F32 && d.b_dtype != HULC_BF16))
         return hulc_fail(-2, "hulc_wgrad_group: operands are fp32 or bf16");
     if (d.lda % ea || d.ldb % eb || ((uintptr_t)d.A | (uintptr_t)d.B) % 16) return hulc_fail(-2, "hulc_wgrad_group: operand rows must be 16-byte aligned");
-    if (d.lda < d.M || d.ldb < d.N || d.ldc < d.N || !d.A || !d.B || !d.C) return hulc_fail(-2, "hulc_wgrad_group: bad leading dimension or null operand");
+    if (d.lda < d.M || d.ldb < d.N || d.ldc < (d.col_mul > 1 ? (d.N - 1) * d.col_mul + 1 : d.N) || !d.A || !d.B || !d.C) return hulc_fail(-2, "hulc_wgrad_group: bad leading dimension or null operand");
     if (d.col_perm < 0 || (d.col_perm > 0 && d.N % d.col_perm)) return hulc_fail(-2, "hulc_wgrad_group: col_perm must divide N");
     return 0;
 }
@@ -325,7 +326,7 @@ extern "C" int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, l
             it.M = d.M; it.N = d.N; it.K = d.K; it.lda = d.lda; it.ldb = d.ldb; it.ldc = d.ldc;
             it.flags = (d.a_dtype == HULC_F32 ? 1 : 0) | (d.b_dtype == HULC_F32 ? 2 : 0) | (d.accumulate ? 4 : 0) | (d.rowsum_accumulate ? 8 : 0);
             p.first[j] = first; it.tn = pl.tn; it.ksplit = pl.ksplit; it.kper = pl.kper;
-            it.ctr0 = ctr; it.slab0 = slab; it.perm = d.col_perm;
+            it.ctr0 = ctr; it.slab0 = slab; it.perm = d.col_perm; it.cmul = d.col_mul > 1 ? d.col_mul : 1;
             first += pl.tiles * pl.ksplit;
             if (pl.ksplit > 1) { ctr += pl.tiles; slab += (long)pl.tiles * pl.ksplit; }
         }

@@ -587,13 +587,13 @@ def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc) -> bool:
     return lda % ea == 0 and ldb % eb == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and C.data_ptr() % 4 == 0
 
 
-def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False, col_perm=0):
+def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False, col_perm=0, col_mul=1):
     """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
     destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
     when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
     if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc):
-        if col_perm:
-            raise _L.HulcKernelError("wgrad: col_perm needs the grouped kernel (check wgrad_group_ok first)")
+        if col_perm or col_mul > 1:
+            raise _L.HulcKernelError("wgrad: col_perm / col_mul need the grouped kernel (check wgrad_group_ok first)")
         fused = rowsum is not None and gemm_fuses_rowsum(M, False) and A.dtype == torch.float32
         gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, accumulate=accumulate,
              rowsum=rowsum if fused else None, rowsum_accumulate=rowsum_accumulate)
@@ -607,7 +607,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     if any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
         wgrad_flush(dev)                    # a second writer of the same destination: keep the order
         q = _wg_pending.setdefault(dev, [])
-    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm)))
+    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm), int(col_mul)))
     if not defer:
         wgrad_flush(dev)
     elif dev not in _wg_armed:
@@ -641,6 +641,7 @@ def wgrad_flush(device=None) -> None:
             it.a_dtype, it.b_dtype = _dt(A), _dt(B)
             it.accumulate, it.rowsum_accumulate = int(acc), int(racc)
             it.col_perm = rest[0] if rest else 0
+            it.col_mul = rest[1] if len(rest) > 1 else 1
             flops += 2.0 * M * N * K
             nbytes += K * M * A.element_size() + K * N * B.element_size() + M * N * 4 * (2 if acc else 1)
         lib = _L.load()
@@ -923,3 +924,104 @@ def sum_chunks(src, W, chunk, dst):
     if src.dtype != dst.dtype:
         raise TypeError("sum_chunks: src and dst share a dtype")
     _call("hulc_sum_chunks", src, _i(_dt(src)), _i(W), _l(chunk), dst)
+
+
+# ------------------------------------------------------------------------------------------------
+# affordance model: padded-grid convolutions and their pointwise / reduction kernels (csrc/gridconv.hip, affordance.hip)
+# ------------------------------------------------------------------------------------------------
+class Grid:
+    """A bf16 map (N, H, W, C) on the padded grid (layout: include/hulc2_amd.h, "PADDED GRID"): `rows` = the 2-D tensor of all rows including
+    the zero guards, `t` = rows [guard, guard + R) — the tensor the kernels address.  Every kernel writes all R rows of its output (borders as
+    zero), so only the guards are cleared here."""
+
+    def __init__(self, N, H, W, C, device):
+        self.N, self.H, self.W, self.C = int(N), int(H), int(W), int(C)
+        self.R = self.N * (self.H + 2) * (self.W + 2)
+        self.guard = (self.W + 3 + 7) // 8 * 8
+        tail = self.guard + 32                                  # + the rows that round R up to a multiple of 32 (weight-gradient K)
+        self.rows = torch.empty(self.guard + self.R + tail, self.C, dtype=torch.bfloat16, device=device)
+        self.rows[:self.guard].zero_()
+        self.rows[self.guard + self.R:].zero_()
+        self.t = self.rows[self.guard:self.guard + self.R]
+
+    @property
+    def Rpad(self) -> int:
+        return (self.R + 31) // 32 * 32
+
+    def pixel_strides(self):
+        """(base tensor view at pixel (0, 0, 0), stride n, stride y, stride x) in elements: the strided-map form grid_upcat takes"""
+        Wp = self.W + 2
+        return self.t[Wp + 1:], (self.H + 2) * Wp * self.C, Wp * self.C, self.C
+
+    def interior(self) -> torch.Tensor:
+        """(N, H, W, C) view of the pixels"""
+        return self.t.view(self.N, self.H + 2, self.W + 2, self.C)[:, 1:-1, 1:-1]
+
+
+def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None, bias0=None, cin=None):
+    """y = conv3x3(x) on the grid; wt bf16 [Cout][9 * Cin]; -> (y Grid or None, stats partials or None)"""
+    Cin = x.C if cin is None else cin
+    _require_cuda(x.rows, wt, out0, bias0)
+    if wt.dtype != torch.bfloat16 or tuple(wt.shape) != (Cout, 9 * Cin) or not wt.is_contiguous():
+        raise _L.HulcKernelError("gridconv3x3: weights are bf16 [Cout][9 * Cin]")
+    if out0 is None and y is None:
+        y = Grid(x.N, x.H, x.W, Cout, x.rows.device)
+    lib = _L.load()
+    lib.hulc_gridconv_stats_bytes.restype = _c.c_long
+    stats = _ws(lib.hulc_gridconv_stats_bytes(_i(x.N), _i(x.H), _i(x.W), _i(Cout)), x.rows.device) if want_stats else None
+    _call("hulc_gridconv3x3", x.t, _l(x.C), wt, (y.t if y is not None else None), _l(y.C if y is not None else 0), _i(x.N), _i(x.H), _i(x.W), _i(Cin), _i(Cout),
+          stats, out0, bias0, key=("gridconv3x3", x.N, x.H, x.W, Cin, Cout), flops=2.0 * x.R * 9 * Cin * Cout,
+          nbytes=float(x.R) * (x.C + Cout) * 2 + Cout * 9 * Cin * 2)
+    return y, stats
+
+
+def grid_bn_finalize(stats, N, H, W, C, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
+    bn = torch.empty(4, C, dtype=torch.float32, device=stats.device)
+    nb = (N * (H + 2) * (W + 2) + 127) // 128
+    _call("hulc_grid_bn_finalize", stats, _i(nb), _i(C), _l(N * H * W), gamma, beta, _f(eps), _f(momentum), bn, run_mean, run_var)
+    return bn
+
+
+def grid_bn_relu_fwd(y: Grid, bn) -> Grid:
+    out = Grid(y.N, y.H, y.W, y.C, y.rows.device)
+    _call("hulc_grid_bn_relu_fwd", y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), out.t, _l(out.C), nbytes=float(y.R) * y.C * 4)
+    return out
+
+
+def grid_bn_relu_bwd(dout: Grid, out: Grid, y: Grid, bn, dgamma, dbeta, accumulate=False) -> Grid:
+    dz = Grid(y.N, y.H, y.W, y.C, y.rows.device)
+    lib = _L.load()
+    lib.hulc_grid_bn_bwd_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_grid_bn_bwd_workspace(_i(y.N), _i(y.H), _i(y.W), _i(y.C)), y.rows.device)
+    _call("hulc_grid_bn_relu_bwd", dout.t, _l(dout.C), out.t, _l(out.C), y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), dz.t, _l(dz.C), dgamma, dbeta,
+          _i(accumulate), ws, nbytes=float(y.R) * y.C * 14)
+    return dz
+
+
+def grid_upcat_fwd(x, xs, g, skip, ss, N, Ho, Wo, s, Cx, Cs) -> Grid:
+    """x / skip: (tensor at pixel (0,0,0), stride_n, stride_y, stride_x) strided bf16 maps; g (N, Cx) fp32 or None"""
+    out = Grid(N, Ho, Wo, Cx + Cs, x.device)
+    _call("hulc_grid_upcat_fwd", x, _l(xs[0]), _l(xs[1]), _l(xs[2]), g, skip, _l(ss[0] if skip is not None else 0), _l(ss[1] if skip is not None else 0),
+          _l(ss[2] if skip is not None else 0), _i(N), _i(Ho), _i(Wo), _i(s), _i(Cx), _i(Cs), out.t, nbytes=float(out.R) * out.C * 4)
+    return out
+
+
+def grid_upcat_bwd(dX: Grid, x, xs, g, N, Hi, Wi, s, Cx, want_dsmall=True, want_dg=True):
+    dsmall = Grid(N, Hi, Wi, Cx, dX.rows.device) if want_dsmall else None
+    dg = torch.empty(N, Cx, dtype=torch.float32, device=dX.rows.device) if want_dg else None
+    _call("hulc_grid_upcat_bwd", dX.t, _l(dX.C), x, _l(xs[0]), _l(xs[1]), _l(xs[2]), g, _i(N), _i(Hi), _i(Wi), _i(s), _i(Cx),
+          (dsmall.t if dsmall is not None else None), dg, _i(0), nbytes=float(dX.R) * Cx * 2)
+    return dsmall, dg
+
+
+def pixel_ce_fwd(logit0, p0, N, H, W):
+    lse = torch.empty(N, dtype=torch.float32, device=logit0.device)
+    picked = torch.empty(N, dtype=torch.float32, device=logit0.device)
+    _call("hulc_pixel_ce_fwd", logit0, p0, _i(N), _i(H), _i(W), lse, picked)
+    return lse, picked
+
+
+def pixel_ce_bwd(logit0, p0, lse, upstream, N, H, W, C) -> Grid:
+    dz = Grid(N, H, W, C, logit0.device)
+    _call("hulc_pixel_ce_bwd", logit0, p0, lse, upstream, _i(N), _i(H), _i(W), _i(C), dz.t)
+    return dz

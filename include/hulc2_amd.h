@@ -340,9 +340,48 @@ typedef struct hulc_wgrad_item {
     int accumulate, rowsum_accumulate;
     int col_perm;                    /* > 0: column n of the product is stored at column (n % col_perm) * (N / col_perm) + n / col_perm — the
                                       * (h, w, c) -> (c, h, w) order of a Linear that follows nn.Flatten on an NHWC map (vision_network_gripper.py:16-17) */
+    int col_mul;                     /* > 1 (with col_perm 0): column n of the product is stored at column n * col_mul — one tap of a convolution
+                                      * weight kept as OIHW: C points at tap t, col_mul = KH KW */
 } hulc_wgrad_item;
 long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n);
 int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream);
+
+/* ---- affordance model (BASELINE configs[4]): the trainable part behind the frozen R3M trunk ---------------------------- */
+/* PixelAffLangDetector.training_step (hulc2/affordance/pixel_aff_lang_detector.py:51-69) in the shipped variant
+ * (conf/affordance/aff_detection/r3m.yaml): UnetLangFusionDecoder (models/core/unet_decoder.py:83-146), the segmentation head
+ * (visual_lang_encoders/r3m_rn18.py:64-69), cross_entropy_with_logits over the pixels (utils/losses.py:6-13).
+ * PADDED GRID layout: a map (N, H, W, C) is stored as rows of C bf16 channels on the grid (N, H + 2, W + 2) — pixel (n, y, x) is grid row
+ * n (H+2)(W+2) + (y+1)(W+2) + (x+1), border rows are ZERO, and at least W + 3 zero rows precede and follow the tensor (pointers below address
+ * grid row 0).  A 3 x 3 / padding-1 convolution is then a shifted GEMM without bounds tests, its data gradient the same kernel with flipped
+ * taps and transposed weights, its weight gradient nine items of hulc_wgrad_group (A = dY rows, B = X rows shifted by the tap, col_mul = 9).
+ * hulc_gridconv3x3: y[r][co] = sum_{t, ci} x[r + off_t][ci] wt[co][t * Cin + ci] (wt bf16 [Cout][9 Cin], Cin / Cout multiples of 32), border
+ *   rows of y forced to zero; stats (optional, hulc_gridconv_stats_bytes): per row-tile partial sums of y and y^2 over the pixels from the fp32
+ *   accumulators; out0 (optional): fp32 [rows] = channel 0 + bias0[0] (the one-channel head; y may then be NULL).
+ * hulc_grid_bn_finalize: nn.BatchNorm2d in training mode from those partials (nb = row tiles, count = N H W): bn[4][C] = mean, rstd,
+ *   scale = gamma rstd, shift = beta - mean scale; running statistics updated (momentum, unbiased variance) when given.
+ * hulc_grid_bn_relu_fwd: out = relu(y scale + shift) on the pixels, zero on the border.   hulc_grid_bn_relu_bwd: dz = BatchNorm backward of
+ *   (dout masked by out > 0) on the pixels, zero on the border; dgamma / dbeta (+)=; ws: hulc_grid_bn_bwd_workspace bytes.
+ * hulc_grid_upcat_fwd: DecoderBlock's input (unet_decoder.py:60-80): out grid (N, Ho, Wo) rows of Cx + Cs = [nearest-up-sampled x * g | skip];
+ *   x (N, Ho/s, Wo/s, Cx) and skip (N, Ho, Wo, Cs) bf16 with element strides (n, y, x) — a grid tensor's pixels or a plain NHWC map; g (N, Cx)
+ *   fp32 or NULL = lang_proj(l) of FusionMult (core/fusion.py:64-73).   hulc_grid_upcat_bwd: dsmall (grid (N, Hi, Wi) rows of Cx, pixels only)
+ *   = g * the s x s block sums of dX's first Cx channels, dg (N, Cx) (+)= sum over pixels of x * block sums (either may be NULL).
+ * hulc_pixel_ce_fwd / _bwd: log-sum-exp over an image's H W logits (logit0: fp32 per grid row) and the labelled pixel's logit
+ *   (p0 (N, 2) int32 = row, col); backward writes upstream (softmax - onehot) / (N H W) into channel 0 of a grid tensor of C channels. */
+long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout);
+int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, float* stats, float* out0,
+                     const float* bias0, void* stream);
+int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum, float* bn,
+                          float* run_mean, float* run_var, void* stream);
+int hulc_grid_bn_relu_fwd(const void* y, long ldy, const float* bn, int N, int H, int W, int C, void* out, long ldo, void* stream);
+long hulc_grid_bn_bwd_workspace(int N, int H, int W, int C);
+int hulc_grid_bn_relu_bwd(const void* dout, long ldd, const void* out, long ldo, const void* y, long ldy, const float* bn, int N, int H, int W, int C,
+                          void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream);
+int hulc_grid_upcat_fwd(const void* x, long xsn, long xsy, long xsx, const float* g, const void* skip, long ssn, long ssy, long ssx, int N, int Ho, int Wo,
+                        int s, int Cx, int Cs, void* out, void* stream);
+int hulc_grid_upcat_bwd(const void* dX, long ldd, const void* x, long xsn, long xsy, long xsx, const float* g, int N, int Hi, int Wi, int s, int Cx,
+                        void* dsmall, float* dg, int accumulate_dg, void* stream);
+int hulc_pixel_ce_fwd(const float* logit0, const int* p0, int N, int H, int W, float* lse, float* picked, void* stream);
+int hulc_pixel_ce_bwd(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, int C, void* dz, void* stream);
 
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.

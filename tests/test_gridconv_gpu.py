@@ -1,0 +1,191 @@
+"""Kernels of the affordance model's trainable part (csrc/gridconv.hip, affordance.hip, wgrad_group's col_mul) against
+torch fp64 on the bf16-rounded operands: the padded-grid 3 x 3 convolution, its data gradient (same kernel, flipped / transposed weights) and
+weight gradient (nine grouped products), BatchNorm(batch statistics) + ReLU forward / backward, the DecoderBlock input (language fusion,
+nearest up-sampling, skip concatenation) forward / backward, and the pixel cross-entropy."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pytestmark = pytest.mark.gpu
+
+from hulc2_amd import kernels as kn  # noqa: E402
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    kn.set_compute("bf16")
+    return torch.device("cuda", 0)
+
+
+def to_grid(x_nchw, dev) -> "kn.Grid":
+    N, C, H, W = x_nchw.shape
+    g = kn.Grid(N, H, W, C, dev)
+    g.t.zero_()
+    g.interior().copy_(x_nchw.permute(0, 2, 3, 1).to(dev))
+    return g
+
+
+def from_grid(g) -> torch.Tensor:
+    return g.interior().float().permute(0, 3, 1, 2).cpu()
+
+
+def borders_zero(g) -> bool:
+    v = g.t.view(g.N, g.H + 2, g.W + 2, g.C).float()
+    return bool((v[:, 0] == 0).all() and (v[:, -1] == 0).all() and (v[:, :, 0] == 0).all() and (v[:, :, -1] == 0).all())
+
+
+def bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+def fwd_weights(w):           # (Cout, Cin, 3, 3) -> bf16 [Cout][9 Cin], k = tap * Cin + ci
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(torch.bfloat16)
+
+
+def dgrad_weights(w):         # -> bf16 [Cin][9 Cout]: flipped taps, transposed channels
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous().to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 5, 64, 32), (3, 14, 14, 96, 128), (2, 9, 9, 32, 64), (1, 30, 17, 160, 256)])
+def test_gridconv_forward_dgrad_wgrad(N, H, W, Cin, Cout):
+    dev = _dev()
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xr = bf(x).requires_grad_(True)
+    wr = bf(w).requires_grad_(True)
+    want = F.conv2d(xr, wr, padding=1)
+    # forward + statistics
+    X = to_grid(x, dev)
+    Y, stats = kn.gridconv3x3(X, fwd_weights(w).to(dev), Cout, want_stats=True)
+    torch.cuda.synchronize()
+    got = from_grid(Y)
+    assert borders_zero(Y)
+    assert (got.double() - want.detach()).abs().max().item() <= 2e-2 * want.abs().max().item()            # bf16 output rounding
+    nb = (X.R + 127) // 128
+    st = stats[:nb * 2 * Cout].view(nb, 2, Cout).double().sum(0).cpu()
+    assert (st[0] - want.detach().sum((0, 2, 3))).abs().max().item() < 1e-3 * max(1.0, want.detach().abs().sum((0, 2, 3)).max().item())
+    assert (st[1] - (want.detach() ** 2).sum((0, 2, 3))).abs().max().item() < 1e-3 * (want.detach() ** 2).sum((0, 2, 3)).max().item()
+    # data gradient: the same kernel on the gradient map
+    want.backward(bf(dy))
+    DY = to_grid(dy, dev)
+    DX, _ = kn.gridconv3x3(DY, dgrad_weights(w).to(dev), Cin)
+    torch.cuda.synchronize()
+    assert borders_zero(DX)
+    assert (from_grid(DX).double() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
+    # weight gradient: nine items of the grouped launch, straight into the OIHW layout
+    dw = torch.full((Cout, Cin * 9), float("nan"), device=dev)
+    Wp = W + 2
+    for t in range(9):
+        off = (t // 3 - 1) * Wp + (t % 3 - 1)
+        B = X.rows[X.guard + off: X.guard + off + X.Rpad]
+        kn._wg_pending.setdefault(dev, []).append((DY.rows[DY.guard: DY.guard + DY.Rpad], B, dw[:, t:], None, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, False, False, 0, 9))
+    kn.wgrad_flush(dev)
+    torch.cuda.synchronize()
+    got_w = dw.view(Cout, Cin, 3, 3).cpu().double()
+    assert torch.isfinite(got_w).all()
+    assert (got_w - wr.grad).abs().max().item() <= 1e-3 * wr.grad.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 7, 5, 64), (3, 12, 12, 32), (2, 5, 9, 128)])
+def test_batchnorm_relu_forward_backward(N, H, W, C):
+    dev = _dev()
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dout = torch.randn(N, C, H, W, generator=g)
+    # through an identity-like convolution so that the statistics come from gridconv's epilogue: 32-channel-aligned one-tap weights
+    w = torch.zeros(C, C, 3, 3)
+    w[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+    X = to_grid(x, dev)
+    Y, stats = kn.gridconv3x3(X, fwd_weights(w).to(dev), C, want_stats=True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    bn = kn.grid_bn_finalize(stats, N, H, W, C, gamma.to(dev), beta.to(dev), rm, rv)
+    O = kn.grid_bn_relu_fwd(Y, bn)
+    torch.cuda.synchronize()
+    yr = bf(x).requires_grad_(True)                                        # Y holds bf16(x) exactly
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    m = torch.nn.BatchNorm2d(C).double().train()
+    with torch.no_grad():
+        m.weight.copy_(gr); m.bias.copy_(br)
+    want = F.relu(m(yr))
+    assert borders_zero(O)
+    assert (from_grid(O).double() - want.detach()).abs().max().item() <= 1.5e-2 * want.detach().abs().max().item()
+    assert (rm.cpu().double() - m.running_mean).abs().max().item() < 1e-4 and (rv.cpu().double() - m.running_var).abs().max().item() < 1e-3
+    want.backward(bf(dout))
+    dg_, db_ = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    DZ = kn.grid_bn_relu_bwd(to_grid(dout, dev), O, Y, bn, dg_, db_)
+    torch.cuda.synchronize()
+    assert borders_zero(DZ)
+    # the ReLU mask comes from the bf16 output: elements within rounding of zero may flip; compare in the L2 sense
+    e = (from_grid(DZ).double() - yr.grad).norm() / yr.grad.norm()
+    assert e < 2e-2, e
+    assert (dg_.cpu().double() - m.weight.grad).abs().max().item() <= 2e-2 * m.weight.grad.abs().max().item()
+    assert (db_.cpu().double() - m.bias.grad).abs().max().item() <= 2e-2 * m.bias.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("N,Hi,Wi,s,Cx,Cs,fused,skip_plain", [(2, 3, 4, 2, 64, 32, True, True), (2, 5, 5, 1, 128, 64, False, True), (3, 4, 4, 4, 64, 0, False, False)])
+def test_decoder_block_input_forward_backward(N, Hi, Wi, s, Cx, Cs, fused, skip_plain):
+    dev = _dev()
+    g = torch.Generator().manual_seed(Cx + s)
+    x = torch.randn(N, Cx, Hi, Wi, generator=g)
+    gv = torch.randn(N, Cx, generator=g) if fused else None
+    Ho, Wo = Hi * s, Wi * s
+    skip = torch.randn(N, Cs, Ho, Wo, generator=g) if Cs else None
+    dX = torch.randn(N, Cx + Cs, Ho, Wo, generator=g)
+    XS = to_grid(x, dev)                                                   # the small map as a grid tensor (a previous block's output)
+    xt, xsn, xsy, xsx = XS.pixel_strides()
+    sk = skip.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev) if Cs else None
+    out = kn.grid_upcat_fwd(xt, (xsn, xsy, xsx), gv.to(dev) if fused else None, sk, (Ho * Wo * Cs, Wo * Cs, Cs), N, Ho, Wo, s, Cx, Cs)
+    torch.cuda.synchronize()
+    xr = bf(x).requires_grad_(True)
+    gr = gv.double().requires_grad_(True) if fused else None
+    up = F.interpolate(xr * gr[:, :, None, None] if fused else xr, scale_factor=s, mode="nearest")
+    want = torch.cat([up, bf(skip)], 1) if Cs else up
+    assert borders_zero(out)
+    assert (from_grid(out).double() - want.detach()).abs().max().item() <= 1e-2 * want.detach().abs().max().item()
+    want.backward(bf(dX))
+    D = to_grid(dX, dev)
+    dsmall, dgv = kn.grid_upcat_bwd(D, xt, (xsn, xsy, xsx), gv.to(dev) if fused else None, N, Hi, Wi, s, Cx, want_dsmall=True, want_dg=fused)
+    torch.cuda.synchronize()
+    assert (from_grid(dsmall).double() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
+    if fused:
+        assert (dgv.cpu().double() - gr.grad).abs().max().item() <= 1e-3 * gr.grad.abs().max().item()
+
+
+def test_pixel_cross_entropy_with_head():
+    """the one-channel head as a 32-channel gridconv with fp32 channel 0, then the cross-entropy over the pixels and its backward"""
+    dev = _dev()
+    N, H, W, C = 3, 11, 13, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(1, C, 3, 3, generator=g) * 0.3
+    b = torch.randn(1, generator=g)
+    p0 = torch.stack([torch.randint(0, H, (N,), generator=g), torch.randint(0, W, (N,), generator=g)], 1).to(torch.int32)
+    w32 = torch.zeros(32, C, 3, 3)
+    w32[0] = w[0]
+    X = to_grid(x, dev)
+    logit0 = torch.empty(X.R, dtype=torch.float32, device=dev)
+    kn.gridconv3x3(X, fwd_weights(w32).to(dev), 32, out0=logit0, bias0=b.to(dev))
+    lse, picked = kn.pixel_ce_fwd(logit0, p0.to(dev), N, H, W)
+    up = torch.tensor([0.7], device=dev)
+    DZ = kn.pixel_ce_bwd(logit0, p0.to(dev), lse, up, N, H, W, 32)
+    torch.cuda.synchronize()
+    xr = bf(x)
+    lg = (F.conv2d(xr, bf(w), b.double(), padding=1)).permute(0, 2, 3, 1).reshape(N, -1).requires_grad_(True)
+    label = torch.zeros(N, H, W, dtype=torch.double)
+    label[torch.arange(N), p0[:, 0].long(), p0[:, 1].long()] = 1
+    loss = (-label.reshape(N, -1) * F.log_softmax(lg, -1)).mean()
+    got_loss = -(picked - lse).sum().item() / (N * H * W)
+    assert abs(got_loss - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-7
+    (loss * 0.7).backward()
+    got = from_grid(DZ)[:, 0].reshape(N, -1).double()
+    assert (got - lg.grad).abs().max().item() <= 1e-2 * lg.grad.abs().max().item()
+    assert float(from_grid(DZ)[:, 1:].abs().max()) == 0.0 and borders_zero(DZ)
