@@ -1,0 +1,165 @@
+"""The language-fused U-Net decoder, segmentation head and pixel cross-entropy of the affordance model as ONE autograd Function over
+padded-grid kernels (csrc/gridconv.hip, csrc/affordance.hip; weight gradients through the grouped launch of csrc/wgrad_group.hip).
+
+Reference: UnetLangFusionDecoder.forward / DecoderBlock.forward (hulc2/affordance/models/core/unet_decoder.py:60-80,131-146), R3M.forward
+(models/visual_lang_encoders/r3m_rn18.py:78-94), AffDepthLangFusionPixel.forward (models/lang_fusion/aff_lang_depth_pixel.py:98-129),
+cross_entropy_with_logits as PixelAffLangDetector.criterion applies it (pixel_aff_lang_detector.py:122-145, utils/losses.py:6-13)."""
+from typing import List, Sequence
+
+import torch
+
+from .. import gradsink, kernels as kn
+from ..shadow import weight_operand
+
+DECODER_CHANNELS = (512, 256, 128, 64, 32)                 # r3m_rn18.py:54
+ENCODER_CHANNELS = (3, 64, 64, 128, 256, 512)              # r3m_rn18.py:59
+
+
+def block_channels():
+    """(in, skip, out) channels of the five DecoderBlocks (unet_decoder.py:104-116)"""
+    enc = list(ENCODER_CHANNELS[1:])[::-1]
+    return list(zip([enc[0]] + list(DECODER_CHANNELS[:-1]), enc[1:] + [0], DECODER_CHANNELS))
+
+
+def _fwd_w(w):          # (Cout, Cin, 3, 3) fp32 -> bf16 [Cout][9 Cin], k = tap * Cin + ci: the trainer's per-step layout shadow when there is one
+    return weight_operand(w, "ohwi")
+
+
+def _dgrad_w(w, cin_keep=None):      # -> bf16 [Cin'][9 Cout] = the UNflipped (ci, kh, kw, co) shadow (gridconv flips the taps); first cin_keep rows
+    m = weight_operand(w, "ihwo").reshape(w.shape[1], -1)
+    return m if cin_keep is None else m[:cin_keep]
+
+
+def _plain_strides(t):   # (N, H, W, C) contiguous NHWC map -> (tensor, (sn, sy, sx))
+    N, H, W, C = t.shape
+    return t, (H * W * C, W * C, C)
+
+
+def _conv_wgrad(dz: "kn.Grid", x: "kn.Grid", w: torch.Tensor, cin: int):
+    """dW (Cout, cin, 3, 3) (+)= nine products dZ^T X[. + off_t] over the grid rows, written straight into the OIHW layout (col_mul = 9):
+    into the trainer's gradient arena at the end of the pass when a sink is registered, else into a fresh tensor handed to autograd"""
+    cout = dz.C
+    sink = gradsink.get(w)
+    out = sink.view(cout, cin * 9) if sink is not None else torch.empty(cout, cin * 9, dtype=torch.float32, device=dz.rows.device)
+    acc = sink is not None and not gradsink.first_write(w)
+    Wp = x.W + 2
+    A = dz.rows[dz.guard:dz.guard + dz.Rpad]
+    for t in range(9):
+        off = (t // 3 - 1) * Wp + (t % 3 - 1)
+        B = x.rows[x.guard + off:x.guard + off + x.Rpad]
+        kn.wgrad(A, B, out[:, t:], cout, cin, x.Rpad, cout, x.C, cin * 9, accumulate=acc, defer=sink is not None, col_mul=9)
+    return None if sink is not None else out.view(cout, cin, 3, 3)
+
+
+def _vec_grad(param, like):
+    """(destination, accumulate flag, tensor to return to autograd or None) of a 1-D parameter gradient"""
+    sink = gradsink.get(param)
+    if sink is None:
+        t = torch.empty_like(param, dtype=torch.float32)
+        return t, False, t
+    return sink, not gradsink.first_write(param), None
+
+
+class AffDecoderLossFn(torch.autograd.Function):
+    """(p0, out_hw, running-stat buffers, g0, g1, g2, stem, l1, l2, l3, l4, 30 block parameters, head weight, head bias) -> (aff_loss, logits)
+
+    g_i (N, C_in_i) fp32 = lang_proj_i(l_enc) for the three language-fused blocks (computed outside: its Linear is an ordinary MLP layer);
+    the trunk maps are NHWC bf16 and receive no gradient (frozen trunk).  BatchNorm runs on batch statistics and updates the running buffers."""
+
+    @staticmethod
+    def forward(ctx, p0, out_hw, buffers, g0, g1, g2, f_stem, f1, f2, f3, f4, *params):
+        if kn.get_compute() != "bf16":
+            raise NotImplementedError("the affordance decoder is built for the bf16 compute mode")
+        blocks, head_w, head_b = params[:30], params[30], params[31]
+        N = f4.shape[0]
+        dev = f4.device
+        gs = (g0, g1, g2)
+        skips = (f3, f2, f1, f_stem, None)
+        chans = block_channels()
+        saved = []
+        x_map, x_str = _plain_strides(f4)
+        hi = f4.shape[1]
+        for i, (cin, cs, cout) in enumerate(chans):
+            w1, ga1, be1, w2, ga2, be2 = blocks[6 * i:6 * i + 6]
+            skip = skips[i]
+            ho = skip.shape[1] if skip is not None else out_hw
+            s = ho // hi
+            g = gs[i].contiguous() if i < 3 else None
+            sk, ss = _plain_strides(skip) if skip is not None else (None, None)
+            X = kn.grid_upcat_fwd(x_map, x_str, g, sk, ss, N, ho, ho, s, cin, cs)
+            Y1, st = kn.gridconv3x3(X, _fwd_w(w1), cout, want_stats=True)
+            bn1 = kn.grid_bn_finalize(st, N, ho, ho, cout, ga1, be1, *(buffers[4 * i:4 * i + 2] if buffers else (None, None)))
+            O1 = kn.grid_bn_relu_fwd(Y1, bn1)
+            Y2, st = kn.gridconv3x3(O1, _fwd_w(w2), cout, want_stats=True)
+            bn2 = kn.grid_bn_finalize(st, N, ho, ho, cout, ga2, be2, *(buffers[4 * i + 2:4 * i + 4] if buffers else (None, None)))
+            O2 = kn.grid_bn_relu_fwd(Y2, bn2)
+            saved.append((X, Y1, bn1, O1, Y2, bn2, O2, x_map, x_str, g, hi, s))
+            x_map, sn, sy, sx = O2.pixel_strides()
+            x_str = (sn, sy, sx)
+            hi = ho
+        last = saved[-1][6]
+        hw32 = torch.zeros(32, head_w.shape[1], 3, 3, dtype=torch.float32, device=dev)
+        hw32[0] = head_w.detach()[0]
+        logit0 = torch.empty(last.R, dtype=torch.float32, device=dev)
+        kn.gridconv3x3(last, hw32.permute(0, 2, 3, 1).reshape(32, -1).contiguous().to(torch.bfloat16), 32, out0=logit0, bias0=head_b.detach())
+        p0i = p0.to(device=dev, dtype=torch.int32).contiguous()
+        lse, picked = kn.pixel_ce_fwd(logit0, p0i, N, out_hw, out_hw)
+        loss = -(picked - lse).sum() / float(N * out_hw * out_hw)
+        ctx.saved = (saved, logit0, lse, p0i, hw32, blocks, head_w, head_b, N, out_hw)
+        logits = logit0.view(N, out_hw + 2, out_hw + 2)[:, 1:-1, 1:-1].reshape(N, -1)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        saved, logit0, lse, p0i, hw32, blocks, head_w, head_b, N, out_hw = ctx.saved
+        dev = logit0.device
+        chans = block_channels()
+        grads_blocks: List = [None] * 30
+        up = dloss.reshape(1).to(torch.float32).contiguous()
+        DZh = kn.pixel_ce_bwd(logit0, p0i, lse, up, N, out_hw, out_hw, 32)
+        last = saved[-1][6]
+        # head: weight gradient of its 32-row padded form, row 0 is the parameter's; the bias gradient is the sum of (softmax - onehot) = 0
+        sink_h = gradsink.get(head_w)
+        dwh = torch.empty(32, head_w.shape[1] * 9, dtype=torch.float32, device=dev)
+        Wp = out_hw + 2
+        for t in range(9):
+            off = (t // 3 - 1) * Wp + (t % 3 - 1)
+            kn.wgrad(DZh.rows[DZh.guard:DZh.guard + DZh.Rpad], last.rows[last.guard + off:last.guard + off + last.Rpad], dwh[:, t:], 32, last.C, last.Rpad, 32, last.C,
+                     last.C * 9, col_mul=9)
+        d_head_w = dwh[0].view(1, head_w.shape[1], 3, 3)
+        d_head_b = torch.zeros_like(head_b, dtype=torch.float32)
+        if sink_h is not None:
+            (sink_h.copy_ if gradsink.first_write(head_w) else sink_h.add_)(d_head_w)
+            d_head_w = None
+        sink_hb = gradsink.get(head_b)
+        if sink_hb is not None:
+            if gradsink.first_write(head_b):
+                sink_hb.zero_()
+            d_head_b = None
+        dO2, _ = kn.gridconv3x3(DZh, hw32.permute(1, 2, 3, 0).reshape(last.C, -1).contiguous().to(torch.bfloat16), last.C, flip=True)
+        dgs = [None, None, None]
+        for i in range(4, -1, -1):
+            cin, cs, cout = chans[i]
+            X, Y1, bn1, O1, Y2, bn2, O2, x_map, x_str, g, hi, s = saved[i]
+            w1, ga1, be1, w2, ga2, be2 = blocks[6 * i:6 * i + 6]
+            d_ga2, a1, r1 = _vec_grad(ga2, bn2)
+            d_be2, a2, r2 = _vec_grad(be2, bn2)
+            DZ2 = kn.grid_bn_relu_bwd(dO2, O2, Y2, bn2, d_ga2, d_be2, accumulate=a1 or a2)
+            grads_blocks[6 * i + 4], grads_blocks[6 * i + 5] = r1, r2
+            grads_blocks[6 * i + 3] = _conv_wgrad(DZ2, O1, w2, cout)
+            dO1, _ = kn.gridconv3x3(DZ2, _dgrad_w(w2), cout, flip=True)
+            d_ga1, a1, r1 = _vec_grad(ga1, bn1)
+            d_be1, a2, r2 = _vec_grad(be1, bn1)
+            DZ1 = kn.grid_bn_relu_bwd(dO1, O1, Y1, bn1, d_ga1, d_be1, accumulate=a1 or a2)
+            grads_blocks[6 * i + 1], grads_blocks[6 * i + 2] = r1, r2
+            grads_blocks[6 * i] = _conv_wgrad(DZ1, X, w1, cin + cs)
+            need_small = i > 0                                          # block 0's input is the frozen trunk's last map
+            need_dg = i < 3
+            if need_small or need_dg:
+                dX, _ = kn.gridconv3x3(DZ1, _dgrad_w(w1, cin), cin, flip=True)
+                dsmall, dg = kn.grid_upcat_bwd(dX, x_map, x_str, g, N, hi, hi, s, cin, want_dsmall=need_small, want_dg=need_dg)
+                if need_dg:
+                    dgs[i] = dg
+                dO2 = dsmall
+        return (None, None, None, dgs[0], dgs[1], dgs[2], None, None, None, None, None, *grads_blocks, d_head_w, d_head_b)

@@ -29,6 +29,7 @@ struct GcP {
     float* out0; const float* bias;
     float* stats;
     int R, H, W, Cin, Cout;
+    int flip;                       // k-block t reads the rows of tap 8 - t: the data gradient on UNflipped weights [ci][t][co]
 };
 
 template <int WN, int TN>
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     for (int q = 0; q < 2; ++q) { const int r = r0 + (tid >> 2) + q * 64; ar[q] = r < p.R ? r : p.R - 1; }
     uint4 ra0, ra1, rb0, rb1;
     rb0 = rb1 = make_uint4(0u, 0u, 0u, 0u);
-    auto tap_off = [&](int t) { return (t / 3 - 1) * Wp + (t % 3 - 1); };
+    auto tap_off = [&](int t) { const int u = p.flip ? 8 - t : t; return (u / 3 - 1) * Wp + (u % 3 - 1); };
 #define GC_LOAD(ks_)                                                                                                   \
     {                                                                                                                  \
         const int t_ = (ks_) / kpt, c0_ = ((ks_) - t_ * kpt) * 32 + ch * 8, off_ = tap_off(t_);                        \
@@ -145,8 +146,8 @@ extern "C" long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout) {
     return ((R + GC_BM - 1) / GC_BM) * 2 * Cout * (long)sizeof(float);
 }
 
-extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, float* stats,
-                                float* out0, const float* bias0, void* stream) {
+extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps,
+                                float* stats, float* out0, const float* bias0, void* stream) {
     if (!x || !wt || (!y && !out0)) return hulc_fail(-1, "hulc_gridconv3x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 32 || Cin <= 0 || Cout % 32 || Cout <= 0) return hulc_fail(-2, "hulc_gridconv3x3: Cin and Cout must be positive multiples of 32");
     if (ldx % 8 || ldx < Cin || (y && (ldy < Cout)) || (uintptr_t)x % 16 || (uintptr_t)wt % 16) return hulc_fail(-3, "hulc_gridconv3x3: rows must be 16-byte aligned");
@@ -154,7 +155,7 @@ extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y
     if (R >= (1L << 31) / 2) return hulc_fail(-2, "hulc_gridconv3x3: grid too large");
     GcP p;
     p.X = (const uint16_t*)x; p.ldx = ldx; p.Wt = (const uint16_t*)wt; p.ldw = 9L * Cin; p.Y = (uint16_t*)y; p.ldy = ldy;
-    p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.flip = flip_taps ? 1 : 0;
     const unsigned gx = (unsigned)((R + GC_BM - 1) / GC_BM);
     hipStream_t s = (hipStream_t)stream;
     if (Cout % 128 == 0) gridconv_kernel<2, 2><<<dim3(gx, Cout / 128), 256, 0, s>>>(p);

@@ -269,7 +269,7 @@ Plan plan_item(const hulc_wgrad_item& d) {
     pl.tm = (d.M + T - 1) / T; pl.tn = (d.N + T - 1) / T; pl.tiles = pl.tm * pl.tn;
     const int nsteps = (d.K + T - 1) / T;
     int want = (nsteps + 3) / 4;                                           // slices of 4 k-steps (256 tokens) ...
-    const int cap = pl.tiles >= 2048 ? 1 : 2048 / pl.tiles;                // ... unless the problem already has thousands of tiles
+    const int cap = pl.tiles >= 1024 ? 1 : 1024 / pl.tiles;                // ... unless the problem already has a thousand tiles (slab bytes = tiles x slices x 16 KB)
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     pl.kper = (nsteps + want - 1) / want;

@@ -573,15 +573,15 @@ _wg_ws = {}             # (device, stream) -> workspace (counters zeroed once, l
 _wg_armed = set()
 
 
-def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc) -> bool:
-    """shapes hulc_wgrad_group takes; the three 2048^3 products of the recurrent decoder stay on their own kernel (gemm_tn128)"""
+def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc, any_size=False) -> bool:
+    """shapes hulc_wgrad_group takes; the three 2048^3 products of the recurrent decoder stay on their own kernel (gemm_tn128) unless any_size"""
     import os
     if _compute_mode != BF16 or os.environ.get("HULC_NO_WGRAD_GROUP"):
         return False
     if K % 32 or M % 8 or N % 8 or C.dtype != torch.float32 or A.dtype not in (torch.float32, torch.bfloat16) \
             or B.dtype not in (torch.float32, torch.bfloat16):
         return False
-    if min(M, N, K) >= 512 and M % 128 == 0 and N % 128 == 0 and K % 128 == 0 and A.dtype == B.dtype == torch.bfloat16:
+    if not any_size and min(M, N, K) >= 512 and M % 128 == 0 and N % 128 == 0 and K % 128 == 0 and A.dtype == B.dtype == torch.bfloat16:
         return False
     ea, eb = (4 if A.dtype == torch.float32 else 8), (4 if B.dtype == torch.float32 else 8)
     return lda % ea == 0 and ldb % eb == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and C.data_ptr() % 4 == 0
@@ -591,7 +591,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
     destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
     when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
-    if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc):
+    if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc, any_size=bool(col_perm) or col_mul > 1):
         if col_perm or col_mul > 1:
             raise _L.HulcKernelError("wgrad: col_perm / col_mul need the grouped kernel (check wgrad_group_ok first)")
         fused = rowsum is not None and gemm_fuses_rowsum(M, False) and A.dtype == torch.float32
@@ -958,7 +958,7 @@ class Grid:
         return self.t.view(self.N, self.H + 2, self.W + 2, self.C)[:, 1:-1, 1:-1]
 
 
-def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None, bias0=None, cin=None):
+def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None, bias0=None, cin=None, flip=False):
     """y = conv3x3(x) on the grid; wt bf16 [Cout][9 * Cin]; -> (y Grid or None, stats partials or None)"""
     Cin = x.C if cin is None else cin
     _require_cuda(x.rows, wt, out0, bias0)
@@ -970,7 +970,7 @@ def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None
     lib.hulc_gridconv_stats_bytes.restype = _c.c_long
     stats = _ws(lib.hulc_gridconv_stats_bytes(_i(x.N), _i(x.H), _i(x.W), _i(Cout)), x.rows.device) if want_stats else None
     _call("hulc_gridconv3x3", x.t, _l(x.C), wt, (y.t if y is not None else None), _l(y.C if y is not None else 0), _i(x.N), _i(x.H), _i(x.W), _i(Cin), _i(Cout),
-          stats, out0, bias0, key=("gridconv3x3", x.N, x.H, x.W, Cin, Cout), flops=2.0 * x.R * 9 * Cin * Cout,
+          _i(flip), stats, out0, bias0, key=("gridconv3x3", x.N, x.H, x.W, Cin, Cout), flops=2.0 * x.R * 9 * Cin * Cout,
           nbytes=float(x.R) * (x.C + Cout) * 2 + Cout * 9 * Cin * 2)
     return y, stats
 

@@ -146,10 +146,14 @@ class VisionR3M(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def trunk_features(self, x: torch.Tensor) -> torch.Tensor:
-        """x (N, 3, H, W) fp32 in [0, 255] -> (N, 512) fp32: normalise, stem, max pool, the residual stages, global average pool."""
+    def trunk_features(self, x: torch.Tensor, want_maps: bool = False, mean=None, std=None):
+        """x (N, 3, H, W) fp32 in [0, 255] -> (N, 512) fp32: normalise, stem, max pool, the residual stages, global average pool.
+        want_maps: return the NHWC maps after the stem (+ max pool) and after each of the four stages instead (the skips of the affordance
+        model's U-Net, hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:71-76); mean / std override the input normalisation."""
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise TypeError("VisionR3M expects fp32 (N, 3, H, W) frames in [0, 255] (conf/datamodule/transforms/real_world_r3m.yaml)")
+        mean = IMAGENET_MEAN if mean is None else mean
+        std = IMAGENET_STD if std is None else std
         f = self._fold_trunk()
         adt = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
         n, _, h, w = x.shape
@@ -163,22 +167,26 @@ class VisionR3M(nn.Module):
             return y, oh, ow
 
         if "stem_packed" in f:
-            xp = kn.r3m_normalize_packed(x.contiguous(), torch.empty((n, h + 6, kn.r3m_packed_width(w), 4), dtype=adt, device=dev),
-                                         IMAGENET_MEAN, IMAGENET_STD)
+            xp = kn.r3m_normalize_packed(x.contiguous(), torch.empty((n, h + 6, kn.r3m_packed_width(w), 4), dtype=adt, device=dev), mean, std)
             oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
             a = kn.r3m_stem_fwd(xp, f["stem_packed"][0], f["stem_packed"][1], torch.empty((n, oh, ow, 64), dtype=adt, device=dev), n, h, w, 64)
             h, w = oh, ow
         else:
-            a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), IMAGENET_MEAN, IMAGENET_STD)
+            a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), mean, std)
             a, h, w = conv(a, f["stem"], h, w, 8, 7, 2, 3, True)
         ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         a = kn.maxpool_nhwc(a, torch.empty((n, ph, pw, 64), dtype=adt, device=dev), n, h, w, 64, 3, 2, 1)
         h, w, c = ph, pw, 64
-        for c1, c2, ds, stride in f["blocks"]:
+        maps = [a]
+        for bi, (c1, c2, ds, stride) in enumerate(f["blocks"]):
             idn = a if ds is None else conv(a, ds, h, w, c, 1, stride, 0, False)[0]
             o, oh, ow = conv(a, c1, h, w, c, 3, stride, 1, True)
             c = c1[0].shape[0]
             a, h, w = conv(o, c2, oh, ow, c, 3, 1, 1, True, add=idn)
+            if bi % 2 == 1:                                    # ResNet-18: two BasicBlocks per stage
+                maps.append(a)
+        if want_maps:
+            return maps
         feat = torch.empty((n, c), dtype=torch.float32, device=dev)
         kn.strided_seq_sum(a, feat, n, h * w, c, h * w * c, c, c, 1.0 / (h * w))
         return feat
@@ -194,3 +202,30 @@ class VisionR3M(nn.Module):
         feat = [self.trunk_features(t) for t in xs]
         feat = feat[0] if len(feat) == 1 else torch.cat(feat, dim=0)
         return HF.mlp(feat, [(self.fc1.weight, self.fc1.bias, True), (self.fc2.weight, self.fc2.bias, False)])
+
+
+class _TrunkOnly(VisionR3M):
+    """VisionR3M's folded-trunk machinery around an existing R3M module (no heads): the affordance model's encoder"""
+
+    def __init__(self, r3m: "R3M"):
+        nn.Module.__init__(self)
+        object.__setattr__(self, "_r3m_ref", r3m)
+        self._folded = None
+        self._folded_key = None
+
+    @property
+    def r3m(self):
+        return self._r3m_ref
+
+
+_trunks = {}
+
+
+def trunk_feature_maps(r3m: "R3M", img: torch.Tensor):
+    """the affordance encoder (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-32,71-76 uses the ResNet's children directly: no
+    / 255, no ImageNet normalisation inside — the dataset transforms did that): img (N, 3, H, W) fp32 -> [stem, layer1, layer2, layer3, layer4]
+    NHWC maps in the compute dtype, BatchNorm folded (inference statistics)"""
+    t = _trunks.get(id(r3m))
+    if t is None or t.r3m is not r3m:
+        t = _trunks[id(r3m)] = _TrunkOnly(r3m)
+    return t.trunk_features(img, want_maps=True, mean=(0.0, 0.0, 0.0), std=(1.0 / 255.0,) * 3)

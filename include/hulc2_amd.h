@@ -354,7 +354,8 @@ int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_byte
  * n (H+2)(W+2) + (y+1)(W+2) + (x+1), border rows are ZERO, and at least W + 3 zero rows precede and follow the tensor (pointers below address
  * grid row 0).  A 3 x 3 / padding-1 convolution is then a shifted GEMM without bounds tests, its data gradient the same kernel with flipped
  * taps and transposed weights, its weight gradient nine items of hulc_wgrad_group (A = dY rows, B = X rows shifted by the tap, col_mul = 9).
- * hulc_gridconv3x3: y[r][co] = sum_{t, ci} x[r + off_t][ci] wt[co][t * Cin + ci] (wt bf16 [Cout][9 Cin], Cin / Cout multiples of 32), border
+ * hulc_gridconv3x3: y[r][co] = sum_{t, ci} x[r + off_t][ci] wt[co][t * Cin + ci] (wt bf16 [Cout][9 Cin], Cin / Cout multiples of 32; flip_taps:
+ *   off_{8-t} instead of off_t — the data gradient reading the UNflipped weights as [ci][kh][kw][co]), border
  *   rows of y forced to zero; stats (optional, hulc_gridconv_stats_bytes): per row-tile partial sums of y and y^2 over the pixels from the fp32
  *   accumulators; out0 (optional): fp32 [rows] = channel 0 + bias0[0] (the one-channel head; y may then be NULL).
  * hulc_grid_bn_finalize: nn.BatchNorm2d in training mode from those partials (nb = row tiles, count = N H W): bn[4][C] = mean, rstd,
@@ -368,8 +369,8 @@ int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_byte
  * hulc_pixel_ce_fwd / _bwd: log-sum-exp over an image's H W logits (logit0: fp32 per grid row) and the labelled pixel's logit
  *   (p0 (N, 2) int32 = row, col); backward writes upstream (softmax - onehot) / (N H W) into channel 0 of a grid tensor of C channels. */
 long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout);
-int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, float* stats, float* out0,
-                     const float* bias0, void* stream);
+int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps, float* stats,
+                     float* out0, const float* bias0, void* stream);
 int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum, float* bn,
                           float* run_mean, float* run_var, void* stream);
 int hulc_grid_bn_relu_fwd(const void* y, long ldy, const float* bn, int N, int H, int W, int C, void* out, long ldo, void* stream);

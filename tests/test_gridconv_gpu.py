@@ -48,8 +48,8 @@ def fwd_weights(w):           # (Cout, Cin, 3, 3) -> bf16 [Cout][9 Cin], k = tap
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(torch.bfloat16)
 
 
-def dgrad_weights(w):         # -> bf16 [Cin][9 Cout]: flipped taps, transposed channels
-    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous().to(torch.bfloat16)
+def dgrad_weights(w):         # -> bf16 [Cin][9 Cout]: (ci, kh, kw, co), taps NOT flipped (the kernel's flip flag walks them backwards)
+    return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous().to(torch.bfloat16)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 5, 64, 32), (3, 14, 14, 96, 128), (2, 9, 9, 32, 64), (1, 30, 17, 160, 256)])
@@ -76,7 +76,7 @@ def test_gridconv_forward_dgrad_wgrad(N, H, W, Cin, Cout):
     # data gradient: the same kernel on the gradient map
     want.backward(bf(dy))
     DY = to_grid(dy, dev)
-    DX, _ = kn.gridconv3x3(DY, dgrad_weights(w).to(dev), Cin)
+    DX, _ = kn.gridconv3x3(DY, dgrad_weights(w).to(dev), Cin, flip=True)
     torch.cuda.synchronize()
     assert borders_zero(DX)
     assert (from_grid(DX).double() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
