@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel time table to stderr")
+    ap.add_argument("--affordance", action="store_true", help="BASELINE configs[4] (secondary): one training step of the affordance model "
+                    "(PixelAffLangDetector, r3m variant) on --batch images of 224 x 224; the metric becomes images per second")
     ap.add_argument("--uint8-frames", action="store_true",
                     help="feed uint8 NHWC frames + shift-augmentation offsets (SURVEY 8 row f-2) instead of transformed fp32 frames; "
                          "a separate data format, not the headline configuration")
@@ -280,14 +282,27 @@ def main():
     kn.set_compute(args.compute)
     if args.real_world and (args.uint8_frames or args.episode_store):
         raise SystemExit("--real-world takes fp32 frames in [0,255] (conf/datamodule/transforms/real_world_r3m.yaml); the uint8 store feeds the CNN config")
-    cfg = real_world_model_config(dropout_p=0.1) if args.real_world else default_model_config(gripper_control=True, dropout_p=0.1)
-    model = instantiate(cfg).to(dev)
-    syn.fill_state_dict_(model.state_dict(), 42)            # same weights on every rank
-    model.train()
     use_graph = not args.no_graph
-    trainer = ArenaTrainer(model, lr=2e-4, overlap=not use_graph, force_comm=force_dist)
-    batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev, **({"static_hw": (150, 200)} if args.real_world else {}))
-    for db in batch.values():
+    if args.affordance:
+        from hulc2_amd.affordance import PixelAffLangDetector
+        model = PixelAffLangDetector(img_size=224).to(dev)
+        syn.fill_affordance_state_dict_({k: v for k, v in model.state_dict().items() if ".r3m." not in k}, 42)
+        syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in model.model.aff_stream.r3m.convnet.state_dict().items()}, 42)
+        model.train()
+        trainer = ArenaTrainer(model, lr=1e-4, overlap=not use_graph, force_comm=force_dist)
+        g = torch.Generator().manual_seed(42 + rank)
+        nb = args.batch
+        batch = ({"img": torch.randn(nb, 3, 224, 224, generator=g).to(dev), "lang_goal": (torch.randn(nb, 384, generator=g) * 0.5).to(dev)},
+                 {"p0": torch.stack([torch.randint(0, 224, (nb,), generator=g), torch.randint(0, 224, (nb,), generator=g)], 1).to(dev),
+                  "normalized_depth": torch.randn(nb, generator=g).to(dev)})
+    else:
+        cfg = real_world_model_config(dropout_p=0.1) if args.real_world else default_model_config(gripper_control=True, dropout_p=0.1)
+        model = instantiate(cfg).to(dev)
+        syn.fill_state_dict_(model.state_dict(), 42)            # same weights on every rank
+        model.train()
+        trainer = ArenaTrainer(model, lr=2e-4, overlap=not use_graph, force_comm=force_dist)
+        batch = syn.make_batch(42 + rank, args.batch, args.seq_len, device=dev, **({"static_hw": (150, 200)} if args.real_world else {}))
+    for db in ({} if args.affordance else batch).values():
         db.pop("plan_idx", None)                            # benchmark samples the latent plan on-device
         if args.real_world:                                 # UpScaleImageTensor: the R3M trunk takes [0, 255]
             db["rgb_obs"]["rgb_static"] = (db["rgb_obs"]["rgb_static"] + 1) * 127.5
@@ -398,26 +413,35 @@ def main():
             print(f"  {t / 3:9.3f} ms/step  {n // 3:4d} launches  {f / a / 1e12:8.1f} TFLOP/s  {b / a / 1e9:8.0f} GB/s  {key}", file=sys.stderr)
         print(f"  sum of kernel time: {total_ms / 3:.3f} ms/step", file=sys.stderr)
 
-    seqs = 2 * args.batch * world * args.steps
+    seqs = (1 if args.affordance else 2) * args.batch * world * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = seqs / elapsed
     # real-world config: frozen trunk forward only (1 167 MMAC per 150x200 frame, by closed form over the 20 convolutions) + 3x the trained part
     seq_flop = (2 * 1167.0e6 * 32 + 3 * 2 * (237.37 + 59.24 + 15.01 + 4.78 + 492.2 + 0.15) * 1e6) if args.real_world else SEQ_FLOP_TRAIN
-    workload = ("BASELINE configs[3] (secondary): cfg_low_level_rw — static 150x200 in [0,255] through the frozen R3M ResNet-18 trunk (random "
+    if args.affordance:
+        # per image: frozen ResNet-18 trunk forward (1.82 GMAC at 224 x 224) + 3 x the trainable part (decoder convolutions 6 256 MMAC by closed
+        # form over unet_decoder.py's ten 3 x 3 layers and the head, depth / text MLPs 21 MMAC)
+        seq_flop = 2 * 1.82e9 + 3 * 2 * (6256.0 + 21.0) * 1e6
+    workload = ("BASELINE configs[4] (secondary): affordance model PixelAffLangDetector.training_step, shipped r3m variant — frozen R3M ResNet-18 trunk "
+                "(random weights, inference-mode BatchNorm), language-fused U-Net decoder with BatchNorm on batch statistics, pixel cross-entropy + "
+                "Gaussian depth NLL, Adam lr 1e-4; 224 x 224 images, lang = random (B,384) embeddings"
+                if args.affordance else
+                "BASELINE configs[3] (secondary): cfg_low_level_rw — static 150x200 in [0,255] through the frozen R3M ResNet-18 trunk (random "
                 "weights), gripper CNN 84x84, decoder on the whole embedding, world-frame actions, no CLIP loss, lang = random (B,384) embeddings"
                 if args.real_world else
                 "BASELINE configs[1]: synthetic CALVIN-shaped batch, Hulc2.training_step fwd+bwd+allreduce+Adam, "
                 "static CNN 200x200 + gripper CNN 84x84, lang = random (B,384) embeddings, dropout 0.1, gripper_control on")
     step_frac = round(value / world * seq_flop / peak, 4)
     out = {
-        "metric": "play-sequences/sec/node (seq_len=32, real-world cfg: R3M static 150x200)" if args.real_world
+        "metric": "affordance-images/sec/node (224x224, r3m variant)" if args.affordance
+                  else "play-sequences/sec/node (seq_len=32, real-world cfg: R3M static 150x200)" if args.real_world
                   else "play-sequences/sec/node (seq_len=32, 200x200 RGB)",
-        "value": round(value, 2), "unit": "play-sequences/s", "n_gpus": world,
+        "value": round(value, 2), "unit": "images/s" if args.affordance else "play-sequences/s", "n_gpus": world,
         "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": workload,
-                   "sequences_per_gpu_step": 2 * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
+                   "sequences_per_gpu_step": (1 if args.affordance else 2) * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
                    "frames": "HBM-resident uint8 episode store, new play windows (20..32 steps, padded by repetition) every step, conv1 reads "
                              "the store through index rows" if args.episode_store
@@ -436,11 +460,11 @@ def main():
                      "step_frac_of_mfma_peak": step_frac,
                      "gpu_kernel_ms_per_step": round(total_ms / 3, 3)},
     }
-    plain = not (args.real_world or args.uint8_frames or args.episode_store or args.no_graph)
+    plain = not (args.real_world or args.uint8_frames or args.episode_store or args.no_graph or args.affordance)
     if world == 1 and args.compute == "bf16" and plain and not args.no_secondary:
         del trainer, model
         out["secondary"] = secondary_fp32(args, dev)
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.affordance:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))

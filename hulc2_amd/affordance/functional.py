@@ -42,12 +42,9 @@ def _conv_wgrad(dz: "kn.Grid", x: "kn.Grid", w: torch.Tensor, cin: int):
     sink = gradsink.get(w)
     out = sink.view(cout, cin * 9) if sink is not None else torch.empty(cout, cin * 9, dtype=torch.float32, device=dz.rows.device)
     acc = sink is not None and not gradsink.first_write(w)
-    Wp = x.W + 2
     A = dz.rows[dz.guard:dz.guard + dz.Rpad]
-    for t in range(9):
-        off = (t // 3 - 1) * Wp + (t % 3 - 1)
-        B = x.rows[x.guard + off:x.guard + off + x.Rpad]
-        kn.wgrad(A, B, out[:, t:], cout, cin, x.Rpad, cout, x.C, cin * 9, accumulate=acc, defer=sink is not None, col_mul=9)
+    B = x.rows[x.guard:x.guard + x.Rpad]                               # tap u reads it shifted by (dy (W + 2) + dx) rows: inside the zero guards
+    kn.wgrad(A, B, out, cout, cin, x.Rpad, cout, x.C, cin * 9, accumulate=acc, defer=sink is not None, col_mul=9, conv_taps_wp=x.W + 2)
     return None if sink is not None else out.view(cout, cin, 3, 3)
 
 
@@ -121,17 +118,13 @@ class AffDecoderLossFn(torch.autograd.Function):
         last = saved[-1][6]
         # head: weight gradient of its 32-row padded form, row 0 is the parameter's; the bias gradient is the sum of (softmax - onehot) = 0
         sink_h = gradsink.get(head_w)
-        dwh = torch.empty(32, head_w.shape[1] * 9, dtype=torch.float32, device=dev)
-        Wp = out_hw + 2
-        for t in range(9):
-            off = (t // 3 - 1) * Wp + (t % 3 - 1)
-            kn.wgrad(DZh.rows[DZh.guard:DZh.guard + DZh.Rpad], last.rows[last.guard + off:last.guard + off + last.Rpad], dwh[:, t:], 32, last.C, last.Rpad, 32, last.C,
-                     last.C * 9, col_mul=9)
-        d_head_w = dwh[0].view(1, head_w.shape[1], 3, 3)
+        ci = head_w.shape[1]
+        dwh = sink_h.view(1, ci * 9) if sink_h is not None else torch.empty(1, ci * 9, dtype=torch.float32, device=dev)
+        acc_h = sink_h is not None and not gradsink.first_write(head_w)
+        kn.wgrad(DZh.rows[DZh.guard:DZh.guard + DZh.Rpad], last.rows[last.guard:last.guard + last.Rpad], dwh, 32, ci, last.Rpad, 32, last.C, ci * 9,
+                 accumulate=acc_h, defer=sink_h is not None, col_mul=9, store_rows=1, conv_taps_wp=out_hw + 2)
+        d_head_w = None if sink_h is not None else dwh.view(1, ci, 3, 3)
         d_head_b = torch.zeros_like(head_b, dtype=torch.float32)
-        if sink_h is not None:
-            (sink_h.copy_ if gradsink.first_write(head_w) else sink_h.add_)(d_head_w)
-            d_head_w = None
         sink_hb = gradsink.get(head_b)
         if sink_hb is not None:
             if gradsink.first_write(head_b):

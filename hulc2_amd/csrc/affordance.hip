@@ -26,14 +26,33 @@ HULC_DEVICE float sum_partials(const float* part, int nb, long ld, int c) {
     return (a0 + a1) + (a2 + a3);
 }
 
+// sums of the two halves of partial rows [nb][2][C] for 64 channels per workgroup: 16 row slices (4 loads in flight each), LDS, fixed order
+HULC_DEVICE void sum_partials_2x(const float* part, int nb, int C, int c, bool cok, float (*red)[16][64], float& s1, float& s2) {
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int per = (nb + 15) / 16, b0 = sl * per, b1 = min(b0 + per, nb);
+    float a = 0.f, b = 0.f;
+    if (cok && b0 < b1) {
+        a = sum_partials(part + (long)b0 * 2 * C, b1 - b0, 2L * C, c);
+        b = sum_partials(part + (long)b0 * 2 * C + C, b1 - b0, 2L * C, c);
+    }
+    red[0][sl][lane] = a; red[1][sl][lane] = b;
+    __syncthreads();
+    s1 = s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { s1 += red[0][w][lane]; s2 += red[1][w][lane]; }
+}
+
 // BatchNorm2d, training mode: partial sums (sum y, sum y^2 over the interior rows; gridconv's epilogue) -> bn[0..3][C] = mean, rstd,
 // scale = gamma rstd, shift = beta - mean scale; running statistics updated with momentum 0.1 and the unbiased variance (nn.BatchNorm2d)
-__global__ void grid_bn_finalize_kernel(const float* __restrict__ part, int nb, int C, float count, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ bn,
-                                        float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float s1 = sum_partials(part, nb, 2L * C, c), s2 = sum_partials(part + C, nb, 2L * C, c);
+__global__ __launch_bounds__(1024) void grid_bn_finalize_kernel(const float* __restrict__ part, int nb, int C, float count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float momentum, float* __restrict__ bn,
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ float red[2][16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool cok = c < C;
+    float s1, s2;
+    sum_partials_2x(part, nb, C, c, cok, red, s1, s2);
+    if (threadIdx.x >= 64 || !cok) return;
     const float mean = s1 / count;
     float var = s2 / count - mean * mean;
     var = var > 0.f ? var : 0.f;
@@ -78,13 +97,22 @@ __global__ __launch_bounds__(256) void grid_bn_relu_bwd_reduce_kernel(const uint
     const float mean = cok ? bn[c] : 0.f, rstd = cok ? bn[C + c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     const int r0 = blockIdx.x * 256;
-    for (int k = sl; k < 256; k += 4) {
-        const int r = r0 + k;
-        if (r >= R || !cok) break;
-        const float o = bf16_bits_to_f32(out[(long)r * ldo + c]);
-        const float d = o > 0.f ? bf16_bits_to_f32(dout[(long)r * ldd + c]) : 0.f;          // border rows: out == 0
-        const float xh = (bf16_bits_to_f32(y[(long)r * ldy + c]) - mean) * rstd;
-        s1 += d; s2 += d * xh;
+    if (cok) {
+        for (int k = sl; k < 256; k += 16) {                   // four rows per trip: twelve independent loads in flight
+            uint16_t vo[4], vd[4], vy[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + k + 4 * q, rc = r < R ? r : R - 1;
+                vo[q] = out[(long)rc * ldo + c]; vd[q] = dout[(long)rc * ldd + c]; vy[q] = y[(long)rc * ldy + c];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool live = r0 + k + 4 * q < R && bf16_bits_to_f32(vo[q]) > 0.f;       // border rows: out == 0
+                const float d = live ? bf16_bits_to_f32(vd[q]) : 0.f;
+                const float xh = (bf16_bits_to_f32(vy[q]) - mean) * rstd;
+                s1 += d; s2 += d * xh;
+            }
+        }
     }
     red[0][sl][lane] = s1; red[1][sl][lane] = s2;
     __syncthreads();
@@ -95,11 +123,14 @@ __global__ __launch_bounds__(256) void grid_bn_relu_bwd_reduce_kernel(const uint
 }
 
 // the two sums, once: sums[0][C] = s1 (= dbeta), sums[1][C] = s2 (= dgamma), also written / accumulated into the parameter gradients
-__global__ void grid_bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float s1 = sum_partials(part, nb, 2L * C, c), s2 = sum_partials(part + C, nb, 2L * C, c);
+__global__ __launch_bounds__(1024) void grid_bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[2][16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool cok = c < C;
+    float s1, s2;
+    sum_partials_2x(part, nb, C, c, cok, red, s1, s2);
+    if (threadIdx.x >= 64 || !cok) return;
     sums[c] = s1; sums[C + c] = s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
@@ -259,7 +290,7 @@ __global__ void pixel_ce_bwd_kernel(const float* __restrict__ logit0, const int*
 extern "C" int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum,
                                      float* bn, float* run_mean, float* run_var, void* stream) {
     if (!part || !gamma || !beta || !bn || C <= 0 || nb <= 0 || count < 2) return hulc_fail(-1, "hulc_grid_bn_finalize: bad argument");
-    grid_bn_finalize_kernel<<<(C + 63) / 64, 64, 0, (hipStream_t)stream>>>(part, nb, C, (float)count, gamma, beta, eps, momentum, bn, run_mean, run_var);
+    grid_bn_finalize_kernel<<<(C + 63) / 64, 1024, 0, (hipStream_t)stream>>>(part, nb, C, (float)count, gamma, beta, eps, momentum, bn, run_mean, run_var);
     return hulc_check_launch("hulc_grid_bn_finalize");
 }
 
@@ -284,7 +315,7 @@ extern "C" int hulc_grid_bn_relu_bwd(const void* dout, long ldd, const void* out
     float* sums = part + (long)nb * 2 * C;
     hipStream_t s = (hipStream_t)stream;
     grid_bn_relu_bwd_reduce_kernel<<<dim3(nb, (C + 63) / 64), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, (int)R, C, part);
-    grid_bn_bwd_sums_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, nb, C, sums, dgamma, dbeta, accumulate_params);
+    grid_bn_bwd_sums_kernel<<<(C + 63) / 64, 1024, 0, s>>>(part, nb, C, sums, dgamma, dbeta, accumulate_params);
     const long n = R * (C / 8);
     grid_bn_relu_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, sums,
                                                                              1.0f / ((float)N * H * W), (int)R, H, W, C, (uint16_t*)dz, ldz);

@@ -23,7 +23,7 @@ namespace {
 constexpr int T = 64;                     // tile edge and k-step
 constexpr int RS = T * 2 + 16;            // LDS row stride of a [k][64] bf16 tile (144 B: the 4 k rows of a transposing read on distinct banks)
 constexpr int TILE_B = T * RS;            // 9216 B
-constexpr int MAX_ITEMS = 38;             // per launch (kernel-argument space: 38 x 96 + 38 x 4 bytes of the 4 KB)
+constexpr int MAX_ITEMS = 34;             // per launch (kernel-argument space: 34 x 112 + 34 x 4 bytes of the 4 KB)
 constexpr int SLAB = T * T + T;           // floats per partial slab (even): the tile, then its 64 bias-gradient partials
 constexpr int CTR_WORDS = 65536;          // counters at the head of the workspace
 
@@ -35,6 +35,8 @@ struct Item {
     int ctr0;                             // first counter
     int perm;                             // > 0: product column n is stored at column (n % perm) * (N / perm) + n / perm
     int cmul;                             // otherwise: at column n * cmul
+    int mstore;                           // rows m < mstore are stored (<= M)
+    int taps_wp;                          // > 0: nine products in one — tap u = (dy, dx) reads B shifted by (dy * taps_wp + dx) rows and writes C + u
     long slab0;                           // first slab
 };
 struct GroupP { int first[MAX_ITEMS]; Item it[MAX_ITEMS]; int n, total; unsigned* ctr; float* slabs; };   // first[j]: first work item of problem j (INT_MAX: unused)
@@ -95,7 +97,11 @@ HULC_DEVICE void raw_store(const Raw<F32>& r, char* dst, bool sum, bool kvalid, 
 template <bool AF32, bool BF32>
 HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem, int* s_last) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int u = 0;
+    if (it.taps_wp > 0) { u = local % 9; local /= 9; }                    // the nine taps of a (tile, slice) are neighbours: one XCD, one L2 copy of A and B
     const int ks_i = local % it.ksplit, t = local / it.ksplit, tn_i = t % it.tn, tm_i = t / it.tn;
+    const int tslab = it.taps_wp > 0 ? t * 9 + u : t;
+    float* const Cb = it.C + u;
     const int m0 = tm_i * T, n0 = tn_i * T;
     const int nsteps_all = (it.K + T - 1) / T;
     const int step0 = ks_i * it.kper, step1 = min(step0 + it.kper, nsteps_all);
@@ -103,7 +109,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
     const bool do_sum = it.rowsum != nullptr && tn_i == 0;
     const int colsA = it.M - m0, colsB = it.N - n0;                        // valid columns of the two tiles (may exceed 64)
     const char* Ab = (const char*)it.A + (long)m0 * (AF32 ? 4 : 2);
-    const char* Bb = (const char*)it.B + (long)n0 * (BF32 ? 4 : 2);
+    const char* Bb = (const char*)it.B + ((long)n0 + (long)((u / 3 - 1) * it.taps_wp + (u % 3 - 1)) * it.ldb * (it.taps_wp > 0 ? 1 : 0)) * (BF32 ? 4 : 2);
 
     f32x16_t acc;
 #pragma unroll
@@ -176,13 +182,13 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 32 + acc_row(e, lane);
-                if (m < it.M) {
-                    float* dst = it.C + (long)m * it.ldc + ncol;
+                if (m < it.mstore) {
+                    float* dst = Cb + (long)m * it.ldc + ncol;
                     *dst = accum ? *dst + acc[e] : acc[e];
                 }
             }
         }
-        if (do_sum && tid < T && m0 + tid < it.M) {
+        if (do_sum && tid < T && m0 + tid < it.mstore) {
             float* dst = it.rowsum + m0 + tid;
             *dst = (it.flags & 8) ? *dst + bsum : bsum;
         }
@@ -191,7 +197,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
     // ---- split tile: slab out, last arrival sums all slabs in slice order.  The slabs travel as agent-scope atomic (write-through / L2-bypassing)
     // 8-byte accesses: ordinary stores + a release / acquire fence pair would write back and invalidate the whole L2 of the XCD once per
     // work item (measured: 0.9 ms for the launch instead of tens of microseconds).
-    unsigned long long* slab = (unsigned long long*)(p.slabs + (it.slab0 + (long)t * it.ksplit + ks_i) * SLAB);
+    unsigned long long* slab = (unsigned long long*)(p.slabs + (it.slab0 + (long)tslab * it.ksplit + ks_i) * SLAB);
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
         const unsigned long long bits = (unsigned long long)__float_as_uint(acc[e]) | ((unsigned long long)__float_as_uint(acc[e + 1]) << 32);
@@ -201,7 +207,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this thread's stores are acknowledged ...
     __syncthreads();                                                       // ... and so are the workgroup's
     if (tid == 0) {
-        unsigned* c = p.ctr + it.ctr0 + t;
+        unsigned* c = p.ctr + it.ctr0 + tslab;
         const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == (unsigned)(it.ksplit - 1);
         if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
@@ -209,7 +215,7 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
     }
     __syncthreads();
     if (!*s_last) return;
-    const unsigned long long* s0 = (const unsigned long long*)(p.slabs + (it.slab0 + (long)t * it.ksplit) * SLAB);
+    const unsigned long long* s0 = (const unsigned long long*)(p.slabs + (it.slab0 + (long)tslab * it.ksplit) * SLAB);
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int s = 0; s < it.ksplit; ++s) {
@@ -226,14 +232,14 @@ HULC_DEVICE void run_item(const Item& it, const GroupP& p, int local, char* smem
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 32 + acc_row(e, lane);
-                if (m < it.M) {
-                    float* dst = it.C + (long)m * it.ldc + ncol;
+                if (m < it.mstore) {
+                    float* dst = Cb + (long)m * it.ldc + ncol;
                     *dst = accum ? *dst + acc[e] : acc[e];
                 }
             }
         }
     }
-    if (do_sum && tid < T && m0 + tid < it.M) {
+    if (do_sum && tid < T && m0 + tid < it.mstore) {
         float b = 0.f;
         for (int s = 0; s < it.ksplit; ++s)
             b += __uint_as_float(__hip_atomic_load((const unsigned*)(s0 + (long)s * (SLAB / 2)) + T * T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(GroupP p) {
     for (int j = 1; j < MAX_ITEMS; ++j) i = w >= p.first[j] ? j : i;       // one wide scalar load of the table, then compares
     const Item& it = p.it[i];
     const int local = w - p.first[i];
-    if (local >= it.tn * ((it.M + T - 1) / T) * it.ksplit) return;        // padding of the last problem
+    if (local >= it.tn * ((it.M + T - 1) / T) * it.ksplit * (it.taps_wp > 0 ? 9 : 1)) return;        // padding of the last problem
     switch (it.flags & 3) {
     case 0: run_item<false, false>(it, p, local, smem, &s_last); break;
     case 1: run_item<true, false>(it, p, local, smem, &s_last); break;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(GroupP p) {
 struct Plan { int tm, tn, ksplit, kper, tiles; };
 Plan plan_item(const hulc_wgrad_item& d) {
     Plan pl;
-    pl.tm = (d.M + T - 1) / T; pl.tn = (d.N + T - 1) / T; pl.tiles = pl.tm * pl.tn;
+    pl.tm = (d.M + T - 1) / T; pl.tn = (d.N + T - 1) / T; pl.tiles = pl.tm * pl.tn * (d.conv_taps_wp > 0 ? 9 : 1);      // (tile, tap) pairs
     const int nsteps = (d.K + T - 1) / T;
     int want = (nsteps + 3) / 4;                                           // slices of 4 k-steps (256 tokens) ...
     const int cap = pl.tiles >= 1024 ? 1 : 1024 / pl.tiles;                // ... unless the problem already has a thousand tiles (slab bytes = tiles x slices x 16 KB)
@@ -285,6 +291,7 @@ int check_item(const hulc_wgrad_item& d) {
         return hulc_fail(-2, "hulc_wgrad_group: operands are fp32 or bf16");
     if (d.lda % ea || d.ldb % eb || ((uintptr_t)d.A | (uintptr_t)d.B) % 16) return hulc_fail(-2, "hulc_wgrad_group: operand rows must be 16-byte aligned");
     if (d.lda < d.M || d.ldb < d.N || d.ldc < (d.col_mul > 1 ? (d.N - 1) * d.col_mul + 1 : d.N) || !d.A || !d.B || !d.C) return hulc_fail(-2, "hulc_wgrad_group: bad leading dimension or null operand");
+    if (d.conv_taps_wp > 0 && (d.rowsum || d.col_mul != 9 || d.col_perm)) return hulc_fail(-2, "hulc_wgrad_group: conv_taps_wp goes with col_mul = 9, no rowsum, no col_perm");
     if (d.col_perm < 0 || (d.col_perm > 0 && d.N % d.col_perm)) return hulc_fail(-2, "hulc_wgrad_group: col_perm must divide N");
     return 0;
 }
@@ -326,7 +333,7 @@ extern "C" int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, l
             it.M = d.M; it.N = d.N; it.K = d.K; it.lda = d.lda; it.ldb = d.ldb; it.ldc = d.ldc;
             it.flags = (d.a_dtype == HULC_F32 ? 1 : 0) | (d.b_dtype == HULC_F32 ? 2 : 0) | (d.accumulate ? 4 : 0) | (d.rowsum_accumulate ? 8 : 0);
             p.first[j] = first; it.tn = pl.tn; it.ksplit = pl.ksplit; it.kper = pl.kper;
-            it.ctr0 = ctr; it.slab0 = slab; it.perm = d.col_perm; it.cmul = d.col_mul > 1 ? d.col_mul : 1;
+            it.ctr0 = ctr; it.slab0 = slab; it.perm = d.col_perm; it.cmul = d.col_mul > 1 ? d.col_mul : 1; it.mstore = d.store_rows > 0 && d.store_rows < d.M ? d.store_rows : d.M; it.taps_wp = d.conv_taps_wp > 0 ? d.conv_taps_wp : 0;
             first += pl.tiles * pl.ksplit;
             if (pl.ksplit > 1) { ctr += pl.tiles; slab += (long)pl.tiles * pl.ksplit; }
         }

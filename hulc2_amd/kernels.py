@@ -587,12 +587,12 @@ def wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc, any_size=False) -> bool:
     return lda % ea == 0 and ldb % eb == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and C.data_ptr() % 4 == 0
 
 
-def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False, col_perm=0, col_mul=1):
+def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum_accumulate=False, defer=False, col_perm=0, col_mul=1, store_rows=0, conv_taps_wp=0):
     """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
     destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
     when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
     if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc, any_size=bool(col_perm) or col_mul > 1):
-        if col_perm or col_mul > 1:
+        if col_perm or col_mul > 1 or store_rows:
             raise _L.HulcKernelError("wgrad: col_perm / col_mul need the grouped kernel (check wgrad_group_ok first)")
         fused = rowsum is not None and gemm_fuses_rowsum(M, False) and A.dtype == torch.float32
         gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, accumulate=accumulate,
@@ -607,7 +607,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     if any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
         wgrad_flush(dev)                    # a second writer of the same destination: keep the order
         q = _wg_pending.setdefault(dev, [])
-    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm), int(col_mul)))
+    q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm), int(col_mul), int(store_rows), int(conv_taps_wp)))
     if not defer:
         wgrad_flush(dev)
     elif dev not in _wg_armed:
@@ -642,7 +642,9 @@ def wgrad_flush(device=None) -> None:
             it.accumulate, it.rowsum_accumulate = int(acc), int(racc)
             it.col_perm = rest[0] if rest else 0
             it.col_mul = rest[1] if len(rest) > 1 else 1
-            flops += 2.0 * M * N * K
+            it.store_rows = rest[2] if len(rest) > 2 else 0
+            it.conv_taps_wp = rest[3] if len(rest) > 3 else 0
+            flops += 2.0 * M * N * K * (9 if (len(rest) > 3 and rest[3]) else 1)
             nbytes += K * M * A.element_size() + K * N * B.element_size() + M * N * 4 * (2 if acc else 1)
         lib = _L.load()
         lib.hulc_wgrad_group_workspace.restype = _c.c_long

@@ -137,7 +137,7 @@ class WgradItem(ctypes.Structure):
         ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int),
         ("a_dtype", ctypes.c_int), ("b_dtype", ctypes.c_int),
         ("accumulate", ctypes.c_int), ("rowsum_accumulate", ctypes.c_int),
-        ("col_perm", ctypes.c_int), ("col_mul", ctypes.c_int),
+        ("col_perm", ctypes.c_int), ("col_mul", ctypes.c_int), ("store_rows", ctypes.c_int), ("conv_taps_wp", ctypes.c_int),
     ]
 
 

@@ -342,6 +342,10 @@ typedef struct hulc_wgrad_item {
                                       * (h, w, c) -> (c, h, w) order of a Linear that follows nn.Flatten on an NHWC map (vision_network_gripper.py:16-17) */
     int col_mul;                     /* > 1 (with col_perm 0): column n of the product is stored at column n * col_mul — one tap of a convolution
                                       * weight kept as OIHW: C points at tap t, col_mul = KH KW */
+    int store_rows;                  /* > 0: only rows m < store_rows of the product (and of rowsum) are stored — A padded with zero columns */
+    int conv_taps_wp;                /* > 0 (with col_mul 9, no rowsum): the item is the nine taps of a 3 x 3 convolution's weight gradient on the padded
+                                      * grid of width conv_taps_wp = W + 2 — tap u = 3 (dy + 1) + (dx + 1) multiplies A with B shifted by dy conv_taps_wp + dx
+                                      * rows and writes C + u; the taps of a tile run side by side and share the cached operands */
 } hulc_wgrad_item;
 long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n);
 int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream);
