@@ -86,39 +86,46 @@ __global__ void grid_bn_relu_fwd_kernel(const uint16_t* __restrict__ y, long ldy
 }
 
 // backward, pass 1: per channel  s1 = sum dY, s2 = sum dY xhat  with dY = dOut where out > 0 (the ReLU), xhat = (y - mean) rstd; a workgroup
-// sums 256 grid rows x 64 channels (lane = channel, 4 waves = row slices), partial rows [block][2][C]
+// sums 256 grid rows x 64 channels: a thread = 8 channels (16-byte loads) of one of 32 row slots, 8 rows each; partial rows [block][2][C]
 __global__ __launch_bounds__(256) void grid_bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dout, long ldd, const uint16_t* __restrict__ out, long ldo,
                                                                       const uint16_t* __restrict__ y, long ldy, const float* __restrict__ bn, int R, int C,
                                                                       float* __restrict__ part) {
-    __shared__ float red[2][4][64];
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + lane;
-    const bool cok = c < C;                                    // (C = 32: half the lanes idle)
-    const float mean = cok ? bn[c] : 0.f, rstd = cok ? bn[C + c] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    __shared__ float red[2][32][64];
+    const int ck = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * 64 + ck * 8;
+    const bool cok = c0 < C;                                     // (C = 32: half the chunks idle)
+    float mean[8], rstd[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mean[e] = cok ? bn[c0 + e] : 0.f; rstd[e] = cok ? bn[C + c0 + e] : 0.f; s1[e] = 0.f; s2[e] = 0.f; }
     const int r0 = blockIdx.x * 256;
     if (cok) {
-        for (int k = sl; k < 256; k += 16) {                   // four rows per trip: twelve independent loads in flight
-            uint16_t vo[4], vd[4], vy[4];
+#pragma unroll 2
+        for (int k = slot; k < 256; k += 32) {
+            const int r = r0 + k, rc = r < R ? r : R - 1;
+            const uint4 vo = *(const uint4*)(out + (long)rc * ldo + c0), vd = *(const uint4*)(dout + (long)rc * ldd + c0), vy = *(const uint4*)(y + (long)rc * ldy + c0);
+            const uint32_t wo[4] = {vo.x, vo.y, vo.z, vo.w}, wd[4] = {vd.x, vd.y, vd.z, vd.w}, wy[4] = {vy.x, vy.y, vy.z, vy.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + k + 4 * q, rc = r < R ? r : R - 1;
-                vo[q] = out[(long)rc * ldo + c]; vd[q] = dout[(long)rc * ldd + c]; vy[q] = y[(long)rc * ldy + c];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool live = r0 + k + 4 * q < R && bf16_bits_to_f32(vo[q]) > 0.f;       // border rows: out == 0
-                const float d = live ? bf16_bits_to_f32(vd[q]) : 0.f;
-                const float xh = (bf16_bits_to_f32(vy[q]) - mean) * rstd;
-                s1 += d; s2 += d * xh;
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t sh = (e & 1) ? 0u : 16u, mk = (e & 1) ? 0xffff0000u : 0xffffffffu;
+                const float ov = __uint_as_float((wo[e >> 1] << sh) & (e & 1 ? mk : 0xffff0000u));
+                const float dv = __uint_as_float((wd[e >> 1] << sh) & (e & 1 ? mk : 0xffff0000u));
+                const float yv = __uint_as_float((wy[e >> 1] << sh) & (e & 1 ? mk : 0xffff0000u));
+                const float d = (r < R && ov > 0.f) ? dv : 0.f;     // border rows: out == 0
+                s1[e] += d; s2[e] += d * (yv - mean[e]) * rstd[e];
             }
         }
     }
-    red[0][sl][lane] = s1; red[1][sl][lane] = s2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][slot][ck * 8 + e] = s1[e]; red[1][slot][ck * 8 + e] = s2[e]; }
     __syncthreads();
-    if (sl == 0 && cok) {
-        part[((long)blockIdx.x * 2) * C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        part[((long)blockIdx.x * 2 + 1) * C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    if (threadIdx.x < 128) {
+        const int h = threadIdx.x >> 6, l = threadIdx.x & 63, c = blockIdx.y * 64 + l;
+        if (c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) t += red[h][w][l];
+            part[((long)blockIdx.x * 2 + h) * C + c] = t;
+        }
     }
 }
 
@@ -203,33 +210,54 @@ __global__ void grid_upcat_fwd_kernel(const uint16_t* __restrict__ x, long xsn, 
 }
 
 // backward of the x branch: dsmall[n, yi, xi, c] = g[n, c] * sum over the s x s block of dX (grid rows, first Cx of ldd channels), written as a
-// grid tensor (N, Hi, Wi) of Cx channels (borders zeroed by a separate fill: this kernel writes interior rows only); dg[n, c] = sum over pixels of
-// x[n, yi, xi, c] * block sum.  Workgroup = (n, 64 channels, pixel tile pt of npt); 4 waves = pixel slices; dg needs npt == 1.
+// grid tensor (N, Hi, Wi) of Cx channels (pixels only: the consumer masks by its own output's border); dg[n, c] = sum over pixels of
+// x[n, yi, xi, c] * block sum.  Workgroup = (n, 64 channels, pixel tile pt of npt); a thread = 8 channels (16-byte loads) of one of 32 pixel
+// slots; dg (needs npt == 1) is reduced over the slots in a fixed order.
 __global__ __launch_bounds__(256) void grid_upcat_bwd_kernel(const uint16_t* __restrict__ dX, long ldd, const uint16_t* __restrict__ x, long xsn, long xsy, long xsx,
                                                              const float* __restrict__ g, int Hi, int Wi, int s, int Cx, uint16_t* __restrict__ dsmall,
                                                              float* __restrict__ dg, int accumulate_dg) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int n = blockIdx.x, c = blockIdx.y * 64 + lane, pt = blockIdx.z, npt = gridDim.z;
+    __shared__ float red[32][64];
+    const int ck = threadIdx.x & 7, slot = threadIdx.x >> 3;                 // 8 chunks x 32 slots
+    const int n = blockIdx.x, c0 = blockIdx.y * 64 + ck * 8, pt = blockIdx.z, npt = gridDim.z;
     const int Ho = Hi * s, Wo = Wi * s, Wpo = Wo + 2, PPo = (Ho + 2) * Wpo, Wpi = Wi + 2, PPi = (Hi + 2) * Wpi;
-    const float gv = g ? g[(long)n * Cx + c] : 1.f;
-    float acc = 0.f;
+    float gv[8], acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gv[e] = g ? g[(long)n * Cx + c0 + e] : 1.f; acc[e] = 0.f; }
     const int npx = Hi * Wi, per = (npx + npt - 1) / npt, p0 = pt * per, p1 = min(p0 + per, npx);
-    for (int px = p0 + sl; px < p1; px += 4) {
+    for (int px = p0 + slot; px < p1; px += 32) {
         const int yi = px / Wi, xi = px - yi * Wi;
-        float bs = 0.f;
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
         for (int a = 0; a < s; ++a)
-            for (int b = 0; b < s; ++b)
-                bs += bf16_bits_to_f32(dX[((long)n * PPo + (long)(yi * s + a + 1) * Wpo + (xi * s + b + 1)) * ldd + c]);
-        if (dsmall) dsmall[((long)n * PPi + (long)(yi + 1) * Wpi + (xi + 1)) * Cx + c] = f32_to_bf16_bits(bs * gv);
-        if (dg) acc += bs * bf16_bits_to_f32(x[(long)n * xsn + (long)yi * xsy + (long)xi * xsx + c]);
+            for (int b = 0; b < s; ++b) {
+                const uint4 v = *(const uint4*)(dX + ((long)n * PPo + (long)(yi * s + a + 1) * Wpo + (xi * s + b + 1)) * ldd + c0);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bs[2 * e] += __uint_as_float(w[e] << 16); bs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+            }
+        if (dsmall) {
+            uint32_t q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = pack_bf16x2(bs[2 * e] * gv[2 * e], bs[2 * e + 1] * gv[2 * e + 1]);
+            *(uint4*)(dsmall + ((long)n * PPi + (long)(yi + 1) * Wpi + (xi + 1)) * Cx + c0) = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+        if (dg) {
+            const uint4 v = *(const uint4*)(x + (long)n * xsn + (long)yi * xsy + (long)xi * xsx + c0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += bs[2 * e] * __uint_as_float(w[e] << 16); acc[2 * e + 1] += bs[2 * e + 1] * __uint_as_float(w[e] & 0xffff0000u); }
+        }
     }
     if (dg) {
-        red[sl][lane] = acc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[slot][ck * 8 + e] = acc[e];
         __syncthreads();
-        if (sl == 0) {
-            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            float* dst = dg + (long)n * Cx + c;
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 32; ++w) t += red[w][threadIdx.x];
+            float* dst = dg + (long)n * Cx + blockIdx.y * 64 + threadIdx.x;
             *dst = accumulate_dg ? *dst + t : t;
         }
     }
