@@ -155,6 +155,7 @@ class PixelAffLangDetector(nn.Module):
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         frame, label = batch
+        kn.Grid.begin_step()                                   # the previous step's activation / gradient grids are free again
         feats = self.trunk_maps(frame["img"])
         depth_key = "normalized_depth" if self.normalize_depth else "depth"
         loss, info = self.forward_losses(feats, frame["lang_goal"], label["p0"], label[depth_key])

@@ -936,14 +936,42 @@ class Grid:
     the zero guards, `t` = rows [guard, guard + R) — the tensor the kernels address.  Every kernel writes all R rows of its output (borders as
     zero), so only the guards are cleared here."""
 
+    _pool = {}            # (device, N, H, W, C) -> [buffers]: guards zeroed once, recycled step after step (Grid.begin_step)
+    _cursor = {}
+    _pooling = False
+
+    @classmethod
+    def begin_step(cls) -> None:
+        """a training step starts: every buffer handed out during the previous step (forward + backward) is free again"""
+        cls._cursor = {}
+        cls._pooling = True
+
+    @classmethod
+    def end_pooling(cls) -> None:
+        cls._pooling = False
+        cls._pool.clear()
+        cls._cursor = {}
+
     def __init__(self, N, H, W, C, device):
         self.N, self.H, self.W, self.C = int(N), int(H), int(W), int(C)
         self.R = self.N * (self.H + 2) * (self.W + 2)
         self.guard = (self.W + 3 + 7) // 8 * 8
         tail = self.guard + 32                                  # + the rows that round R up to a multiple of 32 (weight-gradient K)
-        self.rows = torch.empty(self.guard + self.R + tail, self.C, dtype=torch.bfloat16, device=device)
-        self.rows[:self.guard].zero_()
-        self.rows[self.guard + self.R:].zero_()
+        key = (device, self.N, self.H, self.W, self.C)
+        rows = None
+        if Grid._pooling:
+            i = Grid._cursor.get(key, 0)
+            bufs = Grid._pool.setdefault(key, [])
+            if i < len(bufs):
+                rows = bufs[i]
+            Grid._cursor[key] = i + 1
+        if rows is None:
+            rows = torch.empty(self.guard + self.R + tail, self.C, dtype=torch.bfloat16, device=device)
+            rows[:self.guard].zero_()
+            rows[self.guard + self.R:].zero_()
+            if Grid._pooling and not torch.cuda.is_current_stream_capturing():      # (a graph's private pool dies with the graph)
+                Grid._pool[key].append(rows)
+        self.rows = rows
         self.t = self.rows[self.guard:self.guard + self.R]
 
     @property
