@@ -57,6 +57,13 @@ def _vec_grad(param, like):
     return sink, not gradsink.first_write(param), None
 
 
+def _eval_bn(gamma, beta, run_mean, run_var, eps: float = 1e-5):
+    """the (mean, rstd, scale, shift) table of hulc_grid_bn_relu_fwd from an nn.BatchNorm2d's running statistics (inference mode)"""
+    rstd = torch.rsqrt(run_var + eps)
+    scale = gamma.detach() * rstd
+    return torch.stack([run_mean, rstd, scale, beta.detach() - run_mean * scale]).contiguous()
+
+
 class AffDecoderLossFn(torch.autograd.Function):
     """(p0, out_hw, running-stat buffers, g0, g1, g2, stem, l1, l2, l3, l4, 30 block parameters, head weight, head bias) -> (aff_loss, logits)
 
@@ -65,9 +72,14 @@ class AffDecoderLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p0, out_hw, buffers, g0, g1, g2, f_stem, f1, f2, f3, f4, *params):
+        """buffers: the ten BatchNorms' [running_mean, running_var] * 10 — updated from the batch statistics; ("eval", buffers): inference mode,
+        normalisation BY the running statistics (no update)"""
         if kn.get_compute() != "bf16":
             raise NotImplementedError("the affordance decoder is built for the bf16 compute mode")
         blocks, head_w, head_b = params[:30], params[30], params[31]
+        evalm = isinstance(buffers, tuple) and buffers[0] == "eval"
+        if evalm:
+            buffers = buffers[1]
         N = f4.shape[0]
         dev = f4.device
         gs = (g0, g1, g2)
@@ -84,11 +96,13 @@ class AffDecoderLossFn(torch.autograd.Function):
             g = gs[i].contiguous() if i < 3 else None
             sk, ss = _plain_strides(skip) if skip is not None else (None, None)
             X = kn.grid_upcat_fwd(x_map, x_str, g, sk, ss, N, ho, ho, s, cin, cs)
-            Y1, st = kn.gridconv3x3(X, _fwd_w(w1), cout, want_stats=True)
-            bn1 = kn.grid_bn_finalize(st, N, ho, ho, cout, ga1, be1, *(buffers[4 * i:4 * i + 2] if buffers else (None, None)))
+            Y1, st = kn.gridconv3x3(X, _fwd_w(w1), cout, want_stats=not evalm)
+            bn1 = _eval_bn(ga1, be1, *buffers[4 * i:4 * i + 2]) if evalm else \
+                kn.grid_bn_finalize(st, N, ho, ho, cout, ga1, be1, *(buffers[4 * i:4 * i + 2] if buffers else (None, None)))
             O1 = kn.grid_bn_relu_fwd(Y1, bn1)
-            Y2, st = kn.gridconv3x3(O1, _fwd_w(w2), cout, want_stats=True)
-            bn2 = kn.grid_bn_finalize(st, N, ho, ho, cout, ga2, be2, *(buffers[4 * i + 2:4 * i + 4] if buffers else (None, None)))
+            Y2, st = kn.gridconv3x3(O1, _fwd_w(w2), cout, want_stats=not evalm)
+            bn2 = _eval_bn(ga2, be2, *buffers[4 * i + 2:4 * i + 4]) if evalm else \
+                kn.grid_bn_finalize(st, N, ho, ho, cout, ga2, be2, *(buffers[4 * i + 2:4 * i + 4] if buffers else (None, None)))
             O2 = kn.grid_bn_relu_fwd(Y2, bn2)
             saved.append((X, Y1, bn1, O1, Y2, bn2, O2, x_map, x_str, g, hi, s))
             x_map, sn, sy, sx = O2.pixel_strides()

@@ -145,7 +145,7 @@ class PixelAffLangDetector(nn.Module):
         l_enc = self.text_enc(lang_goal)
         blocks = self.model.aff_stream.decoder.blocks
         gs = [HF.mlp(l_enc, [(blocks[i].lang_proj.weight, blocks[i].lang_proj.bias, False)]) for i in range(3)]        # FusionMult's x2_proj(l)
-        bufs = self.bn_buffers() if self.training else None
+        bufs = self.bn_buffers() if self.training else ("eval", self.bn_buffers())
         aff_loss, logits = AffDecoderLossFn.apply(p0, self.img_size, bufs, *gs, *feats, *self.decoder_params())
         mu, sigma = self.depth(feats[-1], l_enc)
         var = torch.clamp(sigma, min=1e-6)                                                         # nn.GaussianNLLLoss(mu, target, var = sigma), eps 1e-6
@@ -161,6 +161,52 @@ class PixelAffLangDetector(nn.Module):
         loss, info = self.forward_losses(feats, frame["lang_goal"], label["p0"], label[depth_key])
         self.logged = {"Training/total_loss": loss.detach(), "Training/aff_loss": info["aff_loss"].detach(), "Training/depth_loss": info["depth_loss"].detach()}
         return loss
+
+    # ---- inference (AffDepthLangFusionPixel.forward / predict, aff_lang_depth_pixel.py:64-129; PixelAffLangDetector.validation_step :71-93) ----
+    @torch.no_grad()
+    def forward(self, inp: Dict, softmax: bool = True) -> Dict[str, torch.Tensor]:
+        """{"aff": (B, H, W, 1) softmax over the pixels — or the (B, H W) logits —, "depth_dist": (mu, sigma)}; BatchNorm by the running
+        statistics when the module is in eval mode"""
+        B = inp["img"].shape[0]
+        feats = self.trunk_maps(inp["img"])
+        p0 = torch.zeros(B, 2, dtype=torch.int32, device=inp["img"].device)
+        _, info = self.forward_losses(feats, inp["lang_goal"], p0, torch.zeros(B, device=inp["img"].device))
+        aff = info["logits"]
+        if softmax:
+            aff = torch.softmax(aff, -1).reshape(B, self.img_size, self.img_size, 1)
+        return {"aff": aff, "depth_dist": (info["mu"], info["sigma"])}
+
+    @torch.no_grad()
+    def predict_pixels(self, img: torch.Tensor, lang_goal, depth_norm: Tuple[float, float] = (0.0, 1.0), sample: bool = False):
+        """-> (p0 (B, 2) int64 (row, col) of the most likely pixel, depth (B,) in metres, sigma (B,)): the arg-max of the heat map and the mean
+        of the depth distribution (sample=True: one reparametrised draw, as DepthEstimationGaussian.sample), un-normalised by
+        NormalizeVectorInverse(mean, std) (datasets/transforms.py:82-93) when the model predicts normalised depth"""
+        out = self.forward({"img": img, "lang_goal": lang_goal}, softmax=False)
+        idx = out["aff"].argmax(-1)
+        p0 = torch.stack([idx // self.img_size, idx % self.img_size], 1)
+        mu, sigma = out["depth_dist"]
+        d = (mu + sigma * torch.randn_like(mu) if sample else mu).reshape(-1)
+        if self.normalize_depth:
+            mean, std = depth_norm
+            d = d * (std + 1e-10) + mean              # inverse of (x - mean) / std as NormalizeVectorInverse builds it
+        return p0, d, sigma.reshape(-1)
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int = 0, depth_norm: Tuple[float, float] = (0.0, 1.0)) -> Dict[str, torch.Tensor]:
+        """losses as in training plus the two errors the reference logs: summed pixel distance of the arg-max to the label and summed
+        absolute depth error (pixel_aff_lang_detector.py:147-160)"""
+        frame, label = batch
+        feats = self.trunk_maps(frame["img"])
+        depth_key = "normalized_depth" if self.normalize_depth else "depth"
+        loss, info = self.forward_losses(feats, frame["lang_goal"], label["p0"], label[depth_key])
+        idx = info["logits"].argmax(-1)
+        p0 = torch.stack([idx // self.img_size, idx % self.img_size], 1).float()
+        px = (p0 - label["p0"].to(p0.device).float()).norm(dim=1).sum()
+        d = info["mu"].reshape(-1)
+        if self.normalize_depth:
+            d = d * (depth_norm[1] + 1e-10) + depth_norm[0]
+        true_depth = label["depth"] if "depth" in label else label[depth_key]
+        return {"val_loss": loss, "val_attn_dist_err": px, "val_depth_err": (d - true_depth.to(d.device).float()).abs().sum(), "n_imgs": torch.tensor(p0.shape[0])}
 
     def configure_optimizers(self):
         return torch.optim.Adam([p for p in self.parameters() if p.requires_grad], lr=self.lr)      # pixel_aff_lang_detector.py:112-114

@@ -47,8 +47,9 @@ def trainable_shapes(enc_hw: int) -> Dict[str, tuple]:
     return out
 
 
-def conv_bn_relu(x, w, gamma, beta, train: bool, stats=None):
-    """Conv2dReLU = Conv2d(3x3, padding 1, no bias) -> BatchNorm2d -> ReLU (unet_decoder.py:6-28); batch statistics in train mode"""
+def conv_bn_relu(x, w, gamma, beta, train: bool, stats=None, running=None):
+    """Conv2dReLU = Conv2d(3x3, padding 1, no bias) -> BatchNorm2d -> ReLU (unet_decoder.py:6-28); batch statistics in train mode (appended to
+    `stats` as (mean, unbiased variance) for the running-statistics bookkeeping), `running` = (mean, var) in eval mode"""
     y = F.conv2d(x, w, None, padding=1)
     if train:
         mean = y.mean(dim=(0, 2, 3))
@@ -56,12 +57,12 @@ def conv_bn_relu(x, w, gamma, beta, train: bool, stats=None):
         if stats is not None:
             stats.append((mean.detach(), y.var(dim=(0, 2, 3), unbiased=True).detach()))
     else:
-        mean, var = stats
+        mean, var = running
     y = (y - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + 1e-5) * gamma[None, :, None, None] + beta[None, :, None, None]
     return F.relu(y)
 
 
-def decoder_forward(sd: SD, l_enc: torch.Tensor, feats: Sequence[torch.Tensor], out_hw: int, train: bool = True, stats=None) -> torch.Tensor:
+def decoder_forward(sd: SD, l_enc: torch.Tensor, feats: Sequence[torch.Tensor], out_hw: int, train: bool = True, stats=None, running=None) -> torch.Tensor:
     """UnetLangFusionDecoder.forward (unet_decoder.py:131-146) with DecoderBlock.forward (:60-80): blocks 0..2 multiply the incoming map
     by lang_proj(l_enc) per channel (FusionMult + tile_x2, fusion.py:40-47,64-73), every block up-samples (nearest) to its skip's size —
     block 3's skip (the stem map) has the same size, block 4 has no skip and goes to the input resolution — concatenates [x, skip] and runs
@@ -77,8 +78,8 @@ def decoder_forward(sd: SD, l_enc: torch.Tensor, feats: Sequence[torch.Tensor], 
         x = F.interpolate(x, scale_factor=scale, mode="nearest")
         if skip is not None:
             x = torch.cat([x, skip], dim=1)
-        x = conv_bn_relu(x, sd[b + "conv1.0.weight"], sd[b + "conv1.1.weight"], sd[b + "conv1.1.bias"], train, stats)
-        x = conv_bn_relu(x, sd[b + "conv2.0.weight"], sd[b + "conv2.1.weight"], sd[b + "conv2.1.bias"], train, stats)
+        x = conv_bn_relu(x, sd[b + "conv1.0.weight"], sd[b + "conv1.1.weight"], sd[b + "conv1.1.bias"], train, stats, running[2 * i] if running else None)
+        x = conv_bn_relu(x, sd[b + "conv2.0.weight"], sd[b + "conv2.1.weight"], sd[b + "conv2.1.bias"], train, stats, running[2 * i + 1] if running else None)
     return x
 
 
@@ -104,13 +105,14 @@ def gaussian_nll(mu, target, var, eps: float = 1e-6):
 
 
 def training_step(sd: SD, feats: Sequence[torch.Tensor], emb: torch.Tensor, p0: torch.Tensor, gt_depth: torch.Tensor, out_hw: int, train: bool = True,
-                  stats=None) -> Dict[str, torch.Tensor]:
+                  stats=None, running=None) -> Dict[str, torch.Tensor]:
     """PixelAffLangDetector.training_step -> forward(softmax=False) -> criterion (pixel_aff_lang_detector.py:51-69,116-171) for a square
     input (AffDepthLangFusionPixel pads to a square and crops back: no-ops at 224 x 224, aff_lang_depth_pixel.py:17-30,112-115).
-    feats = trunk maps (stem, layer1 .. layer4) NCHW; emb = SBERT sentence embeddings (B, 384); p0 (B, 2) = (row, col) of the labelled pixel."""
+    feats = trunk maps (stem, layer1 .. layer4) NCHW; emb = SBERT sentence embeddings (B, 384); p0 (B, 2) = (row, col) of the labelled pixel.
+    train False + running = [(mean, var)] x 10: the inference forward of AffDepthLangFusionPixel.predict (aff_lang_depth_pixel.py:64-96)."""
     B = emb.shape[0]
     l_enc = F.linear(emb, sd["text_fc.weight"], sd["text_fc.bias"])                      # SBertLang.encode_text (sbert_lang_encoder.py:26-29)
-    dec = decoder_forward(sd, l_enc, feats, out_hw, train, stats)
+    dec = decoder_forward(sd, l_enc, feats, out_hw, train, stats, running)
     aff = F.conv2d(dec, sd["segmentation_head.weight"], sd["segmentation_head.bias"], padding=1)     # r3m_rn18.py:64-69,88
     logits = aff.permute(0, 2, 3, 1).reshape(B, -1)                                     # aff_lang_depth_pixel.py:117-118
     mu, sigma = depth_forward(sd, feats[-1], l_enc)

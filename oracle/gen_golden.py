@@ -595,7 +595,20 @@ def gen_affordance():
     for name in ("decoder.blocks.0.conv1.1.weight", "decoder.blocks.0.conv1.1.bias", "decoder.blocks.3.conv2.1.weight", "decoder.blocks.0.lang_proj.bias",
                  "depth_stream.depth_mu.weight", "depth_stream.fc3.bias", "segmentation_head.bias"):
         out["grad." + name] = net.get_parameter(name).grad.flatten()
+    # inference (eval mode: BatchNorm on the running statistics the step above just updated; AffDepthLangFusionPixel.predict,
+    # aff_lang_depth_pixel.py:64-96): the arg-max pixel and the depth distribution
+    net.eval()
+    with torch.no_grad():
+        l_e = net["text_fc"](emb)
+        lg_e = net["segmentation_head"](net["decoder"](l_e, img, *feats)).permute(0, 2, 3, 1).reshape(B, -1)
+        (_, mu_e, sigma_e), _ = net["depth_stream"](feats[-1], (l_e, None, None))
+    out["eval_logits_sub"], out["eval_argmax"], out["eval_mu"], out["eval_sigma"] = lg_e[:, ::37], lg_e.argmax(-1).to(torch.int32), mu_e, sigma_e
+    out["eval_softmax_max"] = torch.softmax(lg_e, -1).max(-1).values
     sd = net.state_dict()
+    for i in range(5):
+        for c in ("conv1", "conv2"):
+            out[f"run_mean.b{i}{c}"] = sd[f"decoder.blocks.{i}.{c}.1.running_mean"]
+            out[f"run_var.b{i}{c}"] = sd[f"decoder.blocks.{i}.{c}.1.running_var"]
     out["bn_mean.b0c1"] = sd["decoder.blocks.0.conv1.1.running_mean"]
     out["bn_var.b4c2"] = sd["decoder.blocks.4.conv2.1.running_var"]
     save("affordance_step_B2_64", **out)

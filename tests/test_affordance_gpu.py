@@ -96,6 +96,34 @@ def test_training_step_matches_the_reference_fixture():
     print("worst gradient errors:", [(k, round(v, 4)) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]])
 
 
+def test_inference_matches_the_reference_fixture():
+    """eval mode (BatchNorm by the running statistics the reference's step produced): logits, the arg-max pixel, the depth distribution"""
+    dev = _dev()
+    g = dict(np.load(G / "affordance_step_B2_64.npz", allow_pickle=False))
+    B, HW = int(g["B"]), int(g["HW"])
+    m, sd, own = build(HW, int(g["seed"]), dev)
+    blocks = m.model.aff_stream.decoder.blocks
+    with torch.no_grad():
+        for i in range(5):
+            for c in ("conv1", "conv2"):
+                bn = getattr(blocks[i], c)[1]
+                bn.running_mean.copy_(torch.as_tensor(g[f"run_mean.b{i}{c}"]))
+                bn.running_var.copy_(torch.as_tensor(g[f"run_var.b{i}{c}"]))
+    m.eval()
+    feats = [torch.as_tensor(g[f"feat{i}"]).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev) for i in range(5)]
+    with torch.no_grad():
+        _, info = m.forward_losses(feats, torch.as_tensor(g["emb"]).to(dev), torch.as_tensor(g["p0"]).to(dev), torch.as_tensor(g["gt_depth"]).to(dev))
+    torch.cuda.synchronize()
+    lg = info["logits"].float().cpu()
+    assert (lg[:, ::37] - torch.as_tensor(g["eval_logits_sub"])).abs().max().item() <= 3e-2 * np.abs(g["eval_logits_sub"]).max()
+    am = lg.argmax(-1)
+    ref = torch.as_tensor(g["eval_argmax"]).long()
+    for b in range(B):      # bf16 logits: the arg-max may move to a pixel whose reference logit is within the bf16 noise of the maximum
+        assert am[b] == ref[b] or float(lg[b, ref[b]]) >= float(lg[b].max()) - 3e-2 * float(lg[b].abs().max()), (b, int(am[b]), int(ref[b]))
+    assert (info["mu"].cpu() - torch.as_tensor(g["eval_mu"])).abs().max().item() < 2e-2
+    assert rel(torch.softmax(lg, -1).max(-1).values, g["eval_softmax_max"]) < 5e-2
+
+
 def test_training_step_matches_the_oracle_with_sinks_and_trunk():
     """a second shape (B = 3, 96 x 96) end to end through the HIP trunk and the native trainer's gradient arena (deferred grouped weight
     gradients), against the oracle fed with the trunk's own maps"""
@@ -130,3 +158,11 @@ def test_training_step_matches_the_oracle_with_sinks_and_trunk():
     print("gradient errors vs the oracle:", [(k, round(v, 4)) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])])
     for k, e in errs.items():
         assert e <= 0.3, (k, e)
+    # the public inference entry points on the same model: heat map sums to one, arg-max pixel inside the image, validation errors finite
+    m.eval()
+    out = m.forward({"img": img, "lang_goal": emb})
+    assert tuple(out["aff"].shape) == (B, HW, HW, 1) and abs(float(out["aff"].sum()) - B) < 1e-3 * B
+    px, dpt, sig = m.predict_pixels(img, emb, depth_norm=(0.5, 0.1))
+    assert tuple(px.shape) == (B, 2) and int(px.min()) >= 0 and int(px.max()) < HW and torch.isfinite(dpt).all() and (sig > 0).all()
+    val = m.validation_step(({"img": img, "lang_goal": emb}, {"p0": p0.to(dev), "normalized_depth": depth.to(dev), "depth": depth.to(dev) * 0.1 + 0.5}), 0, (0.5, 0.1))
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in val.values())

@@ -478,3 +478,13 @@ def test_affordance_step():
     # BatchNorm2d bookkeeping (momentum 0.1 from mean 0 / var 1, unbiased batch variance)
     close(0.1 * stats[0][0], g["bn_mean.b0c1"], rtol=1e-4, what="running_mean of block 0 conv1")
     close(0.9 + 0.1 * stats[9][1], g["bn_var.b4c2"], rtol=1e-4, what="running_var of block 4 conv2")
+    # inference on the updated running statistics: logits, arg-max pixel, depth distribution
+    running = [(0.1 * m, 0.9 + 0.1 * v) for m, v in stats]
+    for j, (m, v) in enumerate(running):
+        close(m, g[f"run_mean.b{j // 2}conv{j % 2 + 1}"], rtol=1e-4, what=f"running mean {j}")
+        close(v, g[f"run_var.b{j // 2}conv{j % 2 + 1}"], rtol=1e-4, what=f"running var {j}")
+    with torch.no_grad():
+        ev = A.training_step(sd, feats, torch.as_tensor(g["emb"]), torch.as_tensor(g["p0"]), torch.as_tensor(g["gt_depth"]), HW, train=False, running=running)
+    close(ev["logits"][:, ::37], g["eval_logits_sub"], rtol=1e-4, what="eval logits")
+    assert torch.equal(ev["logits"].argmax(-1).to(torch.int32), torch.as_tensor(g["eval_argmax"]))
+    close(ev["mu"], g["eval_mu"], rtol=1e-4, what="eval mu")
