@@ -5,10 +5,22 @@ for the configured cameras: rgb_static + rgb_gripper, proprio/depth/tactile: non
 """
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
 from hulc2_amd.compat import instantiate
+
+
+_side_streams = {}
+
+
+def _encoder_side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 class ConcatEncoders(nn.Module):
@@ -75,11 +87,28 @@ class ConcatEncoders(nn.Module):
         in one pass: rows of the result are modality-major, (sum B, S, latent).  Same arithmetic per frame as `forward`."""
         fr = [self._frames(im, "rgb_static") for im in imgs_list]
         b, s = fr[0][3], fr[0][4]
+        has_gripper = self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list)
+        frg = [self._frames(im, "rgb_gripper") for im in imgs_list] if has_gripper else None
+        run_g = lambda: self.rgb_gripper_encoder([f[0] for f in frg], [f[1] for f in frg], self.aug_pad["rgb_gripper"],
+                                                 [f[2] for f in frg]).reshape(len(frg) * b, s, -1)
+        # The two cameras' encoders are independent chains; the gripper's launches are small (84 x 84 frames: 20 x 20 / 9 x 9 maps, a few hundred
+        # workgroups) and leave most of the chip idle.  On a second stream they fill the tails of the static camera's launches — forward here,
+        # and backward too (autograd runs a node on the stream of its forward).  The streams join before the embedding is used, so the
+        # device-wide-barrier kernels further down (recurrent sweep, MLP chains) still have the GPU to themselves.  HULC_ENC_STREAMS=0: one stream.
+        two = has_gripper and fr[0][0].is_cuda and os.environ.get("HULC_ENC_STREAMS", "1") != "0"
+        if two:
+            cur = torch.cuda.current_stream(fr[0][0].device)
+            side = _encoder_side_stream(fr[0][0].device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g = run_g()
         enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"], [f[2] for f in fr]).reshape(len(fr) * b, s, -1)
-        if self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list):
-            fr = [self._frames(im, "rgb_gripper") for im in imgs_list]
-            enc = torch.cat([enc, self.rgb_gripper_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_gripper"],
-                                                              [f[2] for f in fr]).reshape(len(fr) * b, s, -1)],
-                            dim=-1)
+        if two:
+            cur.wait_stream(side)
+            g.record_stream(cur)
+        elif has_gripper:
+            g = run_g()
+        if has_gripper:
+            enc = torch.cat([enc, g], dim=-1)
         self.current_visual_embedding = enc.detach()
         return enc
