@@ -623,14 +623,51 @@ def wgrad_reset(device) -> None:
     """drop products left behind by a backward pass that raised (start of a trainer step)"""
     _wg_pending.pop(device, None)
     _wg_armed.discard(device)
+    ent = _wg_side.get(device)
+    if ent is not None and len(ent) > 2:
+        torch.cuda.current_stream(device).wait_stream(ent[0])
+        del ent[2:]
+        ent[1].clear()
+
+
+_wg_side = {}           # device -> (side stream, [item lists kept alive until the join])
+
+
+def wgrad_flush_early(device) -> None:
+    """Issue what is pending NOW on a second stream (called from a gradient hook at the perceptual embedding: everything but the camera
+    encoders' layers is queued by then): the grouped launch runs in the gaps of the convolution backward instead of behind it.  The operands
+    stay referenced until wgrad_flush joins the stream at the end of the pass."""
+    import os
+    q = _wg_pending.get(device)
+    if not q or os.environ.get("HULC_WGRAD_EARLY", "0") != "1":     # measured: 4.01 vs 3.73 ms/step — the grouped launch and the convolution
+        return                                                       # backward slow each other down more than the overlap hides; off by default
+    ent = _wg_side.get(device)
+    if ent is None:
+        ent = _wg_side[device] = [torch.cuda.Stream(device=device), []]
+    cur = torch.cuda.current_stream(device)
+    ent[0].wait_stream(cur)
+    ent[1].append(list(q))
+    with torch.cuda.stream(ent[0]):
+        _wgrad_issue(device)
+    ent.append("joined-pending")
 
 
 def wgrad_flush(device=None) -> None:
-    """issue the pending weight-gradient products (all devices when device is None)"""
-    for dev in ([device] if device is not None else list(_wg_pending)):
+    """issue the pending weight-gradient products (all devices when device is None) and join an early flush's stream"""
+    for dev in ([device] if device is not None else list(set(_wg_pending) | set(_wg_side))):
+        ent = _wg_side.get(dev)
+        if ent is not None and len(ent) > 2:
+            torch.cuda.current_stream(dev).wait_stream(ent[0])
+            del ent[2:]
+            ent[1].clear()
+        _wgrad_issue(dev)
+
+
+def _wgrad_issue(dev) -> None:
+    if True:
         q = _wg_pending.pop(dev, None)
         if not q:
-            continue
+            return
         n = len(q)
         items = (_L.WgradItem * n)()
         flops = nbytes = 0.0

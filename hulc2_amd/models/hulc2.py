@@ -113,6 +113,10 @@ class Hulc2(LightningModule):
         mods = list(batch.items())
         if self._batchable(mods):
             emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
+            if emb_all.requires_grad and emb_all.is_cuda:
+                # when backward reaches the embedding every weight gradient outside the camera encoders is queued: HULC_WGRAD_EARLY=1 issues the
+                # grouped launch on a second stream at that point (kernels.wgrad_flush_early; measured slower, off by default)
+                emb_all.register_hook(lambda g_: kn.wgrad_flush_early(g_.device))
             B = mods[0][1]["actions"].shape[0]
             # the embedding's four consumers get their views from one fan-out node (one gather launch forward, ONE merge launch backward
             # instead of autograd's select / slice backward fills and three accumulate adds): emb[:, 0] -> prior, emb[:B, -1] of a leading
