@@ -570,7 +570,7 @@ HULC_DEVICE float gemm_epilogue(const GemmP& p, float acc, int m, int n) {
 }
 
 template <typename CT, int TM, bool AK, bool BK, int NW, int ADT, int BDT>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw) {
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __restrict__ slabs, int splitk, int kw, unsigned* __restrict__ tile_ctr) {
     __shared__ float red[NW][TM][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -622,25 +622,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, float* __
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][i][row][col];
         if (splitk == 1) store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
-        else slabs[((long)blockIdx.y * p.M + m) * p.N + n] = v;
+        else __hip_atomic_store(slabs + ((long)blockIdx.y * p.M + m) * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmP p, const float* __restrict__ slabs, int splitk) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p.rowsum && i < p.M) {                                   // fused bias gradient: row-sum slabs follow the C slabs
-        const float* rsl = slabs + (long)splitk * p.M * p.N;
+    if (splitk == 1) return;
+    // split K over workgroups: the LAST workgroup to arrive at this column strip's counter sums the slabs in slice order and runs the epilogue
+    // (the protocol of gemm_kernel / wgrad_group: agent-scope slab accesses, self-resetting counter) — no second launch
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* c = tile_ctr + blockIdx.x;
+        const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(splitk - 1);
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int idx = tid; idx < TM * 1024; idx += NW * 64) {
+        const int i = idx >> 10, row = (idx >> 5) & 31, col = idx & 31;
+        const int m = i * 32 + row, n = n0 + col;
+        if (m >= p.M || n >= p.N) continue;
         float v = 0.f;
-        for (int s = 0; s < splitk; ++s) v += rsl[(long)s * p.M + i];
-        p.rowsum[i] = p.rowsum_accumulate ? p.rowsum[i] + v : v;
+        for (int sl = 0; sl < splitk; ++sl) v += __hip_atomic_load(slabs + ((long)sl * p.M + m) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
     }
-    if (i >= (long)p.M * p.N) return;
-    const int m = (int)(i / p.N), n = (int)(i % p.N);
-    float v = 0.f;
-    for (int s = 0; s < splitk; ++s) v += slabs[(long)s * p.M * p.N + i];
-    store_elem(p.C, p.c_dtype, (long)m * p.ldc + n, gemm_epilogue(p, v, m, n));
 }
-
 
 // K slices: waves first (up to 16 per workgroup: combined through LDS in the same launch, epilogue fused),
 // then workgroups (fp32 slabs + epilogue kernel) until ~256 workgroups exist; every wave keeps >= 64 k.
@@ -657,14 +664,15 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     const int min_kw = 64;   // measured (tools/rnn_bench.py): more, shorter K slices win even with the extra epilogue launch
     while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= min_kw) splitk *= 2;
     if (force) splitk = atoi(force);
-    ws = ws ? ws + HULC_GEMM_CTR_BYTES / 4 : ws;                 // (the head of the workspace holds the tiled kernel's counters)
+    unsigned* ctr = (unsigned*)ws;                               // the head of the workspace: tile counters (zero between launches)
+    ws = ws ? ws + HULC_GEMM_CTR_BYTES / 4 : ws;
     ws_bytes = ws_bytes > HULC_GEMM_CTR_BYTES ? ws_bytes - HULC_GEMM_CTR_BYTES : 0;
-    while (splitk > 1 && (long)splitk * p.M * p.N * 4 > ws_bytes) splitk /= 2;
+    while (splitk > 1 && ((long)splitk * p.M * p.N * 4 > ws_bytes || (long)colblocks * 4 > HULC_GEMM_CTR_BYTES)) splitk /= 2;
     int kw = (p.K + splitk * nw - 1) / (splitk * nw);
     kw = (kw + 15) / 16 * 16;
     dim3 grid(colblocks, splitk);
     // operand layouts and storage types are template parameters (no run-time branch around a load, see load_operand_chunk_raw)
-#define HULC_SK_DT(TMv, AKv, BKv, NWv, ADTv, BDTv) gemm_skinny_kernel<CT, TMv, AKv, BKv, NWv, ADTv, BDTv><<<grid, NWv * 64, 0, s>>>(p, ws, splitk, kw)
+#define HULC_SK_DT(TMv, AKv, BKv, NWv, ADTv, BDTv) gemm_skinny_kernel<CT, TMv, AKv, BKv, NWv, ADTv, BDTv><<<grid, NWv * 64, 0, s>>>(p, ws, splitk, kw, ctr)
 #define HULC_SK(TMv, AKv, BKv, NWv)                                                                         \
     do {                                                                                                    \
         if (sizeof(CT) == 4 || (p.a_dtype == HULC_F32 && p.b_dtype == HULC_F32)) HULC_SK_DT(TMv, AKv, BKv, NWv, HULC_F32, HULC_F32); \
@@ -687,10 +695,7 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     }
 #undef HULC_SK_DT
 #undef HULC_SK
-    if (splitk > 1) {
-        const long n = (long)p.M * p.N;
-        gemm_splitk_epilogue_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, ws, splitk);
-    }
+    // (split K: summed and finished by the last workgroup of each column strip, inside the launch)
 }
 
 template <typename CT, int TM, int TN, int WM, int WN>
