@@ -43,15 +43,43 @@ HULC_DEVICE void sum_partials_2x(const float* part, int nb, int C, int c, bool c
 }
 
 // BatchNorm2d, training mode: partial sums (sum y, sum y^2 over the interior rows; gridconv's epilogue) -> bn[0..3][C] = mean, rstd,
-// scale = gamma rstd, shift = beta - mean scale; running statistics updated with momentum 0.1 and the unbiased variance (nn.BatchNorm2d)
+// scale = gamma rstd, shift = beta - mean scale; running statistics updated with momentum 0.1 and the unbiased variance (nn.BatchNorm2d).
+// grid = (channel groups of 64, G row groups): every workgroup sums its share of the partial rows (16 slices x 64 channels, fixed order) into
+// mid[g][2][C]; the LAST one to arrive at the channel group's counter adds the G results in order and finalises (G = 1: directly).  A single
+// workgroup per channel group took 40-80 us on the 12 700 partial rows of a 224 x 224 layer.
 __global__ __launch_bounds__(1024) void grid_bn_finalize_kernel(const float* __restrict__ part, int nb, int C, float count, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, float momentum, float* __restrict__ bn,
-                                                                float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ mid,
+                                                                unsigned* __restrict__ ctr) {
     __shared__ float red[2][16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane, G = gridDim.y, g = blockIdx.y;
     const bool cok = c < C;
+    const int per = (nb + G - 1) / G, b0 = g * per, b1 = min(b0 + per, nb);
     float s1, s2;
-    sum_partials_2x(part, nb, C, c, cok, red, s1, s2);
+    sum_partials_2x(part + (long)b0 * 2 * C, b1 > b0 ? b1 - b0 : 0, C, c, cok, red, s1, s2);
+    if (G > 1) {
+        if (threadIdx.x < 64 && cok) {
+            __hip_atomic_store(mid + ((long)g * 2) * C + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mid + ((long)g * 2 + 1) * C + c, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(G - 1);
+            if (last) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        s1 = s2 = 0.f;
+        if (threadIdx.x < 64 && cok)
+            for (int q = 0; q < G; ++q) {
+                s1 += __hip_atomic_load(mid + ((long)q * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(mid + ((long)q * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
     if (threadIdx.x >= 64 || !cok) return;
     const float mean = s1 / count;
     float var = s2 / count - mean * mean;
@@ -129,14 +157,39 @@ __global__ __launch_bounds__(256) void grid_bn_relu_bwd_reduce_kernel(const uint
     }
 }
 
-// the two sums, once: sums[0][C] = s1 (= dbeta), sums[1][C] = s2 (= dgamma), also written / accumulated into the parameter gradients
+// the two sums, once: sums[0][C] = s1 (= dbeta), sums[1][C] = s2 (= dgamma), also written / accumulated into the parameter gradients;
+// spread over G row groups with a last-arriver like grid_bn_finalize_kernel
 __global__ __launch_bounds__(1024) void grid_bn_bwd_sums_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ sums, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int accumulate) {
+                                                                float* __restrict__ dbeta, int accumulate, float* __restrict__ mid, unsigned* __restrict__ ctr) {
     __shared__ float red[2][16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane, G = gridDim.y, g = blockIdx.y;
     const bool cok = c < C;
+    const int per = (nb + G - 1) / G, b0 = g * per, b1 = min(b0 + per, nb);
     float s1, s2;
-    sum_partials_2x(part, nb, C, c, cok, red, s1, s2);
+    sum_partials_2x(part + (long)b0 * 2 * C, b1 > b0 ? b1 - b0 : 0, C, c, cok, red, s1, s2);
+    if (G > 1) {
+        if (threadIdx.x < 64 && cok) {
+            __hip_atomic_store(mid + ((long)g * 2) * C + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mid + ((long)g * 2 + 1) * C + c, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(G - 1);
+            if (last) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        s1 = s2 = 0.f;
+        if (threadIdx.x < 64 && cok)
+            for (int q = 0; q < G; ++q) {
+                s1 += __hip_atomic_load(mid + ((long)q * 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(mid + ((long)q * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
     if (threadIdx.x >= 64 || !cok) return;
     sums[c] = s1; sums[C + c] = s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
@@ -316,9 +369,12 @@ __global__ void pixel_ce_bwd_kernel(const float* __restrict__ logit0, const int*
 
 // ---- C ABI (include/hulc2_amd.h) ---------------------------------------------------------------------------------------------------------
 extern "C" int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum,
-                                     float* bn, float* run_mean, float* run_var, void* stream) {
+                                     float* bn, float* run_mean, float* run_var, float* mid, unsigned* counters, void* stream) {
     if (!part || !gamma || !beta || !bn || C <= 0 || nb <= 0 || count < 2) return hulc_fail(-1, "hulc_grid_bn_finalize: bad argument");
-    grid_bn_finalize_kernel<<<(C + 63) / 64, 1024, 0, (hipStream_t)stream>>>(part, nb, C, (float)count, gamma, beta, eps, momentum, bn, run_mean, run_var);
+    int G = 1;
+    if (mid && counters) { while (G < 32 && nb / (G * 2) >= 64) G *= 2; }      // >= 64 partial rows per row group
+    grid_bn_finalize_kernel<<<dim3((C + 63) / 64, G), 1024, 0, (hipStream_t)stream>>>(part, nb, C, (float)count, gamma, beta, eps, momentum, bn, run_mean, run_var,
+                                                                                      mid, counters);
     return hulc_check_launch("hulc_grid_bn_finalize");
 }
 
@@ -331,19 +387,22 @@ extern "C" int hulc_grid_bn_relu_fwd(const void* y, long ldy, const float* bn, i
 
 extern "C" long hulc_grid_bn_bwd_workspace(int N, int H, int W, int C) {
     const long R = (long)N * (H + 2) * (W + 2);
-    return (((R + 255) / 256) * 2 * C + 2 * C) * (long)sizeof(float);
+    return (((R + 255) / 256) * 2 * C + 2 * C + 64 * C) * (long)sizeof(float);      // partial rows, the two sums, the row groups' intermediate sums
 }
 
 extern "C" int hulc_grid_bn_relu_bwd(const void* dout, long ldd, const void* out, long ldo, const void* y, long ldy, const float* bn, int N, int H, int W,
-                                     int C, void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream) {
+                                     int C, void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, unsigned* counters, void* stream) {
     if (!dout || !out || !y || !bn || !dz || !ws || C % 8) return hulc_fail(-1, "hulc_grid_bn_relu_bwd: bad argument (C must be a multiple of 8)");
     const long R = (long)N * (H + 2) * (W + 2);
     const int nb = (int)((R + 255) / 256);
     float* part = (float*)ws;
     float* sums = part + (long)nb * 2 * C;
+    float* mid = sums + 2 * C;
+    int G = 1;
+    if (counters) { while (G < 32 && nb / (G * 2) >= 64) G *= 2; }
     hipStream_t s = (hipStream_t)stream;
     grid_bn_relu_bwd_reduce_kernel<<<dim3(nb, (C + 63) / 64), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, (int)R, C, part);
-    grid_bn_bwd_sums_kernel<<<(C + 63) / 64, 1024, 0, s>>>(part, nb, C, sums, dgamma, dbeta, accumulate_params);
+    grid_bn_bwd_sums_kernel<<<dim3((C + 63) / 64, G), 1024, 0, s>>>(part, nb, C, sums, dgamma, dbeta, accumulate_params, mid, counters);
     const long n = R * (C / 8);
     grid_bn_relu_bwd_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint16_t*)dout, ldd, (const uint16_t*)out, ldo, (const uint16_t*)y, ldy, bn, sums,
                                                                              1.0f / ((float)N * H * W), (int)R, H, W, C, (uint16_t*)dz, ldz);

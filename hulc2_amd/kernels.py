@@ -1042,11 +1042,24 @@ def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None
     return y, stats
 
 
+_bn_ctr = {}
+
+
+def _bn_counters(device):
+    """self-resetting arrival counters of the BatchNorm reductions, one set per (device, stream)"""
+    key = (device, _stream())
+    ctr = _bn_ctr.get(key)
+    if ctr is None:
+        ctr = _bn_ctr[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return ctr
+
+
 def grid_bn_finalize(stats, N, H, W, C, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
-    bn = torch.empty(4, C, dtype=torch.float32, device=stats.device)
+    bn = torch.empty(4 + 64, C, dtype=torch.float32, device=stats.device)          # the table, then the row groups' intermediate sums
     nb = (N * (H + 2) * (W + 2) + 127) // 128
-    _call("hulc_grid_bn_finalize", stats, _i(nb), _i(C), _l(N * H * W), gamma, beta, _f(eps), _f(momentum), bn, run_mean, run_var)
-    return bn
+    ctr = _bn_counters(stats.device)
+    _call("hulc_grid_bn_finalize", stats, _i(nb), _i(C), _l(N * H * W), gamma, beta, _f(eps), _f(momentum), bn, run_mean, run_var, bn[4:], ctr)
+    return bn[:4]
 
 
 def grid_bn_relu_fwd(y: Grid, bn) -> Grid:
@@ -1061,7 +1074,7 @@ def grid_bn_relu_bwd(dout: Grid, out: Grid, y: Grid, bn, dgamma, dbeta, accumula
     lib.hulc_grid_bn_bwd_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_grid_bn_bwd_workspace(_i(y.N), _i(y.H), _i(y.W), _i(y.C)), y.rows.device)
     _call("hulc_grid_bn_relu_bwd", dout.t, _l(dout.C), out.t, _l(out.C), y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), dz.t, _l(dz.C), dgamma, dbeta,
-          _i(accumulate), ws, nbytes=float(y.R) * y.C * 14)
+          _i(accumulate), ws, _bn_counters(y.rows.device), nbytes=float(y.R) * y.C * 14)
     return dz
 
 

@@ -363,9 +363,12 @@ int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_byte
  *   rows of y forced to zero; stats (optional, hulc_gridconv_stats_bytes): per row-tile partial sums of y and y^2 over the pixels from the fp32
  *   accumulators; out0 (optional): fp32 [rows] = channel 0 + bias0[0] (the one-channel head; y may then be NULL).
  * hulc_grid_bn_finalize: nn.BatchNorm2d in training mode from those partials (nb = row tiles, count = N H W): bn[4][C] = mean, rstd,
- *   scale = gamma rstd, shift = beta - mean scale; running statistics updated (momentum, unbiased variance) when given.
+ *   scale = gamma rstd, shift = beta - mean scale; running statistics updated (momentum, unbiased variance) when given.  mid (32 x 2 x C floats)
+ *   + counters (C / 64 words, zero before the first use, left zero): the sum is spread over up to 32 workgroups per 64 channels, the last to
+ *   arrive finalises (both NULL: one workgroup per 64 channels).
  * hulc_grid_bn_relu_fwd: out = relu(y scale + shift) on the pixels, zero on the border.   hulc_grid_bn_relu_bwd: dz = BatchNorm backward of
- *   (dout masked by out > 0) on the pixels, zero on the border; dgamma / dbeta (+)=; ws: hulc_grid_bn_bwd_workspace bytes.
+ *   (dout masked by out > 0) on the pixels, zero on the border; dgamma / dbeta (+)=; ws: hulc_grid_bn_bwd_workspace bytes; counters as in
+ *   hulc_grid_bn_finalize (or NULL).
  * hulc_grid_upcat_fwd: DecoderBlock's input (unet_decoder.py:60-80): out grid (N, Ho, Wo) rows of Cx + Cs = [nearest-up-sampled x * g | skip];
  *   x (N, Ho/s, Wo/s, Cx) and skip (N, Ho, Wo, Cs) bf16 with element strides (n, y, x) — a grid tensor's pixels or a plain NHWC map; g (N, Cx)
  *   fp32 or NULL = lang_proj(l) of FusionMult (core/fusion.py:64-73).   hulc_grid_upcat_bwd: dsmall (grid (N, Hi, Wi) rows of Cx, pixels only)
@@ -376,11 +379,11 @@ long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout);
 int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps, float* stats,
                      float* out0, const float* bias0, void* stream);
 int hulc_grid_bn_finalize(const float* part, int nb, int C, long count, const float* gamma, const float* beta, float eps, float momentum, float* bn,
-                          float* run_mean, float* run_var, void* stream);
+                          float* run_mean, float* run_var, float* mid, unsigned* counters, void* stream);
 int hulc_grid_bn_relu_fwd(const void* y, long ldy, const float* bn, int N, int H, int W, int C, void* out, long ldo, void* stream);
 long hulc_grid_bn_bwd_workspace(int N, int H, int W, int C);
 int hulc_grid_bn_relu_bwd(const void* dout, long ldd, const void* out, long ldo, const void* y, long ldy, const float* bn, int N, int H, int W, int C,
-                          void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream);
+                          void* dz, long ldz, float* dgamma, float* dbeta, int accumulate_params, void* ws, unsigned* counters, void* stream);
 int hulc_grid_upcat_fwd(const void* x, long xsn, long xsy, long xsx, const float* g, const void* skip, long ssn, long ssy, long ssx, int N, int Ho, int Wo,
                         int s, int Cx, int Cs, void* out, void* stream);
 int hulc_grid_upcat_bwd(const void* dX, long ldd, const void* x, long xsn, long xsy, long xsx, const float* g, int N, int Hi, int Wi, int s, int Cx,
