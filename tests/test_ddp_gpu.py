@@ -106,6 +106,17 @@ def test_bench_gpus_flag_starts_two_ranks():
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]        # finite
 
 
+def test_affordance_bench_runs_on_two_ranks():
+    """BASELINE configs[4] is a DDP run: `bench.py --affordance --gpus 2` (gloo transport, both ranks on this box's one GPU) — the same data
+    parallel trainer, per-rank BatchNorm statistics as in the reference (no sync_batchnorm in conf/affordance/train_affordance.yaml)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    line = _bench(["--affordance", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-secondary"],
+                  {"HULC_BENCH_BACKEND": "gloo", "HULC_NO_RNN_WAVEFRONT": "1", "HULC_NO_MLP_CHAIN": "1"})
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["unit"] == "images/s" and line["value"] > 0
+    assert line["config"]["final_loss"] == line["config"]["final_loss"]
+
+
 @pytest.mark.parametrize("algo,payload,graph", [("ring", "fp32", True), ("ring", "fp32", False), ("direct", "bf16", True), ("direct", "fp32", False)])
 def test_rccl_path_executes_single_rank(algo, payload, graph):
     """The RCCL code path on real hardware: process group "nccl" (device_id bound), the comm-stream collectives between the split training
