@@ -17,6 +17,7 @@
 // order by hulc_grid_bn_finalize), optional fp32 copy of channel 0 + bias (the one-channel segmentation head).
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,11 +33,32 @@ struct GcP {
     int flip;                       // k-block t reads the rows of tap 8 - t: the data gradient on UNflipped weights [ci][t][co]
 };
 
-template <int WN, int TN>
+// one k-step of KCH x 32 channels for a wave's TM x TN accumulators; operand rows RS bytes apart (KCH = 1: 80, KCH = 2: 144 — both keep the 16
+// lanes of a ds_read_b128 group on distinct banks)
+template <int TM, int TN, int KCH, int RS>
+HULC_DEVICE void gc_mma(const char* a_rows, const char* b_rows, f32x16_t (&acc)[TM][TN], int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 2 * KCH; ++ks) {
+        bf16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8_t*)(a_rows + (i * 32 + r) * RS + (ks * 2 + h) * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8_t*)(b_rows + (j * 32 + r) * RS + (ks * 2 + h) * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int WN, int TN, int KCH>
 __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     constexpr int WM = 4 / WN, TM = GC_BM / (WM * 32), BN = WN * TN * 32;
-    constexpr int B_PER = (BN * 4 + 255) / 256;                    // 16-byte chunks of the B tile per thread
-    __shared__ __attribute__((aligned(16))) char smem[2 * (GC_BM + BN) * HULC_ROWB];
+    constexpr int RS = KCH * 64 + 16, CPR = KCH * 4;               // LDS row stride, 16-byte chunks per row of a k-step
+    constexpr int A_PER = GC_BM * CPR / 256, B_PER = (BN * CPR + 255) / 256;      // chunks per thread
+    constexpr int RPP = 256 / CPR;                                 // rows covered by one pass of the 256 threads
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [stage][A tile | B tile]
     __shared__ float sred[2][WM][BN];
     __shared__ unsigned char rowok[GC_BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,32 +77,31 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int kpt = p.Cin / 32, nk = 9 * kpt;                      // k-steps per tap, in all
-    // this thread's chunks: A rows (tid >> 2) and (tid >> 2) + 64, chunk tid & 3; B rows likewise
-    const int ch = tid & 3;
-    int ar[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { const int r = r0 + (tid >> 2) + q * 64; ar[q] = r < p.R ? r : p.R - 1; }
-    uint4 ra0, ra1, rb0, rb1;
-    rb0 = rb1 = make_uint4(0u, 0u, 0u, 0u);
+    const int kpt = p.Cin / (32 * KCH), nk = 9 * kpt;              // k-steps per tap, in all
+    // this thread's chunks: rows (tid / CPR) + q RPP, chunk tid % CPR — the same pattern for the A and the B tile
+    const int ch = tid % CPR, rw = tid / CPR;
+    // staging registers are NAMED values in straight-line code (arrays of them end up in scratch memory: DESIGN.md rule 6); the unused ones of a
+    // configuration are compile-time dead
+    const int ar0 = min(r0 + rw, p.R - 1), ar1 = min(r0 + rw + RPP, p.R - 1), ar2 = min(r0 + rw + 2 * RPP, p.R - 1), ar3 = min(r0 + rw + 3 * RPP, p.R - 1);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
     auto tap_off = [&](int t) { const int u = p.flip ? 8 - t : t; return (u / 3 - 1) * Wp + (u % 3 - 1); };
+    constexpr bool BFULL = BN * CPR % 256 == 0;                    // every thread holds B chunks in every pass
+#define GC_LA(q) if (q < A_PER) ra##q = *(const uint4*)(p.X + (long)(ar##q + off_) * p.ldx + c0_);
+#define GC_LB(q) if (q < B_PER && (BFULL || rw + q * RPP < BN)) rb##q = *(const uint4*)(p.Wt + (long)(n0 + rw + q * RPP) * p.ldw + kb_);
 #define GC_LOAD(ks_)                                                                                                   \
     {                                                                                                                  \
-        const int t_ = (ks_) / kpt, c0_ = ((ks_) - t_ * kpt) * 32 + ch * 8, off_ = tap_off(t_);                        \
-        ra0 = *(const uint4*)(p.X + (long)(ar[0] + off_) * p.ldx + c0_);                                               \
-        ra1 = *(const uint4*)(p.X + (long)(ar[1] + off_) * p.ldx + c0_);                                               \
+        const int t_ = (ks_) / kpt, c0_ = ((ks_) - t_ * kpt) * 32 * KCH + ch * 8, off_ = tap_off(t_);                  \
         const long kb_ = (long)t_ * p.Cin + c0_;                                                                       \
-        if (B_PER == 2 || tid < BN * 4) rb0 = *(const uint4*)(p.Wt + (long)(n0 + (tid >> 2)) * p.ldw + kb_);           \
-        if (B_PER == 2) rb1 = *(const uint4*)(p.Wt + (long)(n0 + (tid >> 2) + 64) * p.ldw + kb_);                      \
+        GC_LA(0) GC_LA(1) GC_LA(2) GC_LA(3) GC_LB(0) GC_LB(1) GC_LB(2) GC_LB(3)                                        \
     }
+#define GC_SA(q) if (q < A_PER) *(uint4*)(As_ + (rw + q * RPP) * RS + ch * 16) = ra##q;
+#define GC_SB(q) if (q < B_PER && (BFULL || rw + q * RPP < BN)) *(uint4*)(Bs_ + (rw + q * RPP) * RS + ch * 16) = rb##q;
 #define GC_STORE(stage_)                                                                                               \
     {                                                                                                                  \
-        char* As_ = smem + (stage_) * (GC_BM + BN) * HULC_ROWB;                                                        \
-        char* Bs_ = As_ + GC_BM * HULC_ROWB;                                                                           \
-        *(uint4*)(As_ + (tid >> 2) * HULC_ROWB + ch * 16) = ra0;                                                       \
-        *(uint4*)(As_ + ((tid >> 2) + 64) * HULC_ROWB + ch * 16) = ra1;                                                \
-        if (B_PER == 2 || tid < BN * 4) *(uint4*)(Bs_ + (tid >> 2) * HULC_ROWB + ch * 16) = rb0;                       \
-        if (B_PER == 2) *(uint4*)(Bs_ + ((tid >> 2) + 64) * HULC_ROWB + ch * 16) = rb1;                                \
+        char* As_ = smem + (stage_) * (GC_BM + BN) * RS;                                                               \
+        char* Bs_ = As_ + GC_BM * RS;                                                                                  \
+        GC_SA(0) GC_SA(1) GC_SA(2) GC_SA(3) GC_SB(0) GC_SB(1) GC_SB(2) GC_SB(3)                                        \
     }
     GC_LOAD(0)
     GC_STORE(0)
@@ -90,15 +111,19 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
         const int nx = ks + 1 < nk ? ks + 1 : ks;                  // last trip reloads its own tile into the other stage: nobody reads it
         GC_LOAD(nx)
         __builtin_amdgcn_sched_barrier(0);
-        const char* As = smem + cur * (GC_BM + BN) * HULC_ROWB;
-        const char* Bs = As + GC_BM * HULC_ROWB;
-        mma_tile_bf16<TM, TN>(As + wm * TM * 32 * HULC_ROWB, Bs + wn * TN * 32 * HULC_ROWB, acc, lane);
+        const char* As = smem + cur * (GC_BM + BN) * RS;
+        const char* Bs = As + GC_BM * RS;
+        gc_mma<TM, TN, KCH, RS>(As + wm * TM * 32 * RS, Bs + wn * TN * 32 * RS, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         GC_STORE(cur ^ 1)
         __syncthreads();
     }
 #undef GC_LOAD
 #undef GC_STORE
+#undef GC_LA
+#undef GC_LB
+#undef GC_SA
+#undef GC_SB
     // ---- epilogue
     float s1[TN], s2[TN];
 #pragma unroll
@@ -158,8 +183,24 @@ extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y
     p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.flip = flip_taps ? 1 : 0;
     const unsigned gx = (unsigned)((R + GC_BM - 1) / GC_BM);
     hipStream_t s = (hipStream_t)stream;
-    if (Cout % 128 == 0) gridconv_kernel<2, 2><<<dim3(gx, Cout / 128), 256, 0, s>>>(p);
-    else if (Cout % 64 == 0) gridconv_kernel<1, 2><<<dim3(gx, Cout / 64), 256, 0, s>>>(p);
-    else gridconv_kernel<1, 1><<<dim3(gx, Cout / 32), 256, 0, s>>>(p);
+    // k-steps of 64 channels (half the barriers per MFMA) where the channel count allows and the layer is not a thin HBM-bound one
+    static const int k64 = getenv("HULC_GRIDCONV_K64") ? atoi(getenv("HULC_GRIDCONV_K64")) : 1;
+    const bool wide = k64 && Cin % 64 == 0 && Cin >= 128;
+#define GC_LAUNCH(WNv, TNv, KCHv, BNv)                                                                                 \
+    {                                                                                                                  \
+        auto kern = gridconv_kernel<WNv, TNv, KCHv>;                                                                   \
+        const size_t lds = (size_t)2 * (GC_BM + BNv) * (KCHv * 64 + 16);                                               \
+        static bool attr = false;                                                                                      \
+        if (!attr && lds > 48 * 1024) {                                                                                \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)    \
+                return hulc_fail(-8, "hulc_gridconv3x3: could not raise the dynamic LDS limit");                       \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        kern<<<dim3(gx, Cout / BNv), 256, lds, s>>>(p);                                                                \
+    }
+    if (Cout % 128 == 0) { if (wide) GC_LAUNCH(2, 2, 2, 128) else GC_LAUNCH(2, 2, 1, 128) }
+    else if (Cout % 64 == 0) { if (wide) GC_LAUNCH(1, 2, 2, 64) else GC_LAUNCH(1, 2, 1, 64) }
+    else { if (wide) GC_LAUNCH(1, 1, 2, 32) else GC_LAUNCH(1, 1, 1, 32) }
+#undef GC_LAUNCH
     return hulc_check_launch("hulc_gridconv3x3");
 }
