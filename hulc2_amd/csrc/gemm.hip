@@ -757,6 +757,7 @@ void launch_ct(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hipStre
 }  // namespace
 
 int hulc_gemm_tn128_try(const hulc_gemm_desc* d, hipStream_t s);   // gemm_tn128.hip
+int hulc_gemm_nt128_try(const hulc_gemm_desc* d, hipStream_t s);   // gemm_nt128.hip
 
 extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return hulc_fail(-1, "hulc_gemm: null operand");
@@ -781,6 +782,11 @@ extern "C" int hulc_gemm(const hulc_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!getenv("HULC_NO_GEMM_TN128")) {          // large row-major x row-major bf16 products (the recurrent weight gradients): 128-deep k-steps
         const int took = hulc_gemm_tn128_try(d, s);
+        if (took < 0) return took;
+        if (took) return hulc_check_launch("hulc_gemm");
+    }
+    {                                             // large k-major x k-major bf16 products: 128 x 128 tiles, 64-deep k-steps, ds_read_b128 operands
+        const int took = hulc_gemm_nt128_try(d, s);
         if (took < 0) return took;
         if (took) return hulc_check_launch("hulc_gemm");
     }

@@ -244,3 +244,37 @@ def test_gemm_tn128_strided_views_and_accumulate(dev, M, N, K, accumulate):
     finally:
         del os.environ["HULC_NO_GEMM_TN128"]
     assert (C - C2).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,accumulate", [(512, 640, 1024, False), (2048, 2048, 2048, True), (768, 512, 576, False)])
+def test_gemm_nt128_strided_views_and_accumulate(dev, M, N, K, accumulate):
+    """the k-major x k-major 128 x 128 kernel (csrc/gemm_nt128.hip) on what the recurrent decoder's transposed mirrors look like: row slices
+    of wider bf16 buffers (lda / ldb beyond K, a column offset), output overwritten or accumulated, fused bias gradient (row sums of A); an
+    asymmetric product; identical to the generic kernel (HULC_NO_GEMM_NT128) up to fp32 summation order"""
+    import os
+    from hulc2_amd import kernels as kn
+
+    kn.set_compute("bf16")
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    Aw = torch.randn(M, K + 64, generator=g).to(dev).to(torch.bfloat16)
+    Bw = torch.randn(N, K + 128, generator=g).to(dev).to(torch.bfloat16)
+    A, B = Aw[:, 64:], Bw[:, :K]
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    rs0 = torch.randn(M, generator=g).to(dev)
+
+    def run():
+        C, rs = C0.clone(), rs0.clone()
+        kn.gemm(A, B, C, M, N, K, K + 64, K + 128, N, a_kmajor=True, b_kmajor=True, accumulate=accumulate, rowsum=rs, rowsum_accumulate=accumulate)
+        torch.cuda.synchronize()
+        return C, rs
+    C, rs = run()
+    ref = A.double() @ B.double().t() + (C0.double() if accumulate else 0)
+    assert (C.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item() + 1e-4
+    want = A.double().sum(1) + (rs0.double() if accumulate else 0)
+    assert (rs.double() - want).abs().max().item() < 1e-4 * K ** 0.5 + 1e-4
+    os.environ["HULC_NO_GEMM_NT128"] = "1"
+    try:
+        C2, rs2 = run()
+    finally:
+        del os.environ["HULC_NO_GEMM_NT128"]
+    assert (C - C2).abs().max().item() < 1e-4 * ref.abs().max().item()
