@@ -284,45 +284,61 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
                                                         const unsigned char* __restrict__ use, const float* __restrict__ logit_scale, int M,
                                                         float* __restrict__ out, const float* __restrict__ gout, float* __restrict__ dim_,
                                                         float* __restrict__ dtx, float* __restrict__ dscale) {
+    // one workgroup; the operands are staged into LDS with coalesced loads and every later phase works from LDS (the earlier form looped
+    // over global memory: 64 dependent loads per thread for the norms, M byte loads for the `use` count, and the projection re-read its own
+    // global stores).  Rows are padded by one float because a lane walks a ROW index in the logit / gradient loops (stride 32 floats would
+    // put every lane on one bank).  Measured: 18 / 25 us per launch against 19 / 27 before — the phases are short dependent chains behind
+    // seven workgroup barriers on ONE CU, not memory time; left there (1 % of the step).
+    constexpr int DP = CLIP_D + 1;
+    const int LP = M + 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* n = sm;                       // [M][D] normalised image features
-    float* t = n + M * CLIP_D;           // [M][D]
-    float* L = t + M * CLIP_D;           // [M][M] logits, later dL
-    float* ni = L + M * M;               // [M] norms
+    float* n = sm;                       // [M][DP] image features, normalised in place
+    float* t = n + M * DP;               // [M][DP]
+    float* L = t + M * DP;               // [M][LP] logits, later dL
+    float* ni = L + M * LP;              // [M] norms
     float* ti = ni + M;                  // [M]
     float* rl = ti + M;                  // [M] row lse
     float* cl = rl + M;                  // [M] col lse
+    float* uf = cl + M;                  // [M] use flags as 0 / 1
+    float* dn = uf + M;                  // [M][DP] gradients w.r.t. the normalised features (GRAD)
+    float* dt = dn + M * DP;             // [M][DP]
     __shared__ float sh[16];
     const int tid = threadIdx.x;
     const float s = expf(logit_scale[0]);
+    for (int i = tid; i < M * CLIP_D; i += blockDim.x) { const int r = i / CLIP_D, d = i % CLIP_D; n[r * DP + d] = im[i]; t[r * DP + d] = tx[i]; }
+    for (int r = tid; r < M; r += blockDim.x) uf[r] = use[r] ? 1.f : 0.f;
+    __syncthreads();
     for (int r = tid; r < M; r += blockDim.x) {
         float a = 0.f, b = 0.f;
-        for (int d = 0; d < CLIP_D; ++d) { a += im[r * CLIP_D + d] * im[r * CLIP_D + d]; b += tx[r * CLIP_D + d] * tx[r * CLIP_D + d]; }
+        for (int d = 0; d < CLIP_D; ++d) { a += n[r * DP + d] * n[r * DP + d]; b += t[r * DP + d] * t[r * DP + d]; }
         ni[r] = sqrtf(a); ti[r] = sqrtf(b);
     }
     __syncthreads();
-    for (int i = tid; i < M * CLIP_D; i += blockDim.x) { n[i] = im[i] / ni[i / CLIP_D]; t[i] = tx[i] / ti[i / CLIP_D]; }
+    for (int i = tid; i < M * CLIP_D; i += blockDim.x) { const int r = i / CLIP_D, q = r * DP + i % CLIP_D; n[q] = n[q] / ni[r]; t[q] = t[q] / ti[r]; }
     __syncthreads();
     for (int i = tid; i < M * M; i += blockDim.x) {
         const int r = i / M, c = i % M;
         float a = 0.f;
-        for (int d = 0; d < CLIP_D; ++d) a += n[r * CLIP_D + d] * t[c * CLIP_D + d];
-        L[i] = s * a;
+        for (int d = 0; d < CLIP_D; ++d) a += n[r * DP + d] * t[c * DP + d];
+        L[r * LP + c] = s * a;
     }
     __syncthreads();
     float cnt = 0.f;
-    for (int r = 0; r < M; ++r) cnt += use[r] ? 1.f : 0.f;
-    for (int r = tid; r < M; r += blockDim.x) {
-        float m1 = -INFINITY, m2 = -INFINITY;
-        for (int c = 0; c < M; ++c) if (use[c]) { m1 = fmaxf(m1, L[r * M + c]); m2 = fmaxf(m2, L[c * M + r]); }
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = 0; c < M; ++c) if (use[c]) { s1 += expf(L[r * M + c] - m1); s2 += expf(L[c * M + r] - m2); }
-        rl[r] = m1 + logf(s1); cl[r] = m2 + logf(s2);
+    for (int r = 0; r < M; ++r) cnt += uf[r];
+    // row and column log-sum-exp: 2 M tasks over the threads (task = r for rows, M + r for columns)
+    for (int q = tid; q < 2 * M; q += blockDim.x) {
+        const bool col = q >= M;
+        const int r = col ? q - M : q;
+        float m1 = -INFINITY;
+        for (int c = 0; c < M; ++c) if (uf[c] != 0.f) m1 = fmaxf(m1, col ? L[c * LP + r] : L[r * LP + c]);
+        float s1 = 0.f;
+        for (int c = 0; c < M; ++c) if (uf[c] != 0.f) s1 += expf((col ? L[c * LP + r] : L[r * LP + c]) - m1);
+        (col ? cl : rl)[r] = m1 + logf(s1);
     }
     __syncthreads();
     if (!GRAD) {
         float acc = 0.f;
-        for (int r = tid; r < M; r += blockDim.x) if (use[r]) acc += (rl[r] - L[r * M + r]) + (cl[r] - L[r * M + r]);
+        for (int r = tid; r < M; r += blockDim.x) if (uf[r] != 0.f) acc += (rl[r] - L[r * LP + r]) + (cl[r] - L[r * LP + r]);
         acc = block_sum(acc, sh);
         if (tid == 0) out[0] = cnt > 0.f ? acc / (2.f * cnt) : 0.f;
         return;
@@ -332,30 +348,30 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     for (int i = tid; i < M * M; i += blockDim.x) {
         const int r = i / M, c = i % M;
         float dl = 0.f;
-        if (use[r] && use[c]) {
-            const float lv = L[i];
+        if (uf[r] != 0.f && uf[c] != 0.f) {
+            const float lv = L[r * LP + c];
             dl = g * (expf(lv - rl[r]) + expf(lv - cl[c]) - (r == c ? 2.f : 0.f));
             ds += dl * lv;                       // d/d logit_scale of s*dot = L
         }
-        L[i] = dl;
+        L[r * LP + c] = dl;
     }
     ds = block_sum(ds, sh);                      // contains a __syncthreads: all dL written
     if (tid == 0) dscale[0] = ds;
     for (int i = tid; i < M * CLIP_D; i += blockDim.x) {
         const int r = i / CLIP_D, d = i % CLIP_D;
         float a = 0.f, b = 0.f;
-        for (int c = 0; c < M; ++c) { a += L[r * M + c] * t[c * CLIP_D + d]; b += L[c * M + r] * n[c * CLIP_D + d]; }
-        dim_[i] = s * a;                         // gradient w.r.t. the normalised feature (projected below)
-        dtx[i] = s * b;
+        for (int c = 0; c < M; ++c) { a += L[r * LP + c] * t[c * DP + d]; b += L[c * LP + r] * n[c * DP + d]; }
+        dn[r * DP + d] = s * a;                  // gradient w.r.t. the normalised feature (projected below)
+        dt[r * DP + d] = s * b;
     }
     __syncthreads();
-    for (int r = tid; r < M; r += blockDim.x) {
+    // projection onto the tangent of the unit sphere, one (row, column) per thread; the row's dot product is recomputed per element from LDS
+    for (int i = tid; i < M * CLIP_D; i += blockDim.x) {
+        const int r = i / CLIP_D, q = r * DP + i % CLIP_D;
         float pa = 0.f, pb = 0.f;
-        for (int d = 0; d < CLIP_D; ++d) { pa += dim_[r * CLIP_D + d] * n[r * CLIP_D + d]; pb += dtx[r * CLIP_D + d] * t[r * CLIP_D + d]; }
-        for (int d = 0; d < CLIP_D; ++d) {
-            dim_[r * CLIP_D + d] = (dim_[r * CLIP_D + d] - n[r * CLIP_D + d] * pa) / ni[r];
-            dtx[r * CLIP_D + d] = (dtx[r * CLIP_D + d] - t[r * CLIP_D + d] * pb) / ti[r];
-        }
+        for (int d = 0; d < CLIP_D; ++d) { pa += dn[r * DP + d] * n[r * DP + d]; pb += dt[r * DP + d] * t[r * DP + d]; }
+        dim_[i] = (dn[q] - n[q] * pa) / ni[r];
+        dtx[i] = (dt[q] - t[q] * pb) / ti[r];
     }
 }
 
@@ -524,12 +540,17 @@ extern "C" int hulc_plan_sample_bwd(const float* logits, const float* dplan, int
     return hulc_check_launch("hulc_plan_sample_bwd");
 }
 
-static size_t clip_smem(int M) { return ((size_t)2 * M * CLIP_D + (size_t)M * M + 4 * (size_t)M) * sizeof(float); }
+static size_t clip_smem(int M) { return ((size_t)4 * M * (CLIP_D + 1) + (size_t)M * (M + 1) + 5 * (size_t)M) * sizeof(float); }
+template <bool G> static int clip_lds_ok() {        // up to 132 KB at M = 128: above the default dynamic-LDS limit
+    static int rc = hipFuncSetAttribute((const void*)clip_loss_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_smem(CLIP_MAXM)) == hipSuccess ? 0 : -8;
+    return rc;
+}
 
 extern "C" int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
                                   float* out, void* stream) {
     if (!im || !tx || !use || !logit_scale || !out) return hulc_fail(-1, "hulc_clip_loss_fwd: null pointer");
     if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_fwd: needs M <= 128 and D == 32");
+    if (clip_lds_ok<false>()) return hulc_fail(-8, "hulc_clip_loss_fwd: could not raise the dynamic LDS limit");
     clip_loss_kernel<false><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, out, nullptr, nullptr, nullptr, nullptr);
     return hulc_check_launch("hulc_clip_loss_fwd");
 }
@@ -537,6 +558,7 @@ extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsign
                                   const float* gout, float* dim, float* dtx, float* dscale, void* stream) {
     if (!im || !tx || !use || !logit_scale || !gout || !dim || !dtx || !dscale) return hulc_fail(-1, "hulc_clip_loss_bwd: null pointer");
     if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128 and D == 32");
+    if (clip_lds_ok<true>()) return hulc_fail(-8, "hulc_clip_loss_bwd: could not raise the dynamic LDS limit");
     clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, nullptr, gout, dim, dtx, dscale);
     return hulc_check_launch("hulc_clip_loss_bwd");
 }
