@@ -247,6 +247,32 @@ def test_whole_step(sd, B, S):
     close(sd["plan_recognition.position_embeddings.weight"].grad, fx["g_pos"], 2e-4, "g pos")
 
 
+def test_euler_convention_against_scipy():
+    """pytorch3d is absent, so the restated euler_angles_to_matrix / matrix_to_euler_angles ('XYZ') are held against an INDEPENDENT
+    implementation of the convention pytorch3d documents (R = Rx(a) Ry(b) Rz(c), intrinsic XYZ): scipy.spatial.transform.Rotation.
+    Still not the reference's own dependency (row a16 stays "unpinned"), but no longer only self-consistent.  The whole frame change
+    (gripper_control.py:16-36) is then rebuilt from scipy objects and compared."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(3)
+    e = (rng.random((64, 3)) * 2 - 1) * np.array([3.0, 1.4, 3.0])
+    R = O.euler_xyz_to_matrix(torch.from_numpy(e)).numpy()
+    np.testing.assert_allclose(R, Rot.from_euler("XYZ", e).as_matrix(), atol=1e-12)
+    back = O.matrix_to_euler_xyz(torch.from_numpy(R)).numpy()
+    np.testing.assert_allclose(back, Rot.from_matrix(R).as_euler("XYZ"), atol=1e-9)
+    act = rng.random((4, 16, 7)) * 2 - 1
+    obs = rng.standard_normal((4, 16, 15))
+    obs[..., 3:6] = (rng.random((4, 16, 3)) * 2 - 1) * np.array([3.0, 1.4, 3.0])
+    got = O.world_to_tcp_frame(torch.from_numpy(act).float(), torch.from_numpy(obs).float()).numpy().reshape(-1, 7)
+    a2, o2 = act.reshape(-1, 7), obs.reshape(-1, 15)
+    w_T_tcp = Rot.from_euler("XYZ", o2[:, 3:6])
+    pos = w_T_tcp.inv().apply(a2[:, :3])
+    new = Rot.from_euler("XYZ", o2[:, 3:6] + 0.01 * a2[:, 3:6])
+    rel = (new.inv() * w_T_tcp).as_euler("XYZ") * 100
+    np.testing.assert_allclose(got[:, :3], pos, atol=2e-6)
+    np.testing.assert_allclose(got[:, 3:6], rel, atol=2e-2)          # float32 rotation products, x 100
+    np.testing.assert_array_equal(got[:, 6], a2[:, 6].astype(np.float32))
+
+
 def test_world_to_tcp_properties():
     """pytorch3d-backed frame change: parity unpinned -> properties (gripper_control.py:16-63)."""
     g = torch.Generator().manual_seed(0)
