@@ -5,3 +5,8 @@
 
 int hulc_fail(int code, const char* msg);          // records msg for hulc_last_error(), returns code
 int hulc_check_launch(const char* where);          // hipGetLastError() -> 0 / -100
+
+// wgrad_taps.hip: the conv_taps_wp items of hulc_wgrad_group that run as nine-tap tiles (one pass over the operands)
+int hulc_wgrad_taps_takes(const hulc_wgrad_item* d);
+long hulc_wgrad_taps_workspace(const hulc_wgrad_item* const* items, int n);       // slab bytes
+int hulc_wgrad_taps_launch(const hulc_wgrad_item* const* items, int n, void* slabs, hipStream_t s);

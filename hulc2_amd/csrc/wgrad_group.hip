@@ -298,21 +298,42 @@ int check_item(const hulc_wgrad_item& d) {
 
 }  // namespace
 
-extern "C" long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n) {
-    long slabs = 0;
+// conv_taps_wp items that wgrad_taps.hip takes run there (second launch, own slab region behind this file's); the rest here
+static void split_items(const hulc_wgrad_item* items, int n, std::vector<hulc_wgrad_item>& rest, std::vector<const hulc_wgrad_item*>& taps) {
     for (int i = 0; i < n; ++i) {
-        const Plan pl = plan_item(items[i]);
+        if (hulc_wgrad_taps_takes(&items[i])) taps.push_back(&items[i]);
+        else rest.push_back(items[i]);
+    }
+}
+static long group_slab_bytes(const std::vector<hulc_wgrad_item>& rest) {
+    long slabs = 0;
+    for (const hulc_wgrad_item& d : rest) {
+        const Plan pl = plan_item(d);
         if (pl.ksplit > 1) slabs += (long)pl.tiles * pl.ksplit;
     }
-    return (long)CTR_WORDS * 4 + slabs * SLAB * 4;
+    return slabs * SLAB * 4;
 }
 
-extern "C" int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream) {
-    if (n <= 0) return 0;
-    if (!items || !ws) return hulc_fail(-2, "hulc_wgrad_group: null argument");
-    if (ws_bytes < hulc_wgrad_group_workspace(items, n)) return hulc_fail(-3, "hulc_wgrad_group: workspace too small (hulc_wgrad_group_workspace)");
-    for (int i = 0; i < n; ++i)
-        if (int rc = check_item(items[i])) return rc;
+extern "C" long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n) {
+    std::vector<hulc_wgrad_item> rest; std::vector<const hulc_wgrad_item*> taps;
+    split_items(items, n, rest, taps);
+    return (long)CTR_WORDS * 4 + group_slab_bytes(rest) + hulc_wgrad_taps_workspace(taps.data(), (int)taps.size());
+}
+
+extern "C" int hulc_wgrad_group(const hulc_wgrad_item* all_items, int n_all, void* ws, long ws_bytes, void* stream) {
+    if (n_all <= 0) return 0;
+    if (!all_items || !ws) return hulc_fail(-2, "hulc_wgrad_group: null argument");
+    for (int i = 0; i < n_all; ++i)
+        if (int rc = check_item(all_items[i])) return rc;
+    std::vector<hulc_wgrad_item> rest; std::vector<const hulc_wgrad_item*> taps;
+    split_items(all_items, n_all, rest, taps);
+    const long own = (long)CTR_WORDS * 4 + group_slab_bytes(rest);
+    if (ws_bytes < own + hulc_wgrad_taps_workspace(taps.data(), (int)taps.size())) return hulc_fail(-3, "hulc_wgrad_group: workspace too small (hulc_wgrad_group_workspace)");
+    if (!taps.empty())
+        if (int rc = hulc_wgrad_taps_launch(taps.data(), (int)taps.size(), (char*)ws + own, (hipStream_t)stream)) return rc;
+    const hulc_wgrad_item* items = rest.data();
+    const int n = (int)rest.size();
+    if (n == 0) return 0;
     // the problems whose work items run longest (most k-steps per slice) go first: the launch ends with the short ones
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;

@@ -94,6 +94,46 @@ def test_gridconv_forward_dgrad_wgrad(N, H, W, Cin, Cout):
     assert (got_w - wr.grad).abs().max().item() <= 1e-3 * wr.grad.abs().max().item() + 1e-4
 
 
+# (N, H, W, Cin, Cout): every wave arrangement of csrc/wgrad_taps.hip (64 x 64 blocks, 32 output / input channels, both), ragged last k-step
+# (rows % 64 == 32), one slice and split tiles (> 64 k-steps; > 256 for the 32 x 32 arrangement), several tiles per item
+TAP_SHAPES = [(2, 6, 5, 64, 64), (1, 30, 17, 192, 128), (4, 40, 40, 64, 128), (3, 9, 9, 64, 32), (2, 30, 30, 32, 64), (5, 62, 62, 64, 32),
+              (8, 46, 46, 32, 32), (2, 11, 7, 32, 32), (2, 14, 14, 768, 512)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", TAP_SHAPES)
+def test_nine_tap_weight_gradient(N, H, W, Cin, Cout):
+    """conv_taps_wp items (csrc/wgrad_taps.hip: all nine taps of a tile from one pass over dZ and X) against fp64 conv2d weight gradients of
+    the bf16-rounded operands; written twice (store, then accumulate on top) and repeated bit for bit"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xr = bf(x)
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, padding=1).backward(bf(dy))
+    X, DY = to_grid(x, dev), to_grid(dy, dev)
+    outs = []
+    for rep in range(2):
+        dw = torch.full((Cout, Cin * 9), float("nan"), device=dev)
+        A = DY.rows[DY.guard:DY.guard + DY.Rpad]
+        B = X.rows[X.guard:X.guard + X.Rpad]
+        kn.wgrad(A, B, dw, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, col_mul=9, conv_taps_wp=W + 2)
+        kn.wgrad(A, B, dw, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, accumulate=True, col_mul=9, conv_taps_wp=W + 2)
+        torch.cuda.synchronize()
+        outs.append(dw.clone())
+    got = outs[0].view(Cout, Cin, 3, 3).cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - 2 * wr.grad).abs().max().item()
+    assert err <= 2e-5 * (N * H * W) ** 0.5 * 8 + 1e-4, err          # fp32 accumulation of N H W unit-variance products (x 2)
+    assert torch.equal(outs[0], outs[1])
+    # store_rows: only the first output channel leaves the kernel (the one-channel segmentation head padded to 32)
+    if Cout == 32:
+        one = torch.full((1, Cin * 9), float("nan"), device=dev)
+        kn.wgrad(A, B, one, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, col_mul=9, store_rows=1, conv_taps_wp=W + 2)
+        torch.cuda.synchronize()
+        assert (one.cpu().double() - wr.grad.view(Cout, -1)[:1]).abs().max().item() <= 2e-5 * (N * H * W) ** 0.5 * 4 + 1e-4
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 7, 5, 64), (3, 12, 12, 32), (2, 5, 9, 128)])
 def test_batchnorm_relu_forward_backward(N, H, W, C):
     dev = _dev()
