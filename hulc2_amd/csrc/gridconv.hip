@@ -163,6 +163,142 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     }
 }
 
+// ---- thin layers (Cin = 32 / 64: the last decoder block, the head and their data gradients — 1.6 M grid rows at 32 images) --------------------
+// The kernel above stages 128 rows x 32 channels per (tap, k-step): nine L2 -> LDS passes over the input, 32-64 FLOP per staged byte, and the
+// layer takes 120-210 us where its HBM traffic is 40-60.  Here a PERSISTENT workgroup keeps the whole filter of its 32 / 64 output channels in
+// registers (9 taps x Cin / 16 fragments) and walks row tiles: per tile it stages three windows of 130 rows x Cin (one per dy; the dx taps are
+// the same window read one row apart) — three passes instead of nine, no weight traffic per tile, one LDS fragment read per MFMA.  The output
+// tile goes through LDS and leaves as 16-byte chunks (a tile of a 32-channel map is one contiguous 8 KB block).  Tiles are dealt so that
+// the workgroups of an XCD work on neighbouring tiles (the dy windows of a tile are the rows of its neighbours: L2 hits).
+template <int CIN, int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void gridconv_thin_kernel(GcP p, int ntiles) {
+    constexpr int CPR = CIN / 8, RS = CIN * 2 + 16, KS = CIN / 16;
+    constexpr int WR = GC_BM + 2;                  // rows of one dy window: r0 - 1 .. r0 + 128
+    constexpr int NCHK = 3 * WR * CPR;             // 16-byte chunks per tile: 3120 (Cin 64) / 1560 (Cin 32)
+    constexpr int FULL = NCHK / 256, REM = NCHK % 256;     // 12 + 48 / 6 + 24
+    constexpr int RPP = 256 / CPR;                 // rows per pass of the 256 threads
+    constexpr int ORS = NB * 64 + 16;              // output tile rows in LDS
+    constexpr int BN = NB * 32;
+    static_assert(REM > 0 && FULL <= 12, "chunk plan");
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [3 WR rows][RS] | output tile [128][ORS]
+    char* const outs = smem + 3 * WR * RS;
+    __shared__ float sred[2][4][BN];
+    __shared__ unsigned char rowok[GC_BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int Wp = p.W + 2, PP = (p.H + 2) * Wp;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int per = (ntiles + 7) / 8, tend = min((xcd + 1) * per, ntiles);
+    int tile = xcd * per + slot;
+    if (tile >= tend) return;
+    // the filter: fragment (u, ks, nb) = k-block of the tap that reads offset u (flip: the data gradient walks the taps backwards)
+    bf16x8_t wf[9][KS][NB];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        const int t = p.flip ? 8 - u : u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                wf[u][ks][nb] = *(const bf16x8_t*)(p.Wt + (long)(n0 + nb * 32 + r) * p.ldw + (long)t * p.Cin + ks * 16 + h * 8);
+    }
+    const int ch = tid % CPR, rw = tid / CPR;
+    const int rwL = (FULL * 256 + tid % REM) / CPR, chL = (tid % REM) % CPR;       // the last, partial pass (the other threads repeat one of its chunks)
+    const int Rm1 = p.R - 1;
+    uint4 g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, gL;
+    g0 = g1 = g2 = g3 = g4 = g5 = g6 = g7 = g8 = g9 = g10 = g11 = make_uint4(0u, 0u, 0u, 0u);
+#define GT_ROW(row_) ({ const int d_ = ((row_) >= WR) + ((row_) >= 2 * WR); (long)(min(r0_ + (row_) - d_ * WR - 1, Rm1) + (d_ - 1) * Wp); })
+#define GT_L(q) if (q < FULL) g##q = *(const uint4*)(p.X + GT_ROW(rw + q * RPP) * p.ldx + ch * 8);
+#define GT_LOAD(tile_)                                                                                                 \
+    {                                                                                                                  \
+        const int r0_ = (tile_) * GC_BM;                                                                               \
+        GT_L(0) GT_L(1) GT_L(2) GT_L(3) GT_L(4) GT_L(5) GT_L(6) GT_L(7) GT_L(8) GT_L(9) GT_L(10) GT_L(11)              \
+        gL = *(const uint4*)(p.X + GT_ROW(rwL) * p.ldx + chL * 8);                                                     \
+    }
+#define GT_S(q) if (q < FULL) *(uint4*)(smem + (rw + q * RPP) * RS + ch * 16) = g##q;
+#define GT_STORE()                                                                                                     \
+    {                                                                                                                  \
+        GT_S(0) GT_S(1) GT_S(2) GT_S(3) GT_S(4) GT_S(5) GT_S(6) GT_S(7) GT_S(8) GT_S(9) GT_S(10) GT_S(11)              \
+        *(uint4*)(smem + rwL * RS + chL * 16) = gL;                                                                    \
+    }
+    GT_LOAD(tile)
+    for (;;) {
+        const int r0 = tile * GC_BM;
+        GT_STORE()
+        const int next = tile + nslots;
+        const bool more = next < tend;
+        GT_LOAD(more ? next : tile)                                // (the last trip reloads its own tile: nobody uses it)
+        if (tid < GC_BM) {
+            const int rr = r0 + tid, rem = rr % PP, yy = rem / Wp, xx = rem - yy * Wp;
+            rowok[tid] = (rr < p.R && yy >= 1 && yy <= p.H && xx >= 1 && xx <= p.W) ? 1 : 0;
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16_t acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+        const char* arow = smem + (wave * 32 + r) * RS + h * 16;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t a = *(const bf16x8_t*)(arow + (d * WR + x) * RS + ks * 32);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[d * 3 + x][ks][nb], acc[nb], 0, 0, 0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: border rows to zero, statistics partials, bf16 tile through LDS
+        float s1[NB], s2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            s1[nb] = 0.f; s2[nb] = 0.f;
+            const int n = n0 + nb * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wave * 32 + acc_row(e, lane);
+                const bool ok = rowok[row] != 0;
+                const float v = ok ? acc[nb][e] : 0.f;
+                s1[nb] += v; s2[nb] += v * v;
+                *(uint16_t*)(outs + row * ORS + (nb * 32 + r) * 2) = f32_to_bf16_bits(v);
+                if (p.out0 && n == 0 && r0 + row < p.R) p.out0[r0 + row] = ok ? v + (p.bias ? p.bias[0] : 0.f) : 0.f;
+            }
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                s1[nb] += __shfl_xor(s1[nb], 32, 64); s2[nb] += __shfl_xor(s2[nb], 32, 64);
+                if (lane < 32) { sred[0][wave][nb * 32 + lane] = s1[nb]; sred[1][wave][nb * 32 + lane] = s2[nb]; }
+            }
+        }
+        __syncthreads();
+        if (p.Y) {
+#pragma unroll
+            for (int k = 0; k < NB * 2; ++k) {
+                const int c = tid + 256 * k, row = c / (NB * 4), cc = c % (NB * 4);
+                if (r0 + row < p.R) *(uint4*)(p.Y + (long)(r0 + row) * p.ldy + n0 + cc * 8) = *(const uint4*)(outs + row * ORS + cc * 16);
+            }
+        }
+        if (p.stats && tid < BN) {
+            const float a = ((sred[0][0][tid] + sred[0][1][tid]) + sred[0][2][tid]) + sred[0][3][tid];
+            const float b = ((sred[1][0][tid] + sred[1][1][tid]) + sred[1][2][tid]) + sred[1][3][tid];
+            p.stats[((long)tile * 2) * p.Cout + n0 + tid] = a;
+            p.stats[((long)tile * 2 + 1) * p.Cout + n0 + tid] = b;
+        }
+        __syncthreads();                                           // windows, rowok, outs and sred are free again
+        if (!more) break;
+        tile = next;
+    }
+#undef GT_ROW
+#undef GT_L
+#undef GT_LOAD
+#undef GT_S
+#undef GT_STORE
+}
+
 }  // namespace
 
 // see include/hulc2_amd.h
@@ -183,6 +319,34 @@ extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y
     p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.flip = flip_taps ? 1 : 0;
     const unsigned gx = (unsigned)((R + GC_BM - 1) / GC_BM);
     hipStream_t s = (hipStream_t)stream;
+    // thin layers: persistent workgroups with the filter in registers (gridconv_thin_kernel)
+    static const int thin = getenv("HULC_GRIDCONV_THIN") ? atoi(getenv("HULC_GRIDCONV_THIN")) : 1;
+    if (thin && ldy % 8 == 0 && (!y || (uintptr_t)y % 16 == 0) && ((Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && (Cout == 32 || (thin > 1 && Cout == 64))))) {
+        int ncu = 256;
+        { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+        static int ncu_cached = 0;
+        if (!ncu_cached) ncu_cached = ncu;
+        static const int occ3 = getenv("HULC_GRIDCONV_THIN_OCC3") ? atoi(getenv("HULC_GRIDCONV_THIN_OCC3")) : 1;
+#define GT_LAUNCH(CINv, NBv, GYv, OCCv)                                                                                \
+        {                                                                                                              \
+            auto kern = gridconv_thin_kernel<CINv, NBv, OCCv>;                                                         \
+            const int wgs = ((OCCv * ncu_cached + 7) / 8) * 8;     /* OCC per CU, a multiple of the 8 XCDs */          \
+            const size_t lds = (size_t)3 * (GC_BM + 2) * (CINv * 2 + 16) + (size_t)GC_BM * (NBv * 64 + 16);            \
+            static bool attr = false;                                                                                  \
+            if (!attr) {                                                                                               \
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)    \
+                    return hulc_fail(-8, "hulc_gridconv3x3: could not raise the dynamic LDS limit (thin)");            \
+                attr = true;                                                                                           \
+            }                                                                                                          \
+            kern<<<dim3(wgs, GYv), 256, lds, s>>>(p, (int)gx);                                                         \
+        }
+        if (Cin == 32 && Cout == 32) { if (occ3) GT_LAUNCH(32, 1, 1, 3) else GT_LAUNCH(32, 1, 1, 2) }
+        else if (Cin == 32) GT_LAUNCH(32, 2, 1, 2)
+        else if (Cout == 32) GT_LAUNCH(64, 1, 1, 2)
+        else GT_LAUNCH(64, 1, 2, 2)
+#undef GT_LAUNCH
+        return hulc_check_launch("hulc_gridconv3x3 (thin)");
+    }
     // k-steps of 64 channels (half the barriers per MFMA) where the channel count allows and the layer is not a thin HBM-bound one
     static const int k64 = getenv("HULC_GRIDCONV_K64") ? atoi(getenv("HULC_GRIDCONV_K64")) : 1;
     const bool wide = k64 && Cin % 64 == 0 && Cin >= 128;

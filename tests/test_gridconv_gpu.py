@@ -52,7 +52,10 @@ def dgrad_weights(w):         # -> bf16 [Cin][9 Cout]: (ci, kh, kw, co), taps NO
     return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous().to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 5, 64, 32), (3, 14, 14, 96, 128), (2, 9, 9, 32, 64), (1, 30, 17, 160, 256)])
+# the thin-layer kernel (Cin 32 / 64, filter in registers, persistent workgroups) takes (64, 32), (32, 64), (32, 32): one tile, a dozen tiles
+# over the XCDs, and 545 tiles (two trips for some workgroups)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 5, 64, 32), (3, 14, 14, 96, 128), (2, 9, 9, 32, 64), (1, 30, 17, 160, 256), (2, 11, 7, 32, 32),
+                                            (3, 20, 20, 64, 32), (4, 130, 130, 32, 32), (2, 40, 33, 32, 64), (2, 23, 23, 64, 64)])
 def test_gridconv_forward_dgrad_wgrad(N, H, W, Cin, Cout):
     dev = _dev()
     g = torch.Generator().manual_seed(N * 100 + H)
