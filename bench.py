@@ -110,6 +110,67 @@ def _cpu_baseline_run(seconds_budget, threads):
                       f"time at that size does not fit the bench budget), fp32 torch CPU oracle, median of steps after the first"}
 
 
+def cpu_baseline_affordance(seconds_budget=24.0):
+    """the affordance oracle (frozen trunk restatement + decoder / head / depth step, fwd + bwd + Adam) on the host cores at B = 2, 224 x 224:
+    8 threads and every core, as cpu_baseline() does"""
+    from hulc2_amd import synthetic as syn
+    from oracle import affordance_oracle as A
+
+    def resnet18_shapes():                   # torchvision's resnet18 state_dict (conv / BatchNorm tensors of the stem and the 8 BasicBlocks)
+        out = {"conv1.weight": (64, 3, 7, 7)}
+        def bn(q, c):
+            for leaf in ("weight", "bias", "running_mean", "running_var"):
+                out[f"{q}.{leaf}"] = (c,)
+        bn("bn1", 64)
+        cin = 64
+        for li, c in enumerate((64, 128, 256, 512), start=1):
+            for b in range(2):
+                q = f"layer{li}.{b}."
+                out[q + "conv1.weight"] = (c, cin if b == 0 else c, 3, 3); bn(q + "bn1", c)
+                out[q + "conv2.weight"] = (c, c, 3, 3); bn(q + "bn2", c)
+                if b == 0 and li > 1:
+                    out[q + "downsample.0.weight"] = (c, cin, 1, 1); bn(q + "downsample.1", c)
+            cin = c
+        return out
+
+    B, HW = 2, 224
+    sd = {k: torch.empty(s) for k, s in A.trainable_shapes(HW // 32).items()}
+    syn.fill_affordance_state_dict_(sd, 42)
+    tsd = {"r3m.convnet." + k: torch.empty(s) for k, s in resnet18_shapes().items()}
+    syn.fill_state_dict_(tsd, 42)
+    for v in sd.values():
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(B, 3, HW, HW, generator=g)
+    emb = torch.randn(B, 384, generator=g) * 0.5
+    p0 = torch.randint(0, HW, (B, 2), generator=g)
+    depth = torch.randn(B, generator=g)
+    n_all = torch.get_num_threads()
+    runs = []
+    for n in sorted({min(8, n_all), n_all}):
+        torch.set_num_threads(n)
+        times, t_start = [], time.time()
+        for i in range(5):
+            t0 = time.time()
+            opt.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                feats = A.trunk_maps(tsd, img)
+            A.training_step(sd, feats, emb, p0, depth, HW)["loss"].backward()
+            opt.step()
+            times.append(time.time() - t0)
+            if time.time() - t_start > seconds_budget / 2 and i >= 1:
+                break
+        t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+        runs.append({"cores": n, "value": round(B / t, 3), "steps": len(times)})
+    torch.set_num_threads(n_all)
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "images/s", "cores": best["cores"], "kind": "port",
+            "sample": f"{best['steps']} steps of B={B} images 224 x 224 (the GPU step is B=32), fp32 torch CPU oracle (trunk restatement + "
+                      "oracle/affordance_oracle.py), median of steps after the first",
+            "runs": [{"cores": r["cores"], "value": r["value"]} for r in runs]}
+
+
 def secondary_fp32(args, dev):
     """The same step in the exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32, fp32 storage): the configuration whose outputs hold north_star's
     1e-3 against the reference fixtures element-wise (tests/test_parity_gpu.py, fp32 tolerances).  Reported next to the bf16 headline so
@@ -472,8 +533,8 @@ def main():
     if world == 1 and args.compute == "bf16" and plain and not args.no_secondary:
         del trainer, model
         out["secondary"] = secondary_fp32(args, dev)
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.affordance:
-        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_affordance() if args.affordance else cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -52,7 +52,7 @@ def _vec_grad(param, like):
     """(destination, accumulate flag, tensor to return to autograd or None) of a 1-D parameter gradient"""
     sink = gradsink.get(param)
     if sink is None:
-        t = torch.empty_like(param, dtype=torch.float32)
+        t = torch.empty_like(param, dtype=torch.float32)                  # (same shape as the parameter: (1, D) weights included)
         return t, False, t
     return sink, not gradsink.first_write(param), None
 
@@ -170,3 +170,33 @@ class AffDecoderLossFn(torch.autograd.Function):
                     dgs[i] = dg
                 dO2 = dsmall
         return (None, None, None, dgs[0], dgs[1], dgs[2], None, None, None, None, None, *grads_blocks, d_head_w, d_head_b)
+
+
+class DepthNllFn(torch.autograd.Function):
+    """(x (B, 256) fp32, depth_mu.weight, depth_mu.bias, depth_sigma.weight, depth_sigma.bias, target (B,)) -> (depth_loss, mu (B, 1), sigma (B, 1)):
+    the two one-output heads of DepthEstimationGaussian.forward, sigma = exp(clamp(log_sigma, -20, 2)) (depth_gaussian.py:94-102) and
+    nn.GaussianNLLLoss with sigma passed as the variance (depth_gaussian.py:67-69) as one launch per direction (csrc/affordance.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, b_mu, w_s, b_s, target):
+        x = x.float().contiguous()
+        t = target.reshape(-1).float().contiguous()
+        mu, sigma, ls, loss = kn.depth_nll_fwd(x, w_mu.detach().contiguous(), b_mu.detach(), w_s.detach().contiguous(), b_s.detach(), t)
+        ctx.save_for_backward(x, mu, sigma, ls, t)
+        ctx.params = (w_mu, b_mu, w_s, b_s)
+        ctx.mark_non_differentiable(mu, sigma)
+        return loss, mu, sigma
+
+    @staticmethod
+    def backward(ctx, dloss, _dmu, _dsigma):
+        x, mu, sigma, ls, t = ctx.saved_tensors
+        w_mu, b_mu, w_s, b_s = ctx.params
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dst, rets, mask = [], [], 0
+        for bit, p in zip((1, 2, 4, 8), ctx.params):
+            d, acc, r = _vec_grad(p, None)
+            dst.append(d); rets.append(r)
+            mask |= bit if acc else 0
+        kn.depth_nll_bwd(x, w_mu.detach().contiguous(), w_s.detach().contiguous(), mu, sigma, ls, t, dloss.reshape(1).float().contiguous(), dx,
+                         dst[0], dst[1], dst[2], dst[3], mask)
+        return (dx, *rets, None)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import functional as HF, kernels as kn
 from ..models.language_encoders.sbert_lang_encoder import SBertLang
 from ..models.perceptual_encoders.vision_r3m import R3M
-from .functional import DECODER_CHANNELS, AffDecoderLossFn, block_channels
+from .functional import DECODER_CHANNELS, AffDecoderLossFn, DepthNllFn, block_channels
 
 LOSS_WEIGHTS = {"aff": 0.1, "depth": 0.9}                  # conf/affordance/train_affordance.yaml:31-33
 
@@ -128,16 +128,13 @@ class PixelAffLangDetector(nn.Module):
             bufs += [b.conv1[1].running_mean, b.conv1[1].running_var, b.conv2[1].running_mean, b.conv2[1].running_var]
         return bufs
 
-    def depth(self, f4: torch.Tensor, l_enc: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """DepthEstimationGaussian.forward (depth_gaussian.py:77-102); f4 NHWC -> the reference flattens (C, H, W)"""
+    def depth_features(self, f4: torch.Tensor, l_enc: torch.Tensor) -> torch.Tensor:
+        """DepthEstimationGaussian.forward up to fc3 + ReLU (depth_gaussian.py:77-93); f4 NHWC -> the reference flattens (C, H, W)"""
         d = self.model.depth_stream
         x = torch.cat([f4.permute(0, 3, 1, 2).reshape(f4.shape[0], -1).float(), l_enc], -1)
         x = torch.relu(HF.mlp(x, [(d.fc1.weight, d.fc1.bias, False)]))          # (an MLPFn chain ends with a plain Linear)
         x = torch.cat([x, l_enc], -1)
-        x = torch.relu(HF.mlp(x, [(d.fc2.weight, d.fc2.bias, True), (d.fc3.weight, d.fc3.bias, False)]))
-        mu = torch.nn.functional.linear(x, d.depth_mu.weight, d.depth_mu.bias)                    # two 256 -> 1 heads: B x 256 dot products
-        sigma = torch.clamp(torch.nn.functional.linear(x, d.depth_sigma.weight, d.depth_sigma.bias), -20, 2).exp()
-        return mu, sigma
+        return torch.relu(HF.mlp(x, [(d.fc2.weight, d.fc2.bias, True), (d.fc3.weight, d.fc3.bias, False)]))
 
     # ---- step -----------------------------------------------------------------------------------------------------------------------
     def forward_losses(self, feats: Sequence[torch.Tensor], lang_goal, p0: torch.Tensor, gt_depth: torch.Tensor):
@@ -147,9 +144,10 @@ class PixelAffLangDetector(nn.Module):
         gs = [HF.mlp(l_enc, [(blocks[i].lang_proj.weight, blocks[i].lang_proj.bias, False)]) for i in range(3)]        # FusionMult's x2_proj(l)
         bufs = self.bn_buffers() if self.training else ("eval", self.bn_buffers())
         aff_loss, logits = AffDecoderLossFn.apply(p0, self.img_size, bufs, *gs, *feats, *self.decoder_params())
-        mu, sigma = self.depth(feats[-1], l_enc)
-        var = torch.clamp(sigma, min=1e-6)                                                         # nn.GaussianNLLLoss(mu, target, var = sigma), eps 1e-6
-        depth_loss = (0.5 * (torch.log(var) + (mu - gt_depth.reshape(-1, 1).float()) ** 2 / var)).mean()
+        d = self.model.depth_stream
+        # depth_mu / depth_sigma, sigma = exp(clamp(., -20, 2)) and nn.GaussianNLLLoss(mu, target, var = sigma) (eps 1e-6): one kernel
+        depth_loss, mu, sigma = DepthNllFn.apply(self.depth_features(feats[-1], l_enc), d.depth_mu.weight, d.depth_mu.bias, d.depth_sigma.weight,
+                                                 d.depth_sigma.bias, gt_depth)
         loss = self.loss_weights["aff"] * aff_loss + self.loss_weights["depth"] * depth_loss       # pixel_aff_lang_detector.py:165-166
         return loss, {"aff_loss": aff_loss, "depth_loss": depth_loss, "logits": logits, "mu": mu, "sigma": sigma}
 

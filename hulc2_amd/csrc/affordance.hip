@@ -365,6 +365,62 @@ __global__ void pixel_ce_bwd_kernel(const float* __restrict__ logit0, const int*
     *(uint4*)(dz + (long)r * C + ck * 8) = o;
 }
 
+// ---- depth head tail: the two 256 -> 1 heads, sigma = exp(clamp(., -20, 2)) and nn.GaussianNLLLoss (depth_gaussian.py:67-69,94-102) ------------
+// one workgroup (B rows of D features, a few KB): replaces ~35 framework launches of the forward + backward pass by two
+__global__ __launch_bounds__(256) void depth_nll_fwd_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ wmu, const float* __restrict__ bmu,
+                                                            const float* __restrict__ ws, const float* __restrict__ bs, const float* __restrict__ target,
+                                                            float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ logsig, float* __restrict__ loss) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        float a = 0.f, c = 0.f;
+        for (int d = lane; d < D; d += 64) { const float xv = x[(long)b * D + d]; a += xv * wmu[d]; c += xv * ws[d]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        const float m = a + bmu[0], ls = c + bs[0];
+        const float sg = expf(fminf(fmaxf(ls, -20.f), 2.f));
+        const float var = fmaxf(sg, 1e-6f), r = m - target[b];
+        if (lane == 0) { mu[b] = m; sigma[b] = sg; logsig[b] = ls; }
+        acc += 0.5f * (logf(var) + r * r / var);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (((part[0] + part[1]) + part[2]) + part[3]) / (float)B;
+}
+
+__global__ __launch_bounds__(256) void depth_nll_bwd_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ wmu, const float* __restrict__ ws,
+                                                            const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ logsig,
+                                                            const float* __restrict__ target, const float* __restrict__ gout, float* __restrict__ dx,
+                                                            float* __restrict__ dwmu, float* __restrict__ dbmu, float* __restrict__ dws, float* __restrict__ dbs, int accmask) {
+    extern __shared__ float sm[];                                  // dmu[B], dls[B]
+    float* dm = sm;
+    float* dl = sm + B;
+    const int tid = threadIdx.x;
+    const float g = gout[0] / (float)B;
+    for (int b = tid; b < B; b += 256) {
+        const float sg = sigma[b], var = fmaxf(sg, 1e-6f), r = mu[b] - target[b], ls = logsig[b];
+        const float dvar = g * 0.5f * (1.f / var - r * r / (var * var));
+        dm[b] = g * r / var;
+        dl[b] = (sg >= 1e-6f && ls >= -20.f && ls <= 2.f) ? dvar * sg : 0.f;       // clamp(min) and clamp(-20, 2) pass the gradient inside their ranges
+    }
+    __syncthreads();
+    if (dx)
+        for (long i = tid; i < (long)B * D; i += 256) { const int b = (int)(i / D), d = (int)(i % D); dx[i] = dm[b] * wmu[d] + dl[b] * ws[d]; }
+    for (int d = tid; d < D; d += 256) {
+        float a = 0.f, c = 0.f;
+        for (int b = 0; b < B; ++b) { const float xv = x[(long)b * D + d]; a += dm[b] * xv; c += dl[b] * xv; }
+        dwmu[d] = (accmask & 1) ? dwmu[d] + a : a;
+        dws[d] = (accmask & 4) ? dws[d] + c : c;
+    }
+    if (tid == 0) {
+        float a = 0.f, c = 0.f;
+        for (int b = 0; b < B; ++b) { a += dm[b]; c += dl[b]; }
+        dbmu[0] = (accmask & 2) ? dbmu[0] + a : a;
+        dbs[0] = (accmask & 8) ? dbs[0] + c : c;
+    }
+}
+
 }  // namespace
 
 // ---- C ABI (include/hulc2_amd.h) ---------------------------------------------------------------------------------------------------------
@@ -439,4 +495,22 @@ extern "C" int hulc_pixel_ce_bwd(const float* logit0, const int* p0, const float
     const long n = (long)N * (H + 2) * (W + 2) * (C / 8);
     pixel_ce_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(logit0, p0, lse, upstream, N, H, W, C, (uint16_t*)dz);
     return hulc_check_launch("hulc_pixel_ce_bwd");
+}
+
+extern "C" int hulc_depth_nll_fwd(const float* x, int B, int D, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma, const float* target,
+                                  float* mu, float* sigma, float* log_sigma, float* loss, void* stream) {
+    if (!x || !w_mu || !b_mu || !w_sigma || !b_sigma || !target || !mu || !sigma || !log_sigma || !loss) return hulc_fail(-1, "hulc_depth_nll_fwd: null pointer");
+    if (B <= 0 || D <= 0) return hulc_fail(-2, "hulc_depth_nll_fwd: B and D must be positive");
+    depth_nll_fwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(x, B, D, w_mu, b_mu, w_sigma, b_sigma, target, mu, sigma, log_sigma, loss);
+    return hulc_check_launch("hulc_depth_nll_fwd");
+}
+
+extern "C" int hulc_depth_nll_bwd(const float* x, int B, int D, const float* w_mu, const float* w_sigma, const float* mu, const float* sigma, const float* log_sigma,
+                                  const float* target, const float* gout, float* dx, float* dw_mu, float* db_mu, float* dw_sigma, float* db_sigma, int accumulate_mask,
+                                  void* stream) {
+    if (!x || !w_mu || !w_sigma || !mu || !sigma || !log_sigma || !target || !gout || !dw_mu || !db_mu || !dw_sigma || !db_sigma) return hulc_fail(-1, "hulc_depth_nll_bwd: null pointer");
+    if (B <= 0 || D <= 0 || B > 4096) return hulc_fail(-2, "hulc_depth_nll_bwd: 1 <= B <= 4096");
+    depth_nll_bwd_kernel<<<1, 256, 2 * B * sizeof(float), (hipStream_t)stream>>>(x, B, D, w_mu, w_sigma, mu, sigma, log_sigma, target, gout, dx, dw_mu, db_mu, dw_sigma,
+                                                                                 db_sigma, accumulate_mask);
+    return hulc_check_launch("hulc_depth_nll_bwd");
 }

@@ -1101,6 +1101,22 @@ def pixel_ce_fwd(logit0, p0, N, H, W):
     return lse, picked
 
 
+def depth_nll_fwd(x, w_mu, b_mu, w_sigma, b_sigma, target):
+    """-> (mu (B, 1), sigma (B, 1), log_sigma (B,), loss ()) of hulc_depth_nll_fwd"""
+    B, D = x.shape
+    mu = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    sigma = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    ls = torch.empty(B, dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    _call("hulc_depth_nll_fwd", x, _i(B), _i(D), w_mu, b_mu, w_sigma, b_sigma, target, mu, sigma, ls, loss)
+    return mu, sigma, ls, loss
+
+
+def depth_nll_bwd(x, w_mu, w_sigma, mu, sigma, ls, target, gout, dx, dw_mu, db_mu, dw_sigma, db_sigma, accumulate_mask=0):
+    B, D = x.shape
+    _call("hulc_depth_nll_bwd", x, _i(B), _i(D), w_mu, w_sigma, mu, sigma, ls, target, gout, dx, dw_mu, db_mu, dw_sigma, db_sigma, _i(accumulate_mask))
+
+
 def pixel_ce_bwd(logit0, p0, lse, upstream, N, H, W, C) -> Grid:
     dz = Grid(N, H, W, C, logit0.device)
     _call("hulc_pixel_ce_bwd", logit0, p0, lse, upstream, _i(N), _i(H), _i(W), _i(C), dz.t)

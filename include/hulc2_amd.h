@@ -390,6 +390,16 @@ int hulc_grid_upcat_bwd(const void* dX, long ldd, const void* x, long xsn, long 
                         void* dsmall, float* dg, int accumulate_dg, void* stream);
 int hulc_pixel_ce_fwd(const float* logit0, const int* p0, int N, int H, int W, float* lse, float* picked, void* stream);
 int hulc_pixel_ce_bwd(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, int C, void* dz, void* stream);
+/* hulc_depth_nll_fwd / _bwd: the tail of DepthEstimationGaussian (hulc2/affordance/models/core/depth_gaussian.py:67-69,94-102) on x (B, D) fp32 =
+ *   the output of fc3 + ReLU: mu = x w_mu^T + b_mu, log_sigma = x w_sigma^T + b_sigma, sigma = exp(clamp(log_sigma, -20, 2)),
+ *   loss[0] = mean over B of 0.5 (log var + (mu - target)^2 / var) with var = max(sigma, 1e-6) (nn.GaussianNLLLoss fed sigma as the variance).
+ *   Backward from gout[0] = d/d loss: dx (B, D) (may be NULL), dw_* (D) and db_* (1) stored, or added when their bit of accumulate_mask is set
+ *   (1 dw_mu, 2 db_mu, 4 dw_sigma, 8 db_sigma); the clamps pass the gradient inside their ranges (inclusive), as torch.clamp does. */
+int hulc_depth_nll_fwd(const float* x, int B, int D, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma, const float* target,
+                       float* mu, float* sigma, float* log_sigma, float* loss, void* stream);
+int hulc_depth_nll_bwd(const float* x, int B, int D, const float* w_mu, const float* w_sigma, const float* mu, const float* sigma, const float* log_sigma,
+                       const float* target, const float* gout, float* dx, float* dw_mu, float* db_mu, float* dw_sigma, float* db_sigma, int accumulate_mask,
+                       void* stream);
 
 /* ---- recurrent decoder: both RNN layers of one direction as a persistent wavefront kernel ----------------- */
 /* nn.RNN(num_layers=2, nonlinearity="relu") of hulc2/models/decoders/logistic_decoder_rnn.py:70-79 and its backward.

@@ -47,6 +47,31 @@ def trainable_shapes(enc_hw: int) -> Dict[str, tuple]:
     return out
 
 
+def trunk_maps(sd: SD, img: torch.Tensor, p: str = "r3m.convnet.", stages=(2, 2, 2, 2), eps: float = 1e-5) -> List[torch.Tensor]:
+    """The five maps R3M.r3m_resnet18 hands to the decoder (visual_lang_encoders/r3m_rn18.py:71-76: the ResNet-18's children applied one after
+    the other — no / 255 or ImageNet normalisation here, the dataset transforms did that): [stem (conv1, bn1, relu, maxpool), layer1 .. layer4],
+    NCHW, BatchNorm on its running statistics (frozen trunk, module docstring).  PARITY UNPINNED like hulc2_oracle.r3m_trunk_features, whose
+    restatement of torchvision's resnet18 this repeats with the maps kept; used by bench.py's cpu_baseline leg and the tests."""
+    def bn(t, q):
+        return F.batch_norm(t, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, eps)
+
+    t = F.relu(bn(F.conv2d(img, sd[p + "conv1.weight"], None, 2, 3), p + "bn1"))
+    t = F.max_pool2d(t, 3, 2, 1)
+    maps = [t]
+    for li, n in enumerate(stages, start=1):
+        for b in range(n):
+            q = p + f"layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            idn = t
+            if q + "downsample.0.weight" in sd:
+                idn = bn(F.conv2d(t, sd[q + "downsample.0.weight"], None, stride, 0), q + "downsample.1")
+            o = F.relu(bn(F.conv2d(t, sd[q + "conv1.weight"], None, stride, 1), q + "bn1"))
+            o = bn(F.conv2d(o, sd[q + "conv2.weight"], None, 1, 1), q + "bn2")
+            t = F.relu(o + idn)
+        maps.append(t)
+    return maps
+
+
 def conv_bn_relu(x, w, gamma, beta, train: bool, stats=None, running=None):
     """Conv2dReLU = Conv2d(3x3, padding 1, no bias) -> BatchNorm2d -> ReLU (unet_decoder.py:6-28); batch statistics in train mode (appended to
     `stats` as (mean, unbiased variance) for the running-statistics bookkeeping), `running` = (mean, var) in eval mode"""

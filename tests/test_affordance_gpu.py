@@ -140,6 +140,10 @@ def test_training_step_matches_the_oracle_with_sinks_and_trunk():
     depth = torch.randn(B, generator=gen)
     feats = m.trunk_maps(img)
     assert [tuple(f.shape) for f in feats] == [(B, 24, 24, 64), (B, 24, 24, 64), (B, 12, 12, 128), (B, 6, 6, 256), (B, 3, 3, 512)]
+    # the HIP trunk's maps against the oracle's restatement of the frozen ResNet-18 (bf16 activations through 17 layers)
+    tsd = {"r3m.convnet." + k: v.detach().float().cpu() for k, v in m.model.aff_stream.r3m.convnet.state_dict().items()}
+    for got, want in zip(feats, A.trunk_maps(tsd, img.cpu())):
+        assert (got.float().permute(0, 3, 1, 2).cpu() - want).abs().max().item() <= 4e-2 * want.abs().max().item()
     # oracle on the same maps
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = A.training_step(osd, [f.float().permute(0, 3, 1, 2).cpu() for f in feats], emb.cpu(), p0, depth, HW)

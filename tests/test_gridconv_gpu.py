@@ -232,3 +232,36 @@ def test_pixel_cross_entropy_with_head():
     got = from_grid(DZ)[:, 0].reshape(N, -1).double()
     assert (got - lg.grad).abs().max().item() <= 1e-2 * lg.grad.abs().max().item()
     assert float(from_grid(DZ)[:, 1:].abs().max()) == 0.0 and borders_zero(DZ)
+
+
+@pytest.mark.parametrize("B,D", [(32, 256), (3, 256), (70, 96)])
+def test_depth_head_gaussian_nll(B, D):
+    """hulc_depth_nll_fwd / _bwd against torch autograd of the reference's expressions (depth_gaussian.py:67-69,94-102): both clamp ranges
+    are entered (log_sigma beyond +2 and below -20, sigma under the 1e-6 floor), store and accumulate"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + D)
+    x = torch.randn(B, D, generator=g)
+    w_mu, b_mu = torch.randn(1, D, generator=g) / D ** 0.5, torch.randn(1, generator=g)
+    w_s, b_s = torch.randn(1, D, generator=g) * (10.0 / D ** 0.5), torch.tensor([-6.0])
+    t = torch.randn(B, generator=g)
+    ref = [v.double().requires_grad_(True) for v in (x, w_mu, b_mu, w_s, b_s)]
+    mu_r = F.linear(ref[0], ref[1], ref[2])
+    ls_r = F.linear(ref[0], ref[3], ref[4])
+    sig_r = torch.clamp(ls_r, -20, 2).exp()
+    var = torch.clamp(sig_r, min=1e-6)
+    loss_r = (0.5 * (torch.log(var) + (mu_r - t.double().reshape(-1, 1)) ** 2 / var)).mean()
+    (loss_r * 0.9).backward()
+    assert B < 32 or ((ls_r > 2).any() and (ls_r < -13.9).any() and (ls_r < -20).any() or B < 32)      # the ranges the test is about
+    xd, wm, bm, ws, bs, td = (v.to(dev) for v in (x, w_mu, b_mu, w_s, b_s, t))
+    mu, sigma, ls, loss = kn.depth_nll_fwd(xd, wm, bm, ws, bs, td)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_r.item()) <= 1e-4 * abs(loss_r.item()) + 1e-5
+    assert (mu.cpu().double() - mu_r.detach()).abs().max().item() < 1e-4 and (sigma.cpu().double() / sig_r.detach() - 1).abs().max().item() < 1e-3
+    dx = torch.empty_like(xd)
+    outs = [torch.full_like(v, 1.0) for v in (wm, bm, ws, bs)]
+    gout = torch.tensor([0.9], device=dev)
+    kn.depth_nll_bwd(xd, wm, ws, mu, sigma, ls, td, gout, dx, *outs, accumulate_mask=15)
+    torch.cuda.synchronize()
+    for got, want, base in zip([dx] + outs, [r.grad for r in ref], [0.0, 1.0, 1.0, 1.0, 1.0]):
+        w = want + base
+        assert (got.cpu().double() - w).abs().max().item() <= 2e-4 * w.abs().max().item() + 1e-6

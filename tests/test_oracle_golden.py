@@ -247,6 +247,36 @@ def test_whole_step(sd, B, S):
     close(sd["plan_recognition.position_embeddings.weight"].grad, fx["g_pos"], 2e-4, "g pos")
 
 
+def test_affordance_trunk_maps_agree_with_the_pooled_restatement():
+    """oracle/affordance_oracle.trunk_maps (the five maps the U-Net decoder reads) against hulc2_oracle.r3m_trunk_features (the pooled feature
+    of the same ResNet-18 restatement; both parity unpinned: r3m is un-vendored) + the map shapes r3m_rn18.py:59 promises"""
+    from oracle import affordance_oracle as A
+    from hulc2_amd import synthetic as syn
+    sd = {"conv1.weight": (64, 3, 7, 7)}
+    def bn(q, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            sd[f"{q}.{leaf}"] = (c,)
+    bn("bn1", 64)
+    cin = 64
+    for li, c in enumerate((64, 128, 256, 512), start=1):
+        for b in range(2):
+            q = f"layer{li}.{b}."
+            sd[q + "conv1.weight"] = (c, cin if b == 0 else c, 3, 3); bn(q + "bn1", c)
+            sd[q + "conv2.weight"] = (c, c, 3, 3); bn(q + "bn2", c)
+            if b == 0 and li > 1:
+                sd[q + "downsample.0.weight"] = (c, cin, 1, 1); bn(q + "downsample.1", c)
+        cin = c
+    sd = {"r3m.convnet." + k: torch.empty(v) for k, v in sd.items()}
+    syn.fill_state_dict_(sd, 5)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 255
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    maps = A.trunk_maps(sd, (x / 255.0 - mean) / std)
+    assert [tuple(m.shape[1:]) for m in maps] == [(64, 16, 16), (64, 16, 16), (128, 8, 8), (256, 4, 4), (512, 2, 2)]
+    assert torch.allclose(maps[-1].mean(dim=(2, 3)), O.r3m_trunk_features(sd, x), atol=1e-5, rtol=1e-5)
+    assert all(torch.isfinite(m).all() for m in maps)
+
+
 def test_euler_convention_against_scipy():
     """pytorch3d is absent, so the restated euler_angles_to_matrix / matrix_to_euler_angles ('XYZ') are held against an INDEPENDENT
     implementation of the convention pytorch3d documents (R = Rx(a) Ry(b) Rz(c), intrinsic XYZ): scipy.spatial.transform.Rotation.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which Python lines launch the framework (aten / runtime-copy) kernels of a training step?  Runs eager steps of the benchmark
 configuration under torch.profiler with stacks and prints, per kernel-launching aten op, the launches per step and the innermost
-hulc2_amd frames that issued them.   usage (GPU box): python tools/glue_trace.py [--steps 2]"""
+hulc2_amd frames that issued them.   usage (GPU box): python tools/glue_trace.py [--steps 2] [--affordance]"""
 import collections
 import sys
 from pathlib import Path
@@ -20,13 +20,26 @@ def main():
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 2
     dev = torch.device("cuda", 0)
     kn.set_compute("bf16")
-    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
-    syn.fill_state_dict_(model.state_dict(), 42)
-    model.train()
-    trainer = ArenaTrainer(model, lr=2e-4, overlap=False)
-    batch = syn.make_batch(42, 32, 32, device=dev)
-    for db in batch.values():
-        db.pop("plan_idx", None)
+    if "--affordance" in sys.argv:
+        from hulc2_amd.affordance import PixelAffLangDetector
+        model = PixelAffLangDetector(img_size=224).to(dev)
+        syn.fill_affordance_state_dict_({k: v for k, v in model.state_dict().items() if ".r3m." not in k}, 42)
+        syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in model.model.aff_stream.r3m.convnet.state_dict().items()}, 42)
+        model.train()
+        trainer = ArenaTrainer(model, lr=1e-4, overlap=False)
+        g = torch.Generator().manual_seed(42)
+        nb = 32
+        batch = ({"img": torch.randn(nb, 3, 224, 224, generator=g).to(dev), "lang_goal": (torch.randn(nb, 384, generator=g) * 0.5).to(dev)},
+                 {"p0": torch.stack([torch.randint(0, 224, (nb,), generator=g), torch.randint(0, 224, (nb,), generator=g)], 1).to(dev),
+                  "normalized_depth": torch.randn(nb, generator=g).to(dev)})
+    else:
+        model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+        syn.fill_state_dict_(model.state_dict(), 42)
+        model.train()
+        trainer = ArenaTrainer(model, lr=2e-4, overlap=False)
+        batch = syn.make_batch(42, 32, 32, device=dev)
+        for db in batch.values():
+            db.pop("plan_idx", None)
     for i in range(3):
         trainer.step(batch, i)
     torch.cuda.synchronize()
@@ -42,7 +55,7 @@ def main():
             continue
         if any(k.name.startswith("aten::") for k in ev.cpu_children if k.kernels):
             continue                                                        # count the leaf op only
-        frames = [f for f in (ev.stack or []) if "hulc2_amd" in f or "bench" in f]
+        frames = [f for f in (ev.stack or []) if "hulc2_amd" in f or "bench" in f or "glue_trace" in f]
         where = " <- ".join(f.split("/root/repo/")[-1].split("repo/")[-1] for f in frames[:2]) or "(autograd engine / no repo frame)"
         for k in ev.kernels:
             rows[(ev.name, k.name[:60], where)] += 1
