@@ -109,34 +109,29 @@ class AffDecoderLossFn(torch.autograd.Function):
             x_str = (sn, sy, sx)
             hi = ho
         last = saved[-1][6]
-        hw32 = torch.zeros(32, head_w.shape[1], 3, 3, dtype=torch.float32, device=dev)
-        hw32[0] = head_w.detach()[0]
-        logit0 = torch.empty(last.R, dtype=torch.float32, device=dev)
-        kn.gridconv3x3(last, hw32.permute(0, 2, 3, 1).reshape(32, -1).contiguous().to(torch.bfloat16), 32, out0=logit0, bias0=head_b.detach())
+        logit0 = kn.head_conv_fwd(last, head_w.detach().contiguous(), head_b.detach())      # the one-channel head: a streaming kernel, no matrix cores
         p0i = p0.to(device=dev, dtype=torch.int32).contiguous()
         lse, picked = kn.pixel_ce_fwd(logit0, p0i, N, out_hw, out_hw)
         loss = -(picked - lse).sum() / float(N * out_hw * out_hw)
-        ctx.saved = (saved, logit0, lse, p0i, hw32, blocks, head_w, head_b, N, out_hw)
+        ctx.saved = (saved, logit0, lse, p0i, blocks, head_w, head_b, N, out_hw)
         logits = logit0.view(N, out_hw + 2, out_hw + 2)[:, 1:-1, 1:-1].reshape(N, -1)
         ctx.mark_non_differentiable(logits)
         return loss, logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
-        saved, logit0, lse, p0i, hw32, blocks, head_w, head_b, N, out_hw = ctx.saved
+        saved, logit0, lse, p0i, blocks, head_w, head_b, N, out_hw = ctx.saved
         dev = logit0.device
         chans = block_channels()
         grads_blocks: List = [None] * 30
         up = dloss.reshape(1).to(torch.float32).contiguous()
-        DZh = kn.pixel_ce_bwd(logit0, p0i, lse, up, N, out_hw, out_hw, 32)
+        g = kn.pixel_ce_bwd_rows(logit0, p0i, lse, up, N, out_hw, out_hw)              # (softmax - onehot) / (N H W) per grid row, fp32
         last = saved[-1][6]
-        # head: weight gradient of its 32-row padded form, row 0 is the parameter's; the bias gradient is the sum of (softmax - onehot) = 0
+        # head: dW[ci][t] = sum_r g[r] x[r + off_t][ci]; the bias gradient is the sum of (softmax - onehot) = 0
         sink_h = gradsink.get(head_w)
         ci = head_w.shape[1]
-        dwh = sink_h.view(1, ci * 9) if sink_h is not None else torch.empty(1, ci * 9, dtype=torch.float32, device=dev)
-        acc_h = sink_h is not None and not gradsink.first_write(head_w)
-        kn.wgrad(DZh.rows[DZh.guard:DZh.guard + DZh.Rpad], last.rows[last.guard:last.guard + last.Rpad], dwh, 32, ci, last.Rpad, 32, last.C, ci * 9,
-                 accumulate=acc_h, defer=sink_h is not None, col_mul=9, store_rows=1, conv_taps_wp=out_hw + 2)
+        dwh = sink_h.view(-1) if sink_h is not None else torch.empty(ci * 9, dtype=torch.float32, device=dev)
+        kn.head_conv_wgrad(last, g, dwh, accumulate=sink_h is not None and not gradsink.first_write(head_w))
         d_head_w = None if sink_h is not None else dwh.view(1, ci, 3, 3)
         d_head_b = torch.zeros_like(head_b, dtype=torch.float32)
         sink_hb = gradsink.get(head_b)
@@ -144,7 +139,7 @@ class AffDecoderLossFn(torch.autograd.Function):
             if gradsink.first_write(head_b):
                 sink_hb.zero_()
             d_head_b = None
-        dO2, _ = kn.gridconv3x3(DZh, hw32.permute(1, 2, 3, 0).reshape(last.C, -1).contiguous().to(torch.bfloat16), last.C, flip=True)
+        dO2 = kn.head_conv_dgrad(g, head_w.detach().contiguous(), N, out_hw, out_hw, last.C)
         dgs = [None, None, None]
         for i in range(4, -1, -1):
             cin, cs, cout = chans[i]

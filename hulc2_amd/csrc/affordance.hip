@@ -365,6 +365,147 @@ __global__ void pixel_ce_bwd_kernel(const float* __restrict__ logit0, const int*
     *(uint4*)(dz + (long)r * C + ck * 8) = o;
 }
 
+// ---- the one-channel segmentation head (r3m_rn18.py:64-69: nn.Conv2d(32, 1, 3, padding = 1)) without matrix cores --------------------------
+// As a 32 -> 32 gridconv with 31 zero output channels the head and its two gradients moved ~100 MB each for 9 x 32 useful weights and took
+// 68 + 68 + 85 us at 32 images; written directly they are streaming kernels: a thread owns 8 channels of a grid row (4 threads per row,
+// 16 rows = 1 KB per wave load), the 9 x C weights sit in LDS as fp32.
+HULC_DEVICE bool grid_interior(int r, int R, int H, int W) {
+    const int Wp = W + 2, PP = (H + 2) * Wp;
+    const int rem = r % PP, yy = rem / Wp, xx = rem - yy * Wp;
+    return r < R && yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+}
+HULC_DEVICE void bf16x8_to_f32(const uint4& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u); f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u); f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+// out0[r] = bias + sum_{t, ci} x[r + off_t][ci] w[ci][t] on the pixels, 0 on the border; w = the parameter (1, C, 3, 3) fp32
+template <int CPR>      // 16-byte chunks per row = threads per row (C = 8 CPR)
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const uint16_t* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int R, int H, int W, float* __restrict__ out0) {
+    constexpr int C = CPR * 8;
+    __shared__ float wl[9 * C];                                     // [tap][ci]
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[i] = w[(i % C) * 9 + i / C];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(i / CPR), ck = (int)(i % CPR), Wp = W + 2;
+    const bool ok = r < R && grid_interior(r, R, H, W);
+    float acc = 0.f;
+    if (ok) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint4 v = *(const uint4*)(x + (long)(r + (t / 3 - 1) * Wp + (t % 3 - 1)) * ldx + ck * 8);
+            float f[8];
+            bf16x8_to_f32(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += f[j] * wl[t * C + ck * 8 + j];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < CPR; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (ck == 0 && r < R) out0[r] = ok ? acc + bias[0] : 0.f;
+}
+// dx[r][ci] = sum_t g[r - off_t] w[ci][t] on the pixels, 0 on the border (g fp32 per grid row, zero on the border rows)
+template <int CPR>
+__global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, int R, int H, int W,
+                                                              uint16_t* __restrict__ dx, long lddx) {
+    constexpr int C = CPR * 8;
+    __shared__ float wl[9 * C];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wl[i] = w[(i % C) * 9 + i / C];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(i / CPR), ck = (int)(i % CPR), Wp = W + 2;
+    if (r >= R) return;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (grid_interior(r, R, H, W)) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float gv = g[r - ((t / 3 - 1) * Wp + (t % 3 - 1))];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += gv * wl[t * C + ck * 8 + j];
+        }
+    }
+    *(uint4*)(dx + (long)r * lddx + ck * 8) = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+}
+// partial[blk][t][ci] = sum over the block's rows r of x[r][ci] g[r - off_t]  (= the rows' share of dW[ci][t] = sum_r g[r] x[r + off_t][ci]);
+// every x row is read once
+template <int CPR>
+__global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const uint16_t* __restrict__ x, long ldx, const float* __restrict__ g, int R, int H, int W,
+                                                              int rows_per_blk, float* __restrict__ partial) {
+    constexpr int C = CPR * 8, RPP = 256 / CPR;
+    __shared__ float red[4][9 * C];
+    const int tid = threadIdx.x, ck = tid % CPR, slot = tid / CPR, Wp = W + 2;
+    const int rbeg = blockIdx.x * rows_per_blk, rend = min(rbeg + rows_per_blk, R);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (int r = rbeg + slot; r < rend; r += RPP) {
+        const uint4 v = *(const uint4*)(x + (long)r * ldx + ck * 8);
+        float f[8];
+        bf16x8_to_f32(v, f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int q = r - ((t / 3 - 1) * Wp + (t % 3 - 1));
+            const float gv = (q >= 0 && q < R) ? g[q] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[t][j] += gv * f[j];
+        }
+    }
+    // lanes with the same chunk (lane % CPR) add up, then the four waves, in a fixed order
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[t][j];
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            acc[t][j] = v;
+        }
+    if ((tid & 63) < CPR) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid >> 6][t * C + ck * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * C; i += 256) partial[(long)blockIdx.x * 9 * C + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+}
+// dw[ci][t] (+)= sum over the blocks, 8 slices of blocks per output then the slices (fixed order); one workgroup per 32 outputs
+__global__ __launch_bounds__(256) void head_conv_wgrad_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dw, int accumulate) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, idx = blockIdx.x * 32 + o;
+    float a = 0.f;
+    if (idx < 9 * C)
+        for (int b = sl; b < nblk; b += 8) a += partial[(long)b * 9 * C + idx];
+    red[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && idx < 9 * C) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k][o];
+        float* dst = dw + (idx % C) * 9 + idx / C;                  // partial is [tap][ci], the parameter (1, C, 3, 3)
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+// d logit = upstream (softmax - onehot) / (N H W) as fp32 per grid row, zero on the border
+__global__ void pixel_ce_bwd_rows_kernel(const float* __restrict__ logit0, const int* __restrict__ p0, const float* __restrict__ lse, const float* __restrict__ upstream,
+                                         int N, int H, int W, float* __restrict__ g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Wp = W + 2, PP = (H + 2) * Wp;
+    if (i >= (long)N * PP) return;
+    const int r = (int)i, n = r / PP, rem = r - n * PP, yy = rem / Wp, xx = rem - yy * Wp;
+    float d = 0.f;
+    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+        d = __expf(logit0[r] - lse[n]);
+        if (yy - 1 == p0[2 * n] && xx - 1 == p0[2 * n + 1]) d -= 1.f;
+        d *= upstream[0] / ((float)N * H * W);
+    }
+    g[r] = d;
+}
+
 // ---- depth head tail: the two 256 -> 1 heads, sigma = exp(clamp(., -20, 2)) and nn.GaussianNLLLoss (depth_gaussian.py:67-69,94-102) ------------
 // one workgroup (B rows of D features, a few KB): replaces ~35 framework launches of the forward + backward pass by two
 __global__ __launch_bounds__(256) void depth_nll_fwd_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ wmu, const float* __restrict__ bmu,
@@ -513,4 +654,55 @@ extern "C" int hulc_depth_nll_bwd(const float* x, int B, int D, const float* w_m
     depth_nll_bwd_kernel<<<1, 256, 2 * B * sizeof(float), (hipStream_t)stream>>>(x, B, D, w_mu, w_sigma, mu, sigma, log_sigma, target, gout, dx, dw_mu, db_mu, dw_sigma,
                                                                                  db_sigma, accumulate_mask);
     return hulc_check_launch("hulc_depth_nll_bwd");
+}
+
+#define HEAD_DISPATCH(C_, CALL)                                                                                        \
+    switch ((C_) / 8) {                                                                                                \
+    case 1: { constexpr int CPR = 1; CALL; } break;                                                                    \
+    case 2: { constexpr int CPR = 2; CALL; } break;                                                                    \
+    case 4: { constexpr int CPR = 4; CALL; } break;                                                                    \
+    case 8: { constexpr int CPR = 8; CALL; } break;                                                                    \
+    default: return hulc_fail(-2, "hulc_head_conv: C must be 8, 16, 32 or 64");                                        \
+    }
+
+extern "C" int hulc_head_conv_fwd(const void* x, long ldx, const float* w, const float* bias, int N, int H, int W, int C, float* out0, void* stream) {
+    if (!x || !w || !bias || !out0 || ldx % 8 || (uintptr_t)x % 16 || C % 8) return hulc_fail(-1, "hulc_head_conv_fwd: bad argument");
+    const long R = (long)N * (H + 2) * (W + 2);
+    const unsigned nb = (unsigned)((R * (C / 8) + 255) / 256);
+    HEAD_DISPATCH(C, (head_conv_fwd_kernel<CPR><<<nb, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, ldx, w, bias, (int)R, H, W, out0)))
+    return hulc_check_launch("hulc_head_conv_fwd");
+}
+
+extern "C" int hulc_head_conv_dgrad(const float* g, const float* w, int N, int H, int W, int C, void* dx, long lddx, void* stream) {
+    if (!g || !w || !dx || lddx % 8 || (uintptr_t)dx % 16 || C % 8) return hulc_fail(-1, "hulc_head_conv_dgrad: bad argument");
+    const long R = (long)N * (H + 2) * (W + 2);
+    const unsigned nb = (unsigned)((R * (C / 8) + 255) / 256);
+    HEAD_DISPATCH(C, (head_conv_dgrad_kernel<CPR><<<nb, 256, 0, (hipStream_t)stream>>>(g, w, (int)R, H, W, (uint16_t*)dx, lddx)))
+    return hulc_check_launch("hulc_head_conv_dgrad");
+}
+
+static int head_wgrad_blocks(long R, int C) {
+    const int rpp = 256 / (C / 8);                                  // rows per pass of a workgroup
+    long nb = (R + 8L * rpp - 1) / (8L * rpp);                      // >= 8 passes per workgroup ...
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));            // ... and at most 1024 of them
+}
+extern "C" long hulc_head_conv_wgrad_workspace(int N, int H, int W, int C) {
+    return (long)head_wgrad_blocks((long)N * (H + 2) * (W + 2), C) * 9 * C * (long)sizeof(float);
+}
+extern "C" int hulc_head_conv_wgrad(const void* x, long ldx, const float* g, int N, int H, int W, int C, float* dw, int accumulate, void* ws, void* stream) {
+    if (!x || !g || !dw || !ws || ldx % 8 || (uintptr_t)x % 16 || C % 8) return hulc_fail(-1, "hulc_head_conv_wgrad: bad argument");
+    const long R = (long)N * (H + 2) * (W + 2);
+    const int nb = head_wgrad_blocks(R, C);
+    const int rows = (int)((R + nb - 1) / nb);
+    HEAD_DISPATCH(C, (head_conv_wgrad_kernel<CPR><<<nb, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, ldx, g, (int)R, H, W, rows, (float*)ws)))
+    head_conv_wgrad_final_kernel<<<(9 * C + 31) / 32, 256, 0, (hipStream_t)stream>>>((const float*)ws, nb, C, dw, accumulate);
+    return hulc_check_launch("hulc_head_conv_wgrad");
+}
+#undef HEAD_DISPATCH
+
+extern "C" int hulc_pixel_ce_bwd_rows(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, float* g, void* stream) {
+    if (!logit0 || !p0 || !lse || !upstream || !g) return hulc_fail(-1, "hulc_pixel_ce_bwd_rows: null pointer");
+    const long n = (long)N * (H + 2) * (W + 2);
+    pixel_ce_bwd_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(logit0, p0, lse, upstream, N, H, W, g);
+    return hulc_check_launch("hulc_pixel_ce_bwd_rows");
 }

@@ -1101,6 +1101,41 @@ def pixel_ce_fwd(logit0, p0, N, H, W):
     return lse, picked
 
 
+def head_conv_fwd(x: Grid, w, bias):
+    """the one-channel head on the grid: -> logit0 fp32 [R] (bias added on the pixels, zero on the border)"""
+    out0 = torch.empty(x.R, dtype=torch.float32, device=x.rows.device)
+    _call("hulc_head_conv_fwd", x.t, _l(x.C), w, bias, _i(x.N), _i(x.H), _i(x.W), _i(x.C), out0)
+    return out0
+
+
+def pixel_ce_bwd_rows(logit0, p0, lse, upstream, N, H, W):
+    g = torch.empty(N * (H + 2) * (W + 2), dtype=torch.float32, device=logit0.device)
+    _call("hulc_pixel_ce_bwd_rows", logit0, p0, lse, upstream, _i(N), _i(H), _i(W), g)
+    return g
+
+
+def head_conv_dgrad(g, w, N, H, W, C) -> Grid:
+    dx = Grid(N, H, W, C, g.device)
+    _call("hulc_head_conv_dgrad", g, w, _i(N), _i(H), _i(W), _i(C), dx.t, _l(C))
+    return dx
+
+
+_head_ws = {}
+
+
+def head_conv_wgrad(x: Grid, g, dw, accumulate=False):
+    lib = _L.load()
+    lib.hulc_head_conv_wgrad_workspace.restype = _c.c_long
+    need = int(lib.hulc_head_conv_wgrad_workspace(_i(x.N), _i(x.H), _i(x.W), _i(x.C)))
+    key = (x.rows.device, _stream())
+    ws = _head_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=x.rows.device)
+        if not torch.cuda.is_current_stream_capturing():
+            _head_ws[key] = ws
+    _call("hulc_head_conv_wgrad", x.t, _l(x.C), g, _i(x.N), _i(x.H), _i(x.W), _i(x.C), dw, _i(1 if accumulate else 0), ws)
+
+
 def depth_nll_fwd(x, w_mu, b_mu, w_sigma, b_sigma, target):
     """-> (mu (B, 1), sigma (B, 1), log_sigma (B,), loss ()) of hulc_depth_nll_fwd"""
     B, D = x.shape

@@ -390,6 +390,18 @@ int hulc_grid_upcat_bwd(const void* dX, long ldd, const void* x, long xsn, long 
                         void* dsmall, float* dg, int accumulate_dg, void* stream);
 int hulc_pixel_ce_fwd(const float* logit0, const int* p0, int N, int H, int W, float* lse, float* picked, void* stream);
 int hulc_pixel_ce_bwd(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, int C, void* dz, void* stream);
+/* The one-channel segmentation head (visual_lang_encoders/r3m_rn18.py:64-69: nn.Conv2d(C, 1, 3, padding = 1), C = 8 / 16 / 32 / 64) on the padded
+ *   grid, as streaming kernels (a 32-output-channel hulc_gridconv3x3 with 31 zero channels moves the same bytes for 1 / 32 of the work):
+ *   hulc_head_conv_fwd: out0[r] = bias[0] + sum_{t, ci} x[r + off_t][ci] w[ci][t] on the pixels, 0 on the border rows (w = the parameter
+ *     (1, C, 3, 3) fp32 as it lies, x bf16 grid rows);  hulc_pixel_ce_bwd_rows: g[r] = upstream (softmax - onehot) / (N H W) fp32 per grid row,
+ *     zero on the border;  hulc_head_conv_dgrad: dx[r][ci] = sum_t g[r - off_t] w[ci][t] (bf16 grid tensor, border rows zero);
+ *   hulc_head_conv_wgrad: dw[ci][t] (+)= sum_r g[r] x[r + off_t][ci], summed in a fixed order through ws (hulc_head_conv_wgrad_workspace bytes);
+ *     the bias gradient is sum_r g[r] = 0 for the cross-entropy (softmax - onehot) and is not computed. */
+int hulc_head_conv_fwd(const void* x, long ldx, const float* w, const float* bias, int N, int H, int W, int C, float* out0, void* stream);
+int hulc_pixel_ce_bwd_rows(const float* logit0, const int* p0, const float* lse, const float* upstream, int N, int H, int W, float* g, void* stream);
+int hulc_head_conv_dgrad(const float* g, const float* w, int N, int H, int W, int C, void* dx, long lddx, void* stream);
+long hulc_head_conv_wgrad_workspace(int N, int H, int W, int C);
+int hulc_head_conv_wgrad(const void* x, long ldx, const float* g, int N, int H, int W, int C, float* dw, int accumulate, void* ws, void* stream);
 /* hulc_depth_nll_fwd / _bwd: the tail of DepthEstimationGaussian (hulc2/affordance/models/core/depth_gaussian.py:67-69,94-102) on x (B, D) fp32 =
  *   the output of fc3 + ReLU: mu = x w_mu^T + b_mu, log_sigma = x w_sigma^T + b_sigma, sigma = exp(clamp(log_sigma, -20, 2)),
  *   loss[0] = mean over B of 0.5 (log var + (mu - target)^2 / var) with var = max(sigma, 1e-6) (nn.GaussianNLLLoss fed sigma as the variance).

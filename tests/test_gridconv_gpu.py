@@ -234,6 +234,46 @@ def test_pixel_cross_entropy_with_head():
     assert float(from_grid(DZ)[:, 1:].abs().max()) == 0.0 and borders_zero(DZ)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(3, 11, 13, 32), (2, 40, 37, 64), (5, 60, 64, 8), (2, 200, 190, 32)])
+def test_one_channel_head_streaming_kernels(N, H, W, C):
+    """hulc_head_conv_fwd / _dgrad / _wgrad + hulc_pixel_ce_bwd_rows (the head without matrix cores) against fp64 conv2d autograd on the
+    bf16-rounded activations; the last shape has more rows than one weight-gradient workgroup pass (several blocks + the fixed-order sum)"""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(N * 7 + C)
+    x = torch.randn(N, C, H, W, generator=gen)
+    w = torch.randn(1, C, 3, 3, generator=gen) * 0.3
+    b = torch.randn(1, generator=gen)
+    p0 = torch.stack([torch.randint(0, H, (N,), generator=gen), torch.randint(0, W, (N,), generator=gen)], 1).to(torch.int32)
+    X = to_grid(x, dev)
+    wd, bd = w.to(dev), b.to(dev)
+    logit0 = kn.head_conv_fwd(X, wd, bd)
+    lse, picked = kn.pixel_ce_fwd(logit0, p0.to(dev), N, H, W)
+    up = torch.tensor([0.7], device=dev)
+    g = kn.pixel_ce_bwd_rows(logit0, p0.to(dev), lse, up, N, H, W)
+    dX = kn.head_conv_dgrad(g, wd, N, H, W, C)
+    dw = torch.full((C * 9,), 2.0, device=dev)
+    kn.head_conv_wgrad(X, g, dw, accumulate=True)
+    dw2 = torch.full((C * 9,), float("nan"), device=dev)
+    kn.head_conv_wgrad(X, g, dw2)
+    torch.cuda.synchronize()
+    xr = bf(x).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    lg = F.conv2d(xr, wr, b.double(), padding=1)
+    got_lg = logit0.view(N, H + 2, W + 2)[:, 1:-1, 1:-1].cpu().double()
+    assert (got_lg - lg.detach()[:, 0]).abs().max().item() <= 1e-5 * lg.detach().abs().max().item() + 1e-5
+    v = logit0.view(N, H + 2, W + 2)
+    assert float(v[:, 0].abs().max()) == 0.0 and float(v[:, :, 0].abs().max()) == 0.0 and float(v[:, -1].abs().max()) == 0.0
+    label = torch.zeros(N, H, W, dtype=torch.double)
+    label[torch.arange(N), p0[:, 0].long(), p0[:, 1].long()] = 1
+    loss = (-label.reshape(N, -1) * F.log_softmax(lg.permute(0, 2, 3, 1).reshape(N, -1), -1)).mean()
+    (loss * 0.7).backward()
+    assert borders_zero(dX)
+    assert (from_grid(dX).double() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()          # bf16 output
+    want_w = wr.grad.reshape(-1)
+    assert (dw2.cpu().double() - want_w).abs().max().item() <= 2e-4 * want_w.abs().max().item() + 1e-9
+    assert (dw.cpu().double() - 2.0 - want_w).abs().max().item() <= 2e-4 * want_w.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("B,D", [(32, 256), (3, 256), (70, 96)])
 def test_depth_head_gaussian_nll(B, D):
     """hulc_depth_nll_fwd / _bwd against torch autograd of the reference's expressions (depth_gaussian.py:67-69,94-102): both clamp ranges
