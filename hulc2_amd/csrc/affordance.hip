@@ -442,16 +442,24 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const uint16_t* __
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    for (int r = rbeg + slot; r < rend; r += RPP) {
-        const uint4 v = *(const uint4*)(x + (long)r * ldx + ck * 8);
-        float f[8];
-        bf16x8_to_f32(v, f);
+    // four rows per trip: four independent 16-byte loads in flight per thread (one at a time left the kernel latency-bound at 2 TB/s)
+    for (int r = rbeg + slot; r < rend; r += 4 * RPP) {
+        uint4 v[4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int q = r - ((t / 3 - 1) * Wp + (t % 3 - 1));
-            const float gv = (q >= 0 && q < R) ? g[q] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = *(const uint4*)(x + (long)min(r + k * RPP, rend - 1) * ldx + ck * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[t][j] += gv * f[j];
+        for (int k = 0; k < 4; ++k) {
+            const int rr = r + k * RPP;
+            const bool live = rr < rend;
+            float f[8];
+            bf16x8_to_f32(v[k], f);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int q = rr - ((t / 3 - 1) * Wp + (t % 3 - 1));
+                const float gv = (live && q >= 0 && q < R) ? g[q] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t][j] += gv * f[j];
+            }
         }
     }
     // lanes with the same chunk (lane % CPR) add up, then the four waves, in a fixed order
@@ -473,19 +481,19 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const uint16_t* __
     __syncthreads();
     for (int i = tid; i < 9 * C; i += 256) partial[(long)blockIdx.x * 9 * C + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 }
-// dw[ci][t] (+)= sum over the blocks, 8 slices of blocks per output then the slices (fixed order); one workgroup per 32 outputs
+// dw[ci][t] (+)= sum over the blocks: 32 slices of blocks per output, then the slices (fixed order); one workgroup per 8 outputs
 __global__ __launch_bounds__(256) void head_conv_wgrad_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dw, int accumulate) {
-    __shared__ float red[8][32];
-    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, idx = blockIdx.x * 32 + o;
+    __shared__ float red[32][8];
+    const int o = threadIdx.x & 7, sl = threadIdx.x >> 3, idx = blockIdx.x * 8 + o;
     float a = 0.f;
     if (idx < 9 * C)
-        for (int b = sl; b < nblk; b += 8) a += partial[(long)b * 9 * C + idx];
+        for (int b = sl; b < nblk; b += 32) a += partial[(long)b * 9 * C + idx];
     red[sl][o] = a;
     __syncthreads();
     if (sl == 0 && idx < 9 * C) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += red[k][o];
+        for (int k = 0; k < 32; ++k) v += red[k][o];
         float* dst = dw + (idx % C) * 9 + idx / C;                  // partial is [tap][ci], the parameter (1, C, 3, 3)
         *dst = accumulate ? *dst + v : v;
     }
@@ -684,7 +692,7 @@ extern "C" int hulc_head_conv_dgrad(const float* g, const float* w, int N, int H
 static int head_wgrad_blocks(long R, int C) {
     const int rpp = 256 / (C / 8);                                  // rows per pass of a workgroup
     long nb = (R + 8L * rpp - 1) / (8L * rpp);                      // >= 8 passes per workgroup ...
-    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));            // ... and at most 1024 of them
+    return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));              // ... and at most 512 of them
 }
 extern "C" long hulc_head_conv_wgrad_workspace(int N, int H, int W, int C) {
     return (long)head_wgrad_blocks((long)N * (H + 2) * (W + 2), C) * 9 * C * (long)sizeof(float);
@@ -695,7 +703,7 @@ extern "C" int hulc_head_conv_wgrad(const void* x, long ldx, const float* g, int
     const int nb = head_wgrad_blocks(R, C);
     const int rows = (int)((R + nb - 1) / nb);
     HEAD_DISPATCH(C, (head_conv_wgrad_kernel<CPR><<<nb, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, ldx, g, (int)R, H, W, rows, (float*)ws)))
-    head_conv_wgrad_final_kernel<<<(9 * C + 31) / 32, 256, 0, (hipStream_t)stream>>>((const float*)ws, nb, C, dw, accumulate);
+    head_conv_wgrad_final_kernel<<<(9 * C + 7) / 8, 256, 0, (hipStream_t)stream>>>((const float*)ws, nb, C, dw, accumulate);
     return hulc_check_launch("hulc_head_conv_wgrad");
 }
 #undef HEAD_DISPATCH
