@@ -30,9 +30,10 @@ def _dgrad_w(w, cin_keep=None):      # -> bf16 [Cin'][9 Cout] = the UNflipped (c
     return m if cin_keep is None else m[:cin_keep]
 
 
-def _plain_strides(t):   # (N, H, W, C) contiguous NHWC map -> (tensor, (sn, sy, sx))
-    N, H, W, C = t.shape
-    return t, (H * W * C, W * C, C)
+def _plain_strides(t):   # (N, H, W, C) NHWC map, dense or a grid tensor's pixel view (channels contiguous) -> (tensor, (sn, sy, sx))
+    if t.stride(3) != 1:
+        raise ValueError("feature maps must be channels-last with contiguous channels")
+    return t, tuple(int(v) for v in t.stride()[:3])
 
 
 def _conv_wgrad(dz: "kn.Grid", x: "kn.Grid", w: torch.Tensor, cin: int):

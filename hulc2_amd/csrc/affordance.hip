@@ -514,6 +514,18 @@ __global__ void pixel_ce_bwd_rows_kernel(const float* __restrict__ logit0, const
     g[r] = d;
 }
 
+// a dense NHWC bf16 map -> the padded grid (pixels copied, border rows zero): entry of the frozen trunk's stride-1 stages into hulc_gridconv3x3_fused
+__global__ void grid_from_nhwc_kernel(const uint16_t* __restrict__ x, int R, int H, int W, int C, uint16_t* __restrict__ y, long ldy) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = C / 8, Wp = W + 2, PP = (H + 2) * Wp;
+    if (i >= (long)R * cpr) return;
+    const int r = (int)(i / cpr), ck = (int)(i % cpr);
+    const int n = r / PP, rem = r - n * PP, yy = rem / Wp, xx = rem - yy * Wp;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) v = *(const uint4*)(x + (((long)n * H + (yy - 1)) * W + (xx - 1)) * C + ck * 8);
+    *(uint4*)(y + (long)r * ldy + ck * 8) = v;
+}
+
 // ---- depth head tail: the two 256 -> 1 heads, sigma = exp(clamp(., -20, 2)) and nn.GaussianNLLLoss (depth_gaussian.py:67-69,94-102) ------------
 // one workgroup (B rows of D features, a few KB): replaces ~35 framework launches of the forward + backward pass by two
 __global__ __launch_bounds__(256) void depth_nll_fwd_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ wmu, const float* __restrict__ bmu,
@@ -713,4 +725,12 @@ extern "C" int hulc_pixel_ce_bwd_rows(const float* logit0, const int* p0, const 
     const long n = (long)N * (H + 2) * (W + 2);
     pixel_ce_bwd_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(logit0, p0, lse, upstream, N, H, W, g);
     return hulc_check_launch("hulc_pixel_ce_bwd_rows");
+}
+
+extern "C" int hulc_grid_from_nhwc(const void* x, int N, int H, int W, int C, void* y, long ldy, void* stream) {
+    if (!x || !y || C % 8 || ldy % 8 || ldy < C || ((uintptr_t)x | (uintptr_t)y) % 16) return hulc_fail(-1, "hulc_grid_from_nhwc: bad argument");
+    const long R = (long)N * (H + 2) * (W + 2);
+    const long n = R * (C / 8);
+    grid_from_nhwc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, (int)R, H, W, C, (uint16_t*)y, ldy);
+    return hulc_check_launch("hulc_grid_from_nhwc");
 }

@@ -31,6 +31,9 @@ struct GcP {
     float* stats;
     int R, H, W, Cin, Cout;
     int flip;                       // k-block t reads the rows of tap 8 - t: the data gradient on UNflipped weights [ci][t][co]
+    const float* cbias;             // optional per-channel bias (a folded BatchNorm's shift), then ...
+    const uint16_t* add; long ldadd;   // ... an optional residual branch (grid tensor), then ...
+    int relu;                       // ... an optional ReLU — the frozen ResNet trunk's BasicBlock (hulc_gridconv3x3_fused)
 };
 
 // one k-step of KCH x 32 channels for a wave's TM x TN accumulators; operand rows RS bytes apart (KCH = 1: 80, KCH = 2: 144 — both keep the 16
@@ -138,7 +141,13 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
                 const int row = (wm * TM + i) * 32 + acc_row(e, lane);
                 const int r = r0 + row;
                 const bool ok = rowok[row] != 0;
-                const float v = ok ? acc[i][j][e] : 0.f;
+                float v = 0.f;
+                if (ok) {
+                    v = acc[i][j][e];
+                    if (p.cbias) v += p.cbias[n];
+                    if (p.add) v += bf16_bits_to_f32(p.add[(long)r * p.ldadd + n]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                }
                 s1[j] += v; s2[j] += v * v;
                 if (r < p.R) {
                     if (p.Y) p.Y[(long)r * p.ldy + n] = f32_to_bf16_bits(v);
@@ -261,7 +270,13 @@ __global__ __launch_bounds__(256, OCC) void gridconv_thin_kernel(GcP p, int ntil
             for (int e = 0; e < 16; ++e) {
                 const int row = wave * 32 + acc_row(e, lane);
                 const bool ok = rowok[row] != 0;
-                const float v = ok ? acc[nb][e] : 0.f;
+                float v = 0.f;
+                if (ok) {
+                    v = acc[nb][e];
+                    if (p.cbias) v += p.cbias[n];
+                    if (p.add) v += bf16_bits_to_f32(p.add[(long)(r0 + row) * p.ldadd + n]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                }
                 s1[nb] += v; s2[nb] += v * v;
                 *(uint16_t*)(outs + row * ORS + (nb * 32 + r) * 2) = f32_to_bf16_bits(v);
                 if (p.out0 && n == 0 && r0 + row < p.R) p.out0[r0 + row] = ok ? v + (p.bias ? p.bias[0] : 0.f) : 0.f;
@@ -307,8 +322,23 @@ extern "C" long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout) {
     return ((R + GC_BM - 1) / GC_BM) * 2 * Cout * (long)sizeof(float);
 }
 
+static int gridconv_launch(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps,
+                           float* stats, float* out0, const float* bias0, const float* cbias, const void* add, long ldadd, int relu, void* stream);
+
 extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps,
                                 float* stats, float* out0, const float* bias0, void* stream) {
+    return gridconv_launch(x, ldx, wt, y, ldy, N, H, W, Cin, Cout, flip_taps, stats, out0, bias0, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int hulc_gridconv3x3_fused(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, const float* bias,
+                                      const void* add, long ldadd, int relu, void* stream) {
+    if (!y) return hulc_fail(-1, "hulc_gridconv3x3_fused: null pointer");
+    if (add && (ldadd < Cout)) return hulc_fail(-3, "hulc_gridconv3x3_fused: residual rows shorter than Cout");
+    return gridconv_launch(x, ldx, wt, y, ldy, N, H, W, Cin, Cout, 0, nullptr, nullptr, nullptr, bias, add, ldadd, relu, stream);
+}
+
+static int gridconv_launch(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps,
+                           float* stats, float* out0, const float* bias0, const float* cbias, const void* add, long ldadd, int relu, void* stream) {
     if (!x || !wt || (!y && !out0)) return hulc_fail(-1, "hulc_gridconv3x3: null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 32 || Cin <= 0 || Cout % 32 || Cout <= 0) return hulc_fail(-2, "hulc_gridconv3x3: Cin and Cout must be positive multiples of 32");
     if (ldx % 8 || ldx < Cin || (y && (ldy < Cout)) || (uintptr_t)x % 16 || (uintptr_t)wt % 16) return hulc_fail(-3, "hulc_gridconv3x3: rows must be 16-byte aligned");
@@ -316,7 +346,7 @@ extern "C" int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y
     if (R >= (1L << 31) / 2) return hulc_fail(-2, "hulc_gridconv3x3: grid too large");
     GcP p;
     p.X = (const uint16_t*)x; p.ldx = ldx; p.Wt = (const uint16_t*)wt; p.ldw = 9L * Cin; p.Y = (uint16_t*)y; p.ldy = ldy;
-    p.out0 = out0; p.bias = bias0; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.flip = flip_taps ? 1 : 0;
+    p.out0 = out0; p.bias = bias0; p.cbias = cbias; p.add = (const uint16_t*)add; p.ldadd = ldadd; p.relu = relu; p.stats = stats; p.R = (int)R; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.flip = flip_taps ? 1 : 0;
     const unsigned gx = (unsigned)((R + GC_BM - 1) / GC_BM);
     hipStream_t s = (hipStream_t)stream;
     // thin layers: persistent workgroups with the filter in registers (gridconv_thin_kernel)

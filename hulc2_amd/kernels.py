@@ -1042,6 +1042,29 @@ def gridconv3x3(x: Grid, wt, Cout, want_stats=False, y: "Grid" = None, out0=None
     return y, stats
 
 
+def gridconv3x3_fused(x: Grid, wt, Cout, bias=None, add: "Grid" = None, relu=False) -> Grid:
+    """y = [relu](conv3x3(x) + bias [+ add]) on the grid (a frozen ResNet BasicBlock's convolutions, BatchNorm folded); wt bf16 [Cout][9 Cin]"""
+    _require_cuda(x.rows, wt, bias)
+    if wt.dtype != torch.bfloat16 or tuple(wt.shape) != (Cout, 9 * x.C) or not wt.is_contiguous():
+        raise _L.HulcKernelError("gridconv3x3_fused: weights are bf16 [Cout][9 * Cin]")
+    if add is not None and (add.C != Cout or (add.N, add.H, add.W) != (x.N, x.H, x.W)):
+        raise _L.HulcKernelError("gridconv3x3_fused: the residual branch must be a grid tensor shaped like the output")
+    y = Grid(x.N, x.H, x.W, Cout, x.rows.device)
+    _call("hulc_gridconv3x3_fused", x.t, _l(x.C), wt, y.t, _l(Cout), _i(x.N), _i(x.H), _i(x.W), _i(x.C), _i(Cout), bias,
+          (add.t if add is not None else None), _l(add.C if add is not None else 0), _i(1 if relu else 0),
+          key=("gridconv3x3", x.N, x.H, x.W, x.C, Cout), flops=2.0 * x.R * 9 * x.C * Cout, nbytes=float(x.R) * (x.C + Cout * (2 if add is not None else 1)) * 2 + Cout * 9 * x.C * 2)
+    return y
+
+
+def grid_from_nhwc(x) -> Grid:
+    """dense (N, H, W, C) bf16 -> grid tensor (border rows zero)"""
+    _require_contiguous(x=x)
+    N, H, W, C = x.shape
+    g = Grid(N, H, W, C, x.device)
+    _call("hulc_grid_from_nhwc", x, _i(N), _i(H), _i(W), _i(C), g.t, _l(C))
+    return g
+
+
 _bn_ctr = {}
 
 

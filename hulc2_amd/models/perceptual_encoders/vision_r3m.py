@@ -178,16 +178,35 @@ class VisionR3M(nn.Module):
         a = kn.maxpool_nhwc(a, torch.empty((n, ph, pw, 64), dtype=adt, device=dev), n, h, w, 64, 3, 2, 1)
         h, w, c = ph, pw, 64
         maps = [a]
+        # HULC_TRUNK_GRID=1 (bf16): the thirteen stride-1 3 x 3 convolutions on the padded grid (csrc/gridconv.hip with the BasicBlock epilogue);
+        # a stage's first block (stride 2 + 1 x 1 shortcut) stays on the gather kernel and its outputs are put on the grid.  OFF by default —
+        # measured twice: the gather kernel is the faster one at the trunk's channel counts (1024 frames of 150 x 200: 64 -> 64 at 38 x 50
+        # 287 TFLOP/s on the grid against ~450 gathered, whole step 19.4 vs 12.9 ms; 32 images of 224 x 224: 5.03 vs 4.99 ms).
+        on_grid = adt == torch.bfloat16 and os.environ.get("HULC_TRUNK_GRID", "0") == "1"
+        ag = kn.grid_from_nhwc(a) if on_grid else None
         for bi, (c1, c2, ds, stride) in enumerate(f["blocks"]):
-            idn = a if ds is None else conv(a, ds, h, w, c, 1, stride, 0, False)[0]
-            o, oh, ow = conv(a, c1, h, w, c, 3, stride, 1, True)
-            c = c1[0].shape[0]
-            a, h, w = conv(o, c2, oh, ow, c, 3, 1, 1, True, add=idn)
+            if on_grid:
+                if ds is None and stride == 1:
+                    o = kn.gridconv3x3_fused(ag, c1[0], c1[0].shape[0], bias=c1[1], relu=True)
+                    ag = kn.gridconv3x3_fused(o, c2[0], c2[0].shape[0], bias=c2[1], add=ag, relu=True)
+                else:
+                    a = ag.interior().contiguous()
+                    idn = kn.grid_from_nhwc(conv(a, ds, h, w, c, 1, stride, 0, False)[0])
+                    o, h, w = conv(a, c1, h, w, c, 3, stride, 1, True)
+                    c = c1[0].shape[0]
+                    ag = kn.gridconv3x3_fused(kn.grid_from_nhwc(o), c2[0], c, bias=c2[1], add=idn, relu=True)
+                a = ag.interior()
+            else:
+                idn = a if ds is None else conv(a, ds, h, w, c, 1, stride, 0, False)[0]
+                o, oh, ow = conv(a, c1, h, w, c, 3, stride, 1, True)
+                c = c1[0].shape[0]
+                a, h, w = conv(o, c2, oh, ow, c, 3, 1, 1, True, add=idn)
             if bi % 2 == 1:                                    # ResNet-18: two BasicBlocks per stage
                 maps.append(a)
         if want_maps:
             return maps
         feat = torch.empty((n, c), dtype=torch.float32, device=dev)
+        a = a.contiguous()                                     # (a grid view on the bf16 path: 25-49 pixels per frame)
         kn.strided_seq_sum(a, feat, n, h * w, c, h * w * c, c, c, 1.0 / (h * w))
         return feat
 

@@ -375,6 +375,13 @@ int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_byte
  *   = g * the s x s block sums of dX's first Cx channels, dg (N, Cx) (+)= sum over pixels of x * block sums (either may be NULL).
  * hulc_pixel_ce_fwd / _bwd: log-sum-exp over an image's H W logits (logit0: fp32 per grid row) and the labelled pixel's logit
  *   (p0 (N, 2) int32 = row, col); backward writes upstream (softmax - onehot) / (N H W) into channel 0 of a grid tensor of C channels. */
+/* hulc_gridconv3x3_fused: the same convolution with the epilogue of a frozen ResNet BasicBlock (torchvision resnet18 as r3m wraps it; BatchNorm
+ *   folded into wt and bias by the host): y = [relu](conv(x) + bias[co] [+ add[r][co]]) on the pixels, border rows zero; add = the residual
+ *   branch as a grid tensor (rows ldadd apart), bias fp32 [Cout] — each may be NULL.   hulc_grid_from_nhwc: a dense (N, H, W, C) bf16 map onto
+ *   the grid (border rows zero). */
+int hulc_gridconv3x3_fused(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, const float* bias,
+                           const void* add, long ldadd, int relu, void* stream);
+int hulc_grid_from_nhwc(const void* x, int N, int H, int W, int C, void* y, long ldy, void* stream);
 long hulc_gridconv_stats_bytes(int N, int H, int W, int Cout);
 int hulc_gridconv3x3(const void* x, long ldx, const void* wt, void* y, long ldy, int N, int H, int W, int Cin, int Cout, int flip_taps, float* stats,
                      float* out0, const float* bias0, void* stream);

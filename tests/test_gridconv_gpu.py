@@ -234,6 +234,29 @@ def test_pixel_cross_entropy_with_head():
     assert float(from_grid(DZ)[:, 1:].abs().max()) == 0.0 and borders_zero(DZ)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 9, 64, 64), (2, 7, 7, 128, 128), (3, 20, 20, 64, 32), (1, 14, 14, 256, 256), (2, 12, 10, 32, 32)])
+@pytest.mark.parametrize("with_add,relu", [(True, True), (False, True), (True, False)])
+def test_gridconv_basic_block_epilogue(N, H, W, Cin, Cout, with_add, relu):
+    """hulc_gridconv3x3_fused (the frozen ResNet trunk's BasicBlock convolutions: folded-BatchNorm bias, residual branch, ReLU) and
+    hulc_grid_from_nhwc against fp64 conv2d on the bf16-rounded operands"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, H, W, generator=g)
+    X = kn.grid_from_nhwc(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev))
+    assert borders_zero(X) and torch.equal(from_grid(X), x.to(torch.bfloat16).float())
+    A = kn.grid_from_nhwc(res.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)) if with_add else None
+    Y = kn.gridconv3x3_fused(X, fwd_weights(w).to(dev), Cout, bias=b.to(dev), add=A, relu=relu)
+    torch.cuda.synchronize()
+    want = F.conv2d(bf(x), bf(w), b.double(), padding=1) + (bf(res) if with_add else 0)
+    if relu:
+        want = want.relu()
+    assert borders_zero(Y)
+    assert (from_grid(Y).double() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("N,H,W,C", [(3, 11, 13, 32), (2, 40, 37, 64), (5, 60, 64, 8), (2, 200, 190, 32)])
 def test_one_channel_head_streaming_kernels(N, H, W, C):
     """hulc_head_conv_fwd / _dgrad / _wgrad + hulc_pixel_ce_bwd_rows (the head without matrix cores) against fp64 conv2d autograd on the
