@@ -352,10 +352,12 @@ static int gridconv_launch(const void* x, long ldx, const void* wt, void* y, lon
     // thin layers: persistent workgroups with the filter in registers (gridconv_thin_kernel)
     static const int thin = getenv("HULC_GRIDCONV_THIN") ? atoi(getenv("HULC_GRIDCONV_THIN")) : 1;
     if (thin && ldy % 8 == 0 && (!y || (uintptr_t)y % 16 == 0) && ((Cin == 32 && (Cout == 32 || Cout == 64)) || (Cin == 64 && (Cout == 32 || (thin > 1 && Cout == 64))))) {
-        int ncu = 256;
-        { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
-        static int ncu_cached = 0;
-        if (!ncu_cached) ncu_cached = ncu;
+        static int ncu_cached = 0;                                  // (one device model per process: the count is asked once)
+        if (!ncu_cached) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            ncu_cached = n;
+        }
         static const int occ3 = getenv("HULC_GRIDCONV_THIN_OCC3") ? atoi(getenv("HULC_GRIDCONV_THIN_OCC3")) : 1;
 #define GT_LAUNCH(CINv, NBv, GYv, OCCv)                                                                                \
         {                                                                                                              \

@@ -208,3 +208,19 @@ def test_training_loop_tracks_the_oracle_and_replays_as_a_graph():
     l1 = float(tr.replay())
     l2 = float(tr.replay())
     assert l1 == l1 and l2 < got[0] and l2 <= l1 * 1.05, (got, l1, l2)
+
+
+def test_trunk_on_the_grid_option_matches_the_default_trunk(monkeypatch):
+    """HULC_TRUNK_GRID=1 (the stride-1 BasicBlock convolutions through hulc_gridconv3x3_fused; an opt-in, slower than the gather kernel at
+    these sizes) hands out the same five maps as strided views"""
+    dev = _dev()
+    m, sd, own = build(64, 3, dev)
+    syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in m.model.aff_stream.r3m.convnet.state_dict().items()}, 3)
+    img = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    base = [f.float().clone() for f in m.trunk_maps(img)]
+    monkeypatch.setenv("HULC_TRUNK_GRID", "1")
+    alt = m.trunk_maps(img)
+    torch.cuda.synchronize()
+    assert not alt[-1].is_contiguous()                       # a grid tensor's pixel view
+    for a, b in zip(alt, base):
+        assert a.shape == b.shape and (a.float() - b).abs().max().item() <= 3e-2 * b.abs().max().item()
