@@ -241,7 +241,16 @@ def spawn_ranks(n: int) -> int:
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, stdout=out))
     rc = 0
+    limit = float(os.environ.get("HULC_BENCH_LIMIT_S", "1500"))       # all ranks stuck (a collective nobody completes): give up instead of waiting forever
+    t_start = time.time()
     while any(p.poll() is None for p in procs):
+        if time.time() - t_start > limit:
+            print(f"[bench] the ranks did not finish within {limit:.0f} s (HULC_BENCH_LIMIT_S): ending them", file=sys.stderr)
+            rc = 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                          # exactly the PIDs started above
+            break
         bad = [p for p in procs if p.poll() not in (None, 0)]
         if bad:                                            # one rank died: the others would wait in a collective forever
             rc = bad[0].returncode or 1
@@ -329,7 +338,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(_free_port())
-        kw = dict(rank=rank, world_size=world)
+        import datetime
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("HULC_BENCH_DIST_TIMEOUT_S", "600"))))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, **kw)
         else:

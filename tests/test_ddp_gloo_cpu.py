@@ -1,5 +1,6 @@
 """Data-parallel path on CPU: world_size-2 gloo run of the gradient arena + bucketed all-reduce of
 hulc2_amd/trainer.py (the RCCL path uses the same code with backend 'nccl')."""
+import datetime
 import os
 import socket
 import sys
@@ -13,6 +14,19 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+def _join_or_end(procs, seconds):
+    """wait for the ranks; a rank still alive after `seconds` is ended (this test started exactly these processes) so that neither the assertion
+    nor the interpreter's exit waits on it"""
+    for p in procs:
+        p.join(seconds)
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.kill()
+        p.join(10)
+    assert not stuck, f"{len(stuck)} rank(s) did not finish within {seconds} s"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -23,7 +37,7 @@ def _free_port():
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))     # (default: 30 min of waiting for a rank that died)
     from hulc2_amd.trainer import ArenaTrainer
 
     torch.manual_seed(0)                                   # identical replicas
@@ -68,9 +82,7 @@ def test_gradient_buckets_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    _join_or_end(procs, 120)
     assert q.get(timeout=5) is True
 
 
@@ -90,7 +102,7 @@ def test_bucket_layout_is_contiguous_and_covers_arena():
 
 def _comm_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))     # (default: 30 min of waiting for a rank that died)
     from hulc2_amd.trainer import GradComm
 
     n = 1003                                               # not a multiple of 8 * world: exercises the zero-padded tail chunk
@@ -129,9 +141,7 @@ def test_gradient_allreduce_algorithms_world2():
     procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    _join_or_end(procs, 120)
     res = q.get(timeout=5)
     assert len(res) == 4
     for key, flags in res.items():

@@ -3,6 +3,7 @@ hulc2_amd/trainer.py on the GPU — eager bucketed all-reduce overlapped with ba
 arena all-reduce between the two graphs (what bench.py runs with --gpus N; there the backend is "nccl" = RCCL, one GPU per
 rank).  Both ranks must stay bit-identical replicas.  Sharing a GPU between processes is exactly the situation the
 device-wide-barrier RNN kernel must not run in, so those are switched off here (HULC_NO_RNN_WAVEFRONT, HULC_NO_MLP_CHAIN)."""
+import datetime
 import os
 import socket
 import sys
@@ -18,6 +19,19 @@ sys.path.insert(0, str(ROOT))
 pytestmark = pytest.mark.gpu
 
 
+def _join_or_end(procs, seconds):
+    """wait for the ranks; a rank still alive after `seconds` is ended (this test started exactly these processes) so that neither the assertion
+    nor the interpreter's exit waits on it"""
+    for p in procs:
+        p.join(seconds)
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.kill()
+        p.join(10)
+    assert not stuck, f"{len(stuck)} rank(s) did not finish within {seconds} s"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -31,7 +45,7 @@ def _worker(rank, world, port, graph, out, real_world=False):
                       HULC_NO_RNN_WAVEFRONT="1", HULC_NO_MLP_CHAIN="1")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))     # (default: 30 min of waiting for a rank that died)
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
     from hulc2_amd.config import default_model_config, real_world_model_config
@@ -76,9 +90,7 @@ def test_two_ranks_stay_identical(graph, real_world):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, graph, q, real_world)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_or_end(procs, 300)
     ok, losses, sums = q.get(timeout=5)
     assert ok, f"replicas diverged or non-finite loss: losses {losses}, parameter checksums {sums}"
 
