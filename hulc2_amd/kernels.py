@@ -1087,7 +1087,8 @@ def grid_bn_finalize(stats, N, H, W, C, gamma, beta, run_mean=None, run_var=None
 
 def grid_bn_relu_fwd(y: Grid, bn) -> Grid:
     out = Grid(y.N, y.H, y.W, y.C, y.rows.device)
-    _call("hulc_grid_bn_relu_fwd", y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), out.t, _l(out.C), nbytes=float(y.R) * y.C * 4)
+    _call("hulc_grid_bn_relu_fwd", y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), out.t, _l(out.C), key=("grid_bn_relu_fwd", y.N, y.H, y.W, y.C),
+          nbytes=float(y.R) * y.C * 4)
     return out
 
 
@@ -1097,7 +1098,8 @@ def grid_bn_relu_bwd(dout: Grid, out: Grid, y: Grid, bn, dgamma, dbeta, accumula
     lib.hulc_grid_bn_bwd_workspace.restype = _c.c_long
     ws = _ws(lib.hulc_grid_bn_bwd_workspace(_i(y.N), _i(y.H), _i(y.W), _i(y.C)), y.rows.device)
     _call("hulc_grid_bn_relu_bwd", dout.t, _l(dout.C), out.t, _l(out.C), y.t, _l(y.C), bn, _i(y.N), _i(y.H), _i(y.W), _i(y.C), dz.t, _l(dz.C), dgamma, dbeta,
-          _i(accumulate), ws, _bn_counters(y.rows.device), nbytes=float(y.R) * y.C * 14)
+          _i(accumulate), ws, _bn_counters(y.rows.device), key=("grid_bn_relu_bwd", y.N, y.H, y.W, y.C),      # (one shape per table row: ten layers of
+          nbytes=float(y.R) * y.C * 14)                                                                         # different sizes must not be averaged)
     return dz
 
 
@@ -1105,7 +1107,8 @@ def grid_upcat_fwd(x, xs, g, skip, ss, N, Ho, Wo, s, Cx, Cs) -> Grid:
     """x / skip: (tensor at pixel (0,0,0), stride_n, stride_y, stride_x) strided bf16 maps; g (N, Cx) fp32 or None"""
     out = Grid(N, Ho, Wo, Cx + Cs, x.device)
     _call("hulc_grid_upcat_fwd", x, _l(xs[0]), _l(xs[1]), _l(xs[2]), g, skip, _l(ss[0] if skip is not None else 0), _l(ss[1] if skip is not None else 0),
-          _l(ss[2] if skip is not None else 0), _i(N), _i(Ho), _i(Wo), _i(s), _i(Cx), _i(Cs), out.t, nbytes=float(out.R) * out.C * 4)
+          _l(ss[2] if skip is not None else 0), _i(N), _i(Ho), _i(Wo), _i(s), _i(Cx), _i(Cs), out.t, key=("grid_upcat_fwd", N, Ho, Wo, Cx + Cs),
+          nbytes=float(out.R) * out.C * 4)
     return out
 
 
@@ -1113,7 +1116,7 @@ def grid_upcat_bwd(dX: Grid, x, xs, g, N, Hi, Wi, s, Cx, want_dsmall=True, want_
     dsmall = Grid(N, Hi, Wi, Cx, dX.rows.device) if want_dsmall else None
     dg = torch.empty(N, Cx, dtype=torch.float32, device=dX.rows.device) if want_dg else None
     _call("hulc_grid_upcat_bwd", dX.t, _l(dX.C), x, _l(xs[0]), _l(xs[1]), _l(xs[2]), g, _i(N), _i(Hi), _i(Wi), _i(s), _i(Cx),
-          (dsmall.t if dsmall is not None else None), dg, _i(0), nbytes=float(dX.R) * Cx * 2)
+          (dsmall.t if dsmall is not None else None), dg, _i(0), key=("grid_upcat_bwd", N, Hi, Wi, Cx), nbytes=float(dX.R) * Cx * 2)
     return dsmall, dg
 
 
@@ -1127,7 +1130,7 @@ def pixel_ce_fwd(logit0, p0, N, H, W):
 def head_conv_fwd(x: Grid, w, bias):
     """the one-channel head on the grid: -> logit0 fp32 [R] (bias added on the pixels, zero on the border)"""
     out0 = torch.empty(x.R, dtype=torch.float32, device=x.rows.device)
-    _call("hulc_head_conv_fwd", x.t, _l(x.C), w, bias, _i(x.N), _i(x.H), _i(x.W), _i(x.C), out0)
+    _call("hulc_head_conv_fwd", x.t, _l(x.C), w, bias, _i(x.N), _i(x.H), _i(x.W), _i(x.C), out0, flops=2.0 * x.R * 9 * x.C, nbytes=float(x.R) * (x.C * 2 + 4))
     return out0
 
 
@@ -1139,7 +1142,7 @@ def pixel_ce_bwd_rows(logit0, p0, lse, upstream, N, H, W):
 
 def head_conv_dgrad(g, w, N, H, W, C) -> Grid:
     dx = Grid(N, H, W, C, g.device)
-    _call("hulc_head_conv_dgrad", g, w, _i(N), _i(H), _i(W), _i(C), dx.t, _l(C))
+    _call("hulc_head_conv_dgrad", g, w, _i(N), _i(H), _i(W), _i(C), dx.t, _l(C), flops=2.0 * dx.R * 9 * C, nbytes=float(dx.R) * (C * 2 + 4))
     return dx
 
 
@@ -1156,7 +1159,8 @@ def head_conv_wgrad(x: Grid, g, dw, accumulate=False):
         ws = torch.empty(need // 4 + 16, dtype=torch.float32, device=x.rows.device)
         if not torch.cuda.is_current_stream_capturing():
             _head_ws[key] = ws
-    _call("hulc_head_conv_wgrad", x.t, _l(x.C), g, _i(x.N), _i(x.H), _i(x.W), _i(x.C), dw, _i(1 if accumulate else 0), ws)
+    _call("hulc_head_conv_wgrad", x.t, _l(x.C), g, _i(x.N), _i(x.H), _i(x.W), _i(x.C), dw, _i(1 if accumulate else 0), ws, flops=2.0 * x.R * 9 * x.C,
+          nbytes=float(x.R) * (x.C * 2 + 4))
 
 
 def depth_nll_fwd(x, w_mu, b_mu, w_sigma, b_sigma, target):
