@@ -345,7 +345,9 @@ typedef struct hulc_wgrad_item {
     int store_rows;                  /* > 0: only rows m < store_rows of the product (and of rowsum) are stored — A padded with zero columns */
     int conv_taps_wp;                /* > 0 (with col_mul 9, no rowsum): the item is the nine taps of a 3 x 3 convolution's weight gradient on the padded
                                       * grid of width conv_taps_wp = W + 2 — tap u = 3 (dy + 1) + (dx + 1) multiplies A with B shifted by dy conv_taps_wp + dx
-                                      * rows and writes C + u; the taps of a tile run side by side and share the cached operands */
+                                      * rows and writes C + u.  bf16 operands with M, N multiples of 64 (or 32) run as nine-tap tiles (wgrad_taps.hip: dZ staged once and X as
+                                      * three row windows per k-step, a second launch sums the fp32 slabs of split tiles in a fixed order); other shapes as
+                                      * nine neighbouring 64 x 64 tiles of the grouped kernel */
 } hulc_wgrad_item;
 long hulc_wgrad_group_workspace(const hulc_wgrad_item* items, int n);
 int hulc_wgrad_group(const hulc_wgrad_item* items, int n, void* ws, long ws_bytes, void* stream);
