@@ -100,7 +100,8 @@ def test_gridconv_forward_dgrad_wgrad(N, H, W, Cin, Cout):
 # (N, H, W, Cin, Cout): every wave arrangement of csrc/wgrad_taps.hip (64 x 64 blocks, 32 output / input channels, both), ragged last k-step
 # (rows % 64 == 32), one slice and split tiles (> 64 k-steps; > 256 for the 32 x 32 arrangement), several tiles per item
 TAP_SHAPES = [(2, 6, 5, 64, 64), (1, 30, 17, 192, 128), (4, 40, 40, 64, 128), (3, 9, 9, 64, 32), (2, 30, 30, 32, 64), (5, 62, 62, 64, 32),
-              (8, 46, 46, 32, 32), (2, 11, 7, 32, 32), (2, 14, 14, 768, 512)]
+              (8, 46, 46, 32, 32), (2, 11, 7, 32, 32), (2, 14, 14, 768, 512),
+              (1, 7, 7, 32, 32), (1, 7, 7, 64, 32), (1, 7, 7, 32, 64), (1, 7, 7, 128, 64)]        # 96 rows: the last k-step is half empty in every wave arrangement
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", TAP_SHAPES)
@@ -135,6 +136,41 @@ def test_nine_tap_weight_gradient(N, H, W, Cin, Cout):
         kn.wgrad(A, B, one, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, col_mul=9, store_rows=1, conv_taps_wp=W + 2)
         torch.cuda.synchronize()
         assert (one.cpu().double() - wr.grad.view(Cout, -1)[:1]).abs().max().item() <= 2e-5 * (N * H * W) ** 0.5 * 4 + 1e-4
+
+
+def test_nine_tap_items_beyond_one_launch_table():
+    """twenty nine-tap items in one hulc_wgrad_group call (the kernel's item table holds 16: two launches, slab regions one after the other)
+    next to three ordinary products"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    q = kn._wg_pending.setdefault(dev, [])
+    want, outs = [], []
+    for i in range(20):
+        N, H, W = 2, 9 + i % 3, 40 + i                                  # > 64 k-steps for some: split tiles among unsplit ones
+        Cin, Cout = (64, 32) if i % 2 else (32, 64)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        dy = torch.randn(N, Cout, H, W, generator=g)
+        wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(bf(x), wr, padding=1).backward(bf(dy))
+        X, DY = to_grid(x, dev), to_grid(dy, dev)
+        dw = torch.full((Cout, Cin * 9), float("nan"), device=dev)
+        q.append((DY.rows[DY.guard:DY.guard + DY.Rpad], X.rows[X.guard:X.guard + X.Rpad], dw, None, Cout, Cin, X.Rpad, Cout, Cin, Cin * 9, False, False, 0, 9, 0, W + 2))
+        want.append(wr.grad)
+        outs.append((dw, X, DY))
+    plain = []
+    for M, Nn, K in [(64, 128, 256), (8, 24, 96), (200, 72, 64)]:
+        A, B = torch.randn(K, M, generator=g).to(dev), torch.randn(K, Nn, generator=g).to(dev)
+        C = torch.empty(M, Nn, device=dev)
+        q.append((A, B, C, None, M, Nn, K, M, Nn, Nn, False, False, 0, 1, 0, 0))
+        plain.append((A, B, C))
+    kn.wgrad_flush(dev)
+    torch.cuda.synchronize()
+    for (dw, X, DY), w in zip(outs, want):
+        got = dw.view(w.shape).cpu().double()
+        assert torch.isfinite(got).all() and (got - w).abs().max().item() <= 2e-5 * X.R ** 0.5 * 4 + 1e-4
+    for A, B, C in plain:
+        ref = A.to(torch.bfloat16).double().t() @ B.to(torch.bfloat16).double()
+        assert (C.double() - ref).abs().max().item() <= 1e-3
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 7, 5, 64), (3, 12, 12, 32), (2, 5, 9, 128)])
