@@ -381,15 +381,17 @@ def add_layer_norm(x, o, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
 class AddPosFn(torch.autograd.Function):
-    """dropout(x + pos[position_ids]) — plan_recognition_net.py:133-136,142."""
+    """dropout(x + pos[position_ids]) — plan_recognition_net.py:133-136,142.  identity: position_ids is arange(S) (what the reference passes):
+    the table's gradient is then the batch sum itself and goes straight into the trainer's gradient sink."""
 
     @staticmethod
-    def forward(ctx, x, pos, pos_ids, drop_p: float, seed: int):
+    def forward(ctx, x, pos, pos_ids, drop_p: float, seed: int, identity: bool = False):
         B, S, D = x.shape
         y = _f32(B, S, D, like=x)
         kn.add_pos_fwd(_c(x), pos, pos_ids, y, B, S, D, drop_p, seed)
         ctx.save_for_backward(pos_ids)
         ctx.meta = (B, S, D, drop_p, seed, pos.shape)
+        ctx.pos = pos if identity else None
         return y
 
     @staticmethod
@@ -402,11 +404,19 @@ class AddPosFn(torch.autograd.Function):
             kn.dropout_bwd(dy, dx, dy.numel(), drop_p, seed)
         else:
             dx = dy
+        sink = gradsink.get(ctx.pos) if ctx.pos is not None else None
+        if sink is not None and dx.dtype == torch.float32:
+            # rows 0 .. S-1 of the table's gradient = the sum over the batch, written (first writer of the step) or added in place
+            first = gradsink.first_write(ctx.pos)
+            kn.colsum(dx, B, S * D, S * D, sink[:S].view(-1), accumulate=not first)
+            if first and pshape[0] > S:
+                sink[S:].zero_()
+            return dx, None, None, None, None, None
         dsum = _f32(S, D, like=dy)
         kn.colsum(dx, B, S * D, S * D, dsum)                 # sum over the batch
         dpos = torch.zeros(pshape, dtype=torch.float32, device=dy.device)
         dpos.index_copy_(0, pos_ids, dsum)                   # row placement by (unique) position id: a copy, no arithmetic
-        return dx, dpos, None, None, None
+        return dx, dpos, None, None, None, None
 
 
 class SeqMeanFn(torch.autograd.Function):

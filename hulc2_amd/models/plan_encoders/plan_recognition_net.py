@@ -51,12 +51,20 @@ class PlanRecognitionTransformersNetwork(nn.Module):
                 "norm1.weight": m.norm1.weight, "norm1.bias": m.norm1.bias,
                 "norm2.weight": m.norm2.weight, "norm2.bias": m.norm2.bias}
 
+    def _position_ids(self, S: int, device) -> torch.Tensor:
+        """arange(S) (plan_recognition_net.py:133): kept per (length, device) instead of one launch per step"""
+        cache = self.__dict__.setdefault("_pos_id_cache", {})
+        ids = cache.get((S, device))
+        if ids is None:
+            ids = cache[(S, device)] = torch.arange(S, dtype=torch.long, device=device)
+        return ids
+
     def forward(self, perceptual_emb: torch.Tensor) -> Tuple[State, torch.Tensor]:
         B, S, E = perceptual_emb.shape
         p = self.dropout_p if self.training else 0.0
         seed = 0x5EED0001           # site id; the per-step stream comes from the device step state (kernels.step_state)
-        position_ids = torch.arange(S, dtype=torch.long, device=perceptual_emb.device)
-        x = HF.AddPosFn.apply(perceptual_emb, self.position_embeddings.weight, position_ids, p, seed)
+        position_ids = self._position_ids(S, perceptual_emb.device)
+        x = HF.AddPosFn.apply(perceptual_emb, self.position_embeddings.weight, position_ids, p, seed, True)
         x = x.reshape(B * S, E)
         for l in range(self.num_layers):
             x = HF.transformer_encoder_layer(x, self._layer_params(l), B, S, self.num_heads, p, seed + 100 * (l + 1))

@@ -44,7 +44,7 @@ def main():
         trainer.step(batch, i)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         for i in range(steps):
             trainer.step(batch, 3 + i)
         torch.cuda.synchronize()
@@ -58,7 +58,7 @@ def main():
         frames = [f for f in (ev.stack or []) if "hulc2_amd" in f or "bench" in f or "glue_trace" in f]
         where = " <- ".join(f.split("/root/repo/")[-1].split("repo/")[-1] for f in frames[:2]) or "(autograd engine / no repo frame)"
         for k in ev.kernels:
-            rows[(ev.name, k.name[:60], where)] += 1
+            rows[(ev.name, k.name[:60], where + "  shapes " + str(getattr(ev, "input_shapes", ""))[:120])] += 1
     total = 0
     for (op, kname, where), n in sorted(rows.items(), key=lambda kv: -kv[1]):
         total += n
