@@ -359,6 +359,14 @@ template <> bool launch_gather_raw<bf16_t>(const GatherP& p, hipStream_t s) {
     // every wave owns 64 pixels x 64 channels (8 MFMAs per 32-wide k tile): 128 x 128 tiles for wide layers, 256 pixels x 64 channels else
     const bool tall = !wide && p.Cout % 64 == 0 && Mtot >= 256 * 512 && !getenv("HULC_GATHER_M128");
     dim3 grid((unsigned)((Mtot + (tall ? 255 : 127)) / (tall ? 256 : 128)), wide ? p.Cout / 128 : (p.Cout + 63) / 64);
+    // few 128 x 128 tiles (the trunk's 128 / 256 / 512-channel stages at 32 images: 196, 98 and 52 workgroups on 256 CUs; measured 5.02 -> 4.80 ms per affordance step): 64 x 64 tiles, four times the
+    // workgroups — twice the LDS bytes per MFMA, but the chip is filled
+    static const long small_thr = getenv("HULC_GATHER_SMALL") ? atol(getenv("HULC_GATHER_SMALL")) : 256;
+    if (wide && p.inner_log2 >= 5 && (long)grid.x * grid.y < small_thr) {
+        dim3 g64((unsigned)((Mtot + 63) / 64), p.Cout / 64);
+        conv_gather_bf16_kernel<1, 1, 2, 2, true><<<g64, 256, 0, s>>>(p);
+        return true;
+    }
     if (p.inner_log2 >= 5) {
         if (wide) conv_gather_bf16_kernel<2, 2, 2, 2, true><<<grid, 256, 0, s>>>(p);
         else if (tall) conv_gather_bf16_kernel<2, 2, 4, 1, true><<<grid, 256, 0, s>>>(p);
