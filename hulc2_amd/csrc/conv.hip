@@ -364,7 +364,12 @@ template <> bool launch_gather_raw<bf16_t>(const GatherP& p, hipStream_t s) {
     static const long small_thr = getenv("HULC_GATHER_SMALL") ? atol(getenv("HULC_GATHER_SMALL")) : 256;
     if (wide && p.inner_log2 >= 5 && (long)grid.x * grid.y < small_thr) {
         dim3 g64((unsigned)((Mtot + 63) / 64), p.Cout / 64);
-        conv_gather_bf16_kernel<1, 1, 2, 2, true><<<g64, 256, 0, s>>>(p);
+        // 128- / 64-wide k tiles where a tap holds them: these launches are a chain of (load, LDS write, barrier, 2 MFMAs per wave) steps — a quarter /
+        // half as many (affordance step, 32 images: 4.81 ms with 32-wide tiles, 4.67 with 64, 4.57 with 128)
+        static const int kt64 = getenv("HULC_GATHER_SMALL_KT64") ? atoi(getenv("HULC_GATHER_SMALL_KT64")) : 2;
+        if (kt64 >= 2 && p.inner_log2 >= 7) conv_gather_bf16_kernel<1, 1, 2, 2, true, 128><<<g64, 256, 0, s>>>(p);
+        else if (kt64 && p.inner_log2 >= 6) conv_gather_bf16_kernel<1, 1, 2, 2, true, 64><<<g64, 256, 0, s>>>(p);
+        else conv_gather_bf16_kernel<1, 1, 2, 2, true><<<g64, 256, 0, s>>>(p);
         return true;
     }
     if (p.inner_log2 >= 5) {

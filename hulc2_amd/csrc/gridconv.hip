@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     // staging registers are NAMED values in straight-line code (arrays of them end up in scratch memory: DESIGN.md rule 6); the unused ones of a
     // configuration are compile-time dead
     const int ar0 = min(r0 + rw, p.R - 1), ar1 = min(r0 + rw + RPP, p.R - 1), ar2 = min(r0 + rw + 2 * RPP, p.R - 1), ar3 = min(r0 + rw + 3 * RPP, p.R - 1);
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
+    const int ar4 = min(r0 + rw + 4 * RPP, p.R - 1), ar5 = min(r0 + rw + 5 * RPP, p.R - 1), ar6 = min(r0 + rw + 6 * RPP, p.R - 1), ar7 = min(r0 + rw + 7 * RPP, p.R - 1);
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+    ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = ra6 = ra7 = rb0 = rb1 = rb2 = rb3 = rb4 = rb5 = rb6 = rb7 = make_uint4(0u, 0u, 0u, 0u);
     auto tap_off = [&](int t) { const int u = p.flip ? 8 - t : t; return (u / 3 - 1) * Wp + (u % 3 - 1); };
     constexpr bool BFULL = BN * CPR % 256 == 0;                    // every thread holds B chunks in every pass
 #define GC_LA(q) if (q < A_PER) ra##q = *(const uint4*)(p.X + (long)(ar##q + off_) * p.ldx + c0_);
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     {                                                                                                                  \
         const int t_ = (ks_) / kpt, c0_ = ((ks_) - t_ * kpt) * 32 * KCH + ch * 8, off_ = tap_off(t_);                  \
         const long kb_ = (long)t_ * p.Cin + c0_;                                                                       \
-        GC_LA(0) GC_LA(1) GC_LA(2) GC_LA(3) GC_LB(0) GC_LB(1) GC_LB(2) GC_LB(3)                                        \
+        GC_LA(0) GC_LA(1) GC_LA(2) GC_LA(3) GC_LA(4) GC_LA(5) GC_LA(6) GC_LA(7)                                        \
+        GC_LB(0) GC_LB(1) GC_LB(2) GC_LB(3) GC_LB(4) GC_LB(5) GC_LB(6) GC_LB(7)                                        \
     }
 #define GC_SA(q) if (q < A_PER) *(uint4*)(As_ + (rw + q * RPP) * RS + ch * 16) = ra##q;
 #define GC_SB(q) if (q < B_PER && (BFULL || rw + q * RPP < BN)) *(uint4*)(Bs_ + (rw + q * RPP) * RS + ch * 16) = rb##q;
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(256) void gridconv_kernel(GcP p) {
     {                                                                                                                  \
         char* As_ = smem + (stage_) * (GC_BM + BN) * RS;                                                               \
         char* Bs_ = As_ + GC_BM * RS;                                                                                  \
-        GC_SA(0) GC_SA(1) GC_SA(2) GC_SA(3) GC_SB(0) GC_SB(1) GC_SB(2) GC_SB(3)                                        \
+        GC_SA(0) GC_SA(1) GC_SA(2) GC_SA(3) GC_SA(4) GC_SA(5) GC_SA(6) GC_SA(7)                                        \
+        GC_SB(0) GC_SB(1) GC_SB(2) GC_SB(3) GC_SB(4) GC_SB(5) GC_SB(6) GC_SB(7)                                        \
     }
     GC_LOAD(0)
     GC_STORE(0)
@@ -394,7 +397,11 @@ static int gridconv_launch(const void* x, long ldx, const void* wt, void* y, lon
         }                                                                                                              \
         kern<<<dim3(gx, Cout / BNv), 256, lds, s>>>(p);                                                                \
     }
-    if (Cout % 128 == 0) { if (wide) GC_LAUNCH(2, 2, 2, 128) else GC_LAUNCH(2, 2, 1, 128) }
+    // 128-channel k-steps for the layers that put at most one 128 x 128 workgroup on a CU (512-channel maps at 14 x 14): nothing overlaps a
+    // workgroup's barriers there, so fewer, longer k-steps
+    static const int k128 = getenv("HULC_GRIDCONV_K128") ? atoi(getenv("HULC_GRIDCONV_K128")) : 1;
+    if (k128 && Cout % 128 == 0 && Cin % 128 == 0 && Cin >= 256 && (long)gx * (Cout / 128) <= 320) GC_LAUNCH(2, 2, 4, 128)
+    else if (Cout % 128 == 0) { if (wide) GC_LAUNCH(2, 2, 2, 128) else GC_LAUNCH(2, 2, 1, 128) }
     else if (Cout % 64 == 0) { if (wide) GC_LAUNCH(1, 2, 2, 64) else GC_LAUNCH(1, 2, 1, 64) }
     else { if (wide) GC_LAUNCH(1, 1, 2, 32) else GC_LAUNCH(1, 1, 1, 32) }
 #undef GC_LAUNCH
