@@ -221,3 +221,30 @@ def test_trainer_optimizer_state_roundtrip_and_reload_hook():
     assert all(torch.equal(a, b) for a, b in zip(m2.parameters(), m.parameters()))
     with pytest.raises(KeyError):
         tr2.load_state_dict({**sd, "state": {k: v for k, v in list(sd["state"].items())[:-1]}})
+
+
+def test_wgrad_group_workspace_counts_the_nine_tap_slabs():
+    """hulc_wgrad_group_workspace is host arithmetic (no GPU): a conv_taps_wp item that wgrad_taps.hip takes (bf16, 64-multiples) adds its own slab
+    region — tiles x slices x (4 blocks x 9 taps x 1024) floats — behind the grouped kernel's counters; an unsplit one (few rows, many tiles) adds none"""
+    import ctypes
+    from hulc2_amd import lib as L
+    lib = L.load()
+    lib.hulc_wgrad_group_workspace.restype = ctypes.c_long
+    buf = (ctypes.c_char * 64)()                                   # any 16-byte aligned, non-null address: nothing is dereferenced
+    base = ctypes.addressof(buf) // 16 * 16 + 16
+
+    def item(M, N, K, wp, bf16=True):
+        it = L.WgradItem()
+        it.A, it.B, it.C = base, base, base
+        it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, M, N, N * 9
+        it.a_dtype = it.b_dtype = 1 if bf16 else 0               # HULC_BF16 / HULC_F32 (include/hulc2_amd.h)
+        it.col_mul, it.conv_taps_wp = 9, wp
+        return it
+
+    counters = 65536 * 4
+    one = (L.WgradItem * 1)(item(512, 768, 8192, 16))              # 96 tiles, 128 k-steps: one slice per tile, no slabs
+    assert lib.hulc_wgrad_group_workspace(one, 1) == counters
+    split = (L.WgradItem * 1)(item(128, 192, 107648, 58))           # 6 tiles, 1682 k-steps -> 27 slices of 63
+    assert lib.hulc_wgrad_group_workspace(split, 1) == counters + 6 * 27 * (4 * 9 * 16 * 64) * 4
+    f32 = (L.WgradItem * 1)(item(128, 192, 107648, 58, bf16=False))  # fp32 operands stay with the grouped kernel: nine tiles per slice
+    assert lib.hulc_wgrad_group_workspace(f32, 1) > counters and lib.hulc_wgrad_group_workspace(f32, 1) != lib.hulc_wgrad_group_workspace(split, 1)
