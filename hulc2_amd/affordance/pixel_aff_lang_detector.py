@@ -166,6 +166,7 @@ class PixelAffLangDetector(nn.Module):
         """{"aff": (B, H, W, 1) softmax over the pixels — or the (B, H W) logits —, "depth_dist": (mu, sigma)}; BatchNorm by the running
         statistics when the module is in eval mode"""
         B = inp["img"].shape[0]
+        kn.Grid.begin_step()                                   # inference between training steps: recycle the grid buffers here too (else the pool grows)
         feats = self.trunk_maps(inp["img"])
         p0 = torch.zeros(B, 2, dtype=torch.int32, device=inp["img"].device)
         _, info = self.forward_losses(feats, inp["lang_goal"], p0, torch.zeros(B, device=inp["img"].device))
@@ -194,6 +195,7 @@ class PixelAffLangDetector(nn.Module):
         """losses as in training plus the two errors the reference logs: summed pixel distance of the arg-max to the label and summed
         absolute depth error (pixel_aff_lang_detector.py:147-160)"""
         frame, label = batch
+        kn.Grid.begin_step()
         feats = self.trunk_maps(frame["img"])
         depth_key = "normalized_depth" if self.normalize_depth else "depth"
         loss, info = self.forward_losses(feats, frame["lang_goal"], label["p0"], label[depth_key])

@@ -122,6 +122,14 @@ def test_inference_matches_the_reference_fixture():
         assert am[b] == ref[b] or float(lg[b, ref[b]]) >= float(lg[b].max()) - 3e-2 * float(lg[b].abs().max()), (b, int(am[b]), int(ref[b]))
     assert (info["mu"].cpu() - torch.as_tensor(g["eval_mu"])).abs().max().item() < 2e-2
     assert rel(torch.softmax(lg, -1).max(-1).values, g["eval_softmax_max"]) < 5e-2
+    # repeated inference recycles the grid buffers (no growth of the pool between calls)
+    img = torch.randn(B, 3, HW, HW, generator=torch.Generator().manual_seed(0)).to(dev)
+    emb = torch.as_tensor(g["emb"]).to(dev)
+    m.forward({"img": img, "lang_goal": emb})
+    held = sum(len(v) for v in kn.Grid._pool.values())
+    for _ in range(3):
+        m.forward({"img": img, "lang_goal": emb})
+    assert sum(len(v) for v in kn.Grid._pool.values()) == held
 
 
 def test_training_step_matches_the_oracle_with_sinks_and_trunk():
