@@ -6,8 +6,8 @@
 // hulc_wgrad_group ran a conv_taps_wp item as nine independent 64 x 64 tiles per k-slice: every tap staged dZ and its own shifted X again
 // (32 FLOP per staged byte, 4 LDS fragment reads per MFMA) — 1.49 ms per step, 300 TFLOP/s.  Here a work unit owns a 64 (co) x 64 (ci) tile of
 // ALL nine taps over a slice of rows: per 64-row k-step it stages dZ once and three 66-row windows of X (one per dy; the dx = -1 / 0 / +1
-// fragments are the same window read one row apart), 143 FLOP per staged byte, and a wave (32 co x 32 ci x 9 taps = 144 accumulator
-// registers) reads one dZ fragment per nine MFMAs.  Tiles with 32 output or input channels (the last decoder block) let the idle waves take
+// fragments are the same window one row apart: three transposing reads + v_alignbit give all three), 143 FLOP per staged byte, and a wave
+// (32 co x 32 ci x 9 taps = 144 accumulator registers) reads one dZ fragment per nine MFMAs — 11 LDS fragment reads per nine MFMAs.  Tiles with 32 output or input channels (the last decoder block) let the idle waves take
 // every second / fourth 16-row sub-step instead and add their accumulators through LDS at the end.
 // Split tiles write fp32 slabs; a second launch sums them in a fixed order (16 slice groups, then the groups) — no atomics, bit-reproducible.
 #include "hulc_common.h"
@@ -36,7 +36,7 @@ struct TItem {
     int mstore;                              // rows m < mstore are stored (the one-channel head padded to 32 output channels)
     long slab0;                              // first slab (split items)
 };
-struct TapsP { int first[MAXI]; int rfirst[MAXI]; TItem it[MAXI]; int n; float* slabs; };
+struct TapsP { int first[MAXI]; int rfirst[MAXI]; TItem it[MAXI]; int n; float* slabs; int dbg; };
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef v4s __attribute__((address_space(3))) * lds_v4s;
@@ -100,6 +100,9 @@ HULC_DEVICE void taps_unit(const TItem& it, const TapsP& p, int local, char* sme
     }
     const int krow = (lane >> 5) * 8 + ((lane & 15) >> 2), col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
     const int fa = krow * RS + col + bm * 64, fb = (T + krow) * RS + col + bn * 64;
+    // the dx = -1 / 0 / +1 fragments of a window are the same 8 rows shifted by one: three transposing reads (rows 0..3, 4..7, 8..11 of the lane
+    // group) give all three — x = 1 by v_alignbit across the six dwords, x = 2 is dwords 1..4 — instead of six: 11 LDS fragment reads per nine
+    // MFMAs instead of 20 (rows 10, 11 are read and dropped; for the last sub-step they lie behind the window: two rows of LDS slack)
 #define TP_MMA(stage_)                                                                                                 \
     {                                                                                                                  \
         const char* s_ = smem + (stage_) * STAGE_B;                                                                    \
@@ -107,13 +110,19 @@ HULC_DEVICE void taps_unit(const TItem& it, const TapsP& p, int local, char* sme
             const int kk_ = (ks * KP + kq) * 16;                                                                       \
             union { v4s v[2]; bf16x8_t f; } a;                                                                         \
             a.v[0] = tr_read(s_ + fa + kk_ * RS); a.v[1] = tr_read(s_ + fa + (kk_ + 4) * RS);                          \
-            _Pragma("unroll") for (int d = 0; d < 3; ++d)                                                              \
-                _Pragma("unroll") for (int x = 0; x < 3; ++x) {                                                        \
-                    union { v4s v[2]; bf16x8_t f; } b;                                                                 \
-                    const char* qb = s_ + fb + (d * WROWS + kk_ + x) * RS;                                             \
-                    b.v[0] = tr_read(qb); b.v[1] = tr_read(qb + 4 * RS);                                               \
-                    acc[d * 3 + x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f, b.f, acc[d * 3 + x], 0, 0, 0);       \
-                }                                                                                                      \
+            _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                            \
+                const char* qb = s_ + fb + (d * WROWS + kk_) * RS;                                                     \
+                union { v4s v[3]; uint32_t w[6]; } t_;                                                                 \
+                t_.v[0] = tr_read(qb); t_.v[1] = tr_read(qb + 4 * RS); t_.v[2] = tr_read(qb + 8 * RS);                 \
+                union { uint32_t w[4]; bf16x8_t f; } b0, b1, b2;                                                       \
+                b0.w[0] = t_.w[0]; b0.w[1] = t_.w[1]; b0.w[2] = t_.w[2]; b0.w[3] = t_.w[3];                            \
+                b1.w[0] = __builtin_amdgcn_alignbit(t_.w[1], t_.w[0], 16); b1.w[1] = __builtin_amdgcn_alignbit(t_.w[2], t_.w[1], 16);   \
+                b1.w[2] = __builtin_amdgcn_alignbit(t_.w[3], t_.w[2], 16); b1.w[3] = __builtin_amdgcn_alignbit(t_.w[4], t_.w[3], 16);   \
+                b2.w[0] = t_.w[1]; b2.w[1] = t_.w[2]; b2.w[2] = t_.w[3]; b2.w[3] = t_.w[4];                            \
+                acc[d * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f, b0.f, acc[d * 3 + 0], 0, 0, 0);          \
+                acc[d * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f, b1.f, acc[d * 3 + 1], 0, 0, 0);          \
+                acc[d * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f, b2.f, acc[d * 3 + 2], 0, 0, 0);          \
+            }                                                                                                          \
         }                                                                                                              \
     }
     TP_LOAD(step0)
@@ -121,9 +130,9 @@ HULC_DEVICE void taps_unit(const TItem& it, const TapsP& p, int local, char* sme
     __syncthreads();
     for (int st = step0; st + 1 < step1; ++st) {
         const int cur = (st - step0) & 1;
-        TP_LOAD(st + 1)
+        if (!(p.dbg & 1)) TP_LOAD(st + 1)
         __builtin_amdgcn_sched_barrier(0);
-        TP_MMA(cur)
+        if (!(p.dbg & 2)) TP_MMA(cur)
         __builtin_amdgcn_sched_barrier(0);
         TP_STORE(cur ^ 1, st + 1)
         __syncthreads();
@@ -276,8 +285,8 @@ int hulc_wgrad_taps_launch(const hulc_wgrad_item* const* items, int n, void* sla
     static const int occ = getenv("HULC_WGRAD_TAPS_OCC") ? atoi(getenv("HULC_WGRAD_TAPS_OCC")) : 2;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)wgrad_taps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wgrad_taps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_taps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B + 2 * RS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_taps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B + 2 * RS) != hipSuccess)
             return hulc_fail(-8, "hulc_wgrad_group: could not raise the dynamic LDS limit (taps)");
         attr = true;
     }
@@ -289,6 +298,7 @@ int hulc_wgrad_taps_launch(const hulc_wgrad_item* const* items, int n, void* sla
         TapsP p;
         p.n = n - base < MAXI ? n - base : MAXI;
         p.slabs = (float*)slabs;
+        p.dbg = getenv("HULC_TAPS_DBG") ? atoi(getenv("HULC_TAPS_DBG")) : 0;      // timing probes: 1 no global loads, 2 no MFMAs (results are wrong)
         int first = 0, rfirst = 0;
         for (int j = 0; j < MAXI; ++j) p.first[j] = p.rfirst[j] = 0x7fffffff;
         for (int j = 0; j < p.n; ++j) {
@@ -309,8 +319,8 @@ int hulc_wgrad_taps_launch(const hulc_wgrad_item* const* items, int n, void* sla
             for (int j = p.n - 1; j >= 0; --j) { if (p.rfirst[j] == 0x7fffffff) p.rfirst[j] = run; else run = p.rfirst[j]; }
         }
         const int total = (first + 63) / 64 * 64;
-        if (occ == 1) wgrad_taps_kernel<1><<<total, 256, 2 * STAGE_B, s>>>(p);
-        else wgrad_taps_kernel<2><<<total, 256, 2 * STAGE_B, s>>>(p);
+        if (occ == 1) wgrad_taps_kernel<1><<<total, 256, 2 * STAGE_B + 2 * RS, s>>>(p);
+        else wgrad_taps_kernel<2><<<total, 256, 2 * STAGE_B + 2 * RS, s>>>(p);
         if (rfirst > 0) wgrad_taps_reduce_kernel<<<rfirst, 1024, 0, s>>>(p);
     }
     return hulc_check_launch("hulc_wgrad_group (taps)");
