@@ -547,7 +547,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_affordance() if args.affordance else cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
