@@ -310,6 +310,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a five-line version banner to the C stdout of every process that creates a
+    # communicator (and gloo its own chatter), flushed at exit — i.e. AFTER the line.  From here on file descriptor 1 is stderr; the line is
+    # written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj) -> None:
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     if args.dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -317,8 +327,7 @@ def main():
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "rank_sum": t.item(),
-                              "gpus_flag": args.gpus}))
+            emit({"dry_run": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "rank_sum": t.item(), "gpus_flag": args.gpus})
         dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
@@ -546,7 +555,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_affordance() if args.affordance else cpu_baseline()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
