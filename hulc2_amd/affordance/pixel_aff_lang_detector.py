@@ -128,6 +128,12 @@ class PixelAffLangDetector(nn.Module):
             bufs += [b.conv1[1].running_mean, b.conv1[1].running_var, b.conv2[1].running_mean, b.conv2[1].running_var]
         return bufs
 
+    def bn_step_counters(self) -> List[torch.Tensor]:
+        out = []
+        for b in self.model.aff_stream.decoder.blocks:
+            out += [b.conv1[1].num_batches_tracked, b.conv2[1].num_batches_tracked]
+        return out
+
     def depth_features(self, f4: torch.Tensor, l_enc: torch.Tensor) -> torch.Tensor:
         """DepthEstimationGaussian.forward up to fc3 + ReLU (depth_gaussian.py:77-93); f4 NHWC -> the reference flattens (C, H, W)"""
         d = self.model.depth_stream
@@ -157,6 +163,8 @@ class PixelAffLangDetector(nn.Module):
         feats = self.trunk_maps(frame["img"])
         depth_key = "normalized_depth" if self.normalize_depth else "depth"
         loss, info = self.forward_losses(feats, frame["lang_goal"], label["p0"], label[depth_key])
+        if self.training:                                      # nn.BatchNorm2d bumps num_batches_tracked on every training forward: state_dicts stay
+            torch._foreach_add_(self.bn_step_counters(), 1)   # interchangeable with the reference's (one multi-tensor launch for the ten counters)
         self.logged = {"Training/total_loss": loss.detach(), "Training/aff_loss": info["aff_loss"].detach(), "Training/depth_loss": info["depth_loss"].detach()}
         return loss
 

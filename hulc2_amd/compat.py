@@ -72,7 +72,7 @@ def instantiate(cfg, *args, **kwargs):
         return None
     if HAVE_HYDRA and not isinstance(cfg, Config) and type(cfg).__name__ in ("DictConfig",):
         tgt = cfg.get("_target_")
-        if tgt and tgt.startswith("hulc2.") and "hulc2" not in sys.modules:
+        if tgt and tgt.startswith("hulc2.") and not any(isinstance(f, _LeafAliasFinder) for f in sys.meta_path):
             install_as_hulc2()
         return _hydra.utils.instantiate(cfg, *args, **kwargs)
     if not isinstance(cfg, dict):
@@ -112,35 +112,127 @@ class _MiniLightningModule(nn.Module):
 LightningModule = _pl.LightningModule if HAVE_LIGHTNING else _MiniLightningModule
 
 
-def install_as_hulc2() -> None:
-    """Expose this package under the reference's import name so yaml `_target_: hulc2.models...` resolves
-    to the MI355X classes.  Call before Hydra instantiates the model."""
-    import hulc2_amd
+# Reference leaf module -> module of this package.  ONLY leaves are aliased: the reference's own packages
+# (`hulc2`, `hulc2.utils`, `hulc2.datasets`, `hulc2.models`, `hulc2.affordance`, ...) stay what they are, so everything
+# else `hulc2/training.py:20-25,40,95` imports (utils.utils, kl_callbacks, the data modules, the rollout callbacks,
+# the transforms) keeps coming from the reference tree.
+LEAF_ALIASES = {
+    "hulc2.models.hulc2": "hulc2_amd.models.hulc2",                                       # conf/model/calvin_hulc++.yaml:14
+    "hulc2.models.perceptual_encoders.concat_encoders": "hulc2_amd.models.perceptual_encoders.concat_encoders",
+    "hulc2.models.perceptual_encoders.vision_network": "hulc2_amd.models.perceptual_encoders.vision_network",
+    "hulc2.models.perceptual_encoders.vision_network_gripper": "hulc2_amd.models.perceptual_encoders.vision_network_gripper",
+    "hulc2.models.perceptual_encoders.vision_r3m": "hulc2_amd.models.perceptual_encoders.vision_r3m",
+    "hulc2.models.encoders.goal_encoders": "hulc2_amd.models.encoders.goal_encoders",
+    "hulc2.models.plan_encoders.plan_proposal_net": "hulc2_amd.models.plan_encoders.plan_proposal_net",
+    "hulc2.models.plan_encoders.plan_recognition_net": "hulc2_amd.models.plan_encoders.plan_recognition_net",
+    "hulc2.models.decoders.action_decoder": "hulc2_amd.models.decoders.action_decoder",
+    "hulc2.models.decoders.logistic_decoder_rnn": "hulc2_amd.models.decoders.logistic_decoder_rnn",
+    "hulc2.models.auxiliary_loss_networks.proj_vis_lang": "hulc2_amd.models.auxiliary_loss_networks.proj_vis_lang",
+    "hulc2.utils.distributions": "hulc2_amd.utils.distributions",
+    "hulc2.affordance.models.language_encoders.sbert_lang_encoder": "hulc2_amd.models.language_encoders.sbert_lang_encoder",
+    "hulc2.affordance.pixel_aff_lang_detector": "hulc2_amd.affordance.pixel_aff_lang_detector",   # conf/affordance/aff_detection/r3m.yaml
+}
 
-    names = [
-        "hulc2_amd", "hulc2_amd.models", "hulc2_amd.models.hulc2", "hulc2_amd.models.perceptual_encoders",
-        "hulc2_amd.models.perceptual_encoders.concat_encoders", "hulc2_amd.models.perceptual_encoders.vision_network",
-        "hulc2_amd.models.perceptual_encoders.vision_network_gripper", "hulc2_amd.models.perceptual_encoders.vision_r3m",
-        "hulc2_amd.models.encoders",
-        "hulc2_amd.models.encoders.goal_encoders", "hulc2_amd.models.plan_encoders",
-        "hulc2_amd.models.plan_encoders.plan_proposal_net", "hulc2_amd.models.plan_encoders.plan_recognition_net",
-        "hulc2_amd.models.decoders", "hulc2_amd.models.decoders.action_decoder", "hulc2_amd.models.decoders.logistic_decoder_rnn",
-        "hulc2_amd.models.auxiliary_loss_networks", "hulc2_amd.models.auxiliary_loss_networks.proj_vis_lang",
-        "hulc2_amd.utils", "hulc2_amd.utils.distributions",
-    ]
-    for n in names:
-        m = importlib.import_module(n)
-        sys.modules["hulc2" + n[len("hulc2_amd"):]] = m
-    # conf/model/language_encoder/sbert.yaml:1 names the sentence encoder under the affordance package
-    import types
-    enc = importlib.import_module("hulc2_amd.models.language_encoders.sbert_lang_encoder")
-    chain = ("hulc2", "hulc2.affordance", "hulc2.affordance.models", "hulc2.affordance.models.language_encoders")
-    for parent, pkg in zip(chain, chain[1:]):
-        if pkg not in sys.modules:
-            mod = types.ModuleType(pkg)
-            mod.__path__ = []
-            sys.modules[pkg] = mod
-        setattr(sys.modules[parent], pkg.rsplit(".", 1)[1], sys.modules[pkg])
-    sys.modules[chain[-1] + ".sbert_lang_encoder"] = enc
-    sys.modules[chain[-1]].sbert_lang_encoder = enc
-    _ = hulc2_amd
+
+def _alias_parents():
+    out = set()
+    for leaf in LEAF_ALIASES:
+        parts = leaf.split(".")
+        for n in range(1, len(parts)):
+            out.add(".".join(parts[:n]))
+    return out
+
+
+class _AliasLoader:
+    """Loader that hands out an already imported hulc2_amd module under the reference's leaf name."""
+
+    def __init__(self, target):
+        self.target = target
+        self._spec = None
+
+    def create_module(self, spec):
+        mod = importlib.import_module(self.target)
+        self._spec = getattr(mod, "__spec__", None)
+        return mod
+
+    def exec_module(self, module):
+        # importlib stamped the alias spec on the module; put its own back (reload / pickling by its real name)
+        if self._spec is not None:
+            module.__spec__ = self._spec
+
+
+class _LeafAliasFinder:
+    """First on sys.meta_path: the aliased leaves resolve to this package whatever `hulc2` tree is importable.
+    Parents are imported by the normal machinery first (the reference's packages when present), and the leaf is
+    bound as an attribute of its parent like any other submodule."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        tgt = LEAF_ALIASES.get(fullname)
+        if tgt is None:
+            return None
+        from importlib.machinery import ModuleSpec
+        return ModuleSpec(fullname, _AliasLoader(tgt), origin="alias:" + tgt)
+
+
+class _EmptyParentFinder:
+    """Last on sys.meta_path: when NO `hulc2` tree is importable (this image, the GPU box) the parents of the aliased
+    leaves become empty packages, so `import hulc2.models.hulc2` still resolves."""
+
+    _parents = None
+
+    def find_spec(self, fullname, path=None, target=None):
+        if _EmptyParentFinder._parents is None:
+            _EmptyParentFinder._parents = _alias_parents()
+        if fullname not in _EmptyParentFinder._parents:
+            return None
+        from importlib.machinery import ModuleSpec
+        spec = ModuleSpec(fullname, _EmptyPackageLoader(), origin="hulc2_amd-empty-parent", is_package=True)
+        spec.submodule_search_locations = []
+        return spec
+
+
+class _EmptyPackageLoader:
+    def create_module(self, spec):
+        return None
+
+    def exec_module(self, module):
+        pass
+
+
+def install_as_hulc2() -> None:
+    """Make the reference's class paths (yaml `_target_: hulc2.models...`) resolve to the MI355X classes.
+
+    Works before or after the reference's `hulc2` package has been imported, and leaves that package alone: only the
+    leaf modules of LEAF_ALIASES are replaced.  Call it once before Hydra instantiates the model."""
+    if not any(isinstance(f, _LeafAliasFinder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _LeafAliasFinder())
+    if not any(isinstance(f, _EmptyParentFinder) for f in sys.meta_path):
+        sys.meta_path.append(_EmptyParentFinder())
+    importlib.invalidate_caches()
+    # leaves (or parents) that were imported before this call: swap the leaf in place
+    for leaf, tgt in LEAF_ALIASES.items():
+        parent, _, name = leaf.rpartition(".")
+        have = sys.modules.get(leaf)
+        if have is not None and getattr(have, "__name__", "") != tgt:
+            sys.modules[leaf] = importlib.import_module(tgt)
+        if leaf in sys.modules and parent in sys.modules:
+            setattr(sys.modules[parent], name, sys.modules[leaf])
+        # names the reference's packages re-export from an aliased leaf (hulc2/models/__init__.py:7 SBertLang)
+    ref_models = sys.modules.get("hulc2.models")
+    if ref_models is not None and hasattr(ref_models, "lang_encoders") and isinstance(ref_models.lang_encoders, dict):
+        enc = importlib.import_module(LEAF_ALIASES["hulc2.affordance.models.language_encoders.sbert_lang_encoder"])
+        ref_models.SBertLang = enc.SBertLang
+        ref_models.lang_encoders["sbert"] = enc.SBertLang
+
+
+def uninstall_as_hulc2() -> None:
+    """Undo install_as_hulc2 (tests)."""
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, (_LeafAliasFinder, _EmptyParentFinder))]
+    for leaf in LEAF_ALIASES:
+        m = sys.modules.get(leaf)
+        if m is not None and getattr(m, "__name__", "").startswith("hulc2_amd"):
+            del sys.modules[leaf]
+    for parent in _alias_parents():
+        m = sys.modules.get(parent)
+        if m is not None and getattr(getattr(m, "__spec__", None), "origin", None) == "hulc2_amd-empty-parent":
+            del sys.modules[parent]

@@ -137,7 +137,8 @@ def check_faults(device) -> None:
     w = int(t.item()) if t is not None else 0
     if w != 0:
         t.zero_()
-        _chain_ws.clear()                 # (a timed-out chain leaves its barrier counters non-zero: fresh workspaces)
+        for ws in _chain_ws.values():     # a timed-out chain leaves its barrier counters non-zero: clear them where they are (the cached
+            ws.zero_()                    # buffers stay valid for eager launches; captured graphs are re-captured by ArenaTrainer._poll_faults)
         who = [n for b, n in ((1, "rnn_wavefront (HULC_NO_RNN_WAVEFRONT=1 selects the per-step GEMM path)"),
                               (2, "mlp_chain (HULC_NO_MLP_CHAIN=1 selects the per-layer GEMM path)")) if w & b]
         raise _L.HulcKernelError(
@@ -591,6 +592,15 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     """C[M,N] (+)= A^T B with A (K, M), B (K, N) row-major (+ rowsum[m] (+)= sum_k A[k][m]).  defer=True (C and rowsum are final
     destinations nobody reads before the backward pass ends — the trainer's gradient arena): the product joins the grouped launch issued
     when autograd finishes the pass; otherwise it runs now.  Returns True when rowsum was (or will be) produced by the same launch."""
+    _require_cuda(A, B, C, rowsum)
+    dev = C.device
+    mine = {C.data_ptr()} | ({rowsum.data_ptr()} if rowsum is not None else set())
+    q = _wg_pending.get(dev)
+    if q and any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
+        # a second writer of the same destination (a shared layer applied twice in one pass, e.g. at different row counts): the queued first
+        # writer runs NOW, whichever path the second one takes — an immediate GEMM with accumulate=True must not land on a slice the deferred
+        # overwrite has not written yet (ADVICE r02)
+        wgrad_flush(dev)
     if not wgrad_group_ok(A, B, C, M, N, K, lda, ldb, ldc, any_size=bool(col_perm) or col_mul > 1):
         if col_perm or col_mul > 1 or store_rows:
             raise _L.HulcKernelError("wgrad: col_perm / col_mul need the grouped kernel (check wgrad_group_ok first)")
@@ -600,13 +610,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
         if rowsum is not None and not fused:
             colsum(A, K, M, lda, rowsum, accumulate=rowsum_accumulate)
         return True
-    _require_cuda(A, B, C, rowsum)
-    dev = C.device
     q = _wg_pending.setdefault(dev, [])
-    mine = {C.data_ptr()} | ({rowsum.data_ptr()} if rowsum is not None else set())
-    if any(e[2].data_ptr() in mine or (e[3] is not None and e[3].data_ptr() in mine) for e in q):
-        wgrad_flush(dev)                    # a second writer of the same destination: keep the order
-        q = _wg_pending.setdefault(dev, [])
     q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm), int(col_mul), int(store_rows), int(conv_taps_wp)))
     if not defer:
         wgrad_flush(dev)

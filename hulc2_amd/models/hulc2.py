@@ -27,6 +27,22 @@ from hulc2_amd.utils.distributions import State
 logger = logging.getLogger(__name__)
 
 
+def _kernel_precision(fn):
+    """Lightning (`precision: 16`, conf/trainer/play_trainer.yaml:3) calls the hooks inside `torch.autocast(fp16)`.  The kernels behind
+    this module choose their own arithmetic (kernels.set_compute) and read their operands through raw pointers, so a framework op that
+    autocast demoted to half would hand a kernel the wrong bytes: the hooks run with autocast off, as the reference itself does around
+    `world_to_tcp_frame` (gripper_control.py:17).  A GradScaler's power-of-two loss scale passes through every backward kernel exactly."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.is_autocast_enabled():
+            with torch.autocast(device_type="cuda", enabled=False):
+                return fn(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class Hulc2(LightningModule):
     def __init__(self, perceptual_encoder, plan_proposal, plan_recognition, language_encoder, language_goal, visual_goal,
                  action_decoder, kl_beta: float, kl_balancing_mix: float, optimizer, lr_scheduler, distribution,
@@ -90,6 +106,7 @@ class Hulc2(LightningModule):
         kl_loss = self.compute_kl_loss(pp_state, pr_state)
         return kl_loss, action_loss, action_loss + kl_loss, pp_state, pr_state, seq_feat
 
+    @_kernel_precision
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
         """hulc2.py:336-442."""
         if self.training:
@@ -245,6 +262,7 @@ class Hulc2(LightningModule):
         return (sampled_plan_pp, action_loss_pp, sampled_plan_pr, action_loss_pr, kl_loss, mae_pp, mae_pr, gripper_sr_pp, gripper_sr_pr,
                 seq_feat)
 
+    @_kernel_precision
     @torch.no_grad()
     def validation_step(self, batch: Dict[str, Dict], batch_idx: int) -> Dict[str, torch.Tensor]:
         """hulc2.py:510-598: same logged names, returns the sampled plans and episode indices per modality."""
@@ -283,6 +301,7 @@ class Hulc2(LightningModule):
         self.latent_goal = None
         self.rollout_step_counter = 0
 
+    @_kernel_precision
     def step(self, obs, goal):
         """hulc2.py:608-628: one control step; a new plan is sampled from the prior every `replan_freq` steps."""
         if self.rollout_step_counter % self.replan_freq == 0:

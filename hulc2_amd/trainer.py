@@ -16,6 +16,7 @@ backward -> DDP bucketed all-reduce -> Adam step).  Lightning is a third-party l
 from typing import Dict, List, Optional
 
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -203,6 +204,10 @@ class ArenaTrainer:
         """force_comm: run the multi-rank control flow (split graphs, comm stream, collectives) even with a single rank in the process
         group — how the RCCL path is exercised on a one-GPU box."""
         self.model = model
+        prev = model.__dict__.get("_hulc_arena_trainer")
+        prev = prev() if prev is not None else None
+        if prev is not None:                               # an earlier trainer of this model: its load hook would keep re-homing weights into a
+            prev.close()                                   # dead arena (and keep that arena alive) — ADVICE r02
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
@@ -337,7 +342,8 @@ class ArenaTrainer:
             kn.step_state(dev)[1] = 0               # the device-resident Adam step count starts with this trainer (the RNG word keeps walking)
         self.graph_fb = self.graph_enc = self.graph_opt = None
         self.static_loss = None
-        model.register_load_state_dict_post_hook(self._after_model_load)
+        self._load_hook = model.register_load_state_dict_post_hook(self._after_model_load)
+        model.__dict__["_hulc_arena_trainer"] = weakref.ref(self)
         # Split point for overlapping the gradient all-reduce with the tail of backward in graph mode: the camera encoders
         # are registered first (arena head, 0.75 M parameters) but their backward (the conv stack) is the LAST ~2 ms of a step,
         # while everything else (98 % of the gradient bytes) is complete once backward reaches the encoder output.
@@ -410,6 +416,75 @@ class ArenaTrainer:
         if self.dev.type == "cuda":
             kn.reset_step_state(self.dev, seed=int(sd["rng_word"]), step=int(sd.get("device_step", sd["step"])))
         self.refresh_shadows()
+
+    # ---- interchange with the reference's checkpoints: `optimizer_states[0]` of a Lightning checkpoint IS torch.optim.Adam.state_dict() ----------
+    def to_torch_adam_state_dict(self) -> Dict:
+        """This trainer's state as `torch.optim.Adam(model.parameters(), lr).state_dict()` would hold it (reference: hulc2.py:185-198,
+        conf/model/optimizer/adam.yaml): `state` keyed by the INDEX of the parameter in `model.parameters()` order with a per-parameter `step`
+        tensor, `param_groups[0]["params"]` = all indices.  Frozen / never-updated parameters have no entry, like in torch.  A reference
+        Lightning run resumes from it with `optimizer.load_state_dict(...)`."""
+        order = list(self.model.parameters())
+        index = {id(p): off for p, off in zip(self.params, self.offsets)}
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(order):
+                off = index.get(id(p))
+                if off is None:
+                    continue
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def from_torch_adam_state_dict(self, sd: Dict) -> None:
+        """Resume from a reference checkpoint's optimizer state (`ckpt["optimizer_states"][0]`): the inverse of to_torch_adam_state_dict.
+        The fused kernel keeps ONE step count, so the per-parameter steps must agree (they do for a torch.optim.Adam that stepped all its
+        parameters together — every parameter of this model receives a gradient every step)."""
+        order = list(self.model.parameters())
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(order):
+            raise KeyError(f"optimizer state for {len(ids)} parameters, model.parameters() has {len(order)}")
+        index = {id(p): off for p, off in zip(self.params, self.offsets)}
+        steps = set()
+        with torch.no_grad():
+            for pos, key in enumerate(ids):
+                p, rec = order[pos], sd["state"].get(key)
+                off = index.get(id(p))
+                if off is None:
+                    continue
+                n = p.numel()
+                if rec is None:                                  # torch creates state lazily: a parameter that never saw a gradient
+                    self.exp_avg[off:off + n].zero_()
+                    self.exp_avg_sq[off:off + n].zero_()
+                    continue
+                if tuple(rec["exp_avg"].shape) != tuple(p.shape):
+                    raise KeyError(f"optimizer state {key}: shape {tuple(rec['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                self.exp_avg[off:off + n].copy_(rec["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(rec["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(rec["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter Adam steps differ ({sorted(steps)}): the arena optimizer keeps one step count")
+        self.step_count = steps.pop() if steps else 0
+        g0 = groups[0]
+        if g0.get("amsgrad") or g0.get("maximize"):
+            raise NotImplementedError("amsgrad / maximize are not built (conf/model/optimizer/adam.yaml uses neither)")
+        self.lr, self.betas, self.eps, self.wd = g0["lr"], tuple(g0["betas"]), g0["eps"], g0.get("weight_decay", 0.0)
+        if self.dev.type == "cuda":
+            kn.step_state(self.dev)[1] = self.step_count
+        self.refresh_shadows()
+
+    def close(self) -> None:
+        """Detach this trainer from the model: the load_state_dict post-hook (which keeps the trainer, hence its four arenas, alive through the
+        model) is removed and the gradient sinks are dropped.  Parameters keep living in the arena until another trainer re-homes them."""
+        h, self._load_hook = getattr(self, "_load_hook", None), None
+        if h is not None:
+            h.remove()
+        gradsink.clear()
 
     def _keep_encoder_output(self, module, inputs, output):
         self._emb = output if (self._split_active and torch.is_tensor(output) and output.requires_grad) else None
@@ -522,7 +597,14 @@ class ArenaTrainer:
         self._since_check += 1
         if self.dev.type == "cuda" and self._since_check >= self._fault_every:
             self._since_check = 0
-            kn.check_faults(self.dev)
+            try:
+                kn.check_faults(self.dev)
+            except Exception:
+                # a timed-out chain kernel leaves its barrier counters non-zero in a workspace whose address is baked into the captured
+                # graphs (or lives in their private pool): replaying them again would mis-count every barrier.  The graphs are dropped —
+                # step() keeps working eagerly on fresh workspaces, replay() asks for a new capture()  
+                self.graph_fb = self.graph_enc = self.graph_opt = None
+                raise
 
     # ---- hipGraph mode: the ~900 launches of a step are captured once and replayed ----------------------
     def capture(self, batch) -> None:
@@ -561,6 +643,8 @@ class ArenaTrainer:
         torch.cuda.synchronize()
 
     def replay(self) -> torch.Tensor:
+        if self.graph_fb is None:
+            raise RuntimeError("ArenaTrainer.replay: no captured graphs (never captured, or dropped after a barrier-kernel fault): call capture(batch)")
         self.graph_fb.replay()
         if self.graph_enc is not None:
             # everything but the encoder gradients is final: reduce it on the comm stream while the conv backward graph runs

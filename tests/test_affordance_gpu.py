@@ -216,6 +216,9 @@ def test_training_loop_tracks_the_oracle_and_replays_as_a_graph():
     l1 = float(tr.replay())
     l2 = float(tr.replay())
     assert l1 == l1 and l2 < got[0] and l2 <= l1 * 1.05, (got, l1, l2)
+    # nn.BatchNorm2d.num_batches_tracked counts every training forward, eager and replayed alike (state_dicts interchange)
+    n_fwd = {int(b) for b in m.bn_step_counters()}
+    assert len(m.bn_step_counters()) == 10 and len(n_fwd) == 1 and n_fwd.pop() >= steps + 2, [int(b) for b in m.bn_step_counters()]
 
 
 def test_trunk_on_the_grid_option_matches_the_default_trunk(monkeypatch):

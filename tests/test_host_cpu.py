@@ -248,3 +248,93 @@ def test_wgrad_group_workspace_counts_the_nine_tap_slabs():
     assert lib.hulc_wgrad_group_workspace(split, 1) == counters + 6 * 27 * (4 * 9 * 16 * 64) * 4
     f32 = (L.WgradItem * 1)(item(128, 192, 107648, 58, bf16=False))  # fp32 operands stay with the grouped kernel: nine tiles per slice
     assert lib.hulc_wgrad_group_workspace(f32, 1) > counters and lib.hulc_wgrad_group_workspace(f32, 1) != lib.hulc_wgrad_group_workspace(split, 1)
+
+
+def test_optimizer_state_interchanges_with_torch_adam():
+    """a reference Lightning checkpoint's `optimizer_states[0]` is torch.optim.Adam.state_dict() — state keyed by the parameter's
+    INDEX in model.parameters() order, per-parameter `step`, `param_groups[0]["params"]`.  to_/from_torch_adam_state_dict convert both ways;
+    checked against torch.optim.Adam.load_state_dict / state_dict themselves, with a frozen parameter in the middle of the order."""
+    from hulc2_amd.trainer import ArenaTrainer
+    torch.manual_seed(1)
+
+    def net():
+        m = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+        m[2].bias.requires_grad_(False)                    # model.parameters() still lists it; torch keeps no state for it
+        return m
+
+    # reference side: three torch.optim.Adam steps
+    ref = net()
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
+    for i in range(3):
+        opt.zero_grad()
+        ref(torch.randn(4, 6)).square().sum().backward()
+        opt.step()
+    sd = opt.state_dict()
+
+    m = net()
+    m.load_state_dict(ref.state_dict())
+    tr = ArenaTrainer(m)
+    tr.from_torch_adam_state_dict(sd)
+    assert tr.step_count == 3 and tr.lr == 2e-4 and tuple(tr.betas) == (0.9, 0.999)
+    order = list(m.parameters())
+    index = {id(p): off for p, off in zip(tr.params, tr.offsets)}
+    for i, p in enumerate(order):
+        if not p.requires_grad:
+            assert i not in sd["state"]
+            continue
+        sl = slice(index[id(p)], index[id(p)] + p.numel())
+        assert torch.equal(tr.exp_avg[sl].view(p.shape), sd["state"][i]["exp_avg"])
+        assert torch.equal(tr.exp_avg_sq[sl].view(p.shape), sd["state"][i]["exp_avg_sq"])
+
+    # and back: torch's own optimizer accepts what the trainer exports, and re-exports the same tensors
+    out = tr.to_torch_adam_state_dict()
+    assert set(out) == {"state", "param_groups"} and out["param_groups"][0]["params"] == list(range(len(order)))
+    assert set(out["state"]) == set(sd["state"])
+    opt2 = torch.optim.Adam(net().parameters(), lr=1.0)
+    opt2.load_state_dict(out)
+    back = opt2.state_dict()
+    assert back["param_groups"][0]["lr"] == 2e-4
+    for i, rec in sd["state"].items():
+        assert float(back["state"][i]["step"]) == float(rec["step"]) == 3.0
+        assert torch.equal(back["state"][i]["exp_avg"], rec["exp_avg"]) and torch.equal(back["state"][i]["exp_avg_sq"], rec["exp_avg_sq"])
+    # the next torch step from the exported state equals the next torch step of the original optimizer
+    x = torch.randn(4, 6)
+    m3 = net()
+    m3.load_state_dict(ref.state_dict())
+    opt3 = torch.optim.Adam(m3.parameters(), lr=2e-4)
+    opt3.load_state_dict(out)
+    for mod, o in ((ref, opt), (m3, opt3)):
+        o.zero_grad()
+        mod(x).square().sum().backward()
+        o.step()
+    assert all(torch.equal(a, b) for a, b in zip(ref.parameters(), m3.parameters()))
+    # a fresh trainer exports an empty state (torch creates state lazily), mismatched layouts raise
+    assert ArenaTrainer(net()).to_torch_adam_state_dict()["state"] == {}
+    with pytest.raises(KeyError):
+        tr.from_torch_adam_state_dict({"state": {}, "param_groups": [{**sd["param_groups"][0], "params": [0, 1]}]})
+    bad = {"state": {k: dict(v) for k, v in sd["state"].items()}, "param_groups": sd["param_groups"]}
+    bad["state"][0]["step"] = torch.tensor(7.0)
+    with pytest.raises(ValueError):
+        tr.from_torch_adam_state_dict(bad)
+
+
+def test_a_second_trainer_retires_the_first_ones_load_hook():
+    """the load_state_dict post-hook of an earlier trainer kept that trainer (four arenas) alive and re-homed the weights into its
+    dead arena on every load.  Building a new trainer closes the old one; close() removes the hook."""
+    import gc
+    import weakref
+    from hulc2_amd.trainer import ArenaTrainer
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3))
+    t1 = ArenaTrainer(m)
+    ref1 = weakref.ref(t1)
+    t2 = ArenaTrainer(m)
+    assert t1._load_hook is None and t2._load_hook is not None
+    assert len(m._load_state_dict_post_hooks) == 1
+    del t1
+    gc.collect()
+    assert ref1() is None                                   # nothing (no hook, no module attribute) holds the first trainer any more
+    m.load_state_dict({k: v.clone() + 1 for k, v in m.state_dict().items()})
+    for p, off in zip(t2.params, t2.offsets):
+        assert p.data_ptr() == t2.flat_p.data_ptr() + 4 * off
+    t2.close()
+    assert len(m._load_state_dict_post_hooks) == 0

@@ -174,3 +174,53 @@ def test_graph_replay_is_immune_to_eager_work_between_replays(dev):
     b, pb = run(True)
     assert all(x == x for x in b), b
     assert a == b and torch.equal(pa, pb), (a, b)
+
+
+def test_training_step_under_lightning_amp_gives_the_same_bits(dev):
+    """Lightning `precision: 16` (conf/trainer/play_trainer.yaml:3; SURVEY §8b "Lightning wraps the step in autocast"): `training_step` inside
+    `torch.autocast("cuda", float16)`, `GradScaler.scale(loss).backward()`, `unscale_` — loss and every gradient must be the bits of the plain
+    call (the hooks switch autocast off; the 2^16 loss scale is exact through every backward kernel)."""
+    m = _model(dev, 5)
+    batch = _batch(dev, 5, B=2, S=8)
+    names = [n for n, _ in m.named_parameters()]
+
+    def grads():
+        return {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in m.named_parameters()}
+
+    kn.reset_step_state(dev)
+    for p in m.parameters():
+        p.grad = None
+    loss = m.training_step(batch, 0)
+    assert loss.dtype == torch.float32
+    loss.backward()
+    ref_loss, ref = loss.detach().clone(), grads()
+
+    kn.reset_step_state(dev)
+    for p in m.parameters():
+        p.grad = None
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=2e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss2 = m.training_step(batch, 0)
+        assert torch.is_autocast_enabled()                  # the hook restored the caller's context
+    assert loss2.dtype == torch.float32 and torch.equal(loss2.detach(), ref_loss)
+    scaler.scale(loss2).backward()
+    scaler.unscale_(opt)
+    got = grads()
+    n_checked = 0
+    for n in names:
+        if ref[n] is None:
+            assert got[n] is None, n
+            continue
+        assert got[n] is not None and got[n].dtype == torch.float32, n
+        assert torch.equal(got[n], ref[n]), f"{n}: max diff {(got[n] - ref[n]).abs().max().item():.3e}"
+        n_checked += 1
+    assert n_checked > 60
+    scaler.step(opt)                                        # finite gradients: the scaler lets the optimizer step
+    scaler.update()
+    assert scaler.get_scale() == 65536.0
+    # validation / rollout hooks under the same context
+    m.eval()
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m.validation_step(_batch(dev, 5), 0)
+    assert all(v.dtype in (torch.float32, torch.int64, torch.int32) for v in out.values())

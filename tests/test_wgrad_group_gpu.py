@@ -176,3 +176,41 @@ def test_deferred_through_autograd_with_sinks():
     finally:
         gradsink.clear()
         gradsink.begin_step(False)
+
+
+def test_shared_layer_at_two_row_counts_under_sinks():
+    """one Linear applied twice in a pass with different row counts (lang B = 32 rows through the grouped launch, vis B = 20 rows:
+    K % 32 != 0, the immediate GEMM path).  Backward reaches the 20-row use... whichever comes first, the deferred overwrite of the other must
+    not swallow the accumulated contribution: arena slice == sum of both contributions."""
+    dev = _dev()
+    torch.manual_seed(11)
+    for first_rows, second_rows in ((32, 20), (20, 32)):
+        lin = torch.nn.Linear(160, 2048).to(dev)
+        ref = torch.nn.Linear(160, 2048).to(dev)
+        ref.load_state_dict(lin.state_dict())
+        xa = torch.randn(first_rows, 160, device=dev)
+        xb = torch.randn(second_rows, 160, device=dev)
+        ra = torch.randn(first_rows, 2048, device=dev)
+        rb = torch.randn(second_rows, 2048, device=dev)
+
+        def run(l):
+            ya = HF.mlp(xa, [(l.weight, l.bias, False)])
+            yb = HF.mlp(xb, [(l.weight, l.bias, False)])
+            ((ya * ra).sum() + (yb * rb).sum()).backward()
+            torch.cuda.synchronize()
+
+        run(ref)
+        arena = torch.full((lin.weight.numel() + lin.bias.numel(),), float("nan"), device=dev)
+        try:
+            gradsink.register(lin.weight, arena[:lin.weight.numel()].view_as(lin.weight))
+            gradsink.register(lin.bias, arena[lin.weight.numel():].view_as(lin.bias))
+            gradsink.begin_step(True)
+            run(lin)
+            gw, gb = arena[:lin.weight.numel()].view_as(lin.weight), arena[lin.weight.numel():]
+            assert lin.weight.grad is None and torch.isfinite(arena).all()
+            for got, want in ((gw, ref.weight.grad), (gb, ref.bias.grad)):
+                assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item(), (first_rows, second_rows)
+                assert (got - want).norm().item() <= 5e-3 * want.norm().item(), (first_rows, second_rows)
+        finally:
+            gradsink.clear()
+            gradsink.begin_step(False)
