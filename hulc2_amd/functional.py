@@ -17,6 +17,25 @@ from . import kernels as kn
 from .shadow import weight_operand
 
 
+def _scoped(cls):
+    """class decorator: the Function's backward runs in the compute mode its forward ran in (kernels.compute_scope)"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._compute = kn.backward_compute()       # (differs from the forward's mode inside a forward-only precision scope: 'mixed' mode)
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        if ctx._compute == kn.get_compute():
+            return bwd(ctx, *grads)
+        with kn.compute_scope(ctx._compute):
+            return bwd(ctx, *grads)
+
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def _f32(*shape, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -37,6 +56,7 @@ def _act_dtype() -> torch.dtype:
 # reference: plan_proposal_net.py:26-47, goal_encoders.py:21-34,53-71, vision_network.py:49-52,
 #            proj_vis_lang.py:10-21, nn.TransformerEncoderLayer feed-forward block
 # ------------------------------------------------------------------------------------------------
+@_scoped
 class MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, relus: Tuple[bool, ...], drops: Tuple[float, ...], seed: int, *params):
@@ -120,6 +140,7 @@ class MLPFn(torch.autograd.Function):
         return (dx, None, None, None, *grads)
 
 
+@_scoped
 class FlattenLinearFn(torch.autograd.Function):
     """relu(Linear(nn.Flatten(x_nchw))) computed on the NHWC activation a (N, H, W, C) as it lies in memory: the reference flattens
     (C, H, W) (vision_network_gripper.py:16-17), so the weight's columns are reordered to (h, w, c) once per optimizer step
@@ -196,6 +217,7 @@ def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Opt
 # conv stack of a camera encoder -> NHWC ReLU activations of conv3
 # reference: vision_network.py:36-47, vision_network_gripper.py:11-20
 # ------------------------------------------------------------------------------------------------
+@_scoped
 class ConvStackFn(torch.autograd.Function):
     """xs: one or more (N_i,3,H,W) NCHW frame tensors -> a3 (sum N_i, OH3, OW3, 64) NHWC.  Several inputs (the vis and lang
     modalities of a step) share one activation buffer from conv1 on: conv1 runs per input (no 1 GB concat of the frames),
@@ -238,7 +260,16 @@ class ConvStackFn(torch.autograd.Function):
             dims.append((h, w_, cin, cout, k, s, nchw))
             acts.append(y)
             inp, h, w_, cin = y, oh, ow, cout
-        ctx.save_for_backward(acts[0], acts[1], acts[2], w2, w3, *xs)
+        saved = acts
+        if kn.backward_compute() == "bf16" and acts[0].dtype != torch.bfloat16:
+            # exact-fp32 forward, bf16 backward ('mixed' mode): the backward kernels get what a bf16 step would have saved — bf16 maps — only
+            # rounded ONCE from the exact values (as operands of the gradient products their rounding costs < 1 %)
+            saved = []
+            for a in acts:
+                h = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+                kn.cast_f32_to_bf16(a, h, a.numel())
+                saved.append(h)
+        ctx.save_for_backward(saved[0], saved[1], saved[2], w2, w3, *xs)
         ctx.conv_w, ctx.conv_b = ws, bs                   # identities for the gradient sinks
         ctx.aug = (pad, shifts, indices)
         ctx.meta = (dims, grad_premasked, Ns)
@@ -250,6 +281,10 @@ class ConvStackFn(torch.autograd.Function):
         dims, premasked, Ns = ctx.meta
         N = sum(Ns)
         g = _c(da3)
+        if premasked and g.dtype != a3.dtype:             # ('mixed' mode: the consumer worked on the fp32 map) -> the saved maps' storage type
+            h = torch.empty(g.shape, dtype=a3.dtype, device=g.device)
+            kn.cast_f32_to_bf16(g, h, g.numel())
+            g = h
         if not premasked:
             gz = torch.empty(g.shape, dtype=torch.float32, device=g.device)
             kn.relu_bwd(g.float() if g.dtype != torch.float32 else g, a3, gz, g.numel())
@@ -301,6 +336,7 @@ def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, fram
     return ConvStackFn.apply(grad_premasked, aug, *params, *xs)
 
 
+@_scoped
 class SpatialSoftmaxFn(torch.autograd.Function):
     """NHWC (N,H,W,C) -> (N,2C); backward also applies the ReLU mask of its input (vision_network.py:100-108)."""
 
@@ -329,6 +365,7 @@ def spatial_softmax(a, xmap, ymap, temperature):
 # ------------------------------------------------------------------------------------------------
 # LayerNorm (optionally fused with residual add + dropout of the residual branch)
 # ------------------------------------------------------------------------------------------------
+@_scoped
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, o, gamma, beta, eps: float, drop_p: float, seed: int):
@@ -380,6 +417,7 @@ def add_layer_norm(x, o, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
 # ------------------------------------------------------------------------------------------------
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
+@_scoped
 class AddPosFn(torch.autograd.Function):
     """dropout(x + pos[position_ids]) — plan_recognition_net.py:133-136,142.  identity: position_ids is arange(S) (what the reference passes):
     the table's gradient is then the batch sum itself and goes straight into the trainer's gradient sink."""
@@ -419,6 +457,7 @@ class AddPosFn(torch.autograd.Function):
         return dx, dpos, None, None, None, None
 
 
+@_scoped
 class SeqMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -436,6 +475,7 @@ class SeqMeanFn(torch.autograd.Function):
         return dx
 
 
+@_scoped
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(dh)) v per (batch, head) on packed qkv (B*S, 3E)."""
 
@@ -460,6 +500,7 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None
 
 
+@_scoped
 class FFNFn(torch.autograd.Function):
     """linear1 -> ReLU -> dropout -> linear2 of the transformer layer as one fused kernel per direction (csrc/ffn_fused.hip):
     the (tokens x 2048) hidden activation never reaches HBM, backward recomputes it.  x (T, 128) fp32 -> f (T, 128) fp32."""
@@ -504,6 +545,7 @@ def _sink_or_new(param, shape, like):
     return sk.view(*shape), not gradsink.first_write(param), None
 
 
+@_scoped
 class TxlLayerFn(torch.autograd.Function):
     """One post-norm nn.TransformerEncoderLayer (plan_recognition_net.py:115-117) on tokens x (B*S, 128), bf16 compute, as
          forward : hulc_txl_attn_fwd (in_proj + MFMA attention + out_proj + residual + dropout + LayerNorm1, one workgroup per sequence)
@@ -693,6 +735,7 @@ def decoder_rnn_infer(plan, emb, goal, lo: int, hi: int, w_ih0, w_hh0, b_ih0, b_
     return h1, h_n
 
 
+@_scoped
 class DecoderRNNFn(torch.autograd.Function):
     """2-layer ReLU RNN over x_t = [plan | emb_t[lo:hi] | goal], h_{-1} = 0  ->  h1 (B, S, H).
 
@@ -853,6 +896,7 @@ class DecoderRNNFn(torch.autograd.Function):
         return (dplan, demb, dgoal, None, None, dw_ih0, dw_hh0, db_ih0, db_hh0, dw_ih1, dw_hh1, db_ih1, db_hh1, None, None)
 
 
+@_scoped
 class EmbFanoutFn(torch.autograd.Function):
     """emb (N, S, D) -> (emb[:, 0], emb[:n_last, -1], emb, emb[:, :, lo:hi] time-major (S, N, hi-lo)): the four views Hulc2.training_step
     hands to the prior, the visual goal encoder, the posterior and the action decoder (hulc2.py:380-387).  One gather launch forward,
@@ -878,6 +922,7 @@ class EmbFanoutFn(torch.autograd.Function):
         return demb, None, None, None
 
 
+@_scoped
 class LossCombineFn(torch.autograd.Function):
     """(kl_loss[m], action_loss[m], clip) -> total (0-dim), logs (3 + n) = {kl mean, action mean, beta * clip, per-modality totals}; hulc2.py:400-430.
     Only `total` carries a gradient."""
@@ -906,6 +951,7 @@ class LossCombineFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # losses
 # ------------------------------------------------------------------------------------------------
+@_scoped
 class MixLossFn(torch.autograd.Function):
     """y (T, 3*A*n_mix + 2 [+pad]) head outputs, actions (T, A+1) -> (nseg,) losses NLL + alpha * gripper CE, each the
     mean over its own T/nseg tokens (nseg = 1: the reference's single mean; nseg = 2: vis and lang batched together)."""
@@ -931,6 +977,7 @@ class MixLossFn(torch.autograd.Function):
         return dy, None, None, None, None, None, None, None, None, None
 
 
+@_scoped
 class CatKLFn(torch.autograd.Function):
     """KL balancing of hulc2.py:444-466 on (B, G*32) logits of prior (pp) and posterior (pr)."""
 
@@ -955,6 +1002,7 @@ class CatKLFn(torch.autograd.Function):
         return dpp, dpr, None, None, None, None, None
 
 
+@_scoped
 class PlanSampleFn(torch.autograd.Function):
     """Straight-through one-hot sample; returns (plan (B, G*CLS), idx (B, G))."""
 
@@ -979,6 +1027,7 @@ class PlanSampleFn(torch.autograd.Function):
         return dl, None, None, None, None
 
 
+@_scoped
 class ClipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, tx, use, logit_scale):

@@ -15,14 +15,82 @@ _COMPUTE = {"bf16": BF16, "fp32": F32, "f32": F32}
 _compute_mode = BF16
 
 
+_base_mode = "bf16"         # what set_compute selected: "bf16" | "fp32" | "mixed"
+_bwd_mode = None            # compute mode autograd Functions created now will run their BACKWARD in (None: the current mode)
+
+
 def set_compute(mode: str) -> None:
-    """Select MFMA arithmetic: 'bf16' (v_mfma_f32_32x32x16_bf16, fp32 accumulate) or 'fp32' (exact)."""
-    global _compute_mode
-    _compute_mode = _COMPUTE[mode]
+    """Select the arithmetic of a step:
+      'bf16'  v_mfma_f32_32x32x16_bf16, fp32 accumulate (the benchmarked mode; the contrastive head alone runs exact fp32, see fp32_sites)
+      'fp32'  exact fp32 MFMA everywhere (parity / debug mode)
+      'mixed' FORWARD exact fp32 for everything upstream of the contrastive head (camera encoders, goal encoders, prior, posterior), BACKWARD
+              and the recurrent decoder bf16 — the gradients of a bf16 step are only as good as its forward activations (DESIGN §5:
+              backward rounding costs < 1 %, forward rounding 5-25 % on this cancellation-prone loss), so the precision goes where it pays."""
+    global _compute_mode, _base_mode, _bwd_mode
+    if mode not in ("bf16", "fp32", "mixed"):
+        raise ValueError(mode)
+    _base_mode, _bwd_mode = mode, None
+    _compute_mode = _COMPUTE["bf16" if mode == "mixed" else mode]
 
 
 def get_compute() -> str:
+    """the MFMA arithmetic of launches issued now: 'bf16' or 'fp32'"""
     return "bf16" if _compute_mode == BF16 else "fp32"
+
+
+def base_mode() -> str:
+    return _base_mode
+
+
+def backward_compute() -> str:
+    """the mode an autograd Function created now runs its backward in"""
+    return _bwd_mode if _bwd_mode is not None else get_compute()
+
+
+class compute_scope:
+    """`with compute_scope("fp32"):` — the MFMA arithmetic of the launches issued inside (selective precision).  Every autograd
+    Function of functional.py records backward_compute() in its forward and re-enters that mode for its backward: the scope's own mode, or —
+    `fwd_only=True` — the mode that was current outside the scope (exact forward, bf16 backward)."""
+
+    def __init__(self, mode: str, fwd_only: bool = False):
+        self.mode, self.fwd_only = _COMPUTE[mode], fwd_only
+
+    def __enter__(self):
+        global _compute_mode, _bwd_mode
+        self.prev = (_compute_mode, _bwd_mode)
+        if self.fwd_only and self.mode != _compute_mode:
+            _bwd_mode = backward_compute()
+        elif not self.fwd_only:
+            _bwd_mode = None
+        _compute_mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _compute_mode, _bwd_mode
+        _compute_mode, _bwd_mode = self.prev
+        return False
+
+
+def fp32_sites() -> frozenset:
+    """Which parts of a bf16-mode step run their FORWARD in exact fp32 (HULC_FP32_SITES, comma separated; default: the contrastive
+    head).  Sites: `head` = plan recognition's 128 -> 4096 projection of the pooled feature, ProjVisLang, the CLIP loss;  `pool` = the
+    sequence mean;  `txl` = the posterior's transformer layers;  `enc` = the camera encoders;  `goal`, `prior`;  `none`."""
+    import os
+    v = os.environ.get("HULC_FP32_SITES", "head")
+    return frozenset(x for x in v.replace(" ", "").split(",") if x and x != "none")
+
+
+def site_scope(site: str):
+    """the scope a part of the step runs in: exact fp32 when selected by HULC_FP32_SITES (bf16 / mixed modes), exact-fp32 FORWARD for every
+    site in 'mixed' mode, else the current mode"""
+    if _base_mode != "fp32" and _compute_mode == BF16:
+        if site in fp32_sites() or _base_mode == "mixed":
+            # forward only: rounding in the BACKWARD products moves no gradient of this model by more than 1 % (tools/study/bf16_emulation.py,
+            # `only_bwd`), and the backward then stays on the grouped / chained bf16 launches.  HULC_FP32_SITES_BWD=1: both directions.
+            import os
+            return compute_scope("fp32", fwd_only=not os.environ.get("HULC_FP32_SITES_BWD"))
+    return compute_scope(get_compute(), fwd_only=_bwd_mode is not None)
+
 
 
 # ------------------------------------------------------------------------------------------------

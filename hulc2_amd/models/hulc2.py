@@ -129,7 +129,8 @@ class Hulc2(LightningModule):
         kl_stacked = None
         mods = list(batch.items())
         if self._batchable(mods):
-            emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
+            with kn.site_scope("enc"):
+                emb_all = self.perceptual_encoder([db["rgb_obs"] for _, db in mods], None, None)
             if emb_all.requires_grad and emb_all.is_cuda:
                 # when backward reaches the embedding every weight gradient outside the camera encoders is queued: HULC_WGRAD_EARLY=1 issues the
                 # grouped launch on a second stream at that point (kernels.wgrad_flush_early; measured slower, off by default)
@@ -143,13 +144,16 @@ class Hulc2(LightningModule):
             fan = vis_first and emb_all.is_cuda
             if fan:
                 emb0, emb_last, emb_rec, emb_dec_t = HF.EmbFanoutFn.apply(emb_all, B, lo, hi)
-                goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(emb_last) for scope, db in mods]
+                with kn.site_scope("goal"):
+                    goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(emb_last) for scope, db in mods]
             else:
                 embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
                 emb0, emb_rec = emb_all[:, 0], emb_all
-                goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
+                with kn.site_scope("goal"):
+                    goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
             goal_all = torch.cat(goals, dim=0)
-            pp_all = self.plan_proposal(emb0, goal_all)
+            with kn.site_scope("prior"):
+                pp_all = self.plan_proposal(emb0, goal_all)
             pr_all, seq_all = self.plan_recognition(emb_rec)
             # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality
             idxs = [db.get("plan_idx") for _, db in mods]
@@ -163,9 +167,12 @@ class Hulc2(LightningModule):
                 per.append((self.modality_scope, db, None, goals[i], seq_all[i * B:(i + 1) * B], None, kls[i]))
         else:
             for self.modality_scope, db in mods:
-                emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
-                latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
-                pp_state = self.plan_proposal(emb[:, 0], latent_goal)
+                with kn.site_scope("enc"):
+                    emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
+                with kn.site_scope("goal"):
+                    latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
+                with kn.site_scope("prior"):
+                    pp_state = self.plan_proposal(emb[:, 0], latent_goal)
                 pr_state, seq_feat = self.plan_recognition(emb)
                 site = 0xA11CE if "lang" in self.modality_scope else 0xB0B
                 plan, _ = self.dist.rsample_plan(pr_state, seed=site, idx=db.get("plan_idx"))
@@ -227,8 +234,9 @@ class Hulc2(LightningModule):
         """hulc2.py:472-508; rows with use_for_aux_loss == False are excluded inside the kernel."""
         if use_for_aux_loss is None:
             use_for_aux_loss = torch.ones(seq_vis_feat.shape[0], dtype=torch.bool, device=seq_vis_feat.device)
-        im, tx = self.proj_vis_lang(seq_vis_feat, encoded_lang)
-        return HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale)
+        with kn.site_scope("head"):              # exact-fp32 projections inside a bf16 step (selective precision, DESIGN §5)
+            im, tx = self.proj_vis_lang(seq_vis_feat, encoded_lang)
+            return HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale)
 
     # ---- validation and rollout inference on the same kernels (SURVEY.md §8 row f-1) ------------------------
     _plan_calls = 0

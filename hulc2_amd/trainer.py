@@ -15,6 +15,7 @@ backward -> DDP bucketed all-reduce -> Adam step).  Lightning is a third-party l
 """
 from typing import Dict, List, Optional
 
+import contextlib
 import os
 import weakref
 
@@ -37,19 +38,67 @@ class GradComm:
       payload  "fp32"   the arena slice as it is
                "bf16"   rounded to bf16 for the wire (half the bytes), widened back into the arena afterwards; changes the arithmetic
                         (gradients pick up one bf16 rounding, the sum of "direct" a second one), hence a switch
-    Defaults come from HULC_ALLREDUCE / HULC_GRAD_PAYLOAD (ring / fp32)."""
+    Defaults (HULC_ALLREDUCE / HULC_GRAD_PAYLOAD override them):
+      payload  bf16 when world >= 4, fp32 below.  Rule: at 4+ ranks the all-reduce no longer fits under the conv backward it hides behind
+               (184 MB fp32 per step against a ~1.3 ms window), halving the bytes is worth one bf16 rounding of the summands —
+               rounding in the BACKWARD direction moves every gradient of this model by < 1 % (tools/study/bf16_emulation.py)
+      algo     "auto": on GPUs with world >= 2 both algorithms are TIMED once on the real fabric when the trainer is built (three reductions
+               of the full arena each, max over ranks) and the faster one is kept — whether RCCL's own multi-ring all-reduce or the direct
+               exchange wins on an 8-GPU xGMI mesh is a property of the node, not of this code; the probe's numbers go into bench.py's line.
+               On CPU (gloo) auto = ring."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, algo: Optional[str] = None, payload: Optional[str] = None, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
-        self.algo = algo or os.environ.get("HULC_ALLREDUCE", "ring")
-        self.payload = payload or os.environ.get("HULC_GRAD_PAYLOAD", "fp32")
-        if self.algo not in ("ring", "direct") or self.payload not in ("fp32", "bf16"):
-            raise ValueError(f"gradient all-reduce: algo {self.algo!r} (ring | direct), payload {self.payload!r} (fp32 | bf16)")
+        self.algo = algo or os.environ.get("HULC_ALLREDUCE", "auto")
+        self.payload = payload or os.environ.get("HULC_GRAD_PAYLOAD") or self.default_payload(self.world)
+        if self.algo not in ("ring", "direct", "auto") or self.payload not in ("fp32", "bf16"):
+            raise ValueError(f"gradient all-reduce: algo {self.algo!r} (ring | direct | auto), payload {self.payload!r} (fp32 | bf16)")
         self.flat_grad = flat_grad
         self.on_gpu = flat_grad.is_cuda
         self._bufs = {}
+        self.probe_ms: Dict[str, float] = {}
+        if self.algo == "auto":
+            fabric = self.active and self.on_gpu and self.world > 1 and dist.get_backend(group) == "nccl"     # (gloo: host staging, nothing to tune)
+            self.algo = self._probe() if fabric else "ring"
+
+    @staticmethod
+    def default_payload(world: int) -> str:
+        return "bf16" if world >= 4 else "fp32"
+
+    def _probe(self) -> str:
+        """time both algorithms on the full arena (scratch copy: the gradients are not touched) and keep the faster; every rank sees the same
+        max-over-ranks timings, so every rank makes the same choice"""
+        keep = self.flat_grad
+        self.flat_grad = torch.zeros_like(keep)
+        n = self.flat_grad.numel()
+        try:
+            for algo in ("ring", "direct"):
+                self.algo = algo
+                self.reduce(0, n)                                   # warm-up: communicators, staging buffers
+                torch.cuda.synchronize()
+                dist.barrier(group=self.group)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.reduce(0, n)
+                e1.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([e0.elapsed_time(e1) / 3], dtype=torch.float32, device=keep.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                self.probe_ms[algo] = round(float(t.item()), 4)
+        finally:
+            self.flat_grad = keep
+        return min(self.probe_ms, key=self.probe_ms.get)
+
+    def describe(self) -> Dict:
+        """what bench.py prints about the gradient exchange: algorithm, payload, bytes, the probe's timings"""
+        n = self.flat_grad.numel()
+        payload_bytes = n * (2 if self.payload == "bf16" else 4)
+        sent = int(2 * (self.world - 1) / max(self.world, 1) * payload_bytes)
+        return {"algo": self.algo, "payload": self.payload, "gradient_bytes": payload_bytes, "bytes_sent_per_rank_per_step": sent,
+                "probe_ms": dict(self.probe_ms)}
 
     def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
         t = self._bufs.get(name)
@@ -342,6 +391,7 @@ class ArenaTrainer:
             kn.step_state(dev)[1] = 0               # the device-resident Adam step count starts with this trainer (the RNG word keeps walking)
         self.graph_fb = self.graph_enc = self.graph_opt = None
         self.static_loss = None
+        self._comm_events = []
         self._load_hook = model.register_load_state_dict_post_hook(self._after_model_load)
         model.__dict__["_hulc_arena_trainer"] = weakref.ref(self)
         # Split point for overlapping the gradient all-reduce with the tail of backward in graph mode: the camera encoders
@@ -581,12 +631,42 @@ class ArenaTrainer:
         kn.wgrad_flush(self.dev)
         return loss.detach()
 
+    # Hook for processes that SHARE one GPU (tests: two gloo ranks on a one-GPU box): a context-manager factory entered around every stretch of GPU
+    # work that holds no collective.  The device-wide-barrier kernels need the GPU to themselves, so such ranks take turns (a file lock that
+    # synchronises the device before it is released).  Default: nothing.
+    gpu_section = staticmethod(contextlib.nullcontext)
+    time_comm = False              # bench.py: record an event pair around the wait for the gradient exchange (exposed communication)
+
+    def _comm_wait_begin(self):
+        if self.time_comm and self.dev.type == "cuda":
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            return ev
+        return None
+
+    def _comm_wait_end(self, ev) -> None:
+        if ev is not None:
+            ev[1].record()
+            self._comm_events.append(ev)
+
+    def comm_exposed_ms(self) -> float:
+        """mean time per step the compute stream spent waiting for the gradient exchange since the last call (synchronises)"""
+        evs, self._comm_events = self._comm_events, []
+        if not evs:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
     def step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         """zero grads -> training_step -> backward (+ overlapped all-reduce) -> fused Adam.  Returns the detached loss."""
-        loss = self._forward_backward(batch, batch_idx)
+        with (self.gpu_section() if not (self.multi and self.buckets.overlap) else contextlib.nullcontext()):
+            loss = self._forward_backward(batch, batch_idx)
+        ev = self._comm_wait_begin()
         self.buckets.finish()
-        self.optimizer_step()
-        self._poll_faults()
+        self._comm_wait_end(ev)
+        with self.gpu_section():
+            self.optimizer_step()
+            self._poll_faults()
         return loss
 
     _fault_every = int(os.environ.get("HULC_FAULT_CHECK_EVERY", "64"))
@@ -645,7 +725,8 @@ class ArenaTrainer:
     def replay(self) -> torch.Tensor:
         if self.graph_fb is None:
             raise RuntimeError("ArenaTrainer.replay: no captured graphs (never captured, or dropped after a barrier-kernel fault): call capture(batch)")
-        self.graph_fb.replay()
+        with self.gpu_section():
+            self.graph_fb.replay()
         if self.graph_enc is not None:
             # everything but the encoder gradients is final: reduce it on the comm stream while the conv backward graph runs
             cur, comm = torch.cuda.current_stream(), self.buckets.comm_stream
@@ -653,13 +734,19 @@ class ArenaTrainer:
             with torch.cuda.stream(comm):
                 for lo, hi in ((0, self.enc_lo), (self.enc_hi, self.total)):
                     self.comm.reduce(lo, hi)
-            self.graph_enc.replay()
+            with self.gpu_section():
+                self.graph_enc.replay()
             comm.wait_stream(cur)                    # the small encoder slice follows on the SAME stream: the staging buffers of the
             with torch.cuda.stream(comm):            # bf16 / direct modes are shared, two reduces must never run concurrently
                 self.comm.reduce(self.enc_lo, self.enc_hi)
+            ev = self._comm_wait_begin()             # (recorded behind the conv backward graph: what follows is exposed communication)
             cur.wait_stream(comm)
+            self._comm_wait_end(ev)
         else:
+            ev = self._comm_wait_begin()
             self.buckets.finish()
-        self.graph_opt.replay()
-        self._poll_faults()
+            self._comm_wait_end(ev)
+        with self.gpu_section():
+            self.graph_opt.replay()
+            self._poll_faults()
         return self.static_loss

@@ -128,6 +128,16 @@ def _comm_worker(rank, world, port, out):
             dist.all_gather(gathered, arena)
             same = all(torch.equal(gathered[0][5:n - 3], t[5:n - 3]) for t in gathered)     # replicas bit-identical after the reduce
             res[(algo, payload)] = (inside, outside, same)
+    # defaults and the description bench.py prints: "auto" resolves to ring on CPU (the timing probe is for GPUs on a real fabric), the payload
+    # rule is fp32 below 4 ranks / bf16 from 4 on (HULC_GRAD_PAYLOAD overrides), bytes on the wire = 2 (W - 1) / W x payload
+    for k in ("HULC_ALLREDUCE", "HULC_GRAD_PAYLOAD"):
+        os.environ.pop(k, None)
+    c = GradComm(torch.zeros(n), None)
+    d = c.describe()
+    res["defaults"] = (c.algo == "ring", c.payload == "fp32", d["gradient_bytes"] == 4 * n and d["bytes_sent_per_rank_per_step"] == 4 * n * (world - 1) * 2 // world)
+    c.world = 8                                            # (the rule itself, without eight processes)
+    os.environ["HULC_GRAD_PAYLOAD"] = ""
+    res["rule"] = (GradComm.default_payload(8) == "bf16", GradComm.default_payload(4) == "bf16", GradComm.default_payload(2) == "fp32")
     if rank == 0:
         out.put(res)
     dist.destroy_process_group()
@@ -143,7 +153,7 @@ def test_gradient_allreduce_algorithms_world2():
         p.start()
     _join_or_end(procs, 120)
     res = q.get(timeout=5)
-    assert len(res) == 4
+    assert len(res) == 6
     for key, flags in res.items():
         assert all(flags), f"{key}: (sum correct, neighbours untouched, replicas identical) = {flags}"
 
