@@ -120,7 +120,7 @@ HULC_DEVICE float mix_nll_lanes(const MixP& p, int t, int d, int i, float gscale
 // Tokens are split into `nseg` equal segments (one per modality when both are batched through the decoder); every
 // segment gets its own mean.  Pass 1: one (token, dim) item per thread, per-workgroup (nll, ce) partials; a workgroup
 // never straddles a segment (items per segment are padded to the workgroup size).  Pass 2: one workgroup per segment
-// adds the partials in a fixed order.  out[seg] = {total, nll_mean, ce_mean}.
+// adds the partials in a fixed order.  out (3, nseg) planar = totals | nll means | ce means.
 __global__ __launch_bounds__(256) void mix_loss_partial_kernel(MixP p, int seg_tokens, int blocks_per_seg, float* __restrict__ partial) {
     __shared__ float sh[16];
     const int seg = blockIdx.x / blocks_per_seg, bl = blockIdx.x % blocks_per_seg;
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(64) void mix_loss_final_kernel(const float* __restr
     nll = wave_sum(nll); ce = wave_sum(ce);
     if (threadIdx.x != 0) return;
     nll /= seg_tokens; ce /= seg_tokens;
-    out[3 * seg] = nll + gripper_alpha * ce; out[3 * seg + 1] = nll; out[3 * seg + 2] = ce;
+    // planar: out[0 .. nseg) = totals (what the step's loss tail reads, contiguous), then the nll means, then the ce means
+    out[seg] = nll + gripper_alpha * ce; out[gridDim.x + seg] = nll; out[2 * gridDim.x + seg] = ce;
 }
 
 // gout[seg] scales segment seg's tokens
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void plan_sample_bwd_kernel(const float* __res
 #define CLIP_D 32
 template <bool GRAD>
 __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ im, const float* __restrict__ tx,
-                                                        const unsigned char* __restrict__ use, const float* __restrict__ logit_scale, int M,
+                                                        const unsigned char* __restrict__ use, int row0, const float* __restrict__ logit_scale, int M,
                                                         float* __restrict__ out, const float* __restrict__ gout, float* __restrict__ dim_,
                                                         float* __restrict__ dtx, float* __restrict__ dscale) {
     // one workgroup; the operands are staged into LDS with coalesced loads and every later phase works from LDS (the earlier form looped
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const float s = expf(logit_scale[0]);
     for (int i = tid; i < M * CLIP_D; i += blockDim.x) { const int r = i / CLIP_D, d = i % CLIP_D; n[r * DP + d] = im[i]; t[r * DP + d] = tx[i]; }
-    for (int r = tid; r < M; r += blockDim.x) uf[r] = use[r] ? 1.f : 0.f;
+    for (int r = tid; r < M; r += blockDim.x) uf[r] = (r >= row0 && use[r - row0]) ? 1.f : 0.f;     // rows below row0 never take part (another modality's rows)
     __syncthreads();
     for (int r = tid; r < M; r += blockDim.x) {
         float a = 0.f, b = 0.f;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
         float acc = 0.f;
         for (int r = tid; r < M; r += blockDim.x) if (uf[r] != 0.f) acc += (rl[r] - L[r * LP + r]) + (cl[r] - L[r * LP + r]);
         acc = block_sum(acc, sh);
-        if (tid == 0) out[0] = cnt > 0.f ? acc / (2.f * cnt) : 0.f;
+        if (tid == 0) {
+            out[0] = cnt > 0.f ? acc / (2.f * cnt) : 0.f;
+            out[1] = cnt > 0.f ? cnt : 1.f;      // batch_size["aux_lang"] of hulc2.py:391-394: the masked-in rows, 1 when there are none
+        }
         return;
     }
     const float g = cnt > 0.f ? gout[0] / (2.f * cnt) : 0.f;
@@ -384,15 +388,10 @@ HULC_DEVICE void euler_xyz(float a, float b, float c, float (&R)[3][3]) {
     R[1][0] = sa * sb * cc + ca * sc; R[1][1] = -sa * sb * sc + ca * cc; R[1][2] = -sa * cb;
     R[2][0] = -ca * sb * cc + sa * sc; R[2][1] = ca * sb * sc + sa * cc; R[2][2] = ca * cb;
 }
-__global__ void world_to_tcp_kernel(const float* __restrict__ act, const float* __restrict__ obs, int n, int obs_dim, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* a = act + (long)i * 7;
-    const float* o = obs + (long)i * obs_dim;
+HULC_DEVICE void world_to_tcp_row(const float* a, const float* o, float* y) {
     float R[3][3], Rn[3][3];
     euler_xyz(o[3], o[4], o[5], R);
     euler_xyz(o[3] + 0.01f * a[3], o[4] + 0.01f * a[4], o[5] + 0.01f * a[5], Rn);
-    float* y = out + (long)i * 7;
     for (int r = 0; r < 3; ++r) y[r] = R[0][r] * a[0] + R[1][r] * a[1] + R[2][r] * a[2];      // R^-1 p = R^T p
     float M[3][3];
     for (int r = 0; r < 3; ++r)
@@ -405,6 +404,24 @@ __global__ void world_to_tcp_kernel(const float* __restrict__ act, const float* 
         y[3 + r] = e[r] * 100.f;
     }
     y[6] = a[6];
+}
+__global__ void world_to_tcp_kernel(const float* __restrict__ act, const float* __restrict__ obs, int n, int obs_dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    world_to_tcp_row(act + (long)i * 7, obs + (long)i * obs_dim, out + (long)i * 7);
+}
+// The decoder's target actions for a step, in the row order the recurrent kernel leaves its outputs in: nseg modality batches (B, S, 7)
+// [+ their robot_obs (B, S, obs_dim)] -> out row (s * nseg * B + seg * B + b), world -> tcp frame applied on the way (to_tcp) or copied.
+// One launch instead of two concatenations, the frame change and a transposing copy.
+struct ActSegP { const float* act[4]; const float* obs[4]; };
+__global__ void actions_time_major_kernel(ActSegP p, int nseg, int B, int S, int obs_dim, int to_tcp, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg * B * S) return;
+    const int st = i / (nseg * B), rem = i % (nseg * B), seg = rem / B, b = rem % B;
+    const float* a = p.act[seg] + ((long)b * S + st) * 7;
+    float* y = out + (long)i * 7;
+    if (to_tcp) world_to_tcp_row(a, p.obs[seg] + ((long)b * S + st) * obs_dim, y);
+    else for (int r = 0; r < 7; ++r) y[r] = a[r];
 }
 
 // tcp -> world frame (gripper_control.py:39-63): pos_w = R p, R_new = R * R(0.01*orn)^-1, orn_w = euler(R_new) - euler_obs, wrapped, x100
@@ -546,20 +563,20 @@ template <bool G> static int clip_lds_ok() {        // up to 132 KB at M = 128: 
     return rc;
 }
 
-extern "C" int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+extern "C" int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, int row0, const float* logit_scale, int M, int D,
                                   float* out, void* stream) {
     if (!im || !tx || !use || !logit_scale || !out) return hulc_fail(-1, "hulc_clip_loss_fwd: null pointer");
-    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_fwd: needs M <= 128 and D == 32");
+    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D || row0 < 0 || row0 >= M) return hulc_fail(-2, "hulc_clip_loss_fwd: needs M <= 128, D == 32, 0 <= row0 < M");
     if (clip_lds_ok<false>()) return hulc_fail(-8, "hulc_clip_loss_fwd: could not raise the dynamic LDS limit");
-    clip_loss_kernel<false><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, out, nullptr, nullptr, nullptr, nullptr);
+    clip_loss_kernel<false><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M, out, nullptr, nullptr, nullptr, nullptr);
     return hulc_check_launch("hulc_clip_loss_fwd");
 }
-extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, int row0, const float* logit_scale, int M, int D,
                                   const float* gout, float* dim, float* dtx, float* dscale, void* stream) {
     if (!im || !tx || !use || !logit_scale || !gout || !dim || !dtx || !dscale) return hulc_fail(-1, "hulc_clip_loss_bwd: null pointer");
-    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128 and D == 32");
+    if (M > CLIP_MAXM || M <= 0 || D != CLIP_D || row0 < 0 || row0 >= M) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128, D == 32, 0 <= row0 < M");
     if (clip_lds_ok<true>()) return hulc_fail(-8, "hulc_clip_loss_bwd: could not raise the dynamic LDS limit");
-    clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, logit_scale, M, nullptr, gout, dim, dtx, dscale);
+    clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M, nullptr, gout, dim, dtx, dscale);
     return hulc_check_launch("hulc_clip_loss_bwd");
 }
 
@@ -592,6 +609,21 @@ extern "C" int hulc_loss_combine_bwd(const float* g, int n, float beta, float* d
     if (n < 1 || n > 64) return hulc_fail(-2, "hulc_loss_combine_bwd: 1..64 modalities");
     loss_combine_bwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(g, n, beta, dkls, dacts, dclip);
     return hulc_check_launch("hulc_loss_combine_bwd");
+}
+
+extern "C" int hulc_actions_time_major(const float* const* act, const float* const* robot_obs, int nseg, int B, int S, int obs_dim, int to_tcp,
+                                       float* out, void* stream) {
+    if (!act || !out || (to_tcp && !robot_obs)) return hulc_fail(-1, "hulc_actions_time_major: null pointer");
+    if (nseg < 1 || nseg > 4 || B < 1 || S < 1 || (to_tcp && obs_dim < 6)) return hulc_fail(-2, "hulc_actions_time_major: 1..4 segments, robot_obs with the euler angles in columns 3:6");
+    ActSegP p{};
+    for (int i = 0; i < nseg; ++i) {
+        if (!act[i] || (to_tcp && !robot_obs[i])) return hulc_fail(-1, "hulc_actions_time_major: null segment pointer");
+        p.act[i] = act[i];
+        p.obs[i] = to_tcp ? robot_obs[i] : nullptr;
+    }
+    const int n = nseg * B * S;
+    actions_time_major_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(p, nseg, B, S, obs_dim, to_tcp, out);
+    return hulc_check_launch("hulc_actions_time_major");
 }
 
 extern "C" int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream) {

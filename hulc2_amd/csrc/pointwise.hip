@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, float eps, int R, int D,
                                                             float* __restrict__ pre_out, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int n_o = 1, long o_stride = 0) {
+                                                            int n_o = 1, long o_stride = 0, long ld_y = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = lane + q * 64;
-        if (c < D) y[(long)r * D + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
+        if (c < D) y[(long)r * (ld_y ? ld_y : D) + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
     }
     if (lane == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
 }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, int R, int D, int rows_per_block,
                                                             float* __restrict__ dpre, float* __restrict__ do_out, float drop_p,
                                                             unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, long ld_dy = 0) {
     __shared__ float red[4][2][256];
     if (seed_dev) seed ^= seed_dev[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             g[q] = 0.f; xh[q] = 0.f;
             if (c < D) {
                 const long i = (long)r * D + c;
-                const float d = dy[i];
+                const float d = dy[ld_dy ? (long)r * ld_dy + c : i];
                 xh[q] = (pre[i] - mean) * rstd;
                 g[q] = d * gamma[c];
                 dg[q] += d * xh[q]; db[q] += d;
@@ -713,6 +713,16 @@ extern "C" int hulc_layernorm_slab_fwd(const float* x, const float* o, int n_o, 
     return hulc_check_launch("hulc_layernorm_slab_fwd");
 }
 
+// the same LayerNorm writing its rows ld_y floats apart: several LayerNorms fill disjoint column / row blocks of ONE tensor (the two camera
+// encoders' 64 + 64 halves of the perceptual embedding, concat_encoders.py:96-107; the per-modality goal encoders' rows) without a concat copy
+extern "C" int hulc_layernorm_fwd_ld(const float* x, const float* gamma, const float* beta, float eps, int R, int D, float* y, long ld_y,
+                                     float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return hulc_fail(-1, "hulc_layernorm_fwd_ld: null pointer");
+    if (D > 256 || D <= 0 || ld_y < D) return hulc_fail(-2, "hulc_layernorm_fwd_ld: D must be in 1..256, ld_y >= D");
+    layernorm_fwd_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, nullptr, 0.f, 0ull, nullptr, gamma, beta, eps, R, D, nullptr, y, mean, rstd, 1, 0, ld_y);
+    return hulc_check_launch("hulc_layernorm_fwd_ld");
+}
+
 // rows per workgroup: ~256 workgroups (one per CU) once there are enough rows, never fewer than 4 rows (one per wave)
 static int ln_bwd_rows_per_block(int R) { const int r = (R + 255) / 256; return r < 4 ? 4 : r; }
 extern "C" long hulc_layernorm_bwd_workspace(int R, int D) {
@@ -731,6 +741,18 @@ extern "C" int hulc_layernorm_bwd(const float* dy, const float* pre, const float
     // partial rows are [dgamma | dbeta]; each half is summed (fixed order) into its own output
     reduce_rows_wide_kernel<<<dim3((D + 63) / 64, 2), 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params, (long)D, dbeta);
     return hulc_check_launch("hulc_layernorm_bwd");
+}
+
+// backward of hulc_layernorm_fwd_ld: the incoming gradient is the block of a wider tensor (rows ld_dy floats apart), read in place
+extern "C" int hulc_layernorm_bwd_ld(const float* dy, long ld_dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R,
+                                     int D, float* dpre, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream) {
+    if (!dy || !pre || !mean || !rstd || !gamma || !dpre || !dgamma || !dbeta || !ws) return hulc_fail(-1, "hulc_layernorm_bwd_ld: null pointer");
+    if (D > 256 || D <= 0 || ld_dy < D) return hulc_fail(-2, "hulc_layernorm_bwd_ld: D must be in 1..256, ld_dy >= D");
+    const int rpb = ln_bwd_rows_per_block(R), nb = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    layernorm_bwd_kernel<<<nb, 256, 0, s>>>(dy, pre, mean, rstd, gamma, R, D, rpb, dpre, nullptr, 0.f, 0ull, nullptr, (float*)ws, ld_dy);
+    reduce_rows_wide_kernel<<<dim3((D + 63) / 64, 2), 1024, 0, s>>>((const float*)ws, dgamma, nb, D, 2 * D, accumulate_params, (long)D, dbeta);
+    return hulc_check_launch("hulc_layernorm_bwd_ld");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -195,7 +195,8 @@ class FlattenLinearFn(torch.autograd.Function):
                 db = None
         da = None
         if ctx.needs_input_grad[0]:
-            da = torch.empty(N, K, dtype=torch.float32, device=g.device)
+            # in the activation's own storage type: autograd would otherwise cast the 2048 x 3136 gradient in a launch of its own
+            da = torch.empty(N, K, dtype=x2.dtype, device=g.device)
             kn.gemm(g, weight_operand(W, "hwc_t", chw=(C, ctx.ashape[1], ctx.ashape[2])), da, N, K, O, O, O, K, mask=x2, ld_mask=K, mask_scale=1.0)   # x (a > 0): conv3's ReLU
             da = da.view(ctx.ashape)
         return da, dW, db
@@ -412,6 +413,114 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 def add_layer_norm(x, o, gamma, beta, eps=1e-5, drop_p=0.0, seed=0):
     """LayerNorm(x + dropout(o)) — the post-norm residual step of nn.TransformerEncoderLayer."""
     return LayerNormFn.apply(x, o, gamma, beta, eps, drop_p, seed)
+
+
+@_scoped
+class LayerNormCatFn(torch.autograd.Function):
+    """cat([LayerNorm_i(x_i)], dim) without the concat: every LayerNorm writes its block of ONE output tensor (rows ld apart) and its backward
+    reads its block of the incoming gradient in place — the cameras' 64 + 64 halves of the perceptual embedding (dim = -1,
+    concat_encoders.py:96-107) and the modalities' latent goals stacked on the batch axis (dim = 0).  args = x_0 .. x_{n-1}, gamma_0, beta_0, ..."""
+
+    @staticmethod
+    def forward(ctx, dim: int, eps: float, n: int, *args):
+        xs = [_c(x.reshape(-1, x.shape[-1])) for x in args[:n]]
+        params = args[n:]
+        if dim == 0:
+            D = xs[0].shape[1]
+            R = sum(x.shape[0] for x in xs)
+            offs, acc = [], 0
+            for x in xs:
+                offs.append(acc * D)
+                acc += x.shape[0]
+            ld = D
+        else:
+            R = xs[0].shape[0]
+            D = sum(x.shape[1] for x in xs)
+            offs, acc = [], 0
+            for x in xs:
+                offs.append(acc)
+                acc += x.shape[1]
+            ld = D
+        y = _f32(R, D, like=xs[0])
+        flat = y.view(-1)
+        stats = []
+        for i, x in enumerate(xs):
+            r, d = x.shape
+            mean, rstd = _f32(r, like=x), _f32(r, like=x)
+            kn.layernorm_fwd_ld(x, params[2 * i], params[2 * i + 1], eps, r, d, flat[offs[i]:], ld, mean, rstd)
+            stats += [mean, rstd]
+        ctx.save_for_backward(*xs, *stats, *[params[2 * i] for i in range(n)])
+        ctx.betas = [params[2 * i + 1] for i in range(n)]
+        ctx.meta = (n, offs, ld, [tuple(a.shape) for a in args[:n]])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, offs, ld, shapes = ctx.meta
+        sv = ctx.saved_tensors
+        xs, stats, gammas = sv[:n], sv[n:3 * n], sv[3 * n:]
+        dyf = _c(dy).view(-1)
+        dxs, dps = [], []
+        for i in range(n):
+            x, gamma, beta = xs[i], gammas[i], ctx.betas[i]
+            r, d = x.shape
+            dx = _f32(r, d, like=dyf)
+            sg, sb = gradsink.get(gamma), gradsink.get(beta)
+            sunk = sg is not None and sb is not None
+            dg, db = (sg, sb) if sunk else (_f32(d, like=dyf), _f32(d, like=dyf))
+            acc = sunk
+            if sunk:
+                fg, fb = gradsink.first_write(gamma), gradsink.first_write(beta)
+                acc = not (fg and fb)
+            kn.layernorm_bwd_ld(dyf[offs[i]:], ld, x, stats[2 * i], stats[2 * i + 1], gamma, r, d, dx, dg, db, accumulate_params=acc)
+            dxs.append(dx.reshape(shapes[i]))
+            dps += [None if sunk else dg, None if sunk else db]
+        return (None, None, None, *dxs, *dps)
+
+
+def layer_norm_cat(xs, norms, dim: int):
+    """cat([F.layer_norm(x_i, ...)], dim) for nn.LayerNorm modules `norms` (2-D results: rows = all leading axes flattened)"""
+    params = [t for m in norms for t in (m.weight, m.bias)]
+    return LayerNormCatFn.apply(int(dim), float(norms[0].eps), len(xs), *xs, *params)
+
+
+@_scoped
+class PlanSampleKLFn(torch.autograd.Function):
+    """The posterior's two consumers in one node: straight-through plan sample (hulc2.py:235-237) + balanced KL against the prior
+    (hulc2.py:444-466) -> (plan, idx, kl (nseg,)).  Backward adds the sample's gradient onto the KL's in the sampling kernel (`accumulate`):
+    no gradient fan-in add on the (rows, 1024) logits."""
+
+    @staticmethod
+    def forward(ctx, pp, pr, idx_in, G: int, CLS: int, seed: int, beta: float, mix: float, nseg: int):
+        pp, pr = _c(pp), _c(pr)
+        B = pr.shape[0]
+        plan = _f32(B, G * CLS, like=pr)
+        idx = torch.empty(B, G, dtype=torch.long, device=pr.device)
+        kn.plan_sample_fwd(pr, _c(idx_in) if idx_in is not None else None, seed, B * G, CLS, idx, plan)
+        out = _f32(nseg, like=pp)
+        klg = _f32(B * G, like=pp)
+        kn.cat_kl_fwd(pp, pr, B, G, CLS, beta, out, klg, nseg)
+        ctx.save_for_backward(pp, pr, klg)
+        ctx.meta = (B, G, CLS, beta, mix, nseg)
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return plan, idx, out
+
+    @staticmethod
+    def backward(ctx, dplan, _didx=None, gkl=None):
+        pp, pr, klg = ctx.saved_tensors
+        B, G, CLS, beta, mix, nseg = ctx.meta
+        dpp = dpr = None
+        if gkl is not None:
+            dpp, dpr = torch.empty_like(pp), torch.empty_like(pr)
+            kn.cat_kl_bwd(pp, pr, klg, B, G, CLS, beta, mix, _c(gkl.reshape(nseg)), dpp, dpr, nseg)
+        if dplan is not None:
+            if dpr is None:
+                dpr = torch.empty_like(pr)
+                kn.plan_sample_bwd(pr, _c(dplan), B * G, CLS, dpr)
+            else:
+                kn.plan_sample_bwd(pr, _c(dplan), B * G, CLS, dpr, accumulate=True)
+        return dpp, dpr, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -934,6 +1043,7 @@ class LossCombineFn(torch.autograd.Function):
         out = _f32(4 + n, like=kls)
         kn.loss_combine_fwd(kls, acts, None if clip is None else clip.reshape(1), n, beta, out)
         ctx.meta = (n, beta, clip is not None)
+        ctx.set_materialize_grads(False)                   # (no zero tensor for the logged values' absent gradient)
         total, logs = out[0], out[1:]                      # two outputs (views of one buffer made here): no select-backward nodes later
         ctx.mark_non_differentiable(logs)
         return total, logs
@@ -962,12 +1072,12 @@ class MixLossFn(torch.autograd.Function):
         """time_major_B > 0: the rows of y / act are time-major (row = step * B + batch row, the order the recurrent kernel produces)"""
         y, act = _c(y), _c(act)
         T, A = act.shape[0], act.shape[1] - 1
-        out = _f32(nseg, 3, like=y)
+        out = _f32(3, nseg, like=y)              # planar: totals | nll means | ce means
         cfg = (T, A, n_mix, num_classes, y.stride(0), log_scale_min, gripper_alpha)
         kn.mix_loss_fwd(y, act, out, *cfg, act_min, act_max, nseg=nseg, time_major_B=time_major_B)
         ctx.save_for_backward(y, act, act_min, act_max)
         ctx.cfg, ctx.nseg, ctx.tmb = cfg, nseg, time_major_B
-        return out[:, 0].contiguous()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -1016,10 +1126,13 @@ class PlanSampleFn(torch.autograd.Function):
         ctx.save_for_backward(logits)
         ctx.meta = (B, G, CLS)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return plan, idx
 
     @staticmethod
-    def backward(ctx, dplan, _didx):
+    def backward(ctx, dplan, _didx=None):
+        if dplan is None:
+            return None, None, None, None, None
         (logits,) = ctx.saved_tensors
         B, G, CLS = ctx.meta
         dl = torch.empty_like(logits)
@@ -1029,24 +1142,55 @@ class PlanSampleFn(torch.autograd.Function):
 
 @_scoped
 class ClipLossFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, im, tx, use, logit_scale):
-        im, tx = _c(im), _c(tx)
-        use_u8 = use.to(torch.uint8)
-        M, D = im.shape
-        out = _f32(1, like=im)
-        ls = logit_scale.reshape(1)
-        kn.clip_loss_fwd(im, tx, use_u8, ls, M, D, out)
-        ctx.save_for_backward(im, tx, use_u8, ls)
-        return out[0]
+    """hulc2.py:472-508 on projected features im / tx (M, 32): -> (loss, number of rows taking part).  row0: rows below it never take part and
+    `use` describes rows row0 .. M-1 (the stacked modalities of a step: only the language rows enter the loss)."""
 
     @staticmethod
-    def backward(ctx, g):
+    def forward(ctx, im, tx, use, logit_scale, row0: int = 0):
+        im, tx = _c(im), _c(tx)
+        use_u8 = _c(use).view(torch.uint8) if use.dtype == torch.bool else use.to(torch.uint8)     # (a bool tensor IS bytes of 0 / 1: no copy)
+        M, D = im.shape
+        out = _f32(2, like=im)
+        ls = logit_scale.reshape(1)
+        kn.clip_loss_fwd(im, tx, use_u8, ls, M, D, out, row0)
+        ctx.save_for_backward(im, tx, use_u8, ls)
+        ctx.row0, ctx.scale_param = int(row0), logit_scale
+        loss, count = out[0], out[1]                       # count = rows with use != 0 (1 when none): batch_size["aux_lang"], hulc2.py:391-394
+        ctx.mark_non_differentiable(count)
+        ctx.set_materialize_grads(False)
+        return loss, count
+
+    @staticmethod
+    def backward(ctx, g, _gcount=None):
+        if g is None:
+            return None, None, None, None, None
         im, tx, use_u8, ls = ctx.saved_tensors
         M, D = im.shape
-        dim, dtx, dscale = torch.empty_like(im), torch.empty_like(tx), _f32(1, like=im)
-        kn.clip_loss_bwd(im, tx, use_u8, ls, M, D, _c(g.reshape(1)), dim, dtx, dscale)
-        return dim, dtx, None, dscale.reshape(())
+        dim, dtx = torch.empty_like(im), torch.empty_like(tx)
+        sink = gradsink.get(ctx.scale_param)
+        if sink is not None and gradsink.first_write(ctx.scale_param):
+            dscale, ret = sink.reshape(1), None            # the step's only writer: straight into the gradient arena (no AccumulateGrad add)
+        else:
+            dscale = _f32(1, like=im)
+            ret = dscale.reshape(())
+        kn.clip_loss_bwd(im, tx, use_u8, ls, M, D, _c(g.reshape(1)), dim, dtx, dscale, ctx.row0)
+        return dim, dtx, None, ret, None
+
+
+@torch.no_grad()
+def actions_time_major(acts, obss, to_tcp: bool) -> torch.Tensor:
+    """per-modality actions (B_i, S, 7) [+ robot_obs (B_i, S, obs_dim)] of equal shapes -> (S * sum B_i, 7) in the recurrent kernel's time-major
+    row order, world -> tcp frame applied on the way when to_tcp (gripper_control.py:16-36; no gradient: actions are data)"""
+    acts = [_c(a.float()) for a in acts]
+    obss = [_c(o.float()) for o in obss]
+    Bm, S, _ = acts[0].shape
+    if len(acts) > 4 or any(a.shape != acts[0].shape for a in acts):
+        a, o = torch.cat(acts, 0), torch.cat(obss, 0)
+        a = world_to_tcp_frame(a, o) if to_tcp else a
+        return a.transpose(0, 1).contiguous().reshape(-1, a.shape[-1])
+    out = torch.empty(S * Bm * len(acts), 7, dtype=torch.float32, device=acts[0].device)
+    kn.actions_time_major(acts, obss, Bm, S, obss[0].shape[-1], to_tcp, out)
+    return out
 
 
 def world_to_tcp_frame(actions, robot_obs):

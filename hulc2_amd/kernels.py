@@ -932,12 +932,12 @@ def plan_sample_bwd(logits, dplan, NG, CLS, dlogits, accumulate=False):
     _call("hulc_plan_sample_bwd", logits, dplan, _i(NG), _i(CLS), dlogits, _i(accumulate))
 
 
-def clip_loss_fwd(im, tx, use, logit_scale, M, D, out):
-    _call("hulc_clip_loss_fwd", im, tx, use, logit_scale, _i(M), _i(D), out)
+def clip_loss_fwd(im, tx, use, logit_scale, M, D, out, row0=0):
+    _call("hulc_clip_loss_fwd", im, tx, use, _i(row0), logit_scale, _i(M), _i(D), out)
 
 
-def clip_loss_bwd(im, tx, use, logit_scale, M, D, gout, dim, dtx, dscale):
-    _call("hulc_clip_loss_bwd", im, tx, use, logit_scale, _i(M), _i(D), gout, dim, dtx, dscale)
+def clip_loss_bwd(im, tx, use, logit_scale, M, D, gout, dim, dtx, dscale, row0=0):
+    _call("hulc_clip_loss_bwd", im, tx, use, _i(row0), logit_scale, _i(M), _i(D), gout, dim, dtx, dscale)
 
 
 def loss_combine_fwd(kls, acts, clip, n, beta, out):
@@ -954,6 +954,28 @@ def emb_fanout_fwd(emb, N, S, D, n_last, lo, hi, e0, elast, edec_t):
 
 def emb_fanin_bwd(g_rec, g0, g_last, g_dec_t, N, S, D, n_last, lo, hi, demb):
     _call("hulc_emb_fanin_bwd", g_rec, g0, g_last, g_dec_t, _i(N), _i(S), _i(D), _i(n_last), _i(lo), _i(hi), demb)
+
+
+def actions_time_major(acts, obss, B, S, obs_dim, to_tcp, out):
+    """acts / obss: lists (<= 4) of contiguous fp32 (B, S, 7) / (B, S, obs_dim) device tensors -> out (S * nseg * B, 7), see the header"""
+    n = len(acts)
+    _require_cuda(*acts, out)
+    A = (_c.c_void_p * n)(*[a.data_ptr() for a in acts])
+    O = (_c.c_void_p * n)(*[o.data_ptr() for o in obss]) if to_tcp else None
+    if to_tcp:
+        _require_cuda(*obss)
+    _call("hulc_actions_time_major", A, O, _i(n), _i(B), _i(S), _i(obs_dim), _i(int(bool(to_tcp))), out)
+
+
+def layernorm_fwd_ld(x, gamma, beta, eps, R, D, y, ld_y, mean, rstd):
+    _call("hulc_layernorm_fwd_ld", x, gamma, beta, _f(eps), _i(R), _i(D), y, _l(ld_y), mean, rstd)
+
+
+def layernorm_bwd_ld(dy, ld_dy, pre, mean, rstd, gamma, R, D, dpre, dgamma, dbeta, accumulate_params=False):
+    lib = _L.load()
+    lib.hulc_layernorm_bwd_workspace.restype = _c.c_long
+    ws = _ws(lib.hulc_layernorm_bwd_workspace(_i(R), _i(D)), dy.device)
+    _call("hulc_layernorm_bwd_ld", dy, _l(ld_dy), pre, mean, rstd, gamma, _i(R), _i(D), dpre, dgamma, dbeta, _i(accumulate_params), ws)
 
 
 def world_to_tcp(act, robot_obs, n, obs_dim, out):

@@ -102,7 +102,7 @@ class LogisticDecoderRNN(ActionDecoder):
         if n > 1 and len({p.shape[0] for p in plans}) > 1:          # unequal batches: fall back to separate passes
             return torch.cat([self.loss_segments([plans[i]], [embs[i]], [goals[i]], [actions[i]], [robot_obs[i]]) for i in range(n)])
         cat = (lambda ts: ts[0] if n == 1 else torch.cat(ts, dim=0))
-        return self.loss_stacked(cat(plans), cat(embs), cat(goals), cat(actions), cat(robot_obs), n)
+        return self.loss_stacked(cat(plans), cat(embs), cat(goals), list(actions), list(robot_obs), n)
 
     def loss_stacked(self, plan, emb, goal, act, obs, n: int = 1, emb_tm: bool = False) -> torch.Tensor:
         """`loss_segments` on inputs that are already stacked on the batch axis (n equal segments, rows segment-major).
@@ -111,11 +111,22 @@ class LogisticDecoderRNN(ActionDecoder):
         # + batch row): the heads read h1 in place, the loss maps rows to modality segments itself — no (B, S, 2048) transposes either way
         B, S = (emb.shape[1], emb.shape[0]) if emb_tm else (emb.shape[0], emb.shape[1])
         y = self._heads(self._rnn(plan, emb, goal, time_major=True, emb_tm=emb_tm))  # (S*B, heads)
-        acts = HF.world_to_tcp_frame(act, obs) if self.gripper_control else act
-        acts_t = acts.transpose(0, 1).contiguous().reshape(S * B, acts.shape[-1])  # 7 floats per token
-        return HF.MixLossFn.apply(y, acts_t, self.action_min_bound[0, 0, :, 0].contiguous(),
-                                  self.action_max_bound[0, 0, :, 0].contiguous(), self.n_dist, self.num_classes,
+        # targets in the same time-major row order, world -> tcp frame on the way (gripper_control.py:16-36): one launch for the stacked
+        # modalities (act / obs: one tensor, or the list of per-modality tensors — no concatenation, no transposing copy)
+        acts_l = list(act) if isinstance(act, (list, tuple)) else list(act.reshape(n, B // n, *act.shape[1:]).unbind(0))
+        obs_l = list(obs) if isinstance(obs, (list, tuple)) else list(obs.reshape(n, B // n, *obs.shape[1:]).unbind(0))
+        acts_t = HF.actions_time_major(acts_l, obs_l, self.gripper_control)           # (S * B, 7)
+        lo_b, hi_b = self._bounds()
+        return HF.MixLossFn.apply(y, acts_t, lo_b, hi_b, self.n_dist, self.num_classes,
                                   float(self.log_scale_min), float(self.gripper_alpha), n, B)
+
+    def _bounds(self):
+        """per-dimension action bounds as contiguous (A,) vectors (column 0 of the reference's (1, 1, A, n_mix) buffers), cached per buffer version"""
+        key = (self.action_min_bound._version, self.action_max_bound._version, self.action_min_bound.data_ptr(), self.action_min_bound.device)
+        c = self.__dict__.get("_bounds_cache")
+        if c is None or c[0] != key:
+            c = self.__dict__["_bounds_cache"] = (key, self.action_min_bound[0, 0, :, 0].contiguous(), self.action_max_bound[0, 0, :, 0].contiguous())
+        return c[1], c[2]
 
     def forward(self, latent_plan, perceptual_emb, latent_goal, h_0: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

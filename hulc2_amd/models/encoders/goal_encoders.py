@@ -25,9 +25,11 @@ class VisualGoalEncoder(nn.Module):
                                  nn.Linear(hidden_size, latent_goal_features))
         self.ln = nn.LayerNorm(latent_goal_features)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pre_ln: bool = False) -> torch.Tensor:
         m = self.mlp
         y = HF.mlp(x, [(m[0].weight, m[0].bias, True), (m[2].weight, m[2].bias, True), (m[4].weight, m[4].bias, False)])
+        if pre_ln:                 # Hulc2.training_step stacks the modalities' goals: the LayerNorms write the rows of one tensor
+            return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)
 
 
@@ -45,9 +47,11 @@ class LanguageGoalEncoder(nn.Module):
                                  nn.Linear(hidden_size, hidden_size), self.act_fn, nn.Linear(hidden_size, latent_goal_features))
         self.ln = nn.LayerNorm(latent_goal_features)
 
-    def forward(self, x) -> torch.Tensor:
+    def forward(self, x, pre_ln: bool = False) -> torch.Tensor:
         if self.lang_net is not None:           # list[str] -> (B, 384); SBERT stays third-party
             x = self.lang_net(x)
         m = self.mlp
         y = HF.mlp(x, [(m[1].weight, m[1].bias, True), (m[3].weight, m[3].bias, True), (m[5].weight, m[5].bias, False)])
+        if pre_ln:
+            return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)

@@ -142,29 +142,44 @@ class Hulc2(LightningModule):
             vis_first = "lang" not in mods[0][0] and all("lang" in sc for sc, _ in mods[1:])
             lo, hi = self.action_decoder.perceptual_emb_slice
             fan = vis_first and emb_all.is_cuda
+            goal_all = None
             if fan:
                 emb0, emb_last, emb_rec, emb_dec_t = HF.EmbFanoutFn.apply(emb_all, B, lo, hi)
                 with kn.site_scope("goal"):
-                    goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(emb_last) for scope, db in mods]
+                    # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
+                    # directly (no concatenation, no strided gradient slices on the way back)
+                    pre = [self.language_goal(db["lang"], pre_ln=True) if "lang" in scope else self.visual_goal(emb_last, pre_ln=True) for scope, db in mods]
+                    goal_all = HF.layer_norm_cat(pre, [self.language_goal.ln if "lang" in scope else self.visual_goal.ln for scope, _ in mods], dim=0)
+                goals = [None] * len(mods)
             else:
                 embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
                 emb0, emb_rec = emb_all[:, 0], emb_all
                 with kn.site_scope("goal"):
                     goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
-            goal_all = torch.cat(goals, dim=0)
+            if goal_all is None:
+                goal_all = torch.cat(goals, dim=0)
             with kn.site_scope("prior"):
                 pp_all = self.plan_proposal(emb0, goal_all)
             pr_all, seq_all = self.plan_recognition(emb_rec)
-            # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality
+            # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality.  Sample + KL are ONE
+            # autograd node (both consume the posterior's logits: their gradients meet inside the kernels, not in a fan-in add)
             idxs = [db.get("plan_idx") for _, db in mods]
             idx_all = torch.cat(idxs, dim=0) if all(i is not None for i in idxs) else None
-            plan_all, _ = self.dist.rsample_plan(pr_all, seed=0xA11CE, idx=idx_all)
-            kls = kl_stacked = self.dist.kl_balanced_segments(pp_all, pr_all, self.kl_beta, self.kl_balancing_mix, len(mods))
+            plan_all, _, kls = self.dist.rsample_plan_and_kl(pp_all, pr_all, 0xA11CE, idx_all, self.kl_beta, self.kl_balancing_mix, len(mods))
+            kl_stacked = kls
             act_losses = self.action_decoder.loss_stacked(plan_all, emb_dec_t if fan else emb_all, goal_all,
-                                                          torch.cat([db["actions"] for _, db in mods], dim=0),
-                                                          torch.cat([db["state_info"]["robot_obs"] for _, db in mods], dim=0), len(mods), emb_tm=fan)
+                                                          [db["actions"] for _, db in mods], [db["state_info"]["robot_obs"] for _, db in mods],
+                                                          len(mods), emb_tm=fan)
+            # the contrastive head sees the stacked rows when the language modality is the last segment: rows below row0 are masked out inside the
+            # loss kernel (their gradient is exactly zero) — no slice of the pooled features / goals, no gradient scatter on the way back
+            lang_ix = [i for i, (sc, _) in enumerate(mods) if "lang" in sc]
+            stacked_head = fan and lang_ix == [len(mods) - 1] and self.use_clip_auxiliary_loss and len(mods) * B <= 128
             for i, (self.modality_scope, db) in enumerate(mods):
-                per.append((self.modality_scope, db, None, goals[i], seq_all[i * B:(i + 1) * B], None, kls[i]))
+                if stacked_head and i == lang_ix[0]:
+                    per.append((self.modality_scope, db, None, goal_all, seq_all, i * B, None))
+                else:
+                    per.append((self.modality_scope, db, None, goals[i] if goals[i] is not None else goal_all[i * B:(i + 1) * B],
+                                seq_all[i * B:(i + 1) * B], None, None))
         else:
             for self.modality_scope, db in mods:
                 with kn.site_scope("enc"):
@@ -184,9 +199,13 @@ class Hulc2(LightningModule):
         # the scalar tail (hulc2.py:400-430) is one launch per direction: total = (sum act + sum kl) / n + beta * clip
         for i, (self.modality_scope, db, emb, latent_goal, seq_feat, plan, kl) in enumerate(per):
             if "lang" in self.modality_scope:
-                batch_size["aux_lang"] = db["actions"].shape[0]
+                batch_size["aux_lang"] = 1
                 if self.use_clip_auxiliary_loss:
-                    lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"]))
+                    row0 = plan if (kl_stacked is not None and isinstance(plan, int)) else 0        # (stacked rows: see `stacked_head` above)
+                    lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"], row0=row0))
+                    # hulc2.py:391-394: the epoch mean of train/lang_clip_loss is weighted by the number of masked-in rows (1 when there are
+                    # none) — counted by the loss kernel, a device value (no torch.any / torch.sum host round trip)
+                    batch_size["aux_lang"] = self._aux_lang_rows
             bs = db["actions"].shape[0]
             batch_size[self.modality_scope] = bs
             total_bs += bs
@@ -230,13 +249,15 @@ class Hulc2(LightningModule):
     def set_kl_beta(self, kl_beta):
         self.kl_beta = kl_beta
 
-    def clip_auxiliary_loss(self, seq_vis_feat, encoded_lang, use_for_aux_loss):
-        """hulc2.py:472-508; rows with use_for_aux_loss == False are excluded inside the kernel."""
+    def clip_auxiliary_loss(self, seq_vis_feat, encoded_lang, use_for_aux_loss, row0: int = 0):
+        """hulc2.py:472-508; rows with use_for_aux_loss == False are excluded inside the kernel.  row0 > 0: the features are the stacked rows of
+        several modalities, the flags describe rows row0 .. and the rows below never take part."""
         if use_for_aux_loss is None:
-            use_for_aux_loss = torch.ones(seq_vis_feat.shape[0], dtype=torch.bool, device=seq_vis_feat.device)
+            use_for_aux_loss = torch.ones(seq_vis_feat.shape[0] - row0, dtype=torch.bool, device=seq_vis_feat.device)
         with kn.site_scope("head"):              # exact-fp32 projections inside a bf16 step (selective precision, DESIGN §5)
             im, tx = self.proj_vis_lang(seq_vis_feat, encoded_lang)
-            return HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale)
+            loss, self._aux_lang_rows = HF.ClipLossFn.apply(im, tx, use_for_aux_loss, self.logit_scale, int(row0))
+            return loss
 
     # ---- validation and rollout inference on the same kernels (SURVEY.md §8 row f-1) ------------------------
     _plan_calls = 0

@@ -89,8 +89,14 @@ class ConcatEncoders(nn.Module):
         b, s = fr[0][3], fr[0][4]
         has_gripper = self.rgb_gripper_encoder is not None and all("rgb_gripper" in im for im in imgs_list)
         frg = [self._frames(im, "rgb_gripper") for im in imgs_list] if has_gripper else None
+        # both cameras' encoders stop in front of their final LayerNorm when they support it: the two LayerNorms then write the halves of the
+        # embedding directly (functional.LayerNormCatFn) — no concatenation copy forward, no strided-gradient copies backward
+        import inspect
+        fuse_ln = has_gripper and all(hasattr(e, "ln") and "pre_ln" in inspect.signature(e.forward).parameters
+                                      for e in (self.rgb_static_encoder, self.rgb_gripper_encoder)) and fr[0][0].is_cuda
+        kw = {"pre_ln": True} if fuse_ln else {}
         run_g = lambda: self.rgb_gripper_encoder([f[0] for f in frg], [f[1] for f in frg], self.aug_pad["rgb_gripper"],
-                                                 [f[2] for f in frg]).reshape(len(frg) * b, s, -1)
+                                                 [f[2] for f in frg], **kw).reshape(len(frg) * b, s, -1)
         # The two cameras' encoders are independent chains; the gripper's launches are small (84 x 84 frames: 20 x 20 / 9 x 9 maps, a few hundred
         # workgroups) and leave most of the chip idle.  On a second stream they fill the tails of the static camera's launches — forward here,
         # and backward too (autograd runs a node on the stream of its forward).  The streams join before the embedding is used, so the
@@ -102,13 +108,16 @@ class ConcatEncoders(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 g = run_g()
-        enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"], [f[2] for f in fr]).reshape(len(fr) * b, s, -1)
+        enc = self.rgb_static_encoder([f[0] for f in fr], [f[1] for f in fr], self.aug_pad["rgb_static"], [f[2] for f in fr], **kw).reshape(len(fr) * b, s, -1)
         if two:
             cur.wait_stream(side)
             g.record_stream(cur)
         elif has_gripper:
             g = run_g()
-        if has_gripper:
+        if fuse_ln:
+            from hulc2_amd import functional as HF
+            enc = HF.layer_norm_cat([enc, g], [self.rgb_static_encoder.ln, self.rgb_gripper_encoder.ln], dim=-1).reshape(len(fr) * b, s, -1)
+        elif has_gripper:
             enc = torch.cat([enc, g], dim=-1)
         self.current_visual_embedding = enc.detach()
         return enc

@@ -38,12 +38,14 @@ class VisionNetwork(nn.Module):
         c = self.conv_model
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)
 
-    def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0, frame_index=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0, frame_index=None, pre_ln: bool = False) -> torch.Tensor:
         a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
         # nn.Flatten + Linear(3136, 128) + ReLU on the NHWC activation in place: the weight's columns are reordered, not the activations
         c = self.conv_model
         y = HF.flatten_linear_relu(a3, c[7].weight, c[7].bias)
         y = HF.mlp(y, [(self.fc1[0].weight, self.fc1[0].bias, True), (self.fc2.weight, self.fc2.bias, False)])
+        if pre_ln:
+            return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)
 
     @staticmethod

@@ -380,9 +380,11 @@ class ArenaTrainer:
         # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
         kn.set_concurrent_streams(dev.type == "cuda" and self.multi and overlap)
         gradsink.clear()
+        self._autograd_written, self._zero_planned, self._acc_hooks = set(), None, []
         if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
             for p, off in zip(self.params, self.offsets):
                 gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape))
+                self._acc_hooks.append(p.register_post_accumulate_grad_hook(self._saw_autograd_grad))
             for pv, gv, _, _ in self.fused:
                 gradsink.register(pv, gv)
         self.step_count = 0
@@ -534,7 +536,19 @@ class ArenaTrainer:
         h, self._load_hook = getattr(self, "_load_hook", None), None
         if h is not None:
             h.remove()
+        for h in getattr(self, "_acc_hooks", ()):
+            h.remove()
+        self._acc_hooks = []
         gradsink.clear()
+
+    def _saw_autograd_grad(self, p) -> None:
+        """post-accumulate hook: this parameter's gradient arrives through autograd's `grad +=` (not a kernel-side sink), so its arena slice must
+        be zeroed before every step.  One that shows up only after the zeroing plan was made invalidates the plan (full zero + re-plan next step)."""
+        k = id(p)
+        if k not in self._autograd_written:
+            self._autograd_written.add(k)
+            if self._zero_planned is not None and k not in self._zero_planned:
+                self._zero_ranges = None
 
     def _keep_encoder_output(self, module, inputs, output):
         self._emb = output if (self._split_active and torch.is_tensor(output) and output.requires_grad) else None
@@ -555,7 +569,7 @@ class ArenaTrainer:
         emb = self._emb
         if emb is None:
             raise RuntimeError("split backward: the perceptual encoder was not called exactly through its module (no output captured)")
-        torch.autograd.backward(loss, inputs=[emb] + self.rest_params)
+        torch.autograd.backward(loss, grad_tensors=self._one_like(loss), inputs=[emb] + self.rest_params)
         kn.wgrad_flush(self.dev)                     # (autograd's end-of-pass callback already issued it: no-op unless the pass was cut short)
         return loss.detach()
 
@@ -575,8 +589,11 @@ class ArenaTrainer:
             if gradsink.written(pv):
                 spans.append((off, off + gv.numel()))
         inside = lambda a, b: any(lo <= a and b <= hi for lo, hi in spans)
+        # ... and of those only the ones autograd really accumulates into (seen by the post-accumulate hooks during this first, fully zeroed
+        # step): a parameter nobody writes (an unused module of the reference's constructor, e.g. plan_recognition.layernorm) stays zero
         need = [(off, off + p.numel()) for p, off in zip(self.params, self.offsets)
-                if not (gradsink.written(p) or inside(off, off + p.numel()))]
+                if not (gradsink.written(p) or inside(off, off + p.numel())) and id(p) in self._autograd_written]
+        self._zero_planned = {id(p) for p in self.params if id(p) in self._autograd_written}
         merged = []
         for a, b in sorted(need):
             if merged and a - merged[-1][1] <= (1 << 18):          # gaps up to 1 MB of fp32 are cheaper to zero than another launch
@@ -627,9 +644,16 @@ class ArenaTrainer:
         kn.wgrad_reset(self.dev)
         self.zero_grad()
         loss = self.model.training_step(batch, batch_idx)
-        loss.backward()
+        torch.autograd.backward(loss, grad_tensors=self._one_like(loss))
         kn.wgrad_flush(self.dev)
         return loss.detach()
+
+    def _one_like(self, loss: torch.Tensor) -> torch.Tensor:
+        """d loss / d loss = 1, kept per (shape, device): backward() would fill a fresh ones tensor every step"""
+        one = self.__dict__.get("_one")
+        if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
+            one = self.__dict__["_one"] = torch.ones_like(loss)
+        return one
 
     # Hook for processes that SHARE one GPU (tests: two gloo ranks on a one-GPU box): a context-manager factory entered around every stretch of GPU
     # work that holds no collective.  The device-wide-barrier kernels need the GPU to themselves, so such ranks take turns (a file lock that

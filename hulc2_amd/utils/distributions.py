@@ -58,3 +58,8 @@ class Distribution:
     def kl_balanced_segments(self, pp_state: DiscState, pr_state: DiscState, kl_beta: float, mix: float, nseg: int) -> torch.Tensor:
         """the same loss for nseg modalities stacked on the batch axis: (nseg,) values, each the mean over its own rows"""
         return HF.CatKLFn.apply(pp_state.logit, pr_state.logit, self.category_size, self.class_size, float(kl_beta), float(mix), int(nseg))
+
+    def rsample_plan_and_kl(self, pp_state: DiscState, pr_state: DiscState, seed: int, idx, kl_beta: float, mix: float, nseg: int = 1):
+        """rsample_plan + kl_balanced_segments as one autograd node -> (plan, idx, kl (nseg,))"""
+        return HF.PlanSampleKLFn.apply(pp_state.logit, pr_state.logit, idx, self.category_size, self.class_size, int(seed), float(kl_beta),
+                                       float(mix), int(nseg))

@@ -113,6 +113,13 @@ int hulc_layernorm_fwd(const float* x, const float* o, float drop_p, unsigned lo
 int hulc_layernorm_slab_fwd(const float* x, const float* o, int n_o, long o_stride, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, const float* gamma, const float* beta, float eps, int R, int D,
                             float* pre_out, float* y, float* mean, float* rstd, void* stream);
+/* (ABI 3) the same LayerNorm (no residual branch) writing row r at y + r * ld_y: several LayerNorms fill disjoint column / row blocks of one
+ * tensor — the cameras' halves of the perceptual embedding (concat_encoders.py:96-107), the modalities' latent goals — with no concat copy;
+ * backward reads its block of the wider gradient in place (ld_dy). */
+int hulc_layernorm_fwd_ld(const float* x, const float* gamma, const float* beta, float eps, int R, int D, float* y, long ld_y, float* mean,
+                          float* rstd, void* stream);
+int hulc_layernorm_bwd_ld(const float* dy, long ld_dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
+                          float* dpre, float* dgamma, float* dbeta, int accumulate_params, void* ws, void* stream);
 long hulc_layernorm_bwd_workspace(int R, int D);
 int hulc_layernorm_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma, int R, int D,
                        float* dpre, float* do_out, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
@@ -146,8 +153,8 @@ int hulc_attention_bwd(const float* qkv, const float* probs, const float* dout, 
 /* ---- losses ---------------------------------------------------------------------------------- */
 /* Discretised logistic mixture NLL + gripper cross-entropy over y[T][ld] = [logit_probs(A*n_mix) |
  * means | log_scales | gripper(2)] and act[T][A+1].  The T tokens form nseg equal segments (one per modality when
- * both are batched through the decoder); out[seg] = {total, nll_mean, ce_mean} with means over the segment's tokens,
- * gout[seg] is the upstream gradient of out[seg][0].
+ * both are batched through the decoder); out (3, nseg) planar = totals | nll means | ce means over the segment's tokens,
+ * gout[seg] is the upstream gradient of the total out[seg].
  * Replaces LogisticDecoderRNN._loss/_logistic_loss, logistic_decoder_rnn.py:133-152,181-228. */
 typedef struct {
     int T, A, n_mix, num_classes, nseg;
@@ -172,11 +179,14 @@ int hulc_plan_sample_fwd(const float* logits, const long* idx_in, unsigned long 
                          int NG, int CLS, long* idx_out, float* plan, void* stream);
 int hulc_plan_sample_bwd(const float* logits, const float* dplan, int NG, int CLS, float* dlogits, int accumulate, void* stream);
 /* CLIP-style symmetric contrastive loss on projected features im/tx [M][32] restricted to rows with
- * use[m] != 0 (hulc2.py:472-508); dscale = d loss / d logit_scale. */
-int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+ * use[m] != 0 (hulc2.py:472-508); dscale = d loss / d logit_scale.  out[2] = {loss, number of rows with use != 0 (1 when none): the weight
+ * `batch_size["aux_lang"]` the step logs the loss with, hulc2.py:391-394 — a device value, no host synchronisation}. */
+int hulc_clip_loss_fwd(const float* im, const float* tx, const unsigned char* use, int row0, const float* logit_scale, int M, int D,
                        float* out, void* stream);
-int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, const float* logit_scale, int M, int D,
+int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, int row0, const float* logit_scale, int M, int D,
                        const float* gout, float* dim, float* dtx, float* dscale, void* stream);
+/* (ABI 3) row0: rows 0 .. row0-1 of im / tx never take part and use[] describes rows row0 .. M-1 — the stacked modalities of a step go through
+ * the projection heads together, only the language rows enter the loss (no slicing of the pooled features, no gradient scatter). */
 /* The scalar tail of Hulc2.training_step (hulc2.py:400-430): total = (sum_m action_loss[m] + sum_m kl_loss[m]) / n + beta * clip (clip may be
  * NULL).  out (4 + n) = {total, kl mean, action mean, beta * clip, action_loss[m] + kl_loss[m] ...}: everything the step logs.  bwd: g = d total. */
 int hulc_loss_combine_fwd(const float* kls, const float* acts, const float* clip, int n, float beta, float* out, void* stream);
@@ -190,6 +200,11 @@ int hulc_emb_fanin_bwd(const float* g_rec, const float* g0, const float* g_last,
 /* Relative actions world -> tcp frame, act[n][7], robot_obs[n][obs_dim] (euler angles in 3:6),
  * gripper_control.py:16-36 (pytorch3d XYZ convention restated; parity unpinned). */
 int hulc_world_to_tcp(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
+/* The decoder's targets of a step in the time-major row order of the recurrent kernel's outputs: nseg (<= 4) modality batches act[i] (B, S, 7)
+ * with robot_obs[i] (B, S, obs_dim) -> out row (s * nseg * B + i * B + b); to_tcp != 0 applies world_to_tcp_frame (gripper_control.py:16-36) on the
+ * way, else the rows are copied (logistic_decoder_rnn.py:118-131 with gripper_control false).  act / robot_obs: HOST arrays of device pointers. */
+int hulc_actions_time_major(const float* const* act, const float* const* robot_obs, int nseg, int B, int S, int obs_dim, int to_tcp, float* out,
+                            void* stream);
 /* inverse frame change for sampled actions, tcp_to_world_frame (gripper_control.py:39-63; without the NaN quaternion fallback) */
 int hulc_tcp_to_world(const float* act, const float* robot_obs, int n, int obs_dim, float* out, void* stream);
 /* LogisticDecoderRNN._sample (logistic_decoder_rnn.py:231-255) on the fused head output y (T rows: [logit_probs | means |

@@ -322,6 +322,8 @@ def test_clip_loss(dev, model, mode):
     goal = torch.randn(B, 32, generator=syn._gen(seed, "x.clip.goal")).to(dev).requires_grad_()
     loss = model.clip_auxiliary_loss(feat, goal, torch.tensor(fx["use"]).to(dev))
     close(loss, fx["loss"], t["loss"] * 5, "clip loss")
+    # batch_size["aux_lang"] (hulc2.py:391-394): the number of masked-in rows, counted on the device by the loss kernel
+    assert float(model._aux_lang_rows) == float(int(fx["use"].sum())) and model._aux_lang_rows.is_cuda and not model._aux_lang_rows.requires_grad
     loss.backward()
     close(feat.grad, fx["g_feat"], t["grad"], "g feat")
     close(goal.grad, fx["g_goal"], t["grad"], "g goal")
@@ -329,7 +331,7 @@ def test_clip_loss(dev, model, mode):
     close(model.proj_vis_lang.mlp_lang[2].weight.grad, fx["g_lang2_w"], t["grad"], "g mlp_lang.2")
     # all-False mask -> zero loss, no NaN
     l0 = model.clip_auxiliary_loss(feat.detach(), goal.detach(), torch.zeros(B, dtype=torch.bool, device=dev))
-    assert float(l0) == 0.0
+    assert float(l0) == 0.0 and float(model._aux_lang_rows) == 1.0          # "batch_size['aux_lang'] = 1" when no row takes part (hulc2.py:392)
 
 
 @pytest.mark.parametrize("B,S", [(2, 16), (2, 32)])
