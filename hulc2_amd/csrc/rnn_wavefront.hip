@@ -24,7 +24,8 @@
 #include <stdlib.h>
 
 #define RNN_CTR_STRIDE 1024                                   // unsigned words between barrier counters (4 KB)
-#define RNN_WS_HEADER (9 * RNN_CTR_STRIDE * 4)                // 8 barrier counters + the error word
+#define RNN_WS_HEADER (17 * RNN_CTR_STRIDE * 4)               // 16 barrier counters (8 in the unpipelined kernel) + the error word
+#define RNN_ERR_WORD (16 * RNN_CTR_STRIDE)
 
 namespace {
 
@@ -262,6 +263,202 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The same sweep, software-pipelined over two independent row groups (round 3).
+//
+// A wave step of the kernel above is a dependent chain: state loads + MFMA (2.8 us) -> 8-wave sum + epilogue -> write-through exchange stores ->
+// their acknowledgement -> barrier arrival -> barrier propagation (1.3 us) -> next state loads: 6.5-7 us, the matrix pipes busy for 0.3 of them.
+// Sequences (batch rows) are independent, so the 32 rows a workgroup owns are split into two groups of 16 (the two MFMA row tiles) with their OWN
+// barrier counters, and the workgroup alternates between them: while group A's stores travel and its barrier collects the other workgroups,
+// group B's state is fetched, multiplied and reduced.  Per sub-step roles (no wave waits for something it does not need):
+//   wave 0      the exchange stores of the group just finished (64 lanes x 16 bytes = the whole 16 x 32 tile) and — one sub-step later, behind
+//               the NEXT group's state loads — `s_waitcnt vmcnt(16)`: vector memory returns in order, so with 16 younger loads outstanding the
+//               older stores have been acknowledged; then lane 0 bumps the group's barrier counter.  Nobody else waits for the acknowledgement.
+//   waves 1-2   fp32 rows (read only after the kernel), wave 3 the row-major bf16 mirror, wave 4 the transposed mirror — from LDS tiles
+//   wave 7      lanes 0-3 poll the four counters of (row half, group); it owns no stores, so its polling loads wait for nothing but themselves
+//               (a polling load behind an un-acknowledged store would wait for that store first)
+template <int H, bool WT>
+__global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
+    constexpr int KS = H / 32;
+    constexpr int KPW = KS / 8;
+    static_assert(KS % 8 == 0, "H must be a multiple of 256");
+    __shared__ float red[8][2][256];             // [wave][ct][reg*64 + lane] partial tiles of the current group
+    __shared__ uint4 wlds[8][KPW][64];
+    __shared__ __attribute__((aligned(16))) uint16_t otile[16][2][16 + 8];   // bf16 outputs of the sub-step, [row][half][col] (+pad)
+    __shared__ __attribute__((aligned(16))) float ftile[16][2][16 + 4];      // the same values in fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kb = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lgrp = xcd + 8 * (slot >> 2);
+    const int rowhalf = lgrp & 1, n0 = ((lgrp >> 1) * 4 + (slot & 3)) * 16;
+    const int nblk = gridDim.x;
+    const long ldz = 2 * H;
+
+    bf16x8_t wfa[KPW], wfb[KPW];
+#pragma unroll
+    for (int q = 0; q < KPW; ++q) {
+        const int k = (wave * KPW + q) * 32 + kb * 8;
+        wfa[q] = load_w<WT>(p.wA, p.ldA, n0 + i, k);
+        wfb[q] = load_w<WT>(p.wB1, p.ldB1, n0 + i, k);
+        union { bf16x8_t b; uint4 u; } wc; wc.b = load_w<WT>(p.wB2, p.ldB2, n0 + i, k);
+        wlds[wave][q][lane] = wc.u;
+    }
+    // this thread's output of a sub-step: tile ct = tid >> 8, accumulator element e
+    const int oct = tid >> 8, oe = tid & 255, oln = oe & 63;
+    const int orow = 4 * (oln >> 4) + (oe >> 6);                  // row inside the 16-row group
+    const int on = n0 + (oln & 15);
+    float obias[2];                                               // per group (the per-row constant differs)
+    {
+        const float* ba = oct ? p.bias2a : p.bias1a;
+        const float* bb = oct ? p.bias2b : p.bias1b;
+        const float b0 = (ba ? ba[on] : 0.f) + (bb ? bb[on] : 0.f);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int m = rowhalf * 32 + g * 16 + orow;
+            obias[g] = b0;
+            if (!oct && p.add1c) obias[g] += p.add1c[(long)(m < p.B ? m : p.B - 1) * p.ld_add1c + on];
+        }
+    }
+    int pending = -1;                                             // wave 0: group whose exchange stores await their acknowledgement
+    const int U = 2 * (p.S + 1);
+    for (int u = 0; u < U; ++u) {
+        const int g = u & 1, tau = u >> 1;
+        const bool first_on = tau < p.S, second_on = tau >= 1;
+        const int om = rowhalf * 32 + g * 16 + orow;
+        if (tau > 0) {
+            // ---- inputs of (g, tau): every workgroup of this row half has published the group's z_tau
+            if (wave == 7 && lane < 4 && !(p.dbg & 2)) {
+                const unsigned per = (unsigned)(nblk / 8) * (unsigned)tau;
+                const unsigned* bar = p.bar + (g * 8 + (xcd & 1) + 2 * lane) * RNN_CTR_STRIDE;
+                long spins = 0;
+                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1L << 22)) {
+                        __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.err_sticky) __hip_atomic_fetch_or(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            asm volatile("" ::: "memory");
+        }
+        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        const bool mul = tau > 0 && !(p.dbg & 1);
+        bf16x8_t af[2][KPW];
+        if (mul) {
+            const uint16_t* a = p.xb + (long)(p.zb_row0 + tau * p.zb_dir) * 64 * ldz + (long)(rowhalf * 32 + g * 16 + i) * 8;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int q = 0; q < KPW; ++q) af[hf][q] = load_state8(a + ((long)(hf * (H / 8) + (wave * KPW + q) * 4 + kb) * 64) * 8);
+        }
+        if (wave == 0 && pending >= 0) {
+            // the previous sub-step's exchange stores are OLDER than everything this wave has issued since (compiler barrier after them): once at
+            // most the 2 * KPW state loads above are outstanding they have been acknowledged — the other workgroups may read them
+            asm volatile("" ::: "memory");
+            if (mul) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && !(p.dbg & 2)) __hip_atomic_fetch_add(p.bar + (pending * 8 + xcd) * RNN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = -1;
+        }
+        // epilogue operands: requested behind the state loads (their latency hides under the MFMAs) and consumed as opaque values in the
+        // epilogue — hipcc otherwise hoists the `mask > 0` compare to the load and waits for it (and for everything older) right here
+        float oadd = 0.f, omask = 1.f;
+        {
+            const int m = om < p.B ? om : p.B - 1;
+            if (oct == 0) {
+                if (p.add1 && first_on) oadd = p.add1[(long)tau * p.add1_step + (long)m * p.ld_add1 + on];
+                if (p.mask1 && first_on) omask = p.mask1[(long)tau * p.mask1_step + (long)m * p.ld_mask1 + on];
+            } else if (p.mask2 && second_on) omask = p.mask2[(long)tau * p.mask2_step + (long)m * p.ld_mask2 + on];
+        }
+        if (mul) {
+#pragma unroll
+            for (int q = 0; q < KPW; ++q) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][q], wfa[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][q], wfb[q], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < KPW; ++q) {
+                union { bf16x8_t b; uint4 u; } wc; wc.u = wlds[wave][q][lane];
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][q], wc.b, acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][ct][e * 64 + lane] = acc[ct][e];
+        __syncthreads();
+        // ---- fixed-order sum over the 8 K slices + epilogue: 512 outputs, one per thread
+        {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w][oct][oe];
+            const bool on_ = oct == 0 ? first_on : second_on;
+            asm volatile("" : "+v"(oadd), "+v"(omask));
+            v += oadd + obias[g];
+            if ((oct == 0 ? p.mask1 : p.mask2) != nullptr) v = omask > 0.f ? v : 0.f;
+            else if (p.relu) v = fmaxf(v, 0.f);
+            if (!on_) v = 0.f;
+            otile[orow][oct][on - n0] = f32_to_bf16_bits(v);
+            ftile[orow][oct][on - n0] = v;
+        }
+        __syncthreads();
+        const int region = p.zb_row0 + (tau + 1) * p.zb_dir;
+        if (wave == 0) {
+            // exchange copy: lane = (row 0..15, half, 8-column chunk); skipped once nobody reads it any more (last wave step)
+            const int row = lane & 15, ct = (lane >> 4) & 1, ch = lane >> 5;
+            const int m = rowhalf * 32 + g * 16 + row;
+            if (tau < p.S) {
+                if (m < p.B && (ct == 1 || first_on)) {
+                    const uint4 v16 = *(const uint4*)&otile[row][ct][ch * 8];
+                    unsigned long long* dst = (unsigned long long*)(p.xb + (long)region * 64 * ldz + ((long)(ct * (H / 8) + n0 / 8 + ch) * 64 + m) * 8);
+                    __hip_atomic_store(dst, (unsigned long long)v16.x | ((unsigned long long)v16.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, (unsigned long long)v16.z | ((unsigned long long)v16.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                pending = g;
+            }
+            asm volatile("" ::: "memory");                         // nothing this wave loads later may be hoisted above the stores
+        } else if (wave <= 2) {
+            // fp32 rows: 16 rows x 2 halves x 4 chunks of 4 columns = 128 float4 pieces
+            const int t = tid - 64, row = t & 15, ct = (t >> 4) & 1, ch = t >> 5;
+            const int m = rowhalf * 32 + g * 16 + row;
+            if (m < p.B && (ct == 1 || first_on)) {
+                float* zn = p.z + (long)(tau + 1) * p.z_step;
+                *(float4*)(zn + (long)m * ldz + ct * H + n0 + ch * 4) = *(const float4*)&ftile[row][ct][ch * 4];
+            }
+        } else if (wave == 3) {
+            const int row = lane & 15, ct = (lane >> 4) & 1, ch = lane >> 5;
+            const int m = rowhalf * 32 + g * 16 + row;
+            if (m < p.B && (ct == 1 || first_on))
+                *(uint4*)(p.zb + (long)region * p.B * ldz + (long)m * ldz + ct * H + n0 + ch * 8) = *(const uint4*)&otile[row][ct][ch * 8];
+        } else if (wave == 4 && p.zt) {
+            // transposed mirror: lane = (half, column, 8-row chunk)
+            const int ct = lane >> 5, col = (lane >> 1) & 15, ch = lane & 1;
+            const int m = rowhalf * 32 + g * 16 + ch * 8;
+            if (m < p.B && (ct == 1 || first_on)) {               // B % 8 == 0 (checked by the launcher)
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (unsigned)otile[ch * 8 + 2 * e][ct][col] | ((unsigned)otile[ch * 8 + 2 * e + 1][ct][col] << 16);
+                *(uint4*)(p.zt + (long)(ct * H + n0 + col) * p.ld_t + (long)region * p.B + m) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        // (the LDS tiles are rewritten two barriers later: no extra barrier needed here)
+    }
+    __syncthreads();
+    if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0) {
+        __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.err_sticky) __hip_atomic_fetch_or(p.err_sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        float* zn = p.z + (long)(p.S + 1) * p.z_step;
+        for (int o = tid; o < 32 * 16; o += 512) {
+            const int m = rowhalf * 32 + o / 16, n = n0 + o % 16;
+            if (m < p.B) { zn[(long)m * ldz + n] = __builtin_nanf(""); zn[(long)m * ldz + H + n] = __builtin_nanf(""); }
+        }
+    }
+}
+
 // zero the barrier header and the bf16 mirror of the initial state row: a kernel, not hipMemsetAsync, so that a captured hipGraph holds
 // nothing but kernel nodes with plain pointer arguments (a captured hipMemsetAsync node
 // was found to leave the barrier header un-zeroed on later replays once other allocations ran in between: NaN from replay 2 on, round 2;
@@ -302,7 +499,7 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     hipStream_t s = (hipStream_t)stream;
     WaveP p;
     p.z = d->z; p.z_step = d->z_step;
-    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8 * RNN_CTR_STRIDE * 4); p.zb = (uint16_t*)((char*)ws + RNN_WS_HEADER);
+    p.bar = (unsigned*)ws; p.err = (int*)((unsigned*)ws + RNN_ERR_WORD); p.zb = (uint16_t*)((char*)ws + RNN_WS_HEADER);
     p.xb = p.zb + (long)(d->S + 2) * d->B * 2 * d->H;
     p.zt = (d->B % 8 || !d->mirror_t) ? nullptr : (uint16_t*)((char*)ws + hulc_rnn_wavefront_mirror_t_offset(d->S, d->B, d->H));
     p.ld_t = (long)(d->S + 2) * d->B;
@@ -337,7 +534,11 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
         rnn_zero2d_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p.zt + (long)p.zb_row0 * d->B, p.ld_t, d->B, 2 * d->H);
     }
     if (d->tA != d->tB1 || d->tA != d->tB2) return hulc_fail(-3, "hulc_rnn_wavefront: the three weight matrices share one layout (tA == tB1 == tB2)");
-    if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    static const bool pipelined = !(getenv("HULC_RNN_PIPE") && atoi(getenv("HULC_RNN_PIPE")) == 0);     // HULC_RNN_PIPE=0: the unpipelined kernel
+    if (pipelined) {
+        if (d->tA) rnn_wavefront2_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
+        else rnn_wavefront2_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    } else if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
     else rnn_wavefront_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);
     return hulc_check_launch("hulc_rnn_wavefront");
 }
