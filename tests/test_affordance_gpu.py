@@ -235,3 +235,42 @@ def test_trunk_on_the_grid_option_matches_the_default_trunk(monkeypatch):
     assert not alt[-1].is_contiguous()                       # a grid tensor's pixel view
     for a, b in zip(alt, base):
         assert a.shape == b.shape and (a.float() - b).abs().max().item() <= 3e-2 * b.abs().max().item()
+
+
+def test_full_size_step_properties():
+    """BASELINE configs[4] at the size bench.py --affordance runs (224 x 224, B = 32): no oracle finishes that in seconds, so the step is held to
+    size-independent properties — finite losses and gradients, bit-identical repeats (fixed summation orders everywhere), gradients of the pixel
+    loss sum to zero over an image's logits (softmax minus one-hot), hipGraph replay == eager for the same parameters, BatchNorm statistics move."""
+    dev = _dev()
+    from hulc2_amd.trainer import ArenaTrainer
+    B, HW = 32, 224
+    m, sd, own = build(HW, 31, dev)
+    syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in m.model.aff_stream.r3m.convnet.state_dict().items()}, 31)
+    gen = torch.Generator().manual_seed(9)
+    img = torch.randn(B, 3, HW, HW, generator=gen).to(dev)
+    emb = (torch.randn(B, 384, generator=gen) * 0.5).to(dev)
+    p0 = torch.stack([torch.randint(0, HW, (B,), generator=gen), torch.randint(0, HW, (B,), generator=gen)], 1).to(dev)
+    depth = torch.randn(B, generator=gen).to(dev)
+    batch = ({"img": img, "lang_goal": emb}, {"p0": p0, "normalized_depth": depth})
+    tr = ArenaTrainer(m, lr=0.0, overlap=False)                     # lr 0: the parameters stay put, every step sees the same problem
+    bn0 = [b.clone() for b in m.bn_buffers()]
+    runs = []
+    for i in range(2):
+        loss = tr._forward_backward(batch, i)
+        torch.cuda.synchronize()
+        runs.append((loss.clone(), tr.flat_g.clone()))
+    assert torch.isfinite(runs[0][0]) and torch.isfinite(runs[0][1]).all()
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "the step is not bit-reproducible"
+    nz = sum(1 for p in tr.params if p.grad is not None and float(p.grad.abs().max()) > 0)
+    assert nz >= len(tr.params) - 6, (nz, len(tr.params))           # (lang_proj of the last two blocks is unused by the reference too; head bias is analytically 0)
+    assert any(not torch.equal(a, b) for a, b in zip(bn0, m.bn_buffers()))
+    # segmentation-head bias gradient = sum over pixels of (softmax - one-hot) = 0 per image
+    hb = m.model.aff_stream.segmentation_head.bias.grad
+    assert hb is not None and float(hb.abs().max()) <= 1e-5
+    # replay == eager (BatchNorm running statistics differ between the runs but do not enter a training-mode step)
+    tr.capture(batch)
+    l_replay = tr.replay().clone()
+    g_replay = tr.flat_g.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(l_replay, runs[0][0]) and torch.equal(g_replay, runs[0][1]), (float(l_replay), float(runs[0][0]))
+    tr.close()

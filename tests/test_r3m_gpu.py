@@ -136,33 +136,67 @@ def test_folded_weights_follow_the_parameters(dev, net):
     assert not torch.equal(a, b) and torch.equal(a, c)
 
 
-def test_real_world_training_step_matches_oracle(dev):
+RW_TOL = {"fp32": dict(loss=1e-3, grad=2e-3), "mixed": dict(loss=2e-3, grad=8e-2), "bf16": dict(loss=5e-3, grad=0.2)}   # (B = 2: the bf16 BACKWARD of conv1 over 64 frames is 6 % off, as torch.autocast is)
+
+
+@pytest.mark.parametrize("B,S,cmode", [(2, 16, "fp32"), (2, 16, "bf16"), (2, 16, "mixed"), (32, 32, "bf16")])
+def test_real_world_training_step_matches_oracle(dev, B, S, cmode):
     """cfg_low_level_rw (BASELINE configs[3]): R3M static camera in [0, 255], whole-embedding decoder input, world-frame actions, no CLIP
-    loss — one training_step against the oracle composed the same way, fp32 compute."""
-    kn.set_compute("fp32")
+    loss — one training_step against the oracle composed the same way: the loss AND the gradient of every trainable parameter, in the exact
+    fp32 mode, the benchmarked bf16 mode and the mixed mode at B = 2, and once at the benchmark's full size (B = 32 per modality, S = 32: the
+    oracle's frozen trunk on 8 host threads takes about a minute).  VERDICT r02 next #9: configs[3] was pinned by one scalar."""
+    kn.set_compute(cmode)
     try:
         cfg = real_world_model_config(dropout_p=0.0)
         m = instantiate(cfg).to(dev)
         syn.fill_state_dict_(m.state_dict(), 21)
         m.train()
-        batch = syn.make_batch(21, 2, 16, static_hw=(150, 200))
+        batch = syn.make_batch(21, B, S, static_hw=(150, 200))
         for mod in batch.values():
             mod["rgb_obs"]["rgb_static"] = (mod["rgb_obs"]["rgb_static"] + 1) * 127.5          # UpScaleImageTensor range
-        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-        flat = {}
-        for name, db in batch.items():
-            flat[name] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
-                              robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
-            if name == "lang":
-                flat[name].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
-        want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
         got = m.training_step(syn._to(batch, dev), 0)
-        assert abs(got.item() - want.item()) <= 1e-3 * abs(want.item())
         got.backward()
-        assert all(p.grad is None for p in m.perceptual_encoder.rgb_static_encoder.r3m.parameters())
-        assert m.perceptual_encoder.rgb_static_encoder.fc1.weight.grad is not None
+        torch.cuda.synchronize()
     finally:
         kn.set_compute("bf16")
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    sd = {}
+    for k, v in m.state_dict().items():
+        sd[k] = v.detach().cpu().clone()
+        if k in trainable:
+            sd[k].requires_grad_(True)
+    flat = {}
+    for name, db in batch.items():
+        flat[name] = dict(rgb_static=db["rgb_obs"]["rgb_static"], rgb_gripper=db["rgb_obs"]["rgb_gripper"], actions=db["actions"],
+                          robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
+        if name == "lang":
+            flat[name].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthreads))
+    try:
+        want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
+        want.backward()
+    finally:
+        torch.set_num_threads(nthreads)
+    t = RW_TOL[cmode]
+    assert abs(got.item() - want.item()) <= t["loss"] * abs(want.item()), (got.item(), want.item())
+    assert all(p.grad is None for p in m.perceptual_encoder.rgb_static_encoder.r3m.parameters())
+    errs, checked = {}, 0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = sd[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        errs[k] = ((p.grad.double().cpu() - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
+        checked += 1
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print(f"[{cmode} B={B}] {checked} gradients, worst:", [(k, round(v, 5)) for k, v in worst])
+    assert checked >= 60
+    bad = {k: v for k, v in errs.items() if v > t["grad"]}
+    assert not bad, bad
 
 
 def test_shipped_real_world_config_with_sentence_encoder(dev):
