@@ -27,10 +27,10 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
-                            const long* cls_wtap, const void* add, hipStream_t s);
+                            const long* cls_wtap, const void* add, unsigned* bits_out, const unsigned* bits_in, int bits_channels, hipStream_t s);
 // LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s);
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, hipStream_t s);
 // LDS-band weight gradient (conv_wgrad_band.hip): same return convention
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
@@ -646,10 +646,42 @@ int validate(const hulc_conv_desc* d, const char* who) {
 
 }  // namespace
 
+// ReLU sign planes of a stored activation y [npix][C] (C % 32 == 0): planes [C / 32][npix], bit c % 32 of plane c / 32 = (y > 0) — the pass
+// behind kernels that do not write the planes from their epilogue
+__global__ __launch_bounds__(256) void relu_bits_kernel(const void* __restrict__ y, int y_dtype, long npix, int nw, unsigned* __restrict__ bits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // word i of pixel-major order: pixel i / nw, plane i % nw
+    if (i >= npix * nw) return;
+    unsigned m = 0;
+    if (y_dtype == HULC_BF16) {
+        const uint4* q = (const uint4*)((const uint16_t*)y + i * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = q[j];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                m |= (((w[e] & 0xffffu) - 1u < 0x7fffu ? 1u : 0u) | ((w[e] >> 16) - 1u < 0x7fffu ? 2u : 0u)) << (8 * j + 2 * e);
+        }
+    } else {
+        const float* q = (const float*)y + i * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) m |= (q[c] > 0.f ? 1u : 0u) << c;
+    }
+    bits[(i % nw) * npix + i / nw] = m;
+}
+static void launch_relu_bits(const hulc_conv_desc* d, const void* y, hipStream_t s) {
+    const int OH = (d->H - d->KH) / d->stride + 1, OW = (d->W - d->KW) / d->stride + 1;
+    const long npix = (long)d->N * OH * OW;
+    const int nw = d->Cout / 32;
+    relu_bits_kernel<<<(unsigned)((npix * nw + 255) / 256), 256, 0, s>>>(y, d->y_dtype, npix, nw, (unsigned*)d->relu_bits);
+}
+
 extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
     int rc = validate(d, "fwd"); if (rc) return rc;
     if (!x || !w || !y) return hulc_fail(-1, "hulc_conv2d_fwd: null pointer");
     GatherP g; fill_gather(g, d);
+    bool bits_pending = false;
+    if (d->relu_bits && (d->Cout % 32 || !d->relu)) return hulc_fail(-4, "hulc_conv2d_fwd: relu_bits needs relu and Cout % 32 == 0");
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = nullptr; g.add_dtype = HULC_F32;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
@@ -662,19 +694,28 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
         }
         rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                      y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
-                                     cOH, cOW, cyo, cco, cw0, ctap, nullptr, (hipStream_t)stream);
+                                     cOH, cOW, cyo, cco, cw0, ctap, nullptr, (d->relu && d->y_dtype == HULC_BF16) ? (unsigned*)d->relu_bits : nullptr, nullptr,
+                                     d->Cout, (hipStream_t)stream);
+        if (rc == 1 && d->relu_bits)            // (the planes' preconditions failed, not the geometry: the same launch without them)
+            rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
+                                         y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
+                                         cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, (hipStream_t)stream), bits_pending = d->relu_bits != nullptr;
+        else bits_pending = false;
         if (rc < 0) return rc;
-        if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(band)");
+        if (rc == 0) { if (bits_pending) launch_relu_bits(d, y, (hipStream_t)stream); return hulc_check_launch("hulc_conv2d_fwd(band)"); }
+        bits_pending = d->relu_bits != nullptr;
     }
     if (d->compute == HULC_BF16 && d->x_nchw && (d->x_dtype == HULC_F32 || d->x_u8_nhwc) && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 &&
         d->stride == 4) {
+        unsigned* planes = (d->relu && d->y_dtype == HULC_BF16) ? (unsigned*)d->relu_bits : nullptr;
         rc = hulc_conv1_band_dispatch((const float*)x, w, d->w_dtype, g.ldw, bias, y, d->y_dtype, d->relu, d->N, d->H, d->W, d->x_u8_nhwc, d->aug_pad,
-                                      d->aug_shift, d->frame_index, (hipStream_t)stream);
+                                      d->aug_shift, d->frame_index, planes, (hipStream_t)stream);
         if (rc < 0) return rc;
-        if (rc == 0) return hulc_check_launch("hulc_conv2d_fwd(conv1 band)");
+        if (rc == 0) { if (d->relu_bits && !planes) launch_relu_bits(d, y, (hipStream_t)stream); return hulc_check_launch("hulc_conv2d_fwd(conv1 band)"); }
     }
     if (d->x_u8_nhwc) return hulc_fail(-6, "hulc_conv2d_fwd: uint8 frames are consumed by the conv1 band kernel only (bf16 compute, 3 -> 32, 8x8 stride 4, W % 4 == 0)");
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
+    if (d->relu_bits) launch_relu_bits(d, y, (hipStream_t)stream);       // kernels without the epilogue: the planes from a second pass over y
     return hulc_check_launch("hulc_conv2d_fwd");
 }
 
@@ -716,7 +757,7 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
         }
         const int rc = hulc_conv_band_dispatch(64, 2, 3, 3, 1, x, d->x_dtype, d->N, d->H, d->W, pad, pad, g.x_sn, g.x_sy, g.x_sx, y, d->y_dtype, g.y_sn,
                                                g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_BF16, d->relu, 2, cOH, cOW, cyo, cco, cw0, ctap,
-                                               add, (hipStream_t)stream);
+                                               add, nullptr, nullptr, 0, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_padded_fwd(band)");
     }
@@ -778,10 +819,17 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
                             for (int tx = 0; tx < V; ++tx)
                                 ctap[c * 16 + ty * V + tx] = ((long)(py + s * (U - 1 - ty)) * d->KW + (px + s * (V - 1 - tx))) * d->Cout;
                     }
-            const int brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
+            int brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
                                                     (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
                                                     (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
-                                                    nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, (hipStream_t)stream);
+                                                    nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr,
+                                                    (const unsigned*)d->relu_bits, d->Cin, (hipStream_t)stream);
+            if (brc == 1 && d->relu_bits)       // the planes' preconditions failed: the same launch with the activation as the mask
+                brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
+                                              (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
+                                              (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
+                                              nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0,
+                                              (hipStream_t)stream);
             if (brc < 0) return brc;
             if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_data(band)");
         }

@@ -20,6 +20,8 @@ struct C1P {
     const void* X; const void* Wt; const float* bias; void* Y;
     int w_dtype, y_dtype, relu;
     int Nimg, H, W, OH, OW, R;
+    unsigned* bits;                              // optional ReLU sign plane: one dword per output pixel (bit c = channel c > 0)
+    int sweep;                                   // unit order: 0 = a workgroup walks whole frames, 1 = the grid sweeps memory in address order
     long ldw;
     int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
 };
@@ -35,7 +37,11 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     const float inv_OW = fast_rcp(p.OW);
     // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
     // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
-    const int nunits = ((p.Nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * bands;     // this workgroup's units
+    // sweep order (HULC_CONV1_SWEEP=1, experiment): unit u of the launch = (frame u / bands, band u % bands), workgroup w takes w, w + grid, ...
+    // — at any moment the grid reads one compact window of a few dozen frames instead of one stream per workgroup 480 KB apart
+    const int total_units = p.Nimg * bands;
+    const int nunits = p.sweep ? (total_units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
+                               : ((p.Nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * bands;     // this workgroup's units
     const int rows_max = (p.R - 1) * S + TH;
     const int PP = (rows_max * p.W + 7) / 8 * 8;                 // plane pitch (elements)
 
@@ -55,8 +61,9 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     // stage_store: any ALU use of a loaded value here would put the wait for the loads in front of the MFMA loop they overlap
     float4 xraw[XCH][2];
     auto unit_geom = [&](int unit, int& n, int& r0, int& R, int& rows) {
-        const int b = unit % bands;
+        int b = unit % bands;
         n = blockIdx.x + (unit / bands) * gridDim.x;
+        if (p.sweep) { const int g = blockIdx.x + unit * gridDim.x; n = g / bands; b = g - n * bands; }
         r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + TH;
     };
     auto stage_load = [&](int unit) {
@@ -155,6 +162,19 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
                         if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         pk[g4] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     }
+                    if (p.bits) {
+                        // sign plane of the stored bf16 values: pk[g4] = channels 8 g4 + 4 h + {0..3}; positive <=> bits in [0x0001, 0x7fff]
+                        unsigned mb = 0;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const unsigned w0 = pk[g4].x, w1 = pk[g4].y;
+                            const unsigned nib = ((w0 & 0xffffu) - 1u < 0x7fffu ? 1u : 0u) | ((w0 >> 16) - 1u < 0x7fffu ? 2u : 0u) |
+                                                 ((w1 & 0xffffu) - 1u < 0x7fffu ? 4u : 0u) | ((w1 >> 16) - 1u < 0x7fffu ? 8u : 0u);
+                            mb |= nib << (8 * g4 + 4 * h);
+                        }
+                        mb |= (unsigned)__shfl_xor((int)mb, 32);
+                        if (q < npix && h == 0) p.bits[yo >> 5] = mb;
+                    }
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
@@ -193,7 +213,9 @@ int launch_conv1(C1P& p, hipStream_t s) {
     p.R = R;
     const int slots = 512;                                       // two workgroups per CU (LDS <= 80 KB each)
     const int per = (p.Nimg + slots - 1) / slots;                // frames per workgroup
-    const int grid = (p.Nimg + per - 1) / per;
+    int grid = (p.Nimg + per - 1) / per;
+    { static const char* e = getenv("HULC_CONV1_SWEEP"); p.sweep = e ? atoi(e) : 0; }
+    if (p.sweep) { const long tu = (long)p.Nimg * bands; grid = (int)(tu < slots ? tu : slots); }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
@@ -209,12 +231,13 @@ int launch_conv1(C1P& p, hipStream_t s) {
 
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, hipStream_t s) {
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
     if (w_dtype != HULC_BF16 || ((uintptr_t)w % 16) || ldw % 8) return u8 ? hulc_fail(-6, "conv1 band: bf16 weights, 16-byte aligned rows") : 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
     C1P p;
-    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
+    if (relu_bits && (y_dtype != HULC_BF16 || !relu)) return 1;       // (planes describe the stored bf16 ReLU output)
+    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx; p.bits = relu_bits;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
     const int rc = launch_conv1<3>(p, s);

@@ -41,6 +41,9 @@ struct BandP {
     long y_sn, y_sy, y_sx;          // output element strides (channels contiguous)
     long ldw;                       // global weight row stride (elements)
     int relu;
+    unsigned* bits_out;             // optional: ReLU sign planes of Y (forward): dword (co / 32) * bplane + pixel, bit = channel % 32
+    const unsigned* bits_in;        // optional: sign planes used as the mask (data gradient) instead of `mask`
+    int bshift; long bplane;        // log2(channels of the tensor the planes describe), pixels of that tensor: planes are [channels / 32][pixels]
     int dbg;                        // timing experiments (HULC_BAND_DBG): 1 skip the MFMA loop, 2 skip the output stores, 4 skip band staging
     BandCls cls[BAND_MAXCLS];
 };
@@ -59,7 +62,9 @@ HULC_DEVICE uint4 band_load_x(const void* X, long off) {
 }
 
 // C: input channels, NSET: weight sets (32 output channels each), TH x TW taps, S: input stride, MAXCH: band chunks/thread
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32>
+// BITS: 0 = no sign planes, 1 = written from the epilogue (forward), 2 = read as the ReLU mask (data gradient) — compile-time: the kernel sits
+// at the 256-VGPR limit and a run-time switch cost every instance 20-60 bytes of scratch per lane
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32, int BITS>
 __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16;
@@ -167,6 +172,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             f32x16_t acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            // the pixel's sign-plane word is requested before the MFMA loop (one dword per lane, both lane halves the same address): its
+            // latency hides under the loop — the bf16 mask below is two 16-byte loads per lane consumed right where they are issued
+            unsigned mb_in = 0;
+            if (BITS == 2) {
+                const long pix_off = cl_yoff + (long)(n + f) * p.y_sn + (long)(r0 + oy) * p.y_sy + (long)ox * p.y_sx;
+                mb_in = p.bits_in[(long)(cl_co >> 5) * p.bplane + (pix_off >> p.bshift)];
+            }
             // pixel fragments are read RD k-steps ahead of the MFMA that consumes them: left to the compiler (256 VGPRs in use) every
             // MFMA waited for the one ds_read_b128 issued just before it — an LDS round trip (~250 cycles with 8 waves reading) per
             // 32-cycle MFMA, 21-27 % of the matrix pipe
@@ -196,6 +208,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 // trades the odd pieces of the lower half for the even pieces of the upper half: every lane then owns 8 consecutive
                 // channels — two 16-byte stores (and mask loads) per pixel instead of four 8-byte ones.
                 uint2 pk[4];
+                unsigned mb_out = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
@@ -217,7 +230,14 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                     const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
                     uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};                 // channels co_base + 16 gp + 8 h + {0..7}
                     const long off = off0 + 16 * gp + 8 * h;
-                    if (p.mask) {
+                    if (BITS == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned two = (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u;
+                            if (!(two & 1u)) o[e] &= 0xffff0000u;
+                            if (!(two & 2u)) o[e] &= 0x0000ffffu;
+                        }
+                    } else if (p.mask) {
                         const uint4 m = *(const uint4*)((const uint16_t*)p.mask + off);
                         const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
@@ -226,7 +246,18 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                             if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) o[e] &= 0x0000ffffu;
                         }
                     }
+                    if (BITS == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned two = ((o[e] & 0xffffu) - 1u < 0x7fffu ? 1u : 0u) | ((o[e] >> 16) - 1u < 0x7fffu ? 2u : 0u);
+                            mb_out |= two << (16 * gp + 8 * h + 2 * e);
+                        }
+                    }
                     if (live && !(p.dbg & 2)) *(uint4*)((uint16_t*)p.Y + off) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                if (BITS == 1) {
+                    mb_out |= (unsigned)__shfl_xor((int)mb_out, 32);
+                    if (live && h == 0) p.bits_out[(long)(cl_co >> 5) * p.bplane + ((off0 - cl_co) >> p.bshift)] = mb_out;   // 32 lanes: 128 contiguous bytes
                 }
             } else if (live) {
                 const long off = off0 + 4 * h;
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     }
 }
 
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32>
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32, int BITS>
 int launch_band_x(BandP& p, hipStream_t s) {
     constexpr int PS = C * 2 + 16, CPP = C / 8;
     const int Wb = (p.OWmax - 1) * S + TW;
@@ -280,7 +311,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
     const int per = (nunits + 255) / 256;                    // balanced persistent grid
     const int grid = (nunits + per - 1) / per;
     if (F > 1) {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32, BITS>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
@@ -288,7 +319,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
         }
         kern<<<grid, 512, lds, s>>>(p);
     } else {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32, BITS>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
@@ -299,9 +330,16 @@ int launch_band_x(BandP& p, hipStream_t s) {
     return 0;
 }
 
-template <int C, int NSET, int TH, int TW, int S, int MAXCH>
+// BITS_OK: which sign-plane role this geometry is ever launched with (1: forward conv2 writes them, 2: the data gradients read them)
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, int BITS_OK>
 int launch_band(BandP& p, hipStream_t s) {
-    return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false>(p, s);
+    const int want = p.bits_out ? 1 : (p.bits_in ? 2 : 0);
+    if (want && want != BITS_OK) return -1;
+    if (want) {
+        constexpr int B = BITS_OK ? BITS_OK : 1;
+        return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, B>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, B>(p, s);
+    }
+    return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, 0>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, 0>(p, s);
 }
 
 }  // namespace
@@ -313,11 +351,21 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
-                            const long* cls_wtap /* [ncls][16] */, const void* add, hipStream_t s) {
+                            const long* cls_wtap /* [ncls][16] */, const void* add, unsigned* bits_out, const unsigned* bits_in, int bits_channels,
+                            hipStream_t s) {
     if (getenv("HULC_NO_BAND")) return 1;
     if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
     BandP p;
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask; p.add = add;
+    p.bits_out = bits_out; p.bits_in = bits_in; p.bshift = 0; p.bplane = 0;
+    if (bits_out || bits_in) {
+        // planes exist for bf16 tensors of 32 / 64 / 128 channels whose pixels are whole multiples of the channel count apart
+        if (y_dtype != HULC_BF16 || (bits_channels != 32 && bits_channels != 64 && bits_channels != 128) || y_sx % bits_channels || y_sy % bits_channels ||
+            y_sn % bits_channels) return 1;
+        for (int c = 0; c < ncls; ++c) if (cls_yoff[c] % bits_channels) return 1;
+        while ((1 << p.bshift) < bits_channels) ++p.bshift;
+        p.bplane = (long)N * y_sn / bits_channels;           // pixels of the (dense) tensor the planes describe
+    }
     if (add && y_dtype != HULC_BF16) return 1;
     if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
@@ -334,9 +382,9 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
         if (cls_OW[c] > p.OWmax) p.OWmax = cls_OW[c];
     }
     int rc = 1;
-    if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12>(p, s);        // conv2 forward
-    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10>(p, s);   // conv3 forward / data gradient
-    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12>(p, s);   // conv2 data gradient, 4 parity classes
+    if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1>(p, s);        // conv2 forward (writes sign planes)
+    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10, 2>(p, s);   // conv3 forward / data gradient (reads them)
+    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12, 2>(p, s);   // conv2 data gradient, 4 parity classes
     else return 1;
     if (rc == -1) return 1;                      // band does not fit: gather kernel
     if (rc < 0) return hulc_fail(-8, "conv band: could not raise the dynamic LDS limit");

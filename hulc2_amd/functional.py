@@ -244,20 +244,27 @@ class ConvStackFn(torch.autograd.Function):
         ws, bs = (w1, w2, w3), (b1, b2, b3)
         acts, dims = [], []
         inp, h, w_, cin = None, H, W, C
+        # ReLU sign planes of conv1's and conv2's outputs (one bit per element, written by the forward kernels' epilogues): all the data
+        # gradients need of those activations is the sign — conv2's data gradient then reads 20 MB instead of 315 MB per 2048 frames
+        want_bits = (_act_dtype() == torch.bfloat16 and any(ctx.needs_input_grad[2:8]) and not os.environ.get("HULC_NO_RELU_BITS"))
+        bits = [None, None, None]
         for li, (k, s) in enumerate(ConvStackFn.GEOM):
             cout = ws[li].shape[0]
             nchw = li == 0
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
             y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=xs[0].device)
+            if want_bits and li < 2 and cout % 32 == 0 and (li > 0 or cout == 32):     # (conv1 writes per input tensor: one plane, pixel-major slices)
+                bits[li] = torch.empty(N * oh * ow * (cout // 32), dtype=torch.int32, device=xs[0].device)
             if li == 0:
                 off = 0
                 for x, n, sh, ix in zip(xs, Ns, shifts, indices):
                     kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
-                                  frame_index=ix)
+                                  frame_index=ix,
+                                  relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
                     off += n
             else:
-                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True)
+                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li])
             dims.append((h, w_, cin, cout, k, s, nchw))
             acts.append(y)
             inp, h, w_, cin = y, oh, ow, cout
@@ -272,6 +279,7 @@ class ConvStackFn(torch.autograd.Function):
                 saved.append(h)
         ctx.save_for_backward(saved[0], saved[1], saved[2], w2, w3, *xs)
         ctx.conv_w, ctx.conv_b = ws, bs                   # identities for the gradient sinks
+        ctx.relu_bits = bits
         ctx.aug = (pad, shifts, indices)
         ctx.meta = (dims, grad_premasked, Ns)
         return acts[2]
@@ -318,7 +326,7 @@ class ConvStackFn(torch.autograd.Function):
                 inp = inputs[li]
                 wt = weight_operand(weights[li], "ihwo")
                 dx = torch.empty(N, h, w_, cin, dtype=inp.dtype, device=g.device)
-                kn.conv2d_bwd_data(g, wt, dx, inp, N, h, w_, cin, cout, k, k, s)   # masked by relu of the layer input
+                kn.conv2d_bwd_data(g, wt, dx, inp, N, h, w_, cin, cout, k, k, s, relu_bits=ctx.relu_bits[li - 1])   # masked by relu of the layer input
                 g = dx
         return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], *([None] * len(xs)))
 

@@ -336,7 +336,7 @@ def _u8_frames(d, x, aug_shift, aug_pad, frame_index=None):
 
 
 def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
-               frame_index=None):
+               frame_index=None, relu_bits=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
     for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
     _require_cuda(x, w2d, bias, y, aug_shift, frame_index)
@@ -344,6 +344,11 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
     _u8_frames(d, x, aug_shift, aug_pad, frame_index)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
+    if relu_bits is not None:              # ReLU sign planes of y: int32 (N * OH * OW * Cout / 32,), written next to y (hulc_conv_desc.relu_bits)
+        _require_cuda(relu_bits)
+        if relu_bits.dtype != torch.int32 or not relu_bits.is_contiguous() or relu_bits.numel() != N * oh * ow * (Cout // 32):
+            raise TypeError("relu_bits: contiguous int32 tensor of N * OH * OW * Cout / 32 words")
+        d.relu_bits = relu_bits.data_ptr()
     macs = float(N) * oh * ow * Cout * Cin * KH * KW
     with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
         _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
@@ -412,13 +417,19 @@ def maxpool_nhwc(x, y, N, H, W, C, k, stride, pad):
     return y
 
 
-def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, compute=None):
-    """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout]."""
-    _require_cuda(dy, wt, dx, relu_src)
+def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, compute=None, relu_bits=None):
+    """dx (NHWC [N][H][W][Cin]) from dy (NHWC); wt = weight as [Cin][KH][KW][Cout].  relu_bits: the sign planes of the layer input
+    (int32, N * H * W * Cin / 32 words) — read instead of relu_src where the band kernel takes the launch."""
+    _require_cuda(dy, wt, dx, relu_src, relu_bits)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, False, _dt(dx), _dt(dy), _dt(wt), False, compute)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
+    if relu_bits is not None:
+        if relu_bits.dtype != torch.int32 or not relu_bits.is_contiguous() or relu_bits.numel() != N * H * W * (Cin // 32):
+            raise TypeError("relu_bits: contiguous int32 tensor of N * H * W * Cin / 32 words")
+        d.relu_bits = relu_bits.data_ptr()
     macs = float(N) * oh * ow * Cout * Cin * KH * KW
-    with _Timed(("conv2d_bwd_data", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(dy, wt, dx, relu_src)):
+    with _Timed(("conv2d_bwd_data", N, H, W, Cin, Cout, KH, stride), 2 * macs,
+                _nbytes(dy, wt, dx, relu_bits if relu_bits is not None else relu_src)):
         _L.check(_L.load().hulc_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wt), _p(dx), _p(relu_src),
                                                 ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_data")
     return dx

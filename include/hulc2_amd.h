@@ -81,6 +81,12 @@ typedef struct {
      * (hulc2/datasets/shm_dataset.py:101-118 reads its windows out of shared memory the same way; pad-by-repetition,
      * base_dataset.py:150-155, is a repeated index).  NULL = frame n. */
     const int* frame_index;
+    /* (ABI 3) ReLU sign bit-planes: one bit per output channel, Cout / 32 planes of one dword per pixel, [Cout/32][N*OH*OW], bit c % 32 of plane
+     * c / 32 = (y > 0).
+     * hulc_conv2d_fwd (relu != 0, bf16 output): written next to y when non-NULL.  hulc_conv2d_bwd_data: the planes of the layer INPUT
+     * (Cin / 32 planes over the N*H*W input pixels), used in place of relu_src where the LDS-band kernel takes the launch — the data gradient of conv2 then
+     * reads 20 MB of sign bits instead of the 315 MB activation (relu_src stays the mask of the other kernels: pass both).  NULL = none. */
+    void* relu_bits;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

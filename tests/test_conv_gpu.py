@@ -100,3 +100,50 @@ def test_conv_bwd_weight(dev, compute, name, N, H, W, Cin, Cout, K, stride, nchw
     want = base_w.double() + ref.reshape(Cout, -1)
     assert (dw2.double() - want).abs().max().item() < 1e-4 * scale + 1e-4, f"{name}: OIHW accumulated dW"
     assert (db2.double() - (base_b.double() + refb)).abs().max().item() < 1e-4 * refb.abs().max().item() + 1e-3, f"{name}: accumulated db"
+
+
+def _pack_bits(y_nhwc):
+    """reference sign planes: (C / 32, npix) int32 flattened, bit c % 32 of plane c / 32 = (y > 0)"""
+    pos = (y_nhwc.float() > 0).reshape(-1, y_nhwc.shape[-1] // 32, 32).to(torch.int64)
+    w = (pos << torch.arange(32, device=y_nhwc.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).t().contiguous().reshape(-1)
+
+
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride,nchw", [l for l in LAYERS if l[0] in ("static1", "static2", "grip1", "grip2")] +
+                         [("odd1", 2, 62, 62, 3, 32, 8, 4, True), ("odd2", 2, 17, 21, 32, 64, 4, 2, False)])
+def test_relu_sign_planes_written_by_the_forward(dev, name, N, H, W, Cin, Cout, K, stride, nchw):
+    """hulc_conv_desc.relu_bits: the planes next to a bf16 ReLU output equal (y > 0) bit for bit — from the band kernels' epilogues and, for
+    geometries they do not take (odd1 / odd2), from the second pass behind the gather kernel; y itself is unchanged by asking for them"""
+    from hulc2_amd import kernels as kn
+
+    x, w, b, _ = _setup(dev, N, H, W, Cin, Cout, K, 21)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    xin = x.contiguous() if nchw else x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    w2d = (w.reshape(Cout, -1) if nchw else w.permute(0, 2, 3, 1).reshape(Cout, -1)).contiguous().to(torch.bfloat16)
+    y0 = torch.empty(N, OH, OW, Cout, device=dev, dtype=torch.bfloat16)
+    y1 = torch.empty_like(y0)
+    bits = torch.full((N * OH * OW * (Cout // 32),), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+    kn.conv2d_fwd(xin, w2d, b, y0, N, H, W, Cin, Cout, K, K, stride, nchw, relu=True, compute=kn.BF16)
+    kn.conv2d_fwd(xin, w2d, b, y1, N, H, W, Cin, Cout, K, K, stride, nchw, relu=True, compute=kn.BF16, relu_bits=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(bits, _pack_bits(y1)), f"{name}: {(bits != _pack_bits(y1)).sum().item()} of {bits.numel()} words differ"
+    assert 0.2 < (y1 > 0).float().mean().item() < 0.8            # (a meaningful mix of signs)
+
+
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride,nchw", [l for l in LAYERS if not l[-1]] + [("odd2", 2, 17, 21, 32, 64, 4, 2, False)])
+def test_data_gradient_masked_by_sign_planes_equals_masked_by_the_activation(dev, name, N, H, W, Cin, Cout, K, stride, nchw):
+    from hulc2_amd import kernels as kn
+
+    x, w, b, g = _setup(dev, N, H, W, Cin, Cout, K, 22)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    dy = torch.randn(N, OH, OW, Cout, generator=g).to(dev).to(torch.bfloat16)
+    act = torch.relu(torch.randn(N, H, W, Cin, generator=g)).to(dev).to(torch.bfloat16)       # the layer input: a stored ReLU output
+    wt = w.permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+    a = torch.full((N, H, W, Cin), float("nan"), device=dev, dtype=torch.bfloat16)
+    b2 = torch.full_like(a, float("nan"))
+    kn.conv2d_bwd_data(dy, wt, a, act, N, H, W, Cin, Cout, K, K, stride, compute=kn.BF16)
+    kn.conv2d_bwd_data(dy, wt, b2, act, N, H, W, Cin, Cout, K, K, stride, compute=kn.BF16, relu_bits=_pack_bits(act))
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b2), f"{name}: {(a != b2).sum().item()} elements differ"
+    assert (a.float().abs() > 0).float().mean().item() > 0.2
