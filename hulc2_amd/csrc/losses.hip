@@ -306,8 +306,13 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     __shared__ float sh[16];
     const int tid = threadIdx.x;
     const float s = expf(logit_scale[0]);
+    // rows below row0 never take part (another modality's rows): the kernel works on rows row0 .. only (its cost is quadratic in the rows);
+    // the backward writes zeros for the rest
+    if (GRAD) for (int i = tid; i < row0 * CLIP_D; i += blockDim.x) { dim_[i] = 0.f; dtx[i] = 0.f; }
+    im += (long)row0 * CLIP_D; tx += (long)row0 * CLIP_D;
+    if (GRAD) { dim_ += (long)row0 * CLIP_D; dtx += (long)row0 * CLIP_D; }
     for (int i = tid; i < M * CLIP_D; i += blockDim.x) { const int r = i / CLIP_D, d = i % CLIP_D; n[r * DP + d] = im[i]; t[r * DP + d] = tx[i]; }
-    for (int r = tid; r < M; r += blockDim.x) uf[r] = (r >= row0 && use[r - row0]) ? 1.f : 0.f;     // rows below row0 never take part (another modality's rows)
+    for (int r = tid; r < M; r += blockDim.x) uf[r] = use[r] ? 1.f : 0.f;
     __syncthreads();
     for (int r = tid; r < M; r += blockDim.x) {
         float a = 0.f, b = 0.f;
@@ -568,7 +573,7 @@ extern "C" int hulc_clip_loss_fwd(const float* im, const float* tx, const unsign
     if (!im || !tx || !use || !logit_scale || !out) return hulc_fail(-1, "hulc_clip_loss_fwd: null pointer");
     if (M > CLIP_MAXM || M <= 0 || D != CLIP_D || row0 < 0 || row0 >= M) return hulc_fail(-2, "hulc_clip_loss_fwd: needs M <= 128, D == 32, 0 <= row0 < M");
     if (clip_lds_ok<false>()) return hulc_fail(-8, "hulc_clip_loss_fwd: could not raise the dynamic LDS limit");
-    clip_loss_kernel<false><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M, out, nullptr, nullptr, nullptr, nullptr);
+    clip_loss_kernel<false><<<1, 256, clip_smem(M - row0), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M - row0, out, nullptr, nullptr, nullptr, nullptr);
     return hulc_check_launch("hulc_clip_loss_fwd");
 }
 extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsigned char* use, int row0, const float* logit_scale, int M, int D,
@@ -576,7 +581,7 @@ extern "C" int hulc_clip_loss_bwd(const float* im, const float* tx, const unsign
     if (!im || !tx || !use || !logit_scale || !gout || !dim || !dtx || !dscale) return hulc_fail(-1, "hulc_clip_loss_bwd: null pointer");
     if (M > CLIP_MAXM || M <= 0 || D != CLIP_D || row0 < 0 || row0 >= M) return hulc_fail(-2, "hulc_clip_loss_bwd: needs M <= 128, D == 32, 0 <= row0 < M");
     if (clip_lds_ok<true>()) return hulc_fail(-8, "hulc_clip_loss_bwd: could not raise the dynamic LDS limit");
-    clip_loss_kernel<true><<<1, 256, clip_smem(M), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M, nullptr, gout, dim, dtx, dscale);
+    clip_loss_kernel<true><<<1, 256, clip_smem(M - row0), (hipStream_t)stream>>>(im, tx, use, row0, logit_scale, M - row0, nullptr, gout, dim, dtx, dscale);
     return hulc_check_launch("hulc_clip_loss_bwd");
 }
 

@@ -393,12 +393,15 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
     (dropout off, injected plan indices): the four losses, the perceptual embeddings and the gradient of EVERY parameter (relative L2).
     VERDICT r01: the fixture-pinned whole step had gripper_control off and the full size was only property-checked.
 
-    What the numbers say (tests/golden/error_budget.json holds every one of them): in bf16 the decoder / prior / goal gradients are
-    0.2-2 % off the fp32 oracle at full size.  Everything upstream of the contrastive head is 30 % off WITH the CLIP loss and a few %
-    without it: with random-initialised weights the 32 pooled sequence features are nearly identical, the contrastive gradient is the
-    small remainder of a sum that cancels, and bf16 rounding of its terms is amplified ~100x before it flows (weight 3.0) into the
-    transformer and the camera encoders.  The exact-fp32 mode meets 2e-3 on the very same tensors — it is the arithmetic type, not the
-    kernels."""
+    What the numbers say (tests/golden/error_budget.json holds every one of them; round 3): with random-initialised weights the 32 pooled
+    sequence features are nearly identical and the contrastive gradient is the small remainder of a sum that cancels, so every bf16 rounding
+    of a FORWARD activation upstream of the head is amplified ~100x before it flows (weight 3.0) back into the posterior and the camera
+    encoders; roundings in the backward products cost < 1 % (tools/study/bf16_emulation.py reproduces the GPU's numbers on the CPU and
+    attributes them site by site).  Three modes, three levels:
+      bf16   (headline; the contrastive head's forward alone in exact fp32): median 13 %, worst 23 % — was 19 % / 40 % with a bf16 head
+      mixed  (exact-fp32 forward upstream of the head, bf16 backward + recurrent decoder, 7.2 ms/step): every tensor <= 1.1 %
+      fp32   (exact everywhere, 18.8 ms/step): every tensor <= 2e-3
+    The flat allowance of round 2 (0.6) is gone: bf16 tensors fed by the contrastive gradient are held to 0.3 AND to 1.5 x their recorded value."""
     from hulc2_amd import kernels as kn, param_spec
     from oracle import hulc2_oracle as O
 
@@ -450,7 +453,7 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
             continue
         lim = t["grad"] * 2
         if cmode == "bf16" and clip and not n.startswith(downstream):
-            lim = 0.6                                              # cancellation-amplified (docstring); pinned by the error budget
+            lim = 0.3                                              # cancellation-amplified forward rounding (docstring); pinned by the error budget
         if cmode == "bf16" and not clip and n.startswith("perceptual_encoder.") and (".ln." in n or ".fc2." in n):
             lim = 0.5       # sums of the embedding gradient over 2048 frames that cancel to a few % of their terms
         if n == "logit_scale":
