@@ -72,8 +72,11 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         if (U8) {                                          // uint8 NHWC frames: one item = 8 elements of all three planes
             const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
             const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
+            // (a uint8 item — 8 pixels of all three channels — is 8 raw dwords, a third of what the same pixels cost as fp32: all XCH register
+            //  slots hold items, so a band is up to three times as tall and the per-unit costs (barriers, index arithmetic, a partly filled
+            //  last tile) are paid a third as often)
 #pragma unroll
-            for (int i = 0; i < XCH / C; ++i) {
+            for (int i = 0; i < XCH; ++i) {
                 const int id = tid + i * NT;
                 const bool inb = id < items;
                 uint32_t raw[8];
@@ -99,13 +102,20 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         if (U8) {
             const int sx = p.shift ? p.shift[2 * n] : p.pad;
 #pragma unroll
-            for (int i = 0; i < XCH / C; ++i) {
+            for (int i = 0; i < XCH; ++i) {
                 const int id = tid + i * NT;
                 const bool inb = id < items;
                 const uint32_t raw[8] = {__float_as_uint(xraw[i][0].x), __float_as_uint(xraw[i][0].y), __float_as_uint(xraw[i][0].z), __float_as_uint(xraw[i][0].w),
                                          __float_as_uint(xraw[i][1].x), __float_as_uint(xraw[i][1].y), __float_as_uint(xraw[i][1].z), __float_as_uint(xraw[i][1].w)};
-                u8_band_chunk3_convert(p.W, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, raw, xpre[i], xpre[XCH / C + i], xpre[2 * (XCH / C) + i]);
+                uint4 q0, q1, q2;
+                u8_band_chunk3_convert(p.W, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, raw, q0, q1, q2);
+                if (inb) {
+                    *(uint4*)(xlds + ((long)0 * PP + id * 8) * 2) = q0;
+                    *(uint4*)(xlds + ((long)1 * PP + id * 8) * 2) = q1;
+                    *(uint4*)(xlds + ((long)2 * PP + id * 8) * 2) = q2;
+                }
             }
+            return;
         } else {
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
@@ -203,7 +213,8 @@ int launch_conv1(C1P& p, hipStream_t s) {
     auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return 32 * (192 * 2 + 16) + 128 + 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
-        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512;
+        static const bool tall = !(getenv("HULC_CONV1_U8_TALL") && atoi(getenv("HULC_CONV1_U8_TALL")) == 0);
+        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * ((p.u8 && tall) ? 1 : 3) <= (long)XCH * 512;
     };
     int R = p.OH;
     while (R > 1 && !fits(R)) --R;

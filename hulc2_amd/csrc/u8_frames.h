@@ -55,7 +55,7 @@ HULC_DEVICE void u8_half4(const unsigned char* img, int H, int W, int row, int x
 
 // 8 band elements starting at flat index e0 (multiple of 8; W % 4 == 0 so a half never straddles a row); elements >= nflt are zero.
 HULC_DEVICE void u8_band_chunk3(const unsigned char* img, int H, int W, int row0, int e0, int nflt, int dx, int dy, uint4& p0, uint4& p1, uint4& p2) {
-    const int rr = e0 / W, x = e0 - rr * W;
+    const int rr = fast_div(e0, fast_rcp(W)), x = e0 - rr * W;      // (an integer division by a run-time W is ~25 instructions, four times per item)
     const bool wrap = x + 4 >= W;
     uint32_t a[3][2], b[3][2];
     u8_half4(img, H, W, row0 + rr, x, dx, dy, e0 < nflt, a);
@@ -113,14 +113,14 @@ HULC_DEVICE void u8_half4_convert(int W, int x, int dx, bool live, const uint32_
 }
 
 HULC_DEVICE void u8_band_chunk3_load(const unsigned char* img, int H, int W, int row0, int e0, int nflt, int dx, int dy, uint32_t* raw) {
-    const int rr = e0 / W, x = e0 - rr * W;
+    const int rr = fast_div(e0, fast_rcp(W)), x = e0 - rr * W;      // (an integer division by a run-time W is ~25 instructions, four times per item)
     const bool wrap = x + 4 >= W;
     u8_half4_load(img, H, W, row0 + rr, x, dx, dy, e0 < nflt, raw);
     u8_half4_load(img, H, W, row0 + rr + (wrap ? 1 : 0), wrap ? 0 : x + 4, dx, dy, e0 + 4 < nflt, raw + 4);
 }
 
 HULC_DEVICE void u8_band_chunk3_convert(int W, int e0, int nflt, int dx, const uint32_t* raw, uint4& p0, uint4& p1, uint4& p2) {
-    const int rr = e0 / W, x = e0 - rr * W;
+    const int rr = fast_div(e0, fast_rcp(W)), x = e0 - rr * W;      // (an integer division by a run-time W is ~25 instructions, four times per item)
     const bool wrap = x + 4 >= W;
     uint32_t a[3][2], b[3][2];
     u8_half4_convert(W, x, dx, e0 < nflt, raw, a);
