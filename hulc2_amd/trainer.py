@@ -76,21 +76,26 @@ class GradComm:
         try:
             for algo in ("ring", "direct"):
                 self.algo = algo
-                self.reduce(0, n)                                   # warm-up: communicators, staging buffers
-                torch.cuda.synchronize()
-                dist.barrier(group=self.group)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    self.reduce(0, n)
-                e1.record()
-                torch.cuda.synchronize()
-                t = torch.tensor([e0.elapsed_time(e1) / 3], dtype=torch.float32, device=keep.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                try:
+                    self.reduce(0, n)                               # warm-up: communicators, staging buffers
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        self.reduce(0, n)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 3
+                except Exception as e:                              # noqa: BLE001 - an algorithm this fabric / build cannot run is simply not chosen
+                    ms = float("inf")
+                    self.probe_error = f"{algo}: {type(e).__name__}: {e}"
+                t = torch.tensor([ms], dtype=torch.float32, device=keep.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)      # (every rank sees the slowest rank's time, or inf)
                 self.probe_ms[algo] = round(float(t.item()), 4)
         finally:
             self.flat_grad = keep
-        return min(self.probe_ms, key=self.probe_ms.get)
+        best = min(self.probe_ms, key=self.probe_ms.get)
+        return best if self.probe_ms[best] != float("inf") else "ring"
 
     def describe(self) -> Dict:
         """what bench.py prints about the gradient exchange: algorithm, payload, bytes, the probe's timings"""
@@ -98,7 +103,8 @@ class GradComm:
         payload_bytes = n * (2 if self.payload == "bf16" else 4)
         sent = int(2 * (self.world - 1) / max(self.world, 1) * payload_bytes)
         return {"algo": self.algo, "payload": self.payload, "gradient_bytes": payload_bytes, "bytes_sent_per_rank_per_step": sent,
-                "probe_ms": dict(self.probe_ms)}
+                "probe_ms": {k: (v if v != float("inf") else None) for k, v in self.probe_ms.items()},
+                **({"probe_error": self.probe_error} if getattr(self, "probe_error", None) else {})}
 
     def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
         t = self._bufs.get(name)

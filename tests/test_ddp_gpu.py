@@ -116,6 +116,10 @@ def test_bench_gpus_flag_starts_two_ranks():
                   {"HULC_BENCH_BACKEND": "gloo", "HULC_NO_RNN_WAVEFRONT": "1", "HULC_NO_MLP_CHAIN": "1"})   # two ranks share one GPU: no device-wide barrier kernels
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]        # finite
+    # what an N-GPU number is made of (VERDICT r02 next #3a): algorithm, payload, bytes, exposed communication time
+    comm = line["comm"]
+    assert comm["algo"] in ("ring", "direct") and comm["payload"] == "fp32" and comm["comm_exposed_ms"] >= 0.0
+    assert comm["gradient_bytes"] > 180e6 and comm["bytes_sent_per_rank_per_step"] == comm["gradient_bytes"]       # 2 (W - 1) / W = 1 at W = 2
 
 
 def test_affordance_bench_runs_on_two_ranks():
