@@ -35,6 +35,9 @@ struct ChLayer {
 };
 struct ChainP {
     ChLayer L[CH_MAXL];
+    ChLayer L2[CH_MAXL];                // dual: the SECOND chain's layers (same depth and widths, its own weights / inputs / outputs)
+    int dual, M2, nl2;                  // nl2 <= nl: the second chain may be shorter (it sits out the trailing layers); dual: rows 0..31 of every 64-row block belong to chain 1 (M <= 32), rows 32.. to chain 2 (M2 <= 32)
+    const float* x0_2; long ld_x0_2; int K0_2;
     int nl, M;
     const float* x0; long ld_x0; int K0;    // layer 0 input, fp32 [M][K0] ...
     uint16_t* x0b;                      // ... and its bf16 blocked copy (chain_stage_input)
@@ -50,12 +53,15 @@ HULC_DEVICE constexpr int s_of(int bi, int q, int ab) { return bi * ab + q; }
 // 256 workgroups then reads it as 16-byte pieces; gathering the fp32 rows directly cost 256 x M x K0 x 4 bytes of strided L2 reads
 // (74 us for a 4096-wide input).
 HULC_DEVICE void chain_stage_input(const ChainP& p, int tid, int nwg) {
-    const long nchunk = ((long)(p.K0 + 7) / 8) * 64;
+    const int kmax = (p.dual && p.K0_2 > p.K0) ? p.K0_2 : p.K0;
+    const long nchunk = ((long)(kmax + 7) / 8) * 64;
     for (long i = (long)blockIdx.x * 256 + tid; i < nchunk; i += (long)nwg * 256) {
         const int m = (int)(i & 63), k = (int)(i >> 6) * 8;
         uint4 o = make_uint4(0u, 0u, 0u, 0u);
-        if (m < p.M && k < p.K0) {                                         // K0 is a multiple of 8
-            const float* src = p.x0 + (long)m * p.ld_x0 + k;
+        const bool second = p.dual && m >= 32;
+        const int mm = second ? m - 32 : m;
+        if (mm < (second ? p.M2 : p.M) && k < (second ? p.K0_2 : p.K0)) {      // K0 is a multiple of 8
+            const float* src = (second ? p.x0_2 + (long)mm * p.ld_x0_2 : p.x0 + (long)mm * p.ld_x0) + k;
             const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
             o = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
         }
@@ -73,18 +79,22 @@ template <int KSW>
 HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const uint16_t* __restrict__ xin, float (*red)[64][16], int tid, bool& timed_out,
                              int nwg) {
     const ChLayer& c = p.L[l];
+    const bool dual = p.dual && l < p.nl2;
+    const ChLayer& c2 = dual ? p.L2[l] : p.L[l];                      // dual: the second chain's layer (row tiles 2, 3)
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int ntile = c.N / 16;
     const bool active = tile < ntile;
     const int n0 = (active ? tile : 0) * 16;
     // ---- weight fragments of this wave's k range: requested before the wait on the previous layer
-    F8 wf[KSW];
+    F8 wf[KSW], wf2[KSW];
     {
         const uint16_t* wrow = c.W + (long)(n0 + r) * c.ldw;
+        const uint16_t* wrow2 = c2.W + (long)(n0 + r) * c2.ldw;
 #pragma unroll
         for (int s = 0; s < KSW; ++s) {
             const int k = (wave * KSW + s) * 32 + g * 8;
             wf[s].u = *(const uint4*)(wrow + (k < c.K ? k : 0));            // clamped (always valid) address; the matching A fragment is zero
+            if (dual) wf2[s].u = *(const uint4*)(wrow2 + (k < c2.K ? k : 0));
         }
     }
     // ---- wait for the previous stage's outputs (all workgroups): stage 0 = the input copy, stage l = layer l - 1
@@ -121,7 +131,8 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
     f32x4_t acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int MT = (p.M + 15) / 16;
+    const int MT = dual ? 2 + (p.M2 + 15) / 16 : (p.M + 15) / 16;     // (dual: tiles 0, 1 = chain 1, tiles 2, 3 = chain 2)
+    const int MT1 = (p.M + 15) / 16;
     constexpr int AB = KSW >= 32 ? 2 : (KSW >= 4 ? 4 : KSW);            // k-steps per batch
     constexpr int NB = KSW / AB;
     static_assert(KSW % AB == 0, "batches tile the k range");
@@ -130,7 +141,7 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
 #pragma unroll
         for (int q = 0; q < AB; ++q) {
             const int k = (wave * KSW + bi * AB + q) * 32 + g * 8;
-            const bool kin = k < c.K;
+            const bool kin = k < (c.K > c2.K ? c.K : c2.K);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = mt * 16 + r;
@@ -147,12 +158,14 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
 #pragma unroll
             for (int q = 0; q < AB; ++q) {
                 const int k = (wave * KSW + bi * AB + q) * 32 + g * 8;
-                const bool kin = k < c.K;
+                const bool kin1 = k < c.K, kin2 = k < c2.K;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     F8 a = af[bi & 1][q][mt];
-                    if (!kin) a.u = make_uint4(0u, 0u, 0u, 0u);
-                    if (mt < MT) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, wf[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
+                    const bool sec = dual && mt >= 2;
+                    if (!(sec ? kin2 : kin1)) a.u = make_uint4(0u, 0u, 0u, 0u);
+                    const bool on = dual ? (mt < 2 ? mt < MT1 : mt < MT) : mt < MT;
+                    if (on) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, (sec ? wf2 : wf)[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -169,21 +182,25 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (red[0][m][n4 + j] + red[1][m][n4 + j]) + (red[2][m][n4 + j] + red[3][m][n4 + j]);
-        const int mc = m < p.M ? m : p.M - 1;
-        if (c.bias) {
-            const float4 b = *(const float4*)(c.bias + n0 + n4);
+        const bool sec = dual && m >= 32;                   // this row belongs to the second chain
+        const ChLayer& e = sec ? c2 : c;
+        const int rows = sec ? p.M2 : p.M, mm = sec ? m - 32 : m;
+        const bool live = mm < rows;
+        const int mc = live ? mm : rows - 1;
+        if (e.bias) {
+            const float4 b = *(const float4*)(e.bias + n0 + n4);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        if (c.mask) {
-            const float4 mk = *(const float4*)(c.mask + (long)mc * c.ld_mask + n0 + n4);
-            v[0] = mk.x > 0.f ? v[0] * c.mask_scale : 0.f; v[1] = mk.y > 0.f ? v[1] * c.mask_scale : 0.f;
-            v[2] = mk.z > 0.f ? v[2] * c.mask_scale : 0.f; v[3] = mk.w > 0.f ? v[3] * c.mask_scale : 0.f;
-        } else if (c.relu) {
+        if (e.mask) {
+            const float4 mk = *(const float4*)(e.mask + (long)mc * e.ld_mask + n0 + n4);
+            v[0] = mk.x > 0.f ? v[0] * e.mask_scale : 0.f; v[1] = mk.y > 0.f ? v[1] * e.mask_scale : 0.f;
+            v[2] = mk.z > 0.f ? v[2] * e.mask_scale : 0.f; v[3] = mk.w > 0.f ? v[3] * e.mask_scale : 0.f;
+        } else if (e.relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        if (m < p.M) *(float4*)(c.out + (long)m * c.ld_out + n0 + n4) = make_float4(v[0], v[1], v[2], v[3]);
-        if (l + 1 < p.nl && m < p.M) {           // exchange copy for the next layer: [n / 8][64][8] bf16, device-scope write-through
+        if (live) *(float4*)(e.out + (long)mm * e.ld_out + n0 + n4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (l + 1 < (sec ? p.nl2 : p.nl) && live) {              // exchange copy for the next layer: [n / 8][64][8] bf16, device-scope write-through
             uint16_t* dst = p.xb + c.xb_off + ((long)((n0 + n4) / 8) * 64 + m) * 8 + (n4 & 7);
             const unsigned long long bits = (unsigned long long)pack_bf16x2(v[0], v[1]) | ((unsigned long long)pack_bf16x2(v[2], v[3]) << 32);
             __hip_atomic_store((unsigned long long*)dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nwg = gridDim.x, tile = blockIdx.x;                         // N <= 16 * gridDim: at most one tile per workgroup and layer
     chain_stage_input(p, tid, nwg);
     for (int l = 0; l < p.nl; ++l) {
-        const int ksw = (p.L[l].K + 127) / 128;
+        const int ksw = ((p.dual && l < p.nl2 && p.L2[l].K > p.L[l].K ? p.L2[l].K : p.L[l].K) + 127) / 128;
         const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : p.x0b;
         switch (ksw) {
             case 1: chain_layer<1>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
@@ -229,16 +246,11 @@ extern "C" long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d) {
     return CH_HEADER + elems * 2 + 64 + ((long)(d->K0 + 7) / 8) * 64 * 16;     // header, exchange regions, the blocked input
 }
 
-// see include/hulc2_amd.h
-extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream) {
-    if (!d || !ws || !d->x0) return hulc_fail(-1, "hulc_mlp_chain: null pointer");
+// validates one chain description and fills its device-side layer table; returns 0 or an error code
+static int chain_fill(const hulc_mlp_chain_desc* d, ChLayer* L, int max_rows) {
     if (d->nl < 1 || d->nl > CH_MAXL) return hulc_fail(-2, "hulc_mlp_chain: 1..8 layers");
-    if (d->M < 1 || d->M > 64) return hulc_fail(-2, "hulc_mlp_chain: 1 <= M <= 64 rows");
-    if ((uintptr_t)ws % 16 || (uintptr_t)d->x0 % 16 || d->ld_x0 % 4) return hulc_fail(-4, "hulc_mlp_chain: workspace / input must be 16-byte aligned");
-    ChainP p = {};
-    p.nl = d->nl; p.M = d->M; p.x0 = d->x0; p.ld_x0 = d->ld_x0; p.K0 = d->K0;
-    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8L * CH_CTR_STRIDE * 4); p.err_sticky = err_sticky;
-    p.xb = (uint16_t*)((char*)ws + CH_HEADER);
+    if (d->M < 1 || d->M > max_rows) return hulc_fail(-2, "hulc_mlp_chain: 1 <= M <= 64 rows (32 per chain of a pair)");
+    if (!d->x0 || (uintptr_t)d->x0 % 16 || d->ld_x0 % 4) return hulc_fail(-4, "hulc_mlp_chain: input must be 16-byte aligned");
     long off = 0;
     int kin = d->K0;
     for (int l = 0; l < d->nl; ++l) {
@@ -251,14 +263,51 @@ extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_s
             return hulc_fail(-3, "hulc_mlp_chain: K must round up to 128 x {1, 2, 3, 4, 8, 16, 32}");
         if (s.bias && (uintptr_t)s.bias % 16) return hulc_fail(-4, "hulc_mlp_chain: bias must be 16-byte aligned");
         if (s.mask && ((uintptr_t)s.mask % 16 || s.ld_mask % 4)) return hulc_fail(-4, "hulc_mlp_chain: mask must be 16-byte aligned");
-        ChLayer& c = p.L[l];
+        ChLayer& c = L[l];
         c.W = (const uint16_t*)s.W; c.ldw = s.ldw; c.bias = s.bias; c.mask = s.mask; c.ld_mask = s.ld_mask; c.mask_scale = s.mask_scale;
         c.out = s.out; c.ld_out = s.ld_out; c.N = s.N; c.K = kin; c.relu = s.relu; c.xb_off = off;
         off += (long)s.N * 64;
         kin = s.N;
     }
-    hipStream_t st = (hipStream_t)stream;
-    p.x0b = p.xb + ((off - (long)d->layers[d->nl - 1].N * 64 + 7) / 8) * 8;          // behind the exchange regions of layers 0 .. nl-2
-    mlp_chain_kernel<<<256, 256, 0, st>>>(p);
+    return 0;
+}
+
+static int chain_launch(const hulc_mlp_chain_desc* d, const hulc_mlp_chain_desc* d2, void* ws, int* err_sticky, void* stream) {
+    if (!d || !ws) return hulc_fail(-1, "hulc_mlp_chain: null pointer");
+    if ((uintptr_t)ws % 16) return hulc_fail(-4, "hulc_mlp_chain: workspace must be 16-byte aligned");
+    ChainP p = {};
+    int rc = chain_fill(d, p.L, d2 ? 32 : 64);
+    if (rc) return rc;
+    p.nl = d->nl; p.M = d->M; p.x0 = d->x0; p.ld_x0 = d->ld_x0; p.K0 = d->K0;
+    if (d2) {
+        rc = chain_fill(d2, p.L2, 32);
+        if (rc) return rc;
+        if (d2->nl > d->nl) return hulc_fail(-2, "hulc_mlp_chain2: the first chain is the deeper one");
+        for (int l = 0; l < d2->nl; ++l)
+            if (d2->layers[l].N != d->layers[l].N) return hulc_fail(-2, "hulc_mlp_chain2: the chains have the same layer widths where both run");
+        p.dual = 1; p.nl2 = d2->nl; p.M2 = d2->M; p.x0_2 = d2->x0; p.ld_x0_2 = d2->ld_x0; p.K0_2 = d2->K0;
+        const int k1 = (d->K0 + 127) / 128, k2 = (d2->K0 + 127) / 128, km = k1 > k2 ? k1 : k2;   // layer 0 runs at the larger input width
+        if (!(km == 1 || km == 2 || km == 3 || km == 4 || km == 8 || km == 16 || km == 32)) return hulc_fail(-3, "hulc_mlp_chain2: K0 must round up to 128 x {1, 2, 3, 4, 8, 16, 32}");
+    }
+    p.bar = (unsigned*)ws; p.err = (int*)((char*)ws + 8L * CH_CTR_STRIDE * 4); p.err_sticky = err_sticky;
+    p.xb = (uint16_t*)((char*)ws + CH_HEADER);
+    long off = 0;
+    for (int l = 0; l + 1 < d->nl; ++l) off += (long)d->layers[l].N * 64;
+    p.x0b = p.xb + ((off + 7) / 8) * 8;                      // behind the exchange regions of layers 0 .. nl-2
+    mlp_chain_kernel<<<256, 256, 0, (hipStream_t)stream>>>(p);
     return hulc_check_launch("hulc_mlp_chain");
+}
+
+// see include/hulc2_amd.h
+extern "C" int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream) {
+    return chain_launch(d, nullptr, ws, err_sticky, stream);
+}
+
+// Two INDEPENDENT chains (their own weights, inputs of possibly different width, outputs, <= 32 rows each; b no deeper than a, and the same
+// layer widths on the layers both run) as one launch: the visual and the language goal encoder (goal_encoders.py:21-34 / :53-71) and their data-gradient chains.  A workgroup's
+// column tile multiplies row tiles 0-1 by the first chain's weight fragments and row tiles 2-3 by the second's; a launch (and a device-wide
+// barrier per layer) is paid once for both.  ws: hulc_mlp_chain_workspace(a) + hulc_mlp_chain_workspace(b) bytes.
+extern "C" int hulc_mlp_chain2(const hulc_mlp_chain_desc* a, const hulc_mlp_chain_desc* b, void* ws, int* err_sticky, void* stream) {
+    if (!a || !b) return hulc_fail(-1, "hulc_mlp_chain2: null pointer");
+    return chain_launch(a, b, ws, err_sticky, stream);
 }

@@ -92,52 +92,116 @@ class MLPFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         x2, acts, params = saved[0], saved[1:L], saved[L:]
         g = _c(dy.reshape(-1, dy.shape[-1]))
-        M = g.shape[0]
-        grads = [None] * (2 * L)
         need_x = ctx.needs_input_grad[0]
-        # data-gradient chain  g_{i-1} = (g_i W_i) * (act_{i-1} > 0)  as one persistent launch when the forward took that path
-        gs = {L - 1: g}
-        lo_layer = 0 if need_x else 1                       # lowest layer whose input gradient is wanted
-        n_chain = L - lo_layer
-        ks = [x2.shape[1]] + [params[2 * i].shape[0] for i in range(L - 1)]      # input width of layer i
-        if (ctx.chain and n_chain >= 2 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0
+        dx, grads = _mlp_backward(x2, acts, params, relus, drops, g, need_x, ctx.chain)
+        return (dx.reshape(xshape) if need_x else None, None, None, None, *grads)
+
+
+def _dgrad_chain_layers(acts, params, relus, drops, g, lo_layer, ks):
+    """the data-gradient chain  g_{i-1} = (g_i W_i) * (act_{i-1} > 0)  of layers L-1 .. lo_layer as mlp_chain layer tuples; -> (layers, {i-1: out})"""
+    L = len(relus)
+    layers, gs = [], {}
+    for i in range(L - 1, lo_layer - 1, -1):
+        out = _f32(g.shape[0], ks[i], like=g)
+        masked = i > 0 and relus[i - 1]
+        layers.append((weight_operand(params[2 * i], "t"), None, False, acts[i - 1] if masked else None,
+                       1.0 / (1.0 - drops[i - 1]) if masked else 1.0, out))
+        gs[i - 1] = out
+    return layers, gs
+
+
+def _mlp_backward(x2, acts, params, relus, drops, g, need_x, chain, gs=None):
+    """backward of a Linear(+ReLU(+Dropout)) stack: -> (dx or None, [dW0, db0, ...] with None where the gradient went into the arena).
+    gs: data gradients {layer index: tensor} a caller already produced (DualMLPFn's paired chain launch)"""
+    L = len(relus)
+    M = g.shape[0]
+    grads = [None] * (2 * L)
+    lo_layer = 0 if need_x else 1                       # lowest layer whose input gradient is wanted
+    n_chain = L - lo_layer
+    ks = [x2.shape[1]] + [params[2 * i].shape[0] for i in range(L - 1)]      # input width of layer i
+    if gs is None:
+        gs = {}
+        # the data-gradient chain as one persistent launch when the forward took that path
+        if (chain and n_chain >= 2 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0
                 and kn.mlp_chain_ok(M, g.shape[1], [ks[i] for i in range(L - 1, lo_layer - 1, -1)], g.device)):
-            layers = []
-            for i in range(L - 1, lo_layer - 1, -1):
-                out = _f32(M, ks[i], like=g)
-                masked = i > 0 and relus[i - 1]
-                layers.append((weight_operand(params[2 * i], "t"), None, False, acts[i - 1] if masked else None,
-                               1.0 / (1.0 - drops[i - 1]) if masked else 1.0, out))
-                gs[i - 1] = out
+            layers, gs = _dgrad_chain_layers(acts, params, relus, drops, g, lo_layer, ks)
             kn.mlp_chain(g, layers, M)
-        for i in range(L - 1, -1, -1):
-            g = gs[i] if i in gs else g
-            W = params[2 * i]
-            N, K = W.shape
-            inp = x2 if i == 0 else acts[i - 1]
-            sw, sb = gradsink.get(W), gradsink.get(params[2 * i + 1])
-            dW = sw if sw is not None else _f32(N, K, like=g)
-            db = sb if sb is not None else _f32(N, like=g)
-            acc_w = sw is not None and not gradsink.first_write(W)
-            acc_b = sb is not None and not gradsink.first_write(params[2 * i + 1])
-            # dW (+)= g^T inp, db (+)= column sums of g: part of the pass's grouped weight-gradient launch when both land in the arena
-            kn.wgrad(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, accumulate=acc_w, rowsum=db, rowsum_accumulate=acc_b,
-                     defer=sw is not None and sb is not None)
-            grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
-            grads[2 * i + 1] = None if sb is not None else db
-            if (i - 1) in gs:
-                continue                                       # produced by the chain launch
-            if i > 0 or need_x:
-                dinp = _f32(M, K, like=g)
-                wt = weight_operand(W, "t")                      # (K, N): the reduction index contiguous, like the forward pass
-                if i > 0 and relus[i - 1]:
-                    kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K, mask=acts[i - 1], ld_mask=K, mask_scale=1.0 / (1.0 - drops[i - 1]))
-                else:
-                    kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K)
-                gs[i - 1] = dinp
-        g = gs.get(-1, g)
-        dx = g.reshape(xshape) if need_x else None
-        return (dx, None, None, None, *grads)
+    gs[L - 1] = g
+    for i in range(L - 1, -1, -1):
+        g = gs[i] if i in gs else g
+        W = params[2 * i]
+        N, K = W.shape
+        inp = x2 if i == 0 else acts[i - 1]
+        sw, sb = gradsink.get(W), gradsink.get(params[2 * i + 1])
+        dW = sw if sw is not None else _f32(N, K, like=g)
+        db = sb if sb is not None else _f32(N, like=g)
+        acc_w = sw is not None and not gradsink.first_write(W)
+        acc_b = sb is not None and not gradsink.first_write(params[2 * i + 1])
+        # dW (+)= g^T inp, db (+)= column sums of g: part of the pass's grouped weight-gradient launch when both land in the arena
+        kn.wgrad(g, inp, dW, N, K, M, g.stride(0), inp.stride(0), K, accumulate=acc_w, rowsum=db, rowsum_accumulate=acc_b,
+                 defer=sw is not None and sb is not None)
+        grads[2 * i] = None if sw is not None else dW          # written straight into the gradient arena
+        grads[2 * i + 1] = None if sb is not None else db
+        if (i - 1) in gs:
+            continue                                       # produced by the chain launch
+        if i > 0 or need_x:
+            dinp = _f32(M, K, like=g)
+            wt = weight_operand(W, "t")                      # (K, N): the reduction index contiguous, like the forward pass
+            if i > 0 and relus[i - 1]:
+                kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K, mask=acts[i - 1], ld_mask=K, mask_scale=1.0 / (1.0 - drops[i - 1]))
+            else:
+                kn.gemm(g, wt, dinp, M, K, N, g.stride(0), N, K)
+            gs[i - 1] = dinp
+    return (gs.get(-1) if need_x else None), grads
+
+
+@_scoped
+class DualMLPFn(torch.autograd.Function):
+    """Two independent Linear(+ReLU) stacks of the same hidden widths on <= 32 rows each — VisualGoalEncoder.mlp and LanguageGoalEncoder.mlp
+    (reference goal_encoders.py:21-34 / :53-71) — as ONE persistent launch forward (hulc_mlp_chain2) and one for the two data-gradient
+    chains backward; the weight gradients join the pass's grouped launch as for MLPFn.  params: the first stack's (W, b) pairs, then the
+    second's.  Only built by dual_mlp() after kernels.mlp_chain2_ok."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, relus: Tuple[bool, ...], *params):
+        L = len(relus)
+        pa, pb = params[:2 * L], params[2 * L:]
+        outs = []
+        for x, ps in ((xa, pa), (xb, pb)):
+            outs.append([_f32(x.shape[0], ps[2 * i].shape[0], like=x) for i in range(L)])
+        kn.mlp_chain2(xa, [(weight_operand(pa[2 * i]), pa[2 * i + 1], relus[i], None, 1.0, outs[0][i]) for i in range(L)], xa.shape[0],
+                      xb, [(weight_operand(pb[2 * i]), pb[2 * i + 1], relus[i], None, 1.0, outs[1][i]) for i in range(L)], xb.shape[0])
+        ctx.save_for_backward(xa, xb, *outs[0][:-1], *outs[1][:-1], *params)
+        ctx.relus = relus
+        return outs[0][-1], outs[1][-1]
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        relus = ctx.relus
+        L = len(relus)
+        saved = ctx.saved_tensors
+        xs = saved[:2]
+        acts = (saved[2:L + 1], saved[L + 1:2 * L])
+        params = (saved[2 * L:4 * L], saved[4 * L:])
+        drops = (0.0,) * L
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        g = [_c(dya), _c(dyb)]
+        order = (0, 1) if (need[0] or not need[1]) else (1, 0)        # the chain that goes down to its input is the deeper one: it leads
+        descr = []
+        for s in order:
+            lo = 0 if need[s] else 1
+            ks = [xs[s].shape[1]] + [params[s][2 * i].shape[0] for i in range(L - 1)]
+            descr.append((lo, ks))
+        widths = [[ks[i] for i in range(L - 1, lo - 1, -1)] for lo, ks in descr]
+        gs = [None, None]
+        if (all(len(w) >= 1 for w in widths) and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in g)
+                and kn.mlp_chain2_ok(g[order[0]].shape[0], g[order[0]].shape[1], widths[0], g[order[1]].shape[0], g[order[1]].shape[1], widths[1],
+                                     g[0].device)):
+            built = [_dgrad_chain_layers(acts[s], params[s], relus, drops, g[s], descr[j][0], descr[j][1]) for j, s in enumerate(order)]
+            kn.mlp_chain2(g[order[0]], built[0][0], g[order[0]].shape[0], g[order[1]], built[1][0], g[order[1]].shape[0])
+            gs[order[0]], gs[order[1]] = built[0][1], built[1][1]
+        res = [_mlp_backward(xs[s], acts[s], params[s], relus, drops, g[s], need[s], True, gs=gs[s]) for s in (0, 1)]
+        return (res[0][0], res[1][0], None, *res[0][1], *res[1][1])
 
 
 @_scoped
@@ -212,6 +276,20 @@ def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Opt
     drops = tuple(float(d) for d in (drops or [0.0] * len(layers)))
     params = [t for W, b, _ in layers for t in (W, b)]
     return MLPFn.apply(x, relus, drops, int(seed), *params)
+
+
+def dual_mlp(xa, layers_a, xb, layers_b):
+    """mlp(xa, layers_a), mlp(xb, layers_b) — as one launch where the pair fits hulc_mlp_chain2 (both <= 32 rows, the same ReLU pattern
+    and hidden widths), else one after the other."""
+    relus = tuple(bool(r) for _, _, r in layers_a)
+    wa, wb = [W.shape[0] for W, _, _ in layers_a], [W.shape[0] for W, _, _ in layers_b]
+    fits = (relus == tuple(bool(r) for _, _, r in layers_b) and not relus[-1] and len(relus) >= 2 and xa.dim() == 2 and xb.dim() == 2
+            and all(x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 for x in (xa, xb))
+            and kn.mlp_chain2_ok(xa.shape[0], xa.shape[1], wa, xb.shape[0], xb.shape[1], wb, xa.device))
+    if not fits:
+        return mlp(xa, layers_a), mlp(xb, layers_b)
+    params = [t for W, b, _ in layers_a for t in (W, b)] + [t for W, b, _ in layers_b for t in (W, b)]
+    return DualMLPFn.apply(xa, xb, relus, *params)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -610,9 +610,7 @@ def mlp_chain_ok(M: int, K0: int, widths, device) -> bool:
 _chain_ws = {}
 
 
-def mlp_chain(x0, layers, M):
-    """layers: [(W bf16 [N][K] k-major, bias fp32 or None, relu flag, mask fp32 (M, N) or None, mask_scale, out fp32 (M, N))]; one persistent
-    launch (csrc/mlp_chain.hip).  x0 fp32 (M, K0), unit inner stride."""
+def _chain_desc(x0, layers, M):
     d = _L.MlpChainDesc()
     d.nl, d.M, d.K0 = len(layers), int(M), int(x0.shape[1])
     _require_cuda(x0)
@@ -630,19 +628,49 @@ def mlp_chain(x0, layers, M):
         flops += 2.0 * M * W.shape[0] * k
         nbytes += W.shape[0] * k * 2 + M * W.shape[0] * 4
         k = W.shape[0]
-    lib = _L.load()
-    lib.hulc_mlp_chain_workspace.restype = _c.c_long
+    return d, flops, nbytes
+
+
+def _chain_workspace(device, need: int):
     # persistent workspace per (device, stream): its header (barrier counters) is zero before the first launch and every launch leaves it
-    # zero; check_faults drops the cache after a barrier timeout (the one case that leaves counts behind)
-    need = int(lib.hulc_mlp_chain_workspace(_c.byref(d)))
-    key = (x0.device, _stream())
+    # zero; check_faults clears it after a barrier timeout (the one case that leaves counts behind)
+    key = (device, _stream())
     ws = _chain_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
-        ws = torch.zeros(max(need, 4 << 20) // 4 + 1, dtype=torch.float32, device=x0.device)
+        ws = torch.zeros(max(need, 4 << 20) // 4 + 1, dtype=torch.float32, device=device)
         if not torch.cuda.is_current_stream_capturing():
             _chain_ws[key] = ws
+    return ws
+
+
+def mlp_chain(x0, layers, M):
+    """layers: [(W bf16 [N][K] k-major, bias fp32 or None, relu flag, mask fp32 (M, N) or None, mask_scale, out fp32 (M, N))]; one persistent
+    launch (csrc/mlp_chain.hip).  x0 fp32 (M, K0), unit inner stride."""
+    d, flops, nbytes = _chain_desc(x0, layers, M)
+    lib = _L.load()
+    lib.hulc_mlp_chain_workspace.restype = _c.c_long
+    ws = _chain_workspace(x0.device, int(lib.hulc_mlp_chain_workspace(_c.byref(d))))
     _call("hulc_mlp_chain", _c.byref(d), ws, fault_word(x0.device), key=("mlp_chain", M, int(x0.shape[1])) + tuple(int(l[0].shape[0]) for l in layers),
           flops=flops, nbytes=nbytes)
+
+
+def mlp_chain2_ok(Ma: int, K0a: int, widths_a, Mb: int, K0b: int, widths_b, device) -> bool:
+    """shapes hulc_mlp_chain2 takes: two chains of <= 32 rows, the second no deeper than the first and of its widths where both run"""
+    widths_a, widths_b = list(widths_a), list(widths_b)
+    return (Ma <= 32 and Mb <= 32 and 1 <= len(widths_b) <= len(widths_a) and widths_a[:len(widths_b)] == widths_b
+            and mlp_chain_ok(Ma, K0a, widths_a, device) and mlp_chain_ok(Mb, K0b, widths_b, device))
+
+
+def mlp_chain2(xa, layers_a, Ma, xb, layers_b, Mb):
+    """two independent chains (mlp_chain's layer tuples) as ONE persistent launch — the visual and the language goal encoder, and their
+    data-gradient chains (hulc_mlp_chain2, include/hulc2_amd.h)"""
+    da, fa, na = _chain_desc(xa, layers_a, Ma)
+    db, fb, nb = _chain_desc(xb, layers_b, Mb)
+    lib = _L.load()
+    lib.hulc_mlp_chain_workspace.restype = _c.c_long
+    ws = _chain_workspace(xa.device, int(lib.hulc_mlp_chain_workspace(_c.byref(da))) + int(lib.hulc_mlp_chain_workspace(_c.byref(db))))
+    _call("hulc_mlp_chain2", _c.byref(da), _c.byref(db), ws, fault_word(xa.device),
+          key=("mlp_chain2", Ma, Mb, int(xa.shape[1]), int(xb.shape[1])) + tuple(int(l[0].shape[0]) for l in layers_a), flops=fa + fb, nbytes=na + nb)
 
 
 # ------------------------------------------------------------------------------------------------

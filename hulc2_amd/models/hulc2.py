@@ -148,7 +148,11 @@ class Hulc2(LightningModule):
                 with kn.site_scope("goal"):
                     # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
                     # directly (no concatenation, no strided gradient slices on the way back)
-                    pre = [self.language_goal(db["lang"], pre_ln=True) if "lang" in scope else self.visual_goal(emb_last, pre_ln=True) for scope, db in mods]
+                    if len(mods) == 2:      # the two goal MLPs (same hidden widths, their own weights) as one launch each way
+                        pre = list(HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
+                                               self.language_goal.mlp_layers()))
+                    else:
+                        pre = [self.language_goal(db["lang"], pre_ln=True) if "lang" in scope else self.visual_goal(emb_last, pre_ln=True) for scope, db in mods]
                     goal_all = HF.layer_norm_cat(pre, [self.language_goal.ln if "lang" in scope else self.visual_goal.ln for scope, _ in mods], dim=0)
                 goals = [None] * len(mods)
             else:

@@ -343,6 +343,10 @@ typedef struct hulc_mlp_chain_desc {
 } hulc_mlp_chain_desc;
 long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d);
 int hulc_mlp_chain(const hulc_mlp_chain_desc* d, void* ws, int* err_sticky, void* stream);
+/* (ABI 3) two independent chains, <= 32 rows each, as ONE launch: VisualGoalEncoder.mlp + LanguageGoalEncoder.mlp (goal_encoders.py:21-34 /
+ * :53-71; own weights, inputs of different width) and the data-gradient chains of their backward.  b->nl <= a->nl, and layer l of b has
+ * layer l of a's width N (b sits out a's trailing layers).  ws: hulc_mlp_chain_workspace(a) + hulc_mlp_chain_workspace(b) bytes. */
+int hulc_mlp_chain2(const hulc_mlp_chain_desc* a, const hulc_mlp_chain_desc* b, void* ws, int* err_sticky, void* stream);
 
 /* ---- all small weight gradients of a backward pass in one launch (csrc/wgrad_group.hip) ------------------- */
 /* For every item i:  C[M][N] (+)= sum_k A[k][m] B[k][n]  and, when rowsum != NULL,  rowsum[m] (+)= sum_k A[k][m]  — the weight and bias

@@ -102,3 +102,54 @@ def test_chain_rows_do_not_mix(dev):
         y2 = HF.mlp(x2, layers)
     same = [i for i in range(33) if torch.equal(y1[i], y2[i])]
     assert same == [i for i in range(33) if i != 20]
+
+
+@pytest.mark.parametrize("Ma,Mb,need_b", [(32, 32, False), (32, 32, True), (5, 17, False), (32, 1, False)])
+def test_paired_chains_match_the_single_chain(dev, Ma, Mb, need_b):
+    """hulc_mlp_chain2 (the visual + the language goal encoder as one launch, and their data-gradient chains as one) against the same two
+    stacks through hulc_mlp_chain one after the other: every output, input gradient and parameter gradient BIT-identical (same tiles, same
+    k split, same reduction order — only the launch is shared)."""
+    import copy
+    kn.set_compute("bf16")
+    da, db_ = (128, 2048, 2048, 32), (384, 2048, 2048, 32)
+    if not kn.mlp_chain2_ok(Ma, da[0], list(da[1:]), Mb, db_[0], list(db_[1:]), dev):
+        pytest.skip("shape not taken by the paired chain kernel on this device")
+    torch.manual_seed(3)
+    la = [torch.nn.Linear(a, b).to(dev) for a, b in zip(da[:-1], da[1:])]
+    lb = [torch.nn.Linear(a, b).to(dev) for a, b in zip(db_[:-1], db_[1:])]
+    xa0, xb0 = torch.randn(Ma, da[0], device=dev), torch.randn(Mb, db_[0], device=dev)
+    ra, rb = torch.randn(Ma, 32, device=dev), torch.randn(Mb, 32, device=dev)
+
+    def layers(ls):
+        return [(l.weight, l.bias, i < len(ls) - 1) for i, l in enumerate(ls)]
+
+    res = []
+    for paired in (True, False):
+        A, Bm = copy.deepcopy(la), copy.deepcopy(lb)
+        xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(need_b)
+        if paired:
+            ya, yb = HF.dual_mlp(xa, layers(A), xb, layers(Bm))
+            assert type(ya.grad_fn).__name__.startswith("DualMLPFn"), type(ya.grad_fn).__name__
+        else:
+            ya, yb = HF.mlp(xa, layers(A)), HF.mlp(xb, layers(Bm))
+        ((ya * ra).sum() + (yb * rb).sum()).backward()
+        torch.cuda.synchronize()
+        res.append([ya.detach(), yb.detach(), xa.grad, xb.grad if need_b else None] + [p.grad for l in A + Bm for p in (l.weight, l.bias)])
+    for i, (p, q) in enumerate(zip(*res)):
+        if p is None:
+            assert q is None
+            continue
+        assert torch.equal(p, q), (i, (p - q).abs().max().item())
+    kn.check_faults(dev)
+
+
+def test_paired_chain_falls_back_when_rows_do_not_fit(dev):
+    kn.set_compute("bf16")
+    la = [torch.nn.Linear(128, 64).to(dev), torch.nn.Linear(64, 32).to(dev)]
+    lb = [torch.nn.Linear(384, 64).to(dev), torch.nn.Linear(64, 32).to(dev)]
+    xa, xb = torch.randn(40, 128, device=dev, requires_grad=True), torch.randn(8, 384, device=dev)
+    ya, yb = HF.dual_mlp(xa, [(la[0].weight, la[0].bias, True), (la[1].weight, la[1].bias, False)],
+                         xb, [(lb[0].weight, lb[0].bias, True), (lb[1].weight, lb[1].bias, False)])
+    assert type(ya.grad_fn).__name__.startswith("MLPFn")
+    (ya.sum() + yb.sum()).backward()
+    assert xa.grad is not None and lb[0].weight.grad is not None
