@@ -228,17 +228,30 @@ HULC_DEVICE float wave_max(float v) {
 // (two rounds of a 64-bit multiply-xorshift); the same (seed, idx) gives the same bit pattern in the
 // forward and the backward kernels, so no mask tensor is stored.
 // ---------------------------------------------------------------------------------------------
-HULC_DEVICE uint32_t hulc_rand32(uint64_t seed, uint64_t idx) {
+HULC_DEVICE uint64_t hulc_rand64(uint64_t seed, uint64_t idx) {
     uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+    return z ^ (z >> 31);
 }
-// keep-probability test: returns 1/(1-p) if kept else 0
+HULC_DEVICE uint32_t hulc_rand32(uint64_t seed, uint64_t idx) { return (uint32_t)(hulc_rand64(seed, idx) >> 32); }
+// Dropout keeps element idx when ITS 16 bits of the 64-bit draw of (seed, idx / 4) reach p * 2^16: four consecutive elements share one
+// draw (three 64-bit multiplies are ~50 instruction slots on this ALU; a kernel that owns 4 consecutive elements pays them once:
+// dropout_scale4), every kernel sees the same mask for the same (seed, idx), and no mask tensor is stored.  The keep probability is
+// 1 - floor(p * 65536) / 65536 (p = 0.1: 0.900009), the scale 1 / (1 - p).
 HULC_DEVICE float dropout_scale(uint64_t seed, uint64_t idx, float p) {
-    uint32_t thr = (uint32_t)(p * 4294967296.0f);
-    return hulc_rand32(seed, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    const uint32_t u = (uint32_t)(hulc_rand64(seed, idx >> 2) >> (16 * (uint32_t)(idx & 3))) & 0xffffu;
+    return u >= thr ? 1.0f / (1.0f - p) : 0.0f;
+}
+// the four elements idx0 .. idx0 + 3 (idx0 a multiple of 4): dropout_scale of each, one draw
+HULC_DEVICE void dropout_scale4(uint64_t seed, uint64_t idx0, float p, float (&s)[4]) {
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    const float keep = 1.0f / (1.0f - p);
+    const uint64_t z = hulc_rand64(seed, idx0 >> 2);
+    const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32);
+    s[0] = (lo & 0xffffu) >= thr ? keep : 0.f; s[1] = (lo >> 16) >= thr ? keep : 0.f;
+    s[2] = (hi & 0xffffu) >= thr ? keep : 0.f; s[3] = (hi >> 16) >= thr ? keep : 0.f;
 }
 HULC_DEVICE float hulc_uniform01(uint64_t seed, uint64_t idx) {
     return (hulc_rand32(seed, idx) >> 8) * (1.0f / 16777216.0f);

@@ -842,6 +842,133 @@ def transformer_encoder_layer(x, p: dict, B: int, S: int, nhead: int, drop_p: fl
     return add_layer_norm(x, ff, p["norm2.weight"], p["norm2.bias"], 1e-5, drop_p, seed + 15)
 
 
+_TXL_KEYS = ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+             "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+@_scoped
+class TxlBlockFn(torch.autograd.Function):
+    """PlanRecognitionTransformersNetwork.forward up to the sequence mean (plan_recognition_net.py:125-146) as ONE launch per direction
+    (csrc/txl_block.hip): dropout(emb + pos) -> L transformer layers -> mean over the sequence, one workgroup per sequence.  Backward leaves
+    the bf16 operands of the 4 L weight-gradient products (they join the pass's grouped launch) and the LayerNorm partials.
+    params: 12 per layer in _TXL_KEYS order.  Same dropout streams as AddPosFn / TxlLayerFn with the same seeds."""
+
+    @staticmethod
+    def forward(ctx, emb, pos, pos_ids, H: int, drop_p: float, seed: int, *params):
+        B, S, E = emb.shape
+        L = len(params) // 12
+        T = B * S
+        FF = params[4].shape[0]
+        emb = _c(emb)
+        keep = any(ctx.needs_input_grad)
+        dev = emb.device
+        x = _f32(T, E, like=emb)
+        recs, kept = [], []
+        for li in range(L):
+            w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+            sd = seed + 100 * (li + 1)
+            t = {"y1": _f32(T, E, like=emb), "y2": _f32(T, E, like=emb)}
+            if keep:
+                t.update(pre1=_f32(T, E, like=emb), mean1=_f32(T, like=emb), rstd1=_f32(T, like=emb), pre2=_f32(T, E, like=emb),
+                         mean2=_f32(T, like=emb), rstd2=_f32(T, like=emb), ctx=torch.empty(T, E, dtype=torch.bfloat16, device=dev))
+            recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2), bqkv=b_in, bo=b_out,
+                             b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2, seed_attn=sd + 11, seed_ln1=sd + 12, seed_ffn=sd + 13, seed_ln2=sd + 15,
+                             x=x, **t))
+            kept.append(t)
+            x = t["y2"]
+        pooled = _f32(B, E, like=emb)
+        d = kn.txl_block_desc(emb, pos, pos_ids, B, S, H, FF, drop_p, seed, 1e-5, recs, pooled=pooled)
+        kn.txl_block_fwd(d, B, S, H, E, FF, L)
+        if keep:
+            flat = [recs[0]["x"]]
+            for t in kept:
+                flat += [t[k] for k in ("y1", "pre1", "mean1", "rstd1", "ctx", "y2", "pre2", "mean2", "rstd2")]
+            ctx.save_for_backward(emb, pos, pos_ids, *flat, *params)
+            ctx.meta = (B, S, E, H, FF, L, drop_p, seed)
+            ctx.pos_identity = bool(getattr(pos_ids, "_hulc_arange", False)) and pos_ids.numel() == S
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        B, S, E, H, FF, L, drop_p, seed = ctx.meta
+        saved = ctx.saved_tensors
+        emb, pos, pos_ids, x0 = saved[:4]
+        acts, params = saved[4:4 + 9 * L], saved[4 + 9 * L:]
+        T = B * S
+        dev = emb.device
+        like = dpooled = _c(dpooled)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        recs, outs = [], []
+        x = x0
+        for li in range(L):
+            w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+            y1, pre1, mean1, rstd1, ctxb, y2, pre2, mean2, rstd2 = acts[9 * li:9 * li + 9]
+            sd = seed + 100 * (li + 1)
+            o = dict(d_o=torch.empty(T, E, **bf), dqkv=torch.empty(T, 3 * E, **bf), df=torch.empty(T, E, **bf), h=torch.empty(T, FF, **bf),
+                     dh=torch.empty(T, FF, **bf), lnp1=_f32(B, 2, E, like=like), lnp2=_f32(B, 2, E, like=like), dy1=_f32(T, E, like=like),
+                     dx=_f32(T, E, like=like))
+            recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2),
+                             WqkvT=weight_operand(w_in, "t"), WoT=weight_operand(w_out, "t"), W1T=weight_operand(w1, "t"), W2T=weight_operand(w2, "t"),
+                             bqkv=b_in, bo=b_out, b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2,
+                             seed_attn=sd + 11, seed_ln1=sd + 12, seed_ffn=sd + 13, seed_ln2=sd + 15,
+                             x=x, y1=y1, pre1=pre1, mean1=mean1, rstd1=rstd1, ctx=ctxb, y2=y2, pre2=pre2, mean2=mean2, rstd2=rstd2, **o))
+            outs.append((o, x, y1, ctxb))
+            x = y2
+        demb = _f32(B, S, E, like=like)
+        d = kn.txl_block_desc(emb, pos, pos_ids, B, S, H, FF, drop_p, seed, 1e-5, recs, dpooled=dpooled, demb=demb)
+        kn.txl_block_bwd(d, B, S, H, E, FF, L)
+        grads = []
+        for li in range(L):
+            w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+            o, xin, y1, ctxb = outs[li]
+            ret = {}
+
+            def sink(name, param, shape):
+                t, acc, r = _sink_or_new(param, shape, like)
+                ret[name] = r
+                return t, acc
+            for lnp, gm, bt, kg, kb in ((o["lnp1"], g1, be1, "g1", "be1"), (o["lnp2"], g2, be2, "g2", "be2")):
+                (dg, a1), (db, a2) = sink(kg, gm, (E,)), sink(kb, bt, (E,))
+                kn.ln_partial_reduce(lnp, B, E, dg, db, accumulate=a1 or a2)
+            # dW = (left operand)^T (right operand) over all T tokens, bias gradient = the left operand's column sums
+            for left, right, W, bias, kw, kb_, M, N in ((o["dqkv"], xin, w_in, b_in, "w_in", "b_in", 3 * E, E), (o["d_o"], ctxb, w_out, b_out, "w_out", "b_out", E, E),
+                                                        (o["dh"], y1, w1, b1, "w1", "b1", FF, E), (o["df"], o["h"], w2, b2, "w2", "b2", E, FF)):
+                (dW, f1), (dbias, f2) = sink(kw, W, (M, N)), sink(kb_, bias, (M,))
+                kn.wgrad(left, right, dW, M, N, T, M, N, N, accumulate=f1, rowsum=dbias, rowsum_accumulate=f2, defer=ret[kw] is None and ret[kb_] is None)
+            grads += [ret[k] for k in ("w_in", "b_in", "w_out", "b_out", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2")]
+        # the position table: rows pos_ids of its gradient = the sum of demb over the batch (AddPosFn.backward)
+        dpos = None
+        sk = gradsink.get(pos)
+        identity = ctx.needs_input_grad[1] and sk is not None and ctx.pos_identity
+        if ctx.needs_input_grad[1]:
+            if identity:
+                first = gradsink.first_write(pos)
+                kn.colsum(demb, B, S * E, S * E, sk[:S].view(-1), accumulate=not first)
+                if first and pos.shape[0] > S:
+                    sk[S:].zero_()
+            else:
+                dsum = _f32(S, E, like=like)
+                kn.colsum(demb, B, S * E, S * E, dsum)
+                dpos = torch.zeros(pos.shape, dtype=torch.float32, device=dev)
+                dpos.index_copy_(0, pos_ids, dsum)
+        return (demb if ctx.needs_input_grad[0] else None, dpos, None, None, None, None, *grads)
+
+
+def txl_block_ok(emb, layer_params, S: int, nhead: int) -> bool:
+    """the whole-trunk launch takes the configured posterior (d_model 128, 8 heads, S <= 32, <= 4 layers, bf16 compute in every site it spans)"""
+    p0 = layer_params[0]
+    return (emb.is_cuda and kn.get_compute() == "bf16" and kn.base_mode() == "bf16" and not ({"txl", "pool"} & kn.fp32_sites())
+            and emb.shape[-1] == 128 and nhead == 8 and 1 <= S <= 32 and 1 <= len(layer_params) <= 4 and emb.dtype == torch.float32
+            and p0["linear1.weight"].shape[0] % 128 == 0 and all(p["linear1.weight"].shape == p0["linear1.weight"].shape for p in layer_params)
+            and not os.environ.get("HULC_NO_TXL_BLOCK") and not os.environ.get("HULC_NO_FUSED_TXL") and not os.environ.get("HULC_NO_FUSED_FFN"))
+
+
+def transformer_trunk_pooled(emb, pos, pos_ids, layer_params, nhead: int, drop_p: float, seed: int):
+    """mean_s(TransformerEncoder(dropout(emb + pos[pos_ids]))) — only call after txl_block_ok"""
+    params = [p[k] for p in layer_params for k in _TXL_KEYS]
+    return TxlBlockFn.apply(emb, pos, pos_ids, int(nhead), float(drop_p), int(seed), *params)
+
+
 # ------------------------------------------------------------------------------------------------
 # action decoder recurrence: 2-layer ReLU RNN over [plan | emb_slice | goal]
 # reference: logistic_decoder_rnn.py:257-270 + decoders/utils/rnn.py:5-14

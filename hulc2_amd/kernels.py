@@ -208,7 +208,8 @@ def check_faults(device) -> None:
         for ws in _chain_ws.values():     # a timed-out chain leaves its barrier counters non-zero: clear them where they are (the cached
             ws.zero_()                    # buffers stay valid for eager launches; captured graphs are re-captured by ArenaTrainer._poll_faults)
         who = [n for b, n in ((1, "rnn_wavefront (HULC_NO_RNN_WAVEFRONT=1 selects the per-step GEMM path)"),
-                              (2, "mlp_chain (HULC_NO_MLP_CHAIN=1 selects the per-layer GEMM path)")) if w & b]
+                              (2, "mlp_chain (HULC_NO_MLP_CHAIN=1 selects the per-layer GEMM path)"),
+                              (4, "txl_block (HULC_TXL_NO_SHARE=1 keeps one workgroup per sequence, HULC_NO_TXL_BLOCK=1 the per-layer launches)")) if w & b]
         raise _L.HulcKernelError(
             "device-wide barrier timed out in " + " and ".join(who) + " — the kernel's 256 workgroups were not all resident (another "
             "kernel / process shared the GPU, or the device is partitioned).  The optimizer update of that step was skipped.")
@@ -886,6 +887,65 @@ def txl_attn_bwd(x, Wqkv, WqkvT, WoT, bqkv, gamma, eps, B, S, H, drop_p, seed_at
     T, E = B * S, x.shape[-1]
     fl = 2.0 * T * E * (2 * E + 5 * E + 3 * E) + 2.0 * 10 * B * H * S * S * (E // H)
     _call("hulc_txl_attn_bwd", _c.byref(d), key=("txl_attn_bwd", B, S), flops=fl, nbytes=_nbytes(x, Wqkv, WqkvT, WoT, dy, dx, d_o, dqkv, pre))
+
+
+def txl_block_desc(emb, pos, pos_ids, B, S, H, FF, drop_p, seed_pos, eps, layers, pooled=None, dpooled=None, demb=None):
+    """hulc_txl_block_desc from tensors.  layers: one dict per layer, keys = the fields of hulc_txl_block_layer (tensors, None, or the four
+    integer seeds)."""
+    d = _L.TxlBlockDesc()
+    _require_cuda(emb, pos, pos_ids, pooled, dpooled, demb)
+    _require_contiguous(emb=emb, pos=pos)
+    if len(layers) > _L.TXL_MAX_LAYERS:
+        raise _L.HulcKernelError("txl_block: at most %d layers" % _L.TXL_MAX_LAYERS)
+    d.L, d.B, d.S, d.H, d.E, d.FF = len(layers), int(B), int(S), int(H), int(emb.shape[-1]), int(FF)
+    d.eps, d.drop_p, d.seed_pos = float(eps), float(drop_p), int(seed_pos) & 0xFFFFFFFFFFFFFFFF
+    d.seed_dev = step_state(emb.device).data_ptr() if drop_p > 0.0 else None
+    d.emb, d.pos, d.pos_ids = emb.data_ptr(), pos.data_ptr(), pos_ids.data_ptr()
+    d.pooled, d.dpooled, d.demb = [t.data_ptr() if t is not None else None for t in (pooled, dpooled, demb)]
+    # sequences shared between workgroups (csrc/txl_block.hip) only on a whole MI355X with the stream to itself, like the chain kernels
+    import os
+    d.exclusive = int(not concurrent_streams() and not os.environ.get("HULC_TXL_NO_SHARE"))
+    if d.exclusive:
+        lib = _L.load()
+        lib.hulc_txl_block_workspace.restype = _c.c_long
+        need = int(lib.hulc_txl_block_workspace(_i(B), _i(len(layers))))
+        key = (emb.device, _stream(), "txl")
+        ws = _chain_ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.zeros(need // 4 + 1, dtype=torch.float32, device=emb.device)
+            if not torch.cuda.is_current_stream_capturing():
+                _chain_ws[key] = ws
+        d._ws = ws                                   # (kept alive with the description)
+        d.ws, d.err_sticky = ws.data_ptr(), fault_word(emb.device).data_ptr()
+    for i, rec in enumerate(layers):
+        e = d.layers[i]
+        for name, v in rec.items():
+            if name.startswith("seed_"):
+                setattr(e, name, int(v) & 0xFFFFFFFFFFFFFFFF)
+            elif v is not None:
+                _require_cuda(v)
+                if not v.is_contiguous():
+                    raise _L.HulcKernelError("txl_block: %s must be contiguous" % name)
+                if name[0] == "W" and v.dtype != torch.bfloat16:
+                    raise _L.HulcKernelError("txl_block: weights are the bf16 shadows (bf16 compute mode)")
+                setattr(e, name, v.data_ptr())
+    return d
+
+
+def _txl_block_flops(B, S, H, E, FF, L, bwd):
+    T = B * S
+    attn = 2.0 * T * E * 4 * E + 2.0 * 2 * B * H * S * S * (E // H)
+    ffn = 2.0 * T * E * FF * 2
+    return L * ((2.5 * attn + 2.5 * ffn) if bwd else (attn + ffn))
+
+
+def txl_block_fwd(d, B, S, H, E, FF, L):
+    """the whole posterior trunk (position embedding -> L transformer layers -> sequence mean) as one launch (csrc/txl_block.hip)"""
+    _call("hulc_txl_block_fwd", _c.byref(d), key=("txl_block_fwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, False))
+
+
+def txl_block_bwd(d, B, S, H, E, FF, L):
+    _call("hulc_txl_block_bwd", _c.byref(d), key=("txl_block_bwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, True))
 
 
 def repack_conv_weights(src_f32, dst_bf16, table):

@@ -130,6 +130,32 @@ class TxlAttnDesc(ctypes.Structure):
     ]
 
 
+class TxlBlockLayer(ctypes.Structure):
+    """mirror of hulc_txl_block_layer (include/hulc2_amd.h)"""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("Wqkv", "Wo", "W1", "W2", "WqkvT", "WoT", "W1T", "W2T",
+                                                "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2")]
+                + [(n, ctypes.c_ulonglong) for n in ("seed_attn", "seed_ln1", "seed_ffn", "seed_ln2")]
+                + [(n, ctypes.c_void_p) for n in ("x", "y1", "pre1", "mean1", "rstd1", "ctx", "y2", "pre2", "mean2", "rstd2",
+                                                  "d_o", "dqkv", "df", "h", "dh", "lnp1", "lnp2", "dy1", "dx")])
+
+
+TXL_MAX_LAYERS = 4
+
+
+class TxlBlockDesc(ctypes.Structure):
+    """mirror of hulc_txl_block_desc (include/hulc2_amd.h)"""
+    _fields_ = [
+        ("L", ctypes.c_int), ("B", ctypes.c_int), ("S", ctypes.c_int), ("H", ctypes.c_int), ("E", ctypes.c_int), ("FF", ctypes.c_int),
+        ("eps", ctypes.c_float), ("drop_p", ctypes.c_float),
+        ("seed_pos", ctypes.c_ulonglong),
+        ("seed_dev", ctypes.c_void_p),
+        ("emb", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("pos_ids", ctypes.c_void_p),
+        ("pooled", ctypes.c_void_p), ("dpooled", ctypes.c_void_p), ("demb", ctypes.c_void_p),
+        ("ws", ctypes.c_void_p), ("exclusive", ctypes.c_int), ("err_sticky", ctypes.c_void_p),
+        ("layers", TxlBlockLayer * TXL_MAX_LAYERS),
+    ]
+
+
 class WgradItem(ctypes.Structure):
     """mirror of hulc_wgrad_item (include/hulc2_amd.h)"""
     _fields_ = [

@@ -58,6 +58,7 @@ class PlanRecognitionTransformersNetwork(nn.Module):
         ids = cache.get((S, device))
         if ids is None:
             ids = cache[(S, device)] = torch.arange(S, dtype=torch.long, device=device)
+            ids._hulc_arange = True          # (rows 0..S-1 in order: the table's gradient rows are the batch sum itself)
         return ids
 
     def forward(self, perceptual_emb: torch.Tensor) -> Tuple[State, torch.Tensor]:
@@ -65,13 +66,18 @@ class PlanRecognitionTransformersNetwork(nn.Module):
         p = self.dropout_p if self.training else 0.0
         seed = 0x5EED0001           # site id; the per-step stream comes from the device step state (kernels.step_state)
         position_ids = self._position_ids(S, perceptual_emb.device)
-        x = HF.AddPosFn.apply(perceptual_emb, self.position_embeddings.weight, position_ids, p, seed, True)
-        x = x.reshape(B * S, E)
-        with kn.site_scope("txl"):
-            for l in range(self.num_layers):
-                x = HF.transformer_encoder_layer(x, self._layer_params(l), B, S, self.num_heads, p, seed + 100 * (l + 1))
-        with kn.site_scope("pool"):
-            pooled = HF.SeqMeanFn.apply(x.reshape(B, S, E))
+        layers = [self._layer_params(l) for l in range(self.num_layers)]
+        if HF.txl_block_ok(perceptual_emb, layers, S, self.num_heads):
+            # position embedding -> every layer -> sequence mean: one launch per direction, one workgroup per sequence (csrc/txl_block.hip)
+            pooled = HF.transformer_trunk_pooled(perceptual_emb, self.position_embeddings.weight, position_ids, layers, self.num_heads, p, seed)
+        else:
+            x = HF.AddPosFn.apply(perceptual_emb, self.position_embeddings.weight, position_ids, p, seed, True)
+            x = x.reshape(B * S, E)
+            with kn.site_scope("txl"):
+                for l in range(self.num_layers):
+                    x = HF.transformer_encoder_layer(x, layers[l], B, S, self.num_heads, p, seed + 100 * (l + 1))
+            with kn.site_scope("pool"):
+                pooled = HF.SeqMeanFn.apply(x.reshape(B, S, E))
         # selective precision: seq_feat feeds the contrastive head, whose gradient is a cancelling remainder of nearly identical
         # rows — its projection runs exact-fp32 inside a bf16 step (67 MFLOP of the step's 904 GFLOP)
         with kn.site_scope("head"):

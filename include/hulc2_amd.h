@@ -318,6 +318,54 @@ int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, fl
 int hulc_txl_attn_fwd(const hulc_txl_attn_desc* d, void* stream);
 int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 
+/* ---- (ABI 3) the whole plan-recognition transformer trunk as ONE launch per direction (bf16 compute) -------------------------------- */
+/* PlanRecognitionTransformersNetwork.forward up to the sequence mean (plan_recognition_net.py:125-146): dropout(emb + pos[position_ids]) ->
+ * L post-norm nn.TransformerEncoderLayer (d_model 128, 8 heads, ReLU feed-forward FF, dropout drop_p) -> mean over the S <= 32 positions.
+ * Every operation is independent per sequence: one workgroup owns one sequence for the whole trunk (hulc_txl_attn_* as its attention
+ * stages; the feed-forward block keeps its hidden activation in MFMA registers).  Weights are the bf16 shadows hulc_txl_attn_* / hulc_ffn_*
+ * take; the tensors marked "kept" are what backward reads, layer l+1's x IS layer l's y2 (same pointer).  Backward additionally leaves,
+ * per layer, the bf16 operands of the weight-gradient products over all T = B S tokens — dWqkv = dqkv^T x, dWo = d_o^T ctx, dW1 = dh^T y1,
+ * dW2 = df^T h (row sums of the left operands = the bias gradients; hulc_wgrad_group) — and the per-sequence LayerNorm partials
+ * lnp1 / lnp2 (B, 2, E) (hulc_ln_partial_reduce).  Dropout streams: the unfused kernels' (same masks for the same seeds). */
+#define HULC_TXL_MAX_LAYERS 4
+typedef struct hulc_txl_block_layer {
+    const void *Wqkv, *Wo, *W1, *W2;                 /* bf16 [3E][E], [E][E], [FF][E], [E][FF] */
+    const void *WqkvT, *WoT, *W1T, *W2T;             /* backward: their transposes */
+    const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+    unsigned long long seed_attn, seed_ln1, seed_ffn, seed_ln2;
+    float* x;                                        /* (T, E) layer input; layer 0: written by the forward launch = dropout(emb + pos) */
+    float *y1, *pre1, *mean1, *rstd1;                /* kept: attention half's output, LayerNorm1 input and statistics (pre1 .. may be null: inference) */
+    void* ctx;                                       /* kept: bf16 (T, E) attention context */
+    float *y2, *pre2, *mean2, *rstd2;                /* kept: the layer's output, LayerNorm2 input and statistics */
+    void *d_o, *dqkv, *df, *h, *dh;                  /* backward out: bf16 (T, E), (T, 3E), (T, E), (T, FF), (T, FF) */
+    float *lnp1, *lnp2;                              /* backward out: (B, 2, E) */
+    float *dy1, *dx;                                 /* backward: (T, E) gradient of y1 (scratch) and of x */
+} hulc_txl_block_layer;
+typedef struct hulc_txl_block_desc {
+    int L, B, S, H, E, FF;
+    float eps, drop_p;
+    unsigned long long seed_pos;
+    const unsigned long long* seed_dev;
+    const float* emb;                                /* (B, S, E) */
+    const float* pos;                                /* position table (rows, E) */
+    const long* pos_ids;                             /* (S,) */
+    float* pooled;                                   /* (B, E) */
+    const float* dpooled;                            /* backward in: (B, E) */
+    float* demb;                                     /* backward out: (B, S, E) gradient of emb (its sum over the batch is the table's) */
+    /* Sharing a sequence between 2 or 4 workgroups (each takes a part of the feed-forward hidden units; partial tiles exchanged through ws,
+     * one arrival counter per sequence) while all of them fit the device at once: ws = hulc_txl_block_workspace(B, L) bytes whose first
+     * 8 KiB (the counters: a fixed-size area, so one buffer serves launches of any B) were ZERO before the first use (every launch that does not time out leaves them zero), exclusive != 0 = the stream runs
+     * nothing else concurrently (the members wait for each other: they must be co-resident).  ws null or exclusive 0: one workgroup per
+     * sequence, no waiting.  A member that waits too long ORs bit 2 (value 4) into *err_sticky (see hulc_rnn_wave_desc.err_sticky). */
+    void* ws;
+    int exclusive;
+    int* err_sticky;
+    hulc_txl_block_layer layers[HULC_TXL_MAX_LAYERS];
+} hulc_txl_block_desc;
+long hulc_txl_block_workspace(int B, int L);
+int hulc_txl_block_fwd(const hulc_txl_block_desc* d, void* stream);
+int hulc_txl_block_bwd(const hulc_txl_block_desc* d, void* stream);
+
 /* ---- a stack of Linear(+ReLU) layers on M <= 64 rows as one persistent launch (bf16 compute) -------------------------------------- */
 /* y_l = f_l(y_{l-1} W_l^T + b_l), l = 0 .. nl-1 (nl <= 8): the per-sequence MLPs of the policy — PlanProposalNetwork (plan_proposal_net.py:
  * 26-47), the goal encoders (goal_encoders.py:21-34,53-71), ProjVisLang (proj_vis_lang.py:10-21), the posterior's fc -> fc_state
