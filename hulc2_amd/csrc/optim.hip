@@ -211,6 +211,52 @@ extern "C" int hulc_transpose_bf16_tiles(const void* src, void* dst, const long*
     return hulc_check_launch("hulc_transpose_bf16_tiles");
 }
 
+// ---- fragment-packed copies of the transformer feed-forward weights (csrc/txl_block.hip) ---------------------------------------------
+// element i = ((hb * 8 + f) * 64 + lane) * 8 + j of a packed array is the j-th k-slot of MFMA fragment f that lane `lane` (r = lane & 31,
+// hf = lane >> 5) needs for the 32 hidden units 32 hb ..: one 16-byte load per lane, 1 KB contiguous per instruction.
+//   layout 0: A of z^T = W1 y^T           source W1  [FF][128]:  row 32 hb + r,  col 16 f + 8 hf + j
+//   layout 1: A of f^T += W2 h^T          source W2  [128][FF]:  row 32 (f >> 1) + r,  col 32 hb + 16 (f & 1) + 4 hf + split(j)
+//   layout 2: A of dh^T = W2^T df^T       source W2T [FF][128]:  row 32 hb + r,  col 32 (f >> 1) + 16 (f & 1) + 4 hf + split(j)
+//   layout 3: A of dy^T += W1^T dh^T      source W1T [128][FF]:  row 32 (f >> 1) + r,  col 32 hb + 16 (f & 1) + 4 hf + split(j)
+// split(j) = j for j < 4, j + 4 otherwise: the k-slot order of an MFMA accumulator tile reused as an operand (txl_fused.hip).
+extern "C" int hulc_ffn_frag_perm(int layout, int FF, int* out) {
+    if (!out || layout < 0 || layout > 3 || FF < 32 || FF % 32) return hulc_fail(-2, "hulc_ffn_frag_perm: layout 0..3, FF a multiple of 32");
+    long i = 0;
+    for (int hb = 0; hb < FF / 32; ++hb)
+        for (int f = 0; f < 8; ++f)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j, ++i) {
+                    const int r = lane & 31, hf = lane >> 5, sp = j < 4 ? j : j + 4;
+                    long src;
+                    if (layout == 0) src = (long)(32 * hb + r) * 128 + 16 * f + 8 * hf + j;
+                    else if (layout == 1) src = (long)(32 * (f >> 1) + r) * FF + 32 * hb + 16 * (f & 1) + 4 * hf + sp;
+                    else if (layout == 2) src = (long)(32 * hb + r) * 128 + 32 * (f >> 1) + 16 * (f & 1) + 4 * hf + sp;
+                    else src = (long)(32 * (f >> 1) + r) * FF + 32 * hb + 16 * (f & 1) + 4 * hf + sp;
+                    out[i] = (int)src;
+                }
+    return 0;
+}
+
+namespace {
+// dst chunk c (4 bf16 = 8 bytes) = chunk idx[c] & 0x7fffffff of src1 (bit 31 set) or src0
+__global__ __launch_bounds__(256) void gather_chunks_kernel(const uint2* __restrict__ src0, const uint2* __restrict__ src1, uint2* __restrict__ dst,
+                                                           const unsigned* __restrict__ idx, long n) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const unsigned k = idx[c];
+    dst[c] = (k >> 31) ? src1[k & 0x7fffffffu] : src0[k];
+}
+}  // namespace
+
+// see include/hulc2_amd.h
+extern "C" int hulc_gather_chunks(const void* src0, const void* src1, void* dst, const unsigned* idx, long nchunks, void* stream) {
+    if (!src0 || !dst || !idx) return hulc_fail(-1, "hulc_gather_chunks: null pointer");
+    if (((uintptr_t)src0 | (uintptr_t)src1 | (uintptr_t)dst) % 8) return hulc_fail(-4, "hulc_gather_chunks: arrays must be 8-byte aligned");
+    if (nchunks <= 0) return 0;
+    gather_chunks_kernel<<<(unsigned)((nchunks + 255) / 256), 256, 0, (hipStream_t)stream>>>((const uint2*)src0, (const uint2*)src1, (uint2*)dst, idx, nchunks);
+    return hulc_check_launch("hulc_gather_chunks");
+}
+
 extern "C" int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream) {
     if (!src || !dst || !table) return hulc_fail(-1, "hulc_repack_conv_weights: null pointer");
     if (n <= 0) return 0;

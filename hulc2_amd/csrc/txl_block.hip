@@ -175,8 +175,16 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) acc[ot] = zero16();
 
+    const uint16_t* W1p = (const uint16_t*)l.W1p;
+    const uint16_t* W2p = (const uint16_t*)l.W2p;
     auto load = [&](FfnFrags& f, int s) {
         const int j0 = s * 128 + 32 * w;
+        if (W1p && W2p) {                                           // fragment-packed copies: 1 KB contiguous per load instruction
+            const long u = ((long)(j0 / 32) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) { f.w1[q8] = ldg16(W1p + u + q8 * 512); f.w2[q8] = ldg16(W2p + u + q8 * 512); }
+            return;
+        }
         const uint16_t* a = W1 + (long)(j0 + r) * E + hf * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) f.w1[ks] = ldg16(a + ks * 16);
@@ -392,7 +400,14 @@ HULC_DEVICE void ffn_bwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
     for (int s = q * NS; s < (q + 1) * NS; ++s) {                   // this member's hidden slices
         const int j0 = s * 128 + 32 * w;
         bf16x8_t w1f[8], w2t[8], w1t[8];
-        {
+        if (l.W1p && l.W2Tp && l.W1Tp) {                            // fragment-packed copies: 1 KB contiguous per load instruction
+            const long u = ((long)(j0 / 32) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+                w1f[q8] = ldg16((const uint16_t*)l.W1p + u + q8 * 512); w2t[q8] = ldg16((const uint16_t*)l.W2Tp + u + q8 * 512);
+                w1t[q8] = ldg16((const uint16_t*)l.W1Tp + u + q8 * 512);
+            }
+        } else {
             const uint16_t* a = W1 + (long)(j0 + r) * E + hf * 8;
             const uint16_t* c = W2T + (long)(j0 + r) * E + 4 * hf;
 #pragma unroll

@@ -871,7 +871,8 @@ class TxlBlockFn(torch.autograd.Function):
             if keep:
                 t.update(pre1=_f32(T, E, like=emb), mean1=_f32(T, like=emb), rstd1=_f32(T, like=emb), pre2=_f32(T, E, like=emb),
                          mean2=_f32(T, like=emb), rstd2=_f32(T, like=emb), ctx=torch.empty(T, E, dtype=torch.bfloat16, device=dev))
-            recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2), bqkv=b_in, bo=b_out,
+            recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2),
+                             W1p=weight_operand(w1, "ffn_p0"), W2p=weight_operand(w2, "ffn_p1"), bqkv=b_in, bo=b_out,
                              b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2, seed_attn=sd + 11, seed_ln1=sd + 12, seed_ffn=sd + 13, seed_ln2=sd + 15,
                              x=x, **t))
             kept.append(t)
@@ -909,6 +910,7 @@ class TxlBlockFn(torch.autograd.Function):
                      dx=_f32(T, E, like=like))
             recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2),
                              WqkvT=weight_operand(w_in, "t"), WoT=weight_operand(w_out, "t"), W1T=weight_operand(w1, "t"), W2T=weight_operand(w2, "t"),
+                             W1p=weight_operand(w1, "ffn_p0"), W2Tp=weight_operand(w2, "ffn_p2"), W1Tp=weight_operand(w1, "ffn_p3"),
                              bqkv=b_in, bo=b_out, b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2,
                              seed_attn=sd + 11, seed_ln1=sd + 12, seed_ffn=sd + 13, seed_ln2=sd + 15,
                              x=x, y1=y1, pre1=pre1, mean1=mean1, rstd1=rstd1, ctx=ctxb, y2=y2, pre2=pre2, mean2=mean2, rstd2=rstd2, **o))

@@ -948,6 +948,20 @@ def txl_block_bwd(d, B, S, H, E, FF, L):
     _call("hulc_txl_block_bwd", _c.byref(d), key=("txl_block_bwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, True))
 
 
+def gather_chunks(src0, src1, dst, idx):
+    """dst 8-byte chunk c = chunk idx[c] of src0 (or of src1 when bit 31 is set): the packed weight copies of a step in one launch"""
+    _call("hulc_gather_chunks", src0, src1, dst, idx, _l(idx.numel()))
+
+
+def ffn_frag_perm(layout: int, FF: int):
+    """host: numpy int32 (FF * 128,) — hulc_ffn_frag_perm (include/hulc2_amd.h)"""
+    import numpy as np
+    out = np.empty(FF * 128, dtype=np.int32)
+    lib = _L.load()
+    _L.check(lib.hulc_ffn_frag_perm(_i(layout), _i(FF), out.ctypes.data_as(_c.c_void_p)), "hulc_ffn_frag_perm")
+    return out
+
+
 def repack_conv_weights(src_f32, dst_bf16, table):
     """table: int64 (n, 7) device tensor {src offset, dst offset, Cout, Cin, KH, KW, mode} (mode 0 oihw_flat, 1 ohwi, 2 ihwo)"""
     _call("hulc_repack_conv_weights", src_f32, dst_bf16, table, _i(table.shape[0]))

@@ -52,6 +52,14 @@ class PlanRecognitionTransformersNetwork(nn.Module):
                 "norm1.weight": m.norm1.weight, "norm1.bias": m.norm1.bias,
                 "norm2.weight": m.norm2.weight, "norm2.bias": m.norm2.bias}
 
+    def frag_operands(self):
+        """(weight, hulc_ffn_frag_perm layout) of the feed-forward weights the whole-trunk launch reads fragment-packed: the trainer keeps
+        these copies fresh with one gather launch per step"""
+        out = []
+        for m in self.transformer_encoder.layers:
+            out += [(m.linear1.weight, 0), (m.linear2.weight, 1), (m.linear2.weight, 2), (m.linear1.weight, 3)]
+        return out
+
     def _position_ids(self, S: int, device) -> torch.Tensor:
         """arange(S) (plan_recognition_net.py:133): kept per (length, device) instead of one launch per step"""
         cache = self.__dict__.setdefault("_pos_id_cache", {})

@@ -54,6 +54,18 @@ def register_layout_view(param: torch.Tensor, layout: str, view_bf16: torch.Tens
     _arena_layout[key] = (weakref.ref(param, lambda _r, k=key: _arena_layout.pop(k, None)), view_bf16)
 
 
+_ffn_perm: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def ffn_frag_perm(n: int, ff: int, device) -> torch.Tensor:
+    """int64 device tensor: source element of every element of the fragment-packed array (include/hulc2_amd.h hulc_ffn_frag_perm)"""
+    key = (n, ff, str(device))
+    t = _ffn_perm.get(key)
+    if t is None:
+        t = _ffn_perm[key] = torch.from_numpy(kn.ffn_frag_perm(n, ff)).to(device=device, dtype=torch.long)
+    return t
+
+
 def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
     if layout is None:
         return w
@@ -65,6 +77,11 @@ def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
         return w.permute(1, 2, 3, 0)
     if layout == "t":                  # transposed 2-D weight: lets dX = dY W stream W k-major
         return w.t()
+    if layout.startswith("ffn_p"):     # fragment-packed feed-forward weights of the transformer block launch (hulc_ffn_frag_perm layouts 0..3)
+        n = int(layout[-1])
+        src = w if n in (0, 1) else w.t()                   # 2: W2^T [FF][128], 3: W1^T [128][FF]
+        ff = w.shape[0] if n in (0, 3) else w.shape[1]
+        return src.contiguous().reshape(-1)[ffn_frag_perm(n, ff, w.device)]
     if layout in ("hwc", "hwc_t"):     # Linear behind nn.Flatten of a (C, H, W) map: columns reordered to the NHWC activation's (h, w, c)
         c, h, w_ = chw
         m = w.view(w.shape[0], c, h, w_).permute(0, 2, 3, 1).reshape(w.shape[0], -1)

@@ -356,6 +356,33 @@ class ArenaTrainer:
                 for t, off in mats:
                     shadow.register_arena_view_t(t, self.flat_bf16_t[off:off + t.numel()].view(t.shape[1], t.shape[0]))
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+        # fragment-packed feed-forward weights of the transformer block launch (modules list them in frag_operands()): one gather launch per
+        # step from the bf16 arena and its transposed shadow, 8-byte chunks
+        self.frag_shadow = self.frag_idx = None
+        if self.flat_bf16 is not None and self.flat_bf16_t is not None:
+            off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+            chunks, views, dst = [], [], 0
+            for m in model.modules():
+                if not hasattr(m, "frag_operands"):
+                    continue
+                for p, n in m.frag_operands():
+                    off = off_of.get(id(p))
+                    if off is None or off % 4 or id(p) in member:
+                        continue
+                    ff = p.shape[0] if n in (0, 3) else p.shape[1]
+                    perm = kn.ffn_frag_perm(n, ff).astype("int64").reshape(-1, 4)
+                    assert (perm[:, 0] % 4 == 0).all() and (perm[:, 1:] - perm[:, :1] == [1, 2, 3]).all(), "fragment permutations move runs of 4"
+                    c = (perm[:, 0] + off) // 4
+                    chunks.append(c | (1 << 31) if n in (2, 3) else c)
+                    views.append((p, "ffn_p%d" % n, dst, p.numel()))
+                    dst += p.numel()
+            if chunks:
+                import numpy as np
+                self.frag_shadow = torch.zeros(dst, dtype=torch.bfloat16, device=dev)
+                self.frag_idx = torch.from_numpy(np.concatenate(chunks).astype(np.uint32).view(np.int32)).to(dev)
+                for p, name, d0, n_el in views:
+                    shadow.register_layout_view(p, name, self.frag_shadow[d0:d0 + n_el])
+                kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
         # conv weights in their kernel layouts (OIHW flat for conv1, OHWI forward, IHWO data gradient): one repack launch per step
         self.conv_shadow = self.conv_table = None
         if self.flat_bf16 is not None:
@@ -428,6 +455,8 @@ class ArenaTrainer:
             kn.cast_f32_to_bf16(self.flat_p, self.flat_bf16, self.total)
             if self.tiles_t is not None:
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+            if self.frag_idx is not None:
+                kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
             if self.conv_table is not None:
                 kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         shadow.bump_epoch()
@@ -640,6 +669,8 @@ class ArenaTrainer:
                      step_state_dev=kn.step_state(self.dev))      # step count lives on the device (graph replay)
         if self.tiles_t is not None:
             kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
+        if self.frag_idx is not None:
+            kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
         if self.conv_table is not None:
             kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         shadow.bump_epoch()

@@ -331,6 +331,8 @@ int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 typedef struct hulc_txl_block_layer {
     const void *Wqkv, *Wo, *W1, *W2;                 /* bf16 [3E][E], [E][E], [FF][E], [E][FF] */
     const void *WqkvT, *WoT, *W1T, *W2T;             /* backward: their transposes */
+    const void *W1p, *W2p, *W2Tp, *W1Tp;             /* optional fragment-packed copies (hulc_ffn_frag_perm layouts 0, 1, 2, 3): every weight fragment
+                                                        of the feed-forward loops is then one coalesced 16-byte load per lane; null = gather from the matrices */
     const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
     unsigned long long seed_attn, seed_ln1, seed_ffn, seed_ln2;
     float* x;                                        /* (T, E) layer input; layer 0: written by the forward launch = dropout(emb + pos) */
@@ -554,6 +556,14 @@ int hulc_sum_chunks(const void* src, int dtype, int W, long chunk, void* dst, vo
  * tile col} over 64 x 64 tiles; dst + offset receives W^T ([cols][rows]).  The data-gradient GEMMs (dX = dY W of every
  * nn.Linear) then read W k-major like the forward pass does. */
 int hulc_transpose_bf16_tiles(const void* src, void* dst, const long* tiles, int ntiles, void* stream);
+/* (ABI 3) Fragment-packed copies of the transformer feed-forward weights for hulc_txl_block_*: out[i] (FF * 128 entries) = the element of
+ * the source matrix that element i of the packed array holds.  layout 0: source W1 [FF][128] (forward / backward A operand of z^T),
+ * 1: source W2 [128][FF] (forward), 2: source W2^T [FF][128], 3: source W1^T [128][FF] (backward); element order in csrc/optim.hip.
+ * Runs on the host (no device work); every permutation moves runs of 4 consecutive source elements. */
+int hulc_ffn_frag_perm(int layout, int FF, int* out);
+/* dst chunk c (8 bytes = 4 bf16) = chunk (idx[c] & 0x7fffffff) of src1 when bit 31 of idx[c] is set, else of src0: every packed weight copy
+ * of a step from the bf16 arena (src0) and its transposed shadow (src1) in one launch. */
+int hulc_gather_chunks(const void* src0, const void* src1, void* dst, const unsigned* idx, long nchunks, void* stream);
 /* All conv-weight repacks of a step in one launch: table[q] = {src offset (fp32 arena elements), dst offset (bf16 elements), Cout, Cin,
  * KH, KW, mode}; mode 0 = OIHW flat (conv1 forward), 1 = OHWI (NHWC forward, k = (kh,kw,c)), 2 = IHWO (data gradient,
  * rows = input channel, k = (kh,kw,cout)).  Replaces a permute copy + cast per layer and layout. */

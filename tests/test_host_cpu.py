@@ -338,3 +338,24 @@ def test_a_second_trainer_retires_the_first_ones_load_hook():
         assert p.data_ptr() == t2.flat_p.data_ptr() + 4 * off
     t2.close()
     assert len(m._load_state_dict_post_hooks) == 0
+
+
+def test_ffn_fragment_permutations():
+    """hulc_ffn_frag_perm (host function of the C ABI): each layout is a permutation of the FF x 128 weight elements that moves runs of 4
+    consecutive source elements (the trainer's gather launch copies 8-byte chunks), and layout 0 keeps a fragment's 8 k-slots consecutive"""
+    import numpy as np
+    from hulc2_amd import kernels as kn
+    for ff in (128, 2048):
+        for n in range(4):
+            p = kn.ffn_frag_perm(n, ff).astype(np.int64)
+            assert p.shape == (ff * 128,) and np.array_equal(np.sort(p), np.arange(ff * 128))
+            q = p.reshape(-1, 4)
+            assert (q[:, 0] % 4 == 0).all() and (q[:, 1:] - q[:, :1] == [1, 2, 3]).all()
+        a = kn.ffn_frag_perm(0, ff).reshape(-1, 8)
+        assert (a[:, 1:] - a[:, :1] == np.arange(1, 8)).all()
+        # layout 1, hidden block hb, fragment f = 2 ot + kk, lane (r, hf): W2[32 ot + r][32 hb + 16 kk + 4 hf + {0..3, 8..11}]
+        b = kn.ffn_frag_perm(1, ff).reshape(ff // 32, 8, 64, 8)
+        hb, f, lane = ff // 32 - 1, 5, 37
+        r, hf = lane & 31, lane >> 5
+        want = [(32 * (f >> 1) + r) * ff + 32 * hb + 16 * (f & 1) + 4 * hf + (j if j < 4 else j + 4) for j in range(8)]
+        assert b[hb, f, lane].tolist() == want
