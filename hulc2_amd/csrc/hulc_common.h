@@ -253,6 +253,20 @@ HULC_DEVICE void dropout_scale4(uint64_t seed, uint64_t idx0, float p, float (&s
     s[0] = (lo & 0xffffu) >= thr ? keep : 0.f; s[1] = (lo >> 16) >= thr ? keep : 0.f;
     s[2] = (hi & 0xffffu) >= thr ? keep : 0.f; s[3] = (hi >> 16) >= thr ? keep : 0.f;
 }
+// the 16 elements an MFMA accumulator lane holds along a row of consecutive indices: base + (e & 3) + 8 (e >> 2) + 4 hf — four runs of 4
+HULC_DEVICE void dropout_scale_acc16(uint64_t seed, uint64_t base, int hf, float p, float (&s)[16]) {
+    if ((base & 3) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float t[4];
+            dropout_scale4(seed, base + 8 * g + 4 * hf, p, t);
+            s[4 * g] = t[0]; s[4 * g + 1] = t[1]; s[4 * g + 2] = t[2]; s[4 * g + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = dropout_scale(seed, base + (e & 3) + 8 * (e >> 2) + 4 * hf, p);
+    }
+}
 HULC_DEVICE float hulc_uniform01(uint64_t seed, uint64_t idx) {
     return (hulc_rand32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }

@@ -815,6 +815,46 @@ extern "C" int hulc_ln_partial_reduce(const float* partial, int P, int D, float*
     return hulc_check_launch("hulc_ln_partial_reduce");
 }
 
+namespace {
+struct LnMultiP { float* dg[8]; float* db[8]; int acc[8]; };
+// blockIdx.z = which LayerNorm; blockIdx.y = dgamma | dbeta; reduce_rows_wide_kernel's summation order
+__global__ __launch_bounds__(1024) void ln_partial_multi_kernel(const float* __restrict__ partial, int P, int D, LnMultiP t) {
+    __shared__ float red[16][64];
+    const int which = blockIdx.z;
+    const float* src = partial + (long)which * P * 2 * D + (blockIdx.y ? D : 0);
+    float* out = blockIdx.y ? t.db[which] : t.dg[which];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int rr = blockIdx.x * 64 + lane;
+    const int per = (P + 15) / 16;
+    const int q0 = sl * per, q1 = q0 + per < P ? q0 + per : P;
+    float s = 0.f;
+    if (rr < D)
+        for (int q = q0; q < q1; ++q) s += src[(long)q * 2 * D + rr];
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && rr < D) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][lane];
+        out[rr] = t.acc[which] ? out[rr] + v : v;
+    }
+}
+}  // namespace
+
+// see include/hulc2_amd.h
+extern "C" int hulc_ln_partial_reduce_multi(const float* partial, int n, int P, int D, float* const* dgamma, float* const* dbeta, const int* accumulate,
+                                            void* stream) {
+    if (!partial || !dgamma || !dbeta || !accumulate) return hulc_fail(-1, "hulc_ln_partial_reduce_multi: null pointer");
+    if (n < 1 || n > 8 || P < 1 || D < 1) return hulc_fail(-2, "hulc_ln_partial_reduce_multi: 1..8 LayerNorms");
+    LnMultiP t = {};
+    for (int i = 0; i < n; ++i) {
+        if (!dgamma[i] || !dbeta[i]) return hulc_fail(-1, "hulc_ln_partial_reduce_multi: null destination");
+        t.dg[i] = dgamma[i]; t.db[i] = dbeta[i]; t.acc[i] = accumulate[i];
+    }
+    ln_partial_multi_kernel<<<dim3((D + 63) / 64, 2, n), 1024, 0, (hipStream_t)stream>>>(partial, P, D, t);
+    return hulc_check_launch("hulc_ln_partial_reduce_multi");
+}
+
 static long colsum_row_blocks(long M, int N) {
     const long gx = (N + 255) / 256;
     long rb = (1024 + gx - 1) / gx;                     // >= ~1024 workgroups ...

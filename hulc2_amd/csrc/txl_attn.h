@@ -145,10 +145,12 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         const long pbase = (((long)b * NH + 2 * w + hh) * S + r) * S;
+        float pk[16];
+        if (p.drop_p > 0.f) dropout_scale_acc16(seed_attn, (uint64_t)pbase, hf, p.drop_p, pk);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             s[e] *= inv;
-            if (p.drop_p > 0.f) s[e] *= dropout_scale(seed_attn, (uint64_t)(pbase + arow(e, hf)), p.drop_p);
+            if (p.drop_p > 0.f) s[e] *= pk[e];
         }
         f32x16_t o = MFMA(vf0, pack8<0>(s), zero16());      // D[v column][query]: rows of the OTHER head of this wave are garbage
         o = MFMA(vf1, pack8<8>(s), o);
@@ -172,15 +174,17 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
     // residual + dropout + LayerNorm over the 128 features of token r (spread over 4 waves x 2 lane halves x 16 registers)
     float pre[16];
     float s1 = 0.f;
+    float lk[16];
+    if (p.drop_p > 0.f) dropout_scale_acc16(seed_ln, (uint64_t)((tok0 + r) * E + 32 * w), hf, p.drop_p, lk);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 xv = xres[g], bv = bov[g];
         const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ba[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = 4 * g + q, n = 32 * w + arow(e, hf);
+            const int e = 4 * g + q;
             float ov = o[e] + ba[q];
-            if (p.drop_p > 0.f) ov *= dropout_scale(seed_ln, (uint64_t)((tok0 + r) * E + n), p.drop_p);
+            if (p.drop_p > 0.f) ov *= lk[e];
             pre[e] = xa[q] + ov;
             s1 += pre[e];
         }
@@ -217,7 +221,10 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
 // out_proj / attention / in_proj data gradients -> dx = dpre + dqkv Wqkv.  Weight gradients are left to two GEMMs over all tokens
 // (dWo = d_o^T ctx, dWqkv = dqkv^T x): this kernel stores d_o and dqkv row-major in bf16 and the per-sequence LayerNorm partials.
 constexpr int TXL_BWD_LDS = 8 * 2 * 32 * 16 + 4 * 2 * 32 * 33 * 4 + 2 * 4 * 32 * 4 + 4 * 3 * 32 * 4;
-HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds) {
+// REGS (the whole-block launch): the incoming gradient arrives in registers (dyr[e] <-> feature 32 w + arow(e, hf) of token r, zero for
+// r >= S) and the input gradient leaves the same way (dxr) instead of through p.dy / p.dx
+template <bool REGS = false>
+HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds, const float* dyr = nullptr, float* dxr = nullptr) {
     uint4* dos = (uint4*)lds;                  // d_o fragments   [k-step][lane half][token]
     // dqkv fragments [k-step][lane half][token] (24 KB, written last) share their storage with the LayerNorm parameter-gradient
     // transposes (33 KB, dead after the first barrier)
@@ -252,8 +259,11 @@ HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds) {
         // accumulation chain cost 64 serial memory round trips here: 40 us per launch)
         float4 dsum[4];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) dsum[q4] = *(const float4*)(p.dy + off + 8 * q4);
-        {
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if constexpr (REGS) dsum[q4] = make_float4(dyr[4 * q4], dyr[4 * q4 + 1], dyr[4 * q4 + 2], dyr[4 * q4 + 3]);
+            else dsum[q4] = *(const float4*)(p.dy + off + 8 * q4);
+        }
+        if constexpr (!REGS) {
             int sl = 0;
             for (; sl + 3 < p.n_slab; sl += 4) {
                 float4 t[4][4];
@@ -294,12 +304,13 @@ HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds) {
         __syncthreads();
         s1 = ((red[0][0][r] + red[0][1][r]) + (red[0][2][r] + red[0][3][r])) * (1.0f / E);
         s2 = ((red[1][0][r] + red[1][1][r]) + (red[1][2][r] + red[1][3][r])) * (1.0f / E);
-        float dov[16];
+        float dov[16], lk[16];
+        if (p.drop_p > 0.f) dropout_scale_acc16(seed_ln, (uint64_t)((tok0 + r) * E + 32 * w), hf, p.drop_p, lk);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             dpre[e] = rstd * (g[e] - s1 - xh[e] * s2);
             dov[e] = dpre[e];
-            if (p.drop_p > 0.f) dov[e] *= dropout_scale(seed_ln, (uint64_t)((tok0 + r) * E + 32 * w + arow(e, hf)), p.drop_p);
+            if (p.drop_p > 0.f) dov[e] *= lk[e];
         }
         { Frag f; f.b = pack8f(dov); dos[((2 * w) * 2 + hf) * 32 + r] = f.u; f.b = pack8f(dov + 8); dos[((2 * w + 1) * 2 + hf) * 32 + r] = f.u; }
         if (live) {
@@ -371,10 +382,11 @@ HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         float mk[16], rs = 0.f;
+        if (p.drop_p > 0.f) dropout_scale_acc16(seed_attn, (uint64_t)((hb + r) * S), hf, p.drop_p, mk);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             sT[e] *= inv;                                                                       // P (before dropout)
-            mk[e] = p.drop_p > 0.f ? dropout_scale(seed_attn, (uint64_t)((hb + r) * S + arow(e, hf)), p.drop_p) : 1.f;
+            if (!(p.drop_p > 0.f)) mk[e] = 1.f;
             rs += dpT[e] * mk[e] * sT[e];
         }
         rs += __shfl_xor(rs, 32, 64);
@@ -438,7 +450,10 @@ HULC_DEVICE void txl_attn_bwd_body(const TxlP& p, const int b, char* lds) {
         Frag f; f.u = dqs[(kk * 2 + hf) * 32 + r];
         ax = MFMA(wtf[kk], f.b, ax);
     }
-    if (live) {
+    if constexpr (REGS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dxr[e] = live ? dpre[e] + ax[e] : 0.f;
+    } else if (live) {
         float* dst = p.dx + (tok0 + r) * E + 32 * w + 4 * hf;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)

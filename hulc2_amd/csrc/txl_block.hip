@@ -58,8 +58,8 @@ HULC_DEVICE TxlP attn_params(const BlockP& d, const LayerP& l) {
     p.bqkv = l.bqkv; p.bo = l.bo; p.gamma = l.g1; p.beta = l.be1; p.eps = d.eps; p.B = d.B; p.S = d.S;
     p.drop_p = d.drop_p; p.seed_attn = l.seed_attn; p.seed_ln = l.seed_ln1; p.seed_dev = d.seed_dev;
     p.y = l.y1; p.pre = l.pre1; p.mean = l.mean1; p.rstd = l.rstd1; p.ctx = (uint16_t*)l.ctx;
-    p.dy = l.dy1; p.dy_slab = nullptr; p.n_slab = 0; p.slab_stride = 0;
-    p.dx = l.dx; p.d_o = (uint16_t*)l.d_o; p.dqkv = (uint16_t*)l.dqkv; p.ln_partial = l.lnp1;
+    p.dy = nullptr; p.dy_slab = nullptr; p.n_slab = 0; p.slab_stride = 0;
+    p.dx = nullptr; p.d_o = (uint16_t*)l.d_o; p.dqkv = (uint16_t*)l.dqkv; p.ln_partial = l.lnp1;
     return p;
 }
 
@@ -157,7 +157,7 @@ HULC_DEVICE void pos_add_seq(const BlockP& d, int b) {
 struct FfnFrags { bf16x8_t w1[8], w2[8]; };
 
 // y2 = LayerNorm2(y1 + dropout(W2 dropout(relu(W1 y1 + b1)) + b2))  for the 32 tokens of sequence b
-HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int li, char* lds) {
+HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int li, char* lds, bool stash) {
     const BlockP& d = k.d;
     float* part = (float*)lds;
     float (*red)[4][32] = (float (*)[4][32])(lds + PART_BYTES);
@@ -274,6 +274,7 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
             out.z = (pre[4 * g + 2] - mean) * rstd * gv.z + bt.z; out.w = (pre[4 * g + 3] - mean) * rstd * gv.w + bt.w;
             *(float4*)(yr + 8 * g) = out;
             if (pr) *(float4*)(pr + 8 * g) = make_float4(pre[4 * g], pre[4 * g + 1], pre[4 * g + 2], pre[4 * g + 3]);
+            if (stash) *(float4*)(part + r * E + 32 * w + 4 * hf + 8 * g) = out;   // the last layer's rows stay in LDS for the sequence mean
         }
         if (w == 0 && hf == 0 && l.mean2) { l.mean2[tok0 + r] = mean; l.rstd2[tok0 + r] = rstd; }
     }
@@ -296,12 +297,12 @@ __global__ __launch_bounds__(256) void txl_block_fwd_kernel(BlockK k) {
         asm volatile("" : "+s"(bb));
         if (!(k.dbg & 1)) txl_attn_fwd_body(p, bb, lds);
         __syncthreads();
-        ffn_fwd_seq(k, l, bb, q, li, lds);
+        ffn_fwd_seq(k, l, bb, q, li, lds, li + 1 == d.L);
         __syncthreads();
     }
     quad_finish(k, b);
-    if (d.pooled && tid < E) {                                      // seq_mean_fwd_kernel's summation order
-        const float* xb = d.layers[d.L - 1].y2 + (long)b * d.S * E + tid;
+    if (d.pooled && tid < E) {                                      // seq_mean_fwd_kernel's summation order, rows from LDS
+        const float* xb = (const float*)lds + tid;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int t = 0;
         for (; t + 3 < d.S; t += 4) {
@@ -351,7 +352,7 @@ HULC_DEVICE void ln_bwd_regs(const float (&dyv)[16], const float* pre, const flo
 }
 
 // LayerNorm2 backward + feed-forward backward of sequence b: dyv = gradient of y2 (registers) -> dy1 (memory), h / dh / df (bf16, memory)
-HULC_DEVICE void ffn_bwd_seq(const BlockK& k, const LayerP& l, int b, int q, int li, const float (&dyv)[16], char* lds) {
+HULC_DEVICE void ffn_bwd_seq(const BlockK& k, const LayerP& l, int b, int q, int li, const float (&dyv)[16], float (&dy1)[16], char* lds) {
     const BlockP& d = k.d;
     // LDS: [dfs 8 KB | lt 33 KB] during the LayerNorm part and the fragment exchange, then the 64 KB of partial tiles over both
     uint4* dfs = (uint4*)lds;
@@ -452,13 +453,8 @@ HULC_DEVICE void ffn_bwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
     f32x16_t ax;
     exchange_tiles(acc, part, w, lane, ax);
     quad_exchange(k, ax, b, q, li, d.L - li);
-    if (live) {
-        float* dst = l.dy1 + (tok0 + r) * E + 32 * w + 4 * hf;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            *(float4*)(dst + 8 * g4) = make_float4(dpre[4 * g4] + ax[4 * g4], dpre[4 * g4 + 1] + ax[4 * g4 + 1], dpre[4 * g4 + 2] + ax[4 * g4 + 2],
-                                                   dpre[4 * g4 + 3] + ax[4 * g4 + 3]);
-    }
+    for (int e = 0; e < 16; ++e) dy1[e] = live ? dpre[e] + ax[e] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void txl_block_bwd_kernel(BlockK k) {
@@ -471,50 +467,41 @@ __global__ __launch_bounds__(256) void txl_block_bwd_kernel(BlockK k) {
     const long tok0 = (long)b * S;
     const bool live = r < S;
     const long off = (tok0 + (live ? r : 0)) * E + 32 * w + 4 * hf;
-    for (int li = d.L - 1; li >= 0; --li) {
-        const LayerP& l = d.layers[li];
-        float dyv[16];
-        if (li == d.L - 1) {                                        // mean over the sequence: every token receives dpooled / S
-            const float* src = d.dpooled + (long)b * E + 32 * w + 4 * hf;
+    float dyv[16];                                                  // gradient of the current layer's output: registers from stage to stage
+    {                                                               // mean over the sequence: every token receives dpooled / S
+        const float* src = d.dpooled + (long)b * E + 32 * w + 4 * hf;
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 a = *(const float4*)(src + 8 * q4);
-                dyv[4 * q4] = a.x / S; dyv[4 * q4 + 1] = a.y / S; dyv[4 * q4 + 2] = a.z / S; dyv[4 * q4 + 3] = a.w / S;
-            }
-        } else {                                                    // the upper layer's input gradient (this lane wrote these 16 values itself)
-            const float* src = d.layers[li + 1].dx + off;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 a = *(const float4*)(src + 8 * q4);
-                dyv[4 * q4] = a.x; dyv[4 * q4 + 1] = a.y; dyv[4 * q4 + 2] = a.z; dyv[4 * q4 + 3] = a.w;
-            }
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 a = *(const float4*)(src + 8 * q4);
+            dyv[4 * q4] = a.x / S; dyv[4 * q4 + 1] = a.y / S; dyv[4 * q4 + 2] = a.z / S; dyv[4 * q4 + 3] = a.w / S;
         }
         if (!live) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) dyv[e] = 0.f;
         }
+    }
+    for (int li = d.L - 1; li >= 0; --li) {
+        const LayerP& l = d.layers[li];
         int bb = b;                                                 // (opaque per layer, see the forward kernel)
         asm volatile("" : "+s"(bb));
-        ffn_bwd_seq(k, l, bb, q, li, dyv, lds);
+        float dy1[16];
+        ffn_bwd_seq(k, l, bb, q, li, dyv, dy1, lds);
         __syncthreads();
         const TxlP p = attn_params(d, l);
         asm volatile("" : "+s"(bb));
-        if (!(k.dbg & 1)) txl_attn_bwd_body(p, bb, lds);
+        if (!(k.dbg & 1)) txl_attn_bwd_body<true>(p, bb, lds, dy1, dyv);
         __syncthreads();
     }
     quad_finish(k, b);
     if (live) {                                                     // dropout of the position-embedded input (dropout_bwd_kernel's stream)
         const unsigned long long seed = d.seed_pos ^ (d.seed_dev ? d.seed_dev[0] : 0ull);
-        const float* src = d.layers[0].dx + off;
         float* dst = d.demb + off;
+        float keep[16];
+        if (d.drop_p > 0.f) dropout_scale_acc16(seed, (uint64_t)((tok0 + r) * E + 32 * w), hf, d.drop_p, keep);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            float4 a = *(const float4*)(src + 8 * q4);
-            if (d.drop_p > 0.f) {
-                const uint64_t i = (uint64_t)(off + 8 * q4);
-                a.x *= dropout_scale(seed, i, d.drop_p); a.y *= dropout_scale(seed, i + 1, d.drop_p);
-                a.z *= dropout_scale(seed, i + 2, d.drop_p); a.w *= dropout_scale(seed, i + 3, d.drop_p);
-            }
+            float4 a = make_float4(dyv[4 * q4], dyv[4 * q4 + 1], dyv[4 * q4 + 2], dyv[4 * q4 + 3]);
+            if (d.drop_p > 0.f) { a.x *= keep[4 * q4]; a.y *= keep[4 * q4 + 1]; a.z *= keep[4 * q4 + 2]; a.w *= keep[4 * q4 + 3]; }
             *(float4*)(dst + 8 * q4) = a;
         }
     }
@@ -533,7 +520,7 @@ int block_check(const hulc_txl_block_desc* d, bool bwd, const char* who) {
             return hulc_fail(-3, "hulc_txl_block: pre / mean / rstd are kept together or not at all");
         if (i + 1 < d->L && d->layers[i + 1].x != l.y2) return hulc_fail(-3, "hulc_txl_block: layer l+1's x is layer l's y2");
         if (bwd && (!l.WqkvT || !l.WoT || !l.W1T || !l.W2T || !l.pre1 || !l.mean1 || !l.rstd1 || !l.ctx || !l.pre2 || !l.mean2 || !l.rstd2 || !l.d_o ||
-                    !l.dqkv || !l.df || !l.h || !l.dh || !l.lnp1 || !l.lnp2 || !l.dy1 || !l.dx))
+                    !l.dqkv || !l.df || !l.h || !l.dh || !l.lnp1 || !l.lnp2))
             return hulc_fail(-1, who);
     }
     return 0;

@@ -901,13 +901,13 @@ class TxlBlockFn(torch.autograd.Function):
         bf = dict(dtype=torch.bfloat16, device=dev)
         recs, outs = [], []
         x = x0
+        lnp = _f32(2 * L, B, 2, E, like=like)              # every LayerNorm's per-sequence partials: one reduce launch
         for li in range(L):
             w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
             y1, pre1, mean1, rstd1, ctxb, y2, pre2, mean2, rstd2 = acts[9 * li:9 * li + 9]
             sd = seed + 100 * (li + 1)
             o = dict(d_o=torch.empty(T, E, **bf), dqkv=torch.empty(T, 3 * E, **bf), df=torch.empty(T, E, **bf), h=torch.empty(T, FF, **bf),
-                     dh=torch.empty(T, FF, **bf), lnp1=_f32(B, 2, E, like=like), lnp2=_f32(B, 2, E, like=like), dy1=_f32(T, E, like=like),
-                     dx=_f32(T, E, like=like))
+                     dh=torch.empty(T, FF, **bf), lnp1=lnp[2 * li], lnp2=lnp[2 * li + 1])
             recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2),
                              WqkvT=weight_operand(w_in, "t"), WoT=weight_operand(w_out, "t"), W1T=weight_operand(w1, "t"), W2T=weight_operand(w2, "t"),
                              W1p=weight_operand(w1, "ffn_p0"), W2Tp=weight_operand(w2, "ffn_p2"), W1Tp=weight_operand(w1, "ffn_p3"),
@@ -920,18 +920,25 @@ class TxlBlockFn(torch.autograd.Function):
         d = kn.txl_block_desc(emb, pos, pos_ids, B, S, H, FF, drop_p, seed, 1e-5, recs, dpooled=dpooled, demb=demb)
         kn.txl_block_bwd(d, B, S, H, E, FF, L)
         grads = []
+        rets = []
+        dgs, dbs, accs = [], [], []
+        for li in range(L):
+            w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+            ret = {}
+            rets.append(ret)
+            for gm, bt, kg, kb in ((g1, be1, "g1", "be1"), (g2, be2, "g2", "be2")):
+                (dg, a1, ret[kg]), (db, a2, ret[kb]) = _sink_or_new(gm, (E,), like), _sink_or_new(bt, (E,), like)
+                dgs.append(dg); dbs.append(db); accs.append(a1 or a2)
+        kn.ln_partial_reduce_multi(lnp, B, E, dgs, dbs, accs)
         for li in range(L):
             w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
             o, xin, y1, ctxb = outs[li]
-            ret = {}
+            ret = rets[li]
 
             def sink(name, param, shape):
                 t, acc, r = _sink_or_new(param, shape, like)
                 ret[name] = r
                 return t, acc
-            for lnp, gm, bt, kg, kb in ((o["lnp1"], g1, be1, "g1", "be1"), (o["lnp2"], g2, be2, "g2", "be2")):
-                (dg, a1), (db, a2) = sink(kg, gm, (E,)), sink(kb, bt, (E,))
-                kn.ln_partial_reduce(lnp, B, E, dg, db, accumulate=a1 or a2)
             # dW = (left operand)^T (right operand) over all T tokens, bias gradient = the left operand's column sums
             for left, right, W, bias, kw, kb_, M, N in ((o["dqkv"], xin, w_in, b_in, "w_in", "b_in", 3 * E, E), (o["d_o"], ctxb, w_out, b_out, "w_out", "b_out", E, E),
                                                         (o["dh"], y1, w1, b1, "w1", "b1", FF, E), (o["df"], o["h"], w2, b2, "w2", "b2", E, FF)):

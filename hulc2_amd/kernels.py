@@ -846,6 +846,16 @@ def ln_partial_reduce(partial, P, D, dgamma, dbeta, accumulate=False):
     _call("hulc_ln_partial_reduce", partial, _i(P), _i(D), dgamma, dbeta, _i(accumulate))
 
 
+def ln_partial_reduce_multi(partial, P, D, dgammas, dbetas, accumulates):
+    """partial (n, P, 2, D) -> n pairs of parameter gradients, one launch (hulc_ln_partial_reduce_multi)"""
+    n = len(dgammas)
+    _require_cuda(partial, *dgammas, *dbetas)
+    dg = (_c.c_void_p * n)(*[t.data_ptr() for t in dgammas])
+    db = (_c.c_void_p * n)(*[t.data_ptr() for t in dbetas])
+    acc = (_c.c_int * n)(*[int(bool(a)) for a in accumulates])
+    _call("hulc_ln_partial_reduce_multi", partial, _i(n), _i(P), _i(D), dg, db, acc)
+
+
 def _txl_desc(x, Wqkv, bqkv, gamma, B, S, H, drop_p, seed_attn, seed_ln, eps):
     d = _L.TxlAttnDesc()
     _require_cuda(x, Wqkv, bqkv, gamma)

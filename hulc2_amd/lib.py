@@ -136,7 +136,7 @@ class TxlBlockLayer(ctypes.Structure):
                                                 "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2")]
                 + [(n, ctypes.c_ulonglong) for n in ("seed_attn", "seed_ln1", "seed_ffn", "seed_ln2")]
                 + [(n, ctypes.c_void_p) for n in ("x", "y1", "pre1", "mean1", "rstd1", "ctx", "y2", "pre2", "mean2", "rstd2",
-                                                  "d_o", "dqkv", "df", "h", "dh", "lnp1", "lnp2", "dy1", "dx")])
+                                                  "d_o", "dqkv", "df", "h", "dh", "lnp1", "lnp2")])
 
 
 TXL_MAX_LAYERS = 4

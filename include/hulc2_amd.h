@@ -315,6 +315,10 @@ typedef struct hulc_txl_attn_desc {
     float* ln_partial;
 } hulc_txl_attn_desc;
 int hulc_ln_partial_reduce(const float* partial, int P, int D, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* (ABI 3) the same for n <= 8 LayerNorms in one launch: partial (n, P, 2, D); dgamma / dbeta / accumulate: HOST arrays of n entries
+ * (hulc_txl_block_bwd's lnp1 / lnp2 of every layer, carved from one buffer). */
+int hulc_ln_partial_reduce_multi(const float* partial, int n, int P, int D, float* const* dgamma, float* const* dbeta, const int* accumulate,
+                                 void* stream);
 int hulc_txl_attn_fwd(const hulc_txl_attn_desc* d, void* stream);
 int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 
@@ -341,7 +345,6 @@ typedef struct hulc_txl_block_layer {
     float *y2, *pre2, *mean2, *rstd2;                /* kept: the layer's output, LayerNorm2 input and statistics */
     void *d_o, *dqkv, *df, *h, *dh;                  /* backward out: bf16 (T, E), (T, 3E), (T, E), (T, FF), (T, FF) */
     float *lnp1, *lnp2;                              /* backward out: (B, 2, E) */
-    float *dy1, *dx;                                 /* backward: (T, E) gradient of y1 (scratch) and of x */
 } hulc_txl_block_layer;
 typedef struct hulc_txl_block_desc {
     int L, B, S, H, E, FF;
