@@ -278,6 +278,45 @@ def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Opt
     return MLPFn.apply(x, relus, drops, int(seed), *params)
 
 
+@_scoped
+class Mlp2RowsFn(torch.autograd.Function):
+    """fc2(relu(fc1(x))) over many rows — the head of both camera encoders (vision_network.py:49-52,60-66) — as one launch per direction
+    (csrc/mlp2_rows.hip): the (rows x 512) hidden activation stays in registers, backward recomputes it and leaves the bf16 operands of the
+    two weight-gradient products for the pass's grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        y = _f32(x.shape[0], W2.shape[0], like=x)
+        kn.mlp2_rows_fwd(x, weight_operand(W1), b1, weight_operand(W2), b2, y)
+        ctx.save_for_backward(x, W1, b1, W2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1, b1, W2, b2 = ctx.saved_tensors
+        T, H, OUT = x.shape[0], W1.shape[0], W2.shape[0]
+        dy = _c(dy)
+        if dy.dtype != torch.float32:
+            dy = dy.float()
+        dx = _f32(T, 128, like=dy) if ctx.needs_input_grad[0] else None
+        h = torch.empty(T, H, dtype=torch.bfloat16, device=dy.device)
+        dh = torch.empty(T, H, dtype=torch.bfloat16, device=dy.device)
+        kn.mlp2_rows_bwd(x, dy, weight_operand(W1), b1, weight_operand(W1, "t"), weight_operand(W2, "t"), dx, h, dh)
+        ret = []
+        for left, right, W, b, M, N in ((dh, x, W1, b1, H, 128), (dy, h, W2, b2, OUT, H)):
+            (dW, a1, rW), (db, a2, rb) = _sink_or_new(W, (M, N), dy), _sink_or_new(b, (M,), dy)
+            kn.wgrad(left, right, dW, M, N, T, M, N, N, accumulate=a1, rowsum=db, rowsum_accumulate=a2, defer=rW is None and rb is None)
+            ret += [rW, rb]
+        return (dx, *ret)
+
+
+def mlp2_rows(x, fc1_w, fc1_b, fc2_w, fc2_b):
+    """fc2(relu(fc1(x))) for x (rows, 128): one launch per direction where hulc_mlp2_rows_* take the shape, else the GEMM chain"""
+    if kn.mlp2_rows_ok(x, fc1_w, fc2_w):
+        return Mlp2RowsFn.apply(x, fc1_w, fc1_b, fc2_w, fc2_b)
+    return mlp(x, [(fc1_w, fc1_b, True), (fc2_w, fc2_b, False)])
+
+
 def dual_mlp(xa, layers_a, xb, layers_b):
     """mlp(xa, layers_a), mlp(xb, layers_b) — as one launch where the pair fits hulc_mlp_chain2 (both <= 32 rows, the same ReLU pattern
     and hidden widths), else one after the other."""

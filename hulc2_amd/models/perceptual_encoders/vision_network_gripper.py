@@ -43,7 +43,7 @@ class VisionNetwork(nn.Module):
         # nn.Flatten + Linear(3136, 128) + ReLU on the NHWC activation in place: the weight's columns are reordered, not the activations
         c = self.conv_model
         y = HF.flatten_linear_relu(a3, c[7].weight, c[7].bias)
-        y = HF.mlp(y, [(self.fc1[0].weight, self.fc1[0].bias, True), (self.fc2.weight, self.fc2.bias, False)])
+        y = HF.mlp2_rows(y, self.fc1[0].weight, self.fc1[0].bias, self.fc2.weight, self.fc2.bias)
         if pre_ln:
             return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)

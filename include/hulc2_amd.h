@@ -322,6 +322,17 @@ int hulc_ln_partial_reduce_multi(const float* partial, int n, int P, int D, floa
 int hulc_txl_attn_fwd(const hulc_txl_attn_desc* d, void* stream);
 int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
 
+/* ---- (ABI 3) Linear(128, H) + ReLU + Linear(H, OUT) over many rows as one launch per direction (bf16 compute) ------------------------ */
+/* The head of both camera encoders, fc2(relu(fc1(x))) (vision_network.py:49-52,60-66, vision_network_gripper.py:36-39,52-55), on the T
+ * frames of a step: x (T, K = 128) fp32, W1 bf16 [H][128] (H a multiple of 128), W2 bf16 [OUT][H] (OUT in {32, 64, 96, 128}) -> y (T, OUT)
+ * fp32; the hidden activation stays in registers.  Backward (W1T [128][H], W2T [H][OUT] = the transposes) recomputes it, writes
+ * dx (T, 128) fp32 (null: not wanted) and the bf16 operands h, dh (T, H) of dW1 = dh^T x, dW2 = dy^T h (row sums of dh / dy = the bias
+ * gradients; hulc_wgrad_group). */
+int hulc_mlp2_rows_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int K, int H, int OUT, float* y,
+                       void* stream);
+int hulc_mlp2_rows_bwd(const float* x, const float* dy, const void* W1, const float* b1, const void* W1T, const void* W2T, int T, int K, int H, int OUT,
+                       float* dx, void* h, void* dh, void* stream);
+
 /* ---- (ABI 3) the whole plan-recognition transformer trunk as ONE launch per direction (bf16 compute) -------------------------------- */
 /* PlanRecognitionTransformersNetwork.forward up to the sequence mean (plan_recognition_net.py:125-146): dropout(emb + pos[position_ids]) ->
  * L post-norm nn.TransformerEncoderLayer (d_model 128, 8 heads, ReLU feed-forward FF, dropout drop_p) -> mean over the S <= 32 positions.
