@@ -140,3 +140,22 @@ def test_first_write_overwrite_equals_zeroed_arena(dev, monkeypatch):
     zeroed = sum(b - a for a, b in planned[1])
     assert zeroed < 0.2 * finals[0].numel(), "most of the arena is written by sinks and no longer zeroed"
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("shapes", [[(2048, 128), (128, 2048), (2048, 2048)], [(64, 72), (100, 36), (33, 17), (8, 8), (520, 24)]])
+def test_transposed_shadow_tiles(dev, shapes):
+    """hulc_transpose_bf16_tiles (the per-step refresh of the transposed bf16 weight shadows): all three access widths (16-, 8-, 2-byte:
+    dimensions / offsets that are multiples of 8, of 4, or neither) against torch's transpose, bit for bit"""
+    from hulc2_amd import kernels as kn
+    offs, tiles, total = [], [], 0
+    for r, c in shapes:
+        offs.append(total)
+        tiles += [(total, r, c, i, j) for i in range((r + 63) // 64) for j in range((c + 63) // 64)]
+        total += r * c
+    src = torch.randn(total, device=dev).to(torch.bfloat16)
+    dst = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+    kn.transpose_bf16_tiles(src, dst, torch.tensor(tiles, dtype=torch.int64, device=dev))
+    torch.cuda.synchronize()
+    for (r, c), off in zip(shapes, offs):
+        want = src[off:off + r * c].view(r, c).t().contiguous().view(-1)
+        assert torch.equal(dst[off:off + r * c], want), (r, c)
