@@ -20,8 +20,16 @@ from hulc2_amd import param_spec, synthetic as syn  # noqa: E402
 from oracle import hulc2_oracle as O  # noqa: E402
 
 
+import os
+
+# HULC_EMU_HALF=fp16: every rounding of the study is to IEEE half (10-bit mantissa) instead of bf16 (7 bits) — with `rest:fo,fs,bo,bs` an
+# emulation of the reference's own `precision: 16` autocast (conf/trainer/play_trainer.yaml:3): conv / linear operands and results in half,
+# fp32 accumulation, everything else fp32 (loss scaling changes no rounding; overflow is not modelled)
+HALF = torch.float16 if os.environ.get("HULC_EMU_HALF") == "fp16" else torch.bfloat16
+
+
 def r16(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(HALF).to(torch.float32)
 
 
 def split(t):
