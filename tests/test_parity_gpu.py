@@ -401,6 +401,8 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
       bf16   (headline; the contrastive head's forward alone in exact fp32): median 13 %, worst 23 % — was 19 % / 40 % with a bf16 head
       mixed  (exact-fp32 forward upstream of the head, bf16 backward + recurrent decoder, 7.2 ms/step): every tensor <= 1.1 %
       fp32   (exact everywhere, 18.8 ms/step): every tensor <= 2e-3
+    Yardstick: the reference's own `precision: 16` autocast, emulated by the same tool (HULC_EMU_HALF=fp16), is median 6.7 % / worst 26 % from
+    this fp32 oracle on this batch.
     The flat allowance of round 2 (0.6) is gone: bf16 tensors fed by the contrastive gradient are held to 0.3 AND to 1.5 x their recorded value."""
     from hulc2_amd import kernels as kn, param_spec
     from oracle import hulc2_oracle as O
