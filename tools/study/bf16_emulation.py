@@ -25,11 +25,18 @@ import os
 # HULC_EMU_HALF=fp16: every rounding of the study is to IEEE half (10-bit mantissa) instead of bf16 (7 bits) — with `rest:fo,fs,bo,bs` an
 # emulation of the reference's own `precision: 16` autocast (conf/trainer/play_trainer.yaml:3): conv / linear operands and results in half,
 # fp32 accumulation, everything else fp32 (loss scaling changes no rounding; overflow is not modelled)
-HALF = torch.float16 if os.environ.get("HULC_EMU_HALF") == "fp16" else torch.bfloat16
+# HULC_EMU_HALF=fp16fwd: half in the forward direction only, bf16 in the backward products (no loss scaling needed: the small numbers live there)
+_MODE = os.environ.get("HULC_EMU_HALF", "")
+HALF = torch.float16 if _MODE in ("fp16", "fp16fwd") else torch.bfloat16
+HALF_BWD = torch.float16 if _MODE == "fp16" else torch.bfloat16
 
 
 def r16(t):
     return t.to(HALF).to(torch.float32)
+
+
+def r16b(t):
+    return t.to(HALF_BWD).to(torch.float32)
 
 
 def split(t):
@@ -98,12 +105,12 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         fl = ctx.fl
-        rd = (lambda t: r16(t)) if ("bo" in fl and "x3" not in fl and "x2" not in fl) else (lambda t: t)
+        rd = (lambda t: r16b(t)) if ("bo" in fl and "x3" not in fl and "x2" not in fl) else (lambda t: t)
         dyr, xr, wr = rd(dy), rd(x), rd(w)
         dx = torch.nn.grad.conv2d_input(x.shape, wr, dyr, stride=ctx.stride) if ctx.needs_input_grad[0] else None
         dw = torch.nn.grad.conv2d_weight(xr, w.shape, dyr, stride=ctx.stride)
         if dx is not None and "bs" in fl:
-            dx = r16(dx)
+            dx = r16b(dx)
         return dx, dw, dy.sum((0, 2, 3)), None, None
 
 
@@ -121,7 +128,7 @@ class LinFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         fl = ctx.fl
-        rd = (lambda t: r16(t)) if ("bo" in fl and "x3" not in fl and "x2" not in fl) else (lambda t: t)
+        rd = (lambda t: r16b(t)) if ("bo" in fl and "x3" not in fl and "x2" not in fl) else (lambda t: t)
         dyr, xr, wr = rd(dy), rd(x), rd(w)
         dx = dyr @ wr
         dw = dyr.reshape(-1, dy.shape[-1]).t() @ xr.reshape(-1, x.shape[-1])
