@@ -93,7 +93,9 @@ class MLPFn(torch.autograd.Function):
         x2, acts, params = saved[0], saved[1:L], saved[L:]
         g = _c(dy.reshape(-1, dy.shape[-1]))
         need_x = ctx.needs_input_grad[0]
-        dx, grads = _mlp_backward(x2, acts, params, relus, drops, g, need_x, ctx.chain)
+        # (the data-gradient chain does not depend on how the forward ran: an exact-fp32 forward — selective precision, mixed mode — leaves the
+        # same fp32 activations behind, and the backward products run in bf16 either way)
+        dx, grads = _mlp_backward(x2, acts, params, relus, drops, g, need_x, ctx.chain or not any(d > 0 for d in drops))
         return (dx.reshape(xshape) if need_x else None, None, None, None, *grads)
 
 
@@ -216,6 +218,12 @@ class FlattenLinearFn(torch.autograd.Function):
         N = a.shape[0]
         K = a[0].numel()
         O = W.shape[0]
+        ctx.a_dtype = a.dtype
+        if kn.get_compute() != "bf16" and a.dtype == torch.bfloat16:
+            # an exact-fp32 site behind a bf16 conv stack (HULC_FP32_SITES "encfc"): the fp32 GEMM takes fp32 operands
+            a32 = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+            kn.cast_bf16_to_f32(_c(a), a32, a.numel())
+            a = a32
         x2 = _c(a).reshape(N, K)
         out = _f32(N, O, like=x2)
         kn.gemm(x2, weight_operand(W, "hwc", chw=(a.shape[3], a.shape[1], a.shape[2])), out, N, O, K, K, K, O, bias=b, relu=True)
@@ -260,7 +268,7 @@ class FlattenLinearFn(torch.autograd.Function):
         da = None
         if ctx.needs_input_grad[0]:
             # in the activation's own storage type: autograd would otherwise cast the 2048 x 3136 gradient in a launch of its own
-            da = torch.empty(N, K, dtype=x2.dtype, device=g.device)
+            da = torch.empty(N, K, dtype=ctx.a_dtype, device=g.device)
             kn.gemm(g, weight_operand(W, "hwc_t", chw=(C, ctx.ashape[1], ctx.ashape[2])), da, N, K, O, O, O, K, mask=x2, ld_mask=K, mask_scale=1.0)   # x (a > 0): conv3's ReLU
             da = da.view(ctx.ashape)
         return da, dW, db

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from hulc2_amd import functional as HF
+from hulc2_amd import kernels as kn
 
 
 class SpatialSoftmax(nn.Module):
@@ -68,7 +69,8 @@ class VisionNetwork(nn.Module):
         """x: (N,3,H,W) fp32 in [-1,1] (or a list of such), or uint8 NHWC frames as stored with the shift augmentation parameters"""
         a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)      # (N, 21, 21, 64) NHWC
         feat = self.spatial_softmax(a3)                                     # (N, 128)
-        y = HF.mlp2_rows(feat, self.fc1[0].weight, self.fc1[0].bias, self.fc2.weight, self.fc2.bias)
+        with kn.site_scope("encfc"):         # (selective precision, DESIGN §5: the fc tail is one of the sites HULC_FP32_SITES can make exact)
+            y = HF.mlp2_rows(feat, self.fc1[0].weight, self.fc1[0].bias, self.fc2.weight, self.fc2.bias)
         if pre_ln:                # ConcatEncoders applies the LayerNorms of both cameras while writing the concatenated embedding
             return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from hulc2_amd import functional as HF
+from hulc2_amd import kernels as kn
 
 
 def nature_cnn(act_fn, num_c):
@@ -42,8 +43,9 @@ class VisionNetwork(nn.Module):
         a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
         # nn.Flatten + Linear(3136, 128) + ReLU on the NHWC activation in place: the weight's columns are reordered, not the activations
         c = self.conv_model
-        y = HF.flatten_linear_relu(a3, c[7].weight, c[7].bias)
-        y = HF.mlp2_rows(y, self.fc1[0].weight, self.fc1[0].bias, self.fc2.weight, self.fc2.bias)
+        with kn.site_scope("encfc"):         # (selective precision)
+            y = HF.flatten_linear_relu(a3, c[7].weight, c[7].bias)
+            y = HF.mlp2_rows(y, self.fc1[0].weight, self.fc1[0].bias, self.fc2.weight, self.fc2.bias)
         if pre_ln:
             return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)
