@@ -280,6 +280,25 @@ extern "C" int hulc_gather_chunks(const void* src0, const void* src1, void* dst,
     return hulc_check_launch("hulc_gather_chunks");
 }
 
+namespace {
+// lo[dst + i] = bf16(p[src + i] - float(hi[src + i])) for the segments of the table {src offset, count, dst offset}
+__global__ __launch_bounds__(256) void residual_bf16_kernel(const float* __restrict__ p32, const uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                           const long* __restrict__ seg) {
+    const long* q = seg + (long)blockIdx.y * 3;
+    const long src = q[0], n = q[1], dst = q[2];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        lo[dst + i] = f32_to_bf16_bits(p32[src + i] - bf16_bits_to_f32(hi[src + i]));
+}
+}  // namespace
+
+// see include/hulc2_amd.h
+extern "C" int hulc_residual_bf16(const float* p32, const void* hi, void* lo, const long* segments, int nseg, void* stream) {
+    if (!p32 || !hi || !lo || !segments) return hulc_fail(-1, "hulc_residual_bf16: null pointer");
+    if (nseg <= 0) return 0;
+    residual_bf16_kernel<<<dim3(64, (unsigned)nseg), 256, 0, (hipStream_t)stream>>>(p32, (const uint16_t*)hi, (uint16_t*)lo, segments);
+    return hulc_check_launch("hulc_residual_bf16");
+}
+
 extern "C" int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream) {
     if (!src || !dst || !table) return hulc_fail(-1, "hulc_repack_conv_weights: null pointer");
     if (n <= 0) return 0;

@@ -13,6 +13,7 @@ constexpr int SMAX = 32;
 struct TxlP {
     const float* x;
     const uint16_t *Wqkv, *Wo, *WqkvT, *WoT;
+    const uint16_t *Wqkv_lo, *Wo_lo;               // X3 forward: bf16 of the rounding remainders w - bf16(w)
     const float *bqkv, *bo, *gamma, *beta;
     float eps;
     int B, S;
@@ -37,6 +38,21 @@ HULC_DEVICE bf16x8_t pack8f(const float* a) {
     Frag f;
     f.u = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
     return f.b;
+}
+// hi = bf16(a), lo = bf16(a - hi): a_hi b_hi + a_lo b_hi + a_hi b_lo reproduces the fp32 product to ~2^-16 (three bf16 MFMAs)
+HULC_DEVICE void split2(float a0, float a1, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a0, a1);
+    lo = pack_bf16x2(a0 - __uint_as_float(hi << 16), a1 - __uint_as_float(hi & 0xffff0000u));
+}
+HULC_DEVICE void pack8f_hl(const float* a, bf16x8_t& hi, bf16x8_t& lo) {
+    Frag h, l;
+    split2(a[0], a[1], h.u.x, l.u.x); split2(a[2], a[3], h.u.y, l.u.y); split2(a[4], a[5], h.u.z, l.u.z); split2(a[6], a[7], h.u.w, l.u.w);
+    hi = h.b; lo = l.b;
+}
+template <int BASE>
+HULC_DEVICE void pack8_hl(const f32x16_t& a, bf16x8_t& hi, bf16x8_t& lo) {
+    const float v[8] = {a[BASE], a[BASE + 1], a[BASE + 2], a[BASE + 3], a[BASE + 4], a[BASE + 5], a[BASE + 6], a[BASE + 7]};
+    pack8f_hl(v, hi, lo);
 }
 HULC_DEVICE bf16x8_t ldg16(const uint16_t* p) { Frag f; f.u = *(const uint4*)p; return f.b; }
 // 8 k-slots = two groups of 4 consecutive columns 8 apart (the register order of an accumulator tile, see the header)
@@ -66,6 +82,18 @@ HULC_DEVICE void load_x_frags(bf16x8_t (&xf)[8], const float* x, long tok0, int 
     }
 }
 
+// the same row as hi / lo fragment pairs (X3)
+HULC_DEVICE void load_x_frags_hl(bf16x8_t (&xh)[8], bf16x8_t (&xl)[8], const float* x, long tok0, int r, int hf, int S) {
+    const float* xr = x + (tok0 + (r < S ? r : 0)) * E + hf * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const float4 a = *(const float4*)(xr + ks * 16), c = *(const float4*)(xr + ks * 16 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        pack8f_hl(v, xh[ks], xl[ks]);
+        if (r >= S) { Frag z; z.u = make_uint4(0u, 0u, 0u, 0u); xh[ks] = z.b; xl[ks] = z.b; }
+    }
+}
+
 // add a per-ROW vector (index 32w + arow(e, hf)) to an accumulator tile: four float4 loads
 HULC_DEVICE void add_row_vec(f32x16_t& a, const float* v, int hf, float scale) {
 #pragma unroll
@@ -79,18 +107,24 @@ HULC_DEVICE void add_row_vec(f32x16_t& a, const float* v, int hf, float scale) {
 // ---------------------------------------------------------------------------------------------------------------- forward
 // cs: 8 KB (ctx fragments [k-step 2w+q][lane half][token]), red: [2][4][32] floats.  Waves 0..3 of the workgroup; the caller separates it from
 // other users of the same LDS with a barrier.
+// X3: every product from hi / lo splits of both operands (three bf16 MFMAs; needs p.Wqkv_lo / p.Wo_lo and 8 KB more LDS for the lo halves of
+// the context fragments): fp32-class forward values on the bf16 matrix pipe — the selective-precision site "txl" 
 constexpr int TXL_FWD_LDS = 8 * 2 * 32 * 16 + 2 * 4 * 32 * 4;
+constexpr int TXL_FWD_LDS_X3 = TXL_FWD_LDS + 8 * 2 * 32 * 16;
+template <bool X3 = false>
 HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
     uint4* cs = (uint4*)lds;
     float (*red)[4][32] = (float (*)[4][32])(lds + 8 * 2 * 32 * 16);
+    uint4* csl = (uint4*)(lds + TXL_FWD_LDS);                 // (X3) lo halves of the ctx fragments
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int S = p.S;
     const long tok0 = (long)b * S;
     const unsigned long long sd = p.seed_dev ? p.seed_dev[0] : 0ull;
     const unsigned long long seed_attn = p.seed_attn ^ sd, seed_ln = p.seed_ln ^ sd;
 
-    bf16x8_t xf[8];
-    load_x_frags(xf, p.x, tok0, r, hf, S);
+    bf16x8_t xf[8], xl[X3 ? 8 : 1];
+    if constexpr (X3) load_x_frags_hl(xf, xl, p.x, tok0, r, hf, S);
+    else load_x_frags(xf, p.x, tok0, r, hf, S);
     // transposed q / k tiles D[col][token] (lane <-> token), plain v tile D[token][col] (lane <-> column)
     f32x16_t qT = zero16(), kT = zero16(), v = zero16();
     {
@@ -104,14 +138,27 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
             qT = MFMA(fq[ks], xf[ks], qT);
             kT = MFMA(fk[ks], xf[ks], kT);
             v = MFMA(xf[ks], fv[ks], v);
+            if constexpr (X3) { qT = MFMA(fq[ks], xl[ks], qT); kT = MFMA(fk[ks], xl[ks], kT); v = MFMA(xl[ks], fv[ks], v); }
+        }
+        if constexpr (X3) {                                 // the weights' remainders against the activations' hi parts (same registers, second trip)
+            const uint16_t* wl = p.Wqkv_lo + (long)(32 * w + r) * E + hf * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { fq[ks] = ldg16(wl + ks * 16); fk[ks] = ldg16(wl + (long)E * E + ks * 16); fv[ks] = ldg16(wl + 2L * E * E + ks * 16); }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { qT = MFMA(fq[ks], xf[ks], qT); kT = MFMA(fk[ks], xf[ks], kT); v = MFMA(xf[ks], fv[ks], v); }
         }
     }
     // operands of the later phases that do not depend on anything computed here: requested now, consumed behind the barriers
-    bf16x8_t wof[8];
+    bf16x8_t wof[8], wol[X3 ? 8 : 1];
     {
         const uint16_t* wo = p.Wo + (long)(32 * w + r) * E + 4 * hf;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) wof[kk] = ldg_split(wo + 32 * (kk >> 1) + 16 * (kk & 1));
+        if constexpr (X3) {
+            const uint16_t* wl = p.Wo_lo + (long)(32 * w + r) * E + 4 * hf;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) wol[kk] = ldg_split(wl + 32 * (kk >> 1) + 16 * (kk & 1));
+        }
     }
     float4 xres[4], bov[4], gmv[4], btv[4];
     {
@@ -129,12 +176,20 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] += bv;
     }
-    const bf16x8_t vf0 = pack8<0>(v), vf1 = pack8<8>(v);
+    bf16x8_t vf0, vf1, vl0, vl1;
+    if constexpr (X3) { pack8_hl<0>(v, vf0, vl0); pack8_hl<8>(v, vf1, vl1); }
+    else { vf0 = pack8<0>(v); vf1 = pack8<8>(v); }
     f32x16_t c;                                              // ctx^T: lane <-> query token, registers <-> this wave's 32 columns
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-        const bf16x8_t qf = hh ? pack8<8>(qT) : pack8<0>(qT), kf = hh ? pack8<8>(kT) : pack8<0>(kT);
+        bf16x8_t qf, kf, ql, kl;
+        if constexpr (X3) {
+            if (hh) { pack8_hl<8>(qT, qf, ql); pack8_hl<8>(kT, kf, kl); } else { pack8_hl<0>(qT, qf, ql); pack8_hl<0>(kT, kf, kl); }
+        } else {
+            qf = hh ? pack8<8>(qT) : pack8<0>(qT); kf = hh ? pack8<8>(kT) : pack8<0>(kT);
+        }
         f32x16_t s = MFMA(kf, qf, zero16());                // D[key j][query i]
+        if constexpr (X3) { s = MFMA(kl, qf, s); s = MFMA(kf, ql, s); }
         float m = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { if (arow(e, hf) >= S) s[e] = -INFINITY; m = fmaxf(m, s[e]); }
@@ -152,8 +207,16 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
             s[e] *= inv;
             if (p.drop_p > 0.f) s[e] *= pk[e];
         }
-        f32x16_t o = MFMA(vf0, pack8<0>(s), zero16());      // D[v column][query]: rows of the OTHER head of this wave are garbage
-        o = MFMA(vf1, pack8<8>(s), o);
+        f32x16_t o;
+        if constexpr (X3) {
+            bf16x8_t p0, p0l, p1, p1l;
+            pack8_hl<0>(s, p0, p0l); pack8_hl<8>(s, p1, p1l);
+            o = MFMA(vf0, p0, zero16()); o = MFMA(vl0, p0, o); o = MFMA(vf0, p0l, o);
+            o = MFMA(vf1, p1, o); o = MFMA(vl1, p1, o); o = MFMA(vf1, p1l, o);
+        } else {
+            o = MFMA(vf0, pack8<0>(s), zero16());           // D[v column][query]: rows of the OTHER head of this wave are garbage
+            o = MFMA(vf1, pack8<8>(s), o);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) c[8 * hh + e] = o[8 * hh + e];
     }
@@ -162,7 +225,11 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) *(uint2*)(dst + 8 * g) = make_uint2(pack_bf16x2(c[4 * g], c[4 * g + 1]), pack_bf16x2(c[4 * g + 2], c[4 * g + 3]));
     }
-    { Frag f; f.b = pack8<0>(c); cs[((2 * w) * 2 + hf) * 32 + r] = f.u; f.b = pack8<8>(c); cs[((2 * w + 1) * 2 + hf) * 32 + r] = f.u; }
+    if constexpr (X3) {
+        Frag fh, fl;
+        pack8_hl<0>(c, fh.b, fl.b); cs[((2 * w) * 2 + hf) * 32 + r] = fh.u; csl[((2 * w) * 2 + hf) * 32 + r] = fl.u;
+        pack8_hl<8>(c, fh.b, fl.b); cs[((2 * w + 1) * 2 + hf) * 32 + r] = fh.u; csl[((2 * w + 1) * 2 + hf) * 32 + r] = fl.u;
+    } else { Frag f; f.b = pack8<0>(c); cs[((2 * w) * 2 + hf) * 32 + r] = f.u; f.b = pack8<8>(c); cs[((2 * w + 1) * 2 + hf) * 32 + r] = f.u; }
     __syncthreads();
     // out_proj for output features 32w..32w+31: D[feature][token] = Wo (columns in fragment order) x ctx^T
     f32x16_t o = zero16();
@@ -170,6 +237,7 @@ HULC_DEVICE void txl_attn_fwd_body(const TxlP& p, const int b, char* lds) {
     for (int kk = 0; kk < 8; ++kk) {
         Frag f; f.u = cs[(kk * 2 + hf) * 32 + r];
         o = MFMA(wof[kk], f.b, o);
+        if constexpr (X3) { Frag g; g.u = csl[(kk * 2 + hf) * 32 + r]; o = MFMA(wof[kk], g.b, o); o = MFMA(wol[kk], f.b, o); }
     }
     // residual + dropout + LayerNorm over the 128 features of token r (spread over 4 waves x 2 lane halves x 16 registers)
     float pre[16];

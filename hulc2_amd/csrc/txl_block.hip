@@ -55,6 +55,7 @@ struct BlockK {
 HULC_DEVICE TxlP attn_params(const BlockP& d, const LayerP& l) {
     TxlP p = {};
     p.x = l.x; p.Wqkv = (const uint16_t*)l.Wqkv; p.Wo = (const uint16_t*)l.Wo; p.WqkvT = (const uint16_t*)l.WqkvT; p.WoT = (const uint16_t*)l.WoT;
+    p.Wqkv_lo = (const uint16_t*)l.Wqkv_lo; p.Wo_lo = (const uint16_t*)l.Wo_lo;
     p.bqkv = l.bqkv; p.bo = l.bo; p.gamma = l.g1; p.beta = l.be1; p.eps = d.eps; p.B = d.B; p.S = d.S;
     p.drop_p = d.drop_p; p.seed_attn = l.seed_attn; p.seed_ln = l.seed_ln1; p.seed_dev = d.seed_dev;
     p.y = l.y1; p.pre = l.pre1; p.mean = l.mean1; p.rstd = l.rstd1; p.ctx = (uint16_t*)l.ctx;
@@ -157,6 +158,8 @@ HULC_DEVICE void pos_add_seq(const BlockP& d, int b) {
 struct FfnFrags { bf16x8_t w1[8], w2[8]; };
 
 // y2 = LayerNorm2(y1 + dropout(W2 dropout(relu(W1 y1 + b1)) + b2))  for the 32 tokens of sequence b
+// X3: both products from hi / lo splits of both operands (three bf16 MFMAs each; packed weights and their remainders required)
+template <bool X3>
 HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int li, char* lds, bool stash) {
     const BlockP& d = k.d;
     float* part = (float*)lds;
@@ -169,8 +172,9 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
     const uint16_t* W1 = (const uint16_t*)l.W1;
     const uint16_t* W2 = (const uint16_t*)l.W2;
 
-    bf16x8_t xf[8];
-    load_x_frags(xf, l.y1, tok0, r, hf, S);
+    bf16x8_t xf[8], xl[X3 ? 8 : 1];
+    if constexpr (X3) load_x_frags_hl(xf, xl, l.y1, tok0, r, hf, S);
+    else load_x_frags(xf, l.y1, tok0, r, hf, S);
     f32x16_t acc[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) acc[ot] = zero16();
@@ -198,6 +202,14 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
         f32x16_t zT = zero16();                                   // [hidden j0 + arow][token r]
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) zT = MFMA(f.w1[ks], xf[ks], zT);
+        FfnFrags fl;                                                // (X3) the weights' remainders of this slice
+        if constexpr (X3) {
+            const long u = ((long)(j0 / 32) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) { fl.w1[q8] = ldg16((const uint16_t*)l.W1p_lo + u + q8 * 512); fl.w2[q8] = ldg16((const uint16_t*)l.W2p_lo + u + q8 * 512); }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { zT = MFMA(f.w1[ks], xl[ks], zT); zT = MFMA(fl.w1[ks], xf[ks], zT); }
+        }
         add_row_vec(zT, l.b1 + j0, hf, 1.f);
         float hv[16];
 #pragma unroll
@@ -207,11 +219,21 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[4 * g4 + i] = fmaxf(zT[4 * g4 + i], 0.f) * keep[i];
         }
-        const bf16x8_t h0 = pack8f(hv), h1 = pack8f(hv + 8);
+        if constexpr (X3) {
+            bf16x8_t h0, h0l, h1, h1l;
+            pack8f_hl(hv, h0, h0l); pack8f_hl(hv + 8, h1, h1l);
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            acc[ot] = MFMA(f.w2[ot * 2], h0, acc[ot]);
-            acc[ot] = MFMA(f.w2[ot * 2 + 1], h1, acc[ot]);
+            for (int ot = 0; ot < 4; ++ot) {
+                acc[ot] = MFMA(f.w2[ot * 2], h0, acc[ot]); acc[ot] = MFMA(f.w2[ot * 2], h0l, acc[ot]); acc[ot] = MFMA(fl.w2[ot * 2], h0, acc[ot]);
+                acc[ot] = MFMA(f.w2[ot * 2 + 1], h1, acc[ot]); acc[ot] = MFMA(f.w2[ot * 2 + 1], h1l, acc[ot]); acc[ot] = MFMA(fl.w2[ot * 2 + 1], h1, acc[ot]);
+            }
+        } else {
+            const bf16x8_t h0 = pack8f(hv), h1 = pack8f(hv + 8);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                acc[ot] = MFMA(f.w2[ot * 2], h0, acc[ot]);
+                acc[ot] = MFMA(f.w2[ot * 2 + 1], h1, acc[ot]);
+            }
         }
     };
     const int NS = (k.dbg & 2) ? 0 : FF / 128 / k.Q, s0 = q * NS, s1 = s0 + NS;     // this member's hidden slices
@@ -280,6 +302,7 @@ HULC_DEVICE void ffn_fwd_seq(const BlockK& k, const LayerP& l, int b, int q, int
     }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void txl_block_fwd_kernel(BlockK k) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const BlockP& d = k.d;
@@ -295,9 +318,9 @@ __global__ __launch_bounds__(256) void txl_block_fwd_kernel(BlockK k) {
         // address products out of this loop — 60+ registers live across both stages, spilled)
         int bb = b;
         asm volatile("" : "+s"(bb));
-        if (!(k.dbg & 1)) txl_attn_fwd_body(p, bb, lds);
+        if (!(k.dbg & 1)) txl_attn_fwd_body<X3>(p, bb, lds);
         __syncthreads();
-        ffn_fwd_seq(k, l, bb, q, li, lds, li + 1 == d.L);
+        ffn_fwd_seq<X3>(k, l, bb, q, li, lds, li + 1 == d.L);
         __syncthreads();
     }
     quad_finish(k, b);
@@ -561,7 +584,7 @@ BlockK block_kernel_params(const hulc_txl_block_desc* d, int Q) {
     return k;
 }
 
-static_assert(BLOCK_LDS >= TXL_BWD_LDS && BLOCK_LDS >= TXL_FWD_LDS, "the attention stages fit the block's LDS");
+static_assert(BLOCK_LDS >= TXL_BWD_LDS && BLOCK_LDS >= TXL_FWD_LDS_X3, "the attention stages fit the block's LDS");
 static_assert(8 * 2 * 32 * 16 + LT_BYTES <= PART_BYTES, "fragment exchange + LayerNorm transposes fit under the partial tiles");
 
 }  // namespace
@@ -574,10 +597,24 @@ extern "C" long hulc_txl_block_workspace(int B, int L) {
 extern "C" int hulc_txl_block_fwd(const hulc_txl_block_desc* d, void* stream) {
     if (int rc = block_check(d, false, "hulc_txl_block_fwd: needs d_model 128, 8 heads, 1 <= S <= 32, 1 <= L <= 4, FF a multiple of 128 and non-null operands")) return rc;
     static bool attr = false;
-    if (!attr) { if (int rc = block_lds((const void*)txl_block_fwd_kernel)) return rc; attr = true; }
+    if (!attr) {
+        if (int rc = block_lds((const void*)txl_block_fwd_kernel<false>)) return rc;
+        if (int rc = block_lds((const void*)txl_block_fwd_kernel<true>)) return rc;
+        attr = true;
+    }
+    int nlo = 0;
+    for (int i = 0; i < d->L; ++i) {
+        const hulc_txl_block_layer& l = d->layers[i];
+        const int have = (l.Wqkv_lo != nullptr) + (l.Wo_lo != nullptr) + (l.W1p_lo != nullptr) + (l.W2p_lo != nullptr);
+        if (have != 0 && (have != 4 || !l.W1p || !l.W2p))
+            return hulc_fail(-3, "hulc_txl_block_fwd: the split-operand forward needs all four remainder arrays and the packed W1p / W2p of a layer");
+        nlo += have == 4;
+    }
+    if (nlo != 0 && nlo != d->L) return hulc_fail(-3, "hulc_txl_block_fwd: remainder arrays on every layer or on none");
     const int Q = block_share(d);
     const unsigned grid = Q == 1 ? (unsigned)d->B : (unsigned)((d->B + 7) / 8 * 8 * Q);
-    txl_block_fwd_kernel<<<grid, 256, BLOCK_LDS, (hipStream_t)stream>>>(block_kernel_params(d, Q));
+    if (nlo) txl_block_fwd_kernel<true><<<grid, 256, BLOCK_LDS, (hipStream_t)stream>>>(block_kernel_params(d, Q));
+    else txl_block_fwd_kernel<false><<<grid, 256, BLOCK_LDS, (hipStream_t)stream>>>(block_kernel_params(d, Q));
     return hulc_check_launch("hulc_txl_block_fwd");
 }
 

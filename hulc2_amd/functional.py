@@ -911,6 +911,7 @@ class TxlBlockFn(torch.autograd.Function):
         dev = emb.device
         x = _f32(T, E, like=emb)
         recs, kept = [], []
+        x3 = "txl" in kn.fp32_sites()
         for li in range(L):
             w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
             sd = seed + 100 * (li + 1)
@@ -918,8 +919,12 @@ class TxlBlockFn(torch.autograd.Function):
             if keep:
                 t.update(pre1=_f32(T, E, like=emb), mean1=_f32(T, like=emb), rstd1=_f32(T, like=emb), pre2=_f32(T, E, like=emb),
                          mean2=_f32(T, like=emb), rstd2=_f32(T, like=emb), ctx=torch.empty(T, E, dtype=torch.bfloat16, device=dev))
+            lo = {}
+            if x3:                 # fp32-class forward: every product from hi / lo splits of both operands (the remainders of the bf16 shadows)
+                lo = dict(Wqkv_lo=weight_operand(w_in, "lo"), Wo_lo=weight_operand(w_out, "lo"), W1p_lo=weight_operand(w1, "ffn_p0_lo"),
+                          W2p_lo=weight_operand(w2, "ffn_p1_lo"))
             recs.append(dict(Wqkv=weight_operand(w_in), Wo=weight_operand(w_out), W1=weight_operand(w1), W2=weight_operand(w2),
-                             W1p=weight_operand(w1, "ffn_p0"), W2p=weight_operand(w2, "ffn_p1"), bqkv=b_in, bo=b_out,
+                             W1p=weight_operand(w1, "ffn_p0"), W2p=weight_operand(w2, "ffn_p1"), **lo, bqkv=b_in, bo=b_out,
                              b1=b1, b2=b2, g1=g1, be1=be1, g2=g2, be2=be2, seed_attn=sd + 11, seed_ln1=sd + 12, seed_ffn=sd + 13, seed_ln2=sd + 15,
                              x=x, **t))
             kept.append(t)
@@ -1013,7 +1018,7 @@ class TxlBlockFn(torch.autograd.Function):
 def txl_block_ok(emb, layer_params, S: int, nhead: int) -> bool:
     """the whole-trunk launch takes the configured posterior (d_model 128, 8 heads, S <= 32, <= 4 layers, bf16 compute in every site it spans)"""
     p0 = layer_params[0]
-    return (emb.is_cuda and kn.get_compute() == "bf16" and kn.base_mode() == "bf16" and not ({"txl", "pool"} & kn.fp32_sites())
+    return (emb.is_cuda and kn.get_compute() == "bf16" and kn.base_mode() == "bf16"
             and emb.shape[-1] == 128 and nhead == 8 and 1 <= S <= 32 and 1 <= len(layer_params) <= 4 and emb.dtype == torch.float32
             and p0["linear1.weight"].shape[0] % 128 == 0 and all(p["linear1.weight"].shape == p0["linear1.weight"].shape for p in layer_params)
             and not os.environ.get("HULC_NO_TXL_BLOCK") and not os.environ.get("HULC_NO_FUSED_TXL") and not os.environ.get("HULC_NO_FUSED_FFN"))

@@ -76,11 +76,13 @@ def fp32_sites() -> frozenset:
     recognition's 128 -> 4096 projection of the pooled feature, ProjVisLang, the CLIP loss;  `goal` = the goal encoders;  `encfc` = the fc
     tails of the camera encoders (flatten-linear, fc1, fc2);  `pool` = the sequence mean;  `txl` = the posterior's transformer layers;
     `enc` = the whole camera encoders;  `prior`;  `none`.
-    Default `head,goal,encfc` (measured at the benchmark's size against the fp32 oracle): every gradient within 13 % (median
-    8 %) — the level of the reference's own fp16 autocast (26 % / 6.7 %) — for +0.08 ms per step; `head` alone: 23 % / 13 % at no cost;
-    `head,pool,txl,goal,encfc`: 9.3 % / 4.8 % for +0.35 ms."""
+    `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
+    the fp32 matrix instruction.
+    Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.2 %,
+    median 4.8 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.14 ms per step (3.48 -> 3.62);
+    `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost."""
     import os
-    v = os.environ.get("HULC_FP32_SITES", "head,goal,encfc")
+    v = os.environ.get("HULC_FP32_SITES", "head,goal,encfc,txl")
     return frozenset(x for x in v.replace(" ", "").split(",") if x and x != "none")
 
 
@@ -982,6 +984,11 @@ def txl_block_fwd(d, B, S, H, E, FF, L):
 
 def txl_block_bwd(d, B, S, H, E, FF, L):
     _call("hulc_txl_block_bwd", _c.byref(d), key=("txl_block_bwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, True))
+
+
+def residual_bf16(p32, hi, lo, segments):
+    """lo = bf16(p32 - float(hi)) on the segments {src offset, count, dst offset} (int64 (n, 3) device tensor)"""
+    _call("hulc_residual_bf16", p32, hi, lo, segments, _i(segments.shape[0]))
 
 
 def gather_chunks(src0, src1, dst, idx):

@@ -133,7 +133,7 @@ class TxlAttnDesc(ctypes.Structure):
 class TxlBlockLayer(ctypes.Structure):
     """mirror of hulc_txl_block_layer (include/hulc2_amd.h)"""
     _fields_ = ([(n, ctypes.c_void_p) for n in ("Wqkv", "Wo", "W1", "W2", "WqkvT", "WoT", "W1T", "W2T", "W1p", "W2p", "W2Tp", "W1Tp",
-                                                "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2")]
+                                                "Wqkv_lo", "Wo_lo", "W1p_lo", "W2p_lo", "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2")]
                 + [(n, ctypes.c_ulonglong) for n in ("seed_attn", "seed_ln1", "seed_ffn", "seed_ln2")]
                 + [(n, ctypes.c_void_p) for n in ("x", "y1", "pre1", "mean1", "rstd1", "ctx", "y2", "pre2", "mean2", "rstd2",
                                                   "d_o", "dqkv", "df", "h", "dh", "lnp1", "lnp2")])

@@ -60,6 +60,14 @@ class PlanRecognitionTransformersNetwork(nn.Module):
             out += [(m.linear1.weight, 0), (m.linear2.weight, 1), (m.linear2.weight, 2), (m.linear1.weight, 3)]
         return out
 
+    def lo_operands(self):
+        """(weight, layout) of the rounding remainders w - bf16(w) the split-operand forward of the whole-trunk launch reads (selective
+        precision site "txl"): kept fresh by the trainer with one residual + one gather launch per step"""
+        out = []
+        for m in self.transformer_encoder.layers:
+            out += [(m.self_attn.in_proj_weight, "lo"), (m.self_attn.out_proj.weight, "lo"), (m.linear1.weight, "ffn_p0_lo"), (m.linear2.weight, "ffn_p1_lo")]
+        return out
+
     def _position_ids(self, S: int, device) -> torch.Tensor:
         """arange(S) (plan_recognition_net.py:133): kept per (length, device) instead of one launch per step"""
         cache = self.__dict__.setdefault("_pos_id_cache", {})

@@ -77,6 +77,9 @@ def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
         return w.permute(1, 2, 3, 0)
     if layout == "t":                  # transposed 2-D weight: lets dX = dY W stream W k-major
         return w.t()
+    if layout == "lo" or layout.endswith("_lo"):   # rounding remainder w - bf16(w) (the caller casts it to bf16): second half of a split operand
+        rem = w - w.to(torch.bfloat16).to(torch.float32)
+        return rem if layout == "lo" else _layout(rem, layout[:-3], chw)
     if layout.startswith("ffn_p"):     # fragment-packed feed-forward weights of the transformer block launch (hulc_ffn_frag_perm layouts 0..3)
         n = int(layout[-1])
         src = w if n in (0, 1) else w.t()                   # 2: W2^T [FF][128], 3: W1^T [128][FF]

@@ -383,6 +383,45 @@ class ArenaTrainer:
                 for p, name, d0, n_el in views:
                     shadow.register_layout_view(p, name, self.frag_shadow[d0:d0 + n_el])
                 kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
+        # rounding remainders w - bf16(w) of the weights a split-operand forward reads (modules list them in lo_operands(): natural layout
+        # "lo", packed "ffn_p0_lo" / "ffn_p1_lo"): one residual launch + one gather launch per step
+        self.lo_shadow = self.lo_seg = self.lo_frag = self.lo_frag_idx = None
+        if self.flat_bf16 is not None:
+            off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+            segs, nat, packed, dst = [], {}, [], 0
+            for m in model.modules():
+                if not hasattr(m, "lo_operands"):
+                    continue
+                for p, layout in m.lo_operands():
+                    off = off_of.get(id(p))
+                    if off is None or off % 4 or id(p) in member:
+                        continue
+                    if id(p) not in nat:
+                        nat[id(p)] = (p, dst)
+                        segs.append((off, p.numel(), dst))
+                        dst += (p.numel() + 3) // 4 * 4
+                    if layout != "lo":
+                        packed.append((p, layout))
+            if segs:
+                import numpy as np
+                self.lo_shadow = torch.zeros(dst, dtype=torch.bfloat16, device=dev)
+                self.lo_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
+                for p, d0 in nat.values():
+                    shadow.register_layout_view(p, "lo", self.lo_shadow[d0:d0 + p.numel()].view(p.shape))
+                chunks, views, fdst = [], [], 0
+                for p, layout in packed:
+                    n = int(layout[5])
+                    ff = p.shape[0] if n in (0, 3) else p.shape[1]
+                    perm = kn.ffn_frag_perm(n, ff).astype("int64").reshape(-1, 4)
+                    chunks.append((perm[:, 0] + nat[id(p)][1]) // 4)
+                    views.append((p, layout, fdst, p.numel()))
+                    fdst += p.numel()
+                if chunks:
+                    self.lo_frag = torch.zeros(fdst, dtype=torch.bfloat16, device=dev)
+                    self.lo_frag_idx = torch.from_numpy(np.concatenate(chunks).astype(np.uint32).view(np.int32)).to(dev)
+                    for p, name, d0, n_el in views:
+                        shadow.register_layout_view(p, name, self.lo_frag[d0:d0 + n_el])
+                self._refresh_lo()
         # conv weights in their kernel layouts (OIHW flat for conv1, OHWI forward, IHWO data gradient): one repack launch per step
         self.conv_shadow = self.conv_table = None
         if self.flat_bf16 is not None:
@@ -445,6 +484,12 @@ class ArenaTrainer:
             model.perceptual_encoder.register_forward_hook(self._keep_encoder_output)
         self._emb = None
 
+    def _refresh_lo(self) -> None:
+        if self.lo_seg is not None:
+            kn.residual_bf16(self.flat_p, self.flat_bf16, self.lo_shadow, self.lo_seg)
+            if self.lo_frag_idx is not None:
+                kn.gather_chunks(self.lo_shadow, None, self.lo_frag, self.lo_frag_idx)
+
     # ---- weights written from outside (checkpoint restore) and optimizer state ----------------------------------------------------
     def refresh_shadows(self) -> None:
         """Re-derive every kernel-side copy of the parameters from the fp32 arena: the bf16 shadow, its transposed tiles and the conv
@@ -457,6 +502,7 @@ class ArenaTrainer:
                 kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
             if self.frag_idx is not None:
                 kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
+            self._refresh_lo()
             if self.conv_table is not None:
                 kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         shadow.bump_epoch()
@@ -671,6 +717,7 @@ class ArenaTrainer:
             kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
         if self.frag_idx is not None:
             kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
+        self._refresh_lo()
         if self.conv_table is not None:
             kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
         shadow.bump_epoch()

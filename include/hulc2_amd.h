@@ -348,6 +348,10 @@ typedef struct hulc_txl_block_layer {
     const void *WqkvT, *WoT, *W1T, *W2T;             /* backward: their transposes */
     const void *W1p, *W2p, *W2Tp, *W1Tp;             /* optional fragment-packed copies (hulc_ffn_frag_perm layouts 0, 1, 2, 3): every weight fragment
                                                         of the feed-forward loops is then one coalesced 16-byte load per lane; null = gather from the matrices */
+    const void *Wqkv_lo, *Wo_lo, *W1p_lo, *W2p_lo;   /* optional (all four or none, on every layer or none): bf16 of the rounding remainders w - bf16(w) of Wqkv, Wo
+                                                        (same layouts) and of W1, W2 in the packed layouts of W1p / W2p.  The FORWARD launch then forms every product
+                                                        from hi / lo splits of both operands (a_hi b_hi + a_lo b_hi + a_hi b_lo, three bf16 MFMAs): forward values of
+                                                        fp32 class (~2^-16) on the bf16 matrix pipe — the selective-precision site "txl" */
     const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
     unsigned long long seed_attn, seed_ln1, seed_ffn, seed_ln2;
     float* x;                                        /* (T, E) layer input; layer 0: written by the forward launch = dropout(emb + pos) */
@@ -578,6 +582,9 @@ int hulc_ffn_frag_perm(int layout, int FF, int* out);
 /* dst chunk c (8 bytes = 4 bf16) = chunk (idx[c] & 0x7fffffff) of src1 when bit 31 of idx[c] is set, else of src0: every packed weight copy
  * of a step from the bf16 arena (src0) and its transposed shadow (src1) in one launch. */
 int hulc_gather_chunks(const void* src0, const void* src1, void* dst, const unsigned* idx, long nchunks, void* stream);
+/* (ABI 3) lo[dst + i] = bf16(p32[src + i] - float(hi[src + i])) for nseg segments {src offset, count, dst offset} (device table of longs): the
+ * rounding remainders of the bf16 weight shadows, the second halves of the split operands of hulc_txl_block_fwd's fp32-class forward. */
+int hulc_residual_bf16(const float* p32, const void* hi, void* lo, const long* segments, int nseg, void* stream);
 /* All conv-weight repacks of a step in one launch: table[q] = {src offset (fp32 arena elements), dst offset (bf16 elements), Cout, Cin,
  * KH, KW, mode}; mode 0 = OIHW flat (conv1 forward), 1 = OHWI (NHWC forward, k = (kh,kw,c)), 2 = IHWO (data gradient,
  * rows = input channel, k = (kh,kw,cout)).  Replaces a permute copy + cast per layer and layout. */

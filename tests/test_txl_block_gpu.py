@@ -21,6 +21,13 @@ from hulc2_amd import functional as HF, kernels as kn  # noqa: E402
 KEYS = HF._TXL_KEYS
 
 
+@pytest.fixture(autouse=True)
+def _plain_bf16_forward(monkeypatch):
+    """the comparisons below are between launches of the SAME arithmetic (bf16 operands): the default selective-precision sites include
+    "txl" (split-operand forward of the block launch); the test of that forward selects it itself"""
+    monkeypatch.setenv("HULC_FP32_SITES", "head")
+
+
 def _trunk(seed, L, p_drop, ff=2048):
     torch.manual_seed(seed)
     layer = torch.nn.TransformerEncoderLayer(128, 8, dim_feedforward=ff, dropout=p_drop)
@@ -175,4 +182,32 @@ def test_one_workspace_serves_launches_of_any_batch_size(dev):
         assert torch.equal(y, y0) and torch.equal(dx, dx0), (it, B, S)
         for k in got:
             assert torch.equal(got[k], got0[k]), (it, B, S, k)
+    kn.check_faults(dev)
+
+
+@pytest.mark.parametrize("B,S", [(64, 32), (3, 17)])
+def test_split_operand_forward_is_fp32_class(dev, B, S, monkeypatch):
+    """selective-precision site "txl": the forward launch forms every product from hi / lo splits of both operands (three bf16 MFMAs).  Its
+    pooled output agrees with fp32 torch to 1e-4 (plain bf16: 1.7e-3); the backward stays on the bf16 products (it recomputes the
+    projections and the hidden tile in bf16: a backward-direction rounding), so the gradients keep their bf16 tolerances."""
+    kn.set_compute("bf16")
+    enc, pos = _trunk(1, 2, 0.0)
+    g = torch.Generator().manual_seed(2)
+    emb, r = torch.randn(B, S, 128, generator=g), torch.randn(B, 128, generator=g)
+    xr = emb.clone().requires_grad_(True)
+    h = xr + pos(torch.arange(S)).unsqueeze(0)
+    yr = enc(h.transpose(0, 1)).transpose(0, 1).mean(dim=1)
+    (yr * r).sum().backward()
+    want = {f"{li}.{k}": p[k].grad.clone() for li, p in enumerate(_layer_params(enc)) for k in KEYS}
+    enc_d, pos_d = _trunk(1, 2, 0.0)
+    enc_d, pos_d = enc_d.to(dev), pos_d.to(dev)
+    y0, dx0, got0 = _run(enc_d, pos_d, emb.to(dev), r.to(dev), 0.0, 77, block=True)
+    monkeypatch.setenv("HULC_FP32_SITES", "head,txl")
+    y, dx, got = _run(enc_d, pos_d, emb.to(dev), r.to(dev), 0.0, 77, block=True)
+    e0, e = _rel(y0, yr.detach()), _rel(y, yr.detach())
+    print(f"pooled vs fp32: bf16 {e0:.2e}, split operands {e:.2e}")
+    assert e < 1e-4 and e < 0.1 * e0, (e, e0)
+    assert _rel(dx, xr.grad) < max(4e-2, 1.5 * _rel(dx0, xr.grad))
+    for k in want:
+        assert _rel(got[k], want[k]) < max(4e-2, 2.0 * _rel(got0[k], want[k])), k
     kn.check_faults(dev)
