@@ -561,6 +561,7 @@ def main():
                    "gradient_allreduce": (f"{trainer.comm.algo} / {trainer.comm.payload} payload, backend {backend}"
                                           + (" (single rank, forced: exercises the collective path)" if world == 1 else ""))
                                          if dist.is_initialized() else "none (one rank, no process group)",
+                   "exact_forward_sites": (",".join(sorted(kn.fp32_sites())) or "none") if args.compute == "bf16" and not args.affordance else None,
                    "final_loss": round(final_loss, 4)},
         # step_frac = the WHOLE step against the dense MFMA roof (the roof that bounds this path), on the algorithmic
         # 14.13 GFLOP / sequence; frac / achieved below describe the single dominant kernel only

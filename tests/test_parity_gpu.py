@@ -398,7 +398,9 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
     of a FORWARD activation upstream of the head is amplified ~100x before it flows (weight 3.0) back into the posterior and the camera
     encoders; roundings in the backward products cost < 1 % (tools/study/bf16_emulation.py reproduces the GPU's numbers on the CPU and
     attributes them site by site).  Three modes, three levels:
-      bf16   (headline; the contrastive head's forward alone in exact fp32): median 13 %, worst 23 % — was 19 % / 40 % with a bf16 head
+      bf16   (headline; exact forward of the contrastive head, the goal encoders, the camera encoders' fc tails and — as split bf16
+             operands — the transformer trunk, kernels.fp32_sites()): median 4.7 %, worst 9.2 % — 13 % / 23 % with the head alone exact,
+             19 % / 40 % with a bf16 head
       mixed  (exact-fp32 forward upstream of the head, bf16 backward + recurrent decoder, 7.2 ms/step): every tensor <= 1.1 %
       fp32   (exact everywhere, 18.8 ms/step): every tensor <= 2e-3
     Yardstick: the reference's own `precision: 16` autocast, emulated by the same tool (HULC_EMU_HALF=fp16), is median 6.7 % / worst 26 % from
