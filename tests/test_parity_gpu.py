@@ -405,7 +405,7 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
       fp32   (exact everywhere, 18.8 ms/step): every tensor <= 2e-3
     Yardstick: the reference's own `precision: 16` autocast, emulated by the same tool (HULC_EMU_HALF=fp16), is median 6.7 % / worst 26 % from
     this fp32 oracle on this batch.
-    The flat allowance of round 2 (0.6) is gone: bf16 tensors fed by the contrastive gradient are held to 0.3 AND to 1.5 x their recorded value."""
+    The flat allowance of round 2 (0.6) is gone: bf16 tensors fed by the contrastive gradient are held to 0.15 AND to 1.5 x their recorded value."""
     from hulc2_amd import kernels as kn, param_spec
     from oracle import hulc2_oracle as O
 
@@ -457,7 +457,7 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode):
             continue
         lim = t["grad"] * 2
         if cmode == "bf16" and clip and not n.startswith(downstream):
-            lim = 0.3                                              # cancellation-amplified forward rounding (docstring); pinned by the error budget
+            lim = 0.15                                             # cancellation-amplified forward rounding of the conv stacks (docstring: worst 9.2 %); pinned by the error budget
         if cmode == "bf16" and not clip and n.startswith("perceptual_encoder.") and (".ln." in n or ".fc2." in n):
             lim = 0.5       # sums of the embedding gradient over 2048 frames that cancel to a few % of their terms
         if n == "logit_scale":
