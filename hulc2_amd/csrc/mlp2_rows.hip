@@ -21,6 +21,7 @@ namespace {
 struct Mlp2P {
     const float* x;                 // (T, 128)
     const uint16_t *W1, *W2;        // bf16 [H][128], [OUT][H]
+    const uint16_t *W1lo, *W2lo;    // X3 forward: bf16 of the rounding remainders w - bf16(w), same layouts
     const uint16_t *W1T, *W2T;      // backward: [128][H], [H][OUT]
     const float *b1, *b2;
     int T, H, OUT;
@@ -70,20 +71,22 @@ HULC_DEVICE void exchange4(const f32x16_t (&acc)[4], float* part, int w, int lan
     }
 }
 
-template <int OT>                   // OT = OUT / 32 output row tiles
+// X3: both products from hi / lo splits of both operands (three bf16 MFMAs each: fp32-class values, the selective-precision site "encfc")
+template <int OT, bool X3>          // OT = OUT / 32 output row tiles
 __global__ __launch_bounds__(256) void mlp2_fwd_kernel(Mlp2P p) {
     __shared__ float part[4 * OT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hf = lane >> 5;
     const long tok0 = (long)blockIdx.x * 32;
     const int S = p.T - tok0 < 32 ? (int)(p.T - tok0) : 32;
-    bf16x8_t xf[8];
-    load_x_frags(xf, p.x, tok0, r, hf, S);
+    bf16x8_t xf[8], xl[X3 ? 8 : 1];
+    if constexpr (X3) load_x_frags_hl(xf, xl, p.x, tok0, r, hf, S);
+    else load_x_frags(xf, p.x, tok0, r, hf, S);
     f32x16_t acc[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) acc[ot] = zero16();
     for (int s = 0; s < p.H / 128; ++s) {
         const int j0 = s * 128 + 32 * w;
-        bf16x8_t w1f[8], w2f[OT * 2];
+        bf16x8_t w1f[8], w2f[OT * 2], w1l[X3 ? 8 : 1], w2l[X3 ? OT * 2 : 1];
         const uint16_t* a = p.W1 + (long)(j0 + r) * E + hf * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) w1f[ks] = ldg16(a + ks * 16);
@@ -91,18 +94,40 @@ __global__ __launch_bounds__(256) void mlp2_fwd_kernel(Mlp2P p) {
         for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) w2f[ot * 2 + kk] = ldg_split(p.W2 + (long)(ot * 32 + r) * p.H + j0 + 16 * kk + 4 * hf);
+        if constexpr (X3) {
+            const uint16_t* al = p.W1lo + (long)(j0 + r) * E + hf * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) w1l[ks] = ldg16(al + ks * 16);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) w2l[ot * 2 + kk] = ldg_split(p.W2lo + (long)(ot * 32 + r) * p.H + j0 + 16 * kk + 4 * hf);
+        }
         f32x16_t zT = zero16();                                     // [hidden j0 + arow][row r]
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) zT = MFMA(w1f[ks], xf[ks], zT);
+        for (int ks = 0; ks < 8; ++ks) {
+            zT = MFMA(w1f[ks], xf[ks], zT);
+            if constexpr (X3) { zT = MFMA(w1f[ks], xl[ks], zT); zT = MFMA(w1l[ks], xf[ks], zT); }
+        }
         add_row_vec(zT, p.b1 + j0, hf, 1.f);
         float hv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) hv[e] = fmaxf(zT[e], 0.f);
-        const bf16x8_t h0 = pack8f(hv), h1 = pack8f(hv + 8);
+        if constexpr (X3) {
+            bf16x8_t h0, h0l, h1, h1l;
+            pack8f_hl(hv, h0, h0l); pack8f_hl(hv + 8, h1, h1l);
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-            acc[ot] = MFMA(w2f[ot * 2], h0, acc[ot]);
-            acc[ot] = MFMA(w2f[ot * 2 + 1], h1, acc[ot]);
+            for (int ot = 0; ot < OT; ++ot) {
+                acc[ot] = MFMA(w2f[ot * 2], h0, acc[ot]); acc[ot] = MFMA(w2f[ot * 2], h0l, acc[ot]); acc[ot] = MFMA(w2l[ot * 2], h0, acc[ot]);
+                acc[ot] = MFMA(w2f[ot * 2 + 1], h1, acc[ot]); acc[ot] = MFMA(w2f[ot * 2 + 1], h1l, acc[ot]); acc[ot] = MFMA(w2l[ot * 2 + 1], h1, acc[ot]);
+            }
+        } else {
+            const bf16x8_t h0 = pack8f(hv), h1 = pack8f(hv + 8);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                acc[ot] = MFMA(w2f[ot * 2], h0, acc[ot]);
+                acc[ot] = MFMA(w2f[ot * 2 + 1], h1, acc[ot]);
+            }
         }
     }
     f32x16_t o;
@@ -221,19 +246,30 @@ int mlp2_check(const float* x, const void* W1, const void* W2, const float* b1, 
 }  // namespace
 
 // see include/hulc2_amd.h
-extern "C" int hulc_mlp2_rows_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int K, int H, int OUT,
-                                  float* y, void* stream) {
+extern "C" int hulc_mlp2_rows_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, const void* W1_lo, const void* W2_lo,
+                                  int T, int K, int H, int OUT, float* y, void* stream) {
     if (int rc = mlp2_check(x, W1, W2, b1, T, K, H, OUT, "hulc_mlp2_rows_fwd: needs K = 128, H a multiple of 128, OUT in {32, 64, 96, 128}, 16-byte aligned operands")) return rc;
     if (!b2 || !y || (uintptr_t)b2 % 16 || (uintptr_t)y % 16) return hulc_fail(-1, "hulc_mlp2_rows_fwd: null or misaligned pointer");
+    if ((W1_lo != nullptr) != (W2_lo != nullptr)) return hulc_fail(-3, "hulc_mlp2_rows_fwd: both remainder arrays or none");
     Mlp2P p = {};
     p.x = x; p.W1 = (const uint16_t*)W1; p.W2 = (const uint16_t*)W2; p.b1 = b1; p.b2 = b2; p.T = T; p.H = H; p.OUT = OUT; p.y = y;
+    p.W1lo = (const uint16_t*)W1_lo; p.W2lo = (const uint16_t*)W2_lo;
     const unsigned grid = (unsigned)((T + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
-    switch (OUT / 32) {
-        case 1: mlp2_fwd_kernel<1><<<grid, 256, 0, s>>>(p); break;
-        case 2: mlp2_fwd_kernel<2><<<grid, 256, 0, s>>>(p); break;
-        case 3: mlp2_fwd_kernel<3><<<grid, 256, 0, s>>>(p); break;
-        default: mlp2_fwd_kernel<4><<<grid, 256, 0, s>>>(p); break;
+    if (W1_lo) {
+        switch (OUT / 32) {
+            case 1: mlp2_fwd_kernel<1, true><<<grid, 256, 0, s>>>(p); break;
+            case 2: mlp2_fwd_kernel<2, true><<<grid, 256, 0, s>>>(p); break;
+            case 3: mlp2_fwd_kernel<3, true><<<grid, 256, 0, s>>>(p); break;
+            default: mlp2_fwd_kernel<4, true><<<grid, 256, 0, s>>>(p); break;
+        }
+    } else {
+        switch (OUT / 32) {
+            case 1: mlp2_fwd_kernel<1, false><<<grid, 256, 0, s>>>(p); break;
+            case 2: mlp2_fwd_kernel<2, false><<<grid, 256, 0, s>>>(p); break;
+            case 3: mlp2_fwd_kernel<3, false><<<grid, 256, 0, s>>>(p); break;
+            default: mlp2_fwd_kernel<4, false><<<grid, 256, 0, s>>>(p); break;
+        }
     }
     return hulc_check_launch("hulc_mlp2_rows_fwd");
 }

@@ -293,9 +293,11 @@ class Mlp2RowsFn(torch.autograd.Function):
     two weight-gradient products for the pass's grouped launch."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2):
+    def forward(ctx, x, W1, b1, W2, b2, x3: bool = False):
         y = _f32(x.shape[0], W2.shape[0], like=x)
-        kn.mlp2_rows_fwd(x, weight_operand(W1), b1, weight_operand(W2), b2, y)
+        with kn.compute_scope("bf16", fwd_only=True):       # (x3: called inside an exact-forward scope — the operands are the bf16 shadows + remainders)
+            lo = (weight_operand(W1, "lo"), weight_operand(W2, "lo")) if x3 else (None, None)
+            kn.mlp2_rows_fwd(x, weight_operand(W1), b1, weight_operand(W2), b2, y, *lo)
         ctx.save_for_backward(x, W1, b1, W2, b2)
         return y
 
@@ -315,13 +317,14 @@ class Mlp2RowsFn(torch.autograd.Function):
             (dW, a1, rW), (db, a2, rb) = _sink_or_new(W, (M, N), dy), _sink_or_new(b, (M,), dy)
             kn.wgrad(left, right, dW, M, N, T, M, N, N, accumulate=a1, rowsum=db, rowsum_accumulate=a2, defer=rW is None and rb is None)
             ret += [rW, rb]
-        return (dx, *ret)
+        return (dx, *ret, None)
 
 
 def mlp2_rows(x, fc1_w, fc1_b, fc2_w, fc2_b):
-    """fc2(relu(fc1(x))) for x (rows, 128): one launch per direction where hulc_mlp2_rows_* take the shape, else the GEMM chain"""
+    """fc2(relu(fc1(x))) for x (rows, 128): one launch per direction where hulc_mlp2_rows_* take the shape, else the GEMM chain.  Inside an
+    exact-forward scope of a bf16 step (site "encfc") the launch forms its products from split operands instead of leaving for fp32 GEMMs."""
     if kn.mlp2_rows_ok(x, fc1_w, fc2_w):
-        return Mlp2RowsFn.apply(x, fc1_w, fc1_b, fc2_w, fc2_b)
+        return Mlp2RowsFn.apply(x, fc1_w, fc1_b, fc2_w, fc2_b, kn.exact_site_in_bf16_step())
     return mlp(x, [(fc1_w, fc1_b, True), (fc2_w, fc2_b, False)])
 
 

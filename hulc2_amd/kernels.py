@@ -905,20 +905,25 @@ def txl_attn_bwd(x, Wqkv, WqkvT, WoT, bqkv, gamma, eps, B, S, H, drop_p, seed_at
     _call("hulc_txl_attn_bwd", _c.byref(d), key=("txl_attn_bwd", B, S), flops=fl, nbytes=_nbytes(x, Wqkv, WqkvT, WoT, dy, dx, d_o, dqkv, pre))
 
 
+def exact_site_in_bf16_step() -> bool:
+    """inside a forward-only exact scope of a bf16 step (site_scope of a selected site): kernels with a split-operand forward take it"""
+    return _base_mode == "bf16" and _compute_mode != BF16 and _bwd_mode == "bf16"
+
+
 def mlp2_rows_ok(x, W1, W2) -> bool:
     """shapes hulc_mlp2_rows_* take (include/hulc2_amd.h): the camera encoders' fc1 -> ReLU -> fc2 head"""
     import os
     H, K = W1.shape
     OUT = W2.shape[0]
-    return (_compute_mode == BF16 and not os.environ.get("HULC_NO_MLP2_ROWS") and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+    return ((_compute_mode == BF16 or exact_site_in_bf16_step()) and not os.environ.get("HULC_NO_MLP2_ROWS") and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and x.is_contiguous() and K == 128 and x.shape[1] == 128 and H % 128 == 0 and OUT % 32 == 0 and 32 <= OUT <= 128 and W2.shape[1] == H
             and x.data_ptr() % 16 == 0)
 
 
-def mlp2_rows_fwd(x, W1, b1, W2, b2, y):
+def mlp2_rows_fwd(x, W1, b1, W2, b2, y, W1_lo=None, W2_lo=None):
     T, H, OUT = x.shape[0], W1.shape[0], W2.shape[0]
-    _call("hulc_mlp2_rows_fwd", x, W1, b1, W2, b2, _i(T), _i(128), _i(H), _i(OUT), y, key=("mlp2_rows_fwd", T, H, OUT),
-          flops=2.0 * T * H * (128 + OUT), nbytes=_nbytes(x, W1, W2, y))
+    _call("hulc_mlp2_rows_fwd", x, W1, b1, W2, b2, W1_lo, W2_lo, _i(T), _i(128), _i(H), _i(OUT), y, key=("mlp2_rows_fwd", T, H, OUT, W1_lo is not None),
+          flops=2.0 * T * H * (128 + OUT) * (3 if W1_lo is not None else 1), nbytes=_nbytes(x, W1, W2, y))
 
 
 def mlp2_rows_bwd(x, dy, W1, b1, W1T, W2T, dx, h, dh):

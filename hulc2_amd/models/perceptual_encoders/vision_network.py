@@ -61,6 +61,10 @@ class VisionNetwork(nn.Module):
         self.fc2 = nn.Linear(512, visual_features)
         self.ln = nn.LayerNorm(visual_features)
 
+    def lo_operands(self):
+        """rounding remainders the split-operand forward of the fc1 -> fc2 head reads (precision site "encfc"; trainer-maintained)"""
+        return [(self.fc1[0].weight, "lo"), (self.fc2.weight, "lo")]
+
     def conv_params(self):
         c = self.conv_model
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)

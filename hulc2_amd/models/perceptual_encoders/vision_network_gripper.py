@@ -35,6 +35,10 @@ class VisionNetwork(nn.Module):
         """(weight, (C, H, W)) of Linear layers behind nn.Flatten: the trainer keeps their (h, w, c)-ordered bf16 shadows fresh"""
         return [(self.conv_model[7].weight, (64, 7, 7))]
 
+    def lo_operands(self):
+        """rounding remainders the split-operand forward of the fc1 -> fc2 head reads (precision site "encfc"; trainer-maintained)"""
+        return [(self.fc1[0].weight, "lo"), (self.fc2.weight, "lo")]
+
     def conv_params(self):
         c = self.conv_model
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)

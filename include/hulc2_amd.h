@@ -328,8 +328,10 @@ int hulc_txl_attn_bwd(const hulc_txl_attn_desc* d, void* stream);
  * fp32; the hidden activation stays in registers.  Backward (W1T [128][H], W2T [H][OUT] = the transposes) recomputes it, writes
  * dx (T, 128) fp32 (null: not wanted) and the bf16 operands h, dh (T, H) of dW1 = dh^T x, dW2 = dy^T h (row sums of dh / dy = the bias
  * gradients; hulc_wgrad_group). */
-int hulc_mlp2_rows_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, int T, int K, int H, int OUT, float* y,
-                       void* stream);
+/* W1_lo / W2_lo (both or none): bf16 of the rounding remainders w - bf16(w), same layouts — the forward then forms both products from hi / lo
+ * splits of both operands (three bf16 MFMAs: fp32-class values; the selective-precision site "encfc"). */
+int hulc_mlp2_rows_fwd(const float* x, const void* W1, const float* b1, const void* W2, const float* b2, const void* W1_lo, const void* W2_lo,
+                       int T, int K, int H, int OUT, float* y, void* stream);
 int hulc_mlp2_rows_bwd(const float* x, const float* dy, const void* W1, const float* b1, const void* W1T, const void* W2T, int T, int K, int H, int OUT,
                        float* dx, void* h, void* dh, void* stream);
 

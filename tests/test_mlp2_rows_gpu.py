@@ -72,3 +72,24 @@ def test_head_without_input_gradient_and_determinism(dev):
     assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and torch.equal(y0, y1)
     for a, b, c in zip(g0, g1, g2):
         assert torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_split_operand_forward_inside_an_exact_site(dev, monkeypatch):
+    """inside kernels.site_scope("encfc") of a bf16 step the head launch forms its products from hi / lo splits of both operands: output
+    within 1e-5 of fp32 torch (plain bf16: ~3e-3), gradients at their bf16 level (the backward recomputes the hidden tile in bf16)"""
+    kn.set_compute("bf16")
+    monkeypatch.setenv("HULC_FP32_SITES", "head,encfc")
+    torch.manual_seed(5)
+    fc1, fc2 = torch.nn.Linear(128, 512), torch.nn.Linear(512, 64)
+    x, r = torch.randn(777, 128), torch.randn(777, 64)
+    xr = x.clone().requires_grad_(True)
+    yr = fc2(torch.relu(fc1(xr)))
+    (yr * r).sum().backward()
+    fc1, fc2 = fc1.to(dev), fc2.to(dev)
+    y0, dx0, g0 = _run(fc1, fc2, x.to(dev), r.to(dev))
+    with kn.site_scope("encfc"):
+        y, dx, g = _run(fc1, fc2, x.to(dev), r.to(dev))
+    assert type(y.grad_fn).__name__.startswith("Mlp2RowsFn")
+    e0, e = _rel(y0, yr.detach()), _rel(y, yr.detach())
+    assert e < 1e-5 and e < 0.01 * e0, (e, e0)
+    assert _rel(dx, xr.grad) < max(1.5e-2, 1.3 * _rel(dx0, xr.grad))
