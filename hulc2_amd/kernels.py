@@ -78,8 +78,8 @@ def fp32_sites() -> frozenset:
     `enc` = the whole camera encoders;  `prior`;  `none`.
     `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
     the fp32 matrix instruction.
-    Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.2 %,
-    median 4.8 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.14 ms per step (3.48 -> 3.62);
+    Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.4 %,
+    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.14 ms per step (3.48 -> 3.62);
     `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost."""
     import os
     v = os.environ.get("HULC_FP32_SITES", "head,goal,encfc,txl")
