@@ -18,6 +18,7 @@ namespace {
 
 struct C1P {
     const void* X; const void* Wt; const float* bias; void* Y;
+    const void* Wlo;                             // X3: bf16 remainders of the weights (same layout)
     int w_dtype, y_dtype, relu;
     int Nimg, H, W, OH, OW, R;
     unsigned* bits;                              // optional ReLU sign plane: one dword per output pixel (bit c = channel c > 0)
@@ -27,8 +28,10 @@ struct C1P {
 };
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
-template <int XCH, bool U8>
-__global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
+// X3 (fp32 frames only): the band is staged as hi + lo bf16 planes, the weights as hi + remainder, every product from the splits of both
+// operands (a_hi b_hi + a_lo b_hi + a_hi b_lo): fp32-class outputs; the layer is HBM-bound, the two extra MFMAs per k-step are not what it waits for
+template <int XCH, bool U8, bool X3 = false>
+__global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {     // (X3: twice the LDS per workgroup, two per CU: 256 registers)
     constexpr int NT = 512, C = 3, TH = 8, TW = 8, S = 4, K = C * TH * TW, KSTEPS = K / 16;   // 12 k-steps of (c, kh pair)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,11 +53,14 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
     constexpr int WROW = K * 2 + 16;
     char* wlds = smem;
     float* blds = (float*)(smem + 32 * WROW);                    // bias in LDS: a global load inside the tile loop would wait, in order, behind the prefetch
-    char* xlds = smem + 32 * WROW + 128;
+    char* wlo = smem + 32 * WROW + 128;                          // (X3) the weights' remainders
+    char* xlds = smem + (X3 ? 2 : 1) * 32 * WROW + 128;
+    char* xlo = xlds + (long)C * PP * 2;                         // (X3) lo planes behind the hi planes
     if (tid < 32) blds[tid] = p.bias ? p.bias[tid] : 0.f;
     for (int id = tid; id < 32 * (K / 8); id += NT) {
         const int row = id / (K / 8), ch = id % (K / 8);
         *(uint4*)(wlds + row * WROW + ch * 16) = *(const uint4*)((const uint16_t*)p.Wt + (long)row * p.ldw + ch * 8);   // bf16 weights (dispatch checks)
+        if (X3) *(uint4*)(wlo + row * WROW + ch * 16) = *(const uint4*)((const uint16_t*)p.Wlo + (long)row * p.ldw + ch * 8);
     }
 
     // the prefetched band stays RAW in registers (8 floats per item / the aligned dword windows of uint8 frames) and is converted in
@@ -129,6 +135,15 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
         for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             if (id < items) *(uint4*)(xlds + ((long)c * PP + id * 8) * 2) = xpre[j];
+            if (X3 && id < items) {                             // remainders a - bf16(a) of the same 8 values
+                const float4 a = xraw[j][0], b = xraw[j][1];
+                const uint4 hi = xpre[j];
+                const uint4 lo = make_uint4(pack_bf16x2(a.x - __uint_as_float(hi.x << 16), a.y - __uint_as_float(hi.x & 0xffff0000u)),
+                                            pack_bf16x2(a.z - __uint_as_float(hi.y << 16), a.w - __uint_as_float(hi.y & 0xffff0000u)),
+                                            hi.z | hi.w ? pack_bf16x2(b.x - __uint_as_float(hi.z << 16), b.y - __uint_as_float(hi.z & 0xffff0000u)) : 0u,
+                                            hi.z | hi.w ? pack_bf16x2(b.z - __uint_as_float(hi.w << 16), b.w - __uint_as_float(hi.w & 0xffff0000u)) : 0u);
+                *(uint4*)(xlo + ((long)c * PP + id * 8) * 2) = lo;
+            }
         }
     };
 
@@ -158,6 +173,14 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
                 x.u[0] = *(const uint2*)src; x.u[1] = *(const uint2*)(src + 8);
                 const bf16x8_t wf = *(const bf16x8_t*)(wrow + ks * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x.b, acc, 0, 0, 0);
+                if (X3) {
+                    union { uint2 u[2]; bf16x8_t b; } xl;
+                    const char* sl = src + (xlo - xlds);
+                    xl.u[0] = *(const uint2*)sl; xl.u[1] = *(const uint2*)(sl + 8);
+                    const bf16x8_t wl = *(const bf16x8_t*)(wrow + (wlo - wlds) + ks * 32);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xl.b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, x.b, acc, 0, 0, 0);
+                }
             }
             {
                 const long yo = (((long)n * p.OH + r0) * p.OW + qc) * 32;       // band pixels are contiguous in the NHWC output (qc: clamped, always valid)
@@ -210,7 +233,8 @@ __global__ __launch_bounds__(512, 4) void conv1_band_kernel(C1P p) {
 
 template <int XCH>
 int launch_conv1(C1P& p, hipStream_t s) {
-    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return 32 * (192 * 2 + 16) + 128 + 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
+    const int x3 = p.Wlo != nullptr;
+    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return (1 + x3) * 32 * (192 * 2 + 16) + 128 + (1 + x3) * 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         static const bool tall = !(getenv("HULC_CONV1_U8_TALL") && atoi(getenv("HULC_CONV1_U8_TALL")) == 0);
@@ -230,10 +254,12 @@ int launch_conv1(C1P& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
         attr_set = true;
     }
-    if (p.u8) conv1_band_kernel<XCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    if (x3) conv1_band_kernel<XCH, false, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    else if (p.u8) conv1_band_kernel<XCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     else conv1_band_kernel<XCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     return 0;
 }
@@ -242,13 +268,14 @@ int launch_conv1(C1P& p, hipStream_t s) {
 
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, hipStream_t s) {
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, const void* w_lo, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
     if (w_dtype != HULC_BF16 || ((uintptr_t)w % 16) || ldw % 8) return u8 ? hulc_fail(-6, "conv1 band: bf16 weights, 16-byte aligned rows") : 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
     C1P p;
     if (relu_bits && (y_dtype != HULC_BF16 || !relu)) return 1;       // (planes describe the stored bf16 ReLU output)
-    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx; p.bits = relu_bits;
+    if (w_lo && (u8 || (uintptr_t)w_lo % 16)) return hulc_fail(-6, "conv1 band: split operands need fp32 frames and 16-byte aligned remainders");
+    p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx; p.bits = relu_bits; p.Wlo = w_lo;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
     const int rc = launch_conv1<3>(p, s);

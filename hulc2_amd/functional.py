@@ -376,19 +376,25 @@ class ConvStackFn(torch.autograd.Function):
         # gradients need of those activations is the sign — conv2's data gradient then reads 20 MB instead of 315 MB per 2048 frames
         want_bits = (_act_dtype() == torch.bfloat16 and any(ctx.needs_input_grad[2:8]) and not os.environ.get("HULC_NO_RELU_BITS"))
         bits = [None, None, None]
+        # selective precision site "a3" (DESIGN §5): the stack's OUTPUT (conv3's ReLU map, the spatial softmax's / flatten-linear's input) is
+        # kept in fp32 inside a bf16 step — its rounding to bf16 alone costs as much gradient fidelity as all of conv1's operand rounding
+        a3_exact = _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16" and "a3" in kn.fp32_sites()
         for li, (k, s) in enumerate(ConvStackFn.GEOM):
             cout = ws[li].shape[0]
             nchw = li == 0
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
-            y = torch.empty(N, oh, ow, cout, dtype=_act_dtype(), device=xs[0].device)
+            y = torch.empty(N, oh, ow, cout, dtype=torch.float32 if (a3_exact and li == 2) else _act_dtype(), device=xs[0].device)
             if want_bits and li < 2 and cout % 32 == 0 and (li > 0 or cout == 32):     # (conv1 writes per input tensor: one plane, pixel-major slices)
                 bits[li] = torch.empty(N * oh * ow * (cout // 32), dtype=torch.int32, device=xs[0].device)
             if li == 0:
                 off = 0
+                # selective precision site "conv1": fp32 frames and weights as hi + lo bf16 splits, three MFMAs per product (fp32-class a1)
+                w_lo = weight_operand(ws[0], "oihw_flat_lo") if (not u8 and _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16"
+                                                                  and "conv1" in kn.fp32_sites()) else None
                 for x, n, sh, ix in zip(xs, Ns, shifts, indices):
                     kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
-                                  frame_index=ix,
+                                  frame_index=ix, w_lo=w_lo,
                                   relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
                     off += n
             else:
@@ -405,6 +411,7 @@ class ConvStackFn(torch.autograd.Function):
                 h = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
                 kn.cast_f32_to_bf16(a, h, a.numel())
                 saved.append(h)
+        ctx.g_dtype = saved[1].dtype                      # storage type of the gradient maps the backward kernels work on
         ctx.save_for_backward(saved[0], saved[1], saved[2], w2, w3, *xs)
         ctx.conv_w, ctx.conv_b = ws, bs                   # identities for the gradient sinks
         ctx.relu_bits = bits
@@ -418,8 +425,8 @@ class ConvStackFn(torch.autograd.Function):
         dims, premasked, Ns = ctx.meta
         N = sum(Ns)
         g = _c(da3)
-        if premasked and g.dtype != a3.dtype:             # ('mixed' mode: the consumer worked on the fp32 map) -> the saved maps' storage type
-            h = torch.empty(g.shape, dtype=a3.dtype, device=g.device)
+        if premasked and g.dtype != ctx.g_dtype:          # ('mixed' mode / site "a3": the consumer worked on the fp32 map) -> the saved maps' storage type
+            h = torch.empty(g.shape, dtype=ctx.g_dtype, device=g.device)
             kn.cast_f32_to_bf16(g, h, g.numel())
             g = h
         if not premasked:
@@ -490,7 +497,9 @@ class SpatialSoftmaxFn(torch.autograd.Function):
     def backward(ctx, dout):
         a, xmap, ymap, temperature, out, stats = ctx.saved_tensors
         N, H, W, C = a.shape
-        dx = torch.empty_like(a)
+        # (an fp32 map inside a bf16 step — site "a3": the gradient leaves in the conv stack's gradient type, no cast launch behind it)
+        gdt = torch.bfloat16 if (a.dtype == torch.float32 and kn.base_mode() == "bf16" and kn.get_compute() == "bf16") else a.dtype
+        dx = torch.empty(a.shape, dtype=gdt, device=a.device)
         kn.spatial_softmax_bwd(a, N, H * W, C, xmap, ymap, temperature, out, stats, _c(dout), dx, relu_mask=True)
         return dx, None, None, None
 

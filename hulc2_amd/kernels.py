@@ -75,12 +75,14 @@ def fp32_sites() -> frozenset:
     """Which parts of a bf16-mode step run their FORWARD in exact fp32 (HULC_FP32_SITES, comma separated).  Sites: `head` = plan
     recognition's 128 -> 4096 projection of the pooled feature, ProjVisLang, the CLIP loss;  `goal` = the goal encoders;  `encfc` = the fc
     tails of the camera encoders (flatten-linear, fc1, fc2);  `pool` = the sequence mean;  `txl` = the posterior's transformer layers;
-    `enc` = the whole camera encoders;  `prior`;  `none`.
+    `conv1` = conv1 of the camera encoders from split bf16 operands (fp32 frames only);  `a3` = the conv stacks' output map kept in fp32;
+    `enc` = the whole camera encoders (exact-fp32 MFMA);  `prior`;  `none`.
     `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
     the fp32 matrix instruction.
     Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.4 %,
     median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.14 ms per step (3.48 -> 3.62);
-    `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost."""
+    `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost; `head,goal,encfc,txl,conv1,a3`: median
+    0.84 % (worst 10 %: the conv stacks' own parameters) for +0.45 ms."""
     import os
     v = os.environ.get("HULC_FP32_SITES", "head,goal,encfc,txl")
     return frozenset(x for x in v.replace(" ", "").split(",") if x and x != "none")
@@ -343,7 +345,7 @@ def _u8_frames(d, x, aug_shift, aug_pad, frame_index=None):
 
 
 def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
-               frame_index=None, relu_bits=None):
+               frame_index=None, relu_bits=None, w_lo=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
     for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
     _require_cuda(x, w2d, bias, y, aug_shift, frame_index)
@@ -356,7 +358,12 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
         if relu_bits.dtype != torch.int32 or not relu_bits.is_contiguous() or relu_bits.numel() != N * oh * ow * (Cout // 32):
             raise TypeError("relu_bits: contiguous int32 tensor of N * OH * OW * Cout / 32 words")
         d.relu_bits = relu_bits.data_ptr()
-    macs = float(N) * oh * ow * Cout * Cin * KH * KW
+    if w_lo is not None:                   # conv1, fp32 frames: split-operand products (hulc_conv_desc.w_lo)
+        _require_cuda(w_lo)
+        if w_lo.dtype != torch.bfloat16 or w_lo.shape != w2d.shape or not w_lo.is_contiguous():
+            raise TypeError("w_lo: the bf16 remainders of w2d, same shape")
+        d.w_lo = w_lo.data_ptr()
+    macs = float(N) * oh * ow * Cout * Cin * KH * KW * (3 if w_lo is not None else 1)
     with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
         _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
                  "hulc_conv2d_fwd")

@@ -77,6 +77,7 @@ class ConvDesc(ctypes.Structure):
         ("dw_oihw", ctypes.c_int), ("dw_accumulate", ctypes.c_int),
         ("x_u8_nhwc", ctypes.c_int), ("aug_pad", ctypes.c_int), ("aug_shift", ctypes.c_void_p), ("frame_index", ctypes.c_void_p),
         ("relu_bits", ctypes.c_void_p),
+        ("w_lo", ctypes.c_void_p),
     ]
 
 

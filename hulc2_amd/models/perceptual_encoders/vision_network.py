@@ -63,7 +63,7 @@ class VisionNetwork(nn.Module):
 
     def lo_operands(self):
         """rounding remainders the split-operand forward of the fc1 -> fc2 head reads (precision site "encfc"; trainer-maintained)"""
-        return [(self.fc1[0].weight, "lo"), (self.fc2.weight, "lo")]
+        return [(self.fc1[0].weight, "lo"), (self.fc2.weight, "lo"), (self.conv_model[0].weight, "oihw_flat_lo")]
 
     def conv_params(self):
         c = self.conv_model

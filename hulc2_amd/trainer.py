@@ -400,7 +400,7 @@ class ArenaTrainer:
                         nat[id(p)] = (p, dst)
                         segs.append((off, p.numel(), dst))
                         dst += (p.numel() + 3) // 4 * 4
-                    if layout != "lo":
+                    if layout not in ("lo", "oihw_flat_lo"):
                         packed.append((p, layout))
             if segs:
                 import numpy as np
@@ -408,6 +408,8 @@ class ArenaTrainer:
                 self.lo_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
                 for p, d0 in nat.values():
                     shadow.register_layout_view(p, "lo", self.lo_shadow[d0:d0 + p.numel()].view(p.shape))
+                    if p.dim() == 4:                        # conv weight: its OIHW-flat remainder is the same memory
+                        shadow.register_layout_view(p, "oihw_flat_lo", self.lo_shadow[d0:d0 + p.numel()].view(p.shape[0], -1))
                 chunks, views, fdst = [], [], 0
                 for p, layout in packed:
                     n = int(layout[5])

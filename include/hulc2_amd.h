@@ -87,6 +87,11 @@ typedef struct {
      * (Cin / 32 planes over the N*H*W input pixels), used in place of relu_src where the LDS-band kernel takes the launch — the data gradient of conv2 then
      * reads 20 MB of sign bits instead of the 315 MB activation (relu_src stays the mask of the other kernels: pass both).  NULL = none. */
     void* relu_bits;
+    /* (ABI 3) hulc_conv2d_fwd, conv1 (fp32 NCHW frames, 3 -> 32, 8 x 8 stride 4) on the LDS-band kernel only: bf16 of the rounding remainders
+     * w - bf16(w), laid out like w.  The frames are then split into hi + lo bf16 planes while staged and every product is formed from the
+     * splits of both operands (three bf16 MFMAs): fp32-class outputs on the bf16 matrix pipe — the selective-precision site "conv1"
+     * (DESIGN §5).  NULL = plain bf16 operands. */
+    const void* w_lo;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

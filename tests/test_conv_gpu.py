@@ -147,3 +147,30 @@ def test_data_gradient_masked_by_sign_planes_equals_masked_by_the_activation(dev
     torch.cuda.synchronize()
     assert torch.isfinite(a.float()).all() and torch.equal(a, b2), f"{name}: {(a != b2).sum().item()} elements differ"
     assert (a.float().abs() > 0).float().mean().item() > 0.2
+
+
+@pytest.mark.parametrize("name,N,H,W", [("static1", 5, 200, 200), ("grip1", 7, 84, 84)])
+def test_conv1_split_operands_are_fp32_class(dev, name, N, H, W):
+    """hulc_conv_desc.w_lo (selective-precision site "conv1"): fp32 frames and weights as hi + lo bf16 splits, three MFMAs per product —
+    the output agrees with the UNROUNDED float64 convolution to 2e-5 of its range (plain bf16 operands: ~3e-3), fp32 and bf16 outputs"""
+    from hulc2_amd import kernels as kn
+
+    x, w, b, _ = _setup(dev, N, H, W, 3, 32, 8, 13)
+    OH, OW = kn.conv_out_hw(H, W, 8, 8, 4)
+    w2d = w.reshape(32, -1).contiguous()
+    whi = w2d.to(torch.bfloat16)
+    wlo = (w2d - whi.float()).to(torch.bfloat16)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), stride=4)).permute(0, 2, 3, 1)
+    y = torch.full((N, OH, OW, 32), float("nan"), device=dev)
+    kn.conv2d_fwd(x.contiguous(), whi, b, y, N, H, W, 3, 32, 8, 8, 4, True, relu=True, compute=kn.BF16, w_lo=wlo)
+    y0 = torch.empty_like(y)
+    kn.conv2d_fwd(x.contiguous(), whi, b, y0, N, H, W, 3, 32, 8, 8, 4, True, relu=True, compute=kn.BF16)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    e, e0 = (y.double() - ref).abs().max().item() / scale, (y0.double() - ref).abs().max().item() / scale
+    assert torch.isfinite(y).all()
+    assert e < 2e-5 and e < 0.02 * e0, (name, e, e0)
+    yb = torch.empty(N, OH, OW, 32, dtype=torch.bfloat16, device=dev)          # bf16 storage of the fp32-class values: one rounding
+    kn.conv2d_fwd(x.contiguous(), whi, b, yb, N, H, W, 3, 32, 8, 8, 4, True, relu=True, compute=kn.BF16, w_lo=wlo)
+    torch.cuda.synchronize()
+    assert torch.equal(yb, y.to(torch.bfloat16)) or ((yb.double() - ref).abs().max().item() / scale) < 4e-3

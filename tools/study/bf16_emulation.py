@@ -46,6 +46,9 @@ def split(t):
 
 SITES = {
     "conv": lambda n: "conv_model" in n and not n.endswith("conv_model.7.weight"),
+    "conv1": lambda n: "conv_model.0." in n,
+    "conv2": lambda n: "conv_model.2." in n,
+    "conv3": lambda n: "conv_model.4." in n,
     "encfc": lambda n: n.startswith("perceptual_encoder.") and ("fc1" in n or "fc2" in n or "conv_model.7" in n),
     "encfc1": lambda n: n.startswith("perceptual_encoder.") and "fc1" in n,
     "encfc2": lambda n: n.startswith("perceptual_encoder.") and "fc2" in n,
@@ -181,8 +184,11 @@ def run(B, S, spec, sd_vals, batch, seed):
     if "fs" in conv_fl:                         # conv activations stored bf16 (after ReLU) — wrap the oracle's conv stack
         def stack(sd_, p, x):
             F = O.F
+            keep = set(os.environ.get("HULC_EMU_FS_LAYERS", "0,2,4").split(","))        # which conv outputs are stored rounded
             for i, st in ((0, 4), (2, 2), (4, 1)):
-                x = StoreRound.apply(F.relu(F.conv2d(x, sd_[p + f"conv_model.{i}.weight"], sd_[p + f"conv_model.{i}.bias"], stride=st)))
+                x = F.relu(F.conv2d(x, sd_[p + f"conv_model.{i}.weight"], sd_[p + f"conv_model.{i}.bias"], stride=st))
+                if str(i) in keep:
+                    x = StoreRound.apply(x)
             return x
         O._conv_stack = stack
     try:
