@@ -85,7 +85,14 @@ def fp32_sites() -> frozenset:
     0.84 % (worst 10 %: the conv stacks' own parameters) for +0.45 ms."""
     import os
     v = os.environ.get("HULC_FP32_SITES", "head,goal,encfc,txl")
-    return frozenset(x for x in v.replace(" ", "").split(",") if x and x != "none")
+    sites = frozenset(x for x in v.replace(" ", "").split(",") if x and x != "none")
+    unknown = sites - _KNOWN_SITES
+    if unknown:
+        raise ValueError(f"HULC_FP32_SITES: unknown site(s) {sorted(unknown)}; known: {sorted(_KNOWN_SITES)}")
+    return sites
+
+
+_KNOWN_SITES = frozenset(("head", "goal", "encfc", "txl", "pool", "enc", "prior", "conv1", "a3"))
 
 
 def site_scope(site: str):

@@ -359,3 +359,17 @@ def test_ffn_fragment_permutations():
         r, hf = lane & 31, lane >> 5
         want = [(32 * (f >> 1) + r) * ff + 32 * hb + 16 * (f & 1) + 4 * hf + (j if j < 4 else j + 4) for j in range(8)]
         assert b[hb, f, lane].tolist() == want
+
+
+def test_precision_sites_are_validated(monkeypatch):
+    """HULC_FP32_SITES (selective precision): the default, 'none', and a misspelt site name"""
+    from hulc2_amd import kernels as kn
+    monkeypatch.delenv("HULC_FP32_SITES", raising=False)
+    assert kn.fp32_sites() == {"head", "goal", "encfc", "txl"}
+    monkeypatch.setenv("HULC_FP32_SITES", "none")
+    assert kn.fp32_sites() == frozenset()
+    monkeypatch.setenv("HULC_FP32_SITES", "head, conv1 ,a3")
+    assert kn.fp32_sites() == {"head", "conv1", "a3"}
+    monkeypatch.setenv("HULC_FP32_SITES", "head,tlx")
+    with pytest.raises(ValueError):
+        kn.fp32_sites()
