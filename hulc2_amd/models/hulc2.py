@@ -95,6 +95,15 @@ class Hulc2(LightningModule):
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
 
     # ---- hot path ----------------------------------------------------------------------------------
+    @staticmethod
+    def _goal_site(is_lang: bool):
+        """precision scope of a goal encoder: only the LANGUAGE goal is upstream of the contrastive head — in a bf16 step the
+        site "goal" makes that encoder's forward exact and leaves the visual one on its bf16 launches; 'mixed' / 'fp32' steps treat both alike"""
+        import contextlib
+        if is_lang or kn.base_mode() != "bf16":
+            return kn.site_scope("goal")
+        return contextlib.nullcontext()
+
     def lmp_train(self, perceptual_emb, latent_goal, train_acts, robot_obs, plan_idx: Optional[torch.Tensor] = None
                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, State, State, torch.Tensor]:
         """hulc2.py:200-245; returns the prior/posterior *states* in place of torch.distributions objects."""
@@ -145,10 +154,20 @@ class Hulc2(LightningModule):
             goal_all = None
             if fan:
                 emb0, emb_last, emb_rec, emb_dec_t = HF.EmbFanoutFn.apply(emb_all, B, lo, hi)
+                # selective precision: of the goal encoders only the LANGUAGE one is upstream of the contrastive head; inside a bf16
+                # step with site "goal" it alone runs its forward exactly, the visual one stays on its bf16 chain launch
+                lang_only_exact = kn.base_mode() == "bf16" and kn.get_compute() == "bf16" and "goal" in kn.fp32_sites() and len(mods) == 2
+                if lang_only_exact:
+                    pre_v = self.visual_goal(emb_last, pre_ln=True)
+                    with kn.site_scope("goal"):
+                        pre_l = self.language_goal(mods[1][1]["lang"], pre_ln=True)
+                    pre = [pre_v, pre_l]
                 with kn.site_scope("goal"):
                     # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
                     # directly (no concatenation, no strided gradient slices on the way back)
-                    if len(mods) == 2:      # the two goal MLPs (same hidden widths, their own weights) as one launch each way
+                    if lang_only_exact:
+                        pass
+                    elif len(mods) == 2:    # the two goal MLPs (same hidden widths, their own weights) as one launch each way
                         pre = list(HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
                                                self.language_goal.mlp_layers()))
                     else:
@@ -158,8 +177,10 @@ class Hulc2(LightningModule):
             else:
                 embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
                 emb0, emb_rec = emb_all[:, 0], emb_all
-                with kn.site_scope("goal"):
-                    goals = [self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]) for i, (scope, db) in enumerate(mods)]
+                goals = []
+                for i, (scope, db) in enumerate(mods):
+                    with self._goal_site("lang" in scope):
+                        goals.append(self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]))
             if goal_all is None:
                 goal_all = torch.cat(goals, dim=0)
             with kn.site_scope("prior"):
@@ -188,7 +209,7 @@ class Hulc2(LightningModule):
             for self.modality_scope, db in mods:
                 with kn.site_scope("enc"):
                     emb = self.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
-                with kn.site_scope("goal"):
+                with self._goal_site("lang" in self.modality_scope):
                     latent_goal = self.language_goal(db["lang"]) if "lang" in self.modality_scope else self.visual_goal(emb[:, -1])
                 with kn.site_scope("prior"):
                     pp_state = self.plan_proposal(emb[:, 0], latent_goal)
