@@ -73,14 +73,14 @@ class compute_scope:
 
 def fp32_sites() -> frozenset:
     """Which parts of a bf16-mode step run their FORWARD in exact fp32 (HULC_FP32_SITES, comma separated).  Sites: `head` = plan
-    recognition's 128 -> 4096 projection of the pooled feature, ProjVisLang, the CLIP loss;  `goal` = the goal encoders;  `encfc` = the fc
+    recognition's 128 -> 4096 projection of the pooled feature, ProjVisLang, the CLIP loss;  `goal` = the language goal encoder (in a bf16 step; the visual one is not upstream of the contrastive head and stays bf16);  `encfc` = the fc
     tails of the camera encoders (flatten-linear, fc1, fc2);  `pool` = the sequence mean;  `txl` = the posterior's transformer layers;
     `conv1` = conv1 of the camera encoders from split bf16 operands (fp32 frames only);  `a3` = the conv stacks' output map kept in fp32;
     `enc` = the whole camera encoders (exact-fp32 MFMA);  `prior`;  `none`.
     `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
     the fp32 matrix instruction.
     Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.4 %,
-    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.14 ms per step (3.48 -> 3.62);
+    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.10 ms per step (3.50 -> 3.60);
     `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost; `head,goal,encfc,txl,conv1,a3`: median
     0.84 % (worst 10 %: the conv stacks' own parameters) for +0.45 ms."""
     import os
