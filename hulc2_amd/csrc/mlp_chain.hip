@@ -27,6 +27,7 @@ constexpr long CH_HEADER = 9L * CH_CTR_STRIDE * 4;   // 8 counters + the error w
 
 struct ChLayer {
     const uint16_t* W; long ldw;        // bf16 [N][K], k contiguous
+    const uint16_t* Wlo;                // split operands (X3): bf16 of the remainders w - bf16(w), same layout, or null
     const float* bias;                  // [N] or null
     const float* mask; long ld_mask; float mask_scale;   // out = mask > 0 ? v * mask_scale : 0   (data-gradient chain) or null
     float* out; long ld_out;            // fp32 [M][N]
@@ -42,6 +43,9 @@ struct ChainP {
     const float* x0; long ld_x0; int K0;    // layer 0 input, fp32 [M][K0] ...
     uint16_t* x0b;                      // ... and its bf16 blocked copy (chain_stage_input)
     uint16_t* xb;
+    // split operands (X3): the "exact" chain — the second one of a pair, else the only one (then M <= 32) — forms its products from hi / lo
+    // splits of both operands (three MFMAs): lo copies of its input and of its exchanged activations live in x0b_lo / xb_lo (same offsets)
+    int x3; uint16_t* x0b_lo; uint16_t* xb_lo;
     unsigned* bar; int* err; int* err_sticky;
 };
 
@@ -57,17 +61,26 @@ HULC_DEVICE void chain_stage_input(const ChainP& p, int tid, int nwg) {
     const long nchunk = ((long)(kmax + 7) / 8) * 64;
     for (long i = (long)blockIdx.x * 256 + tid; i < nchunk; i += (long)nwg * 256) {
         const int m = (int)(i & 63), k = (int)(i >> 6) * 8;
-        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        uint4 o = make_uint4(0u, 0u, 0u, 0u), ol = make_uint4(0u, 0u, 0u, 0u);
         const bool second = p.dual && m >= 32;
         const int mm = second ? m - 32 : m;
         if (mm < (second ? p.M2 : p.M) && k < (second ? p.K0_2 : p.K0)) {      // K0 is a multiple of 8
             const float* src = (second ? p.x0_2 + (long)mm * p.ld_x0_2 : p.x0 + (long)mm * p.ld_x0) + k;
             const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
             o = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+            ol = make_uint4(pack_bf16x2(a.x - __uint_as_float(o.x << 16), a.y - __uint_as_float(o.x & 0xffff0000u)),
+                            pack_bf16x2(a.z - __uint_as_float(o.y << 16), a.w - __uint_as_float(o.y & 0xffff0000u)),
+                            pack_bf16x2(b.x - __uint_as_float(o.z << 16), b.y - __uint_as_float(o.z & 0xffff0000u)),
+                            pack_bf16x2(b.z - __uint_as_float(o.w << 16), b.w - __uint_as_float(o.w & 0xffff0000u)));
         }
         unsigned long long* dst = (unsigned long long*)(p.x0b + i * 8);
         __hip_atomic_store(dst, (unsigned long long)o.x | ((unsigned long long)o.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 1, (unsigned long long)o.z | ((unsigned long long)o.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.x3 && (second || !p.dual)) {                           // the exact chain's remainders
+            unsigned long long* dl = (unsigned long long*)(p.x0b_lo + i * 8);
+            __hip_atomic_store(dl, (unsigned long long)ol.x | ((unsigned long long)ol.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dl + 1, (unsigned long long)ol.z | ((unsigned long long)ol.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -75,26 +88,29 @@ HULC_DEVICE void chain_stage_input(const ChainP& p, int tid, int nwg) {
 }
 
 // one layer for this workgroup's column tile; KSW = k-steps (of 32) per wave, K padded up to 128 * KSW
-template <int KSW>
-HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const uint16_t* __restrict__ xin, float (*red)[64][16], int tid, bool& timed_out,
-                             int nwg) {
+template <int KSW, bool X3>
+HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const uint16_t* __restrict__ xin, const uint16_t* __restrict__ xin_lo,
+                             float (*red)[64][16], int tid, bool& timed_out, int nwg) {
     const ChLayer& c = p.L[l];
     const bool dual = p.dual && l < p.nl2;
     const ChLayer& c2 = dual ? p.L2[l] : p.L[l];                      // dual: the second chain's layer (row tiles 2, 3)
+    const bool x3 = X3 && (p.dual ? dual : true);                     // (a pair's second chain may be shorter: no exact tiles in the trailing layers)
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int ntile = c.N / 16;
     const bool active = tile < ntile;
     const int n0 = (active ? tile : 0) * 16;
     // ---- weight fragments of this wave's k range: requested before the wait on the previous layer
-    F8 wf[KSW], wf2[KSW];
+    F8 wf[KSW], wf2[KSW], wfl[X3 ? KSW : 1];
     {
         const uint16_t* wrow = c.W + (long)(n0 + r) * c.ldw;
         const uint16_t* wrow2 = c2.W + (long)(n0 + r) * c2.ldw;
+        const uint16_t* wrowl = x3 ? c2.Wlo + (long)(n0 + r) * c2.ldw : nullptr;      // (c2 == c for a single chain)
 #pragma unroll
         for (int s = 0; s < KSW; ++s) {
             const int k = (wave * KSW + s) * 32 + g * 8;
             wf[s].u = *(const uint4*)(wrow + (k < c.K ? k : 0));            // clamped (always valid) address; the matching A fragment is zero
             if (dual) wf2[s].u = *(const uint4*)(wrow2 + (k < c2.K ? k : 0));
+            if (X3 && x3) wfl[s].u = *(const uint4*)(wrowl + (k < c2.K ? k : 0));
         }
     }
     // ---- wait for the previous stage's outputs (all workgroups): stage 0 = the input copy, stage l = layer l - 1
@@ -136,8 +152,9 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
     constexpr int AB = KSW >= 32 ? 2 : (KSW >= 4 ? 4 : KSW);            // k-steps per batch
     constexpr int NB = KSW / AB;
     static_assert(KSW % AB == 0, "batches tile the k range");
-    F8 af[2][AB][4];
-    auto load_batch = [&](F8 (&dst)[AB][4], int bi) {
+    F8 af[2][AB][4], afl[2][AB][X3 ? 2 : 1];                         // afl: lo fragments of the exact chain's two row tiles
+    const int xt0 = dual ? 2 : 0;                                      // first row tile of the exact chain
+    auto load_batch = [&](F8 (&dst)[AB][4], F8 (&dstl)[AB][X3 ? 2 : 1], int bi) {
 #pragma unroll
         for (int q = 0; q < AB; ++q) {
             const int k = (wave * KSW + bi * AB + q) * 32 + g * 8;
@@ -147,13 +164,17 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
                 const int m = mt * 16 + r;
                 dst[q][mt].u = *(const uint4*)(xin + ((long)((kin ? k : 0) / 8) * 64 + m) * 8);
             }
+            if (X3 && x3) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dstl[q][t].u = *(const uint4*)(xin_lo + ((long)((kin ? k : 0) / 8) * 64 + (xt0 + t) * 16 + r) * 8);
+            }
         }
     };
     if (active) {
-        load_batch(af[0], 0);
+        load_batch(af[0], afl[0], 0);
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
-            if (bi + 1 < NB) load_batch(af[(bi + 1) & 1], bi + 1);
+            if (bi + 1 < NB) load_batch(af[(bi + 1) & 1], afl[(bi + 1) & 1], bi + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < AB; ++q) {
@@ -166,6 +187,12 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
                     if (!(sec ? kin2 : kin1)) a.u = make_uint4(0u, 0u, 0u, 0u);
                     const bool on = dual ? (mt < 2 ? mt < MT1 : mt < MT) : mt < MT;
                     if (on) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, (sec ? wf2 : wf)[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
+                    if (X3 && x3 && on && (dual ? mt >= 2 : mt < 2)) {       // + a_lo w_hi + a_hi w_lo   (exact tiles 2, 3 of a pair / 0, 1 alone: slot mt & 1)
+                        F8 al = afl[bi & 1][q][mt & 1];
+                        if (!(sec ? kin2 : kin1)) al.u = make_uint4(0u, 0u, 0u, 0u);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.b, (sec ? wf2 : wf)[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, wfl[s_of(bi, q, AB)].b, acc[mt], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -202,8 +229,15 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
         if (live) *(float4*)(e.out + (long)mm * e.ld_out + n0 + n4) = make_float4(v[0], v[1], v[2], v[3]);
         if (l + 1 < (sec ? p.nl2 : p.nl) && live) {              // exchange copy for the next layer: [n / 8][64][8] bf16, device-scope write-through
             uint16_t* dst = p.xb + c.xb_off + ((long)((n0 + n4) / 8) * 64 + m) * 8 + (n4 & 7);
-            const unsigned long long bits = (unsigned long long)pack_bf16x2(v[0], v[1]) | ((unsigned long long)pack_bf16x2(v[2], v[3]) << 32);
+            const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+            const unsigned long long bits = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
             __hip_atomic_store((unsigned long long*)dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (X3 && x3 && (sec || !p.dual)) {                  // the exact chain also hands on the remainders of its activations
+                const uint32_t l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                __hip_atomic_store((unsigned long long*)(p.xb_lo + (dst - p.xb)), (unsigned long long)l0 | ((unsigned long long)l1 << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (l + 1 < p.nl) {                          // arrival: everybody's outputs acknowledged before anybody may read them
@@ -216,6 +250,8 @@ HULC_DEVICE void chain_layer(const ChainP& p, int l, int tile, bool last, const 
     (void)timed_out;
 }
 
+// X3 = the split-operand instance (p.x3): its own kernel, so that the plain one keeps its register allocation (no scratch)
+template <bool X3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_chain_kernel(ChainP p) {
     __shared__ float red[4][64][16];
     const int tid = threadIdx.x;
@@ -225,15 +261,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int l = 0; l < p.nl; ++l) {
         const int ksw = ((p.dual && l < p.nl2 && p.L2[l].K > p.L[l].K ? p.L2[l].K : p.L[l].K) + 127) / 128;
         const uint16_t* xin = l ? p.xb + p.L[l - 1].xb_off : p.x0b;
+        const uint16_t* xin_lo = l ? p.xb_lo + p.L[l - 1].xb_off : p.x0b_lo;
+#define CH_CASE(N) case N: chain_layer<N, X3>(p, l, tile, l + 1 == p.nl, xin, xin_lo, red, tid, timed_out, nwg); break;
         switch (ksw) {
-            case 1: chain_layer<1>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            case 2: chain_layer<2>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            case 3: chain_layer<3>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            case 4: chain_layer<4>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            case 8: chain_layer<8>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            case 16: chain_layer<16>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
-            default: chain_layer<32>(p, l, tile, l + 1 == p.nl, xin, red, tid, timed_out, nwg); break;
+            CH_CASE(1) CH_CASE(2) CH_CASE(3) CH_CASE(4) CH_CASE(8) CH_CASE(16)
+            default: if constexpr (!X3) chain_layer<32, false>(p, l, tile, l + 1 == p.nl, xin, xin_lo, red, tid, timed_out, nwg);   // (X3: K <= 2048, host-checked)
+                     break;
         }
+#undef CH_CASE
     }
 }
 
@@ -243,7 +278,8 @@ extern "C" long hulc_mlp_chain_workspace(const hulc_mlp_chain_desc* d) {
     if (!d || d->nl < 1 || d->nl > CH_MAXL) return 0;
     long elems = 0;
     for (int l = 0; l + 1 < d->nl; ++l) elems += (long)d->layers[l].N * 64;
-    return CH_HEADER + elems * 2 + 64 + ((long)(d->K0 + 7) / 8) * 64 * 16;     // header, exchange regions, the blocked input
+    // header, exchange regions, the blocked input — twice: the split-operand mode keeps remainder copies of both
+    return CH_HEADER + 2 * (elems * 2 + 64 + ((long)(d->K0 + 7) / 8) * 64 * 16);
 }
 
 // validates one chain description and fills its device-side layer table; returns 0 or an error code
@@ -264,7 +300,8 @@ static int chain_fill(const hulc_mlp_chain_desc* d, ChLayer* L, int max_rows) {
         if (s.bias && (uintptr_t)s.bias % 16) return hulc_fail(-4, "hulc_mlp_chain: bias must be 16-byte aligned");
         if (s.mask && ((uintptr_t)s.mask % 16 || s.ld_mask % 4)) return hulc_fail(-4, "hulc_mlp_chain: mask must be 16-byte aligned");
         ChLayer& c = L[l];
-        c.W = (const uint16_t*)s.W; c.ldw = s.ldw; c.bias = s.bias; c.mask = s.mask; c.ld_mask = s.ld_mask; c.mask_scale = s.mask_scale;
+        if (s.W_lo && (uintptr_t)s.W_lo % 16) return hulc_fail(-4, "hulc_mlp_chain: W_lo must be 16-byte aligned");
+        c.W = (const uint16_t*)s.W; c.Wlo = (const uint16_t*)s.W_lo; c.ldw = s.ldw; c.bias = s.bias; c.mask = s.mask; c.ld_mask = s.ld_mask; c.mask_scale = s.mask_scale;
         c.out = s.out; c.ld_out = s.ld_out; c.N = s.N; c.K = kin; c.relu = s.relu; c.xb_off = off;
         off += (long)s.N * 64;
         kin = s.N;
@@ -294,7 +331,28 @@ static int chain_launch(const hulc_mlp_chain_desc* d, const hulc_mlp_chain_desc*
     long off = 0;
     for (int l = 0; l + 1 < d->nl; ++l) off += (long)d->layers[l].N * 64;
     p.x0b = p.xb + ((off + 7) / 8) * 8;                      // behind the exchange regions of layers 0 .. nl-2
-    mlp_chain_kernel<<<256, 256, 0, (hipStream_t)stream>>>(p);
+    {   // split operands: the exact chain (the second of a pair, else the only one) carries W_lo on every layer
+        const hulc_mlp_chain_desc* ex = d2 ? d2 : d;
+        int nlo = 0;
+        for (int l = 0; l < ex->nl; ++l) nlo += ex->layers[l].W_lo != nullptr;
+        if (nlo != 0 && nlo != ex->nl) return hulc_fail(-3, "hulc_mlp_chain: W_lo on every layer of the chain or on none");
+        if (nlo && !d2 && d->M > 32) return hulc_fail(-2, "hulc_mlp_chain: split operands take <= 32 rows");
+        if (d2) for (int l = 0; l < d->nl; ++l) if (d->layers[l].W_lo) return hulc_fail(-3, "hulc_mlp_chain2: split operands are the second chain's");
+        p.x3 = nlo != 0;
+        const int k1 = d->K0, k2 = d2 ? d2->K0 : 0, km = k1 > k2 ? k1 : k2;
+        const long data = ((off + 7) / 8) * 8 + ((long)(km + 7) / 8) * 64 * 8 + 64;    // elements of one copy (exchange regions + blocked input)
+        p.xb_lo = p.xb + data;
+        p.x0b_lo = p.xb_lo + ((off + 7) / 8) * 8;
+    }
+    if (p.x3) {
+        for (int l = 0; l < d->nl; ++l) {
+            const int kk = d2 && l < d2->nl && p.L2[l].K > p.L[l].K ? p.L2[l].K : p.L[l].K;
+            if (kk > 2048) return hulc_fail(-3, "hulc_mlp_chain: split operands take K <= 2048");
+        }
+        mlp_chain_kernel<true><<<256, 256, 0, (hipStream_t)stream>>>(p);
+    } else {
+        mlp_chain_kernel<false><<<256, 256, 0, (hipStream_t)stream>>>(p);
+    }
     return hulc_check_launch("hulc_mlp_chain");
 }
 

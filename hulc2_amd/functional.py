@@ -60,6 +60,8 @@ def _act_dtype() -> torch.dtype:
 class MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, relus: Tuple[bool, ...], drops: Tuple[float, ...], seed: int, *params):
+        x3 = len(relus) > 0 and relus[-1] == "x3"          # caller's hint (mlp(..., x3=True)): split-operand chain inside an exact-forward scope
+        relus = tuple(relus[:-1]) if x3 else tuple(relus)
         L = len(relus)
         assert len(params) == 2 * L and not relus[-1], "chain must end with a plain Linear"
         # a 2-D input with unit inner stride is consumed in place (row stride = lda): the recurrent decoder hands in a column slice
@@ -67,9 +69,18 @@ class MLPFn(torch.autograd.Function):
         M = x2.shape[0]
         acts: List[torch.Tensor] = []
         widths = [params[2 * i].shape[0] for i in range(L)]
-        chain = (L >= 2 and not any(d > 0 for d in drops) and x2.dtype == torch.float32 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
-                 and kn.mlp_chain_ok(M, x2.shape[1], widths, x2.device))
-        if chain:      # the whole stack as one persistent launch (csrc/mlp_chain.hip): no per-layer launch, no split-K epilogues
+        pre_ok = L >= 2 and not any(d > 0 for d in drops) and x2.dtype == torch.float32 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+        chain = pre_ok and kn.mlp_chain_ok(M, x2.shape[1], widths, x2.device)
+        if (not chain) and x3 and pre_ok and M <= 32 and max(widths[:-1] + [x2.shape[1]]) <= 2048 and kn.exact_site_in_bf16_step():
+            # exact-forward scope of a bf16 step: the chain launch with split operands (three MFMAs per product, fp32-class values) instead of
+            # per-layer exact-fp32 GEMMs — the arithmetic of the paired launch's second stack (DualMLPFn), bit for bit
+            with kn.compute_scope("bf16", fwd_only=True):
+                if kn.mlp_chain_ok(M, x2.shape[1], widths, x2.device):
+                    acts = [_f32(M, n, like=x2) for n in widths]
+                    kn.mlp_chain(x2, [(weight_operand(params[2 * i]), params[2 * i + 1], relus[i], None, 1.0, acts[i], weight_operand(params[2 * i], "lo"))
+                                      for i in range(L)], M)
+                    chain = True
+        elif chain:    # the whole stack as one persistent launch (csrc/mlp_chain.hip): no per-layer launch, no split-K epilogues
             acts = [_f32(M, n, like=x2) for n in widths]
             kn.mlp_chain(x2, [(weight_operand(params[2 * i]), params[2 * i + 1], relus[i], None, 1.0, acts[i]) for i in range(L)], M)
         inp = x2
@@ -165,14 +176,18 @@ class DualMLPFn(torch.autograd.Function):
     second's.  Only built by dual_mlp() after kernels.mlp_chain2_ok."""
 
     @staticmethod
-    def forward(ctx, xa, xb, relus: Tuple[bool, ...], *params):
+    def forward(ctx, xa, xb, relus, *params):
+        """relus: tuple of flags; a trailing string "exact_b" in it selects split operands (fp32-class forward) for the SECOND stack"""
+        exact_b = len(relus) > 0 and relus[-1] == "exact_b"
+        relus = tuple(relus[:-1]) if exact_b else tuple(relus)
         L = len(relus)
         pa, pb = params[:2 * L], params[2 * L:]
         outs = []
         for x, ps in ((xa, pa), (xb, pb)):
             outs.append([_f32(x.shape[0], ps[2 * i].shape[0], like=x) for i in range(L)])
+        lo = [(weight_operand(pb[2 * i], "lo"),) if exact_b else () for i in range(L)]
         kn.mlp_chain2(xa, [(weight_operand(pa[2 * i]), pa[2 * i + 1], relus[i], None, 1.0, outs[0][i]) for i in range(L)], xa.shape[0],
-                      xb, [(weight_operand(pb[2 * i]), pb[2 * i + 1], relus[i], None, 1.0, outs[1][i]) for i in range(L)], xb.shape[0])
+                      xb, [(weight_operand(pb[2 * i]), pb[2 * i + 1], relus[i], None, 1.0, outs[1][i]) + lo[i] for i in range(L)], xb.shape[0])
         ctx.save_for_backward(xa, xb, *outs[0][:-1], *outs[1][:-1], *params)
         ctx.relus = relus
         return outs[0][-1], outs[1][-1]
@@ -278,9 +293,10 @@ def flatten_linear_relu(a_nhwc, W, b):
     return FlattenLinearFn.apply(a_nhwc, W, b)
 
 
-def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Optional[Sequence[float]] = None, seed: int = 0):
-    """layers: [(weight, bias, relu), ...]; dropout (inverted, after the ReLU) per layer optional."""
-    relus = tuple(bool(r) for _, _, r in layers)
+def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Optional[Sequence[float]] = None, seed: int = 0, x3: bool = False):
+    """layers: [(weight, bias, relu), ...]; dropout (inverted, after the ReLU) per layer optional.  x3: inside an exact-forward scope of a
+    bf16 step, prefer the split-operand chain launch to the exact-fp32 GEMMs (<= 32 rows)."""
+    relus = tuple(bool(r) for _, _, r in layers) + (("x3",) if x3 else ())
     drops = tuple(float(d) for d in (drops or [0.0] * len(layers)))
     params = [t for W, b, _ in layers for t in (W, b)]
     return MLPFn.apply(x, relus, drops, int(seed), *params)
@@ -328,18 +344,19 @@ def mlp2_rows(x, fc1_w, fc1_b, fc2_w, fc2_b):
     return mlp(x, [(fc1_w, fc1_b, True), (fc2_w, fc2_b, False)])
 
 
-def dual_mlp(xa, layers_a, xb, layers_b):
+def dual_mlp(xa, layers_a, xb, layers_b, exact_b: bool = False):
     """mlp(xa, layers_a), mlp(xb, layers_b) — as one launch where the pair fits hulc_mlp_chain2 (both <= 32 rows, the same ReLU pattern
-    and hidden widths), else one after the other."""
+    and hidden widths), else one after the other.  exact_b: the second stack's forward from split operands (fp32-class values, three MFMAs
+    per product; precision site "goal") — only with the paired launch (the caller falls back to an exact-fp32 scope otherwise: None)."""
     relus = tuple(bool(r) for _, _, r in layers_a)
     wa, wb = [W.shape[0] for W, _, _ in layers_a], [W.shape[0] for W, _, _ in layers_b]
     fits = (relus == tuple(bool(r) for _, _, r in layers_b) and not relus[-1] and len(relus) >= 2 and xa.dim() == 2 and xb.dim() == 2
             and all(x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 for x in (xa, xb))
             and kn.mlp_chain2_ok(xa.shape[0], xa.shape[1], wa, xb.shape[0], xb.shape[1], wb, xa.device))
     if not fits:
-        return mlp(xa, layers_a), mlp(xb, layers_b)
+        return None if exact_b else (mlp(xa, layers_a), mlp(xb, layers_b))
     params = [t for W, b, _ in layers_a for t in (W, b)] + [t for W, b, _ in layers_b for t in (W, b)]
-    return DualMLPFn.apply(xa, xb, relus, *params)
+    return DualMLPFn.apply(xa, xb, relus + ("exact_b",) if exact_b else relus, *params)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -637,12 +637,18 @@ def _chain_desc(x0, layers, M):
     _require_cuda(x0)
     d.x0, d.ld_x0 = x0.data_ptr(), x0.stride(0)
     flops, nbytes, k = 0.0, float(x0.numel() * 4), x0.shape[1]
-    for i, (W, bias, relu, mask, mscale, out) in enumerate(layers):
+    for i, lay in enumerate(layers):
+        W, bias, relu, mask, mscale, out = lay[:6]
+        W_lo = lay[6] if len(lay) > 6 else None          # (split operands: the remainders of W, same layout)
         if W.dtype != torch.bfloat16 or W.stride(1) != 1:
             raise _L.HulcKernelError("mlp_chain: weights are bf16 k-major shadows")
-        _require_cuda(W, bias, mask, out)
+        _require_cuda(W, bias, mask, out, W_lo)
         e = d.layers[i]
         e.W, e.ldw = W.data_ptr(), W.stride(0)
+        if W_lo is not None:
+            if W_lo.dtype != torch.bfloat16 or W_lo.shape != W.shape or W_lo.stride() != W.stride():
+                raise _L.HulcKernelError("mlp_chain: W_lo is laid out like W")
+            e.W_lo = W_lo.data_ptr()
         e.bias = bias.data_ptr() if bias is not None else None
         e.mask, e.ld_mask, e.mask_scale = (mask.data_ptr(), mask.stride(0), float(mscale)) if mask is not None else (None, 0, 1.0)
         e.out, e.ld_out, e.N, e.relu = out.data_ptr(), out.stride(0), int(W.shape[0]), int(bool(relu))

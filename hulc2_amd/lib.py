@@ -173,6 +173,7 @@ class MlpChainLayer(ctypes.Structure):
     """mirror of hulc_mlp_chain_layer (include/hulc2_amd.h)"""
     _fields_ = [
         ("W", ctypes.c_void_p), ("ldw", ctypes.c_long),
+        ("W_lo", ctypes.c_void_p),
         ("bias", ctypes.c_void_p),
         ("mask", ctypes.c_void_p), ("ld_mask", ctypes.c_long), ("mask_scale", ctypes.c_float),
         ("out", ctypes.c_void_p), ("ld_out", ctypes.c_long),

@@ -54,12 +54,17 @@ class LanguageGoalEncoder(nn.Module):
         m = self.mlp
         return [(m[1].weight, m[1].bias, True), (m[3].weight, m[3].bias, True), (m[5].weight, m[5].bias, False)]
 
+    def lo_operands(self):
+        """rounding remainders the split-operand forward of the paired goal launch reads (precision site "goal"; trainer-maintained)"""
+        m = self.mlp
+        return [(m[1].weight, "lo"), (m[3].weight, "lo"), (m[5].weight, "lo")]
+
     def embed(self, x):
         """list[str] -> (B, 384) where the encoder carries its language network; SBERT stays third-party"""
         return self.lang_net(x) if self.lang_net is not None else x
 
     def forward(self, x, pre_ln: bool = False) -> torch.Tensor:
-        y = HF.mlp(self.embed(x), self.mlp_layers())
+        y = HF.mlp(self.embed(x), self.mlp_layers(), x3=True)      # (precision site "goal": split-operand chain, the paired launch's arithmetic)
         if pre_ln:
             return y
         return HF.layer_norm(y, self.ln.weight, self.ln.bias, self.ln.eps)

@@ -158,10 +158,15 @@ class Hulc2(LightningModule):
                 # step with site "goal" it alone runs its forward exactly, the visual one stays on its bf16 chain launch
                 lang_only_exact = kn.base_mode() == "bf16" and kn.get_compute() == "bf16" and "goal" in kn.fp32_sites() and len(mods) == 2
                 if lang_only_exact:
-                    pre_v = self.visual_goal(emb_last, pre_ln=True)
-                    with kn.site_scope("goal"):
-                        pre_l = self.language_goal(mods[1][1]["lang"], pre_ln=True)
-                    pre = [pre_v, pre_l]
+                    # both encoders in ONE launch, the language one from split operands (three MFMAs per product: fp32-class values) ...
+                    pair = HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
+                                       self.language_goal.mlp_layers(), exact_b=True)
+                    if pair is None:        # ... or, where the pair does not fit the launch, on the exact-fp32 GEMMs
+                        pre_v = self.visual_goal(emb_last, pre_ln=True)
+                        with kn.site_scope("goal"):
+                            pre_l = self.language_goal(mods[1][1]["lang"], pre_ln=True)
+                        pair = (pre_v, pre_l)
+                    pre = list(pair)
                 with kn.site_scope("goal"):
                     # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
                     # directly (no concatenation, no strided gradient slices on the way back)

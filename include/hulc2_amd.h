@@ -406,6 +406,9 @@ int hulc_txl_block_bwd(const hulc_txl_block_desc* d, void* stream);
  * so one buffer serves all launches of a stream (a single launch, no memset). */
 typedef struct hulc_mlp_chain_layer {
     const void* W; long ldw;
+    const void* W_lo;                                /* (ABI 3) optional, on every layer of a chain or none: bf16 of the remainders w - bf16(w), laid out like W.
+                                                        The chain — the SECOND one of hulc_mlp_chain2, or a single chain of <= 32 rows — then forms its products
+                                                        from hi / lo splits of both operands (three MFMAs: fp32-class values; precision site "goal") */
     const float* bias;
     const float* mask; long ld_mask; float mask_scale;
     float* out; long ld_out;

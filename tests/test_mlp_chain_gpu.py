@@ -153,3 +153,37 @@ def test_paired_chain_falls_back_when_rows_do_not_fit(dev):
     assert type(ya.grad_fn).__name__.startswith("MLPFn")
     (ya.sum() + yb.sum()).backward()
     assert xa.grad is not None and lb[0].weight.grad is not None
+
+
+@pytest.mark.parametrize("Ma,Mb", [(32, 32), (7, 19)])
+def test_paired_chain_with_an_exact_second_stack(dev, Ma, Mb):
+    """hulc_mlp_chain_layer.W_lo (precision site "goal"): the SECOND chain of the paired launch forms its products from hi / lo splits of
+    both operands (three MFMAs) — its output agrees with fp32 torch to 2e-5 (plain bf16: ~3e-3) while the first chain's output is the
+    plain launch's, bit for bit; gradients come from the bf16 data-gradient chains as before"""
+    import copy
+    kn.set_compute("bf16")
+    da, db_ = (128, 2048, 2048, 32), (384, 2048, 2048, 32)
+    torch.manual_seed(9)
+    la = [torch.nn.Linear(a, b) for a, b in zip(da[:-1], da[1:])]
+    lb = [torch.nn.Linear(a, b) for a, b in zip(db_[:-1], db_[1:])]
+    xa0, xb0 = torch.randn(Ma, da[0]), torch.randn(Mb, db_[0])
+    h = xb0
+    for i, l in enumerate(lb):
+        h = l(h)
+        if i < len(lb) - 1:
+            h = torch.relu(h)
+    want_b = h.detach()
+    la, lb = [l.to(dev) for l in la], [l.to(dev) for l in lb]
+    layers = lambda ls: [(l.weight, l.bias, i < len(ls) - 1) for i, l in enumerate(ls)]
+    xa, xb = xa0.to(dev).requires_grad_(True), xb0.to(dev)
+    ya0, yb0 = HF.dual_mlp(xa, layers(la), xb, layers(lb))
+    pair = HF.dual_mlp(xa, layers(la), xb, layers(lb), exact_b=True)
+    assert pair is not None
+    ya, yb = pair
+    assert torch.equal(ya, ya0)
+    e0, e = _rel(yb0, want_b), _rel(yb, want_b)
+    print(f"second stack vs fp32: bf16 {e0:.2e}, split operands {e:.2e}")
+    assert e < 2e-5 and e < 0.02 * e0, (e, e0)
+    (ya.sum() + yb.sum()).backward()
+    assert xa.grad is not None and lb[0].weight.grad is not None and torch.isfinite(lb[0].weight.grad).all()
+    kn.check_faults(dev)
