@@ -80,7 +80,7 @@ def fp32_sites() -> frozenset:
     `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
     the fp32 matrix instruction.
     Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.4 %,
-    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.10 ms per step (3.50 -> 3.60);
+    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.06-0.10 ms per step (3.50 -> 3.58);
     `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost; `head,goal,encfc,txl,conv1,a3`: median
     0.84 % (worst 10 %: the conv stacks' own parameters) for +0.45 ms."""
     import os
