@@ -44,6 +44,7 @@ struct BandP {
     unsigned* bits_out;             // optional: ReLU sign planes of Y (forward): dword (co / 32) * bplane + pixel, bit = channel % 32
     const unsigned* bits_in;        // optional: sign planes used as the mask (data gradient) instead of `mask`
     int bshift; long bplane;        // log2(channels of the tensor the planes describe), pixels of that tensor: planes are [channels / 32][pixels]
+    int lds_band;                   // bytes of one LDS band (the second one of the double-buffered instances starts there)
     int dbg;                        // timing experiments (HULC_BAND_DBG): 1 skip the MFMA loop, 2 skip the output stores, 4 skip band staging
     BandCls cls[BAND_MAXCLS];
 };
@@ -64,7 +65,12 @@ HULC_DEVICE uint4 band_load_x(const void* X, long off) {
 // C: input channels, NSET: weight sets (32 output channels each), TH x TW taps, S: input stride, MAXCH: band chunks/thread
 // BITS: 0 = no sign planes, 1 = written from the epilogue (forward), 2 = read as the ReLU mask (data gradient) — compile-time: the kernel sits
 // at the 256-VGPR limit and a run-time switch cost every instance 20-60 bytes of scratch per lane
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32, int BITS>
+// DB: two LDS bands (round 4).  A unit's band is written while the PREVIOUS unit is still being multiplied — by every wave between the MFMA
+// loop and the epilogue of one of its tiles, i.e. before that tile's stores: the wait the compiler puts in front of the LDS write (vmcnt(0):
+// vector memory returns in order and the stores of the tile loop are counted with the loads) then covers the prefetch and stores that are a
+// tile old, not the write acknowledgements of the stores just issued (single band: +1.4 us per unit, HULC_BAND_DBG=2) — and one workgroup
+// barrier per unit instead of two.
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32, int BITS, bool DB>
 __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16;
@@ -72,11 +78,11 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     constexpr int WPS = 8 / NSET;           // waves per weight set
     constexpr int CPP = C / 8;              // 16-byte chunks per pixel
     static_assert(NT % CPP == 0, "a thread keeps one channel chunk");
-    extern __shared__ __attribute__((aligned(16))) char band[];
+    extern __shared__ __attribute__((aligned(16))) char band0[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int set = wave % NSET, part = wave / NSET;
+    const int set = wave % NSET, part = wave / NSET;           // wave-uniform (SGPRs): p.cls[set] is read with scalar loads
     const BandCls& cl = p.cls[set];
     // The class fields used inside the unit loop live in SGPRs: `set` comes from threadIdx, so p.cls[set] is a VECTOR load from the
     // kernel-argument segment, and under register pressure the compiler re-issued those loads inside the loop — each one consumed at
@@ -89,27 +95,6 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     const float inv_Wb = __builtin_amdgcn_rcpf((float)Wb), inv_OW = __builtin_amdgcn_rcpf((float)cl_OW);
     const int bands = (p.OHmax + p.R - 1) / p.R;
     const int nunits = MULTI ? (p.Nimg + p.F - 1) / p.F : p.Nimg * bands;
-
-    // ---- this wave's weight tile -> registers (A operand: lane = output channel row, 8 consecutive k)
-    bf16x8_t wfrag[KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int k0 = ks * 16 + h * 8;
-        const int t = k0 / C, c0 = k0 % C;
-        union { uint4 u; bf16x8_t b; } x;
-        x.u = band_load_bits(p.Wt, (cl.w_row0 + r) * p.ldw + cl.w_tap_off[t] + c0);
-        wfrag[ks] = x.b;
-    }
-
-    // bias of this set's 32 output channels: in LDS (the lane's 16 values would occupy 16 of the 256 VGPRs the weight tile, the prefetched
-    // band and the fragment read-ahead compete for); read back per tile behind the MFMA loop
-    __shared__ float sbias[BAND_MAXCLS * 32];
-    if (tid < NSET * 32) sbias[tid] = p.bias ? p.bias[p.cls[tid >> 5].co_base + (tid & 31)] : 0.f;
-
-    // The resident operands are complete before the unit loop starts.  Without this the compiler keeps "weight fragment k may still be
-    // in flight" alive around the loop and guards MFMA k of EVERY tile with s_waitcnt vmcnt(31 - k): harmless for the weights, but the
-    // small counts also drain the prefetch issued just before the tile (vector memory returns in order).
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) only
 
     // ---- band staging plan of this thread: chunk j covers band pixel (tid / CPP + j * NT / CPP), channel chunk tid % CPP
     const int cc = tid % CPP;
@@ -140,22 +125,78 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             pre_live = j == 0 ? (inb ? 1u : 0u) : (pre_live | ((inb ? 1u : 0u) << j));
         }
     };
-    auto stage_store = [&](int unit) {
+    auto stage_store = [&](int unit, char* band) {
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int npx = fu * rows * Wb;
+        // the thread id is made opaque here: inside the tile loop (double band) the compiler would otherwise compute the MAXCH LDS addresses
+        // and predicates once per unit and keep them in registers across the MFMA loops (spills at the 256-VGPR budget)
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int px0 = t2 / CPP, c2 = t2 % CPP;
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j) {
-            const int px = tid / CPP + j * (NT / CPP);
-            if (px < npx) *(uint4*)(band + px * PS + cc * 16) = ((pre_live >> j) & 1u) ? pre[j] : make_uint4(0, 0, 0, 0);
+            const int px = px0 + j * (NT / CPP);
+            if (px < npx) *(uint4*)(band + px * PS + c2 * 16) = ((pre_live >> j) & 1u) ? pre[j] : make_uint4(0, 0, 0, 0);
         }
     };
 
+    // ---- prologue (round 4).  Was: every wave fetched its own 32 x K weight tile straight into registers, lane r = row r — 36 load
+    // instructions per wave that each touch 32 rows (32 tag lookups for 1 KB), the same tile by every wave of a set, and the per-class tap
+    // offsets as vector loads in front of them: 288 KB through the CU's L1 per workgroup and ~9.5 us before the first MFMA of a launch
+    // (HULC_BAND_DBG=32 in round 3's build; twelve such launches per step).  Now the workgroup copies the NSET x 32 x K weights ONCE,
+    // coalesced (a load instruction = 64 / CPP rows of one tap, whole 64 / 128-byte runs; tap and set are wave-uniform, so the offsets
+    // are scalar loads), through registers into the (still empty) band area of the LDS, rows padded by 16 bytes, and every wave picks its
+    // fragments up with ds_read_b128; the first band's loads are requested in between and land while that happens.
+    constexpr int RPI = 64 / CPP;                            // weight rows one load instruction covers
+    constexpr int WITEMS = (32 / RPI) * TH * TW;             // load instructions per weight set
+    constexpr int NW = (WITEMS + WPS - 1) / WPS;             // ... per wave
+    constexpr int WS = K * 2 + 16;                           // LDS bytes per weight row
+    uint4 wtmp[NW];
+    {
+        const int wrow = lane / CPP, wc = lane % CPP;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS;                   // item = (row group, tap) of this wave's set; wave-uniform
+            const int itc = it < WITEMS ? it : WITEMS - 1;
+            const int rg = itc / (TH * TW), t = itc % (TH * TW);
+            wtmp[i] = band_load_bits(p.Wt, (cl.w_row0 + rg * RPI + wrow) * p.ldw + cl.w_tap_off[t] + wc * 8);
+        }
+    }
     int unit = blockIdx.x;
-    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    if (unit < nunits) stage_load(unit);
+    {
+        const int wrow = lane / CPP, wc = lane % CPP;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS;
+            if (it < WITEMS) {
+                const int rg = it / (TH * TW), t = it % (TH * TW);
+                *(uint4*)(band0 + (set * 32 + rg * RPI + wrow) * WS + (t * C + wc * 8) * 2) = wtmp[i];
+            }
+        }
+    }
+    // bias of this set's 32 output channels: in LDS (16 registers per lane otherwise); the accumulators start from it
+    __shared__ float sbias[BAND_MAXCLS * 32];
+    if (tid < NSET * 32) sbias[tid] = p.bias ? p.bias[p.cls[tid >> 5].co_base + (tid & 31)] : 0.f;
+    __syncthreads();
+    // ---- this wave's weight tile -> registers (A operand: lane = output channel row, 8 consecutive k)
+    bf16x8_t wfrag[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)(band0 + (set * 32 + r) * WS + (ks * 16 + h * 8) * 2);
+    // The resident operands are complete before the band area is overwritten (and before the unit loop: a fragment "possibly still in
+    // flight" would be guarded by a wait in front of every MFMA that uses it).
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) only
+    __syncthreads();
+
+    char* band = band0;
+    if (unit < nunits) stage_store(unit, band);
     __syncthreads();
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits && !(p.dbg & 4)) stage_load(next);                 // in flight during the MFMA loop below
+        const bool have_next = next < nunits && !(p.dbg & 4);
+        if (have_next) stage_load(next);                                     // in flight during the MFMA loop below
+        char* band_next = DB ? (band == band0 ? band0 + p.lds_band : band0) : band;
+        bool staged = !DB || !have_next;
 
         int n, fu, r0, R, rows; band_rows(unit, n, fu, r0, R, rows);
         const int Rc = r0 < cl_OH ? ((r0 + R <= cl_OH) ? R : cl_OH - r0) : 0;   // this class may have fewer rows/cols
@@ -169,9 +210,14 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             if (MULTI) { f = fast_div(q, __builtin_amdgcn_rcpf((float)fpix)); q -= f * fpix; }
             const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
             const char* a0 = band + ((f * rows + oy * S) * Wb + ox * S) * PS + h * 16;
+            // the accumulator starts as the bias (registers 4g..4g+3 = channels co_base + 8g + 4h + {0..3}): four LDS reads that travel with
+            // the first pixel fragments instead of four read -> wait -> add round trips in the epilogue
             f32x16_t acc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
+                acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+            }
             // the pixel's sign-plane word is requested before the MFMA loop (one dword per lane, both lane halves the same address): its
             // latency hides under the loop — the bf16 mask below is two 16-byte loads per lane consumed right where they are issued
             unsigned mb_in = 0;
@@ -211,8 +257,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 unsigned mb_out = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
-                    float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     if (p.add) {
                         const uint2 a = *(const uint2*)((const uint16_t*)p.add + off0 + 8 * g + 4 * h);
                         v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
@@ -224,6 +269,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                     }
                     pk[g] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
+                // (double band) the next band goes to LDS here — behind the wave's SECOND MFMA loop, with the tile packed into 8 registers and
+                // BEFORE its stores: the vmcnt(0) in front of the LDS write covers the prefetch and the previous tile's stores only
+                if (DB && !staged && tile >= part + WPS) { stage_store(next, band_next); staged = true; }
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
@@ -259,12 +307,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                     mb_out |= (unsigned)__shfl_xor((int)mb_out, 32);
                     if (live && h == 0) p.bits_out[(long)(cl_co >> 5) * p.bplane + ((off0 - cl_co) >> p.bshift)] = mb_out;   // 32 lanes: 128 contiguous bytes
                 }
-            } else if (live) {
+            } else {
+              if (DB && !staged && tile >= part + WPS) { stage_store(next, band_next); staged = true; }
+              if (live) {
                 const long off = off0 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
-                    float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+                    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -278,19 +327,26 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                     }
                     *(float4*)((float*)p.Y + off + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
                 }
+              }
             }
         }
-        __syncthreads();                                     // every wave is done reading this band
-        if (next < nunits && !(p.dbg & 4)) stage_store(next);
-        __syncthreads();
+        if (DB) {
+            if (!staged) stage_store(next, band_next);       // (a wave with fewer than two tiles in this unit)
+            __syncthreads();                                 // every wave is done reading this band and has written its part of the next
+            band = band_next;
+        } else {
+            __syncthreads();                                 // every wave is done reading this band
+            if (have_next) stage_store(next, band);
+            __syncthreads();
+        }
     }
 }
 
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32, int BITS>
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool XF32, int BITS, bool DB>
 int launch_band_x(BandP& p, hipStream_t s) {
     constexpr int PS = C * 2 + 16, CPP = C / 8;
     const int Wb = (p.OWmax - 1) * S + TW;
-    const long budget = 160 * 1024 - 1024;                   // (512 B of static LDS: the bias table)
+    const long budget = (160 * 1024 - 1024) / (DB ? 2 : 1) / 16 * 16;   // (512 B of static LDS: the bias table)
     const long max_px = (long)MAXCH * (512 / CPP);           // pixels one register-staged band can hold
     int R = p.OHmax;
     auto px_of = [&](int rr) { return (long)((rr - 1) * S + TH) * Wb; };
@@ -307,11 +363,14 @@ int launch_band_x(BandP& p, hipStream_t s) {
     }
     p.R = R; p.F = F;
     if ((long)F * R * p.OWmax < 128) return -1;              // a unit that cannot feed 8 waves: the gather kernel is faster
-    const size_t lds = (size_t)px_of(R) * F * PS;
+    p.lds_band = (int)(((size_t)px_of(R) * F * PS + 15) / 16 * 16);
+    size_t lds = (size_t)p.lds_band * (DB ? 2 : 1);
+    const size_t wbytes = (size_t)NSET * 32 * (TH * TW * C * 2 + 16);     // the prologue parks the weights in the band area
+    if (lds < wbytes) lds = wbytes;
     const int per = (nunits + 255) / 256;                    // balanced persistent grid
     const int grid = (nunits + per - 1) / per;
     if (F > 1) {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32, BITS>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, true, XF32, BITS, DB>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
@@ -319,7 +378,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
         }
         kern<<<grid, 512, lds, s>>>(p);
     } else {
-        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32, BITS>;
+        auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32, BITS, DB>;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
@@ -331,15 +390,27 @@ int launch_band_x(BandP& p, hipStream_t s) {
 }
 
 // BITS_OK: which sign-plane role this geometry is ever launched with (1: forward conv2 writes them, 2: the data gradients read them)
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, int BITS_OK>
-int launch_band(BandP& p, hipStream_t s) {
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, int BITS_OK, bool DB>
+int launch_band_db(BandP& p, hipStream_t s) {
     const int want = p.bits_out ? 1 : (p.bits_in ? 2 : 0);
     if (want && want != BITS_OK) return -1;
     if (want) {
         constexpr int B = BITS_OK ? BITS_OK : 1;
-        return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, B>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, B>(p, s);
+        return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, B, DB>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, B, DB>(p, s);
     }
-    return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, 0>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, 0>(p, s);
+    return p.x_dtype == HULC_F32 ? launch_band_x<C, NSET, TH, TW, S, MAXCH, true, 0, DB>(p, s) : launch_band_x<C, NSET, TH, TW, S, MAXCH, false, 0, DB>(p, s);
+}
+// MAXCH_DB: staging registers of the double-band instance — its bands are at most half the LDS, so fewer chunks per thread (and the registers
+// they would occupy are what keeps the instance from spilling the prefetch around its MFMA loops)
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, int BITS_OK, int MAXCH_DB>
+int launch_band(BandP& p, hipStream_t s) {
+    static const char* e = getenv("HULC_BAND_DB");
+    const bool db = e ? atoi(e) != 0 : false;               // (measured slower on every geometry of the policy: opt-in)
+    if (db) {
+        const int rc = launch_band_db<C, NSET, TH, TW, S, MAXCH_DB, BITS_OK, true>(p, s);
+        if (rc != -1) return rc;                             // (-1: half the LDS cannot hold a useful band — single band)
+    }
+    return launch_band_db<C, NSET, TH, TW, S, MAXCH, BITS_OK, false>(p, s);
 }
 
 }  // namespace
@@ -382,9 +453,9 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
         if (cls_OW[c] > p.OWmax) p.OWmax = cls_OW[c];
     }
     int rc = 1;
-    if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1>(p, s);        // conv2 forward (writes sign planes)
-    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10, 2>(p, s);   // conv3 forward / data gradient (reads them)
-    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12, 2>(p, s);   // conv2 data gradient, 4 parity classes
+    if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1, 7>(p, s);        // conv2 forward (writes sign planes)
+    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s);   // conv3 forward / data gradient (reads them)
+    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12, 2, 9>(p, s);   // conv2 data gradient, 4 parity classes
     else return 1;
     if (rc == -1) return 1;                      // band does not fit: gather kernel
     if (rc < 0) return hulc_fail(-8, "conv band: could not raise the dynamic LDS limit");

@@ -19,9 +19,16 @@ def clear() -> None:
     _sinks.clear()
 
 
-def register(param: torch.Tensor, grad_view: torch.Tensor) -> None:
+def unregister(keys) -> None:
+    """drop the sinks a trainer registered (its own keys only: another live trainer's sinks — an affordance model next to the policy — stay)"""
+    for k in keys:
+        _sinks.pop(k, None)
+
+
+def register(param: torch.Tensor, grad_view: torch.Tensor) -> int:
     key = id(param)
     _sinks[key] = (weakref.ref(param, lambda _r, k=key: _sinks.pop(k, None)), grad_view)
+    return key
 
 
 def get(param: torch.Tensor) -> Optional[torch.Tensor]:

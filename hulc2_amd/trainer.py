@@ -39,13 +39,17 @@ class GradComm:
                "bf16"   rounded to bf16 for the wire (half the bytes), widened back into the arena afterwards; changes the arithmetic
                         (gradients pick up one bf16 rounding, the sum of "direct" a second one), hence a switch
     Defaults (HULC_ALLREDUCE / HULC_GRAD_PAYLOAD override them):
-      payload  bf16 when world >= 4, fp32 below.  Rule: at 4+ ranks the all-reduce no longer fits under the conv backward it hides behind
-               (184 MB fp32 per step against a ~1.3 ms window), halving the bytes is worth one bf16 rounding of the summands —
-               rounding in the BACKWARD direction moves every gradient of this model by < 1 % (tools/study/bf16_emulation.py)
-      algo     "auto": on GPUs with world >= 2 both algorithms are TIMED once on the real fabric when the trainer is built (three reductions
-               of the full arena each, max over ranks) and the faster one is kept — whether RCCL's own multi-ring all-reduce or the direct
-               exchange wins on an 8-GPU xGMI mesh is a property of the node, not of this code; the probe's numbers go into bench.py's line.
-               On CPU (gloo) auto = ring."""
+      payload  fp32 at every world size — the reference's DDP all-reduce is fp32 (hulc2/training.py:72-75), and the arithmetic of the
+               gradients must not depend on how many ranks a job has.  bf16 is opt-in (HULC_GRAD_PAYLOAD=bf16 / grad_payload="bf16"): half the
+               bytes for one bf16 rounding of the summands; with bf16 and algo "auto" the exchange is always "direct" (hulc_sum_chunks
+               accumulates in fp32: one rounding) — "ring" with a bf16 buffer lets RCCL add in bf16 at every hop (W - 1 roundings) and runs
+               only when asked for by name.
+      algo     "auto" (fp32): on GPUs with world >= 2 both algorithms are TIMED once on the real fabric when the trainer is built (three
+               reductions of a 32 MB slice each, max over ranks; the ranks agree on every step of the probe before they enter a collective)
+               and the faster one is kept — whether RCCL's own multi-ring all-reduce or the direct exchange wins on an 8-GPU xGMI mesh is a
+               property of the node.  Ring and direct sum in different orders, so the choice is part of a run's numerics: it is printed
+               (bench.py's line, `describe()`), stored in ArenaTrainer.state_dict()["comm"], re-applied by load_state_dict, and pinned with
+               HULC_ALLREDUCE=ring|direct.  On CPU (gloo) auto = ring."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, algo: Optional[str] = None, payload: Optional[str] = None, force: bool = False):
         self.group = group
@@ -59,41 +63,75 @@ class GradComm:
         self.on_gpu = flat_grad.is_cuda
         self._bufs = {}
         self.probe_ms: Dict[str, float] = {}
+        self.chosen_by = "pinned"
         if self.algo == "auto":
             fabric = self.active and self.on_gpu and self.world > 1 and dist.get_backend(group) == "nccl"     # (gloo: host staging, nothing to tune)
-            self.algo = self._probe() if fabric else "ring"
+            if self.payload == "bf16":
+                self.algo, self.chosen_by = "direct", "rule (bf16 payload: fp32-accumulating exchange)"
+            elif fabric:
+                self.algo, self.chosen_by = self._probe(), "probe"
+            else:
+                self.algo, self.chosen_by = "ring", "rule (no fabric to probe)"
 
     @staticmethod
     def default_payload(world: int) -> str:
-        return "bf16" if world >= 4 else "fp32"
+        return "fp32"
+
+    def pin(self, algo: str) -> None:
+        """re-apply a recorded choice (ArenaTrainer.load_state_dict): a resumed run keeps the summation order it started with"""
+        if algo not in ("ring", "direct"):
+            raise ValueError(f"gradient all-reduce: cannot pin {algo!r}")
+        if algo != self.algo:
+            self.algo, self.chosen_by = algo, "checkpoint"
+            self._bufs = {}
+
+    def _agree(self, ok: bool) -> bool:
+        """True when EVERY rank says ok — a rank that failed locally (allocation) must not leave its peers alone inside a collective"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.flat_grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    PROBE_ELEMS = 8 << 20          # 32 MB of fp32 gradients: enough to be bandwidth-bound on xGMI, small next to the 288 GB
 
     def _probe(self) -> str:
-        """time both algorithms on the full arena (scratch copy: the gradients are not touched) and keep the faster; every rank sees the same
-        max-over-ranks timings, so every rank makes the same choice"""
+        """time both algorithms on a bounded scratch slice (the gradients are not touched) and keep the faster; every rank sees the same
+        max-over-ranks timings, so every rank makes the same choice.  Local failures (an allocation) are agreed on with an all_reduce(MIN)
+        BEFORE the ranks enter the algorithm's collectives; the staging buffers of the probe are dropped afterwards."""
         keep = self.flat_grad
-        self.flat_grad = torch.zeros_like(keep)
-        n = self.flat_grad.numel()
+        n = min(keep.numel(), self.PROBE_ELEMS)
+        scratch = None
+        try:
+            scratch = torch.zeros(n, dtype=keep.dtype, device=keep.device)
+        except Exception as e:                                      # noqa: BLE001
+            self.probe_error = f"scratch: {type(e).__name__}: {e}"
+        if not self._agree(scratch is not None):
+            return "ring"
+        self.flat_grad = scratch
         try:
             for algo in ("ring", "direct"):
                 self.algo = algo
+                ok = True
                 try:
-                    self.reduce(0, n)                               # warm-up: communicators, staging buffers
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        self.reduce(0, n)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / 3
-                except Exception as e:                              # noqa: BLE001 - an algorithm this fabric / build cannot run is simply not chosen
-                    ms = float("inf")
-                    self.probe_error = f"{algo}: {type(e).__name__}: {e}"
-                t = torch.tensor([ms], dtype=torch.float32, device=keep.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)      # (every rank sees the slowest rank's time, or inf)
+                    self.reserve()                                  # local: staging buffers of this algorithm
+                except Exception as e:                              # noqa: BLE001
+                    ok, self.probe_error = False, f"{algo}: {type(e).__name__}: {e}"
+                if not self._agree(ok):
+                    self.probe_ms[algo] = float("inf")
+                    continue
+                self.reduce(0, n)                                   # warm-up: communicators (an error HERE is every rank's error: it propagates)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.reduce(0, n)
+                e1.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([e0.elapsed_time(e1) / 3], dtype=torch.float32, device=keep.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)      # (every rank sees the slowest rank's time)
                 self.probe_ms[algo] = round(float(t.item()), 4)
         finally:
             self.flat_grad = keep
+            self._bufs = {}                                         # (reserve() re-creates what the chosen algorithm needs, at arena size)
         best = min(self.probe_ms, key=self.probe_ms.get)
         return best if self.probe_ms[best] != float("inf") else "ring"
 
@@ -102,7 +140,7 @@ class GradComm:
         n = self.flat_grad.numel()
         payload_bytes = n * (2 if self.payload == "bf16" else 4)
         sent = int(2 * (self.world - 1) / max(self.world, 1) * payload_bytes)
-        return {"algo": self.algo, "payload": self.payload, "gradient_bytes": payload_bytes, "bytes_sent_per_rank_per_step": sent,
+        return {"algo": self.algo, "chosen_by": self.chosen_by, "payload": self.payload, "gradient_bytes": payload_bytes, "bytes_sent_per_rank_per_step": sent,
                 "probe_ms": {k: (v if v != float("inf") else None) for k, v in self.probe_ms.items()},
                 **({"probe_error": self.probe_error} if getattr(self, "probe_error", None) else {})}
 
@@ -198,10 +236,17 @@ class GradBuckets:
             self.members[b] += 1
         self.handles = []
         self.overlap = overlap
+        self._hook_handles = []
         if self.active and overlap:
             for p in params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
         self.reset()
+
+    def close(self) -> None:
+        """remove the per-parameter hooks (a dead trainer's buckets must not keep launching all-reduces on its arena)"""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
 
     def reset(self):
         for i, b in enumerate(self.buckets):
@@ -453,14 +498,14 @@ class ArenaTrainer:
         self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap, comm=self.comm)
         # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
         kn.set_concurrent_streams(dev.type == "cuda" and self.multi and overlap)
-        gradsink.clear()
-        self._autograd_written, self._zero_planned, self._acc_hooks = set(), None, []
+        self._autograd_written, self._zero_planned, self._acc_hooks, self._sink_keys = set(), None, [], []
+        self._replan_pending = False
         if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
             for p, off in zip(self.params, self.offsets):
-                gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape))
+                self._sink_keys.append(gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape)))
                 self._acc_hooks.append(p.register_post_accumulate_grad_hook(self._saw_autograd_grad))
             for pv, gv, _, _ in self.fused:
-                gradsink.register(pv, gv)
+                self._sink_keys.append(gradsink.register(pv, gv))
         self.step_count = 0
         self.dev = dev
         if dev.type == "cuda":
@@ -529,6 +574,7 @@ class ArenaTrainer:
                                 "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
         words = kn.step_state(self.dev).tolist() if self.dev.type == "cuda" else [0, self.step_count]
         return {"state": st, "step": int(self.step_count), "rng_word": int(words[0]), "device_step": int(words[1]),
+                "comm": {"algo": self.comm.algo, "payload": self.comm.payload, "chosen_by": self.comm.chosen_by},
                 "hparams": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}}
 
     def load_state_dict(self, sd: Dict) -> None:
@@ -547,7 +593,10 @@ class ArenaTrainer:
                 self.exp_avg_sq[off:off + k].copy_(rec["exp_avg_sq"].reshape(-1))
         self.step_count = int(sd["step"])
         hp = sd.get("hparams", {})
-        self.lr, self.betas, self.eps, self.wd = hp.get("lr", self.lr), tuple(hp.get("betas", self.betas)), hp.get("eps", self.eps), hp.get("weight_decay", self.wd)
+        self._set_hparams(hp.get("lr", self.lr), hp.get("betas", self.betas), hp.get("eps", self.eps), hp.get("weight_decay", self.wd))
+        algo = (sd.get("comm") or {}).get("algo")
+        if algo in ("ring", "direct") and self.comm.active and not os.environ.get("HULC_ALLREDUCE"):
+            self.comm.pin(algo)                                   # a resumed run keeps the summation order it started with
         if self.dev.type == "cuda":
             kn.reset_step_state(self.dev, seed=int(sd["rng_word"]), step=int(sd.get("device_step", sd["step"])))
         self.refresh_shadows()
@@ -608,10 +657,20 @@ class ArenaTrainer:
         g0 = groups[0]
         if g0.get("amsgrad") or g0.get("maximize"):
             raise NotImplementedError("amsgrad / maximize are not built (conf/model/optimizer/adam.yaml uses neither)")
-        self.lr, self.betas, self.eps, self.wd = g0["lr"], tuple(g0["betas"]), g0["eps"], g0.get("weight_decay", 0.0)
+        self._set_hparams(g0["lr"], g0["betas"], g0["eps"], g0.get("weight_decay", 0.0))
         if self.dev.type == "cuda":
             kn.step_state(self.dev)[1] = self.step_count
         self.refresh_shadows()
+
+    def _set_hparams(self, lr, betas, eps, wd) -> None:
+        """lr / betas / eps / weight decay are scalar kernel arguments: a captured optimizer graph has the OLD ones baked in, so a change
+        after capture() drops the graphs — replay() then asks for a new capture() instead of silently stepping with the pre-load values
+        (the lr in a Lightning checkpoint is the scheduler's current value, not the constructor's)."""
+        new = (float(lr), tuple(float(b) for b in betas), float(eps), float(wd))
+        old = (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps), float(self.wd))
+        self.lr, self.betas, self.eps, self.wd = lr, tuple(betas), eps, wd
+        if new != old and getattr(self, "graph_opt", None) is not None:
+            self.graph_fb = self.graph_enc = self.graph_opt = None
 
     def close(self) -> None:
         """Detach this trainer from the model: the load_state_dict post-hook (which keeps the trainer, hence its four arenas, alive through the
@@ -622,16 +681,22 @@ class ArenaTrainer:
         for h in getattr(self, "_acc_hooks", ()):
             h.remove()
         self._acc_hooks = []
-        gradsink.clear()
+        b = getattr(self, "buckets", None)
+        if b is not None:
+            b.close()
+        gradsink.unregister(getattr(self, "_sink_keys", ()))       # this trainer's sinks only (another live trainer keeps its own)
+        self._sink_keys = []
 
     def _saw_autograd_grad(self, p) -> None:
         """post-accumulate hook: this parameter's gradient arrives through autograd's `grad +=` (not a kernel-side sink), so its arena slice must
-        be zeroed before every step.  One that shows up only after the zeroing plan was made invalidates the plan (full zero + re-plan next step)."""
+        be zeroed before every step.  One that shows up only after the zeroing plan was made asks for a new plan — through a flag that
+        optimizer_step() acts on AFTER its clean-up of this step: the backward that is running was started in overwrite mode and must be
+        finished in it (clearing the plan here skipped the clean-up of planned-but-unwritten sinks for this very step)."""
         k = id(p)
         if k not in self._autograd_written:
             self._autograd_written.add(k)
             if self._zero_planned is not None and k not in self._zero_planned:
-                self._zero_ranges = None
+                self._replan_pending = True
 
     def _keep_encoder_output(self, module, inputs, output):
         self._emb = output if (self._split_active and torch.is_tensor(output) and output.requires_grad) else None
@@ -708,9 +773,21 @@ class ArenaTrainer:
         elif self._zero_ranges is not None:
             # a sink the plan expects to be overwritten was not written by this backward (a branch of the model did not run): its slice
             # still holds the previous step's gradient — the true gradient is zero
-            for k in self._planned_written - gradsink.written_ids():
+            now = gradsink.written_ids()
+            for k in self._planned_written - now:
                 a, b = self._sink_slices[k]
                 self.flat_g[a:b].zero_()
+            # a sink written for the first time AFTER the plan was made (untouched in the planning step, so neither zeroed per step nor
+            # expected to be overwritten): from now on it is "expected" — a later step that does not write it gets the clean-up above
+            # instead of Adam applying the stale slice (second case)
+            new = {k for k in now if k in self._sink_slices} - self._planned_written
+            if new:
+                self._planned_written = self._planned_written | new
+            if self._replan_pending:
+                # a parameter autograd accumulates into showed up after the plan: its slice was zero when this backward started (unplanned
+                # slices are only ever written through sinks, and those are cleaned above), so THIS step's sum is right; the next step
+                # runs on a fully zeroed arena and the plan is re-made behind it
+                self._zero_ranges, self._replan_pending = None, False
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,

@@ -129,15 +129,19 @@ def _comm_worker(rank, world, port, out):
             same = all(torch.equal(gathered[0][5:n - 3], t[5:n - 3]) for t in gathered)     # replicas bit-identical after the reduce
             res[(algo, payload)] = (inside, outside, same)
     # defaults and the description bench.py prints: "auto" resolves to ring on CPU (the timing probe is for GPUs on a real fabric), the payload
-    # rule is fp32 below 4 ranks / bf16 from 4 on (HULC_GRAD_PAYLOAD overrides), bytes on the wire = 2 (W - 1) / W x payload
+    # is fp32 at EVERY world size like the reference's DDP (bf16 is opt-in: HULC_GRAD_PAYLOAD / grad_payload), bytes on the wire = 2 (W - 1) / W x payload
     for k in ("HULC_ALLREDUCE", "HULC_GRAD_PAYLOAD"):
         os.environ.pop(k, None)
     c = GradComm(torch.zeros(n), None)
     d = c.describe()
     res["defaults"] = (c.algo == "ring", c.payload == "fp32", d["gradient_bytes"] == 4 * n and d["bytes_sent_per_rank_per_step"] == 4 * n * (world - 1) * 2 // world)
-    c.world = 8                                            # (the rule itself, without eight processes)
-    os.environ["HULC_GRAD_PAYLOAD"] = ""
-    res["rule"] = (GradComm.default_payload(8) == "bf16", GradComm.default_payload(4) == "bf16", GradComm.default_payload(2) == "fp32")
+    res["rule"] = (GradComm.default_payload(8) == "fp32", GradComm.default_payload(4) == "fp32", GradComm.default_payload(2) == "fp32")
+    # an opted-in bf16 payload with algo "auto" takes the fp32-accumulating direct exchange (one rounding), never a bf16 ring chosen by a timer;
+    # the choice is recorded and can be re-applied (ArenaTrainer.load_state_dict -> pin)
+    cb = GradComm(torch.zeros(n), None, None, "bf16")
+    res["bf16_auto"] = (cb.algo == "direct", cb.describe()["chosen_by"].startswith("rule"), d["chosen_by"].startswith("rule"))
+    c.pin("direct")
+    res["pin"] = (c.algo == "direct", c.describe()["chosen_by"] == "checkpoint")
     if rank == 0:
         out.put(res)
     dist.destroy_process_group()
@@ -153,7 +157,7 @@ def test_gradient_allreduce_algorithms_world2():
         p.start()
     _join_or_end(procs, 120)
     res = q.get(timeout=5)
-    assert len(res) == 6
+    assert len(res) == 8
     for key, flags in res.items():
         assert all(flags), f"{key}: (sum correct, neighbours untouched, replicas identical) = {flags}"
 
