@@ -9,10 +9,16 @@
 
 namespace {
 
+// lo ranges (round 4): the rounding remainders w - bf16(w) of the weights a split-operand forward reads are written by THIS pass (the new
+// value is in registers) into a second shadow arena at the same offsets — they were a separate residual launch behind Adam (66-73 us per
+// step: a read of p and of the shadow for 6 M elements through 2-byte stores).  Up to 8 element ranges, multiples of 4, kernel arguments.
+struct LoRanges { int n; long b[8], e[8]; };
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
-                                                   const unsigned long long* __restrict__ step_state, const int* __restrict__ skip_flag) {
+                                                   const unsigned long long* __restrict__ step_state, const int* __restrict__ skip_flag,
+                                                   uint16_t* __restrict__ lo, LoRanges lr_) {
     if (skip_flag && *skip_flag) return;    // an upstream kernel reported a fault (barrier timeout): keep the weights, the host raises
     if (step_state) {                       // bias corrections from the device-resident step count (graph replay)
         const float t = (float)step_state[1];
@@ -39,6 +45,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             if (shadow) {
                 uint2 s; s.x = pack_bf16x2(pa[0], pa[1]); s.y = pack_bf16x2(pa[2], pa[3]);
                 *(uint2*)(shadow + i) = s;
+                if (lo) {
+                    bool in = false;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) in = in || (q < lr_.n && i >= lr_.b[q] && i < lr_.e[q]);
+                    if (in) {
+                        uint2 l;
+                        l.x = pack_bf16x2(pa[0] - __uint_as_float(s.x << 16), pa[1] - __uint_as_float(s.x & 0xFFFF0000u));
+                        l.y = pack_bf16x2(pa[2] - __uint_as_float(s.y << 16), pa[3] - __uint_as_float(s.y & 0xFFFF0000u));
+                        *(uint2*)(lo + i) = l;
+                    }
+                }
             }
         } else {
             for (long k = i; k < n; ++k) {
@@ -47,7 +64,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 m[k] = mm; v[k] = vv;
                 float pn = p[k] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
                 p[k] = pn;
-                if (shadow) shadow[k] = f32_to_bf16_bits(pn);
+                if (shadow) {
+                    const uint16_t hb = f32_to_bf16_bits(pn);
+                    shadow[k] = hb;
+                    if (lo) {
+                        bool in = false;
+                        for (int q = 0; q < lr_.n; ++q) in = in || (k >= lr_.b[q] && k < lr_.e[q]);
+                        if (in) lo[k] = f32_to_bf16_bits(pn - bf16_bits_to_f32(hb));
+                    }
+                }
             }
         }
     }
@@ -112,10 +137,10 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 // transposed bf16 copies of 2-D weights, all in one launch: tile q = {src offset, rows, cols, tile row, tile col} (64 x 64 tiles);
 // dst holds W^T ([cols][rows]) at the same offset.  Lets the data-gradient GEMMs dX = dY W stream W k-major.
-__global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
-                                                              const long* __restrict__ tiles, int ntiles) {
+HULC_DEVICE void transpose_tiles_job(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ tiles, int ntiles,
+                                     int first, int stride) {
     __shared__ __attribute__((aligned(16))) uint16_t t[64][72];
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = first; tile < ntiles; tile += stride) {
     const long* q = tiles + (long)tile * 5;
     const long off = q[0]; const int rows = (int)q[1], cols = (int)q[2], r0 = (int)q[3] * 64, c0 = (int)q[4] * 64;
     __syncthreads();                                                            // the previous tile's reads of t are done
@@ -161,13 +186,18 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __
     }
 }
 
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                              const long* __restrict__ tiles, int ntiles) {
+    transpose_tiles_job(src, dst, tiles, ntiles, blockIdx.x, gridDim.x);
+}
+
 // conv weight repacks (fp32 OIHW parameter -> bf16 kernel layouts), one workgroup column per table entry
-__global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ table) {
-    const long* q = table + (long)blockIdx.y * 7;
+HULC_DEVICE void repack_conv_job(const float* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ table, int entry, int sub, int nsub) {
+    const long* q = table + (long)entry * 7;
     const long so = q[0], d0 = q[1];
     const int Cout = (int)q[2], Cin = (int)q[3], KH = (int)q[4], KW = (int)q[5], mode = (int)q[6];
     const int n = Cout * Cin * KH * KW, taps = KH * KW;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = sub * blockDim.x + threadIdx.x; i < n; i += nsub * blockDim.x) {
         int o, c, t;                                      // destination index i -> (o, c, tap)
         if (mode == 0) { o = i / (Cin * taps); c = (i / taps) % Cin; t = i % taps; }
         else if (mode == 1) { o = i / (taps * Cin); t = (i / Cin) % taps; c = i % Cin; }
@@ -177,7 +207,34 @@ __global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void repack_conv_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ table) {
+    repack_conv_job(src, dst, table, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// (round 4) the transposed tiles and the conv repacks of a step as ONE launch: independent jobs on disjoint block ranges — the first nbt
+// workgroups walk the tiles, the rest are 128 workgroups per conv-table entry.  They were two launches (38 + 12 us) behind Adam.
+__global__ __launch_bounds__(256) void derive_copies_kernel(const uint16_t* __restrict__ bf16, uint16_t* __restrict__ bf16_t, const long* __restrict__ tiles,
+                                                            int ntiles, int nbt, const float* __restrict__ p32, uint16_t* __restrict__ conv_dst,
+                                                            const long* __restrict__ conv_table) {
+    const int b = blockIdx.x;
+    if (b < nbt) transpose_tiles_job(bf16, bf16_t, tiles, ntiles, b, nbt);
+    else repack_conv_job(p32, conv_dst, conv_table, (b - nbt) / 128, (b - nbt) % 128, 128);
+}
+
 }  // namespace
+
+extern "C" int hulc_derive_copies(const void* bf16, void* bf16_t, const long* tiles, int ntiles, const float* p32, void* conv_dst,
+                                  const long* conv_table, int nconv, void* stream) {
+    if (ntiles > 0 && (!bf16 || !bf16_t || !tiles)) return hulc_fail(-1, "hulc_derive_copies: null pointer (tiles)");
+    if (nconv > 0 && (!p32 || !conv_dst || !conv_table)) return hulc_fail(-1, "hulc_derive_copies: null pointer (conv table)");
+    if (ntiles < 0 || nconv < 0) return hulc_fail(-2, "hulc_derive_copies: negative count");
+    const int nbt = ntiles < 4096 ? ntiles : 4096;
+    const long grid = (long)nbt + (long)nconv * 128;
+    if (grid == 0) return 0;
+    derive_copies_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)bf16, (uint16_t*)bf16_t, tiles, ntiles, nbt, p32,
+                                                                         (uint16_t*)conv_dst, conv_table);
+    return hulc_check_launch("hulc_derive_copies");
+}
 
 extern "C" int hulc_step_state_advance_words(unsigned long long* state, int rng, int step, void* stream) {
     if (!state) return hulc_fail(-1, "hulc_step_state_advance: null pointer");
@@ -206,16 +263,40 @@ extern "C" int hulc_sum_chunks(const void* src, int dtype, int W, long chunk, vo
     return hulc_check_launch("hulc_sum_chunks");
 }
 
+extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                                 void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream);
+
 extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag, void* stream) {
+    return hulc_adam_step_lo(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, step_state, grad_scale, skip_flag, nullptr, nullptr, 0, stream);
+}
+
+// see include/hulc2_amd.h
+extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                                 void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream) {
     if (!p || !g || !m || !v) return hulc_fail(-1, "hulc_adam_step: null pointer");
+    LoRanges lr_;
+    lr_.n = 0;
+    for (int q = 0; q < 8; ++q) lr_.b[q] = lr_.e[q] = 0;
+    if (lo_shadow) {
+        if (!bf16_shadow || !lo_ranges || n_ranges < 1 || n_ranges > 8) return hulc_fail(-2, "hulc_adam_step_lo: lo_shadow needs bf16_shadow and 1..8 ranges");
+        if ((uintptr_t)lo_shadow % 8) return hulc_fail(-4, "hulc_adam_step_lo: lo_shadow must be 8-byte aligned");
+        for (int q = 0; q < n_ranges; ++q) {
+            if ((lo_ranges[2 * q] & 3) || lo_ranges[2 * q] < 0 || lo_ranges[2 * q + 1] < lo_ranges[2 * q] || lo_ranges[2 * q + 1] > n)
+                return hulc_fail(-2, "hulc_adam_step_lo: ranges must start at multiples of 4 inside the arena");
+            lr_.b[q] = lo_ranges[2 * q]; lr_.e[q] = lo_ranges[2 * q + 1];
+        }
+        lr_.n = n_ranges;
+    }
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return hulc_fail(-4, "hulc_adam_step: arenas must be 16-byte aligned");
     if (!step_state && step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
     if (step < 1) step = 1;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
-                                                                   bc1, bc2s, grad_scale, step_state, skip_flag);
+                                                                   bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_);
     return hulc_check_launch("hulc_adam_step");
 }
 
@@ -270,6 +351,38 @@ __global__ __launch_bounds__(256) void gather_chunks_kernel(const uint2* __restr
     dst[c] = (k >> 31) ? src1[k & 0x7fffffffu] : src0[k];
 }
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void gather_chunks2_kernel(const uint2* __restrict__ a0, const uint2* __restrict__ a1, uint2* __restrict__ ad,
+                                                            const unsigned* __restrict__ ai, long an, const uint2* __restrict__ b0,
+                                                            uint2* __restrict__ bd, const unsigned* __restrict__ bi, long bn) {
+    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long ablocks = (an + 255) / 256 * 256;
+    if (c < ablocks) {
+        if (c >= an) return;
+        const unsigned k = ai[c];
+        ad[c] = (k >> 31) ? a1[k & 0x7fffffffu] : a0[k];
+    } else {
+        c -= ablocks;
+        if (c >= bn) return;
+        bd[c] = b0[bi[c] & 0x7fffffffu];
+    }
+}
+}  // namespace
+
+// see include/hulc2_amd.h
+extern "C" int hulc_gather_chunks2(const void* a0, const void* a1, void* ad, const unsigned* ai, long an, const void* b0, void* bd,
+                                   const unsigned* bi, long bn, void* stream) {
+    if (an < 0 || bn < 0) return hulc_fail(-2, "hulc_gather_chunks2: negative count");
+    if (an > 0 && (!a0 || !ad || !ai)) return hulc_fail(-1, "hulc_gather_chunks2: null pointer (first gather)");
+    if (bn > 0 && (!b0 || !bd || !bi)) return hulc_fail(-1, "hulc_gather_chunks2: null pointer (second gather)");
+    if (((uintptr_t)a0 | (uintptr_t)a1 | (uintptr_t)ad | (uintptr_t)b0 | (uintptr_t)bd) % 8) return hulc_fail(-4, "hulc_gather_chunks2: arrays must be 8-byte aligned");
+    const long blocks = (an + 255) / 256 + (bn + 255) / 256;
+    if (blocks == 0) return 0;
+    gather_chunks2_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint2*)a0, (const uint2*)a1, (uint2*)ad, ai, an, (const uint2*)b0,
+                                                                            (uint2*)bd, bi, bn);
+    return hulc_check_launch("hulc_gather_chunks2");
+}
 
 // see include/hulc2_amd.h
 extern "C" int hulc_gather_chunks(const void* src0, const void* src1, void* dst, const unsigned* idx, long nchunks, void* stream) {

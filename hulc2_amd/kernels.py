@@ -1218,11 +1218,30 @@ def window_rows(store, starts, sizes, B, S, out, zero_cols=(0, 0)):
     return out
 
 
-def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None):
+def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None, lo=None, lo_ranges=()):
     """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device.  The update is skipped
-    on the device while the fault word is set (a barrier kernel timed out upstream) — check_faults() then raises on the host."""
-    _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
-          step_state_dev, _f(grad_scale), fault_word(p.device))
+    on the device while the fault word is set (a barrier kernel timed out upstream) — check_faults() then raises on the host.
+    lo (bf16 arena like shadow) + lo_ranges (<= 8 (begin, end) element ranges): the rounding remainders w - bf16(w) of the updated weights
+    inside the ranges are written by the same pass (hulc_adam_step_lo)."""
+    if lo is None or not lo_ranges:
+        _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
+              step_state_dev, _f(grad_scale), fault_word(p.device))
+        return
+    flat = [int(x) for r in lo_ranges for x in r]
+    arr = (_c.c_long * len(flat))(*flat)
+    _call("hulc_adam_step_lo", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
+          step_state_dev, _f(grad_scale), fault_word(p.device), lo, arr, _i(len(lo_ranges)))
+
+
+def derive_copies(bf16, bf16_t, tiles, p32, conv_dst, conv_table):
+    """the transposed tiles (bf16 -> bf16_t) and the conv repacks (p32 -> conv_dst) of a step as one launch; either table may be None"""
+    _call("hulc_derive_copies", bf16, bf16_t, tiles, _i(0 if tiles is None else tiles.shape[0]), p32, conv_dst, conv_table,
+          _i(0 if conv_table is None else conv_table.shape[0]))
+
+
+def gather_chunks2(a0, a1, ad, ai, b0, bd, bi):
+    """two 8-byte-chunk gathers as one launch: (a0 | a1 by bit 31 of ai) -> ad, b0 -> bd; either index tensor may be None"""
+    _call("hulc_gather_chunks2", a0, a1, ad, ai, _l(0 if ai is None else ai.numel()), b0, bd, bi, _l(0 if bi is None else bi.numel()))
 
 
 def cast_f32_to_bf16(src, dst, n):

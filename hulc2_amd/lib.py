@@ -12,6 +12,8 @@ import torch  # noqa: F401  -- must be imported BEFORE the CDLL below: torch shi
 #                              would bring a second HIP runtime into the process that owns no device context
 
 _LIB_PATH = Path(__file__).resolve().parent / "libhulc2_amd.so"
+if os.environ.get("HULC_LIB"):          # A/B measurements: another BUILD of the same library (e.g. the previous commit's), same ABI
+    _LIB_PATH = Path(os.environ["HULC_LIB"]).resolve()
 _lib = None
 
 

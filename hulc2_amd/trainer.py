@@ -429,11 +429,14 @@ class ArenaTrainer:
                     shadow.register_layout_view(p, name, self.frag_shadow[d0:d0 + n_el])
                 kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
         # rounding remainders w - bf16(w) of the weights a split-operand forward reads (modules list them in lo_operands(): natural layout
-        # "lo", packed "ffn_p0_lo" / "ffn_p1_lo"): one residual launch + one gather launch per step
-        self.lo_shadow = self.lo_seg = self.lo_frag = self.lo_frag_idx = None
+        # "lo", packed "ffn_p0_lo" / "ffn_p1_lo").  Round 4: a second shadow ARENA (same offsets as the bf16 shadow; 94 MB of the 288 GB) that
+        # the Adam kernel fills inside <= 8 element ranges while the new weights are in its registers — the separate residual launch
+        # (66-73 us per step) is only used when weights are written from outside (refresh_shadows)
+        self.flat_lo = self.lo_seg = self.lo_frag = self.lo_frag_idx = None
+        self.lo_ranges = []
         if self.flat_bf16 is not None:
             off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
-            segs, nat, packed, dst = [], {}, [], 0
+            segs, nat, packed = [], {}, []
             for m in model.modules():
                 if not hasattr(m, "lo_operands"):
                     continue
@@ -442,19 +445,30 @@ class ArenaTrainer:
                     if off is None or off % 4 or id(p) in member:
                         continue
                     if id(p) not in nat:
-                        nat[id(p)] = (p, dst)
-                        segs.append((off, p.numel(), dst))
-                        dst += (p.numel() + 3) // 4 * 4
+                        nat[id(p)] = (p, off)
+                        segs.append((off, p.numel(), off))
                     if layout not in ("lo", "oihw_flat_lo"):
                         packed.append((p, layout))
             if segs:
                 import numpy as np
-                self.lo_shadow = torch.zeros(dst, dtype=torch.bfloat16, device=dev)
+                self.flat_lo = torch.zeros(total, dtype=torch.bfloat16, device=dev)
                 self.lo_seg = torch.tensor(segs, dtype=torch.int64, device=dev)
+                ranges = sorted([a, a + (n + 3) // 4 * 4] for a, n, _ in segs)      # (offsets are multiples of 8: the padding is the slice's own)
+                merged = []
+                for a, b in ranges:
+                    if merged and a <= merged[-1][1]:
+                        merged[-1][1] = max(merged[-1][1], b)
+                    else:
+                        merged.append([a, b])
+                while len(merged) > 8:                       # the kernel takes 8: close the smallest gaps (remainders of the weights between
+                    gi = min(range(len(merged) - 1), key=lambda i: merged[i + 1][0] - merged[i][1])   # them are written too: harmless)
+                    merged[gi][1] = merged[gi + 1][1]
+                    del merged[gi + 1]
+                self.lo_ranges = [(a, min(b, total)) for a, b in merged]
                 for p, d0 in nat.values():
-                    shadow.register_layout_view(p, "lo", self.lo_shadow[d0:d0 + p.numel()].view(p.shape))
+                    shadow.register_layout_view(p, "lo", self.flat_lo[d0:d0 + p.numel()].view(p.shape))
                     if p.dim() == 4:                        # conv weight: its OIHW-flat remainder is the same memory
-                        shadow.register_layout_view(p, "oihw_flat_lo", self.lo_shadow[d0:d0 + p.numel()].view(p.shape[0], -1))
+                        shadow.register_layout_view(p, "oihw_flat_lo", self.flat_lo[d0:d0 + p.numel()].view(p.shape[0], -1))
                 chunks, views, fdst = [], [], 0
                 for p, layout in packed:
                     n = int(layout[5])
@@ -532,10 +546,11 @@ class ArenaTrainer:
         self._emb = None
 
     def _refresh_lo(self) -> None:
+        """the remainders from scratch (weights written from outside; the optimizer step keeps them fresh inside the Adam kernel)"""
         if self.lo_seg is not None:
-            kn.residual_bf16(self.flat_p, self.flat_bf16, self.lo_shadow, self.lo_seg)
+            kn.residual_bf16(self.flat_p, self.flat_bf16, self.flat_lo, self.lo_seg)
             if self.lo_frag_idx is not None:
-                kn.gather_chunks(self.lo_shadow, None, self.lo_frag, self.lo_frag_idx)
+                kn.gather_chunks(self.flat_lo, None, self.lo_frag, self.lo_frag_idx)
 
     # ---- weights written from outside (checkpoint restore) and optimizer state ----------------------------------------------------
     def refresh_shadows(self) -> None:
@@ -791,14 +806,13 @@ class ArenaTrainer:
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,
-                     step_state_dev=kn.step_state(self.dev))      # step count lives on the device (graph replay)
-        if self.tiles_t is not None:
-            kn.transpose_bf16_tiles(self.flat_bf16, self.flat_bf16_t, self.tiles_t)
-        if self.frag_idx is not None:
-            kn.gather_chunks(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx)
-        self._refresh_lo()
-        if self.conv_table is not None:
-            kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
+                     step_state_dev=kn.step_state(self.dev),       # step count lives on the device (graph replay)
+                     lo=self.flat_lo, lo_ranges=self.lo_ranges)    # (the split operands' remainders come out of the same pass)
+        # the derived copies: two launches behind Adam (were five: transposed tiles, fragment gather, residual, remainder gather, conv repack)
+        if self.tiles_t is not None or self.conv_table is not None:
+            kn.derive_copies(self.flat_bf16, self.flat_bf16_t, self.tiles_t, self.flat_p, self.conv_shadow, self.conv_table)
+        if self.frag_idx is not None or self.lo_frag_idx is not None:
+            kn.gather_chunks2(self.flat_bf16, self.flat_bf16_t, self.frag_shadow, self.frag_idx, self.flat_lo, self.lo_frag, self.lo_frag_idx)
         shadow.bump_epoch()
 
     def _forward_backward(self, batch, batch_idx: int) -> torch.Tensor:

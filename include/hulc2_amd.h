@@ -566,6 +566,13 @@ int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* stream);
 int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
                    void* stream);   /* skip_flag (optional device word): non-zero = leave parameters and moments untouched (kernel fault upstream) */
+/* (ABI 4) The same step, additionally writing the ROUNDING REMAINDERS lo = bf16(w - float(bf16(w))) of the updated weights into a second
+ * shadow arena (same element offsets as bf16_shadow) inside up to 8 element ranges lo_ranges[2 i] <= k < lo_ranges[2 i + 1] (HOST array,
+ * starts multiples of 4): the second halves of the split operands of the fp32-class forwards (conv1, transformer trunk, camera heads,
+ * language goal encoder).  Replaces the separate hulc_residual_bf16 launch behind the optimizer. */
+int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                      void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream);
 /* Device-resident step state {rng word, optimizer step count}: advanced by one kernel per training step so that
  * a captured hipGraph replays with fresh dropout masks / plan samples and the right Adam bias correction.
  * RNG kernels xor state[0] into their site seed (seed_dev = state); hulc_adam_step reads state[1] when
@@ -599,6 +606,13 @@ int hulc_residual_bf16(const float* p32, const void* hi, void* lo, const long* s
  * KH, KW, mode}; mode 0 = OIHW flat (conv1 forward), 1 = OHWI (NHWC forward, k = (kh,kw,c)), 2 = IHWO (data gradient,
  * rows = input channel, k = (kh,kw,cout)).  Replaces a permute copy + cast per layer and layout. */
 int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream);
+/* (ABI 4) hulc_transpose_bf16_tiles and hulc_repack_conv_weights of a step as ONE launch (independent jobs on disjoint workgroup ranges);
+ * either half may be empty (count 0). */
+int hulc_derive_copies(const void* bf16, void* bf16_t, const long* tiles, int ntiles, const float* p32, void* conv_dst, const long* conv_table,
+                       int nconv, void* stream);
+/* (ABI 4) two chunk gathers as ONE launch: the first as hulc_gather_chunks (sources a0 / a1), the second from the single source b0. */
+int hulc_gather_chunks2(const void* a0, const void* a1, void* ad, const unsigned* ai, long an, const void* b0, void* bd, const unsigned* bi,
+                        long bn, void* stream);
 
 #ifdef __cplusplus
 }

@@ -159,3 +159,60 @@ def test_transposed_shadow_tiles(dev, shapes):
     for (r, c), off in zip(shapes, offs):
         want = src[off:off + r * c].view(r, c).t().contiguous().view(-1)
         assert torch.equal(dst[off:off + r * c], want), (r, c)
+
+
+def test_derived_copies_after_a_step_equal_a_fresh_derivation(dev):
+    """Round 4: the Adam kernel writes the split operands' rounding remainders itself (hulc_adam_step_lo, <= 8 element ranges of a second shadow
+    arena) and the other derived weight copies come from two launches (hulc_derive_copies: transposed tiles + conv repacks; hulc_gather_chunks2:
+    fragment-packed copies of the shadow and of the remainders).  After optimizer steps every derived copy must be bit-identical to what
+    refresh_shadows() derives from the fp32 arena with the single-purpose kernels (cast, transpose, gather, residual, repack)."""
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.trainer import ArenaTrainer
+
+    kn.set_compute("bf16")
+    m = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+    syn.fill_state_dict_(m.state_dict(), 3)
+    m.train()
+    tr = ArenaTrainer(m, lr=2e-4)
+    assert tr.flat_lo is not None and 1 <= len(tr.lo_ranges) <= 8 and tr.lo_frag_idx is not None
+    batch = syn.make_batch(9, 2, 8, device=dev)
+    kn.reset_step_state(dev)
+    for i in range(3):
+        tr.step(batch, i)
+    torch.cuda.synchronize()
+    names = ["flat_bf16", "flat_bf16_t", "frag_shadow", "lo_frag", "conv_shadow"]
+    got = {n: getattr(tr, n).clone() for n in names}
+    lo_got = tr.flat_lo.clone()
+    tr.refresh_shadows()
+    torch.cuda.synchronize()
+    for n in names:
+        assert torch.equal(got[n].view(torch.int16), getattr(tr, n).view(torch.int16)), n
+    # the remainders: identical on every registered operand (between merged ranges the fused pass may write more than the operands)
+    for off, cnt, _ in tr.lo_seg.tolist():
+        assert torch.equal(lo_got[off:off + cnt].view(torch.int16), tr.flat_lo[off:off + cnt].view(torch.int16)), off
+    # and they are what they claim to be: hi + lo reproduces the fp32 weight to ~2^-17 relative
+    off, cnt, _ = max(tr.lo_seg.tolist(), key=lambda r: r[1])
+    w = tr.flat_p[off:off + cnt]
+    err = (w - (tr.flat_bf16[off:off + cnt].float() + tr.flat_lo[off:off + cnt].float())).abs().max() / w.abs().max()
+    assert float(err) < 2e-5, float(err)
+
+
+def test_adam_lo_ranges_are_validated(dev):
+    """hulc_adam_step_lo refuses more than 8 ranges / unaligned starts (error code + message, no launch)"""
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.lib import HulcKernelError
+    n = 64
+    p, g, mm, v = (torch.zeros(n, device=dev) for _ in range(4))
+    sh, lo = torch.zeros(n, dtype=torch.bfloat16, device=dev), torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(HulcKernelError):
+        kn.adam_step(p, g, mm, v, sh, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, lo=lo, lo_ranges=[(2, 8)])
+    with pytest.raises(HulcKernelError):
+        kn.adam_step(p, g, mm, v, sh, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, lo=lo, lo_ranges=[(4 * i, 4 * i + 4) for i in range(9)])
+    g.fill_(1.0)
+    kn.adam_step(p, g, mm, v, sh, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, lo=lo, lo_ranges=[(8, 16), (32, 64)])
+    torch.cuda.synchronize()
+    want = (p - sh.float()).to(torch.bfloat16)
+    inside = torch.zeros(n, dtype=torch.bool, device=dev)
+    inside[8:16] = True
+    inside[32:64] = True
+    assert torch.equal(lo[inside].view(torch.int16), want[inside].view(torch.int16)) and float(lo[~inside].float().abs().max()) == 0.0
