@@ -3,8 +3,9 @@ produced by the reference's own modules and (b) the CPU oracle on the same seede
 
 Tolerances (north_star: 1e-3 relative to the fp32 reference):
   fp32 compute (exact-fp32 MFMA)  : 1e-4 of the tensor's max-abs for activations, 1e-3 for gradients
-  bf16 compute (bf16 MFMA, fp32 accumulate; the benchmarked mode): 3e-2 of max-abs for activations, 2e-3 relative
-    for the scalar losses, 0.15 relative L2 for gradients.  bf16 operands carry 8 mantissa bits, so element-wise
+  bf16 compute (bf16 MFMA, fp32 accumulate; the benchmarked mode): 2e-2 of max-abs for activations (2e-3 for the LayerNorm-ed
+    embeddings), 2e-4 relative for the scalar losses, 0.15 relative L2 for gradients — and, on the benchmarked configuration at full
+    size, the per-mode BARS table of test_benchmarked_config_against_oracle (headline: median <= 5 %, worst <= 10 %).  bf16 operands carry 8 mantissa bits, so element-wise
     1e-3 is not reachable; the gradient bound is calibrated against torch.autocast(bfloat16) run on the oracle graph
     (same fixtures: conv1 weight-gradient 7.7 % L2 / conv3 14 % max-abs off the fp32 reference) — DESIGN.md §5.
 Gradients are compared in relative L2 (||a-b|| / ||b||), activations in max-abs relative to the tensor's max-abs.
@@ -26,9 +27,12 @@ from hulc2_amd.compat import instantiate  # noqa: E402
 from hulc2_amd.config import default_model_config  # noqa: E402
 
 G = ROOT / "tests" / "golden"
-TOL = {"fp32": dict(act=1e-4, grad=1e-3, loss=1e-4), "bf16": dict(act=3e-2, grad=0.15, loss=2e-3),
+# flat tolerances of the module / fixture tests = the largest error this build measures in any of them on an MI355X with <= 2x head-room
+# (round 4; bf16 was act 3e-2 / loss 2e-3): activations 8.9e-3 (spatial softmax coordinates), LayerNorm-ed embeddings 8.4e-4, losses 9.5e-5
+# (KL at B = 2), gradients 9.3 % (conv1 weight of the static camera; torch.autocast(bfloat16) on the oracle graph: 7.7 %)
+TOL = {"fp32": dict(act=1e-4, emb=3e-4, grad=1e-3, loss=1e-4), "bf16": dict(act=2e-2, emb=2e-3, grad=0.15, loss=2e-4),
        # 'mixed' (kernels.set_compute): exact-fp32 forward upstream of the contrastive head, bf16 backward + bf16 recurrent decoder
-       "mixed": dict(act=1e-4, grad=0.01, loss=2e-3)}
+       "mixed": dict(act=1e-4, emb=3e-4, grad=0.01, loss=2e-4)}
 
 
 def load(name):
@@ -78,7 +82,7 @@ def test_vision_encoders(dev, model, mode, tag, hw):
     x = (torch.rand(n, 3, hw, hw, generator=syn._gen(seed, "x." + tag)) * 2 - 1).to(dev)
     net = model.perceptual_encoder.rgb_static_encoder if tag == "vision_static" else model.perceptual_encoder.rgb_gripper_encoder
     out = net(x)
-    close(out, fx["out"], t["act"] * 3, "encoder output")        # LayerNorm output (unit scale) amplifies relative error
+    close(out, fx["out"], t["emb"], "encoder output")            # LayerNorm output (unit scale)
     if tag == "vision_static":
         close(net.spatial_softmax.coords, fx["ssm"], t["act"], "spatial softmax")
     r = torch.randn(out.shape, generator=syn._gen(seed, "r." + tag)).to(dev)
@@ -104,8 +108,8 @@ def test_goal_encoders_and_proposal(dev, model, mode):
     xv = torch.randn(B, 128, generator=syn._gen(seed, "x.visual_goal")).to(dev).requires_grad_()
     xl = (torch.randn(B, 384, generator=syn._gen(seed, "x.language_goal")) * 0.05).to(dev).requires_grad_()
     ov, ol = model.visual_goal(xv), model.language_goal(xl)
-    close(ov, fx["out_vis"], t["act"] * 3, "visual goal")
-    close(ol, fx["out_lang"], t["act"] * 3, "language goal")
+    close(ov, fx["out_vis"], t["act"], "visual goal")
+    close(ol, fx["out_lang"], t["act"], "language goal")
     rv = torch.randn(B, 32, generator=syn._gen(seed, "r.visual_goal")).to(dev)
     rl = torch.randn(B, 32, generator=syn._gen(seed, "r.language_goal")).to(dev)
     ((ov * rv).sum() + (ol * rl).sum()).backward()
@@ -321,7 +325,7 @@ def test_clip_loss(dev, model, mode):
     feat = torch.randn(B, 4096, generator=syn._gen(seed, "x.clip.feat")).to(dev).requires_grad_()
     goal = torch.randn(B, 32, generator=syn._gen(seed, "x.clip.goal")).to(dev).requires_grad_()
     loss = model.clip_auxiliary_loss(feat, goal, torch.tensor(fx["use"]).to(dev))
-    close(loss, fx["loss"], t["loss"] * 5, "clip loss")
+    close(loss, fx["loss"], t["loss"], "clip loss")
     # batch_size["aux_lang"] (hulc2.py:391-394): the number of masked-in rows, counted on the device by the loss kernel
     assert float(model._aux_lang_rows) == float(int(fx["use"].sum())) and model._aux_lang_rows.is_cuda and not model._aux_lang_rows.requires_grad
     loss.backward()
@@ -346,12 +350,12 @@ def test_whole_training_step(dev, model, mode, B, S):
     for h in hooks:
         h.remove()
     close(total, fx["total_loss"], t["loss"], "total loss")
-    close(model.logged["train/kl_loss"], fx["kl_loss"], t["loss"] * 5, "kl loss")
+    close(model.logged["train/kl_loss"], fx["kl_loss"], t["loss"], "kl loss")
     close(model.logged["train/action_loss"], fx["action_loss"], t["loss"], "action loss")
-    close(model.logged["train/lang_clip_loss"] / 3.0, fx["clip_loss"], t["loss"] * 5, "clip loss")
+    close(model.logged["train/lang_clip_loss"] / 3.0, fx["clip_loss"], t["loss"], "clip loss")
     embs = torch.cat(list(taps["emb"]), dim=0)      # one batched call (rows modality-major) or one call per modality
-    close(embs[:B], fx["emb_vis"], t["act"] * 3, "perceptual emb vis")
-    close(embs[B:], fx["emb_lang"], t["act"] * 3, "perceptual emb lang")
+    close(embs[:B], fx["emb_vis"], t["emb"], "perceptual emb vis")
+    close(embs[B:], fx["emb_lang"], t["emb"], "perceptual emb lang")
     total.backward()
     names = [str(n) for n in fx["grad_names"]]
     P = dict(model.named_parameters())
@@ -367,12 +371,13 @@ def test_whole_training_step(dev, model, mode, B, S):
         # projection-head gradients are only loosely bounded in bf16 mode at B=2 (fp32 mode keeps the tight bound)
         lim = t["grad"] * 2 if not (mode == "bf16" and (n.startswith("proj_vis_lang") or n == "logit_scale")) else 0.6
         assert rel <= lim, f"grad norm {n}: {got:.6e} vs {ref:.6e} (rel {rel:.2e})"
-    close(P["perceptual_encoder.rgb_static_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_static"], t["grad"] * 2, "g conv1 static")
+    close(P["perceptual_encoder.rgb_static_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_static"], t["grad"], "g conv1 static")
     # the reference's own fp32 value of this tensor is 2.7e-3 (relative L2) away from the float64 evaluation of the same
     # graph (measured with the oracle in float64, B=2 S=16: ill-conditioned sum over four consumers of the gripper half)
-    close(P["perceptual_encoder.rgb_gripper_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_gripper"], max(t["grad"] * 2, 6e-3), "g conv1 gripper")
+    close(P["perceptual_encoder.rgb_gripper_encoder.conv_model.0.weight"].grad, fx["g_conv0_w_gripper"], max(t["grad"], 6e-3), "g conv1 gripper")
+    # two samples: the position embedding's gradient is a 64-token sum that cancels (bf16: 27 % at S = 16, 12 % at S = 32; 4.6 % median at B = 32)
     close(P["plan_recognition.position_embeddings.weight"].grad, fx["g_pos"], t["grad"] * 2, "g pos")
-    close(P["action_decoder.gripper_fc.weight"].grad, fx["g_grip_w"], t["grad"] * 2, "g gripper_fc")
+    close(P["action_decoder.gripper_fc.weight"].grad, fx["g_grip_w"], t["grad"], "g gripper_fc")
 
 
 def _oracle_batch(raw):
@@ -383,6 +388,25 @@ def _oracle_batch(raw):
         if m == "lang":
             ob[m].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
     return ob
+
+
+# What every arithmetic mode is HELD to on the benchmarked configuration, stated here in the test (the flat tolerances did
+# not state the bar, a builder-recorded file did).  Losses / embeddings: max-abs relative; gradients: relative L2 per tensor — `worst` bounds
+# every tensor upstream of (or inside) the networks the contrastive gradient reaches, `down` the tensors it does not reach (decoder, prior,
+# visual goal encoder), `med` the median over all tensors.  Values = what this build measures on an MI355X with <= 2x head-room, except the
+# headline row, which is the bar itself: median <= 5 %, worst <= 10 %.  tests/golden/error_budget.json stays on top as the regression
+# ratchet (every tensor also within 1.5x of its recorded error).
+BARS = {
+    # (mode, B, clip)            losses      embeddings  median      worst        downstream worst
+    ("bf16", 32, True): dict(loss=1e-4, emb=2e-3, med=0.05, worst=0.10, down=0.04),           # measured 4.8 % / 9.4 % / 2.0 %
+    ("bf16", 32, False): dict(loss=1e-4, emb=2e-3, med=0.015, worst=0.33, down=0.04),         # measured 0.6 % / 16.4 % (static conv biases) / 2.0 %
+    ("bf16", 2, True): dict(loss=1e-4, emb=2e-3, med=0.03, worst=0.19, down=0.12),            # measured 1.5 % / 9.3 % / 5.7 %
+    ("bf16+sites", 32, True): dict(loss=1e-4, emb=2e-3, med=0.02, worst=0.20, down=0.04),     # measured 0.86 % / 10 % / 2.0 %
+    ("mixed", 32, True): dict(loss=1e-4, emb=1e-5, med=0.013, worst=0.021, down=0.016),       # measured 0.65 % / 1.04 % / 0.8 %
+    # fp32: north_star's 1e-3 holds for every tensor but two of the gripper conv1 / static conv2 weights (1.8e-3) — the reference's own fp32
+    # gradient of that tensor is 2.7e-3 away from the float64 evaluation of the same graph (measured noise floor)
+    ("fp32", 32, True): dict(loss=1e-5, emb=1e-5, med=1e-3, worst=3e-3, down=1.6e-3),
+}
 
 
 @pytest.mark.parametrize("B,S,clip,cmode", [(2, 16, True, "bf16"), (32, 32, True, "bf16"), (32, 32, False, "bf16"), (32, 32, True, "fp32"),
@@ -407,10 +431,12 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode, monkeypatch):
       fp32   (exact everywhere, 18.8 ms/step): every tensor <= 2e-3
     Yardstick: the reference's own `precision: 16` autocast, emulated by the same tool (HULC_EMU_HALF=fp16), is median 6.7 % / worst 26 % from
     this fp32 oracle on this batch.
-    The flat allowance of round 2 (0.6) is gone: bf16 tensors fed by the contrastive gradient are held to 0.15 AND to 1.5 x their recorded value."""
+    Round 4: the bars are the BARS table above (per mode: losses, embeddings, median / worst / downstream-worst gradient error, asserted in
+    this body); the recorded-error file is a regression ratchet on top of them, not the statement of the bar."""
     from hulc2_amd import kernels as kn, param_spec
     from oracle import hulc2_oracle as O
 
+    bar = BARS[(cmode, B, clip)]
     sites_all = cmode == "bf16+sites"
     if sites_all:                  # the bf16 step with every cheap exact-forward site on: + conv1 as split operands, + the conv stacks' output in fp32
         monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl,conv1,a3")
@@ -447,25 +473,21 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode, monkeypatch):
         out["total_loss"].backward()
     finally:
         torch.set_num_threads(nthreads)
-    close(total, out["total_loss"], t["loss"], "total loss")
-    close(m.logged["train/kl_loss"], out["kl_loss"], t["loss"] * 5, "kl loss")
-    close(m.logged["train/action_loss"], out["action_loss"], t["loss"], "action loss")
+    close(total, out["total_loss"], bar["loss"], "total loss")
+    close(m.logged["train/kl_loss"], out["kl_loss"], bar["loss"], "kl loss")
+    close(m.logged["train/action_loss"], out["action_loss"], bar["loss"], "action loss")
     if clip:
-        close(m.logged["train/lang_clip_loss"] / 3.0, out["clip_loss"], t["loss"] * 5, "clip loss")
+        close(m.logged["train/lang_clip_loss"] / 3.0, out["clip_loss"], bar["loss"], "clip loss")
     embs = torch.cat(taps, dim=0)
-    close(embs[:B], out["emb_vis"], t["act"] * 3, "perceptual emb vis")
-    close(embs[B:], out["emb_lang"], t["act"] * 3, "perceptual emb lang")
+    close(embs[:B], out["emb_vis"], bar["emb"], "perceptual emb vis")
+    close(embs[B:], out["emb_lang"], bar["emb"], "perceptual emb lang")
     downstream = ("action_decoder.", "plan_proposal.", "visual_goal.", "plan_recognition.fc_state")      # not fed by the contrastive gradient
     failures = []
     for n, ref in sd.items():
         if ref.grad is None:
             assert P[n].grad is None or float(P[n].grad.abs().max()) == 0.0, n
             continue
-        lim = t["grad"] * 2
-        if cmode == "bf16" and clip and not n.startswith(downstream):
-            lim = 0.15                                             # cancellation-amplified forward rounding of the conv stacks (docstring: worst 9.4 %); pinned by the error budget
-        if cmode == "bf16" and not clip and n.startswith("perceptual_encoder.") and (".ln." in n or ".fc2." in n):
-            lim = 0.5       # sums of the embedding gradient over 2048 frames that cancel to a few % of their terms
+        lim = bar["down"] if n.startswith(downstream) else bar["worst"]
         if n == "logit_scale":
             got, want = P[n].grad.reshape(1), ref.grad.reshape(1)
             rel = (got.cpu() - want).abs().item() / (want.abs().item() + 1e-12)
@@ -477,10 +499,12 @@ def test_benchmarked_config_against_oracle(dev, B, S, clip, cmode, monkeypatch):
             except AssertionError as e:
                 failures.append(str(e)[:160])
     assert not failures, "\n".join(failures)
+    errs = sorted(((P[n].grad.double().cpu() - ref.grad.double()).norm() / (ref.grad.double().norm() + 1e-30)).item()
+                  for n, ref in sd.items() if ref.grad is not None and n != "logit_scale")
+    print(f"[{cmode} B={B} clip={clip}] gradient error: median {errs[len(errs) // 2]:.4f}, worst {errs[-1]:.4f} over {len(errs)} tensors")
+    assert errs[len(errs) // 2] <= bar["med"] and errs[-1] <= bar["worst"], (errs[len(errs) // 2], errs[-5:])
     if sites_all:
-        errs = sorted(((P[n].grad.double().cpu() - ref.grad.double()).norm() / (ref.grad.double().norm() + 1e-30)).item()
-                      for n, ref in sd.items() if ref.grad is not None and n != "logit_scale")
-        assert errs[len(errs) // 2] < 0.02 and sum(e > 0.05 for e in errs) <= 16, (errs[len(errs) // 2], errs[-5:])
+        assert sum(e > 0.05 for e in errs) <= 16, errs[-20:]
 
 
 def test_world_to_tcp_matches_oracle(dev):

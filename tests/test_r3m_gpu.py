@@ -136,15 +136,31 @@ def test_folded_weights_follow_the_parameters(dev, net):
     assert not torch.equal(a, b) and torch.equal(a, c)
 
 
-RW_TOL = {"fp32": dict(loss=1e-3, grad=2e-3), "mixed": dict(loss=2e-3, grad=8e-2), "bf16": dict(loss=5e-3, grad=0.2)}   # (B = 2: the bf16 BACKWARD of conv1 over 64 frames is 6 % off, as torch.autocast is)
+# what each mode is held to on configs[3], stated here: loss (relative), median and worst relative-L2 gradient error over the 89 trainable
+# tensors = measured on an MI355X (round 4) with <= 2x head-room.  Worst tensor in every bf16-family mode: the gripper camera's conv1 weight,
+# whose bf16 BACKWARD product over the frames is 6-12 % off (torch.autocast(bfloat16) on the oracle: the same).
+RW_BARS = {("fp32", 2): dict(loss=1e-5, med=1e-3, worst=2e-3),              # measured 1e-7 / 0 / 0
+           ("bf16", 2): dict(loss=1e-4, med=0.045, worst=0.25),             # 1.1e-5 / 2.1 % / 12.3 %
+           ("mixed", 2): dict(loss=1e-4, med=0.03, worst=0.13),             # 2.2e-6 / 1.4 % / 6.5 %
+           ("bf16", 32): dict(loss=1e-4, med=0.016, worst=0.24),            # 8.8e-6 / 0.77 % / 11.7 %
+           ("mixed", 32): dict(loss=1e-4, med=0.01, worst=0.105),           # 1.0e-6 / 0.47 % / 5.2 %
+           ("bf16+sites", 32): dict(loss=1e-4, med=0.016, worst=0.22)}      # 8.6e-6 / 0.77 % / 10.7 %
 
 
-@pytest.mark.parametrize("B,S,cmode", [(2, 16, "fp32"), (2, 16, "bf16"), (2, 16, "mixed"), (32, 32, "bf16")])
-def test_real_world_training_step_matches_oracle(dev, B, S, cmode):
+_rw_oracle_cache = {}         # (B, S) -> (loss, {name: gradient}): the oracle's frozen trunk at B = 32 takes about a minute on 8 host threads
+
+
+@pytest.mark.parametrize("B,S,cmode", [(2, 16, "fp32"), (2, 16, "bf16"), (2, 16, "mixed"), (32, 32, "bf16"), (32, 32, "mixed"), (32, 32, "bf16+sites")])
+def test_real_world_training_step_matches_oracle(dev, B, S, cmode, monkeypatch):
     """cfg_low_level_rw (BASELINE configs[3]): R3M static camera in [0, 255], whole-embedding decoder input, world-frame actions, no CLIP
     loss — one training_step against the oracle composed the same way: the loss AND the gradient of every trainable parameter, in the exact
-    fp32 mode, the benchmarked bf16 mode and the mixed mode at B = 2, and once at the benchmark's full size (B = 32 per modality, S = 32: the
-    oracle's frozen trunk on 8 host threads takes about a minute).  VERDICT r02 next #9: configs[3] was pinned by one scalar."""
+    fp32 mode, the benchmarked bf16 mode and the mixed mode at B = 2, and at the benchmark's full size (B = 32 per modality, S = 32) in the
+    bf16, mixed and bf16 + every-exact-site modes (the oracle runs once per size).  VERDICT r02 next #9: configs[3] was
+    pinned by one scalar."""
+    tol_key = cmode
+    if cmode == "bf16+sites":
+        monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl,conv1,a3")
+        cmode = "bf16"
     kn.set_compute(cmode)
     try:
         cfg = real_world_model_config(dropout_p=0.0)
@@ -171,21 +187,24 @@ def test_real_world_training_step_matches_oracle(dev, B, S, cmode):
                           robot_obs=db["state_info"]["robot_obs"], plan_idx=db["plan_idx"])
         if name == "lang":
             flat[name].update(lang=db["lang"], use_for_aux_lang_loss=db["use_for_aux_lang_loss"])
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(min(8, nthreads))
-    try:
-        want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
-        want.backward()
-    finally:
-        torch.set_num_threads(nthreads)
-    t = RW_TOL[cmode]
-    assert abs(got.item() - want.item()) <= t["loss"] * abs(want.item()), (got.item(), want.item())
+    if (B, S) not in _rw_oracle_cache:
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(min(8, nthreads))
+        try:
+            want = O.training_step(sd, flat, O.real_world_cfg())["total_loss"]
+            want.backward()
+        finally:
+            torch.set_num_threads(nthreads)
+        _rw_oracle_cache[(B, S)] = (want.item(), {k: v.grad.clone() for k, v in sd.items() if v.grad is not None})
+    want_loss, want_grads = _rw_oracle_cache[(B, S)]
+    t = RW_BARS[(tol_key, B)]
+    assert abs(got.item() - want_loss) <= t["loss"] * abs(want_loss), (got.item(), want_loss)
     assert all(p.grad is None for p in m.perceptual_encoder.rgb_static_encoder.r3m.parameters())
     errs, checked = {}, 0
     for k, p in m.named_parameters():
         if not p.requires_grad:
             continue
-        ref = sd[k].grad
+        ref = want_grads.get(k)
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
@@ -193,10 +212,12 @@ def test_real_world_training_step_matches_oracle(dev, B, S, cmode):
         errs[k] = ((p.grad.double().cpu() - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
         checked += 1
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
-    print(f"[{cmode} B={B}] {checked} gradients, worst:", [(k, round(v, 5)) for k, v in worst])
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"[{tol_key} B={B}] loss rel {abs(got.item() - want_loss) / abs(want_loss):.2e}; {checked} gradients, median {med:.5f}, worst:", [(k, round(v, 5)) for k, v in worst])
     assert checked >= 60
-    bad = {k: v for k, v in errs.items() if v > t["grad"]}
+    bad = {k: v for k, v in errs.items() if v > t["worst"]}
     assert not bad, bad
+    assert med <= t["med"], med
 
 
 def test_shipped_real_world_config_with_sentence_encoder(dev):

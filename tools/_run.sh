@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_optimizer_gpu.py tests/test_trainer_gpu.py -x -q -m gpu 2>&1 | tail -5
-for i in 1 2; do
-HULC_LIB=hulc2_amd/libhulc2_amd_base.so python3 bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-230 | sed 's/.*"ms_per_step"/base ms_per_step/'
-python3 bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-230 | sed 's/.*"ms_per_step"/new  ms_per_step/'
-done
+python3 -m pytest tests/test_parity_gpu.py -x -q -m gpu -s 2>&1 | grep -v "^$" | grep "gradient error\|passed\|failed\|Error\|assert" | head -30
+python3 -m pytest tests/test_r3m_gpu.py -x -q -m gpu -s -k real_world_training_step 2>&1 | grep "gradients, median\|passed\|failed\|Error\|assert" | cut -c1-400 | head -20
