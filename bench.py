@@ -232,6 +232,155 @@ def secondary_mode(args, dev, mode):
         kn.set_compute(args.compute)
 
 
+def lightning_loop(args, dev):
+    """The loop the reference's trainer actually drives (hulc2/training.py:79-82: Lightning -> training_step -> backward -> optimizer.step;
+    conf/trainer/play_trainer.yaml:3 `precision: 16`): `model.training_step` inside torch.autocast(fp16), GradScaler.scale(loss).backward(),
+    scaler.step(torch.optim.Adam), eager launches, no ArenaTrainer, no hipGraph — what a user gets who only swaps the class paths
+    (INTEGRATION §1).  Two variants: the cooperative (device-wide barrier) kernels ON — one process, nothing else on the GPU — and with
+    kernels.set_concurrent_streams(True), the setting torch's own DDP needs unless hulc2_amd.ddp.register_parked_comm_hook is used.
+    Secondary, never `value`."""
+    from hulc2_amd import kernels as kn, synthetic as syn
+    from hulc2_amd.compat import instantiate
+    from hulc2_amd.config import default_model_config
+    res = {"what": "Lightning-style eager loop: autocast(fp16) + GradScaler + model.training_step + loss.backward() + torch.optim.Adam.step(), "
+                   "no ArenaTrainer / hipGraph (hulc2/training.py:79-82 with the class paths swapped, INTEGRATION §1)", "unit": "play-sequences/s"}
+    try:
+        kn.set_compute("bf16")
+        model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+        syn.fill_state_dict_(model.state_dict(), 42)
+        model.train()
+        batch = syn.make_batch(42, args.batch, args.seq_len, device=dev)
+        for db in batch.values():
+            db.pop("plan_idx", None)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+
+        def step(i):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = model.training_step(batch, i)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            return loss
+
+        def measure(name):
+            for i in range(3):
+                loss = step(i)
+            torch.cuda.synchronize()
+            k = max(3, min(args.steps, 20))
+            t0 = time.perf_counter()
+            for i in range(k):
+                loss = step(i)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            kn.check_faults(dev)
+            res[name] = {"value": round(2 * args.batch * k / el, 2), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
+                         "final_loss": round(float(loss), 4)}
+
+        for name, conc in (("cooperative_kernels", False), ("concurrent_streams", True)):
+            kn.set_concurrent_streams(conc)
+            measure(name)
+        # the same loop under torch's own DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75), on a ONE-rank
+        # RCCL group — the collectives move nothing, the reducer's bucket copies, hooks and stream hand-overs are all there: with
+        # hulc2_amd.ddp.register_parked_comm_hook (cooperative kernels stay on, bucket all-reduces parked behind the last cooperative kernel of
+        # the backward) and with torch's default hook + set_concurrent_streams(True) (round 3's only option under DDP)
+        own_group = False
+        try:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            from hulc2_amd.ddp import register_parked_comm_hook
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+                own_group = True
+
+            class _Step(torch.nn.Module):               # Lightning's _LightningModuleWrapperBase: forward = training_step
+                def __init__(self, m):
+                    super().__init__()
+                    self.module = m
+
+                def forward(self, b, i):
+                    return self.module.training_step(b, i)
+
+            for name, conc, parked in (("torch_ddp_parked_hook", False, True), ("torch_ddp_concurrent_streams", True, False)):
+                kn.set_concurrent_streams(conc)
+                ddp = DDP(_Step(model), device_ids=[dev.index or 0], static_graph=True, find_unused_parameters=False)
+                if parked:
+                    register_parked_comm_hook(ddp)
+                inner_step = step
+
+                def step(i, ddp=ddp):                   # noqa: F811 - the same loop, the module called through DDP
+                    opt.zero_grad(set_to_none=True)
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        loss = ddp(batch, i)
+                    scaler.scale(loss).backward()
+                    scaler.step(opt)
+                    scaler.update()
+                    return loss
+                try:
+                    measure(name)
+                finally:
+                    step = inner_step
+                    del ddp
+        except Exception as e:                              # noqa: BLE001
+            res["torch_ddp_error"] = f"{type(e).__name__}: {e}"
+        finally:
+            if own_group and dist.is_initialized():
+                dist.destroy_process_group()
+    except Exception as e:                                  # noqa: BLE001 - the headline line must still be printed
+        res["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        kn.set_concurrent_streams(False)
+        kn.set_compute(args.compute)
+    return res
+
+
+TXL_FLOP_PER_SEQ = 229.6e6        # SURVEY §8d: the two transformer layers, forward + backward, per 32-step play sequence (2 x 598 016 MAC per token and layer)
+
+
+def txl_roofline(table, model, dev, peak, seqs_in_step):
+    """north_star's one explicit kernel target (>= 60 % of the MFMA roof on the transformer block) as numbers in the line: the posterior's trunk
+    launches (csrc/txl_block.hip: one launch per direction) inside the step — from the same HIP-event leg as `roofline` — and the same two
+    launches alone at 256 and 1024 sequences, where the launch is no longer latency-bound (the kernel's asymptotic MFMA fraction next to the
+    64-sequence figure).  flops = sequences x 229.6 MFLOP (algorithmic), frac = flops / (fwd + bwd time) / dense bf16 MFMA peak."""
+    from hulc2_amd import kernels as kn
+
+    def pick(tbl, B):
+        us = {}
+        for k, (n, t, _, _) in tbl.items():
+            if k[0] in ("txl_block_fwd", "txl_block_bwd") and k[1] == B and n:
+                us[k[0]] = t / n * 1e3
+        return us
+
+    def entry(B, us):
+        if len(us) != 2:
+            return {"sequences": B, "error": "the whole-trunk launches did not run (per-layer path)"}
+        tot = us["txl_block_fwd"] + us["txl_block_bwd"]
+        fl = B * TXL_FLOP_PER_SEQ
+        return {"sequences": B, "fwd_us": round(us["txl_block_fwd"], 1), "bwd_us": round(us["txl_block_bwd"], 1), "flops": fl,
+                "achieved_tflops": round(fl / (tot * 1e-6) / 1e12, 1), "frac": round(fl / (tot * 1e-6) / peak, 4)}
+
+    out = {"bound": "mfma", "peak": peak / 1e12, "unit": "TFLOP/s", "in_step": entry(seqs_in_step, pick(table, seqs_in_step)), "alone": []}
+    net = getattr(model, "plan_recognition", None)
+    if net is None:
+        return out
+    for B in (256, 1024):
+        try:
+            emb = torch.randn(B, 32, 128, device=dev, requires_grad=True)
+            for _ in range(2):
+                st, feat = net(emb)
+                (st.logit.sum() + feat.sum()).backward()
+            kn.start_timing()
+            for _ in range(5):
+                st, feat = net(emb)
+                (st.logit.sum() + feat.sum()).backward()
+            out["alone"].append(entry(B, pick(kn.stop_timing(), B)))
+        except Exception as e:                              # noqa: BLE001 - a secondary figure must not cost the headline line
+            out["alone"].append({"sequences": B, "error": f"{type(e).__name__}: {e}"})
+    for prm in net.parameters():
+        prm.grad = None
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -531,6 +680,12 @@ def main():
         rl = {"bound": "mfma", "achieved": round(dom_flops / avg_s / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
               "frac": round(dom_flops / avg_s / peak, 4)}
     rl["traffic"] = pmc_traffic(dom_key)
+    rl_txl = None
+    if not (args.affordance or args.real_world) and args.compute == "bf16":
+        try:
+            rl_txl = txl_roofline(table, model, dev, peak, 2 * args.batch)
+        except Exception as e:                              # noqa: BLE001
+            rl_txl = {"error": f"{type(e).__name__}: {e}"}
     if args.breakdown and rank == 0:
         rows = int(os.environ.get("HULC_BREAKDOWN_ROWS", "25"))
         for key, (n, t, f, b) in sorted(table.items(), key=lambda kv: -kv[1][1])[:rows]:
@@ -586,6 +741,8 @@ def main():
                      "step_frac_of_mfma_peak": step_frac,
                      "gpu_kernel_ms_per_step": round(total_ms / 3, 3)},
     }
+    if rl_txl is not None:
+        out["roofline_txl"] = rl_txl
     if comm_info is not None:
         out["comm"] = comm_info
     plain = not (args.real_world or args.uint8_frames or args.episode_store or args.no_graph or args.affordance)
@@ -601,6 +758,9 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["secondary_exact_sites"] = secondary_mode(args, dev, "bf16+sites")
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["secondary_lightning_loop"] = lightning_loop(args, dev)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_affordance() if args.affordance else cpu_baseline()
     if rank == 0:

@@ -1,0 +1,154 @@
+"""torch DistributedDataParallel next to the cooperative kernels: a communication hook that PARKS the bucket all-reduces.
+
+The reference trains through Lightning's DDPStrategy (hulc2/training.py:72-75: `DDPStrategy(find_unused_parameters=False, static_graph=True)`):
+torch's reducer launches one all-reduce per 25 MB bucket as soon as the bucket's gradients exist, i.e. WHILE the backward is still running.  Three
+kernels of this build's backward are cooperative — the recurrent decoder's sweep (csrc/rnn_wavefront.hip), the MLP chains (mlp_chain.hip) and the
+shared-sequence transformer trunk (txl_block.hip) wait inside the kernel for all of their workgroups — and an RCCL kernel that holds compute units
+until its peers arrive can keep such a workgroup from ever becoming resident (0.1 s timeout, sticky fault word, HulcKernelError).  Until round 4 the
+only answer was `kernels.set_concurrent_streams(True)`: the non-cooperative per-layer kernels, 6.3 instead of 3.6 ms per step.
+
+`register_parked_comm_hook(ddp_model)` keeps the cooperative kernels AND torch DDP: every cooperative launch of a backward pass is issued before
+autograd reaches the camera encoders (their backward is the conv stack: ordinary kernels, the last ~1.3 ms of the pass; the same cut as
+ArenaTrainer's split graphs).  The hook therefore
+  * parks the buckets that become ready before that point (decoder, prior, posterior, goal encoders: 98 % of the gradient bytes),
+  * records an event on the compute stream when the encoder output's gradient arrives (a tensor hook on `cut_module`'s output), makes the
+    communication stream wait for it and releases the parked all-reduces in bucket order — they run under the conv backward,
+  * sends later buckets (the camera encoders' own 3 MB) straight away, behind what the compute stream holds at that moment (conv kernels),
+  * and releases at the last bucket in a pass where the cut tensor receives no gradient (frozen encoders).
+Gradients are averaged exactly like torch's default hook (divide by the world size, sum over the ranks).  Works on CPU process groups (gloo) too —
+there is no stream to park on there, the release order is the same (tests/test_ddp_gloo_cpu.py).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class ParkedCommState:
+    """state object of the hook (DDP hands it back on every bucket)"""
+
+    def __init__(self, process_group=None, device: Optional[torch.device] = None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.device = device
+        self.on_gpu = device is not None and device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self.released = False                       # this backward pass: has the cut been passed?
+        self.event = None
+        self.parked: List[Tuple["dist.GradBucket", torch.futures.Future]] = []
+        self.log: List[str] = []                    # ("park" | "send" | "release") in host order — what the tests read
+        self.keep_log = False
+
+    # -- bookkeeping -------------------------------------------------------------------------------------------------------------
+    def _note(self, what: str) -> None:
+        if self.keep_log:
+            self.log.append(what)
+
+    def begin_pass(self) -> None:
+        self.released, self.event = False, None
+
+    # -- communication -----------------------------------------------------------------------------------------------------------
+    def _send(self, bucket, fut: Optional[torch.futures.Future]) -> torch.futures.Future:
+        """average one bucket over the ranks.  On a GPU the collective runs on the communication stream: a parked bucket (fut given) behind the cut
+        event, a bucket that became ready after the cut behind everything the compute stream holds right now (its own gradients — conv kernels)"""
+        buf = bucket.buffer()
+        self._note("send")
+        if self.on_gpu:
+            if fut is not None and self.event is not None:
+                self.comm_stream.wait_event(self.event)
+            else:
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                buf.div_(self.world)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            buf.record_stream(self.comm_stream)
+        else:
+            buf.div_(self.world)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        done = work.get_future().then(lambda f: f.value()[0])
+        if fut is None:
+            return done
+        done.then(lambda f: fut.set_result(f.value()))
+        return fut
+
+    def release(self) -> None:
+        """the cut has been passed: every cooperative kernel of this backward is already in the compute stream's queue"""
+        if self.released:
+            return
+        self.released = True
+        self._note("release")
+        if self.on_gpu:
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(self.device))
+        parked, self.parked = self.parked, []
+        for bucket, fut in parked:
+            self._send(bucket, fut)
+
+
+def parked_allreduce_hook(state: ParkedCommState, bucket: dist.GradBucket) -> torch.futures.Future[torch.Tensor]:
+    """DDP communication hook (torch.nn.parallel.DistributedDataParallel.register_comm_hook).  The reducer launches buckets strictly in index
+    order and the last one only when every gradient of the pass exists, so "the last bucket" is a safe release point for a pass in which the
+    cut tensor never receives a gradient (frozen encoders)."""
+    if state.released:
+        return state._send(bucket, None)
+    fut = torch.futures.Future(devices=[state.device]) if state.on_gpu else torch.futures.Future()
+    state._note("park")
+    state.parked.append((bucket, fut))
+    if bucket.is_last():
+        state.release()
+    return fut
+
+
+def register_parked_comm_hook(ddp_model, cut_module: Optional[torch.nn.Module] = None, process_group=None) -> ParkedCommState:
+    """Install the parking hook on a DistributedDataParallel-wrapped Hulc2 (or any module whose `cut_module` output separates the part of the
+    backward that holds cooperative kernels from the rest).  cut_module defaults to `ddp_model.module.perceptual_encoder`.  Returns the state
+    object (its `.log` records park / release / send when `.keep_log` is set).  Call once, before the first forward."""
+    inner = ddp_model.module
+    cut = cut_module
+    if cut is None:                                 # (Lightning wraps the LightningModule once more: look through the wrappers)
+        for m in inner.modules():
+            if isinstance(getattr(m, "perceptual_encoder", None), torch.nn.Module):
+                cut = m.perceptual_encoder
+                break
+    if cut is None:
+        raise ValueError("register_parked_comm_hook: no `perceptual_encoder` inside the wrapped module; pass cut_module")
+    params = [p for p in inner.parameters() if p.requires_grad]
+    dev = params[0].device if params else None
+    state = ParkedCommState(process_group, dev)
+
+    def on_cut_grad(grad):
+        state.release()
+        return None
+
+    def first_tensor(o):
+        if torch.is_tensor(o):
+            return o
+        if isinstance(o, (tuple, list)):
+            for x in o:
+                t = first_tensor(x)
+                if t is not None:
+                    return t
+        if isinstance(o, dict):
+            for x in o.values():
+                t = first_tensor(x)
+                if t is not None:
+                    return t
+        return None
+
+    calls = {"n": 0}
+
+    def after_cut_forward(module, inputs, output):
+        # (a module called once per modality: the release belongs to the call whose gradient arrives LAST in the backward = the first call)
+        t = first_tensor(output)
+        if calls["n"] == 0 and t is not None and t.requires_grad:
+            t.register_hook(on_cut_grad)
+        calls["n"] += 1
+
+    def before_forward(module, inputs):
+        calls["n"] = 0
+        state.begin_pass()
+
+    inner.register_forward_pre_hook(before_forward)
+    cut.register_forward_hook(after_cut_forward)
+    ddp_model.register_comm_hook(state, parked_allreduce_hook)
+    return state

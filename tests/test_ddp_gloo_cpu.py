@@ -186,3 +186,80 @@ def test_bench_launcher_propagates_rank_failure():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+class _Toy(torch.nn.Module):
+    """stands in for Hulc2 under torch DDP: `perceptual_encoder` first (its gradients are the LAST of a backward), a head of two large layers"""
+
+    def __init__(self):
+        super().__init__()
+        self.perceptual_encoder = torch.nn.Linear(48, 64)
+        self.head = torch.nn.Sequential(torch.nn.Linear(64, 4096), torch.nn.ReLU(), torch.nn.Linear(4096, 300))
+
+    def forward(self, x):
+        return self.head(self.perceptual_encoder(x)).pow(2).mean()
+
+
+def _parked_hook_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    import copy
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from hulc2_amd.ddp import register_parked_comm_hook
+
+    res = {}
+    for frozen in (False, True):
+        torch.manual_seed(0)
+        model = _Toy()
+        if frozen:                                        # the cut tensor never receives a gradient: the last bucket releases
+            for p in model.perceptual_encoder.parameters():
+                p.requires_grad_(False)
+        ref = copy.deepcopy(model)
+        ddp = DDP(model, bucket_cap_mb=1, static_graph=True)          # (the reference: DDPStrategy(static_graph=True), hulc2/training.py:72-75)
+        st = register_parked_comm_hook(ddp)
+        st.keep_log = True
+        ok, logs = True, []
+        for step in range(3):
+            xs = [torch.randn(8, 48, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(world)]
+            st.log.clear()
+            for p in model.parameters():
+                p.grad = None
+            ddp(xs[rank]).backward()
+            logs.append(list(st.log))
+            want = {}
+            for r in range(world):                        # every rank can rebuild every rank's local gradients
+                ref.zero_grad(set_to_none=True)
+                ref(xs[r]).backward()
+                for n, p in ref.named_parameters():
+                    if p.grad is not None:
+                        want[n] = want.get(n, 0) + p.grad / world
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    ok = ok and p.grad is not None and torch.allclose(p.grad, want[n], atol=1e-6, rtol=1e-5)
+        # order: nothing is sent before the release; every parked bucket is sent right behind it; buckets after the cut go straight out
+        order_ok = all(l.count("release") == 1 and "send" not in l[:l.index("release")] and l.count("send") >= l.count("park")
+                       and l[l.index("release") + 1:l.index("release") + 1 + l.count("park")] == ["send"] * l.count("park") for l in logs)
+        res["frozen" if frozen else "trainable"] = (ok, order_ok, logs[-1])
+    if rank == 0:
+        out.put(res)
+    dist.destroy_process_group()
+
+
+def test_ddp_parked_comm_hook_world2():
+    """hulc2_amd.ddp.register_parked_comm_hook under torch DDP (gloo, 2 ranks): averaged gradients equal the ranks' mean, no all-reduce is issued
+    before the cut (the encoder output's gradient) has been reached, the parked buckets follow it in order, later buckets go straight out; with
+    a frozen encoder the last bucket is the release point."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_parked_hook_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    _join_or_end(procs, 120)
+    res = q.get(timeout=5)
+    for key, (ok, order_ok, last) in res.items():
+        assert ok and order_ok, (key, ok, order_ok, last)
+    # trainable encoder: at least one bucket parked AND at least one sent after the release without parking (the encoder's own bucket)
+    last = res["trainable"][2]
+    assert last.count("park") >= 1 and last.count("send") > last.count("park"), last
+    assert res["frozen"][2].count("send") == res["frozen"][2].count("park"), res["frozen"][2]

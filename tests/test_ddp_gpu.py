@@ -233,3 +233,85 @@ def test_two_ranks_graph_mode_with_barrier_kernels_at_full_batch(tmp_path):
     assert ok, f"replicas diverged or non-finite loss: losses {losses}, parameter checksums {sums}"
     assert calls["rnn"] >= 2 and calls["chain"] >= 2, calls                 # the barrier kernels really were on the path
     assert losses[-1] < losses[0] * 1.5
+
+
+def _torch_ddp_worker(port, out):
+    """one process = one rank of an RCCL group on the GPU: Hulc2 under torch's own DistributedDataParallel with the parked comm hook"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    for k in ("HULC_NO_RNN_WAVEFRONT", "HULC_NO_MLP_CHAIN"):
+        os.environ.pop(k, None)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=300))
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from hulc2_amd import kernels as kn, synthetic as syn
+    from hulc2_amd.compat import instantiate
+    from hulc2_amd.config import default_model_config
+    from hulc2_amd.ddp import register_parked_comm_hook
+
+    kn.set_compute("bf16")
+    kn.set_concurrent_streams(False)                       # the cooperative kernels stay ON: that is the point of the hook
+    calls = {"rnn": 0, "chain": 0}
+    rnn0, chain0 = kn.rnn_wavefront, kn.mlp_chain
+    kn.rnn_wavefront = lambda *a, **k: (calls.__setitem__("rnn", calls["rnn"] + 1), rnn0(*a, **k))[1]
+    kn.mlp_chain = lambda *a, **k: (calls.__setitem__("chain", calls["chain"] + 1), chain0(*a, **k))[1]
+    model = instantiate(default_model_config(gripper_control=True, dropout_p=0.0)).to(dev)
+    syn.fill_state_dict_(model.state_dict(), 42)
+    model.train()
+    batch = syn.make_batch(7, 8, 32, device=dev)
+    for db in batch.values():
+        db.pop("plan_idx", None)
+
+    class Step(torch.nn.Module):                           # Lightning's module wrapper: forward = training_step
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+        def forward(self, b, i):
+            return self.module.training_step(b, i)
+
+    kn.reset_step_state(dev)
+    model.training_step(batch, 0).backward()               # the plain call: reference bits
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    ddp = DDP(Step(model), device_ids=[0], static_graph=True, find_unused_parameters=False)
+    st = register_parked_comm_hook(ddp)
+    st.keep_log = True
+    same, logs = True, []
+    for it in range(4):
+        kn.reset_step_state(dev)
+        st.log.clear()
+        for p in model.parameters():
+            p.grad = None
+        ddp(batch, 0).backward()
+        torch.cuda.synchronize()
+        logs.append(list(st.log))
+        got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        same = same and set(got) == set(ref) and all(torch.equal(got[n], ref[n]) for n in ref)
+    kn.check_faults(dev)                                    # no barrier kernel timed out next to the collectives
+    out.put({"same": bool(same), "logs": logs, "calls": calls})
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_with_parked_comm_hook_keeps_the_cooperative_kernels():
+    """Hulc2 under torch.nn.parallel.DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75) with
+    hulc2_amd.ddp.register_parked_comm_hook on a one-rank RCCL group — the cooperative kernels (recurrent sweep, MLP chains) run, no fault, the
+    averaged gradients are the bits of the plain backward, the bucket all-reduces of everything behind the camera encoders are parked until the
+    encoder output's gradient exists and the encoders' own bucket goes out after it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_torch_ddp_worker, args=(_free_port(), q))
+    p.start()
+    _join_or_end([p], 300)
+    res = q.get(timeout=5)
+    assert res["same"], "gradients under DDP + parked hook differ from the plain backward"
+    assert res["calls"]["rnn"] >= 2 and res["calls"]["chain"] >= 2, res["calls"]
+    print(res["logs"])
+    # (static_graph: the reducer delays every all-reduce of the first two passes to their end while it learns the graph and rebuilds its
+    # buckets — nothing to park there)
+    for log in res["logs"][2:]:
+        assert log.count("release") == 1 and log.count("park") >= 2 and "send" not in log[:log.index("release")], log
+        assert log.count("send") > log.count("park"), log      # the encoders' bucket: sent after the release without parking
