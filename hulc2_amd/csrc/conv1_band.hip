@@ -25,6 +25,7 @@ struct C1P {
     int sweep;                                   // unit order: 0 = a workgroup walks whole frames, 1 = the grid sweeps memory in address order
     long ldw;
     int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
+    const void* X2; int nsplit;                  // fp32 frames: frames n >= nsplit come from X2 (pre-offset by -nsplit frames); X2 == X when unused
 };
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
-            xraw[j][0] = *(const float4*)((const float*)p.X + off);
-            xraw[j][1] = *(const float4*)((const float*)p.X + (inb2 ? off + 4 : off));
+            const float* xb = (const float*)(n < p.nsplit ? p.X : p.X2);       // (n is uniform: a scalar select)
+            xraw[j][0] = *(const float4*)(xb + off);
+            xraw[j][1] = *(const float4*)(xb + (inb2 ? off + 4 : off));
         }
     };
     auto stage_store = [&](int unit) {
@@ -268,7 +270,8 @@ int launch_conv1(C1P& p, hipStream_t s) {
 
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
-                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, const void* w_lo, hipStream_t s) {
+                             int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, const void* w_lo,
+                             const void* x2, int n_split, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
     if (w_dtype != HULC_BF16 || ((uintptr_t)w % 16) || ldw % 8) return u8 ? hulc_fail(-6, "conv1 band: bf16 weights, 16-byte aligned rows") : 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
@@ -277,6 +280,11 @@ int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ld
     if (w_lo && (u8 || (uintptr_t)w_lo % 16)) return hulc_fail(-6, "conv1 band: split operands need fp32 frames and 16-byte aligned remainders");
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx; p.bits = relu_bits; p.Wlo = w_lo;
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
+    p.X2 = x; p.nsplit = N;
+    if (x2) {
+        if (u8 || n_split < 0 || n_split > N || ((uintptr_t)x2 % 16)) return hulc_fail(-6, "conv1 band: x2 needs fp32 frames, 0 <= n_split <= N, 16-byte alignment");
+        p.X2 = (const float*)x2 - (long)n_split * 3 * H * W; p.nsplit = n_split;
+    }
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
     const int rc = launch_conv1<3>(p, s);
     if (rc == -1) return 1;

@@ -364,6 +364,7 @@ struct W1P {
     float* partial_w; float* partial_b;
     int u8, pad; const int* shift; const int* fidx;
     int dbg;
+    const void* X2; int nsplit;             // fp32 frames: frames n >= nsplit come from X2 (pre-offset by -nsplit frames); X2 == X when unused
 };
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes); dY is bf16 (other gradients dtypes take the generic kernel).  Both are compile-time so
@@ -432,8 +433,9 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
-            xraw[j][0] = *(const float4*)((const float*)p.X + off);
-            xraw[j][1] = *(const float4*)((const float*)p.X + (inb2 ? off + 4 : off));
+            const float* xb = (const float*)(n < p.nsplit ? p.X : p.X2);       // (n is uniform: a scalar select)
+            xraw[j][0] = *(const float4*)(xb + off);
+            xraw[j][1] = *(const float4*)(xb + (inb2 ? off + 4 : off));
         }
         const int npix = R * p.OW, ycc = tid % YCPP;
 #pragma unroll
@@ -683,7 +685,7 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error.  dw is [Cout][K] fp32 in the forward k order.
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
-                                  const int* shift, const int* fidx, hipStream_t s) {
+                                  const int* shift, const int* fidx, const void* x2, int n_split, hipStream_t s) {
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
@@ -701,17 +703,21 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
         rc = pure16 ? launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1, true>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s)
                     : launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0))) {
+        if (x2 && (u8 || dy_dtype != HULC_BF16 || n_split < 0 || n_split > N || ((uintptr_t)x2 % 16) || getenv("HULC_CONV1_WGRAD_OLD")))
+            return hulc_fail(-6, "conv1 weight gradient: x2 needs fp32 frames, a bf16 gradient map, 0 <= n_split <= N, 16-byte alignment");
         if (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16) rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
         else {
             W1P q;
             q.X = x; q.dY = dy; q.dy_dtype = dy_dtype; q.Nimg = N; q.H = H; q.W = W; q.OH = p.OH; q.OW = p.OW;
             q.dy_sn = p.dy_sn; q.dy_sy = p.dy_sy; q.dy_sx = p.dy_sx;
             q.u8 = u8; q.pad = pad; q.shift = shift; q.fidx = fidx;
+            q.X2 = x; q.nsplit = N;
+            if (x2) { q.X2 = (const float*)x2 - (long)n_split * 3 * H * W; q.nsplit = n_split; }
             q.dbg = getenv("HULC_W1_DBG") ? atoi(getenv("HULC_W1_DBG")) : 0;
             rc = launch_conv1_wgrad(q, dw, db, ws, ws_bytes, accumulate, s);
         }
     }
-    else return 1;
+    else return x2 ? hulc_fail(-6, "conv weight gradient: x2 is for conv1 only") : 1;
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv wgrad band: could not raise the dynamic LDS limit");
     return 0;

@@ -363,6 +363,15 @@ def dual_mlp(xa, layers_a, xb, layers_b, exact_b: bool = False):
 # conv stack of a camera encoder -> NHWC ReLU activations of conv3
 # reference: vision_network.py:36-47, vision_network_gripper.py:11-20
 # ------------------------------------------------------------------------------------------------
+def _conv1_pair_ok(xs, u8, bits, cout) -> bool:
+    """two fp32 NCHW frame tensors of one geometry in the bf16 modes: conv1 takes both in one launch (the band kernels' x2); the sign plane of a
+    32-channel conv1 is one plane, so the two inputs' slices are one contiguous tensor"""
+    return (len(xs) == 2 and not u8 and xs[0].dtype == torch.float32 and xs[1].dtype == torch.float32 and xs[0].shape[1:] == xs[1].shape[1:]
+            and xs[0].shape[-1] % 4 == 0 and (xs[0].shape[-2] - 8) % 4 == 0 and xs[0].is_contiguous() and xs[1].is_contiguous()
+            and xs[0].data_ptr() % 16 == 0 and xs[1].data_ptr() % 16 == 0 and cout == 32
+            and kn.base_mode() != "fp32" and kn.get_compute() == "bf16" and not os.environ.get("HULC_CONV1_PER_INPUT"))
+
+
 @_scoped
 class ConvStackFn(torch.autograd.Function):
     """xs: one or more (N_i,3,H,W) NCHW frame tensors -> a3 (sum N_i, OH3, OW3, 64) NHWC.  Several inputs (the vis and lang
@@ -409,11 +418,15 @@ class ConvStackFn(torch.autograd.Function):
                 # selective precision site "conv1": fp32 frames and weights as hi + lo bf16 splits, three MFMAs per product (fp32-class a1)
                 w_lo = weight_operand(ws[0], "oihw_flat_lo") if (not u8 and _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16"
                                                                   and "conv1" in kn.fp32_sites()) else None
-                for x, n, sh, ix in zip(xs, Ns, shifts, indices):
-                    kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
-                                  frame_index=ix, w_lo=w_lo,
-                                  relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
-                    off += n
+                if _conv1_pair_ok(xs, u8, bits[li], cout):
+                    # the two modalities of a step (two frame tensors, never concatenated) as ONE conv1 launch: hulc_conv_desc.x2 (round 4)
+                    kn.conv2d_fwd(xs[0], w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, w_lo=w_lo, relu_bits=bits[li], x2=xs[1])
+                else:
+                    for x, n, sh, ix in zip(xs, Ns, shifts, indices):
+                        kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
+                                      frame_index=ix, w_lo=w_lo,
+                                      relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
+                        off += n
             else:
                 kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li])
             dims.append((h, w_, cin, cout, k, s, nchw))
@@ -466,10 +479,13 @@ class ConvStackFn(torch.autograd.Function):
             if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
                 pad, shifts, indices = ctx.aug
-                for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
-                    kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc or j > 0,
-                                         aug_shift=sh, aug_pad=pad, frame_index=ix)
-                    off += n
+                if _conv1_pair_ok(xs, xs[0].dtype == torch.uint8, None, cout) and g.dtype == torch.bfloat16:
+                    kn.conv2d_bwd_weight(xs[0], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc, x2=xs[1])
+                else:
+                    for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
+                        kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc or j > 0,
+                                             aug_shift=sh, aug_pad=pad, frame_index=ix)
+                        off += n
             else:
                 kn.conv2d_bwd_weight(inputs[li], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc)
             grads_w[li] = None if sunk else dw.view(cout, cin, k, k)

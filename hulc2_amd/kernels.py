@@ -351,14 +351,25 @@ def _u8_frames(d, x, aug_shift, aug_pad, frame_index=None):
     d.aug_shift = aug_shift.data_ptr() if aug_shift is not None else None
 
 
+def _second_frames(d, x, x2, N, Cin, H, W):
+    """hulc_conv_desc.x2 / n_split: conv1 over two fp32 NCHW frame tensors (the modalities of a step) as one launch"""
+    if x2 is None:
+        return
+    _require_cuda(x2)
+    if x.dtype != torch.float32 or x2.dtype != torch.float32 or not x2.is_contiguous() or x2.shape[1:] != x.shape[1:] or x.shape[0] + x2.shape[0] != N:
+        raise TypeError("x2: a second contiguous fp32 NCHW frame tensor; N = frames of x + frames of x2")
+    d.x2, d.n_split = x2.data_ptr(), int(x.shape[0])
+
+
 def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
-               frame_index=None, relu_bits=None, w_lo=None):
+               frame_index=None, relu_bits=None, w_lo=None, x2=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
     for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
     _require_cuda(x, w2d, bias, y, aug_shift, frame_index)
     _require_contiguous(x=x, w2d=w2d, y=y)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
     _u8_frames(d, x, aug_shift, aug_pad, frame_index)
+    _second_frames(d, x, x2, N, Cin, H, W)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
     if relu_bits is not None:              # ReLU sign planes of y: int32 (N * OH * OW * Cout / 32,), written next to y (hulc_conv_desc.relu_bits)
         _require_cuda(relu_bits)
@@ -371,7 +382,7 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
             raise TypeError("w_lo: the bf16 remainders of w2d, same shape")
         d.w_lo = w_lo.data_ptr()
     macs = float(N) * oh * ow * Cout * Cin * KH * KW * (3 if w_lo is not None else 1)
-    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y)):
+    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y) + (_nbytes(x2) if x2 is not None else 0)):
         _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
                  "hulc_conv2d_fwd")
     return y
@@ -457,7 +468,7 @@ def conv2d_bwd_data(dy, wt, dx, relu_src, N, H, W, Cin, Cout, KH, KW, stride, co
 
 
 def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, compute=None, dw_oihw=False, accumulate=False,
-                      aug_shift=None, aug_pad=0, frame_index=None):
+                      aug_shift=None, aug_pad=0, frame_index=None, x2=None):
     """dw [Cout][K] / db [Cout] (fp32) from x and dy (NHWC).  dw_oihw: dw in the parameter's OIHW order (else the forward k order);
     accumulate: add into dw / db (gradient arena sinks)."""
     _require_cuda(x, dy, dw, db)
@@ -467,11 +478,12 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(dy), F32, False, compute)
     d.dw_oihw, d.dw_accumulate = int(dw_oihw), int(accumulate)
     _u8_frames(d, x, aug_shift, aug_pad, frame_index)
+    _second_frames(d, x, x2, N, Cin, H, W)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
     macs = float(N) * oh * ow * Cout * Cin * KH * KW
-    with _Timed(("conv2d_bwd_weight", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, dy, dw, db)):
+    with _Timed(("conv2d_bwd_weight", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, dy, dw, db) + (_nbytes(x2) if x2 is not None else 0)):
         _L.check(lib.hulc_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                             ctypes.c_void_p(_stream())), "hulc_conv2d_bwd_weight")
     return dw, db

@@ -80,6 +80,7 @@ class ConvDesc(ctypes.Structure):
         ("x_u8_nhwc", ctypes.c_int), ("aug_pad", ctypes.c_int), ("aug_shift", ctypes.c_void_p), ("frame_index", ctypes.c_void_p),
         ("relu_bits", ctypes.c_void_p),
         ("w_lo", ctypes.c_void_p),
+        ("x2", ctypes.c_void_p), ("n_split", ctypes.c_int),
     ]
 
 

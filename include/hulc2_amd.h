@@ -92,6 +92,12 @@ typedef struct {
      * splits of both operands (three bf16 MFMAs): fp32-class outputs on the bf16 matrix pipe — the selective-precision site "conv1"
      * (DESIGN §5).  NULL = plain bf16 operands. */
     const void* w_lo;
+    /* (ABI 4) conv1 on fp32 NCHW frames (hulc_conv2d_fwd and hulc_conv2d_bwd_weight, LDS-band kernels only): a SECOND frame tensor — frames
+     * n >= n_split are frame n - n_split of x2.  The vision and the language modality of a step are two tensors (hulc2.py:336-361: one
+     * batch dict per modality) that are never concatenated (1 GB); with x2 their conv1 runs as ONE launch per direction instead of one per
+     * modality (one prologue, one set of weight-gradient slabs, one reduce).  NULL = all N frames in x. */
+    const void* x2;
+    int n_split;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

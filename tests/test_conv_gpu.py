@@ -174,3 +174,42 @@ def test_conv1_split_operands_are_fp32_class(dev, name, N, H, W):
     kn.conv2d_fwd(x.contiguous(), whi, b, yb, N, H, W, 3, 32, 8, 8, 4, True, relu=True, compute=kn.BF16, w_lo=wlo)
     torch.cuda.synchronize()
     assert torch.equal(yb, y.to(torch.bfloat16)) or ((yb.double() - ref).abs().max().item() / scale) < 4e-3
+
+
+@pytest.mark.parametrize("name,Na,Nb,H,W", [("static1", 5, 3, 200, 200), ("grip1", 2, 7, 84, 84), ("static1-empty-second", 4, 0, 200, 200)])
+def test_conv1_two_frame_tensors_in_one_launch(dev, name, Na, Nb, H, W):
+    """hulc_conv_desc.x2 / n_split (round 4): conv1's forward (with its ReLU sign plane) over two fp32 NCHW frame tensors as ONE launch is
+    bit-identical to the two launches it replaces; the weight gradient (one set of slabs instead of two accumulating launches: another
+    summation order) agrees to fp32 rounding and with torch's conv2d autograd in float64 on the bf16-rounded operands."""
+    from hulc2_amd import kernels as kn
+    g = torch.Generator().manual_seed(5)
+    xa = (torch.rand(Na, 3, H, W, generator=g) * 2 - 1).to(dev)
+    xb = (torch.rand(Nb, 3, H, W, generator=g) * 2 - 1).to(dev)
+    w = ((torch.rand(32, 3, 8, 8, generator=g) * 2 - 1) / 192 ** 0.5).to(dev)
+    b = ((torch.rand(32, generator=g) * 2 - 1) * 0.1).to(dev)
+    w2d = w.reshape(32, -1).contiguous().to(torch.bfloat16)
+    N = Na + Nb
+    OH, OW = kn.conv_out_hw(H, W, 8, 8, 4)
+    y1 = torch.zeros(N, OH, OW, 32, dtype=torch.bfloat16, device=dev)
+    y2 = torch.zeros_like(y1)
+    b1 = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev)
+    b2 = torch.zeros_like(b1)
+    kn.conv2d_fwd(xa, w2d, b, y1[:Na], Na, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b1[:Na * OH * OW])
+    if Nb:
+        kn.conv2d_fwd(xb, w2d, b, y1[Na:], Nb, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b1[Na * OH * OW:])
+    kn.conv2d_fwd(xa, w2d, b, y2, N, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b2, x2=xb)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)) and torch.equal(b1, b2)
+    dy = torch.randn(N, OH, OW, 32, generator=g).to(dev).to(torch.bfloat16)
+    dw1, db1 = torch.zeros(32, 192, device=dev), torch.zeros(32, device=dev)
+    dw2, db2 = torch.zeros(32, 192, device=dev), torch.zeros(32, device=dev)
+    kn.conv2d_bwd_weight(xa, dy[:Na].contiguous(), dw1, db1, Na, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16)
+    if Nb:
+        kn.conv2d_bwd_weight(xb, dy[Na:].contiguous(), dw1, db1, Nb, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, accumulate=True)
+    kn.conv2d_bwd_weight(xa, dy, dw2, db2, N, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, x2=xb)
+    torch.cuda.synchronize()
+    assert float((dw1 - dw2).abs().max()) <= 1e-5 * float(dw1.abs().max()) and float((db1 - db2).abs().max()) <= 1e-5 * float(db1.abs().max())
+    xall = torch.cat([xa, xb]).to(torch.bfloat16).double().requires_grad_(False)
+    wd = torch.zeros(32, 3, 8, 8, dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(xall, wd, None, stride=4).backward(dy.double().permute(0, 3, 1, 2))
+    assert float((dw2.double() - wd.grad.reshape(32, -1)).abs().max()) <= 2e-3 * float(wd.grad.abs().max())
