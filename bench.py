@@ -337,7 +337,7 @@ def lightning_loop(args, dev):
 TXL_FLOP_PER_SEQ = 229.6e6        # the two transformer layers, forward + backward, per 32-step play sequence (2 x 598 016 MAC per token and layer)
 
 
-def txl_roofline(table, model, dev, peak, seqs_in_step):
+def txl_roofline(table, model, dev, peak, seqs_in_step, alone=True):
     """north_star's one explicit kernel target (>= 60 % of the MFMA roof on the transformer block) as numbers in the line: the posterior's trunk
     launches (csrc/txl_block.hip: one launch per direction) inside the step — from the same HIP-event leg as `roofline` — and the same two
     launches alone at 256 and 1024 sequences, where the launch is no longer latency-bound (the kernel's asymptotic MFMA fraction next to the
@@ -361,7 +361,7 @@ def txl_roofline(table, model, dev, peak, seqs_in_step):
 
     out = {"bound": "mfma", "peak": peak / 1e12, "unit": "TFLOP/s", "in_step": entry(seqs_in_step, pick(table, seqs_in_step)), "alone": []}
     net = getattr(model, "plan_recognition", None)
-    if net is None:
+    if net is None or not alone:                            # (--no-secondary: profiling runs keep the step's own launches only)
         return out
     for B in (256, 1024):
         try:
@@ -458,6 +458,9 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--affordance", action="store_true", help="BASELINE configs[4] (secondary): one training step of the affordance model "
                     "(PixelAffLangDetector, r3m variant) on --batch images of 224 x 224; the metric becomes images per second")
+    ap.add_argument("--trunk-mode", default="frozen", choices=["frozen", "reference"],
+                    help="--affordance: 'frozen' = inference-mode trunk (default), 'reference' = the trunk's BatchNorms on batch statistics as the "
+                         "reference's training loop runs them (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-43)")
     ap.add_argument("--uint8-frames", action="store_true",
                     help="feed uint8 NHWC frames + shift-augmentation offsets (SURVEY 8 row f-2) instead of transformed fp32 frames; "
                          "a separate data format, not the headline configuration")
@@ -537,7 +540,7 @@ def main():
     use_graph = not args.no_graph
     if args.affordance:
         from hulc2_amd.affordance import PixelAffLangDetector
-        model = PixelAffLangDetector(img_size=224).to(dev)
+        model = PixelAffLangDetector(img_size=224, trunk_mode=args.trunk_mode).to(dev)
         syn.fill_affordance_state_dict_({k: v for k, v in model.state_dict().items() if ".r3m." not in k}, 42)
         syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in model.model.aff_stream.r3m.convnet.state_dict().items()}, 42)
         model.train()
@@ -683,7 +686,7 @@ def main():
     rl_txl = None
     if not (args.affordance or args.real_world) and args.compute == "bf16":
         try:
-            rl_txl = txl_roofline(table, model, dev, peak, 2 * args.batch)
+            rl_txl = txl_roofline(table, model, dev, peak, 2 * args.batch, alone=not args.no_secondary)
         except Exception as e:                              # noqa: BLE001
             rl_txl = {"error": f"{type(e).__name__}: {e}"}
     if args.breakdown and rank == 0:
@@ -703,7 +706,10 @@ def main():
         # form over unet_decoder.py's ten 3 x 3 layers and the head, depth / text MLPs 21 MMAC)
         seq_flop = 2 * 1.82e9 + 3 * 2 * (6256.0 + 21.0) * 1e6
     workload = ("BASELINE configs[4] (secondary): affordance model PixelAffLangDetector.training_step, shipped r3m variant — frozen R3M ResNet-18 trunk "
-                "(random weights, inference-mode BatchNorm), language-fused U-Net decoder with BatchNorm on batch statistics, pixel cross-entropy + "
+                + ("(random weights, trunk_mode=frozen: inference-mode BatchNorm folded into the convolutions)" if args.trunk_mode == "frozen" else
+                   "(random weights, trunk_mode=reference: every trunk BatchNorm on BATCH statistics with running statistics updated, as the "
+                   "reference's train() leaves them — r3m_rn18.py:27-43; the stem stays frozen)")
+                + ", language-fused U-Net decoder with BatchNorm on batch statistics, pixel cross-entropy + "
                 "Gaussian depth NLL, Adam lr 1e-4; 224 x 224 images, lang = random (B,384) embeddings"
                 if args.affordance else
                 "BASELINE configs[3] (secondary): cfg_low_level_rw — static 150x200 in [0,255] through the frozen R3M ResNet-18 trunk (random "

@@ -8,9 +8,12 @@ Module tree and parameter names follow the reference's state_dict: `model.lang_e
 `model.aff_stream.r3m.convnet.*` (the reference additionally registers the trunk's stages a second time as `stem` / `layer1..4`: aliases of
 the same tensors, not repeated here).
 
-Deviations, shared with the oracle (oracle/affordance_oracle.py): the WHOLE trunk is a frozen inference-mode feature extractor — the
-reference freezes layer1..layer4 only (r3m_rn18.py:34-38), which leaves conv1 / bn1 of the stem trainable by omission and runs the frozen
-BatchNorms on batch statistics under Lightning's train().  Third-party arithmetic (r3m weights, sentence-transformers) is absent: parity of
+Trunk modes (`trunk_mode`): "frozen" (default) — the WHOLE trunk is a frozen inference-mode feature extractor (BatchNorm folded into the
+convolutions).  "reference" (round 4) — the BatchNorms of the trunk as the reference runs them: r3m_rn18.py:34-38 freezes the PARAMETERS of
+layer1..layer4 only and pixel_aff_lang_detector.py:51-53 leaves Lightning's train() on, so in training every BatchNorm2d of the ResNet
+normalises with the statistics of the batch and updates its running statistics (eval mode: running statistics, = "frozen").  Still a deviation
+in both modes, shared with the oracle: the reference's freeze leaves conv1 / bn1 of the STEM trainable by omission (a full ResNet-18 backward:
+not built); here no trunk parameter receives a gradient.  Third-party arithmetic (r3m weights, sentence-transformers) is absent: parity of
 the trunk and of SBERT is unpinned; everything behind them is pinned on the reference's own modules."""
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -94,10 +97,13 @@ class PixelAffLangDetector(nn.Module):
     label["normalized_depth"] (or "depth" with normalize_depth False): (B,)."""
 
     def __init__(self, img_size: int = 224, normalize_depth: bool = True, loss_weights: Optional[Dict[str, float]] = None, lr: float = 1e-4,
-                 sbert: Optional[str] = None):
+                 sbert: Optional[str] = None, trunk_mode: str = "frozen"):
         super().__init__()
         if img_size % 32:
             raise ValueError("img_size must be a multiple of 32 (ResNet-18 trunk)")
+        if trunk_mode not in ("frozen", "reference"):
+            raise ValueError("trunk_mode: 'frozen' (inference-mode trunk) or 'reference' (BatchNorm on batch statistics while training)")
+        self.trunk_mode = trunk_mode
         self.img_size, self.normalize_depth, self.lr = img_size, normalize_depth, lr
         self.loss_weights = dict(loss_weights or LOSS_WEIGHTS)
         self.model = AffDepthLangFusionPixel(img_size, sbert)
@@ -106,9 +112,10 @@ class PixelAffLangDetector(nn.Module):
     # ---- pieces ---------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def trunk_maps(self, img: torch.Tensor) -> List[torch.Tensor]:
-        """R3M.r3m_resnet18 (r3m_rn18.py:71-76): the stem's and the four stages' outputs, NHWC bf16, from the folded inference-mode trunk"""
+        """R3M.r3m_resnet18 (r3m_rn18.py:71-76): the stem's and the four stages' outputs, NHWC bf16 — from the folded inference-mode trunk, or
+        (trunk_mode "reference", training) with every BatchNorm on the statistics of the batch"""
         from ..models.perceptual_encoders.vision_r3m import trunk_feature_maps
-        return trunk_feature_maps(self.model.aff_stream.r3m, img)
+        return trunk_feature_maps(self.model.aff_stream.r3m, img, batch_stats=self.trunk_mode == "reference" and self.training)
 
     def text_enc(self, lang_goal) -> torch.Tensor:
         le = self.model.lang_encoder

@@ -77,7 +77,108 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const void* __restric
     }
 }
 
+// ---- BatchNorm2d on BATCH statistics over NHWC rows (round 4: the affordance trunk "as the reference runs it") --------------------------------
+// hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-43 freezes the PARAMETERS of layer1..layer4 and
+// pixel_aff_lang_detector.py:51-53 never puts the trunk into eval mode: under Lightning's train() its nn.BatchNorm2d layers normalise with
+// the statistics of the batch (biased variance) and keep updating running_mean / running_var (momentum 0.1, unbiased variance).  Three
+// launches per layer behind the (unfolded, bias-free) convolution: partial sums, finalize, apply.
+//
+// partial[p][0][c] = sum z, partial[p][1][c] = sum z^2 over the rows of slice p; rows per slice fixed, lanes walk channels (coalesced), the row
+// lanes of a workgroup are summed in a fixed order: bit-reproducible
+__global__ __launch_bounds__(256) void nhwc_bn_stats_kernel(const void* __restrict__ z, int dtype, long M, int C, long rows_per, float* __restrict__ partial) {
+    __shared__ float red[2][256];
+    const int RL = C >= 256 ? 1 : 256 / C;                  // row lanes
+    const int rl = threadIdx.x / (C >= 256 ? 256 : C), c0 = threadIdx.x % (C >= 256 ? 256 : C);
+    const long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+    for (int c = c0; c < C; c += 256) {
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;        // two independent chains per statistic (one load per trip would be a latency chain)
+        long r = r0 + rl;
+        for (; r + RL < r1; r += 2 * RL) {
+            const float a = load_elem(z, dtype, r * C + c), b = load_elem(z, dtype, (r + RL) * C + c);
+            s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+        }
+        if (r < r1) { const float a = load_elem(z, dtype, r * C + c); s0 += a; q0 += a * a; }
+        float s = s0 + s1, q = q0 + q1;
+        if (RL > 1) {
+            red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+            __syncthreads();
+            if (rl == 0) {
+                s = 0.f; q = 0.f;
+                for (int k = 0; k < RL; ++k) { s += red[0][k * C + c0]; q += red[1][k * C + c0]; }
+            }
+            __syncthreads();
+        }
+        if (rl == 0) { partial[((long)blockIdx.x * 2) * C + c] = s; partial[((long)blockIdx.x * 2 + 1) * C + c] = q; }
+    }
+}
+
+// per channel: the P partials summed in order (double), scale = gamma * rsqrt(var_biased + eps), shift = beta - mean * scale; running statistics
+// updated like nn.BatchNorm2d in training mode (momentum, unbiased variance); ss[c] = scale, ss[C + c] = shift
+__global__ __launch_bounds__(256) void nhwc_bn_finalize_kernel(const float* __restrict__ partial, int P, long M, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                                                               float* __restrict__ run_var, float* __restrict__ ss) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < P; ++p) { s += (double)partial[((long)p * 2) * C + c]; q += (double)partial[((long)p * 2 + 1) * C + c]; }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float scale = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    ss[c] = scale; ss[C + c] = beta[c] - (float)mean * scale;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+    if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(M > 1 ? var * (double)M / (double)(M - 1) : var);
+}
+
+// y = relu?(z * scale[c] + shift[c] + add): 8 channels per thread
+__global__ __launch_bounds__(256) void nhwc_bn_apply_kernel(const void* __restrict__ z, int z_dtype, long total8, int C8, const float* __restrict__ ss,
+                                                            const void* __restrict__ add, int add_dtype, int relu, void* __restrict__ y, int y_dtype) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int c = (int)(i % C8) * 8, C = C8 * 8;
+    Chunk8 v, a;
+    chunk_load_contig(v, z, z_dtype, i * 8);
+    if (add) chunk_load_contig(a, add, add_dtype, i * 8);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = v.v[e] * ss[c + e] + ss[C + c + e] + (add ? a.v[e] : 0.f);
+        if (relu) o[e] = fmaxf(o[e], 0.f);
+    }
+    if (y_dtype == HULC_BF16) {
+        *(uint4*)((uint16_t*)y + i * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    } else {
+        float4* q = (float4*)((float*)y + i * 8);
+        q[0] = make_float4(o[0], o[1], o[2], o[3]); q[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
 }  // namespace
+
+// see include/hulc2_amd.h
+extern "C" long hulc_nhwc_bn_train_workspace(long M, int C) {
+    long P = (M + 255) / 256; if (P > 1024) P = 1024; if (P < 1) P = 1;
+    return (P * 2 * C + 2 * C) * (long)sizeof(float);
+}
+
+extern "C" int hulc_nhwc_bn_train_fwd(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                      float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype, void* ws,
+                                      void* stream) {
+    if (!z || !gamma || !beta || !y || !ws) return hulc_fail(-1, "hulc_nhwc_bn_train_fwd: null pointer");
+    if (M < 1 || C < 8 || C % 8 || C > 2048 || (C < 256 && 256 % C)) return hulc_fail(-2, "hulc_nhwc_bn_train_fwd: C must be a multiple of 8 (a divisor of 256 below 256)");
+    if (((uintptr_t)z | (uintptr_t)y | (uintptr_t)add) % 16) return hulc_fail(-4, "hulc_nhwc_bn_train_fwd: 16-byte aligned rows");
+    long P = (M + 255) / 256; if (P > 1024) P = 1024; if (P < 1) P = 1;
+    const long rows_per = (M + P - 1) / P;
+    P = (M + rows_per - 1) / rows_per;
+    float* partial = (float*)ws;
+    float* ss = partial + P * 2 * C;
+    hipStream_t s = (hipStream_t)stream;
+    nhwc_bn_stats_kernel<<<(unsigned)P, 256, 0, s>>>(z, z_dtype, M, C, rows_per, partial);
+    nhwc_bn_finalize_kernel<<<(unsigned)((C + 255) / 256), 256, 0, s>>>(partial, (int)P, M, C, gamma, beta, eps, momentum, run_mean, run_var, ss);
+    const long total8 = M * (C / 8);
+    nhwc_bn_apply_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(z, z_dtype, total8, C / 8, ss, add, add_dtype, relu, y, y_dtype);
+    return hulc_check_launch("hulc_nhwc_bn_train_fwd");
+}
 
 extern "C" int hulc_r3m_normalize(const float* x, int N, int H, int W, const float* mean3, const float* std3, void* y, int y_dtype, void* stream) {
     if (!x || !mean3 || !std3 || !y) return hulc_fail(-1, "hulc_r3m_normalize: null pointer");

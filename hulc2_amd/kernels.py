@@ -444,6 +444,16 @@ def r3m_stem_fwd(xp, w, bias, y, N, H, W, Cout, relu=True):
     return y
 
 
+def nhwc_bn_train_fwd(z, M, C, gamma, beta, eps, momentum, run_mean, run_var, y, add=None, relu=False):
+    """nn.BatchNorm2d in training mode over NHWC rows z (M, C) -> y (+ add, ReLU); running statistics updated in place (may be None)"""
+    lib = _L.load()
+    lib.hulc_nhwc_bn_train_workspace.restype = ctypes.c_long
+    ws = _ws(lib.hulc_nhwc_bn_train_workspace(_l(M), _i(C)), z.device)
+    _call("hulc_nhwc_bn_train_fwd", z, _i(_dt(z)), _l(M), _i(C), gamma, beta, _f(eps), _f(momentum), run_mean, run_var, add,
+          _i(_dt(add) if add is not None else F32), _i(int(relu)), y, _i(_dt(y)), ws)
+    return y
+
+
 def maxpool_nhwc(x, y, N, H, W, C, k, stride, pad):
     _call("hulc_maxpool_nhwc", x, _i(_dt(x)), _i(N), _i(H), _i(W), _i(C), _i(k), _i(stride), _i(pad), y)
     return y

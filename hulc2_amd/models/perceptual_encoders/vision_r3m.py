@@ -144,9 +144,68 @@ class VisionR3M(nn.Module):
             self._folded, self._folded_key = f, key
         return self._folded
 
+    def _raw_trunk(self):
+        """the convolution weights alone (OHWI, compute dtype), no BatchNorm folded in: the operands of the batch-statistics path"""
+        ws = [p for n, p in self.r3m.convnet.named_parameters() if n.endswith("conv1.weight") or n.endswith("conv2.weight")
+              or n.endswith("downsample.0.weight")]
+        wdtype = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
+        key = (wdtype, ws[0].device, tuple(t._version for t in ws), tuple(t.data_ptr() for t in ws))
+        if key != getattr(self, "_raw_key", None):
+            def raw(conv, cin_pad=0):
+                w = conv.weight.float()
+                if cin_pad > w.shape[1]:
+                    w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
+                return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(wdtype)
+            net = self.r3m.convnet
+            with torch.no_grad():
+                self._raw = {"stem": raw(net.conv1, 8),
+                             "blocks": [(raw(b.conv1), raw(b.conv2), raw(b.downsample[0]) if b.downsample is not None else None, b.stride)
+                                        for b in net.blocks()],
+                             "zero": torch.zeros(512, dtype=torch.float32, device=ws[0].device)}
+            self._raw_key = key
+        return self._raw
+
+    @torch.no_grad()
+    def _trunk_maps_batch_stats(self, x: torch.Tensor, mean, std):
+        """The trunk with every BatchNorm2d in TRAINING mode (statistics of the batch, running statistics and num_batches_tracked updated): what
+        hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-43 + pixel_aff_lang_detector.py:51-53 run during training (the
+        parameters of layer1..4 are frozen, the modules stay in train mode).  Per layer: the bias-free convolution into an fp32 map,
+        then hulc_nhwc_bn_train_fwd (partial sums in a fixed order, finalize, apply + residual + ReLU).  Returns the five NHWC maps."""
+        f = self._raw_trunk()
+        net = self.r3m.convnet
+        adt = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
+        n, _, h, w = x.shape
+        dev = x.device
+
+        def conv_bn(a, wt, bn, hh, ww, cin, k, stride, pad, relu, add=None):
+            cout = wt.shape[0]
+            oh, ow = (hh + 2 * pad - k) // stride + 1, (ww + 2 * pad - k) // stride + 1
+            z = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=dev)
+            kn.conv2d_padded_fwd(a, wt, f["zero"][:cout], z, n, hh, ww, cin, cout, k, k, stride, pad, relu=False)
+            y = torch.empty((n, oh, ow, cout), dtype=adt, device=dev)
+            kn.nhwc_bn_train_fwd(z, n * oh * ow, cout, bn.weight, bn.bias, bn.eps, 0.1 if bn.momentum is None else bn.momentum,
+                                 bn.running_mean, bn.running_var, y, add=add, relu=relu)
+            bn.num_batches_tracked += 1
+            return y, oh, ow
+
+        a = kn.r3m_normalize(x.contiguous(), torch.empty((n, h, w, 8), dtype=adt, device=dev), mean, std)
+        a, h, w = conv_bn(a, f["stem"], net.bn1, h, w, 8, 7, 2, 3, True)
+        ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        a = kn.maxpool_nhwc(a, torch.empty((n, ph, pw, 64), dtype=adt, device=dev), n, h, w, 64, 3, 2, 1)
+        h, w, c = ph, pw, 64
+        maps = [a]
+        for bi, (blk, (w1, w2, wd, stride)) in enumerate(zip(net.blocks(), f["blocks"])):
+            idn = a if wd is None else conv_bn(a, wd, blk.downsample[1], h, w, c, 1, stride, 0, False)[0]
+            o, oh, ow = conv_bn(a, w1, blk.bn1, h, w, c, 3, stride, 1, True)
+            c = w1.shape[0]
+            a, h, w = conv_bn(o, w2, blk.bn2, oh, ow, c, 3, 1, 1, True, add=idn)
+            if bi % 2 == 1:
+                maps.append(a)
+        return maps
+
     # ---- forward -------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def trunk_features(self, x: torch.Tensor, want_maps: bool = False, mean=None, std=None):
+    def trunk_features(self, x: torch.Tensor, want_maps: bool = False, mean=None, std=None, batch_stats: bool = False):
         """x (N, 3, H, W) fp32 in [0, 255] -> (N, 512) fp32: normalise, stem, max pool, the residual stages, global average pool.
         want_maps: return the NHWC maps after the stem (+ max pool) and after each of the four stages instead (the skips of the affordance
         model's U-Net, hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:71-76); mean / std override the input normalisation."""
@@ -154,6 +213,11 @@ class VisionR3M(nn.Module):
             raise TypeError("VisionR3M expects fp32 (N, 3, H, W) frames in [0, 255] (conf/datamodule/transforms/real_world_r3m.yaml)")
         mean = IMAGENET_MEAN if mean is None else mean
         std = IMAGENET_STD if std is None else std
+        if batch_stats:
+            if not want_maps:
+                raise NotImplementedError("batch-statistics BatchNorm is the affordance model's trunk mode (maps); VisionR3M runs its trunk "
+                                          "under no_grad in whatever mode Lightning set — use trunk_feature_maps")
+            return self._trunk_maps_batch_stats(x, mean, std)
         f = self._fold_trunk()
         adt = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
         n, _, h, w = x.shape
@@ -240,11 +304,12 @@ class _TrunkOnly(VisionR3M):
 _trunks = {}
 
 
-def trunk_feature_maps(r3m: "R3M", img: torch.Tensor):
+def trunk_feature_maps(r3m: "R3M", img: torch.Tensor, batch_stats: bool = False):
     """the affordance encoder (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-32,71-76 uses the ResNet's children directly: no
     / 255, no ImageNet normalisation inside — the dataset transforms did that): img (N, 3, H, W) fp32 -> [stem, layer1, layer2, layer3, layer4]
-    NHWC maps in the compute dtype, BatchNorm folded (inference statistics)"""
+    NHWC maps in the compute dtype, BatchNorm folded (inference statistics) — or, batch_stats, every BatchNorm in training mode (statistics of the
+    batch, running statistics updated): the trunk as the reference runs it while training"""
     t = _trunks.get(id(r3m))
     if t is None or t.r3m is not r3m:
         t = _trunks[id(r3m)] = _TrunkOnly(r3m)
-    return t.trunk_features(img, want_maps=True, mean=(0.0, 0.0, 0.0), std=(1.0 / 255.0,) * 3)
+    return t.trunk_features(img, want_maps=True, mean=(0.0, 0.0, 0.0), std=(1.0 / 255.0,) * 3, batch_stats=batch_stats)

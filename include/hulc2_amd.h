@@ -270,6 +270,14 @@ int hulc_r3m_normalize(const float* x, int N, int H, int W, const float* mean3, 
 int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const void* x, const void* w, const float* bias, const void* add, void* y,
                            void* stream);
 int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* y, void* stream);
+/* (ABI 4) nn.BatchNorm2d in TRAINING mode over NHWC rows z [M][C] (M = N*H*W pixels), forward only: y = relu?(gamma (z - mean_batch) /
+ * sqrt(var_biased + eps) + beta + add); run_mean / run_var (optional) are updated with `momentum` and the unbiased variance.  The affordance
+ * model's trunk as the reference runs it (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-43 freezes the PARAMETERS of
+ * layer1..4 only; pixel_aff_lang_detector.py:51-53 leaves train mode on, so the trunk's BatchNorms use batch statistics).  z / add / y: fp32
+ * or bf16; C a multiple of 8 (a divisor of 256 below 256); ws: hulc_nhwc_bn_train_workspace(M, C) bytes.  Fixed summation order. */
+long hulc_nhwc_bn_train_workspace(long M, int C);
+int hulc_nhwc_bn_train_fwd(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                           float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype, void* ws, void* stream);
 /* The stem (7x7, stride 2, padding 3, 3 -> Cout) on a packed input, bf16: hulc_r3m_normalize_packed writes xp [N][H+6][Wp][4] with
  * Wp = hulc_r3m_packed_width(W), pixel (y, x) at [y+3][x+3] = normalised (R, G, B, 0), zero border; hulc_r3m_stem_fwd computes
  * y NHWC [N][OH][OW][Cout] = [relu](conv + bias) from it with w [Cout][7][8][4] bf16 = the (BatchNorm-folded) stem weight as [o][kh][kw][c],

@@ -47,12 +47,21 @@ def trainable_shapes(enc_hw: int) -> Dict[str, tuple]:
     return out
 
 
-def trunk_maps(sd: SD, img: torch.Tensor, p: str = "r3m.convnet.", stages=(2, 2, 2, 2), eps: float = 1e-5) -> List[torch.Tensor]:
+def trunk_maps(sd: SD, img: torch.Tensor, p: str = "r3m.convnet.", stages=(2, 2, 2, 2), eps: float = 1e-5, bn_train: bool = False,
+               momentum: float = 0.1) -> List[torch.Tensor]:
     """The five maps R3M.r3m_resnet18 hands to the decoder (visual_lang_encoders/r3m_rn18.py:71-76: the ResNet-18's children applied one after
     the other — no / 255 or ImageNet normalisation here, the dataset transforms did that): [stem (conv1, bn1, relu, maxpool), layer1 .. layer4],
     NCHW, BatchNorm on its running statistics (frozen trunk, module docstring).  PARITY UNPINNED like hulc2_oracle.r3m_trunk_features, whose
-    restatement of torchvision's resnet18 this repeats with the maps kept; used by bench.py's cpu_baseline leg and the tests."""
+    restatement of torchvision's resnet18 this repeats with the maps kept; used by bench.py's cpu_baseline leg and the tests.
+    bn_train: the trunk AS THE REFERENCE RUNS IT during training — r3m_rn18.py:34-38 freezes the parameters of layer1..layer4, nothing puts the
+    ResNet into eval mode and pixel_aff_lang_detector.py:51-53 leaves Lightning's train() on, so every BatchNorm2d normalises with the batch
+    statistics and updates sd[... running_mean / running_var / num_batches_tracked] IN PLACE (pass copies).  Pinned by
+    tests/golden/r3m_trunk_trainmode.npz (torch's own nn layers in train mode, oracle/gen_golden.py::gen_r3m_trunk_trainmode)."""
     def bn(t, q):
+        if bn_train:
+            if q + ".num_batches_tracked" in sd:
+                sd[q + ".num_batches_tracked"] += 1
+            return F.batch_norm(t, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], True, momentum, eps)
         return F.batch_norm(t, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, eps)
 
     t = F.relu(bn(F.conv2d(img, sd[p + "conv1.weight"], None, 2, 3), p + "bn1"))

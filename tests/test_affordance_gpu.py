@@ -279,3 +279,48 @@ def test_full_size_step_properties():
     torch.cuda.synchronize()
     assert torch.equal(l_replay, runs[0][0]) and torch.equal(g_replay, runs[0][1]), (float(l_replay), float(runs[0][0]))
     tr.close()
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 2e-4), ("bf16", 5e-2)])
+def test_reference_trunk_mode_matches_train_mode_batchnorm_fixture(compute, tol):
+    """VERDICT r03 missing #1: `trunk_mode="reference"` — the trunk with every BatchNorm2d in training mode, as the reference runs it
+    (r3m_rn18.py:27-43 freezes the parameters of layer1..4 only; pixel_aff_lang_detector.py:51-53 leaves train mode on) — against
+    tests/golden/r3m_trunk_trainmode.npz from torch's own nn.Conv2d / nn.BatchNorm2d / nn.MaxPool2d layers in TRAIN mode: the five maps the
+    decoder receives, the running statistics after the forward, num_batches_tracked; eval mode falls back to the running statistics; the
+    default mode ("frozen") is unchanged and differs."""
+    dev = _dev()
+    from hulc2_amd.affordance import PixelAffLangDetector
+    g = dict(np.load(G / "r3m_trunk_trainmode.npz", allow_pickle=False))
+    B, HW, seed = int(g["B"]), int(g["HW"]), int(g["seed"])
+    kn.set_compute(compute)
+    try:
+        m = PixelAffLangDetector(img_size=HW, trunk_mode="reference").to(dev)
+        net = m.model.aff_stream.r3m.convnet
+        syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in net.state_dict().items()}, seed)
+        for b in net.buffers():
+            if not b.is_floating_point():
+                b.zero_()
+        img = torch.randn(B, 3, HW, HW, generator=syn._gen(seed, "x.trunk.train")).to(dev)
+        m.train()
+        maps = m.trunk_maps(img)
+        torch.cuda.synchronize()
+        for i, got in enumerate(maps):
+            want = torch.as_tensor(g[f"map{i}"])
+            got = got.float().permute(0, 3, 1, 2).cpu()
+            assert got.shape == want.shape and (got - want).abs().max().item() <= tol * want.abs().max().item(), (i, (got - want).abs().max().item())
+        sd = net.state_dict()
+        for name, want in zip(g["stat_names"], g["stat_sums"]):
+            got = float(sd[str(name)].double().sum())
+            assert abs(got - float(want)) <= (1e-4 if compute == "fp32" else 2e-2) * max(1.0, abs(float(want))), (name, got, float(want))
+        assert int(sd["bn1.num_batches_tracked"]) == 1 and int(sd["layer3.0.downsample.1.num_batches_tracked"]) == 1
+        # eval mode: the running statistics (now the updated ones) — identical to what the frozen mode computes from the same buffers
+        m.eval()
+        ev = m.trunk_maps(img)
+        m2 = PixelAffLangDetector(img_size=HW).to(dev)
+        m2.model.aff_stream.r3m.load_state_dict(m.model.aff_stream.r3m.state_dict())
+        m2.train()
+        fr = m2.trunk_maps(img)
+        assert all(torch.equal(a, b) for a, b in zip(ev, fr))
+        assert (fr[4].float() - maps[4].float()).abs().max().item() > 0.05 * maps[4].float().abs().max().item()
+    finally:
+        kn.set_compute("bf16")
