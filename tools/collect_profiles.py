@@ -5,7 +5,7 @@ tag = sys.argv[1]
 import os
 RN = os.environ.get('HULC_ROUND', '02')
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-bench = open('gpurun_out/bench_default.log').read().strip().splitlines()[-1]
+bench = [l for l in open('gpurun_out/bench_default.log').read().splitlines() if l.startswith('{"metric"')][-1]
 eager = [l for l in open('gpurun_out/pk.log').read().splitlines() if l.startswith('{"metric"')][-1]
 hdr = f"# round {int(RN)}, commit {commit}, 1x MI355X, bf16 compute, 64 play-sequences per step\n"
 open(f'profiles/r{RN}_{tag}_kernel_stats.txt', 'w').write(
