@@ -16,6 +16,8 @@ import logging
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -115,6 +117,26 @@ class Hulc2(LightningModule):
         kl_loss = self.compute_kl_loss(pp_state, pr_state)
         return kl_loss, action_loss, action_loss + kl_loss, pp_state, pr_state, seq_feat
 
+    def _keep_weight_copies_fresh(self) -> None:
+        """Under an EXTERNAL optimizer (Lightning + torch.optim.Adam, hulc2/training.py:79-82) nobody maintains the kernel-side copies of the
+        weights (bf16 shadows, transposed tiles, packed fragments, split-operand remainders, conv repacks): shadow.weight_operand re-derives
+        each of them per parameter and layout with torch ops when the parameter's version has changed — ~200 small launches per step.  The
+        first training-mode step on a GPU without an ArenaTrainer therefore installs ArenaTrainer(shadows_only=True): the parameters move into
+        one arena (same Parameter objects, same values: optimizers, DDP and checkpoints are unaffected) and all copies are re-made by five
+        launches whenever the optimizer has stepped.  bf16 arithmetic modes only; HULC_NO_AUTO_SHADOWS=1 keeps the lazy per-parameter path."""
+        if kn.base_mode() == "fp32" or os.environ.get("HULC_NO_AUTO_SHADOWS"):
+            return
+        ref = self.__dict__.get("_hulc_arena_trainer")
+        tr = ref() if ref is not None else None
+        if tr is not None and tr.model is not self:               # (a deep copy of a model carries the original's weak reference along)
+            tr = None
+        if tr is None:
+            from ..trainer import ArenaTrainer
+            tr = self.__dict__["_hulc_shadow_keeper"] = ArenaTrainer(self, shadows_only=True)    # the model owns its keeper (a deepcopy of the
+                                                                                                # model gets None here and builds its own)
+        if getattr(tr, "shadows_only", False):
+            tr.refresh_if_stale()
+
     @_kernel_precision
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
         """hulc2.py:336-442."""
@@ -124,6 +146,7 @@ class Hulc2(LightningModule):
             p0 = next(self.parameters())
             if p0.is_cuda:
                 kn.ensure_fresh_rng(p0.device)
+                self._keep_weight_copies_fresh()
         kl_loss = action_loss = total_loss = lang_clip_loss = None
         batch_size: Dict[str, int] = {}
         total_bs = 0

@@ -297,15 +297,38 @@ class GradBuckets:
         self.reset()
 
 
+class _LoadHook:
+    """load_state_dict post-hook of a model with a trainer: re-derive the kernel-side copies (ArenaTrainer._after_model_load)"""
+
+    def __init__(self, trainer):
+        self.ref = weakref.ref(trainer)
+
+    def __call__(self, module, incompatible_keys):
+        tr = self.ref()
+        if tr is not None and tr.model is module:
+            tr._after_model_load(module, incompatible_keys)
+
+    def __deepcopy__(self, memo):
+        return self
+
+
 class ArenaTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  bucket_mb: int = 32, group=None, overlap: bool = True, comm_algo: Optional[str] = None, grad_payload: Optional[str] = None,
-                 force_comm: bool = False):
+                 force_comm: bool = False, shadows_only: bool = False):
         """force_comm: run the multi-rank control flow (split graphs, comm stream, collectives) even with a single rank in the process
-        group — how the RCCL path is exercised on a one-GPU box."""
+        group — how the RCCL path is exercised on a one-GPU box.
+        shadows_only (round 4): keep the KERNEL-SIDE COPIES of the parameters only — the parameters move into the fp32 arena, every derived
+        copy (bf16 shadow, transposed tiles, packed fragments, remainders, conv repacks) is allocated and registered, refresh_if_stale()
+        re-derives all of them with five launches when an external optimizer has stepped (any parameter's version counter moved) — and leave gradients, optimizer state and
+        communication to the caller (Lightning + torch.optim.Adam + torch DDP: hulc2/training.py:79-82).  Without it that loop re-derives every
+        copy per parameter and layout through torch ops (~200 small launches per step)."""
         self.model = model
+        self.shadows_only = bool(shadows_only)
         prev = model.__dict__.get("_hulc_arena_trainer")
         prev = prev() if prev is not None else None
+        if prev is not None and prev.model is not model:       # (a deep copy of a model carries the original's weak reference along)
+            prev = None
         if prev is not None:                               # an earlier trainer of this model: its load hook would keep re-homing weights into a
             prev.close()                                   # dead arena (and keep that arena alive) — ADVICE r02
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -316,7 +339,7 @@ class ArenaTrainer:
         # through a sink only, so they exist only when sinks do (not with per-parameter all-reduce hooks).
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.multi = self.world > 1 or (force_comm and dist.is_initialized())
-        use_sinks = dev.type == "cuda" and (not self.multi or not overlap)
+        use_sinks = dev.type == "cuda" and (not self.multi or not overlap) and not self.shadows_only
         groups = []
         for mod in model.modules():                     # views installed by an earlier trainer die with its arena
             if getattr(mod, "fused_param_groups", None) is not None:
@@ -351,16 +374,18 @@ class ArenaTrainer:
         self._groups = groups
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        n_state = 0 if self.shadows_only else total            # (gradients and Adam moments belong to the caller's optimizer then)
+        self.flat_g = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.flat_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 n = p.numel()
                 self.flat_p[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
-                p.grad = self.flat_g[off:off + n].view(p.shape)
+                if not self.shadows_only:
+                    p.grad = self.flat_g[off:off + n].view(p.shape)
                 if self.flat_bf16 is not None and p.dim() == 2:
                     shadow.register_arena_view(p, self.flat_bf16[off:off + n].view(p.shape))
         # fused group views: parameter view for the kernels, gradient view as its sink, bf16 shadow like any 2-D weight
@@ -508,10 +533,12 @@ class ArenaTrainer:
                 for p, name, d0, shape in views:
                     shadow.register_layout_view(p, name, self.conv_shadow[d0:d0 + p.numel()].view(shape))
                 kn.repack_conv_weights(self.flat_p, self.conv_shadow, self.conv_table)
-        self.comm = GradComm(self.flat_g, group, comm_algo, grad_payload, force=force_comm)
-        self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap, comm=self.comm)
-        # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
-        kn.set_concurrent_streams(dev.type == "cuda" and self.multi and overlap)
+        self.comm = self.buckets = None
+        if not self.shadows_only:
+            self.comm = GradComm(self.flat_g, group, comm_algo, grad_payload, force=force_comm)
+            self.buckets = GradBuckets(self.params, self.offsets, self.flat_g, bucket_mb << 20, group, overlap, comm=self.comm)
+            # bucket all-reduces overlapped with backward share the GPU with the compute stream: barrier kernels are then off
+            kn.set_concurrent_streams(dev.type == "cuda" and self.multi and overlap)
         self._autograd_written, self._zero_planned, self._acc_hooks, self._sink_keys = set(), None, [], []
         self._replan_pending = False
         if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
@@ -522,12 +549,14 @@ class ArenaTrainer:
                 self._sink_keys.append(gradsink.register(pv, gv))
         self.step_count = 0
         self.dev = dev
-        if dev.type == "cuda":
+        if dev.type == "cuda" and not self.shadows_only:
             kn.step_state(dev)[1] = 0               # the device-resident Adam step count starts with this trainer (the RNG word keeps walking)
         self.graph_fb = self.graph_enc = self.graph_opt = None
         self.static_loss = None
         self._comm_events = []
-        self._load_hook = model.register_load_state_dict_post_hook(self._after_model_load)
+        # (not a bound method: copy.deepcopy(model) copies the module's hook table, and a bound method would drag the trainer — arenas and all —
+        # into the copy; the copy's hook finds that the trainer belongs to another module and does nothing)
+        self._load_hook = model.register_load_state_dict_post_hook(_LoadHook(self))
         model.__dict__["_hulc_arena_trainer"] = weakref.ref(self)
         # Split point for overlapping the gradient all-reduce with the tail of backward in graph mode: the camera encoders
         # are registered first (arena head, 0.75 M parameters) but their backward (the conv stack) is the LAST ~2 ms of a step,
@@ -542,8 +571,37 @@ class ArenaTrainer:
             self.enc_hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else total
             self.enc_params = [self.params[i] for i in idx]
             self.rest_params = [p for i, p in enumerate(self.params) if not enc[i]]
-            model.perceptual_encoder.register_forward_hook(self._keep_encoder_output)
+            if not self.shadows_only:                             # (the split backward belongs to this trainer's own step)
+                model.perceptual_encoder.register_forward_hook(self._keep_encoder_output)
         self._emb = None
+
+    def __deepcopy__(self, memo):
+        """the shadows-only keeper is not copied with its model (copy.deepcopy(model) reaches it through the model's __dict__): the copy
+        starts without one and builds its own on its first training step.  A full trainer copies like any object."""
+        if self.shadows_only:
+            return None
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+    def refresh_if_stale(self) -> bool:
+        """shadows_only mode: an external optimizer steps the parameters in place (views of the arena) and bumps their version counters; one
+        look at three of them decides whether the derived copies are re-made (five launches for the whole model)"""
+        ps = self.params
+        sig = sum(p._version for p in ps)                      # (every in-place write to any parameter — optimizer, load, a test's nudge — moves it)
+        if sig == getattr(self, "_fresh_sig", None):
+            return False
+        for p, off in zip(ps, self.offsets):                  # (an optimizer that REPLACED .data would have left the arena)
+            if p.data_ptr() != self.flat_p.data_ptr() + off * 4:
+                self._after_model_load(None, None)
+                break
+        else:
+            self.refresh_shadows()
+        self._fresh_sig = sig
+        return True
 
     def _refresh_lo(self) -> None:
         """the remainders from scratch (weights written from outside; the optimizer step keeps them fresh inside the Adam kernel)"""
@@ -589,7 +647,7 @@ class ArenaTrainer:
                                 "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
         words = kn.step_state(self.dev).tolist() if self.dev.type == "cuda" else [0, self.step_count]
         return {"state": st, "step": int(self.step_count), "rng_word": int(words[0]), "device_step": int(words[1]),
-                "comm": {"algo": self.comm.algo, "payload": self.comm.payload, "chosen_by": self.comm.chosen_by},
+                "comm": ({"algo": self.comm.algo, "payload": self.comm.payload, "chosen_by": self.comm.chosen_by} if self.comm is not None else None),
                 "hparams": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}}
 
     def load_state_dict(self, sd: Dict) -> None:
@@ -610,7 +668,7 @@ class ArenaTrainer:
         hp = sd.get("hparams", {})
         self._set_hparams(hp.get("lr", self.lr), hp.get("betas", self.betas), hp.get("eps", self.eps), hp.get("weight_decay", self.wd))
         algo = (sd.get("comm") or {}).get("algo")
-        if algo in ("ring", "direct") and self.comm.active and not os.environ.get("HULC_ALLREDUCE"):
+        if algo in ("ring", "direct") and self.comm is not None and self.comm.active and not os.environ.get("HULC_ALLREDUCE"):
             self.comm.pin(algo)                                   # a resumed run keeps the summation order it started with
         if self.dev.type == "cuda":
             kn.reset_step_state(self.dev, seed=int(sd["rng_word"]), step=int(sd.get("device_step", sd["step"])))
@@ -771,6 +829,8 @@ class ArenaTrainer:
     _zero_ranges = None
 
     def zero_grad(self):
+        if self.shadows_only:
+            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
         if self._zero_ranges is None or os.environ.get("HULC_FULL_ZERO_GRAD"):
             self.flat_g.zero_()
             gradsink.begin_step(False)
@@ -783,6 +843,8 @@ class ArenaTrainer:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
 
     def optimizer_step(self):
+        if self.shadows_only:
+            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
         if self._zero_ranges is None and gradsink._sinks and not os.environ.get("HULC_FULL_ZERO_GRAD"):
             self._plan_partial_zero()                              # the backward that just finished ran on a fully zeroed arena
         elif self._zero_ranges is not None:

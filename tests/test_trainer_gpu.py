@@ -224,3 +224,59 @@ def test_training_step_under_lightning_amp_gives_the_same_bits(dev):
     with torch.autocast("cuda", dtype=torch.float16):
         out = m.validation_step(_batch(dev, 5), 0)
     assert all(v.dtype in (torch.float32, torch.int64, torch.int32) for v in out.values())
+
+
+def test_external_optimizer_loop_keeps_weight_copies_fresh_with_a_shadows_only_trainer(dev):
+    """Round 4: under an external optimizer (Lightning + torch.optim.Adam, hulc2/training.py:79-82) the first training-mode step installs
+    ArenaTrainer(shadows_only=True) — parameters re-homed into one arena, all kernel-side weight copies re-derived by a handful of launches
+    when the optimizer has stepped.  The loop's losses must be the bits of the lazy per-parameter path (HULC_NO_AUTO_SHADOWS=1), a nudge of
+    ONE parameter must be seen, and copy.deepcopy(model) must not drag the keeper along."""
+    import copy
+    import os
+
+    def run(auto):
+        if auto:
+            os.environ.pop("HULC_NO_AUTO_SHADOWS", None)
+        else:
+            os.environ["HULC_NO_AUTO_SHADOWS"] = "1"
+        try:
+            kn.reset_step_state(dev)
+            m = _model(dev, 9)
+            batch = _batch(dev, 9, B=2, S=8)
+            opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=2e-4)
+            losses = []
+            for i in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = m.training_step(batch, i)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            return m, batch, losses
+        finally:
+            os.environ.pop("HULC_NO_AUTO_SHADOWS", None)
+
+    m_lazy, _, want = run(False)
+    assert "_hulc_shadow_keeper" not in m_lazy.__dict__
+    m, batch, got = run(True)
+    keeper = m.__dict__.get("_hulc_shadow_keeper")
+    assert keeper is not None and keeper.shadows_only and keeper.flat_g.numel() == 0
+    assert got == want, (got, want)
+    assert all(p.data_ptr() == keeper.flat_p.data_ptr() + 4 * off for p, off in zip(keeper.params, keeper.offsets))
+    # one parameter nudged in place: the next step must run on the new value
+    kn.reset_step_state(dev)
+    a = float(m.training_step(batch, 0))
+    with torch.no_grad():
+        m.plan_proposal.fc_model[2].weight.mul_(1.5)
+    kn.reset_step_state(dev)
+    b = float(m.training_step(batch, 0))
+    assert a != b
+    m2 = copy.deepcopy(m)
+    assert m2.__dict__.get("_hulc_shadow_keeper") is None
+    kn.reset_step_state(dev)
+    c = float(m2.training_step(batch, 0))
+    assert c == b and m2.__dict__["_hulc_shadow_keeper"] is not keeper
+    # a full trainer takes over from the keeper
+    from hulc2_amd.trainer import ArenaTrainer
+    tr = ArenaTrainer(m)
+    assert not tr.shadows_only
+    float(tr.step(batch, 0))
