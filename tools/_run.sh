@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_trainer_gpu.py -q -m gpu -k "external_optimizer" 2>&1 | tail -12
+HULC_BREAKDOWN_ROWS=70 python3 bench.py --no-cpu-baseline --no-secondary --breakdown --steps 20 2>&1 | grep "ms/step" | cut -c1-200
