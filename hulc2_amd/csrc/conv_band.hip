@@ -389,6 +389,155 @@ int launch_band_x(BandP& p, hipStream_t s) {
     return 0;
 }
 
+
+// ---- (round 4) the stride-1, 64-channel forward geometry (conv3 of the static camera) with its bands brought in by DIRECT global -> LDS
+// loads (global_load_lds_dwordx4) into two LDS bands: no staging registers, no LDS write pass, one barrier per unit.  A wave instruction fills 1 KB
+// of LDS in lane order (the destination is wave-uniform base + lane * 16), so the image is pixel-major 128-byte pixels WITHOUT padding and the
+// bank spread of the fragment reads comes from an XOR swizzle applied on the SOURCE address: slot j of pixel q holds channel chunk
+// j ^ ((q >> 1) & 7) — 16 consecutive pixels of one chunk fall on 16 different 16-byte bank columns.  Whole frames per unit, no zero padding
+// (forward, pad 0), bf16 output, no mask / residual / sign planes.
+constexpr int GLDS_BAND_BYTES = 68 * 1024;      // a 23 x 23 x 64-channel frame = 67 712 bytes, rounded to whole 1 KB instructions
+template <int NSET, int TH, int TW>
+__global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
+    constexpr int C = 64, NT = 512, S = 1;
+    constexpr int K = TH * TW * C, KSTEPS = K / 16, CPP = 8, WPS = 8 / NSET;
+    // two STATIC LDS arrays (distinct objects: an LDS read of one is then provably independent of a direct load in flight into the other —
+    // with one dynamic array hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read behind a glds, i.e. drains the next band before the tile)
+    constexpr int BANDB = GLDS_BAND_BYTES;
+    // (neither band may sit at LDS address 0: there the base folds into the offset arithmetic, the access loses its underlying object and is
+    // guarded again — the bias table is given the larger alignment so that it takes the first slot)
+    __shared__ __attribute__((aligned(2048))) float sbias[BAND_MAXCLS * 32 + 384];
+    __shared__ __attribute__((aligned(256))) char bandA_[BANDB];
+    __shared__ __attribute__((aligned(256))) char bandB_[BANDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int set = wave % NSET, part = wave / NSET;
+    const BandCls& cl = p.cls[set];
+    const int cl_OH = cl.OH, cl_OW = cl.OW, cl_co = cl.co_base;
+    const int Wb = p.W;                                     // (pad 0, stride 1: the band IS the frame)
+    const float inv_OW = __builtin_amdgcn_rcpf((float)cl_OW);
+    const int nunits = p.Nimg;
+    const int P = p.H * p.W, NSLOT = P * CPP, NINS = (NSLOT + 63) / 64;     // glds instructions per band
+
+    // ---- prologue: weights once through LDS (as conv_band_kernel), parked across both (still empty) bands
+    constexpr int RPI = 64 / CPP, WITEMS = (32 / RPI) * TH * TW, NW = (WITEMS + WPS - 1) / WPS, WS = K * 2 + 16;
+    uint4 wtmp[NW];
+    {
+        const int wrow = lane / CPP, wc = lane % CPP;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS, itc = it < WITEMS ? it : WITEMS - 1;
+            const int rg = itc / (TH * TW), t = itc % (TH * TW);
+            wtmp[i] = band_load_bits(p.Wt, (cl.w_row0 + rg * RPI + wrow) * p.ldw + cl.w_tap_off[t] + wc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS;
+            if (it < WITEMS) {
+                const int rg = it / (TH * TW), t = it % (TH * TW);
+                *(uint4*)((set ? bandB_ : bandA_) + (rg * RPI + wrow) * WS + (t * C + wc * 8) * 2) = wtmp[i];   // (a set per band array: 37 KB each)
+            }
+        }
+    }
+    if (tid < NSET * 32) sbias[tid] = p.bias ? p.bias[p.cls[tid >> 5].co_base + (tid & 31)] : 0.f;
+    __syncthreads();
+    bf16x8_t wfrag[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)((set ? bandB_ : bandA_) + r * WS + (ks * 16 + h * 8) * 2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+    __syncthreads();
+
+    // direct loads of one frame into a band: instruction i of this wave covers slots [64 i, 64 i + 64)
+    auto glds_band = [&](int unit, char* band) {
+        const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn;
+        for (int i = wave; i < NINS; i += 8) {
+            int slot = i * 64 + lane;
+            if (slot >= NSLOT) slot = NSLOT - 1;             // (the tail lanes of the last instruction re-fetch the last chunk into the band's slack)
+            const int q = slot >> 3, j = slot & 7, c = j ^ ((q >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C + c * 8),
+                                             (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int unit = blockIdx.x;
+    if (unit < nunits) glds_band(unit, bandA_);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) — the BUILTIN: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and guards the band reads again)
+    __builtin_amdgcn_s_barrier();
+    auto do_unit = [&](int unit, const char* __restrict__ band, char* __restrict__ band_next) {
+        const int next = unit + gridDim.x;
+        if (next < nunits) glds_band(next, band_next);        // lands while this unit is multiplied
+
+        const int npix = cl_OH * cl_OW, ntile = (npix + 31) / 32;
+        for (int tile = part; tile < ntile; tile += WPS) {
+            int q = tile * 32 + r;
+            const bool live = q < npix;
+            if (!live) q = npix - 1;
+            const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
+            const unsigned qb = (unsigned)(oy * Wb + ox);
+            f32x16_t acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
+                acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+            }
+            constexpr int RD = 8;
+            auto frag = [&](int ks) {
+                const int k0 = ks * 16, t = k0 / C, kc = (k0 % C) / 16;
+                const int ty = t / TW, tx = t % TW;
+                const unsigned qt = qb + (unsigned)(ty * Wb + tx);
+                const unsigned u = qt << 3;
+                const unsigned off = (u << 4) + ((((unsigned)(2 * kc) + (unsigned)h) << 4) ^ (u & 0x70u));
+                return *(const bf16x8_t*)(band + off);
+            };
+            bf16x8_t pf[RD];
+#pragma unroll
+            for (int i = 0; i < RD; ++i) pf[i] = frag(i);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const bf16x8_t px = pf[ks % RD];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + RD < KSTEPS) pf[ks % RD] = frag(ks + RD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const long off0 = (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
+            uint2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                pk[g] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
+                if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) — the BUILTIN: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and guards the band reads again)       // the next band has landed (and this unit's stores are acknowledged)
+        __builtin_amdgcn_s_barrier();                          // every wave is done reading this band
+    };
+    for (; unit < nunits; unit += 2 * gridDim.x) {
+        do_unit(unit, bandA_, bandB_);
+        if (unit + (int)gridDim.x < nunits) do_unit(unit + gridDim.x, bandB_, bandA_);
+    }
+}
+
+template <int NSET, int TH, int TW>
+int launch_band_glds(BandP& p, hipStream_t s) {
+    const long P = (long)p.H * p.W;
+    if ((P * 128 + 1023) / 1024 * 1024 > GLDS_BAND_BYTES) return -1;
+    const size_t lds = 0;                                    // (static LDS: two bands + the bias table)
+    const int nunits = p.Nimg, per = (nunits + 255) / 256, grid = (nunits + per - 1) / per;
+    auto kern = conv_band_glds_kernel<NSET, TH, TW>;
+    kern<<<grid, 512, lds, s>>>(p);
+    return 0;
+}
+
 // BITS_OK: which sign-plane role this geometry is ever launched with (1: forward conv2 writes them, 2: the data gradients read them)
 template <int C, int NSET, int TH, int TW, int S, int MAXCH, int BITS_OK, bool DB>
 int launch_band_db(BandP& p, hipStream_t s) {
@@ -454,7 +603,16 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     }
     int rc = 1;
     if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1, 7>(p, s);        // conv2 forward (writes sign planes)
-    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) rc = launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s);   // conv3 forward / data gradient (reads them)
+    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) {                                                   // conv3 forward / data gradient (reads them)
+        static const char* ge = getenv("HULC_BAND_GLDS");
+        rc = -1;
+        // the forward of a frame-sized map (conv3 of the static camera) takes the direct-to-LDS instance: 85 -> 76 us per 2048 frames
+        // (HULC_BAND_GLDS=0: the register-staged kernel; small maps pack several frames into a unit there)
+        if (!(ge && !atoi(ge)) && pad_y == 0 && pad_x == 0 && !mask && !add && !bits_out && !bits_in && x_dtype == HULC_BF16 && y_dtype == HULC_BF16 &&
+            x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && (long)p.OHmax * p.OWmax >= 256 && ((uintptr_t)x % 16) == 0 && !p.dbg)
+            rc = launch_band_glds<2, 3, 3>(p, s);
+        if (rc == -1) rc = launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s);
+    }
     else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12, 2, 9>(p, s);   // conv2 data gradient, 4 parity classes
     else return 1;
     if (rc == -1) return 1;                      // band does not fit: gather kernel
