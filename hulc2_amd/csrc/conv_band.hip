@@ -397,10 +397,15 @@ int launch_band_x(BandP& p, hipStream_t s) {
 // j ^ ((q >> 1) & 7) — 16 consecutive pixels of one chunk fall on 16 different 16-byte bank columns.  Whole frames per unit, no zero padding
 // (forward, pad 0), bf16 output, no mask / residual / sign planes.
 constexpr int GLDS_BAND_BYTES = 68 * 1024;      // a 23 x 23 x 64-channel frame = 67 712 bytes, rounded to whole 1 KB instructions
-template <int NSET, int TH, int TW>
+// PAD: the band is the (unpadded) input frame + ONE zero pixel behind it; a tap that falls outside the frame reads that pixel (the data
+// gradients' zero padding without materialising a padded band: 26 x 26 padded pixels of conv2's data gradient would not fit two bands).
+// BITS = 2: the ReLU sign-plane word of every output pixel masks the result; the words of the NEXT unit's tiles are requested before the
+// unit's direct loads and consumed a unit later (an ordinary load consumed while a direct load is in flight drains it: vmcnt counts both).
+template <int NSET, int TH, int TW, int BITS, bool PAD>
 __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
-    constexpr int C = 64, NT = 512, S = 1;
+    constexpr int C = 64, NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16, CPP = 8, WPS = 8 / NSET;
+    constexpr int SPA = NSET / 2;                           // weight sets parked per band array in the prologue
     // two STATIC LDS arrays (distinct objects: an LDS read of one is then provably independent of a direct load in flight into the other —
     // with one dynamic array hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read behind a glds, i.e. drains the next band before the tile)
     constexpr int BANDB = GLDS_BAND_BYTES;
@@ -409,18 +414,24 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
     __shared__ __attribute__((aligned(2048))) float sbias[BAND_MAXCLS * 32 + 384];
     __shared__ __attribute__((aligned(256))) char bandA_[BANDB];
     __shared__ __attribute__((aligned(256))) char bandB_[BANDB];
+    constexpr int MAXTW = BITS == 2 ? (NSET == 2 ? 6 : 12) : 1;             // tiles of one wave per unit that carry a sign-plane word
+    __shared__ unsigned smask[8][MAXTW][32];                                // ... parked here between the unit that fetched them and the unit that uses them
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int set = wave % NSET, part = wave / NSET;
     const BandCls& cl = p.cls[set];
     const int cl_OH = cl.OH, cl_OW = cl.OW, cl_co = cl.co_base;
-    const int Wb = p.W;                                     // (pad 0, stride 1: the band IS the frame)
+    const long cl_yoff = cl.y_off;
+    const int Wb = p.W;                                     // the band IS the input frame (stride 1); padding = the zero pixel
     const float inv_OW = __builtin_amdgcn_rcpf((float)cl_OW);
     const int nunits = p.Nimg;
-    const int P = p.H * p.W, NSLOT = P * CPP, NINS = (NSLOT + 63) / 64;     // glds instructions per band
+    const int P = p.H * p.W, NSLOT = P * CPP, NINS = (NSLOT + 63) / 64;     // glds instructions per band; pixel P = the zero pixel
+    const int npix = cl_OH * cl_OW, ntile = (npix + 31) / 32;
 
-    // ---- prologue: weights once through LDS (as conv_band_kernel), parked across both (still empty) bands
+    // ---- prologue: weights once through LDS (as conv_band_kernel), SPA sets per (still empty) band array
     constexpr int RPI = 64 / CPP, WITEMS = (32 / RPI) * TH * TW, NW = (WITEMS + WPS - 1) / WPS, WS = K * 2 + 16;
+    static_assert((long)SPA * 32 * WS <= BANDB, "the parked weights fit a band array");
+    char* const wpark = ((set / SPA) ? bandB_ : bandA_) + (set % SPA) * 32 * WS;
     uint4 wtmp[NW];
     {
         const int wrow = lane / CPP, wc = lane % CPP;
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
             const int it = part + i * WPS;
             if (it < WITEMS) {
                 const int rg = it / (TH * TW), t = it % (TH * TW);
-                *(uint4*)((set ? bandB_ : bandA_) + (rg * RPI + wrow) * WS + (t * C + wc * 8) * 2) = wtmp[i];   // (a set per band array: 37 KB each)
+                *(uint4*)(wpark + (rg * RPI + wrow) * WS + (t * C + wc * 8) * 2) = wtmp[i];
             }
         }
     }
@@ -443,37 +454,70 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
     __syncthreads();
     bf16x8_t wfrag[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)((set ? bandB_ : bandA_) + r * WS + (ks * 16 + h * 8) * 2);
+    for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)(wpark + r * WS + (ks * 16 + h * 8) * 2);
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
     __syncthreads();
+    if (PAD && tid < 16) *(uint4*)((tid < 8 ? bandA_ : bandB_) + P * 128 + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);   // the zero pixels (never written again)
 
-    // direct loads of one frame into a band: instruction i of this wave covers slots [64 i, 64 i + 64)
+    // direct loads of one frame into a band: instruction i of this wave covers slots [64 i, 64 i + 64); lanes past the frame stay out
+    // (EXEC-masked: the zero pixel sits right behind it)
     auto glds_band = [&](int unit, char* band) {
         const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn;
         for (int i = wave; i < NINS; i += 8) {
-            int slot = i * 64 + lane;
-            if (slot >= NSLOT) slot = NSLOT - 1;             // (the tail lanes of the last instruction re-fetch the last chunk into the band's slack)
-            const int q = slot >> 3, j = slot & 7, c = j ^ ((q >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C + c * 8),
-                                             (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
+            const int slot = i * 64 + lane;
+            if (slot < NSLOT) {
+                const int q = slot >> 3, j = slot & 7, c = j ^ ((q >> 1) & 7);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C + c * 8),
+                                                 (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // sign-plane words of a unit's tiles (one dword per output pixel and 32-channel plane)
+    // (registers while in flight, written to smask behind the unit's closing wait — a tile loop that indexes registers would have to be fully
+    //  unrolled: 12 tiles' index arithmetic live at once spilled 400-550 registers)
+    unsigned mbn[MAXTW];
+    auto mask_park = [&]() {
+        if (BITS == 2 && lane < 32) {
+#pragma unroll
+            for (int i = 0; i < MAXTW; ++i) smask[wave][i][lane] = mbn[i];
+        }
+    };
+    auto mask_fetch = [&](int unit) {
+#pragma unroll
+        for (int i = 0; i < MAXTW; ++i) {
+            const int tile = part + i * WPS;
+            int q = tile * 32 + r;
+            q = q < npix ? q : npix - 1;
+            if (tile >= ntile) q = 0;
+            const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
+            const long pix_off = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx;
+            mbn[i] = p.bits_in[(long)(cl_co >> 5) * p.bplane + (pix_off >> p.bshift)];
         }
     };
 
     int unit = blockIdx.x;
+    if (BITS == 2 && unit < nunits) mask_fetch(unit);
     if (unit < nunits) glds_band(unit, bandA_);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) — the BUILTIN: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and guards the band reads again)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) — the BUILTIN: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and guards the band reads again)
+    mask_park();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the zero pixels are in LDS before anybody passes the (raw) barrier
     __builtin_amdgcn_s_barrier();
     auto do_unit = [&](int unit, const char* __restrict__ band, char* __restrict__ band_next) {
         const int next = unit + gridDim.x;
+        if (BITS == 2 && next < nunits) mask_fetch(next);         // requested BEFORE the direct loads, parked behind the closing wait, used a unit later
         if (next < nunits) glds_band(next, band_next);        // lands while this unit is multiplied
 
-        const int npix = cl_OH * cl_OW, ntile = (npix + 31) / 32;
-        for (int tile = part; tile < ntile; tile += WPS) {
+        auto do_tile = [&](int tile, unsigned mb_in) {
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
             const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
-            const unsigned qb = (unsigned)(oy * Wb + ox);
+            // band pixel of tap (ty, tx) = (oy + ty - pad_y) * W + (ox + tx - pad_x), or the zero pixel outside the frame
+            int rowq[TH], colq[TW];
+#pragma unroll
+            for (int ty = 0; ty < TH; ++ty) { const int iy = oy + ty - p.pad_y; rowq[ty] = (!PAD || (iy >= 0 && iy < p.H)) ? iy * Wb : -0x40000000; }
+#pragma unroll
+            for (int tx = 0; tx < TW; ++tx) { const int ix = ox + tx - p.pad_x; colq[tx] = (!PAD || (ix >= 0 && ix < p.W)) ? ix : -0x40000000; }
             f32x16_t acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -484,8 +528,9 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
             auto frag = [&](int ks) {
                 const int k0 = ks * 16, t = k0 / C, kc = (k0 % C) / 16;
                 const int ty = t / TW, tx = t % TW;
-                const unsigned qt = qb + (unsigned)(ty * Wb + tx);
-                const unsigned u = qt << 3;
+                int qs = rowq[ty] + colq[tx];
+                if (PAD) qs = qs < 0 ? P : qs;
+                const unsigned u = (unsigned)qs << 3;
                 const unsigned off = (u << 4) + ((((unsigned)(2 * kc) + (unsigned)h) << 4) ^ (u & 0x70u));
                 return *(const bf16x8_t*)(band + off);
             };
@@ -500,7 +545,7 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
                 if (ks + RD < KSTEPS) pf[ks % RD] = frag(ks + RD);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const long off0 = (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
+            const long off0 = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
             uint2 pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -515,10 +560,22 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
             for (int gp = 0; gp < 2; ++gp) {
                 const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
-                if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};                 // channels co_base + 16 gp + 8 h + {0..7}
+                if (BITS == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned two = (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u;
+                        if (!(two & 1u)) o[e] &= 0xffff0000u;
+                        if (!(two & 2u)) o[e] &= 0x0000ffffu;
+                    }
+                }
+                if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) — the BUILTIN: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and guards the band reads again)       // the next band has landed (and this unit's stores are acknowledged)
+        };
+        int ti = 0;
+        for (int tile = part; tile < ntile; tile += WPS, ++ti) do_tile(tile, BITS == 2 ? smask[wave][ti][r] : 0u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the next band has landed (and this unit's stores are acknowledged)
+        if (next < nunits) mask_park();                        // (this unit's words have all been read: same wave, program order)
         __builtin_amdgcn_s_barrier();                          // every wave is done reading this band
     };
     for (; unit < nunits; unit += 2 * gridDim.x) {
@@ -527,13 +584,15 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
     }
 }
 
-template <int NSET, int TH, int TW>
+template <int NSET, int TH, int TW, int BITS, bool PAD>
 int launch_band_glds(BandP& p, hipStream_t s) {
-    const long P = (long)p.H * p.W;
+    const long P = (long)p.H * p.W + (PAD ? 1 : 0);
     if ((P * 128 + 1023) / 1024 * 1024 > GLDS_BAND_BYTES) return -1;
+    const long npix = (long)p.OHmax * p.OWmax;
+    if (BITS == 2 && (npix + 31) / 32 > (long)(NSET == 2 ? 6 : 12) * (8 / NSET)) return -1;      // the per-wave sign-word registers cover a unit's tiles
     const size_t lds = 0;                                    // (static LDS: two bands + the bias table)
     const int nunits = p.Nimg, per = (nunits + 255) / 256, grid = (nunits + per - 1) / per;
-    auto kern = conv_band_glds_kernel<NSET, TH, TW>;
+    auto kern = conv_band_glds_kernel<NSET, TH, TW, BITS, PAD>;
     kern<<<grid, 512, lds, s>>>(p);
     return 0;
 }
@@ -561,6 +620,9 @@ int launch_band(BandP& p, hipStream_t s) {
     }
     return launch_band_db<C, NSET, TH, TW, S, MAXCH, BITS_OK, false>(p, s);
 }
+
+// a ReLU mask that comes as an activation tensor only (no sign planes): the direct-to-LDS instances read planes
+inline bool mask_only(const void* mask, const unsigned* bits_in) { return mask != nullptr && bits_in == nullptr; }
 
 }  // namespace
 
@@ -603,17 +665,21 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     }
     int rc = 1;
     if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1, 7>(p, s);        // conv2 forward (writes sign planes)
-    else if (C == 64 && NSET == 2 && TH == 3 && TW == 3 && S == 1) {                                                   // conv3 forward / data gradient (reads them)
+    else if (C == 64 && S == 1 && ((NSET == 2 && TH == 3 && TW == 3) || (NSET == 4 && TH == 2 && TW == 2))) {
+        // conv3 forward / data gradient, conv2 data gradient (4 parity classes).  Frame-sized maps take the direct-to-LDS instances
+        // (conv_band_glds_kernel; HULC_BAND_GLDS=0: the register-staged kernel; small maps pack several frames into a unit there)
         static const char* ge = getenv("HULC_BAND_GLDS");
         rc = -1;
-        // the forward of a frame-sized map (conv3 of the static camera) takes the direct-to-LDS instance: 85 -> 76 us per 2048 frames
-        // (HULC_BAND_GLDS=0: the register-staged kernel; small maps pack several frames into a unit there)
-        if (!(ge && !atoi(ge)) && pad_y == 0 && pad_x == 0 && !mask && !add && !bits_out && !bits_in && x_dtype == HULC_BF16 && y_dtype == HULC_BF16 &&
-            x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && (long)p.OHmax * p.OWmax >= 256 && ((uintptr_t)x % 16) == 0 && !p.dbg)
-            rc = launch_band_glds<2, 3, 3>(p, s);
-        if (rc == -1) rc = launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s);
+        const bool contiguous = x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && ((uintptr_t)x % 16) == 0;
+        if (!(ge && !atoi(ge)) && !mask_only(mask, bits_in) && !add && !bits_out && x_dtype == HULC_BF16 && y_dtype == HULC_BF16 && contiguous &&
+            (long)p.OHmax * p.OWmax >= 256 && !p.dbg) {
+            const bool padded = pad_y != 0 || pad_x != 0;
+            if (NSET == 2 && !padded && !bits_in) rc = launch_band_glds<2, 3, 3, 0, false>(p, s);
+            else if (NSET == 2 && padded && bits_in) rc = launch_band_glds<2, 3, 3, 2, true>(p, s);
+            else if (NSET == 4 && padded && bits_in) rc = launch_band_glds<4, 2, 2, 2, true>(p, s);
+        }
+        if (rc == -1) rc = NSET == 2 ? launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s) : launch_band<64, 4, 2, 2, 1, 12, 2, 9>(p, s);
     }
-    else if (C == 64 && NSET == 4 && TH == 2 && TW == 2 && S == 1) rc = launch_band<64, 4, 2, 2, 1, 12, 2, 9>(p, s);   // conv2 data gradient, 4 parity classes
     else return 1;
     if (rc == -1) return 1;                      // band does not fit: gather kernel
     if (rc < 0) return hulc_fail(-8, "conv band: could not raise the dynamic LDS limit");
