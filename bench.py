@@ -72,7 +72,8 @@ def cpu_baseline(seconds_budget=24.0):
     threads (the reference's slurm allocation, slurm_scripts/slurm_training.py:22-26, and what the build container has) and with every
     core torch sees.  `value` is the better of the two (a baseline, not a target); both are reported."""
     n_all = torch.get_num_threads()
-    counts = sorted({min(8, n_all), _physical_cores(n_all), n_all})    # 8 (the reference's allocation), the PHYSICAL cores, every hardware thread
+    # 8 (the reference's allocation), 32 (where torch's intra-op scaling of this batch usually peaks), the PHYSICAL cores, every hardware thread
+    counts = sorted({min(8, n_all), min(32, n_all), _physical_cores(n_all), n_all})
     runs = []
     for n in counts:
         torch.set_num_threads(n)

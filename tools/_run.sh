@@ -1,6 +1,10 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_parity_gpu.py tests/test_trainer_gpu.py tests/test_r3m_gpu.py tests/test_uint8_frames_gpu.py -q -m gpu 2>&1 | tail -3
-for i in 1 2 3; do
-HULC_BAND_GLDS=0 python3 bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-230 | sed 's/.*"ms_per_step"/regs ms_per_step/'
-python3 bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-230 | sed 's/.*"ms_per_step"/glds ms_per_step/'
-done
+t0=$(date +%s)
+python3 bench.py > gpurun_out/bench_full.log 2> gpurun_out/bench_full.err
+t1=$(date +%s)
+echo "wall $((t1-t0)) s"
+python3 - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/bench_full.log') if l.startswith('{"metric"')][-1])
+print(d['ms_per_step'], d['value'], json.dumps(d['cpu_baseline'])[:500])
+PY
