@@ -119,14 +119,22 @@ class GradComm:
                     self.probe_ms[algo] = float("inf")
                     continue
                 self.reduce(0, n)                                   # warm-up: communicators (an error HERE is every rank's error: it propagates)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    self.reduce(0, n)
-                e1.record()
-                torch.cuda.synchronize()
-                t = torch.tensor([e0.elapsed_time(e1) / 3], dtype=torch.float32, device=keep.device)
+                if self.on_gpu:
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        self.reduce(0, n)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 3
+                else:                                               # (host process groups: the same probe on the wall clock — what the CPU tests run)
+                    import time
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        self.reduce(0, n)
+                    ms = (time.perf_counter() - t0) / 3 * 1e3
+                t = torch.tensor([ms], dtype=torch.float32, device=keep.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)      # (every rank sees the slowest rank's time)
                 self.probe_ms[algo] = round(float(t.item()), 4)
         finally:

@@ -142,6 +142,17 @@ def _comm_worker(rank, world, port, out):
     res["bf16_auto"] = (cb.algo == "direct", cb.describe()["chosen_by"].startswith("rule"), d["chosen_by"].startswith("rule"))
     c.pin("direct")
     res["pin"] = (c.algo == "direct", c.describe()["chosen_by"] == "checkpoint")
+    # the timing probe itself (on a real fabric it runs when the trainer is built; here on the wall clock): both algorithms timed, every rank
+    # draws the same conclusion, the gradients are untouched, no staging buffer survives
+    g = torch.Generator().manual_seed(3 + rank)
+    arena = torch.randn(4099, generator=g)
+    before = arena.clone()
+    cp = GradComm(arena, None, "ring", "fp32")
+    cp.PROBE_ELEMS = 1024
+    best = cp._probe()
+    votes = [None] * world
+    dist.all_gather_object(votes, best)
+    res["probe"] = (best in ("ring", "direct"), len(set(votes)) == 1, set(cp.probe_ms) == {"ring", "direct"}, torch.equal(arena, before), cp._bufs == {})
     if rank == 0:
         out.put(res)
     dist.destroy_process_group()
@@ -157,7 +168,7 @@ def test_gradient_allreduce_algorithms_world2():
         p.start()
     _join_or_end(procs, 120)
     res = q.get(timeout=5)
-    assert len(res) == 8
+    assert len(res) == 9
     for key, flags in res.items():
         assert all(flags), f"{key}: (sum correct, neighbours untouched, replicas identical) = {flags}"
 
