@@ -24,6 +24,7 @@ struct C1P {
     unsigned* bits;                              // optional ReLU sign plane: one dword per output pixel (bit c = channel c > 0)
     int sweep;                                   // unit order: 0 = a workgroup walks whole frames, 1 = the grid sweeps memory in address order
     long ldw;
+    int dbg;
     int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
     const void* X2; int nsplit;                  // fp32 frames: frames n >= nsplit come from X2 (pre-offset by -nsplit frames); X2 == X when unused
 };
@@ -31,6 +32,19 @@ struct C1P {
 // U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
 // X3 (fp32 frames only): the band is staged as hi + lo bf16 planes, the weights as hi + remainder, every product from the splits of both
 // operands (a_hi b_hi + a_lo b_hi + a_hi b_lo): fp32-class outputs; the layer is HBM-bound, the two extra MFMAs per k-step are not what it waits for
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+HULC_DEVICE uint32_t max_s16x2(uint32_t w, uint32_t floor2) {      // floor2 = 0: ReLU of two bf16; 0x80008000 (the smallest pair): identity
+    union { uint32_t u; s16x2_t s; } x, f; x.u = w; f.u = floor2;
+    x.s = __builtin_elementwise_max(x.s, f.s);
+    return x.u;
+}
+HULC_DEVICE uint32_t nonzero_u16x2(uint32_t w) {                     // 1 per non-zero 16-bit half (as min(half, 1); written as an elementwise min the
+    uint32_t r;                                                      //  compiler turns it into compare + select + permute per half)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
+    return r;
+}
+
 template <int XCH, bool U8, bool X3 = false>
 __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {     // (X3: twice the LDS per workgroup, two per CU: 256 registers)
     constexpr int NT = 512, C = 3, TH = 8, TW = 8, S = 4, K = C * TH * TW, KSTEPS = K / 16;   // 12 k-steps of (c, kh pair)
@@ -66,19 +80,42 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
 
     // the prefetched band stays RAW in registers (8 floats per item / the aligned dword windows of uint8 frames) and is converted in
     // stage_store: any ALU use of a loaded value here would put the wait for the loads in front of the MFMA loop they overlap
-    float4 xraw[XCH][2];
+    constexpr int XF = U8 ? C : XCH;                          // register slots of the fp32 path (dead code in the uint8 instance)
+    f32x4_t xraw[U8 ? 1 : XCH][2];
+    uint32_t uraw[U8 ? XCH * 8 : 1];                          // (uint8 frames: plain dwords — packing a dwordx3 + dword into float4 tuples made the compiler
+                                                             //  copy registers right behind the loads, i.e. wait for every load where it was issued)
     auto unit_geom = [&](int unit, int& n, int& r0, int& R, int& rows) {
         int b = unit % bands;
         n = blockIdx.x + (unit / bands) * gridDim.x;
         if (p.sweep) { const int g = blockIdx.x + unit * gridDim.x; n = g / bands; b = g - n * bands; }
         r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + TH;
     };
+    // (uint8 frames) per-frame parameters — augmentation shift, frame index — of this workgroup's first MAXU units, read once into LDS: as global
+    // loads in front of every unit's prefetch they were two dependent round trips to memory per unit (the pointers sit in a by-value struct,
+    // so the compiler cannot prove them read-only and will not use scalar loads)
+    constexpr int MAXU = 256;
+    int4* ftab = (int4*)(xlds + (long)C * PP * 2);
+    auto frame_params = [&](int unit, int n, int& sx, int& sy, int& fi) {
+        if (unit < MAXU) {
+            const int4 e = ftab[unit];
+            sx = __builtin_amdgcn_readfirstlane(e.x); sy = __builtin_amdgcn_readfirstlane(e.y); fi = __builtin_amdgcn_readfirstlane(e.z);
+        } else {
+            sx = p.shift ? p.shift[2 * n] : p.pad; sy = p.shift ? p.shift[2 * n + 1] : p.pad; fi = p.fidx ? p.fidx[n] : n;
+        }
+    };
+    if (U8) {
+        for (int u = tid; u < (nunits < MAXU ? nunits : MAXU); u += NT) {
+            int n, r0, R, rows; unit_geom(u, n, r0, R, rows);
+            ftab[u] = make_int4(p.shift ? p.shift[2 * n] : p.pad, p.shift ? p.shift[2 * n + 1] : p.pad, p.fidx ? p.fidx[n] : n, 0);
+        }
+        __syncthreads();
+    }
     auto stage_load = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         if (U8) {                                          // uint8 NHWC frames: one item = 8 elements of all three planes
-            const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-            const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
+            int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
+            const unsigned char* img = (const unsigned char*)(n < p.nsplit ? p.X : p.X2) + (long)fi * p.H * p.W * 3;   // (n is uniform: a scalar select)
             // (a uint8 item — 8 pixels of all three channels — is 8 raw dwords, a third of what the same pixels cost as fp32: all XCH register
             //  slots hold items, so a band is up to three times as tall and the per-unit costs (barriers, index arithmetic, a partly filled
             //  last tile) are paid a third as often)
@@ -86,35 +123,31 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             for (int i = 0; i < XCH; ++i) {
                 const int id = tid + i * NT;
                 const bool inb = id < items;
-                uint32_t raw[8];
-                u8_band_chunk3_load(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad, raw);
-                xraw[i][0] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
-                xraw[i][1] = make_float4(__uint_as_float(raw[4]), __uint_as_float(raw[5]), __uint_as_float(raw[6]), __uint_as_float(raw[7]));
+                u8_band_chunk3_load(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad, &uraw[(U8 ? i : 0) * 8]);
             }
             return;
         }
 #pragma unroll
-        for (int j = 0; j < XCH; ++j) {
-            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+        for (int j = 0; j < XF; ++j) {
+            const int c = j / (XF / C), id = tid + (j % (XF / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
             const float* xb = (const float*)(n < p.nsplit ? p.X : p.X2);       // (n is uniform: a scalar select)
-            xraw[j][0] = *(const float4*)(xb + off);
-            xraw[j][1] = *(const float4*)(xb + (inb2 ? off + 4 : off));
+            xraw[U8 ? 0 : j][0] = *(const f32x4_t*)(xb + off);
+            xraw[U8 ? 0 : j][1] = *(const f32x4_t*)(xb + (inb2 ? off + 4 : off));
         }
     };
     auto stage_store = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
-        uint4 xpre[XCH];
+        uint4 xpre[XF];
         if (U8) {
-            const int sx = p.shift ? p.shift[2 * n] : p.pad;
+            int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
                 const int id = tid + i * NT;
                 const bool inb = id < items;
-                const uint32_t raw[8] = {__float_as_uint(xraw[i][0].x), __float_as_uint(xraw[i][0].y), __float_as_uint(xraw[i][0].z), __float_as_uint(xraw[i][0].w),
-                                         __float_as_uint(xraw[i][1].x), __float_as_uint(xraw[i][1].y), __float_as_uint(xraw[i][1].z), __float_as_uint(xraw[i][1].w)};
+                const uint32_t* raw = &uraw[(U8 ? i : 0) * 8];
                 uint4 q0, q1, q2;
                 u8_band_chunk3_convert(p.W, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, raw, q0, q1, q2);
                 if (inb) {
@@ -126,19 +159,19 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             return;
         } else {
 #pragma unroll
-            for (int j = 0; j < XCH; ++j) {
-                const int id = tid + (j % (XCH / C)) * NT;
+            for (int j = 0; j < XF; ++j) {
+                const int id = tid + (j % (XF / C)) * NT;
                 const bool inb2 = id * 8 + 8 <= nflt;
-                const float4 a = xraw[j][0], b = xraw[j][1];
+                const f32x4_t a = xraw[U8 ? 0 : j][0], b = xraw[U8 ? 0 : j][1];
                 xpre[j] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), inb2 ? pack_bf16x2(b.x, b.y) : 0u, inb2 ? pack_bf16x2(b.z, b.w) : 0u);
             }
         }
 #pragma unroll
-        for (int j = 0; j < XCH; ++j) {
-            const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
+        for (int j = 0; j < XF; ++j) {
+            const int c = j / (XF / C), id = tid + (j % (XF / C)) * NT;
             if (id < items) *(uint4*)(xlds + ((long)c * PP + id * 8) * 2) = xpre[j];
             if (X3 && id < items) {                             // remainders a - bf16(a) of the same 8 values
-                const float4 a = xraw[j][0], b = xraw[j][1];
+                const f32x4_t a = xraw[U8 ? 0 : j][0], b = xraw[U8 ? 0 : j][1];
                 const uint4 hi = xpre[j];
                 const uint4 lo = make_uint4(pack_bf16x2(a.x - __uint_as_float(hi.x << 16), a.y - __uint_as_float(hi.x & 0xffff0000u)),
                                             pack_bf16x2(a.z - __uint_as_float(hi.y << 16), a.w - __uint_as_float(hi.y & 0xffff0000u)),
@@ -154,34 +187,59 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
     __syncthreads();
     for (; unit < nunits; ++unit) {
         const int next = unit + 1;
-        if (next < nunits) stage_load(next);
+        // (uint8 frames: the prefetch is unconditional — after the last unit it re-reads that unit's band, from L2, into registers nobody uses.  With
+        //  the previous unit's values flowing around a skipped prefetch the register allocator copied loaded dwords into the loop-carried registers
+        //  right behind each load: a wait for the load where it was issued)
+        if (U8) { if (!(p.dbg & 2)) stage_load(next < nunits ? next : unit); }
+        else if (next < nunits && !(p.dbg & 2)) stage_load(next);
+        // this lane's A-operand fragments (output channel r, half h of every k-step) live in registers over the unit's tiles only: re-read per
+        // unit (12 LDS reads against 36+ fragment reads), they do not sit on the register budget while the next band is converted
+        bf16x8_t wreg[X3 ? 1 : KSTEPS];
+        if (!X3) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) wreg[ks] = *(const bf16x8_t*)(wlds + r * WROW + h * 16 + ks * 32);
+        }
 
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int npix = R * p.OW, ntiles = (npix + 31) / 32;
-        for (int t = wave; t < ntiles; t += 8) {
+        for (int t = wave; t < ((p.dbg & 1) ? 0 : ntiles); t += 8) {
             const int q = t * 32 + r;
             const int qc = q < npix ? q : npix - 1;
             const int oy = fast_div(qc, inv_OW), ox = qc - oy * p.OW;
-            const char* patch = xlds + ((oy * S) * p.W + ox * S + h * p.W) * 2;   // 8-byte aligned: ox*S*2 = 8*ox; lane half h = odd patch row
+            // byte offset of the lane's patch in LDS, band base included (8-byte aligned: ox*S*2 = 8*ox; lane half h = odd patch row): a k-step adds
+            // ONE scalar to it (as pointer + (c, kh) offset + band base the compiler spent two vector adds per k-step)
+            const int patch = (int)(xlds - smem) + ((oy * S) * p.W + ox * S + h * p.W) * 2;
             const char* wrow = wlds + r * WROW + h * 16;
-            f32x16_t acc;
+            f32x16_t acc;                                          // starts from the bias (read next to the first band fragments: one wait, no adds in the epilogue)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int c = ks / 4, kh2 = (ks % 4) * 2;                     // patch row kh2 + h of channel c
-                const char* src = patch + ((long)c * PP + kh2 * p.W) * 2;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 b4 = *(const float4*)(blds + 8 * g4 + 4 * h);
+                acc[g4 * 4 + 0] = b4.x; acc[g4 * 4 + 1] = b4.y; acc[g4 * 4 + 2] = b4.z; acc[g4 * 4 + 3] = b4.w;
+            }
+            // the band fragments of PF k-steps ahead are requested before each MFMA (left alone the compiler reads one fragment, waits for
+            // it, multiplies: the LDS round trip twelve times per tile with four waves per SIMD to hide it)
+            constexpr int PF = X3 ? 1 : 1;
+            auto frag = [&](int ks, int base) {
+                const int c = ks / 4, kh2 = (ks % 4) * 2;                         // patch row kh2 + h of channel c
+                const char* src = smem + (base + (c * PP + kh2 * p.W) * 2);
                 union { uint2 u[2]; bf16x8_t b; } x;
                 x.u[0] = *(const uint2*)src; x.u[1] = *(const uint2*)(src + 8);
-                const bf16x8_t wf = *(const bf16x8_t*)(wrow + ks * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x.b, acc, 0, 0, 0);
+                return x.b;
+            };
+            bf16x8_t xb[PF + 1];
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) xb[ks] = frag(ks, patch);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + PF < KSTEPS) xb[(ks + PF) % (PF + 1)] = frag(ks + PF, patch);
+                if (!X3) __builtin_amdgcn_sched_barrier(0);
+                const bf16x8_t wf = X3 ? *(const bf16x8_t*)(wrow + ks * 32) : wreg[X3 ? 0 : ks];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xb[ks % (PF + 1)], acc, 0, 0, 0);
                 if (X3) {
-                    union { uint2 u[2]; bf16x8_t b; } xl;
-                    const char* sl = src + (xlo - xlds);
-                    xl.u[0] = *(const uint2*)sl; xl.u[1] = *(const uint2*)(sl + 8);
+                    const bf16x8_t xl = frag(ks, patch + (int)(xlo - xlds));
                     const bf16x8_t wl = *(const bf16x8_t*)(wrow + (wlo - wlds) + ks * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xl.b, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, x.b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xb[ks % (PF + 1)], acc, 0, 0, 0);
                 }
             }
             {
@@ -189,26 +247,28 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
                 if (p.y_dtype == HULC_BF16) {
                     // the two lane halves of a pixel hold interleaved groups of 4 channels: v_permlane32_swap gives every lane 8 consecutive
                     // channels — two 16-byte stores per pixel instead of four 8-byte ones
+                    // ReLU on the PACKED words: bf16 bit patterns compare like sign-magnitude integers, so max(x, 0) per signed 16-bit half clears
+                    // exactly the negative halves (-0 included) — 8 v_pk_max_i16 where fmaxf on the 16 floats was 32 VALU (canonicalise + max).
+                    // The tile loop is bound by instruction issue (MFMA 12 x 8 passes against ~200 VALU per tile before this), not by memory.
+                    const uint32_t floor2 = p.relu ? 0u : 0x80008000u;
                     uint2 pk[4];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 b4 = *(const float4*)(blds + 8 * g4 + 4 * h);
-                        float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
-                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                        pk[g4] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        pk[g4] = make_uint2(pack_bf16x2(acc[g4 * 4 + 0], acc[g4 * 4 + 1]), pack_bf16x2(acc[g4 * 4 + 2], acc[g4 * 4 + 3]));
+                        pk[g4].x = max_s16x2(pk[g4].x, floor2); pk[g4].y = max_s16x2(pk[g4].y, floor2);
                     }
                     if (p.bits) {
-                        // sign plane of the stored bf16 values: pk[g4] = channels 8 g4 + 4 h + {0..3}; positive <=> bits in [0x0001, 0x7fff]
+                        // sign plane of the stored (rectified) bf16 values: pk[g4] = channels 8 g4 + 4 h + {0..3}; positive <=> half != 0.
+                        // min(half, 1) per unsigned half gives the bits at positions 0 / 16; two words make a nibble with three more operations
                         unsigned mb = 0;
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
-                            const unsigned w0 = pk[g4].x, w1 = pk[g4].y;
-                            const unsigned nib = ((w0 & 0xffffu) - 1u < 0x7fffu ? 1u : 0u) | ((w0 >> 16) - 1u < 0x7fffu ? 2u : 0u) |
-                                                 ((w1 & 0xffffu) - 1u < 0x7fffu ? 4u : 0u) | ((w1 >> 16) - 1u < 0x7fffu ? 8u : 0u);
-                            mb |= nib << (8 * g4 + 4 * h);
+                            const unsigned u = nonzero_u16x2(pk[g4].x) | (nonzero_u16x2(pk[g4].y) << 2);     // bits 0, 16, 2, 18 = channels 0, 1, 2, 3
+                            mb |= ((u | (u >> 15)) & 0xfu) << (8 * g4);
                         }
-                        mb |= (unsigned)__shfl_xor((int)mb, 32);
-                        if (q < npix && h == 0) p.bits[yo >> 5] = mb;
+                        mb <<= 4 * h;
+                        const auto other = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // [1] on the lower lanes = the upper half's word
+                        if (q < npix && h == 0) p.bits[yo >> 5] = mb | other[1];
                     }
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
@@ -219,8 +279,7 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
                 } else if (q < npix) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 b4 = *(const float4*)(blds + 8 * g4 + 4 * h);
-                        float v0 = acc[g4 * 4 + 0] + b4.x, v1 = acc[g4 * 4 + 1] + b4.y, v2 = acc[g4 * 4 + 2] + b4.z, v3 = acc[g4 * 4 + 3] + b4.w;
+                        float v0 = acc[g4 * 4 + 0], v1 = acc[g4 * 4 + 1], v2 = acc[g4 * 4 + 2], v3 = acc[g4 * 4 + 3];
                         if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         *(float4*)((float*)p.Y + yo + 8 * g4 + 4 * h) = make_float4(v0, v1, v2, v3);
                     }
@@ -228,19 +287,19 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             }
         }
         __syncthreads();
-        if (next < nunits) stage_store(next);
+        if (next < nunits && !(p.dbg & 2)) stage_store(next);
         __syncthreads();
     }
 }
 
-template <int XCH>
+template <int XCH, int UX>
 int launch_conv1(C1P& p, hipStream_t s) {
     const int x3 = p.Wlo != nullptr;
-    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return (1 + x3) * 32 * (192 * 2 + 16) + 128 + (1 + x3) * 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64; };
+    auto lds_of = [&](int R) -> long { const long rows = (R - 1) * 4 + 8; return (1 + x3) * 32 * (192 * 2 + 16) + 128 + (1 + x3) * 3 * ((rows * p.W + 7) / 8 * 8) * 2 + 64 + (p.u8 ? 256 * 16 : 0); };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         static const bool tall = !(getenv("HULC_CONV1_U8_TALL") && atoi(getenv("HULC_CONV1_U8_TALL")) == 0);
-        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * ((p.u8 && tall) ? 1 : 3) <= (long)XCH * 512;
+        return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * ((p.u8 && tall) ? 1 : 3) <= (long)(p.u8 ? UX : XCH) * 512;
     };
     int R = p.OH;
     while (R > 1 && !fits(R)) --R;
@@ -257,11 +316,11 @@ int launch_conv1(C1P& p, hipStream_t s) {
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv1_band_kernel<XCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
+            hipFuncSetAttribute((const void*)conv1_band_kernel<UX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
         attr_set = true;
     }
     if (x3) conv1_band_kernel<XCH, false, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
-    else if (p.u8) conv1_band_kernel<XCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
+    else if (p.u8) conv1_band_kernel<UX, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     else conv1_band_kernel<XCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     return 0;
 }
@@ -279,14 +338,17 @@ int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ld
     if (relu_bits && (y_dtype != HULC_BF16 || !relu)) return 1;       // (planes describe the stored bf16 ReLU output)
     if (w_lo && (u8 || (uintptr_t)w_lo % 16)) return hulc_fail(-6, "conv1 band: split operands need fp32 frames and 16-byte aligned remainders");
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx; p.bits = relu_bits; p.Wlo = w_lo;
+    { static const char* e = getenv("HULC_C1_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.X2 = x; p.nsplit = N;
     if (x2) {
-        if (u8 || n_split < 0 || n_split > N || ((uintptr_t)x2 % 16)) return hulc_fail(-6, "conv1 band: x2 needs fp32 frames, 0 <= n_split <= N, 16-byte alignment");
-        p.X2 = (const float*)x2 - (long)n_split * 3 * H * W; p.nsplit = n_split;
+        if (n_split < 0 || n_split > N || ((uintptr_t)x2 % (u8 ? 4 : 16)) || (u8 && fidx))
+            return hulc_fail(-6, "conv1 band: x2 needs 0 <= n_split <= N, 16-byte (uint8 frames: 4-byte) alignment and no frame_index");
+        p.X2 = u8 ? (const float*)((const unsigned char*)x2 - (long)n_split * 3 * H * W) : (const float*)x2 - (long)n_split * 3 * H * W;
+        p.nsplit = n_split;
     }
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - 8) / 4 + 1; p.OW = (W - 8) / 4 + 1; p.R = 1; p.ldw = ldw;
-    const int rc = launch_conv1<3>(p, s);
+    const int rc = launch_conv1<3, 2>(p, s);
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv1 band: could not raise the dynamic LDS limit");
     return 0;

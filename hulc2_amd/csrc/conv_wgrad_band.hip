@@ -412,12 +412,31 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         n = blockIdx.x + (unit / bands) * gridDim.x;
         r0 = b * p.R; R = (r0 + p.R <= p.OH) ? p.R : p.OH - r0; rows = (R - 1) * S + 8;
     };
+    // (uint8 frames) per-frame parameters — augmentation shift, frame index — of this workgroup's first MAXU units, read once into LDS (see
+    // conv1_band.hip: as global loads they were two dependent round trips to memory in front of every unit's prefetch)
+    constexpr int MAXU = 256;
+    int4* ftab = (int4*)(smem + xbytes + (p.R * p.OWP + 8) * 96 + 64);
+    auto frame_params = [&](int unit, int n, int& sx, int& sy, int& fi) {
+        if (unit < MAXU) {
+            const int4 e = ftab[unit];
+            sx = __builtin_amdgcn_readfirstlane(e.x); sy = __builtin_amdgcn_readfirstlane(e.y); fi = __builtin_amdgcn_readfirstlane(e.z);
+        } else {
+            sx = p.shift ? p.shift[2 * n] : p.pad; sy = p.shift ? p.shift[2 * n + 1] : p.pad; fi = p.fidx ? p.fidx[n] : n;
+        }
+    };
+    if (U8) {
+        for (int u = tid; u < (nunits < MAXU ? nunits : MAXU); u += NT) {
+            int n, r0, R, rows; unit_geom(u, n, r0, R, rows);
+            ftab[u] = make_int4(p.shift ? p.shift[2 * n] : p.pad, p.shift ? p.shift[2 * n + 1] : p.pad, p.fidx ? p.fidx[n] : n, 0);
+        }
+        __syncthreads();
+    }
     auto stage_load = [&](int unit) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         if (U8) {                                          // uint8 NHWC frames: item = 8 elements of all three planes = 2 x (4 aligned dwords)
-            const int sx = p.shift ? p.shift[2 * n] : p.pad, sy = p.shift ? p.shift[2 * n + 1] : p.pad;
-            const unsigned char* img = (const unsigned char*)p.X + (long)(p.fidx ? p.fidx[n] : n) * p.H * p.W * 3;
+            int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
+            const unsigned char* img = (const unsigned char*)(n < p.nsplit ? p.X : p.X2) + (long)fi * p.H * p.W * 3;   // (n is uniform: a scalar select)
 #pragma unroll
             for (int i = 0; i < XCH / 3; ++i) {
                 const int id = tid + i * NT;
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         const bool w8 = (p.W & 7) == 0;                    // chunks never straddle a row and start at an even plane index
         uint4 xpre[XCH];
         if (U8) {
-            const int sx = p.shift ? p.shift[2 * n] : p.pad;
+            int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
 #pragma unroll
             for (int i = 0; i < XCH / 3; ++i) {
                 const int id = tid + i * NT;
@@ -595,7 +614,7 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     p.PSTR = ((p.OWP + 2) * 2 + 15) / 16 * 16;
     if (((p.PSTR / 16) & 1) == 0) p.PSTR += 16;
     auto at_row = [&](int R) -> int { int a = R * p.OWP * 2 + 16; if (((a / 16) & 1) == 0) a += 16; return a; };
-    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + (long)(R * p.OWP + 8) * 96 + 64; };
+    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + (long)(R * p.OWP + 8) * 96 + 64 + (p.u8 ? 256 * 16 : 0); };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512 && (long)R * p.OW * 4 <= (long)YCH * 512;
@@ -703,8 +722,8 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
         rc = pure16 ? launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1, true>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s)
                     : launch_wband<32, 2, 4, 4, 2, false, 10, 5, 1>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
     else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0))) {
-        if (x2 && (u8 || dy_dtype != HULC_BF16 || n_split < 0 || n_split > N || ((uintptr_t)x2 % 16) || getenv("HULC_CONV1_WGRAD_OLD")))
-            return hulc_fail(-6, "conv1 weight gradient: x2 needs fp32 frames, a bf16 gradient map, 0 <= n_split <= N, 16-byte alignment");
+        if (x2 && (dy_dtype != HULC_BF16 || n_split < 0 || n_split > N || ((uintptr_t)x2 % (u8 ? 4 : 16)) || (u8 && fidx) || getenv("HULC_CONV1_WGRAD_OLD")))
+            return hulc_fail(-6, "conv1 weight gradient: x2 needs a bf16 gradient map, 0 <= n_split <= N, 16-byte (uint8 frames: 4-byte) alignment, no frame_index");
         if (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16) rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
         else {
             W1P q;
@@ -712,7 +731,10 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
             q.dy_sn = p.dy_sn; q.dy_sy = p.dy_sy; q.dy_sx = p.dy_sx;
             q.u8 = u8; q.pad = pad; q.shift = shift; q.fidx = fidx;
             q.X2 = x; q.nsplit = N;
-            if (x2) { q.X2 = (const float*)x2 - (long)n_split * 3 * H * W; q.nsplit = n_split; }
+            if (x2) {
+                q.X2 = u8 ? (const float*)((const unsigned char*)x2 - (long)n_split * 3 * H * W) : (const float*)x2 - (long)n_split * 3 * H * W;
+                q.nsplit = n_split;
+            }
             q.dbg = getenv("HULC_W1_DBG") ? atoi(getenv("HULC_W1_DBG")) : 0;
             rc = launch_conv1_wgrad(q, dw, db, ws, ws_bytes, accumulate, s);
         }

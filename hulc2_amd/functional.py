@@ -363,13 +363,22 @@ def dual_mlp(xa, layers_a, xb, layers_b, exact_b: bool = False):
 # conv stack of a camera encoder -> NHWC ReLU activations of conv3
 # reference: vision_network.py:36-47, vision_network_gripper.py:11-20
 # ------------------------------------------------------------------------------------------------
-def _conv1_pair_ok(xs, u8, bits, cout) -> bool:
-    """two fp32 NCHW frame tensors of one geometry in the bf16 modes: conv1 takes both in one launch (the band kernels' x2); the sign plane of a
-    32-channel conv1 is one plane, so the two inputs' slices are one contiguous tensor"""
-    return (len(xs) == 2 and not u8 and xs[0].dtype == torch.float32 and xs[1].dtype == torch.float32 and xs[0].shape[1:] == xs[1].shape[1:]
-            and xs[0].shape[-1] % 4 == 0 and (xs[0].shape[-2] - 8) % 4 == 0 and xs[0].is_contiguous() and xs[1].is_contiguous()
-            and xs[0].data_ptr() % 16 == 0 and xs[1].data_ptr() % 16 == 0 and cout == 32
-            and kn.base_mode() != "fp32" and kn.get_compute() == "bf16" and not os.environ.get("HULC_CONV1_PER_INPUT"))
+def _conv1_pair_ok(xs, u8, bits, cout, shifts=None, indices=None) -> bool:
+    """two frame tensors of one geometry in the bf16 modes — fp32 NCHW, or uint8 NHWC with both or neither augmentation shift (plain tensors, or
+    both inputs windows of ONE episode store: then the launch indexes the store with the two index lists back to back): conv1 takes both in one launch (the band kernels' x2); the sign plane of a 32-channel conv1 is one plane, so the two inputs'
+    slices are one contiguous tensor"""
+    if len(xs) != 2 or xs[0].dtype != xs[1].dtype or xs[0].shape[1:] != xs[1].shape[1:] or not (xs[0].is_contiguous() and xs[1].is_contiguous()):
+        return False
+    if cout != 32 or kn.base_mode() == "fp32" or kn.get_compute() != "bf16" or os.environ.get("HULC_CONV1_PER_INPUT"):
+        return False
+    if u8:
+        H, W = xs[0].shape[1], xs[0].shape[2]
+        sh, ix = shifts or [None, None], indices or [None, None]
+        same_store = ix[0] is not None and ix[1] is not None and xs[0].data_ptr() == xs[1].data_ptr() and xs[0].shape == xs[1].shape
+        return (xs[0].dtype == torch.uint8 and W % 4 == 0 and (H - 8) % 4 == 0 and (W - 8) % 4 == 0 and ((ix[0] is None and ix[1] is None) or same_store)
+                and (sh[0] is None) == (sh[1] is None) and xs[0].data_ptr() % 4 == 0 and xs[1].data_ptr() % 4 == 0)
+    return (xs[0].dtype == torch.float32 and xs[0].shape[-1] % 4 == 0 and (xs[0].shape[-2] - 8) % 4 == 0
+            and xs[0].data_ptr() % 16 == 0 and xs[1].data_ptr() % 16 == 0)
 
 
 @_scoped
@@ -418,9 +427,14 @@ class ConvStackFn(torch.autograd.Function):
                 # selective precision site "conv1": fp32 frames and weights as hi + lo bf16 splits, three MFMAs per product (fp32-class a1)
                 w_lo = weight_operand(ws[0], "oihw_flat_lo") if (not u8 and _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16"
                                                                   and "conv1" in kn.fp32_sites()) else None
-                if _conv1_pair_ok(xs, u8, bits[li], cout):
+                if _conv1_pair_ok(xs, u8, bits[li], cout, shifts, indices):
                     # the two modalities of a step (two frame tensors, never concatenated) as ONE conv1 launch: hulc_conv_desc.x2 (round 4)
-                    kn.conv2d_fwd(xs[0], w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, w_lo=w_lo, relu_bits=bits[li], x2=xs[1])
+                    # (uint8 frames: the per-frame shifts of the two inputs as one small tensor, kept for the weight gradient)
+                    pair_shift = torch.cat([shifts[0], shifts[1]]) if (u8 and shifts[0] is not None) else None
+                    pair_index = torch.cat([indices[0], indices[1]]) if (u8 and indices[0] is not None) else None
+                    ctx.pair_aug = (pair_shift, pair_index)
+                    kn.conv2d_fwd(xs[0], w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, w_lo=w_lo, relu_bits=bits[li],
+                                  x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
                 else:
                     for x, n, sh, ix in zip(xs, Ns, shifts, indices):
                         kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
@@ -479,8 +493,10 @@ class ConvStackFn(torch.autograd.Function):
             if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
                 pad, shifts, indices = ctx.aug
-                if _conv1_pair_ok(xs, xs[0].dtype == torch.uint8, None, cout) and g.dtype == torch.bfloat16:
-                    kn.conv2d_bwd_weight(xs[0], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc, x2=xs[1])
+                if _conv1_pair_ok(xs, xs[0].dtype == torch.uint8, None, cout, shifts, indices) and g.dtype == torch.bfloat16:
+                    pair_shift, pair_index = getattr(ctx, "pair_aug", (None, None))
+                    kn.conv2d_bwd_weight(xs[0], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc,
+                                         x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
                 else:
                     for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
                         kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc or j > 0,

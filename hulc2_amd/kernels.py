@@ -352,12 +352,13 @@ def _u8_frames(d, x, aug_shift, aug_pad, frame_index=None):
 
 
 def _second_frames(d, x, x2, N, Cin, H, W):
-    """hulc_conv_desc.x2 / n_split: conv1 over two fp32 NCHW frame tensors (the modalities of a step) as one launch"""
+    """hulc_conv_desc.x2 / n_split: conv1 over two frame tensors (the modalities of a step; fp32 NCHW or uint8 NHWC, both alike) as one launch"""
     if x2 is None:
         return
     _require_cuda(x2)
-    if x.dtype != torch.float32 or x2.dtype != torch.float32 or not x2.is_contiguous() or x2.shape[1:] != x.shape[1:] or x.shape[0] + x2.shape[0] != N:
-        raise TypeError("x2: a second contiguous fp32 NCHW frame tensor; N = frames of x + frames of x2")
+    if (x.dtype not in (torch.float32, torch.uint8) or x2.dtype != x.dtype or not x2.is_contiguous() or x2.shape[1:] != x.shape[1:]
+            or x.shape[0] + x2.shape[0] != N):
+        raise TypeError("x2: a second contiguous frame tensor of x's type and geometry (fp32 NCHW or uint8 NHWC); N = frames of x + frames of x2")
     d.x2, d.n_split = x2.data_ptr(), int(x.shape[0])
 
 

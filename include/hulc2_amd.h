@@ -92,7 +92,8 @@ typedef struct {
      * splits of both operands (three bf16 MFMAs): fp32-class outputs on the bf16 matrix pipe — the selective-precision site "conv1"
      * (DESIGN §5).  NULL = plain bf16 operands. */
     const void* w_lo;
-    /* (ABI 4) conv1 on fp32 NCHW frames (hulc_conv2d_fwd and hulc_conv2d_bwd_weight, LDS-band kernels only): a SECOND frame tensor — frames
+    /* (ABI 4) conv1 on fp32 NCHW frames — or uint8 NHWC frames without frame_index, aug_shift then holding all N frames' shifts —
+     * (hulc_conv2d_fwd and hulc_conv2d_bwd_weight, LDS-band kernels only): a SECOND frame tensor of x's type and geometry — frames
      * n >= n_split are frame n - n_split of x2.  The vision and the language modality of a step are two tensors (hulc2.py:336-361: one
      * batch dict per modality) that are never concatenated (1 GB); with x2 their conv1 runs as ONE launch per direction instead of one per
      * modality (one prologue, one set of weight-gradient slabs, one reduce).  NULL = all N frames in x. */

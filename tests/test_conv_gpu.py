@@ -213,3 +213,39 @@ def test_conv1_two_frame_tensors_in_one_launch(dev, name, Na, Nb, H, W):
     wd = torch.zeros(32, 3, 8, 8, dtype=torch.float64, device=dev, requires_grad=True)
     F.conv2d(xall, wd, None, stride=4).backward(dy.double().permute(0, 3, 1, 2))
     assert float((dw2.double() - wd.grad.reshape(32, -1)).abs().max()) <= 2e-3 * float(wd.grad.abs().max())
+
+
+@pytest.mark.parametrize("name,Na,Nb,H,W,shift", [("static1", 5, 3, 200, 200, True), ("grip1", 2, 7, 84, 84, True), ("static1-no-aug", 3, 4, 200, 200, False)])
+def test_conv1_two_uint8_frame_tensors_in_one_launch(dev, name, Na, Nb, H, W, shift):
+    """x2 with uint8 NHWC frames: the two modalities' frame tensors, their per-frame augmentation shifts as one (N, 2)
+    tensor — forward and sign plane bit-identical to the two launches, weight gradient to fp32 rounding (one set of slabs instead of two
+    accumulating launches)."""
+    from hulc2_amd import kernels as kn
+    g = torch.Generator().manual_seed(6)
+    xa = torch.randint(0, 256, (Na, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    xb = torch.randint(0, 256, (Nb, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    pad = 10 if H == 200 else 4
+    sa = torch.randint(0, 2 * pad + 1, (Na, 2), generator=g, dtype=torch.int32).to(dev) if shift else None
+    sb = torch.randint(0, 2 * pad + 1, (Nb, 2), generator=g, dtype=torch.int32).to(dev) if shift else None
+    sab = torch.cat([sa, sb]) if shift else None
+    w2d = ((torch.rand(32, 192, generator=g) * 2 - 1) / 192 ** 0.5).to(dev).to(torch.bfloat16)
+    b = ((torch.rand(32, generator=g) * 2 - 1) * 0.1).to(dev)
+    N = Na + Nb
+    OH, OW = kn.conv_out_hw(H, W, 8, 8, 4)
+    y1 = torch.zeros(N, OH, OW, 32, dtype=torch.bfloat16, device=dev)
+    y2 = torch.zeros_like(y1)
+    b1 = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev)
+    b2 = torch.zeros_like(b1)
+    kn.conv2d_fwd(xa, w2d, b, y1[:Na], Na, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b1[:Na * OH * OW], aug_shift=sa, aug_pad=pad)
+    kn.conv2d_fwd(xb, w2d, b, y1[Na:], Nb, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b1[Na * OH * OW:], aug_shift=sb, aug_pad=pad)
+    kn.conv2d_fwd(xa, w2d, b, y2, N, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=b2, x2=xb, aug_shift=sab, aug_pad=pad)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)) and torch.equal(b1, b2)
+    dy = torch.randn(N, OH, OW, 32, generator=g).to(dev).to(torch.bfloat16)
+    dw1, db1 = torch.zeros(32, 192, device=dev), torch.zeros(32, device=dev)
+    dw2, db2 = torch.zeros(32, 192, device=dev), torch.zeros(32, device=dev)
+    kn.conv2d_bwd_weight(xa, dy[:Na].contiguous(), dw1, db1, Na, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, aug_shift=sa, aug_pad=pad)
+    kn.conv2d_bwd_weight(xb, dy[Na:].contiguous(), dw1, db1, Nb, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, accumulate=True, aug_shift=sb, aug_pad=pad)
+    kn.conv2d_bwd_weight(xa, dy, dw2, db2, N, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, x2=xb, aug_shift=sab, aug_pad=pad)
+    torch.cuda.synchronize()
+    assert float((dw1 - dw2).abs().max()) <= 1e-5 * float(dw1.abs().max()) and float((db1 - db2).abs().max()) <= 1e-5 * float(db1.abs().max())

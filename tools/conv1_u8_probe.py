@@ -1,5 +1,6 @@
 """conv1 on uint8 NHWC frames vs fp32 NCHW frames: forward and weight gradient, 1024 static frames, graph-timed.
-HULC_W1_DBG bits (1: no MFMA loop, 8: no prefetch loads) split the weight gradient's time."""
+HULC_W1_DBG bits (1: no MFMA loop, 8: no prefetch loads) split the weight gradient's time, HULC_C1_DBG bits (1: no tile loop, 2: no
+staging after the first band) the forward's.  HULC_LIB=<another build of the library> gives an A/B inside one gpurun call."""
 import os, sys
 import torch
 sys.path.insert(0, '.')
