@@ -32,19 +32,6 @@ struct C1P {
 // U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
 // X3 (fp32 frames only): the band is staged as hi + lo bf16 planes, the weights as hi + remainder, every product from the splits of both
 // operands (a_hi b_hi + a_lo b_hi + a_hi b_lo): fp32-class outputs; the layer is HBM-bound, the two extra MFMAs per k-step are not what it waits for
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-HULC_DEVICE uint32_t max_s16x2(uint32_t w, uint32_t floor2) {      // floor2 = 0: ReLU of two bf16; 0x80008000 (the smallest pair): identity
-    union { uint32_t u; s16x2_t s; } x, f; x.u = w; f.u = floor2;
-    x.s = __builtin_elementwise_max(x.s, f.s);
-    return x.u;
-}
-HULC_DEVICE uint32_t nonzero_u16x2(uint32_t w) {                     // 1 per non-zero 16-bit half (as min(half, 1); written as an elementwise min the
-    uint32_t r;                                                      //  compiler turns it into compare + select + permute per half)
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
-    return r;
-}
-
 template <int XCH, bool U8, bool X3 = false>
 __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {     // (X3: twice the LDS per workgroup, two per CU: 256 registers)
     constexpr int NT = 512, C = 3, TH = 8, TW = 8, S = 4, K = C * TH * TW, KSTEPS = K / 16;   // 12 k-steps of (c, kh pair)

@@ -253,8 +253,11 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                 // bf16 outputs: the two lane halves of a pixel hold interleaved groups of 4 channels (8-byte pieces).  v_permlane32_swap
                 // trades the odd pieces of the lower half for the even pieces of the upper half: every lane then owns 8 consecutive
                 // channels — two 16-byte stores (and mask loads) per pixel instead of four 8-byte ones.
+                // (ReLU on the PACKED words — max per signed 16-bit half —, sign bits from min(half, 1), mask bits applied as a packed multiply:
+                //  a tile's MFMAs and its epilogue VALU share the SIMD's issue slot, ~60 instructions fewer per tile than float max / compare chains)
                 uint2 pk[4];
                 unsigned mb_out = 0;
+                const uint32_t floor2 = p.relu ? 0u : 0x80008000u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
@@ -263,11 +266,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                         v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
                         v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
                     }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    pk[g] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    pk[g] = make_uint2(max_s16x2(pack_bf16x2(v[0], v[1]), floor2), max_s16x2(pack_bf16x2(v[2], v[3]), floor2));
                 }
                 // (double band) the next band goes to LDS here — behind the wave's SECOND MFMA loop, with the tile packed into 8 registers and
                 // BEFORE its stores: the vmcnt(0) in front of the LDS write covers the prefetch and the previous tile's stores only
@@ -280,11 +279,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                     const long off = off0 + 16 * gp + 8 * h;
                     if (BITS == 2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned two = (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u;
-                            if (!(two & 1u)) o[e] &= 0xffff0000u;
-                            if (!(two & 2u)) o[e] &= 0x0000ffffu;
-                        }
+                        for (int e = 0; e < 4; ++e) o[e] = keep_u16x2(o[e], (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u);
                     } else if (p.mask) {
                         const uint4 m = *(const uint4*)((const uint16_t*)p.mask + off);
                         const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
@@ -294,17 +289,16 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                             if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) o[e] &= 0x0000ffffu;
                         }
                     }
-                    if (BITS == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned two = ((o[e] & 0xffffu) - 1u < 0x7fffu ? 1u : 0u) | ((o[e] >> 16) - 1u < 0x7fffu ? 2u : 0u);
-                            mb_out |= two << (16 * gp + 8 * h + 2 * e);
-                        }
+                    if (BITS == 1) {                                              // (rectified values: positive <=> half != 0; the dispatch insists on relu)
+                        const unsigned a = nonzero_u16x2(o[0]) | (nonzero_u16x2(o[1]) << 2) | (nonzero_u16x2(o[2]) << 4) | (nonzero_u16x2(o[3]) << 6);
+                        mb_out |= ((a | (a >> 15)) & 0xffu) << (16 * gp);         // even bits from the low halves, odd bits from the high halves
                     }
                     if (live && !(p.dbg & 2)) *(uint4*)((uint16_t*)p.Y + off) = make_uint4(o[0], o[1], o[2], o[3]);
                 }
                 if (BITS == 1) {
-                    mb_out |= (unsigned)__shfl_xor((int)mb_out, 32);
+                    mb_out <<= 8 * h;
+                    const auto other = __builtin_amdgcn_permlane32_swap(mb_out, mb_out, false, false);   // [1] on the lower lanes = the upper half's word
+                    mb_out |= other[1];
                     if (live && h == 0) p.bits_out[(long)(cl_co >> 5) * p.bplane + ((off0 - cl_co) >> p.bshift)] = mb_out;   // 32 lanes: 128 contiguous bytes
                 }
             } else {
@@ -547,15 +541,10 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
             }
             const long off0 = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
             uint2 pk[4];
+            const uint32_t floor2 = p.relu ? 0u : 0x80008000u;  // (ReLU on the packed words: see the register kernel's epilogue)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                pk[g] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
+            for (int g = 0; g < 4; ++g)
+                pk[g] = make_uint2(max_s16x2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), floor2), max_s16x2(pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]), floor2));
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
@@ -563,11 +552,7 @@ __global__ __launch_bounds__(512) void conv_band_glds_kernel(BandP p) {
                 uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};                 // channels co_base + 16 gp + 8 h + {0..7}
                 if (BITS == 2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned two = (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u;
-                        if (!(two & 1u)) o[e] &= 0xffff0000u;
-                        if (!(two & 2u)) o[e] &= 0x0000ffffu;
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] = keep_u16x2(o[e], (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u);
                 }
                 if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
             }
@@ -649,6 +634,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
         p.bplane = (long)N * y_sn / bits_channels;           // pixels of the (dense) tensor the planes describe
     }
     if (add && y_dtype != HULC_BF16) return 1;
+    if (bits_out && !relu) return 1;                        // (the planes describe a rectified map: positive <=> non-zero)
     if (w_dtype != HULC_BF16 || (mask && mask_dtype != HULC_BF16)) return 1;   // the gather kernel serves other storage types
     p.x_dtype = x_dtype; p.y_dtype = y_dtype; p.w_dtype = w_dtype; p.mask_dtype = mask_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.pad_y = pad_y; p.pad_x = pad_x; p.R = 1; p.F = 1;

@@ -38,6 +38,25 @@ HULC_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
     return x.u;
 }
 
+// ---- packed bf16 pairs as 16-bit integers (epilogues of the band kernels: their tile loops are bound by instruction issue, every VALU counts)
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+HULC_DEVICE uint32_t max_s16x2(uint32_t w, uint32_t floor2) {      // floor2 = 0: ReLU of two bf16 (their bit patterns order like sign-magnitude
+    union { uint32_t u; s16x2_t s; } x, f; x.u = w; f.u = floor2;   //  integers: negative halves, -0 included, become +0); 0x80008000: identity
+    x.s = __builtin_elementwise_max(x.s, f.s);
+    return x.u;
+}
+HULC_DEVICE uint32_t nonzero_u16x2(uint32_t w) {                    // 1 per non-zero 16-bit half, at bits 0 and 16 (as min(half, 1); written as an
+    uint32_t r;                                                     //  elementwise min the compiler expands it to compare + select + permute per half)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
+    return r;
+}
+HULC_DEVICE uint32_t keep_u16x2(uint32_t w, uint32_t two) {         // bit 0 / bit 1 of `two`: keep the low / high half of w, else zero it
+    const uint32_t t = (two | (two << 15)) & 0x00010001u;
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(t));
+    return r;
+}
+
 HULC_DEVICE uint16_t f32_to_bf16_bits(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // generic typed element load/store by runtime dtype code

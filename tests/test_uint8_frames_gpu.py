@@ -97,3 +97,44 @@ def test_training_step_from_uint8_frames(dev):
         # whole-step bf16 gradients: the 6e-5 input differences (grid_sample rounding) flip bf16 roundings / ReLU masks upstream;
         # same bound as the bf16 gradient tolerance of tests/test_parity_gpu.py
         assert ((outs[0][i] - outs[1][i]).norm() / outs[0][i].norm()).item() < 0.15
+
+
+@pytest.mark.parametrize("form", ["two_tensors", "one_store"])
+def test_conv_stack_takes_both_modalities_in_one_conv1_launch(dev, form, monkeypatch):
+    """functional.conv_stack on the two modalities' uint8 frames: conv1 as ONE launch per direction (two frame tensors: hulc_conv_desc.x2; two
+    windows of one episode store: one index list) against one launch per modality (HULC_CONV1_PER_INPUT=1) — the activations bit for bit,
+    conv1's weight and bias gradients to fp32 rounding of another summation order (1e-5 of the largest entry), everything downstream bit for bit."""
+    from hulc2_amd import functional as HF, kernels as kn
+
+    kn.set_compute("bf16")
+    g = torch.Generator().manual_seed(12)
+    hw, pad, Na, Nb = 200, 10, 6, 4
+    ws = [((torch.rand(32, 3, 8, 8, generator=g) * 2 - 1) / 192 ** 0.5), torch.zeros(32),
+          ((torch.rand(64, 32, 4, 4, generator=g) * 2 - 1) / 512 ** 0.5), torch.zeros(64),
+          ((torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 576 ** 0.5), torch.zeros(64)]
+    sa = torch.randint(0, 2 * pad + 1, (Na, 2), generator=g, dtype=torch.int32).to(dev)
+    sb = torch.randint(0, 2 * pad + 1, (Nb, 2), generator=g, dtype=torch.int32).to(dev)
+    if form == "two_tensors":
+        xs = [torch.randint(0, 256, (n, hw, hw, 3), generator=g, dtype=torch.uint8).to(dev) for n in (Na, Nb)]
+        index = None
+    else:
+        store = torch.randint(0, 256, (16, hw, hw, 3), generator=g, dtype=torch.uint8).to(dev)
+        xs = [store, store]
+        index = [torch.randint(0, 16, (n,), generator=g, dtype=torch.int32).to(dev) for n in (Na, Nb)]
+    outs = []
+    for per_input in ("1", ""):
+        if per_input:
+            monkeypatch.setenv("HULC_CONV1_PER_INPUT", per_input)
+        else:
+            monkeypatch.delenv("HULC_CONV1_PER_INPUT", raising=False)
+        params = [w.clone().to(dev).requires_grad_(True) for w in ws]
+        a3 = HF.conv_stack(xs, params, aug_pad=pad, aug_shifts=[sa, sb], frame_index=index)
+        (a3.float() * torch.linspace(-1, 1, a3.numel(), device=dev).reshape(a3.shape)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((a3.detach().clone(), [q.grad.clone() for q in params]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for i, (a, c) in enumerate(zip(outs[0][1], outs[1][1])):
+        if i < 2:                                        # conv1's weight and bias gradients: one set of partial sums instead of two
+            assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), f"gradient {i}"
+        else:
+            assert torch.equal(a, c), f"gradient {i}"

@@ -188,8 +188,11 @@ def test_conv1_reads_the_store_in_place(dev, tag, hw, pad):
 
 
 @pytest.mark.gpu
-def test_training_step_from_the_store(dev):
-    """Hulc2.training_step on store-backed windows (index rows, nothing gathered) == on the materialised padded uint8 windows"""
+def test_training_step_from_the_store(dev, monkeypatch):
+    """Hulc2.training_step on store-backed windows (index rows, nothing gathered) == on the materialised padded uint8 windows, bit for bit.
+    (conv1 launched per modality on both sides: two materialised tensors would otherwise share ONE launch — another summation order of the
+    weight gradient's slabs — while windows of two different stores cannot; the one-launch forms have their own test in test_conv_gpu.py)"""
+    monkeypatch.setenv("HULC_CONV1_PER_INPUT", "1")
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
     from hulc2_amd.config import default_model_config
