@@ -238,10 +238,13 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             auto tr = [](const char* a) -> v4s { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)a); };
             const int prow = (lane & 15) >> 2;                                  // pixel row of the 4 x 16 block this lane addresses
             const char* abase = at + prow * DROW + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
-            for (int s = 0; s < nsteps; ++s) {
-                const int m0 = s * 16 + h * 8;                                  // this lane half's 8 pixels
-                const int po0 = pixoff[m0 + prow], po1 = pixoff[m0 + 4 + prow];
-                bf16x8_t a[CT];
+            // software-pipelined by hand, two steps per trip (fragment sets A / B alternate, nothing is copied): the patch offsets of a step are
+            // read two steps ahead, its fragments one step ahead (their addresses need the offsets), its MFMAs last.  Left as
+            // read offsets -> wait -> read fragments -> wait -> multiply, every step paid two LDS round trips with two waves per SIMD to hide them
+            // (MFMA pipe 20 % busy).  Steps past the end re-read the last step (clamped), they are not multiplied.
+            auto load_po = [&](int st, int& q0, int& q1) { const int m0 = st * 16 + h * 8; q0 = pixoff[m0 + prow]; q1 = pixoff[m0 + 4 + prow]; };
+            auto load_fr = [&](int st, int q0, int q1, bf16x8_t (&a)[CT], bf16x8_t (&x)[MAXT]) {
+                const int m0 = st * 16 + h * 8;                                 // this lane half's 8 pixels
 #pragma unroll
                 for (int i = 0; i < CT; ++i) {
                     union { v4s v[2]; bf16x8_t b; } f;
@@ -251,11 +254,61 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
                     if (!kt_live[t]) continue;                                  // wave-uniform
-                    union { v4s v[2]; bf16x8_t b; } x;
-                    x.v[0] = tr(xband + po0 + koff[t]); x.v[1] = tr(xband + po1 + koff[t]);
-#pragma unroll
-                    for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
+                    union { v4s v[2]; bf16x8_t b; } f;
+                    f.v[0] = tr(xband + q0 + koff[t]); f.v[1] = tr(xband + q1 + koff[t]);
+                    x[t] = f.b;
                 }
+            };
+            auto mm = [&](const bf16x8_t (&a)[CT], const bf16x8_t (&x)[MAXT]) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    if (!kt_live[t]) continue;
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x[t], acc[t][i], 0, 0, 0);
+                }
+            };
+            // (conv2's geometry only: with conv3's three k tiles per wave the alternating sets cost registers and tail re-reads, measured 5 % slower)
+            constexpr bool PIPE = (C == 32);
+            if (!PIPE) {
+                for (int st = 0; st < nsteps; ++st) {
+                    const int m0 = st * 16 + h * 8;                             // this lane half's 8 pixels
+                    const int po0 = pixoff[m0 + prow], po1 = pixoff[m0 + 4 + prow];
+                    bf16x8_t a[CT];
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) {
+                        union { v4s v[2]; bf16x8_t b; } f;
+                        f.v[0] = tr(abase + m0 * DROW + i * 64); f.v[1] = tr(abase + (m0 + 4) * DROW + i * 64);
+                        a[i] = f.b;
+                    }
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) {
+                        if (!kt_live[t]) continue;                              // wave-uniform
+                        union { v4s v[2]; bf16x8_t b; } x;
+                        x.v[0] = tr(xband + po0 + koff[t]); x.v[1] = tr(xband + po1 + koff[t]);
+#pragma unroll
+                        for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
+                    }
+                }
+            } else {
+            const int last = nsteps - 1;
+            int pa0, pa1, pb0, pb1;
+            bf16x8_t aA[CT], xA[MAXT], aB[CT], xB[MAXT];
+            load_po(0, pa0, pa1); load_po(last < 1 ? last : 1, pb0, pb1);
+            load_fr(0, pa0, pa1, aA, xA);
+            for (int st = 0; st < nsteps; st += 2) {
+                load_po(st + 2 < last ? st + 2 : last, pa0, pa1);
+                load_fr(st + 1 < last ? st + 1 : last, pb0, pb1, aB, xB);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(aA, xA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < nsteps) {
+                    load_po(st + 3 < last ? st + 3 : last, pb0, pb1);
+                    load_fr(st + 2 < last ? st + 2 : last, pa0, pa1, aA, xA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(aB, xB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             }
         } else
         for (int s = 0; s < nsteps; ++s) {
@@ -515,6 +568,9 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
             }
         }
         const int npix = R * p.OW, ycc = tid % YCPP;
+        // an odd number of 8-slot blocks: the MFMA loop's last step pairs the last block with the 8 slots behind it — zeros (after a partial band
+        // they would hold the previous band's next row; behind a full band they are the padding slots, zero anyway)
+        if (((R * nbx) & 1) && tid < 8 * DR1 / 16) *(uint4*)(at + R * p.OWP * DR1 + tid * 16) = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
             const int q = tid / YCPP + j * (NT / YCPP);
@@ -539,26 +595,32 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
         if (live && !(p.dbg & 1)) {
             const int nblk = R * nbx, nsteps = (nblk + 1) / 2;
-            int oy = 0, bx = h;                              // this lane half's pixel block: b = 2 * s + h
-            if (bx >= nbx) { bx -= nbx; ++oy; }
-            // one step = 16 pixel slots: dY^T fragment (ds_read_b128), X fragment (ds_read_b128 + ds_read_b32, realigned), one MFMA
+            // this lane half's pixel block b = 2 * s + h as (row, column bx) — only its X offset `xo` is kept: + 32 bytes per step, one row of
+            // planes further when the column wraps.  An odd block count leaves the last step's second block empty: its dY^T slots are zero
+            // (stage_store clears them), so its X fragment may be anything finite in LDS.  (The MFMA loop is bound by instruction issue: this
+            // form spends ~11 VALU per MFMA where block validity selects and a multiply per address spent 21.)
+            int bx = h, xo = koff + h * 16;
+            int xwrap = S * 4 * p.PSTR - nbx * 16;
+            asm volatile("" : "+v"(xwrap));                  // (kept in a vector register)
+            const char* ab = at + (h * 8 + ((lane & 15) >> 2)) * DR1 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+            // one step = 16 pixel slots: dY^T fragment (two ds_read_b64_tr_b16), X fragment (ds_read_b128 + ds_read_b32, realigned), one MFMA
             auto fetch = [&](int st, uint4& a, uint4& w, uint32_t& w4) {
-                const bool valid = 2 * st + h < nblk;        // odd block count: the last step's second block does not exist
                 {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     typedef v4s __attribute__((address_space(3))) * lds_v4s;
-                    const char* ab = at + ((2 * st + h) * 8 + ((lane & 15) >> 2)) * DR1 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
                     union { v4s v[2]; uint4 u; } f;
                     f.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)ab);
                     f.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(__attribute__((address_space(3))) char*)(ab + 4 * DR1));
                     a = f.u;
+                    ab += 16 * DR1;
                 }
-                if (!valid) a = make_uint4(0, 0, 0, 0);
-                const char* src = xband + koff + (valid ? oy : 0) * (S * 4) * p.PSTR + (valid ? bx : 0) * 16;
+                const char* src = xband + xo;
                 w = *(const uint4*)src;
                 w4 = *(const uint32_t*)(src + 16);
-                bx += 2;
-                if (bx >= nbx) { bx -= nbx; ++oy; }
+                const int t = bx + 2 - nbx;                  // (selects between vector registers only: a select with a scalar operand next to the
+                const bool wrap = t >= 0;                    //  condition mask costs a move per step on this target)
+                bx = wrap ? t : bx + 2;
+                xo += 32 + (wrap ? xwrap : 0);
             };
             auto mma = [&](f32x16_t& c, const uint4& a, const uint4& w, uint32_t w4) {
                 union { uint4 u; bf16x8_t b; } af; af.u = a;
@@ -569,16 +631,21 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
             };
             // software-pipelined: the next step's fragments are in flight while this step's MFMA issues (one accumulator: a second
             // chain or deeper prefetch spills at the 128-VGPR budget of two workgroups per CU)
-            if (nsteps > 0) {
-                uint4 a0, w0; uint32_t e0;
+            if (nsteps > 0) {                                // (two steps per trip: the fragment registers alternate instead of being copied)
+                uint4 a0, w0, a1, w1; uint32_t e0, e1;
                 fetch(0, a0, w0, e0);
-                for (int st = 1; st < nsteps; ++st) {
-                    uint4 a1, w1; uint32_t e1;
+                int st = 1;
+                for (; st + 1 < nsteps; st += 2) {
                     fetch(st, a1, w1, e1);
                     mma(acc, a0, w0, e0);
-                    a0 = a1; w0 = w1; e0 = e1;
+                    fetch(st + 1, a0, w0, e0);
+                    mma(acc, a1, w1, e1);
                 }
-                mma(acc, a0, w0, e0);
+                if (st < nsteps) {
+                    fetch(st, a1, w1, e1);
+                    mma(acc, a0, w0, e0);
+                    mma(acc, a1, w1, e1);
+                } else mma(acc, a0, w0, e0);
             }
         }
         __syncthreads();
@@ -611,6 +678,7 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     constexpr int XCH = 3, YCH = 2, K = 192;
     if (p.W % 4) return -1;
     p.OWP = (p.OW + 7) / 8 * 8;
+    if (p.OWP < 16) return -1;                               // (the MFMA loop's column walk wraps at most once per step: two 8-pixel blocks per row at least)
     p.PSTR = ((p.OWP + 2) * 2 + 15) / 16 * 16;
     if (((p.PSTR / 16) & 1) == 0) p.PSTR += 16;
     auto at_row = [&](int R) -> int { int a = R * p.OWP * 2 + 16; if (((a / 16) & 1) == 0) a += 16; return a; };
