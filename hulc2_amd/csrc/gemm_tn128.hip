@@ -10,6 +10,8 @@
 //   * two LDS stages (2 x 72 KB): the next k-step's 16-byte loads are issued into registers before the 32 MFMAs of the current one and
 //     written to the other stage behind them — one barrier per k-step, loads never waited for in front of the MFMAs;
 //   * epilogue: fp32 store or accumulate; the first column block also sums its A tile columns in fp32 (the bias gradient, fixed order).
+#include <cstdio>
+#include <vector>
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 
@@ -25,6 +27,8 @@ struct TnP {
     int M, N, K;
     int accumulate;
     float* rowsum; int rowsum_accumulate;
+    unsigned long long* tstamp;         // HULC_TN_DBG & 8: per workgroup, s_memrealtime at kernel start / first tile in LDS / k loop done / epilogue done
+    int dbg;                            // HULC_TN_DBG (probe): 8 = time stamps of the first launches, printed by the next call; 16 = all loads from tile 0
 };
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -33,6 +37,9 @@ HULC_DEVICE v4s tr_read(const char* q) { return __builtin_amdgcn_ds_read_tr16_b6
 
 // one workgroup per CU (147 KB of LDS): tell the register allocator that one wave per SIMD is the plan — with dynamic LDS it otherwise
 // budgets 128 VGPRs for two, spills the prefetched tile to scratch and waits for the loads in front of the MFMAs (61 us instead of ...)
+// DEEP (K a multiple of 256): the operand tiles are requested TWO k-steps ahead (two named register sets alternate, two k-steps per trip) — a
+// k-step's 32 MFMAs per wave last 0.55 us, an L2 / fabric round trip about 2: one k-step ahead the loop was bound by that latency (2.3 us per k-step)
+template <bool DEEP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_tn128_kernel(TnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [stage][A tile | B tile]
     __shared__ float rsum[16][BT];
@@ -57,7 +64,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the staging registers are sixteen NAMED values touched only by straight-line, unconditional code: as arrays (or behind a lambda or a
     // condition) hipcc kept part of them in scratch memory and waited for each load right where it was issued
     uint4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;        // (DEEP) the second set
 #define TN_LD1(q, kt_) ra##q = *(const uint4*)(ga + ((long)(kt_) * BT + 16 * q) * p.lda); rb##q = *(const uint4*)(gb + ((long)(kt_) * BT + 16 * q) * p.ldb);
+#define TN_LD2(q, kt_) sa##q = *(const uint4*)(ga + ((long)(kt_) * BT + 16 * q) * p.lda); sb##q = *(const uint4*)(gb + ((long)(kt_) * BT + 16 * q) * p.ldb);
+#define TN_LOAD2(kt_) TN_LD2(0, kt_) TN_LD2(1, kt_) TN_LD2(2, kt_) TN_LD2(3, kt_) TN_LD2(4, kt_) TN_LD2(5, kt_) TN_LD2(6, kt_) TN_LD2(7, kt_)
 #define TN_LOAD(kt_) TN_LD1(0, kt_) TN_LD1(1, kt_) TN_LD1(2, kt_) TN_LD1(3, kt_) TN_LD1(4, kt_) TN_LD1(5, kt_) TN_LD1(6, kt_) TN_LD1(7, kt_)
 #define TN_SUM1(w_, sum_)                                                                                              \
     rs[0] += (sum_) * __uint_as_float(w_.x << 16); rs[1] += (sum_) * __uint_as_float(w_.x & 0xffff0000u);             \
@@ -72,21 +82,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         TN_ST1(0, At_, Bt_) TN_ST1(1, At_, Bt_) TN_ST1(2, At_, Bt_) TN_ST1(3, At_, Bt_)                                \
         TN_ST1(4, At_, Bt_) TN_ST1(5, At_, Bt_) TN_ST1(6, At_, Bt_) TN_ST1(7, At_, Bt_)                                \
     }
+#define TN_ST2(q, At_, Bt_) *(uint4*)(At_ + (kr0 + 16 * q) * RST + mc * 16) = sa##q; *(uint4*)(Bt_ + (kr0 + 16 * q) * RST + mc * 16) = sb##q;
+#define TN_STORE2(stage_)                                                                                              \
+    {                                                                                                                  \
+        char* At_ = smem + (stage_) * 2 * TILE_B;                                                                      \
+        char* Bt_ = At_ + TILE_B;                                                                                      \
+        TN_ST2(0, At_, Bt_) TN_ST2(1, At_, Bt_) TN_ST2(2, At_, Bt_) TN_ST2(3, At_, Bt_)                                \
+        TN_ST2(4, At_, Bt_) TN_ST2(5, At_, Bt_) TN_ST2(6, At_, Bt_) TN_ST2(7, At_, Bt_)                                \
+    }
     const int nkt = p.K / BT;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.tstamp && tid == 0) p.tstamp[wg * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     TN_LOAD(0)
     TN_STORE(0)
     __syncthreads();
+    if (p.tstamp && tid == 0) p.tstamp[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     const int krow = (lane >> 5) * 8 + ((lane & 15) >> 2), col = (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const int ktn = kt + 1 < nkt ? kt + 1 : kt;                    // last trip: reloads its own tile (never consumed), no branch
-        TN_LOAD(ktn)                                                   // in flight behind the MFMAs below ...
-        __builtin_amdgcn_sched_barrier(0);                             // ... pinned: the scheduler otherwise sinks the loads to their use
+    auto kstep = [&](int cur) {                                        // the 32 MFMAs of one k-step on LDS stage `cur` (+ the bias gradient's sums)
         const char* At = smem + cur * 2 * TILE_B + wm * 64 * 2;
         const char* Bt = smem + cur * 2 * TILE_B + TILE_B + wn * 64 * 2;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {                               // 16 k per step
-            bf16x8_t a[2], b[2];
+        // fragments of k-step ks + 1 are requested BEFORE the four MFMAs of ks (two register sets, pinned by scheduling barriers): with one wave per
+        // SIMD nobody else hides an LDS round trip, and left to itself the compiler issued the reads behind the MFMAs and waited for them at once
+        bf16x8_t fa[2][2], fb[2][2];
+        auto frags = [&](int ks, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 union { v4s v[2]; bf16x8_t f; } x;
@@ -101,10 +119,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 x.v[0] = tr_read(q); x.v[1] = tr_read(q + 4 * RST);
                 b[j] = x.f;
             }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {                               // 16 k per step
+            if (ks + 1 < 8) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (do_rowsum) {      // bias gradient: column sums of the CURRENT A tile, read back from LDS — never from the staging registers (any
                               // arithmetic on a prefetched value is hoisted to the load and turns the prefetch into a wait)
@@ -115,10 +140,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 TN_SUM1(w_, 1.f)
             }
         }
+    };
+    if (DEEP) {
+        // One k-step, interleaved: per 16-deep slice q — the fragments of slice q + 1, ONE pair of operand loads of the tile two k-steps ahead, the
+        // four MFMAs of slice q, ONE pair of LDS stores of the tile one k-step ahead (into the stage nobody reads).  Issued in a bunch in front of /
+        // behind the 32 MFMAs, the 16 loads and 16 stores of a wave held its in-order issue for about as long as the MFMAs themselves.
+#define TN_KS_I(q, LD, kld, ST, At_, Bt_)                                                                              \
+        if (q + 1 < 8) frags_at(At, Bt, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);                                      \
+        LD(q, kld)                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        mma4(fa[q & 1], fb[q & 1]);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        ST(q, At_, Bt_)                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);
+#define TN_KSTEP_I(cur_, LD, kld, ST)                                                                                  \
+        {                                                                                                              \
+            const char* At = smem + (cur_) * 2 * TILE_B + wm * 64 * 2;                                                 \
+            const char* Bt = smem + (cur_) * 2 * TILE_B + TILE_B + wn * 64 * 2;                                        \
+            char* At_ = smem + ((cur_) ^ 1) * 2 * TILE_B;                                                              \
+            char* Bt_ = At_ + TILE_B;                                                                                  \
+            bf16x8_t fa[2][2], fb[2][2];                                                                               \
+            frags_at(At, Bt, 0, fa[0], fb[0]);                                                                         \
+            TN_KS_I(0, LD, kld, ST, At_, Bt_) TN_KS_I(1, LD, kld, ST, At_, Bt_) TN_KS_I(2, LD, kld, ST, At_, Bt_)      \
+            TN_KS_I(3, LD, kld, ST, At_, Bt_) TN_KS_I(4, LD, kld, ST, At_, Bt_) TN_KS_I(5, LD, kld, ST, At_, Bt_)      \
+            TN_KS_I(6, LD, kld, ST, At_, Bt_) TN_KS_I(7, LD, kld, ST, At_, Bt_)                                        \
+            if (do_rowsum) rowsum_of(cur_);                                                                            \
+        }
+        auto frags_at = [&](const char* At, const char* Bt, int ks, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                union { v4s v[2]; bf16x8_t f; } x;
+                const char* q = At + (ks * 16 + krow) * RST + col + i * 64;
+                x.v[0] = tr_read(q); x.v[1] = tr_read(q + 4 * RST);
+                a[i] = x.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                union { v4s v[2]; bf16x8_t f; } x;
+                const char* q = Bt + (ks * 16 + krow) * RST + col + j * 64;
+                x.v[0] = tr_read(q); x.v[1] = tr_read(q + 4 * RST);
+                b[j] = x.f;
+            }
+        };
+        auto mma4 = [&](const bf16x8_t (&a)[2], const bf16x8_t (&b)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        auto rowsum_of = [&](int cur) {      // bias gradient: column sums of the CURRENT A tile, read back from LDS
+            const char* Ac = smem + cur * 2 * TILE_B;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 w_ = *(const uint4*)(Ac + (kr0 + 16 * q) * RST + mc * 16);
+                TN_SUM1(w_, 1.f)
+            }
+        };
+        // tile 1 -> set r (tile 0 is in LDS), in the loop's order q = 0..7: the loop's first store waits for "all but the youngest N" loads, and a
+        // prologue that fetched r0 last would make that N two for every trip (the wait counts of the two paths into the loop are merged)
+#define TN_LD1_PINNED(q, kt_) TN_LD1(q, kt_) __builtin_amdgcn_sched_barrier(0);
+        { const int k1 = nkt > 1 ? 1 : 0;
+          TN_LD1_PINNED(0, k1) TN_LD1_PINNED(1, k1) TN_LD1_PINNED(2, k1) TN_LD1_PINNED(3, k1) TN_LD1_PINNED(4, k1) TN_LD1_PINNED(5, k1) TN_LD1_PINNED(6, k1) TN_LD1_PINNED(7, k1) }
+        for (int kt = 0; kt < nkt; kt += 2) {                          // nkt is even
+            int k2 = kt + 2 < nkt ? kt + 2 : kt, k3 = kt + 3 < nkt ? kt + 3 : kt + 1;   // past the end: tiles nobody consumes, no branch
+            if (p.dbg & 16) k2 = k3 = 0;                               // (probe: every load hits the same hot tile — wrong results, memory taken out of the timing)
+            TN_KSTEP_I(0, TN_LD2, k2, TN_ST1)                          // stage 0: tile kt; loads tile kt + 2 -> set s; stores tile kt + 1 (set r) -> stage 1
+            __syncthreads();
+            TN_KSTEP_I(1, TN_LD1, k3, TN_ST2)                          // stage 1: tile kt + 1; loads tile kt + 3 -> set r; stores tile kt + 2 (set s) -> stage 0
+            __syncthreads();
+        }
+    } else
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = kt + 1 < nkt ? kt + 1 : kt;                    // last trip: reloads its own tile (never consumed), no branch
+        TN_LOAD(ktn)                                                   // in flight behind the MFMAs below ...
+        __builtin_amdgcn_sched_barrier(0);                             // ... pinned: the scheduler otherwise sinks the loads to their use
+        kstep(cur);
         __builtin_amdgcn_sched_barrier(0);
         TN_STORE(cur ^ 1)                                              // the other stage: its last readers passed the previous barrier
         __syncthreads();
     }
+    if (p.tstamp && tid == 0) p.tstamp[wg * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -132,6 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 *dst = p.accumulate ? *dst + acc[i][j][e] : acc[i][j][e];
             }
         }
+    if (p.tstamp) { __builtin_amdgcn_s_waitcnt(0x0F70); if (tid == 0) p.tstamp[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }   // (vmcnt(0): the stores are acknowledged)
     if (do_rowsum) {                                                   // 16 k-row groups per column chunk, summed in a fixed order
 #pragma unroll
         for (int j = 0; j < 8; ++j) rsum[kr0][mc * 8 + j] = rs[j];
@@ -161,10 +264,31 @@ int hulc_gemm_tn128_try(const hulc_gemm_desc* d, hipStream_t s) {
     static bool attr = false;
     const size_t lds = (size_t)4 * TILE_B;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_tn128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * BT * 4) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_tn128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * BT * 4) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_tn128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * BT * 4) != hipSuccess)
             return hulc_fail(-8, "hulc_gemm: could not raise the dynamic LDS limit (tn128)");
         attr = true;
     }
-    gemm_tn128_kernel<<<dim3(d->N / BT, d->M / BT), 256, lds, s>>>(p);
+    { static const char* e = getenv("HULC_TN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.tstamp = nullptr;
+    if (p.dbg & 8) {
+        static unsigned long long* buf = nullptr; static int calls = 0, nwg = 0;
+        if (!buf) hipMalloc(&buf, 4096 * 4 * 8);
+        if ((calls == 1 || calls == 2) && nwg) {             // the second and third (eager) calls print the launch before them
+            std::vector<unsigned long long> h(nwg * 4);
+            hipMemcpy(h.data(), buf, nwg * 4 * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull; for (int i = 0; i < nwg; ++i) t0 = h[i * 4] < t0 ? h[i * 4] : t0;
+            double s1 = 0, s2 = 0, s3 = 0, st = 0, last = 0;
+            for (int i = 0; i < nwg; ++i) { st += (h[i * 4] - t0); s1 += h[i * 4 + 1] - h[i * 4]; s2 += h[i * 4 + 2] - h[i * 4 + 1]; s3 += h[i * 4 + 3] - h[i * 4 + 2];
+                                            last = (h[i * 4 + 3] - t0) > last ? (double)(h[i * 4 + 3] - t0) : last; }
+            fprintf(stderr, "[tn128 stamps, 10 ns ticks, %d workgroups] mean start offset %.0f, first tile %.0f, k loop %.0f, epilogue %.0f; last end %.0f\n",
+                    nwg, st / nwg, s1 / nwg, s2 / nwg, s3 / nwg, last);
+        }
+        if (calls < 2 || (calls == 2 && 0)) { p.tstamp = buf; nwg = (d->N / BT) * (d->M / BT) <= 4096 ? (d->N / BT) * (d->M / BT) : 0; if (!nwg) p.tstamp = nullptr; }
+        ++calls;
+    }
+    static const bool deep_ok = !(getenv("HULC_TN128_DEEP") && atoi(getenv("HULC_TN128_DEEP")) == 0);
+    if (deep_ok && d->K % (2 * BT) == 0) gemm_tn128_kernel<true><<<dim3(d->N / BT, d->M / BT), 256, lds, s>>>(p);
+    else gemm_tn128_kernel<false><<<dim3(d->N / BT, d->M / BT), 256, lds, s>>>(p);
     return 1;
 }
