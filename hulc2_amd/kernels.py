@@ -1246,14 +1246,18 @@ def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, 
     on the device while the fault word is set (a barrier kernel timed out upstream) — check_faults() then raises on the host.
     lo (bf16 arena like shadow) + lo_ranges (<= 8 (begin, end) element ranges): the rounding remainders w - bf16(w) of the updated weights
     inside the ranges are written by the same pass (hulc_adam_step_lo)."""
+    # algorithmic bytes per element (bench.py's roofline): p, g, m, v read (16 B), p, m, v written (12 B), the bf16 shadow (2 B) and, inside
+    # lo_ranges, the remainder (2 B)
+    n_lo = sum(int(e) - int(b) for b, e in lo_ranges) if (lo is not None and lo_ranges) else 0
+    nbytes = float(n) * (16 + 12 + (2 if shadow is not None else 0)) + 2.0 * n_lo
     if lo is None or not lo_ranges:
         _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
-              step_state_dev, _f(grad_scale), fault_word(p.device))
+              step_state_dev, _f(grad_scale), fault_word(p.device), nbytes=nbytes)
         return
     flat = [int(x) for r in lo_ranges for x in r]
     arr = (_c.c_long * len(flat))(*flat)
     _call("hulc_adam_step_lo", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
-          step_state_dev, _f(grad_scale), fault_word(p.device), lo, arr, _i(len(lo_ranges)))
+          step_state_dev, _f(grad_scale), fault_word(p.device), lo, arr, _i(len(lo_ranges)), nbytes=nbytes)
 
 
 def derive_copies(bf16, bf16_t, tiles, p32, conv_dst, conv_table):
