@@ -274,8 +274,13 @@ Plan plan_item(const hulc_wgrad_item& d) {
     Plan pl;
     pl.tm = (d.M + T - 1) / T; pl.tn = (d.N + T - 1) / T; pl.tiles = pl.tm * pl.tn * (d.conv_taps_wp > 0 ? 9 : 1);      // (tile, tap) pairs
     const int nsteps = (d.K + T - 1) / T;
-    int want = (nsteps + 3) / 4;                                           // slices of 4 k-steps (256 tokens) ...
-    const int cap = pl.tiles >= 1024 ? 1 : 1024 / pl.tiles;                // ... unless the problem already has a thousand tiles (slab bytes = tiles x slices x 16 KB)
+    // slices of 32 k-steps (2048 tokens: the per-timestep layers of a 64-sequence step are NOT split), at most 256 slabs per problem.  Round 4: with
+    // slices of 4 k-steps / 1024 slabs the launch moved 594 MB, two thirds of it partial slabs written through to memory and read back (a slab is
+    // 16 KB per tile and slice), at 4.6 TB/s — bound by traffic it created itself; 0.115 -> 0.086 ms (HULC_WGG_SLICE / HULC_WGG_CAP: the sweep)
+    static const int slice = getenv("HULC_WGG_SLICE") ? atoi(getenv("HULC_WGG_SLICE")) : 32;
+    static const int maxslabs = getenv("HULC_WGG_CAP") ? atoi(getenv("HULC_WGG_CAP")) : 256;
+    int want = (nsteps + slice - 1) / slice;
+    const int cap = pl.tiles >= maxslabs ? 1 : maxslabs / pl.tiles;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     pl.kper = (nsteps + want - 1) / want;
