@@ -19,6 +19,8 @@
 //   * wave steps are separated by a device-wide barrier (agent-scope counters, one per row half and XCD).  All 256 workgroups
 //     are co-resident (1 per CU by register footprint; the stream runs nothing else), the spin is bounded, and a timeout
 //     poisons the output with NaN instead of hanging the GPU.
+#include <cstdio>
+#include <vector>
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 #include <stdlib.h>
@@ -44,6 +46,7 @@ struct WaveP {
     int relu, S, B, H;
     unsigned* bar; int* err; int* err_sticky;
     const float* add1c; long ld_add1c;           // per-row constant of the first half, the same at every step (nullable): folded into the bias term
+    unsigned long long* ts;                      // HULC_RNN_DBG & 8: s_memrealtime stamps [workgroup 0 / 100][wave 1, 0, 7][sub-step][7 phases] (printed by the next launch)
     int dbg;                                     // experiments / tests only (HULC_RNN_DBG): 1 = skip state loads + MFMAs, 2 = skip the barrier, 4 = inject a barrier timeout
 };
 
@@ -277,7 +280,11 @@ __global__ __launch_bounds__(512) void rnn_wavefront_kernel(WaveP p) {
 //   waves 1-2   fp32 rows (read only after the kernel), wave 3 the row-major bf16 mirror, wave 4 the transposed mirror — from LDS tiles
 //   wave 7      lanes 0-3 poll the four counters of (row half, group); it owns no stores, so its polling loads wait for nothing but themselves
 //               (a polling load behind an un-acknowledged store would wait for that store first)
-template <int H, bool WT>
+// Round 4, phase stamps (HULC_RNN_DBG=8, the TS instance): a sub-step of 2.75 us = poll + barrier 0.3, state loads + MFMAs 1.35 (first wave) ... 1.85 (last
+// wave: 128 KB per CU at 29 B/clk), 8-wave sum + epilogue 0.22, stores 0.13-0.23.  Reading the NEXT sub-step's counters at the end of this one (to save the
+// round trip at the top) made the pass 11 % slower: the counters are not complete yet at that point — a group's chain (stores -> acknowledgement ->
+// counter -> propagation -> loads -> MFMAs -> sum) is as long as the two sub-steps it has; the kernel is bound by that chain, not by throughput.
+template <int H, bool WT, bool TS = false>      // TS: the probe's instance with phase time stamps (HULC_RNN_DBG & 8) — the stamps' branches cost the plain kernel 5 %
 __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
     constexpr int KS = H / 32;
     constexpr int KPW = KS / 8;
@@ -321,8 +328,13 @@ __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
     }
     int pending = -1;                                             // wave 0: group whose exchange stores await their acknowledgement
     const int U = 2 * (p.S + 1);
+    // (probe) phase stamps of workgroups 0 and 100, waves 1 (an ordinary wave), 0 (exchange stores) and 7 (polls)
+    const int ts_wg = blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : -1), ts_wv = wave == 1 ? 0 : (wave == 0 ? 1 : (wave == 7 ? 2 : -1));
+    unsigned long long* ts = (TS && p.ts && ts_wg >= 0 && ts_wv >= 0 && lane == 0) ? p.ts + (long)((ts_wg * 3 + ts_wv) * 80) * 8 : nullptr;
+#define RNN_TS(u_, ph_) if constexpr (TS) { if (ts && (u_) < 80) ts[(u_) * 8 + (ph_)] = __builtin_amdgcn_s_memrealtime(); }
     for (int u = 0; u < U; ++u) {
         const int g = u & 1, tau = u >> 1;
+        RNN_TS(u, 0)
         const bool first_on = tau < p.S, second_on = tau >= 1;
         const int om = rowhalf * 32 + g * 16 + orow;
         if (tau > 0) {
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
             __syncthreads();
             asm volatile("" ::: "memory");
         }
+        RNN_TS(u, 1)
         f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
         const bool mul = tau > 0 && !(p.dbg & 1);
         bf16x8_t af[2][KPW];
@@ -388,7 +401,10 @@ __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[wave][ct][e * 64 + lane] = acc[ct][e];
+        if constexpr (TS) { if (ts) __builtin_amdgcn_s_waitcnt(0xC07F); }   // (lgkmcnt(0): the partial tile is in LDS = the MFMAs are done)
+        RNN_TS(u, 2)
         __syncthreads();
+        RNN_TS(u, 3)
         // ---- fixed-order sum over the 8 K slices + epilogue: 512 outputs, one per thread
         {
             float v = 0.f;
@@ -403,7 +419,9 @@ __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
             otile[orow][oct][on - n0] = f32_to_bf16_bits(v);
             ftile[orow][oct][on - n0] = v;
         }
+        RNN_TS(u, 4)
         __syncthreads();
+        RNN_TS(u, 5)
         const int region = p.zb_row0 + (tau + 1) * p.zb_dir;
         if (wave == 0) {
             // exchange copy: lane = (row 0..15, half, 8-column chunk); skipped once nobody reads it any more (last wave step)
@@ -444,7 +462,9 @@ __global__ __launch_bounds__(512) void rnn_wavefront2_kernel(WaveP p) {
             }
         }
         // (the LDS tiles are rewritten two barriers later: no extra barrier needed here)
+        RNN_TS(u, 6)
     }
+#undef RNN_TS
     __syncthreads();
     if ((p.dbg & 4) && blockIdx.x == 0 && tid == 0) {
         __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -512,6 +532,31 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     p.relu = d->relu; p.S = d->S; p.B = d->B; p.H = d->H; p.err_sticky = d->err_sticky;
     p.add1c = d->add1c; p.ld_add1c = d->ld_add1c;
     p.dbg = getenv("HULC_RNN_DBG") ? atoi(getenv("HULC_RNN_DBG")) : 0;
+    p.ts = nullptr;
+    if (p.dbg & 8) {                                         // (probe, eager launches only: the next call prints the previous launch's phase stamps)
+        static unsigned long long* buf = nullptr; static int calls = 0;
+        const int NW = 2 * 3 * 80 * 8;
+        if (!buf) { hipMalloc(&buf, NW * 8); hipMemset(buf, 0, NW * 8); }
+        if (calls >= 1 && calls <= 4) {
+            std::vector<unsigned long long> h(NW);
+            hipMemcpy(h.data(), buf, NW * 8, hipMemcpyDeviceToHost);
+            const char* wn[3] = {"wave 1", "wave 0 (exchange)", "wave 7 (poll)"};
+            for (int wg = 0; wg < 2; ++wg) for (int wv = 0; wv < 3; ++wv) {
+                double ph[7] = {0, 0, 0, 0, 0, 0, 0}; int cnt = 0;
+                for (int u = 8; u < 60; ++u) {
+                    const unsigned long long* t = &h[((wg * 3 + wv) * 80 + u) * 8];
+                    const unsigned long long* tn = t + 8;
+                    if (!t[0] || !tn[0]) continue;
+                    for (int k = 0; k < 6; ++k) ph[k] += (double)(t[k + 1] - t[k]);
+                    ph[6] += (double)(tn[0] - t[6]); ++cnt;
+                }
+                if (cnt) fprintf(stderr, "[rnn stamps call %d wg %d %s, 10 ns ticks, mean of %d sub-steps] poll+sync %.1f | loads+mfma %.1f | sync2 %.1f | sum+epilogue %.1f | sync3 %.1f | stores %.1f | loop %.1f\n",
+                                 calls - 1, wg ? 100 : 0, wn[wv], cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, ph[5] / cnt, ph[6] / cnt);
+            }
+        }
+        if (calls < 4) p.ts = buf;
+        ++calls;
+    }
     p.zb_row0 = d->z_step > 0 ? 0 : d->S + 1; p.zb_dir = d->z_step > 0 ? 1 : -1;
     // barrier words, and the bf16 copy of the (zero) initial state row: the copy is a full mirror of the fp32 rows for the weight-gradient GEMMs
     static const bool use_memset = getenv("HULC_RNN_MEMSET") != nullptr;
@@ -535,7 +580,10 @@ extern "C" int hulc_rnn_wavefront(const hulc_rnn_wave_desc* d, void* ws, void* s
     }
     if (d->tA != d->tB1 || d->tA != d->tB2) return hulc_fail(-3, "hulc_rnn_wavefront: the three weight matrices share one layout (tA == tB1 == tB2)");
     static const bool pipelined = !(getenv("HULC_RNN_PIPE") && atoi(getenv("HULC_RNN_PIPE")) == 0);     // HULC_RNN_PIPE=0: the unpipelined kernel
-    if (pipelined) {
+    if (pipelined && p.ts) {
+        if (d->tA) rnn_wavefront2_kernel<2048, true, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
+        else rnn_wavefront2_kernel<2048, false, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
+    } else if (pipelined) {
         if (d->tA) rnn_wavefront2_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
         else rnn_wavefront2_kernel<2048, false><<<2 * (2048 / 16), 512, 0, s>>>(p);
     } else if (d->tA) rnn_wavefront_kernel<2048, true><<<2 * (2048 / 16), 512, 0, s>>>(p);
