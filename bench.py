@@ -307,6 +307,16 @@ def lightning_loop(args, dev):
         for name, conc in (("cooperative_kernels", False), ("concurrent_streams", True)):
             kn.set_concurrent_streams(conc)
             measure(name)
+        # the same loop with ONE class path more swapped: `optimizer._target_: hulc2_amd.optim.Adam` (torch.optim.Adam's rule and state_dict; the step
+        # is the arena launch that also writes the kernel-side weight copies — torch's multi-tensor step costs ~1.5 ms of host time here)
+        from hulc2_amd.optim import Adam as HulcAdam
+        kn.set_concurrent_streams(False)
+        torch_opt = opt
+        opt = HulcAdam([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+        opt.load_state_dict(torch_opt.state_dict())
+        measure("cooperative_kernels_hulc2_amd_adam")
+        res["cooperative_kernels_hulc2_amd_adam"]["fused_steps"] = int(opt.fused_launches)
+        opt = torch_opt
         # the same loop under torch's own DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75), on a ONE-rank
         # RCCL group — the collectives move nothing, the reducer's bucket copies, hooks and stream hand-overs are all there: with
         # hulc2_amd.ddp.register_parked_comm_hook (cooperative kernels stay on, bucket all-reduces parked behind the last cooperative kernel of

@@ -4,6 +4,7 @@
 //   conf/model/optimizer/adam.yaml + hulc2/models/hulc2.py:185-198, applied to one contiguous fp32
 //   arena (params / grads / exp_avg / exp_avg_sq share offsets).  HBM-bound: 4 reads + 3 writes of
 //   4 bytes (+2 for the bf16 weight shadow the MFMA kernels consume) per parameter, float4-vectorised.
+#include <cmath>
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 
@@ -18,12 +19,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
                                                    const unsigned long long* __restrict__ step_state, const int* __restrict__ skip_flag,
-                                                   uint16_t* __restrict__ lo, LoRanges lr_) {
+                                                   uint16_t* __restrict__ lo, LoRanges lr_, float omb1, float omb2, double b1d, double b2d) {
+    // omb1 / omb2 = 1 - beta as torch forms them: in DOUBLE from the decimal the caller meant (0.999), then rounded to fp32 — 1.f - 0.999f is
+    // 4.7e-5 (relative) away from that, and exp_avg_sq with it; the bias corrections likewise come from double powers (torch: Python floats)
     if (skip_flag && *skip_flag) return;    // an upstream kernel reported a fault (barrier timeout): keep the weights, the host raises
     if (step_state) {                       // bias corrections from the device-resident step count (graph replay)
-        const float t = (float)step_state[1];
-        bc1 = 1.f - powf(b1, t);
-        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+        const double t = (double)step_state[1];
+        bc1 = (float)(1.0 - pow(b1d, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow(b2d, t));
     }
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -34,8 +37,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float gg = ga[k] * gscale + wd * pa[k];
-                ma[k] = b1 * ma[k] + (1.f - b1) * gg;
-                va[k] = b2 * va[k] + (1.f - b2) * gg * gg;
+                ma[k] = b1 * ma[k] + omb1 * gg;
+                va[k] = b2 * va[k] + omb2 * gg * gg;
                 const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
                 pa[k] -= (lr / bc1) * (ma[k] / denom);
             }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         } else {
             for (long k = i; k < n; ++k) {
                 float gg = g[k] * gscale + wd * p[k];
-                float mm = b1 * m[k] + (1.f - b1) * gg, vv = b2 * v[k] + (1.f - b2) * gg * gg;
+                float mm = b1 * m[k] + omb1 * gg, vv = b2 * v[k] + omb2 * gg * gg;
                 m[k] = mm; v[k] = vv;
                 float pn = p[k] - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
                 p[k] = pn;
@@ -293,10 +296,14 @@ extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, v
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return hulc_fail(-4, "hulc_adam_step: arenas must be 16-byte aligned");
     if (!step_state && step < 1) return hulc_fail(-2, "hulc_adam_step: step counts from 1");
     if (step < 1) step = 1;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // the betas arrive as floats (ABI); the decimal the caller wrote is recovered when the float is within rounding of a 7-digit decimal
+    auto meant = [](float b) -> double { const double d = (double)b, r = std::round(d * 1e7) / 1e7; return std::fabs(r - d) <= 6e-8 * std::fabs(d) ? r : d; };
+    const double b1d = meant(beta1), b2d = meant(beta2);
+    const float bc1 = (float)(1.0 - std::pow(b1d, (double)step)), bc2s = (float)std::sqrt(1.0 - std::pow(b2d, (double)step));
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
-                                                                   bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_);
+                                                                   bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_,
+                                                                   (float)(1.0 - b1d), (float)(1.0 - b2d), b1d, b2d);
     return hulc_check_launch("hulc_adam_step");
 }
 

@@ -26,6 +26,28 @@ from . import gradsink
 from . import kernels as kn
 from . import shadow
 
+# parameter arenas by the address of their storage (weak: an arena lives as long as its trainer / the model's keeper)
+_ARENAS: "weakref.WeakValueDictionary[int, ArenaTrainer]" = weakref.WeakValueDictionary()
+
+
+def arena_of(params) -> "Optional[ArenaTrainer]":
+    """the ArenaTrainer whose fp32 arena holds exactly these parameters (same objects, every one a view of the arena), else None"""
+    params = list(params)
+    if not params or params[0].device.type != "cuda":
+        return None
+    tr = _ARENAS.get(params[0].untyped_storage().data_ptr())
+    if tr is None or len(params) != len(tr.params):
+        return None
+    mine = {id(p) for p in tr.params}
+    base = tr.flat_p.data_ptr()
+    for p in params:
+        if id(p) not in mine:
+            return None
+    for p, off in zip(tr.params, tr.offsets):
+        if p.data_ptr() != base + off * 4 or p.dtype != torch.float32:
+            return None
+    return tr
+
 
 class GradComm:
     """Sums slices of the fp32 gradient arena over the ranks, in place (replaces the NCCL ring inside Lightning's DDPStrategy,
@@ -382,6 +404,7 @@ class ArenaTrainer:
         self._groups = groups
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        _ARENAS[self.flat_p.untyped_storage().data_ptr()] = self    # (hulc2_amd.optim.Adam finds the arena behind a parameter list here)
         n_state = 0 if self.shadows_only else total            # (gradients and Adam moments belong to the caller's optimizer then)
         self.flat_g = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n_state, dtype=torch.float32, device=dev)

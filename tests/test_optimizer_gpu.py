@@ -216,3 +216,63 @@ def test_adam_lo_ranges_are_validated(dev):
     inside[8:16] = True
     inside[32:64] = True
     assert torch.equal(lo[inside].view(torch.int16), want[inside].view(torch.int16)) and float(lo[~inside].float().abs().max()) == 0.0
+
+
+def test_drop_in_adam_takes_the_arena_step(dev):
+    """hulc2_amd.optim.Adam in the reference's own loop (hulc2.py:185-198: `optimizer._target_`; training.py:79-82: training_step -> backward ->
+    optimizer.step under fp16 autocast + GradScaler): once Hulc2 has moved its parameters into the keeper's arena every step is the fused arena
+    launch.  Fed the SAME gradients, torch.optim.Adam on clones of the parameters lands on the same values after three steps — parameters within
+    2e-6 of their scale + 1e-3 lr, moments within 1e-6 of their largest entry (fp32 rounding of two evaluation orders) — the state_dict has torch's
+    layout (no entries for the two parameters the step never reaches), and each optimizer resumes from the other's checkpoint."""
+    import copy
+    from hulc2_amd import kernels as kn
+    from hulc2_amd.optim import Adam
+
+    kn.set_compute("bf16")
+    try:
+        lr = 2e-4
+        batch = syn.make_batch(5, 2, 8, device=dev)
+        for db in batch.values():
+            db.pop("plan_idx", None)
+        m = instantiate(default_model_config(gripper_control=True, dropout_p=0.0)).to(dev)
+        syn.fill_state_dict_(m.state_dict(), 11)
+        m.train()
+        opt = Adam(m.parameters(), lr=lr)
+        clones = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+        ref = torch.optim.Adam(clones, lr=lr)
+        kn.reset_step_state(dev)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        for i in range(3):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = m.training_step(batch, i)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            for c, p in zip(clones, m.parameters()):
+                c.grad = None if p.grad is None else p.grad.detach().clone()
+            scaler.step(opt)
+            scaler.update()
+            ref.step()
+        torch.cuda.synchronize()
+        assert opt.fused_launches == 3, "every step of hulc2_amd.optim.Adam should have been the arena launch"
+        for (n, p), c in zip(m.named_parameters(), clones):
+            assert float((p - c).abs().max()) <= 2e-6 * max(float(c.abs().max()), 1.0) + 1e-3 * lr, n
+        sa, sb = ref.state_dict(), opt.state_dict()
+        assert sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"] and sa["state"].keys() == sb["state"].keys()
+        assert len(sb["state"]) == len(clones) - 2                   # (plan_recognition.layernorm is not on the step's path: no gradient, no state)
+        for k in sa["state"]:
+            assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 3.0
+            for key in ("exp_avg", "exp_avg_sq"):
+                x, y = sa["state"][k][key], sb["state"][k][key]
+                assert float((x - y).abs().max()) <= 1e-6 * max(float(x.abs().max()), 1e-30), (k, key)
+        twin = torch.optim.Adam(m.parameters(), lr=lr)
+        twin.load_state_dict(copy.deepcopy(sb))                      # torch's optimizer resumes from the fused one's checkpoint ...
+        opt.load_state_dict(copy.deepcopy(sa))                       # ... and the other way round; the next step is fused again
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = m.training_step(batch, 3)
+        loss.backward()
+        opt.step()
+        assert opt.fused_launches == 4 and float(opt.state_dict()["state"][0]["step"]) == 4.0
+    finally:
+        kn.reset_step_state(dev)
