@@ -661,7 +661,7 @@ void launch_skinny(const GemmP& p, int ak, int bk, float* ws, long ws_bytes, hip
     const int nw = big ? 16 : (big2 ? 8 : 4);
     int splitk = 1;
     const char* force = getenv("HULC_SKINNY_SPLITK");           // tuning knob for A/B runs
-    const int min_kw = 64;   // measured (tools/rnn_bench.py): more, shorter K slices win even with the extra epilogue launch
+    static const int min_kw = getenv("HULC_SKINNY_MINKW") ? atoi(getenv("HULC_SKINNY_MINKW")) : 64;   // measured (tools/rnn_bench.py): more, shorter K slices win even with the extra epilogue launch
     while (colblocks * splitk < 200 && p.K / (nw * (splitk * 2)) >= min_kw) splitk *= 2;
     if (force) splitk = atoi(force);
     unsigned* ctr = (unsigned*)ws;                               // the head of the workspace: tile counters (zero between launches)
