@@ -693,7 +693,9 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     const int bands = (p.OH + R - 1) / R;
     R = (p.OH + bands - 1) / bands;
     p.R = R; p.AT_ROW = at_row(R);
-    const int slots = 512;                                   // two workgroups per CU
+    // two workgroups per CU (LDS <= 80 KB each).  HULC_CONV1_SLOTS (tests): fewer, so that a workgroup walks more than the 256 units its LDS
+    // table of per-frame parameters holds and the direct loads behind the table are exercised
+    const int slots = getenv("HULC_CONV1_SLOTS") && atoi(getenv("HULC_CONV1_SLOTS")) > 0 ? atoi(getenv("HULC_CONV1_SLOTS")) : 512;
     const int per = (p.Nimg + slots - 1) / slots;            // frames per workgroup
     const int grid = (p.Nimg + per - 1) / per;
     if ((long)grid * 32 * (K + 1) * 4 > ws_bytes) return -1;

@@ -138,3 +138,34 @@ def test_conv_stack_takes_both_modalities_in_one_conv1_launch(dev, form, monkeyp
             assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), f"gradient {i}"
         else:
             assert torch.equal(a, c), f"gradient {i}"
+
+
+def test_conv1_uint8_beyond_the_frame_parameter_table(dev, monkeypatch):
+    """a workgroup of the uint8 conv1 kernels reads its frames' shift / index from an LDS table of 256 units and, past it, straight from memory:
+    with two workgroups for 120 frames (HULC_CONV1_SLOTS=2: 360 / 780 units each) most units take the second path — forward, sign plane and
+    weight gradient equal the default launch (forward bit for bit; the gradient's slabs are summed per workgroup: fp32 rounding)."""
+    from hulc2_amd import kernels as kn
+    g = torch.Generator().manual_seed(21)
+    N, hw, pad = 120, 200, 10
+    x = torch.randint(0, 256, (16, hw, hw, 3), generator=g, dtype=torch.uint8).to(dev)
+    ix = torch.randint(0, 16, (N,), generator=g, dtype=torch.int32).to(dev)
+    sh = torch.randint(0, 2 * pad + 1, (N, 2), generator=g, dtype=torch.int32).to(dev)
+    w2d = ((torch.rand(32, 192, generator=g) * 2 - 1) / 192 ** 0.5).to(dev).to(torch.bfloat16)
+    b = ((torch.rand(32, generator=g) * 2 - 1) * 0.1).to(dev)
+    OH, OW = kn.conv_out_hw(hw, hw, 8, 8, 4)
+    dy = torch.randn(N, OH, OW, 32, generator=g).to(dev).to(torch.bfloat16)
+    outs = []
+    for slots in (None, "2"):
+        if slots:
+            monkeypatch.setenv("HULC_CONV1_SLOTS", slots)
+        y = torch.zeros(N, OH, OW, 32, dtype=torch.bfloat16, device=dev)
+        bits = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev)
+        dw, db = torch.zeros(32, 192, device=dev), torch.zeros(32, device=dev)
+        kn.conv2d_fwd(x, w2d, b, y, N, hw, hw, 3, 32, 8, 8, 4, True, compute=kn.BF16, relu_bits=bits, aug_shift=sh, aug_pad=pad, frame_index=ix)
+        kn.conv2d_bwd_weight(x, dy, dw, db, N, hw, hw, 3, 32, 8, 8, 4, True, compute=kn.BF16, aug_shift=sh, aug_pad=pad, frame_index=ix)
+        torch.cuda.synchronize()
+        outs.append((y, bits, dw, db))
+    monkeypatch.delenv("HULC_CONV1_SLOTS", raising=False)
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5 * float(outs[0][2].abs().max())
+    assert float((outs[0][3] - outs[1][3]).abs().max()) <= 1e-5 * float(outs[0][3].abs().max())
