@@ -14,6 +14,8 @@ LAYERS = [
     ("grip1", 5, 84, 84, 3, 32, 8, 4, True),
     ("grip2", 5, 20, 20, 32, 64, 4, 2, False),
     ("grip3", 5, 9, 9, 64, 64, 3, 1, False),
+    # 36 x 36 frames: 8 output columns = one 8-pixel block per row — the conv1 weight-gradient band kernel leaves the shape to the generic one
+    ("tiny1", 4, 36, 36, 3, 32, 8, 4, True),
 ]
 
 
