@@ -96,8 +96,9 @@ class Adam(torch.optim.Adam):
         if arena is None:
             self._sync_steps()
             super().step()
-            if self._arena is not None:                           # (same parameters, per-tensor path this once: the counters moved on)
-                self._fused_steps = int(float(self.state[self._arena[0].params[0]]["step"]))
+            # torch's path may have made state of its own (a parameter's first gradient) and has moved the step counters: the next fused step
+            # re-homes whatever the state holds now into fresh arenas (_bind)
+            self._arena = None
             return loss
         tr, flat_g, views, m, v = arena
         g = self.param_groups[0]

@@ -265,14 +265,26 @@ def test_drop_in_adam_takes_the_arena_step(dev):
             for key in ("exp_avg", "exp_avg_sq"):
                 x, y = sa["state"][k][key], sb["state"][k][key]
                 assert float((x - y).abs().max()) <= 1e-6 * max(float(x.abs().max()), 1e-30), (k, key)
+        # a step in which a parameter that HAS moments misses its gradient: torch skips it (no update, its step stays behind) — this optimizer takes
+        # torch's per-tensor path for that step and is fused again in the next one, on the state that path left
+        for i in (3, 4):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = m.training_step(batch, i)
+            loss.backward()
+            if i == 3:
+                next(iter(m.parameters())).grad = None
+            for c, p in zip(clones, m.parameters()):
+                c.grad = None if p.grad is None else p.grad.detach().clone()
+            opt.step()
+            ref.step()
+        assert opt.fused_launches == 3, "two parameters now have different step counts: torch's per-tensor path from here on"
+        for (n, p), c in zip(m.named_parameters(), clones):
+            assert float((p - c).abs().max()) <= 3e-6 * max(float(c.abs().max()), 1.0) + 1e-3 * lr, n
+        sa, sb = ref.state_dict(), opt.state_dict()
+        assert float(sb["state"][0]["step"]) == float(sa["state"][0]["step"]) == 4.0 and float(sb["state"][1]["step"]) == 5.0
         twin = torch.optim.Adam(m.parameters(), lr=lr)
-        twin.load_state_dict(copy.deepcopy(sb))                      # torch's optimizer resumes from the fused one's checkpoint ...
-        opt.load_state_dict(copy.deepcopy(sa))                       # ... and the other way round; the next step is fused again
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.float16):
-            loss = m.training_step(batch, 3)
-        loss.backward()
-        opt.step()
-        assert opt.fused_launches == 4 and float(opt.state_dict()["state"][0]["step"]) == 4.0
+        twin.load_state_dict(copy.deepcopy(sb))                      # torch's optimizer resumes from this one's checkpoint and the other way round
+        opt.load_state_dict(copy.deepcopy(sa))
     finally:
         kn.reset_step_state(dev)
