@@ -9,8 +9,8 @@ budget, tools/eager_profile.py) and leaves the kernel-side weight copies stale, 
 arena Adam kernel updates parameters and moments and writes the bf16 shadow and the split operands' remainders, two more derive the
 transposed / repacked copies — exactly what ArenaTrainer.optimizer_step launches.
 
-Whenever the fused form does not apply — parameters not (yet) in an arena, a parameter without a gradient, amsgrad / maximize, several
-parameter groups, CPU — `step()` is torch.optim.Adam.step(), on the same state tensors."""
+Whenever the fused form does not apply — parameters not (yet) in an arena, a parameter without a gradient, amsgrad / maximize / decoupled weight decay,
+several parameter groups, CPU — `step()` is torch.optim.Adam.step(), on the same state tensors."""
 from typing import Optional
 
 import torch
@@ -33,7 +33,7 @@ class Adam(torch.optim.Adam):
         if len(self.param_groups) != 1:
             return None
         g = self.param_groups[0]
-        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or g.get("capturable"):
+        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or g.get("capturable") or g.get("decoupled_weight_decay"):
             return None
         params = [p for p in g["params"] if p.requires_grad]     # (frozen parameters never get a gradient: torch skips them, the arena does not hold them)
         tr = arena_of(params)
