@@ -268,8 +268,9 @@ def lightning_loop(args, dev):
     from hulc2_amd import kernels as kn, synthetic as syn
     from hulc2_amd.compat import instantiate
     from hulc2_amd.config import default_model_config
-    res = {"what": "Lightning-style eager loop: autocast(fp16) + GradScaler + model.training_step + loss.backward() + torch.optim.Adam.step(), "
-                   "no ArenaTrainer / hipGraph (hulc2/training.py:79-82 with the class paths swapped, INTEGRATION §1)", "unit": "play-sequences/s"}
+    res = {"what": "Lightning-style loop: autocast(fp16) + GradScaler + model.training_step + loss.backward() + torch.optim.Adam.step(), no ArenaTrainer "
+                   "(hulc2/training.py:79-82 with the class paths swapped, INTEGRATION §1); round 5: training_step is ONE autograd node, two replayed "
+                   "hipGraphs from its third call on (hulc2_amd/stepnode.py); `cooperative_kernels_no_step_node` = round 4's loop", "unit": "play-sequences/s"}
     try:
         kn.set_compute("bf16")
         model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
@@ -304,9 +305,16 @@ def lightning_loop(args, dev):
             res[name] = {"value": round(2 * args.batch * k / el, 2), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
                          "final_loss": round(float(loss), 4)}
 
+        def node_stats(name):
+            node = model.__dict__.get("_hulc_step_node")
+            if node is not None:
+                res[name]["step_node"] = {"replays": node.replays, "eager_steps": node.eager_steps, "captures": node.captures,
+                                          "input_copies": node.input_copies, "disabled": node.disabled}
+
         for name, conc in (("cooperative_kernels", False), ("concurrent_streams", True)):
             kn.set_concurrent_streams(conc)
             measure(name)
+            node_stats(name)
         # the same loop with ONE class path more swapped: `optimizer._target_: hulc2_amd.optim.Adam` (torch.optim.Adam's rule and state_dict; the step
         # is the arena launch that also writes the kernel-side weight copies — torch's multi-tensor step costs ~1.5 ms of host time here)
         from hulc2_amd.optim import Adam as HulcAdam
@@ -316,6 +324,7 @@ def lightning_loop(args, dev):
         opt.load_state_dict(torch_opt.state_dict())
         measure("cooperative_kernels_hulc2_amd_adam")
         res["cooperative_kernels_hulc2_amd_adam"]["fused_steps"] = int(opt.fused_launches)
+        node_stats("cooperative_kernels_hulc2_amd_adam")
         opt = torch_opt
         # the same loop under torch's own DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75), on a ONE-rank
         # RCCL group — the collectives move nothing, the reducer's bucket copies, hooks and stream hand-overs are all there: with
@@ -354,6 +363,7 @@ def lightning_loop(args, dev):
                     return loss
                 try:
                     measure(name)
+                    node_stats(name)
                 finally:
                     step = inner_step
                     del ddp
@@ -362,6 +372,25 @@ def lightning_loop(args, dev):
         finally:
             if own_group and dist.is_initialized():
                 dist.destroy_process_group()
+        # round 4's loop for comparison: the step as ~160 autograd Functions instead of ONE node (HULC_NO_STEP_NODE=1; a fresh model: the
+        # keeper of the first one owns a gradient arena and the node)
+        had = os.environ.get("HULC_NO_STEP_NODE")
+        os.environ["HULC_NO_STEP_NODE"] = "1"
+        try:
+            kn.set_concurrent_streams(False)
+            del model, opt, torch_opt
+            model = instantiate(default_model_config(gripper_control=True, dropout_p=0.1)).to(dev)
+            syn.fill_state_dict_(model.state_dict(), 42)
+            model.train()
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+            measure("cooperative_kernels_no_step_node")
+        except Exception as e:                              # noqa: BLE001
+            res["no_step_node_error"] = f"{type(e).__name__}: {e}"
+        finally:
+            if had is None:
+                os.environ.pop("HULC_NO_STEP_NODE", None)
+            else:
+                os.environ["HULC_NO_STEP_NODE"] = had
     except Exception as e:                                  # noqa: BLE001 - the headline line must still be printed
         res["error"] = f"{type(e).__name__}: {e}"
     finally:

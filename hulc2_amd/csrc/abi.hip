@@ -18,4 +18,4 @@ int hulc_check_launch(const char* where) {
 }
 
 extern "C" const char* hulc_last_error(void) { return g_err; }
-extern "C" int hulc_abi_version(void) { return 4; }
+extern "C" int hulc_abi_version(void) { return 5; }

@@ -19,10 +19,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
                                                    const unsigned long long* __restrict__ step_state, const int* __restrict__ skip_flag,
-                                                   uint16_t* __restrict__ lo, LoRanges lr_, float omb1, float omb2, double b1d, double b2d) {
+                                                   uint16_t* __restrict__ lo, LoRanges lr_, float omb1, float omb2, double b1d, double b2d,
+                                                   const float* __restrict__ loss_scale, const float* __restrict__ found_inf) {
     // omb1 / omb2 = 1 - beta as torch forms them: in DOUBLE from the decimal the caller meant (0.999), then rounded to fp32 — 1.f - 0.999f is
     // 4.7e-5 (relative) away from that, and exp_avg_sq with it; the bias corrections likewise come from double powers (torch: Python floats)
     if (skip_flag && *skip_flag) return;    // an upstream kernel reported a fault (barrier timeout): keep the weights, the host raises
+    // torch.amp.GradScaler's device scalars (ABI 5, hulc_adam_step_amp): a step whose gradients hold an inf / NaN is skipped (found_inf != 0),
+    // the gradients are still multiplied by the loss scale S: unscaled here by 1 / S formed as torch's unscale_ forms it (double reciprocal)
+    if (found_inf && *found_inf != 0.f) return;
+    if (loss_scale) gscale *= (float)(1.0 / (double)*loss_scale);
     if (step_state) {                       // bias corrections from the device-resident step count (graph replay)
         const double t = (double)step_state[1];
         bc1 = (float)(1.0 - pow(b1d, t));
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             }
         }
     }
+}
+
+__global__ void step_count_advance_if_kernel(unsigned long long* state, const float* found_inf) {
+    if (!found_inf || *found_inf == 0.f) state[1] += 1ull;      // (torch's fused Adam takes a skipped step's increment back the same way)
 }
 
 __global__ void step_state_advance_kernel(unsigned long long* state, int rng, int step) {
@@ -266,6 +275,9 @@ extern "C" int hulc_sum_chunks(const void* src, int dtype, int W, long chunk, vo
     return hulc_check_launch("hulc_sum_chunks");
 }
 
+extern "C" int hulc_adam_step_amp(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                                  void* lo_shadow, const long* lo_ranges, int n_ranges, const float* loss_scale, const float* found_inf, void* stream);
 extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
                                  float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
                                  void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream);
@@ -275,10 +287,23 @@ extern "C" int hulc_adam_step(float* p, const float* g, float* m, float* v, void
     return hulc_adam_step_lo(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, step_state, grad_scale, skip_flag, nullptr, nullptr, 0, stream);
 }
 
-// see include/hulc2_amd.h
 extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
                                  float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
                                  void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream) {
+    return hulc_adam_step_amp(p, g, m, v, bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step, step_state, grad_scale, skip_flag, lo_shadow, lo_ranges,
+                              n_ranges, nullptr, nullptr, stream);
+}
+
+extern "C" int hulc_step_count_advance_if(unsigned long long* state, const float* found_inf, void* stream) {
+    if (!state) return hulc_fail(-1, "hulc_step_count_advance_if: null state");
+    step_count_advance_if_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, found_inf);
+    return hulc_check_launch("hulc_step_count_advance_if");
+}
+
+// see include/hulc2_amd.h
+extern "C" int hulc_adam_step_amp(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                                  void* lo_shadow, const long* lo_ranges, int n_ranges, const float* loss_scale, const float* found_inf, void* stream) {
     if (!p || !g || !m || !v) return hulc_fail(-1, "hulc_adam_step: null pointer");
     LoRanges lr_;
     lr_.n = 0;
@@ -303,7 +328,7 @@ extern "C" int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, v
     long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
                                                                    bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_,
-                                                                   (float)(1.0 - b1d), (float)(1.0 - b2d), b1d, b2d);
+                                                                   (float)(1.0 - b1d), (float)(1.0 - b2d), b1d, b2d, loss_scale, found_inf);
     return hulc_check_launch("hulc_adam_step");
 }
 

@@ -38,6 +38,14 @@ class ParkedCommState:
         self.parked: List[Tuple["dist.GradBucket", torch.futures.Future]] = []
         self.log: List[str] = []                    # ("park" | "send" | "release") in host order — what the tests read
         self.keep_log = False
+        self.handles = []                           # the two forward hooks register_parked_comm_hook installed
+
+    def remove_hooks(self) -> None:
+        """take the forward hooks off the wrapped module again (DDP itself offers no way to unregister a communication hook: with the hooks
+        gone every bucket is parked until the last one and released there — torch's default timing)"""
+        for h in self.handles:
+            h.remove()
+        self.handles = []
 
     # -- bookkeeping -------------------------------------------------------------------------------------------------------------
     def _note(self, what: str) -> None:
@@ -68,7 +76,13 @@ class ParkedCommState:
         done = work.get_future().then(lambda f: f.value()[0])
         if fut is None:
             return done
-        done.then(lambda f: fut.set_result(f.value()))
+        def hand_over(f):
+            # a failed collective must surface in DDP's finalize, not leave the parked future pending for ever
+            try:
+                fut.set_result(f.value())
+            except Exception as e:                          # noqa: BLE001
+                fut.set_exception(e)
+        done.then(hand_over)
         return fut
 
     def release(self) -> None:
@@ -148,7 +162,6 @@ def register_parked_comm_hook(ddp_model, cut_module: Optional[torch.nn.Module] =
         calls["n"] = 0
         state.begin_pass()
 
-    inner.register_forward_pre_hook(before_forward)
-    cut.register_forward_hook(after_cut_forward)
+    state.handles = [inner.register_forward_pre_hook(before_forward), cut.register_forward_hook(after_cut_forward)]
     ddp_model.register_comm_hook(state, parked_allreduce_hook)
     return state

@@ -381,6 +381,13 @@ def _conv1_pair_ok(xs, u8, bits, cout, shifts=None, indices=None) -> bool:
             and xs[0].data_ptr() % 16 == 0 and xs[1].data_ptr() % 16 == 0)
 
 
+def _pair_not_covered(e: Exception) -> bool:
+    """the library's answer to a two-tensor conv1 launch (hulc_conv_desc.x2) on a geometry its band kernels do not take — small frames
+    (W <= 40: fewer than two 8-pixel blocks per output row), LDS / workspace limits, HULC_NO_BAND_WGRAD: nothing was launched, the caller
+    runs the per-input loop instead"""
+    return "(x2) is taken by the conv1 band kernel only" in str(e)
+
+
 @_scoped
 class ConvStackFn(torch.autograd.Function):
     """xs: one or more (N_i,3,H,W) NCHW frame tensors -> a3 (sum N_i, OH3, OW3, 64) NHWC.  Several inputs (the vis and lang
@@ -427,15 +434,21 @@ class ConvStackFn(torch.autograd.Function):
                 # selective precision site "conv1": fp32 frames and weights as hi + lo bf16 splits, three MFMAs per product (fp32-class a1)
                 w_lo = weight_operand(ws[0], "oihw_flat_lo") if (not u8 and _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16"
                                                                   and "conv1" in kn.fp32_sites()) else None
+                paired = False
                 if _conv1_pair_ok(xs, u8, bits[li], cout, shifts, indices):
                     # the two modalities of a step (two frame tensors, never concatenated) as ONE conv1 launch: hulc_conv_desc.x2 (round 4)
                     # (uint8 frames: the per-frame shifts of the two inputs as one small tensor, kept for the weight gradient)
                     pair_shift = torch.cat([shifts[0], shifts[1]]) if (u8 and shifts[0] is not None) else None
                     pair_index = torch.cat([indices[0], indices[1]]) if (u8 and indices[0] is not None) else None
                     ctx.pair_aug = (pair_shift, pair_index)
-                    kn.conv2d_fwd(xs[0], w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, w_lo=w_lo, relu_bits=bits[li],
-                                  x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
-                else:
+                    try:
+                        kn.conv2d_fwd(xs[0], w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, w_lo=w_lo, relu_bits=bits[li],
+                                      x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
+                        paired = True
+                    except kn._L.HulcKernelError as e:
+                        if not _pair_not_covered(e):
+                            raise
+                if not paired:
                     for x, n, sh, ix in zip(xs, Ns, shifts, indices):
                         kn.conv2d_fwd(x, w2d, bs[li], y[off:off + n], n, h, w_, cin, cout, k, k, s, nchw, relu=True, aug_shift=sh, aug_pad=pad,
                                       frame_index=ix, w_lo=w_lo,
@@ -493,11 +506,17 @@ class ConvStackFn(torch.autograd.Function):
             if li == 0:                                  # per input tensor: the second one accumulates
                 off = 0
                 pad, shifts, indices = ctx.aug
+                paired = False
                 if _conv1_pair_ok(xs, xs[0].dtype == torch.uint8, None, cout, shifts, indices) and g.dtype == torch.bfloat16:
                     pair_shift, pair_index = getattr(ctx, "pair_aug", (None, None))
-                    kn.conv2d_bwd_weight(xs[0], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc,
-                                         x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
-                else:
+                    try:
+                        kn.conv2d_bwd_weight(xs[0], g, dw, db, N, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc,
+                                             x2=None if pair_index is not None else xs[1], aug_shift=pair_shift, aug_pad=pad, frame_index=pair_index)
+                        paired = True
+                    except kn._L.HulcKernelError as e:
+                        if not _pair_not_covered(e):
+                            raise
+                if not paired:
                     for j, (x, n, sh, ix) in enumerate(zip(xs, Ns, shifts, indices)):
                         kn.conv2d_bwd_weight(x, g[off:off + n], dw, db, n, h, w_, cin, cout, k, k, s, nchw, dw_oihw=True, accumulate=acc or j > 0,
                                              aug_shift=sh, aug_pad=pad, frame_index=ix)

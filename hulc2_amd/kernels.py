@@ -1249,7 +1249,8 @@ def window_rows(store, starts, sizes, B, S, out, zero_cols=(0, 0)):
     return out
 
 
-def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None, lo=None, lo_ranges=()):
+def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_state_dev=None, lo=None, lo_ranges=(),
+              loss_scale_dev=None, found_inf_dev=None):
     """step_state_dev: device {rng, step} words (see step_state); when given, the step count is read on device.  The update is skipped
     on the device while the fault word is set (a barrier kernel timed out upstream) — check_faults() then raises on the host.
     lo (bf16 arena like shadow) + lo_ranges (<= 8 (begin, end) element ranges): the rounding remainders w - bf16(w) of the updated weights
@@ -1258,6 +1259,18 @@ def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, 
     # lo_ranges, the remainder (2 B)
     n_lo = sum(int(e) - int(b) for b, e in lo_ranges) if (lo is not None and lo_ranges) else 0
     nbytes = float(n) * (16 + 12 + (2 if shadow is not None else 0)) + 2.0 * n_lo
+    if loss_scale_dev is not None or found_inf_dev is not None:
+        # torch.amp.GradScaler's device scalars (hulc_adam_step_amp, ABI 5): fp32 tensors of one element on the arena's device
+        for t in (loss_scale_dev, found_inf_dev):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != 1 or t.device != p.device):
+                raise _L.HulcKernelError("adam_step: loss_scale / found_inf are one-element fp32 tensors on the parameters' device")
+        has_lo = lo is not None and bool(lo_ranges)
+        flat = [int(x) for r in lo_ranges for x in r] if has_lo else [0, 0]
+        arr = (_c.c_long * len(flat))(*flat)
+        _call("hulc_adam_step_amp", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
+              step_state_dev, _f(grad_scale), fault_word(p.device), lo if has_lo else None, arr if has_lo else None,
+              _i(len(lo_ranges) if has_lo else 0), loss_scale_dev, found_inf_dev, nbytes=nbytes)
+        return
     if lo is None or not lo_ranges:
         _call("hulc_adam_step", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
               step_state_dev, _f(grad_scale), fault_word(p.device), nbytes=nbytes)
@@ -1266,6 +1279,11 @@ def adam_step(p, g, m, v, shadow, n, lr, beta1, beta2, eps, weight_decay, step, 
     arr = (_c.c_long * len(flat))(*flat)
     _call("hulc_adam_step_lo", p, g, m, v, shadow, _l(n), _f(lr), _f(beta1), _f(beta2), _f(eps), _f(weight_decay), _i(step),
           step_state_dev, _f(grad_scale), fault_word(p.device), lo, arr, _i(len(lo_ranges)), nbytes=nbytes)
+
+
+def step_count_advance_if(state, found_inf_dev=None) -> None:
+    """state[1] += 1 unless the GradScaler's found_inf (device float) is set — the device-resident step count of hulc2_amd.optim.Adam"""
+    _call("hulc_step_count_advance_if", state, found_inf_dev)
 
 
 def derive_copies(bf16, bf16_t, tiles, p32, conv_dst, conv_table):

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from hulc2_amd import functional as HF
+from hulc2_amd import gradsink
 from hulc2_amd.models.decoders.action_decoder import ActionDecoder
 
 
@@ -75,7 +76,8 @@ class LogisticDecoderRNN(ActionDecoder):
 
     def _heads(self, h: torch.Tensor) -> torch.Tensor:
         """(B,S,H) -> (B*S, 184): [logit_probs 60 | means 60 | log_scales 60 | gripper 2 | 2 zero pad columns]."""
-        if self._fused is not None:
+        if self._fused is not None and (not torch.is_grad_enabled() or gradsink.get(self._fused["heads_w"]) is not None):
+            # (the fused view carries no autograd edge: its gradient exists only as a sink — a trainer's, or the keeper's inside the step node)
             return HF.mlp(h.reshape(-1, h.shape[-1]), [(self._fused["heads_w"], self._fused["heads_b"], False)])
         pad = self._head_rows()[1]
         w = torch.cat([self.prob_fc.weight, self.mean_fc.weight, self.log_scale_fc.weight, self.gripper_fc.weight,

@@ -117,36 +117,74 @@ class Hulc2(LightningModule):
         kl_loss = self.compute_kl_loss(pp_state, pr_state)
         return kl_loss, action_loss, action_loss + kl_loss, pp_state, pr_state, seq_feat
 
-    def _keep_weight_copies_fresh(self) -> None:
+    def _keep_weight_copies_fresh(self):
         """Under an EXTERNAL optimizer (Lightning + torch.optim.Adam, hulc2/training.py:79-82) nobody maintains the kernel-side copies of the
         weights (bf16 shadows, transposed tiles, packed fragments, split-operand remainders, conv repacks): shadow.weight_operand re-derives
         each of them per parameter and layout with torch ops when the parameter's version has changed — ~200 small launches per step.  The
         first training-mode step on a GPU without an ArenaTrainer therefore installs ArenaTrainer(shadows_only=True): the parameters move into
         one arena (same Parameter objects, same values: optimizers, DDP and checkpoints are unaffected) and all copies are re-made by five
-        launches whenever the optimizer has stepped.  bf16 arithmetic modes only; HULC_NO_AUTO_SHADOWS=1 keeps the lazy per-parameter path."""
+        launches whenever the optimizer has stepped.  bf16 arithmetic modes only; HULC_NO_AUTO_SHADOWS=1 keeps the lazy per-parameter path.
+        Round 5: the keeper also owns the gradient arena of the step node (hulc2_amd/stepnode.py; HULC_NO_STEP_NODE=1: weight copies only).
+        Returns the keeper when it is this model's (else None: a full ArenaTrainer drives the step, or the lazy path is selected)."""
         if kn.base_mode() == "fp32" or os.environ.get("HULC_NO_AUTO_SHADOWS"):
-            return
+            return None
         ref = self.__dict__.get("_hulc_arena_trainer")
         tr = ref() if ref is not None else None
         if tr is not None and tr.model is not self:               # (a deep copy of a model carries the original's weak reference along)
             tr = None
         if tr is None:
             from ..trainer import ArenaTrainer
-            tr = self.__dict__["_hulc_shadow_keeper"] = ArenaTrainer(self, shadows_only=True)    # the model owns its keeper (a deepcopy of the
-                                                                                                # model gets None here and builds its own)
+            tr = self.__dict__["_hulc_shadow_keeper"] = ArenaTrainer(self, shadows_only=True,     # the model owns its keeper (a deepcopy of the
+                                                                     step_node=not os.environ.get("HULC_NO_STEP_NODE"))    # model gets None here and builds its own)
         if getattr(tr, "shadows_only", False):
             tr.refresh_if_stale()
+            return tr
+        return None
+
+    def _fresh_weight_copies(self) -> None:
+        """every forward entry point that is NOT a training step (validation, rollout): under an external optimizer the keeper's copies are
+        re-derived when a parameter has been written since (optimizer.step(), an EMA swap, weight surgery) — the arena views the kernels
+        read carry no version of their own"""
+        tr = self.__dict__.get("_hulc_shadow_keeper")
+        if tr is not None and getattr(tr, "shadows_only", False):
+            ref = self.__dict__.get("_hulc_arena_trainer")
+            if ref is not None and ref() is tr:
+                tr.refresh_if_stale()
+
+    def _step_node(self, keeper):
+        """the whole training step as one autograd node (hulc2_amd/stepnode.py) when this model's keeper owns a gradient arena and the call can
+        take it: gradients enabled, no gradient being accumulated over several calls, the keeper's parameter set still the trainable one"""
+        if keeper is None or not getattr(keeper, "step_node", False) or not torch.is_grad_enabled():
+            return None
+        node = self.__dict__.get("_hulc_step_node")
+        if node is None or node.keeper is not keeper:
+            from ..stepnode import StepNode
+            node = self.__dict__["_hulc_step_node"] = StepNode(self, keeper)
+        return node if node.usable() else None
 
     @_kernel_precision
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
         """hulc2.py:336-442."""
+        node = None
         if self.training:
             # every training-mode call draws fresh dropout masks and a fresh latent-plan sample (the device RNG word, kernels.step_state),
             # under any trainer: Lightning + a torch optimizer never touches that word, ArenaTrainer marks it fresh for this step itself
             p0 = next(self.parameters())
             if p0.is_cuda:
-                kn.ensure_fresh_rng(p0.device)
-                self._keep_weight_copies_fresh()
+                node = self._step_node(self._keep_weight_copies_fresh())
+                if node is None:                               # (the step node walks the word itself: inside its captured forward graph)
+                    kn.ensure_fresh_rng(p0.device)
+        else:
+            self._fresh_weight_copies()
+        # under an external optimizer (Lightning's loop, hulc2/training.py:79-82) the step is ONE autograd node — eager at first, two replayed
+        # hipGraphs from the third step of a configuration on (hulc2_amd/stepnode.py); otherwise the Functions of functional.py hang on the loss
+        total_loss, logs = node(batch, batch_idx) if node is not None else self._training_step_impl(batch, batch_idx)
+        for name, value, kw in logs:
+            self.log(name, value, **kw)
+        return total_loss
+
+    def _training_step_impl(self, batch: Dict[str, Dict], batch_idx: int):
+        """the arithmetic of training_step: -> (total loss, [(logged name, value, self.log keyword arguments)])"""
         kl_loss = action_loss = total_loss = lang_clip_loss = None
         batch_size: Dict[str, int] = {}
         total_bs = 0
@@ -268,18 +306,18 @@ class Hulc2(LightningModule):
         clip_term = lang_clip_loss if (self.use_clip_auxiliary_loss and lang_clip_loss is not None) else None
         total_loss, logs = HF.LossCombineFn.apply(kl_vec, act_vec, clip_term, float(self.clip_auxiliary_loss_beta))
         kl_d, act_d = kl_vec.detach(), act_vec.detach()
+        logged = []
         for i, (scope, db, *_rest) in enumerate(per):
             bs = db["actions"].shape[0]
-            self.log(f"train/kl_loss_scaled_{scope}", kl_d[i], on_step=False, on_epoch=True, batch_size=bs)
-            self.log(f"train/action_loss_{scope}", act_d[i], on_step=False, on_epoch=True, batch_size=bs)
-            self.log(f"train/total_loss_{scope}", logs[3 + i], on_step=False, on_epoch=True, batch_size=bs)
+            logged.append((f"train/kl_loss_scaled_{scope}", kl_d[i], dict(on_step=False, on_epoch=True, batch_size=bs)))
+            logged.append((f"train/action_loss_{scope}", act_d[i], dict(on_step=False, on_epoch=True, batch_size=bs)))
+            logged.append((f"train/total_loss_{scope}", logs[3 + i], dict(on_step=False, on_epoch=True, batch_size=bs)))
         if clip_term is not None:
-            self.log("train/lang_clip_loss", logs[2], on_step=False, on_epoch=True,
-                     batch_size=batch_size.get("aux_lang", 1), sync_dist=True)
-        self.log("train/kl_loss", logs[0], on_step=False, on_epoch=True, batch_size=total_bs)
-        self.log("train/action_loss", logs[1], on_step=False, on_epoch=True, batch_size=total_bs)
-        self.log("train/total_loss", total_loss, on_step=False, on_epoch=True, batch_size=total_bs)
-        return total_loss
+            logged.append(("train/lang_clip_loss", logs[2], dict(on_step=False, on_epoch=True, batch_size=batch_size.get("aux_lang", 1), sync_dist=True)))
+        logged.append(("train/kl_loss", logs[0], dict(on_step=False, on_epoch=True, batch_size=total_bs)))
+        logged.append(("train/action_loss", logs[1], dict(on_step=False, on_epoch=True, batch_size=total_bs)))
+        logged.append(("train/total_loss", total_loss, dict(on_step=False, on_epoch=True, batch_size=total_bs)))
+        return total_loss, logged
 
     @staticmethod
     def _batchable(mods) -> bool:
@@ -348,6 +386,7 @@ class Hulc2(LightningModule):
     @torch.no_grad()
     def validation_step(self, batch: Dict[str, Dict], batch_idx: int) -> Dict[str, torch.Tensor]:
         """hulc2.py:510-598: same logged names, returns the sampled plans and episode indices per modality."""
+        self._fresh_weight_copies()
         output = {}
         val_total_act_loss_pp = None
         for self.modality_scope, db in batch.items():
@@ -398,6 +437,7 @@ class Hulc2(LightningModule):
     @torch.no_grad()
     def predict_with_plan(self, obs, latent_goal, sampled_plan):
         """hulc2.py:630-652."""
+        self._fresh_weight_copies()
         emb = self.perceptual_encoder(obs["rgb_obs"], obs["depth_obs"], obs["robot_obs"])
         return self.action_decoder.act(sampled_plan, emb, latent_goal, obs["robot_obs_raw"])
 
@@ -405,6 +445,7 @@ class Hulc2(LightningModule):
     def get_pp_plan_vision(self, obs: dict, goal: dict):
         """hulc2.py:654-683: current and goal frames as a 2-step sequence through the encoders, plan from the prior."""
         assert len(obs["rgb_obs"]) == len(goal["rgb_obs"])
+        self._fresh_weight_copies()
         imgs = {k: torch.cat([v, goal["rgb_obs"][k]], dim=1) for k, v in obs["rgb_obs"].items()}     # (1, 2, C, H, W)
         state = torch.cat([obs["robot_obs"], goal["robot_obs"]], dim=1) if "robot_obs" in obs and "robot_obs" in goal else None
         emb = self.perceptual_encoder(imgs, {}, state)
@@ -416,6 +457,7 @@ class Hulc2(LightningModule):
     @torch.no_grad()
     def get_pp_plan_lang(self, obs: dict, goal: dict):
         """hulc2.py:685-707."""
+        self._fresh_weight_copies()
         emb = self.perceptual_encoder(obs["rgb_obs"], obs["depth_obs"], obs["robot_obs"])
         latent_goal = self.language_goal(goal["lang"])
         sampled_plan = self._sample_plan(self.plan_proposal(emb[:, 0], latent_goal))

@@ -12,6 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import kernels as kn
+from .gradsink import resolve as _resolve
 
 _cache: Dict[Tuple[int, Optional[str], int], Tuple[int, torch.Tensor, "weakref.ref"]] = {}
 _arena: Dict[int, Tuple["weakref.ref", torch.Tensor]] = {}   # id(param) -> (weakref(param), bf16 view into the shadow arena)
@@ -96,6 +97,7 @@ def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
 def weight_operand(w: torch.Tensor, layout: Optional[str] = None, chw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
     """Tensor handed to the kernels for parameter `w`: fp32 (repacked if asked) in fp32 compute mode, a
     cached bf16 copy in bf16 mode."""
+    w = _resolve(w)                      # (a detached leaf alias of a parameter, installed while the step node captures: hulc2_amd/gradsink.py)
     bf16 = kn.get_compute() == "bf16"
     base = w.detach()
     if not bf16:

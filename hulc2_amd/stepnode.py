@@ -1,0 +1,251 @@
+"""One autograd node per training step — the reference's own trainer loop at the speed of the captured graphs.
+
+reference: hulc2/training.py:72-82 (Lightning: `training_step` -> `loss.backward()` -> `optimizer.step()`, precision 16 =
+`torch.autocast` + `GradScaler`, conf/trainer/play_trainer.yaml:3; DDPStrategy on top).  Whoever drives that loop sees `Hulc2.training_step`
+return a scalar loss and calls `backward()` on (a multiple of) it.  Until round 4 the loss hung on ~160 autograd Functions whose Python
+forward / backward bodies and ctypes launches made the loop host-bound: 7.3 ms per step against 3.4 ms for ArenaTrainer's replayed graphs.
+
+Here the whole step is ONE node whose inputs are the parameters:
+
+  forward   runs the step's forward (`Hulc2._training_step_impl`) under `torch.enable_grad()` and keeps the inner loss,
+  backward  runs the inner backward with the incoming gradient as its root — under a GradScaler that is the loss scale, a device scalar the
+            first backward kernel multiplies by (a power of two: exact through every kernel) — while the keeper's gradient sinks are live
+            (trainer.ArenaTrainer(shadows_only=True, step_node=True)): the backward kernels write the weight gradients straight into one
+            gradient arena (one grouped launch, the first writer of a slice overwrites it), and the node hands the arena views to autograd
+            as the parameters' gradients.  AccumulateGrad takes them without a copy; DDP's reducer hooks, `GradScaler.unscale_`,
+            gradient clipping and any torch optimizer see ordinary `.grad` tensors.
+
+From the third step of an unchanged configuration on (same batch layout, same arithmetic mode) both halves are two hipGraphs captured on a
+side stream — forward (RNG word advance, forward, losses) and backward (root = a static device scalar) — and the node's forward / backward
+are one `replay()` each: ~12 000 Python-level calls per step become ~10.  The batch of the capturing call is the graphs' input buffer;
+a later batch at other addresses is copied into it (one multi-tensor copy), one at the same addresses (a resident batch, an HBM episode
+store's fixed windows) costs nothing.  Anything the graphs cannot express falls back to the eager node or to the plain call: gradients
+being accumulated over several calls (a live `.grad`), a batch with host data (sentences for the on-device tokenizer), an active capture
+or per-launch timing, a capture that fails (kept as `disabled`).  HULC_NO_STEP_NODE=1 keeps round 4's loop, HULC_NO_STEP_GRAPH=1 the eager node.
+"""
+import os
+import warnings
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import gradsink
+from . import kernels as kn
+from . import shadow
+
+
+def _leaves(obj, prefix: str, out: list) -> bool:
+    """flatten a batch into (path, tensor) pairs in a fixed order; False when it holds anything a graph cannot take as an input"""
+    if torch.is_tensor(obj):
+        out.append((prefix, obj))
+        return True
+    if isinstance(obj, dict):
+        return all(_leaves(v, f"{prefix}/{k}", out) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return all(_leaves(v, f"{prefix}/{i}", out) for i, v in enumerate(obj))
+    return obj is None or isinstance(obj, (bool, int))
+
+
+class _EagerStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, node, batch, batch_idx, *params):
+        loss, logs = node._inner_forward(batch, batch_idx)
+        ctx.node, ctx.inner = node, loss
+        node._logs = logs
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        inner, ctx.inner = ctx.inner, None
+        if inner is None:
+            raise RuntimeError("hulc2_amd step node: backward through one training step twice (the inner graph is freed by its first backward)")
+        return (None, None, None, *ctx.node._inner_backward(inner, g))
+
+
+class _GraphStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, node, *params):
+        node.graph_fwd.replay()
+        ctx.node = node
+        return node.static_loss.clone()                   # (the caller may keep the loss beyond the next replay)
+
+    @staticmethod
+    def backward(ctx, g):
+        node = ctx.node
+        node.static_g.copy_(g.reshape(node.static_g.shape))
+        node.graph_bwd.replay()
+        return (None, *[None if o is None else o.detach() for o in node.static_outs])
+
+
+class StepNode:
+    """the step node of one Hulc2 module under its shadows-only keeper (`Hulc2._step_node`)"""
+
+    EAGER_STEPS = 2                   # eager-node steps of a configuration before it is captured (the second one runs in sink-overwrite mode)
+
+    def __init__(self, model, keeper):
+        import weakref
+        self._model = weakref.ref(model)
+        self.keeper = keeper
+        self.dev = keeper.dev
+        self.views = [keeper.flat_g[off:off + p.numel()].view(p.shape) for p, off in zip(keeper.params, keeper.offsets)]
+        # members of a fused group (the decoder's four heads as one matrix view) are written through the GROUP's sink
+        self.group_of = [None] * len(keeper.params)
+        for pv, gv, off, shape in keeper.fused:
+            for i, (p, o) in enumerate(zip(keeper.params, keeper.offsets)):
+                if off <= o < off + gv.numel():
+                    self.group_of[i] = pv
+        self.sig = None
+        self.eager_seen = 0
+        self.graph_fwd = self.graph_bwd = None
+        self.static_loss = self.static_g = None
+        self.static_outs: List[Optional[torch.Tensor]] = []
+        self.static_leaves: List[torch.Tensor] = []
+        self.static_logs = []
+        self.disabled: Optional[str] = "HULC_NO_STEP_GRAPH" if os.environ.get("HULC_NO_STEP_GRAPH") else None
+        self.replays = self.eager_steps = self.captures = self.input_copies = 0      # (tests / bench read these)
+        self._logs = []
+
+    def __deepcopy__(self, memo):
+        return None                    # (copy.deepcopy(model): the copy builds its own keeper and node on its first training step)
+
+    # ---- the two halves of a step ------------------------------------------------------------------------------------------------
+    def _inner_forward(self, batch, batch_idx) -> Tuple[torch.Tensor, list]:
+        dev = self.dev
+        kn.advance_step_state(dev, rng=True, step=False)      # fresh dropout masks / plan sample (inside a capture: part of the graph)
+        kn._rng_fresh.pop(dev, None)
+        shadow.bump_epoch()                                   # every lazily cached weight operand is re-made inside this step (and inside a capture)
+        kn.wgrad_reset(dev)
+        with torch.enable_grad(), gradsink.active(self.keeper):
+            loss, logs = self._model()._training_step_impl(batch, batch_idx)
+        return loss, [(n, v.detach() if torch.is_tensor(v) else v, kw) for n, v, kw in logs]
+
+    def _inner_backward(self, inner: torch.Tensor, g: torch.Tensor, leaves=None) -> list:
+        tr = self.keeper
+        tr._zero_arena()
+        with gradsink.active(tr):
+            res = torch.autograd.grad(inner, tr.params if leaves is None else leaves, grad_outputs=g.reshape(inner.shape), allow_unused=True)
+            kn.wgrad_flush(self.dev)                          # (autograd's end-of-pass callback already issued it: no-op unless the pass was cut short)
+        tr._settle_sinks()
+        outs = []
+        for i, (p, v, r) in enumerate(zip(tr.params, self.views, res)):
+            pv = self.group_of[i]
+            sunk = gradsink.written(p) or (pv is not None and gradsink.written(pv))
+            if r is None:
+                outs.append(v.detach() if sunk else None)     # (a parameter nobody wrote has no gradient, as in the plain loop: .grad stays None)
+            else:
+                outs.append(v + r if sunk else r)             # the rare parameter autograd itself produced a gradient for
+        return outs
+
+    # ---- dispatch -----------------------------------------------------------------------------------------------------------------
+    def _signature(self, leaves) -> tuple:
+        m = self._model()
+        return (tuple((path, tuple(t.shape), t.dtype, t.device) for path, t in leaves), kn.base_mode(), kn.get_compute(),
+                os.environ.get("HULC_FP32_SITES"), kn.concurrent_streams(), float(m.kl_beta), float(m.kl_balancing_mix),
+                float(m.clip_auxiliary_loss_beta), bool(m.use_clip_auxiliary_loss))
+
+    def usable(self) -> bool:
+        """the keeper's parameter list is still the model's trainable set, and no gradient is being accumulated over several calls (a live
+        .grad may alias the arena the next backward overwrites: such steps take the plain path, where autograd adds into it)"""
+        tr = self.keeper
+        for p in tr.params:
+            if p.grad is not None or not p.requires_grad:
+                return False
+        return True
+
+    def __call__(self, batch, batch_idx) -> Tuple[torch.Tensor, list]:
+        tr = self.keeper
+        leaves: list = []
+        graphable = (self.disabled is None and _leaves(batch, "", leaves) and kn._timing is None
+                     and not torch.cuda.is_current_stream_capturing())
+        if graphable:
+            sig = self._signature(leaves)
+            if sig != self.sig:
+                self._drop_graphs()
+                self.sig, self.eager_seen = sig, 0
+            if self.graph_fwd is None and self.eager_seen >= self.EAGER_STEPS:
+                try:
+                    self._capture(batch, batch_idx, [t for _, t in leaves])
+                except Exception as e:                        # noqa: BLE001 - the step must still be taken
+                    self._drop_graphs()
+                    self.disabled = f"capture failed: {type(e).__name__}: {e}"
+                    warnings.warn(f"hulc2_amd step node: {self.disabled}; the step stays on the eager node")
+            if self.graph_fwd is not None:
+                src, dst = [], []
+                for (_, t), st in zip(leaves, self.static_leaves):
+                    if t.data_ptr() != st.data_ptr():
+                        src.append(t)
+                        dst.append(st)
+                if src:
+                    torch._foreach_copy_(dst, src)
+                    self.input_copies += 1
+                self.replays += 1
+                loss = _GraphStepFn.apply(self, *tr.params)
+                return loss, self.static_logs
+        self.eager_seen += 1
+        self.eager_steps += 1
+        loss = _EagerStepFn.apply(self, batch, batch_idx, *tr.params)
+        logs, self._logs = self._logs, []
+        return loss, logs
+
+    def _drop_graphs(self) -> None:
+        self.graph_fwd = self.graph_bwd = None
+        self.static_loss = None
+        self.static_outs, self.static_leaves, self.static_logs = [], [], []
+
+    def _param_slots(self):
+        """(module, attribute name, index into keeper.params) of every place a module holds one of the keeper's parameters"""
+        index = {id(p): i for i, p in enumerate(self.keeper.params)}
+        slots = []
+        for mod in self._model().modules():
+            for name, p in mod._parameters.items():
+                if p is not None and id(p) in index:
+                    slots.append((mod, name, index[id(p)]))
+        return slots
+
+    def _capture(self, batch, batch_idx, leaves) -> None:
+        """forward and backward of this batch layout as two hipGraphs on a side stream (shared memory pool).  A warm-up pass on that stream
+        comes first: per-stream workspaces and lazily made buffers exist before the capture; the RNG word it drew from is put back, so the
+        loop's sequence of draws is the eager loop's.
+        Inside the capture the modules hold detached leaf ALIASES of the parameters (same memory): the real parameters' AccumulateGrad nodes
+        are alive on the caller's stream (the previous step's loss, the outer node, DDP's reducer all reference them) and autograd would
+        synchronise the capturing stream with that stream — which pulls it into the capture (hipErrorStreamCaptureUnjoined).  The aliases'
+        accumulators are born on the capturing stream and die with the captured graph."""
+        dev = self.dev
+        torch.cuda.synchronize(dev)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        words = kn.step_state(dev).clone()
+        one = torch.ones((), dtype=torch.float32, device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            loss, _ = self._inner_forward(batch, batch_idx)
+            self._inner_backward(loss, one)
+            del loss
+            kn.step_state(dev).copy_(words)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.static_g = torch.ones((), dtype=torch.float32, device=dev)
+        g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # (a process group's watchdog thread may query events while this thread captures: only this thread's calls are policed then)
+        mode = {"capture_error_mode": "thread_local"} if (torch.distributed.is_available() and torch.distributed.is_initialized()) else {}
+        slots = self._param_slots()
+        aliases = [p.detach().requires_grad_(True) for p in self.keeper.params]
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        try:
+            for mod, name, i in slots:
+                mod._parameters[name] = aliases[i]
+            gradsink.set_aliases(aliases, self.keeper.params)
+            with torch.cuda.graph(g_f, stream=side, **mode):
+                loss, logs = self._inner_forward(batch, batch_idx)
+            with torch.cuda.graph(g_b, pool=g_f.pool(), stream=side, **mode):
+                outs = self._inner_backward(loss, self.static_g, leaves=aliases)
+        finally:
+            for mod, name, i in slots:
+                mod._parameters[name] = self.keeper.params[i]
+            gradsink.clear_aliases()
+        self.static_loss, self.static_logs, self.static_outs = loss.detach(), logs, outs
+        del loss, aliases
+        self.static_leaves = list(leaves)
+        self.graph_fwd, self.graph_bwd = g_f, g_b
+        self.captures += 1
+        torch.cuda.synchronize(dev)

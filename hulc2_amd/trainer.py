@@ -345,16 +345,21 @@ class _LoadHook:
 class ArenaTrainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  bucket_mb: int = 32, group=None, overlap: bool = True, comm_algo: Optional[str] = None, grad_payload: Optional[str] = None,
-                 force_comm: bool = False, shadows_only: bool = False):
+                 force_comm: bool = False, shadows_only: bool = False, step_node: bool = False):
         """force_comm: run the multi-rank control flow (split graphs, comm stream, collectives) even with a single rank in the process
         group — how the RCCL path is exercised on a one-GPU box.
         shadows_only (round 4): keep the KERNEL-SIDE COPIES of the parameters only — the parameters move into the fp32 arena, every derived
         copy (bf16 shadow, transposed tiles, packed fragments, remainders, conv repacks) is allocated and registered, refresh_if_stale()
         re-derives all of them with five launches when an external optimizer has stepped (any parameter's version counter moved) — and leave gradients, optimizer state and
         communication to the caller (Lightning + torch.optim.Adam + torch DDP: hulc2/training.py:79-82).  Without it that loop re-derives every
-        copy per parameter and layout through torch ops (~200 small launches per step)."""
+        copy per parameter and layout through torch ops (~200 small launches per step).
+        step_node (round 5, with shadows_only): the keeper also owns a GRADIENT arena and registers every parameter's slice as a gradient sink
+        that is live only inside the model's step node (hulc2_amd/stepnode.py: the whole forward + backward of a training step as ONE autograd
+        node, eager or as two replayed hipGraphs) — the backward kernels write weight gradients straight into the arena (grouped launch,
+        first writer overwrites), the node hands the arena views to autograd as the parameters' gradients.  No Adam moments, no communication."""
         self.model = model
         self.shadows_only = bool(shadows_only)
+        self.step_node = bool(step_node) and self.shadows_only
         prev = model.__dict__.get("_hulc_arena_trainer")
         prev = prev() if prev is not None else None
         if prev is not None and prev.model is not model:       # (a deep copy of a model carries the original's weak reference along)
@@ -369,7 +374,7 @@ class ArenaTrainer:
         # through a sink only, so they exist only when sinks do (not with per-parameter all-reduce hooks).
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.multi = self.world > 1 or (force_comm and dist.is_initialized())
-        use_sinks = dev.type == "cuda" and (not self.multi or not overlap) and not self.shadows_only
+        use_sinks = dev.type == "cuda" and ((not self.multi or not overlap) and not self.shadows_only or self.step_node)
         groups = []
         for mod in model.modules():                     # views installed by an earlier trainer die with its arena
             if getattr(mod, "fused_param_groups", None) is not None:
@@ -406,7 +411,7 @@ class ArenaTrainer:
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         _ARENAS[self.flat_p.untyped_storage().data_ptr()] = self    # (hulc2_amd.optim.Adam finds the arena behind a parameter list here)
         n_state = 0 if self.shadows_only else total            # (gradients and Adam moments belong to the caller's optimizer then)
-        self.flat_g = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total if self.step_node else n_state, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.flat_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
@@ -573,11 +578,13 @@ class ArenaTrainer:
         self._autograd_written, self._zero_planned, self._acc_hooks, self._sink_keys = set(), None, [], []
         self._replan_pending = False
         if use_sinks:                                     # no per-parameter all-reduce hooks depend on AccumulateGrad
+            owner = self if self.shadows_only else None       # (the keeper's sinks are live inside its model's step node only)
             for p, off in zip(self.params, self.offsets):
-                self._sink_keys.append(gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape)))
-                self._acc_hooks.append(p.register_post_accumulate_grad_hook(self._saw_autograd_grad))
+                self._sink_keys.append(gradsink.register(p, self.flat_g[off:off + p.numel()].view(p.shape), owner))
+                if not self.shadows_only:                     # (the step node takes autograd-made gradients with autograd.grad: nothing accumulates into the arena)
+                    self._acc_hooks.append(p.register_post_accumulate_grad_hook(self._saw_autograd_grad))
             for pv, gv, _, _ in self.fused:
-                self._sink_keys.append(gradsink.register(pv, gv))
+                self._sink_keys.append(gradsink.register(pv, gv, owner))
         self.step_count = 0
         self.dev = dev
         if dev.type == "cuda" and not self.shadows_only:
@@ -859,9 +866,9 @@ class ArenaTrainer:
 
     _zero_ranges = None
 
-    def zero_grad(self):
-        if self.shadows_only:
-            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
+    def _zero_arena(self) -> None:
+        """what a backward pass needs of the gradient arena before it starts: everything zeroed (first pass: sinks accumulate) or only the slices
+        autograd accumulates into (later passes: the first sink writer of a slice overwrites it)"""
         if self._zero_ranges is None or os.environ.get("HULC_FULL_ZERO_GRAD"):
             self.flat_g.zero_()
             gradsink.begin_step(False)
@@ -869,13 +876,17 @@ class ArenaTrainer:
             for a, b in self._zero_ranges:
                 self.flat_g[a:b].zero_()
             gradsink.begin_step(True)
+
+    def zero_grad(self):
+        if self.shadows_only:
+            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
+        self._zero_arena()
         for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point at the arena
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
 
-    def optimizer_step(self):
-        if self.shadows_only:
-            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
+    def _settle_sinks(self) -> None:
+        """bookkeeping behind a finished backward pass: the first (fully zeroed) pass makes the zeroing plan; later passes clean up after it"""
         if self._zero_ranges is None and gradsink._sinks and not os.environ.get("HULC_FULL_ZERO_GRAD"):
             self._plan_partial_zero()                              # the backward that just finished ran on a fully zeroed arena
         elif self._zero_ranges is not None:
@@ -896,6 +907,11 @@ class ArenaTrainer:
                 # slices are only ever written through sinks, and those are cleaned above), so THIS step's sum is right; the next step
                 # runs on a fully zeroed arena and the plan is re-made behind it
                 self._zero_ranges, self._replan_pending = None, False
+
+    def optimizer_step(self):
+        if self.shadows_only:
+            raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
+        self._settle_sinks()
         self.step_count += 1
         kn.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, self.total, self.lr, self.betas[0],
                      self.betas[1], self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world,

@@ -588,6 +588,15 @@ int hulc_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shad
 int hulc_adam_step_lo(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
                       void* lo_shadow, const long* lo_ranges, int n_ranges, void* stream);
+/* (ABI 5) The same step under torch.amp.GradScaler WITHOUT a host synchronisation (reference: conf/trainer/play_trainer.yaml:3 `precision: 16`
+ * -> Lightning's scaler.step(optimizer), hulc2/training.py:79-82; an optimizer that sets `_step_supports_amp_scaling` is handed the scaler's
+ * device scalars instead of a `found_inf.item()`): loss_scale (optional device float S: the gradients are multiplied by grad_scale / S, the
+ * reciprocal formed in double as torch's unscale_ forms it) and found_inf (optional device float: non-zero = the step is skipped, parameters,
+ * moments and shadows untouched).  hulc_step_count_advance_if bumps state[1] unless found_inf is set (a skipped step does not count). */
+int hulc_adam_step_amp(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, const unsigned long long* step_state, float grad_scale, const int* skip_flag,
+                       void* lo_shadow, const long* lo_ranges, int n_ranges, const float* loss_scale, const float* found_inf, void* stream);
+int hulc_step_count_advance_if(unsigned long long* state, const float* found_inf, void* stream);
 /* Device-resident step state {rng word, optimizer step count}: advanced by one kernel per training step so that
  * a captured hipGraph replays with fresh dropout masks / plan samples and the right Adam bias correction.
  * RNG kernels xor state[0] into their site seed (seed_dev = state); hulc_adam_step reads state[1] when

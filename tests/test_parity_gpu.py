@@ -398,9 +398,11 @@ def _oracle_batch(raw):
 # ratchet (every tensor also within 1.5x of its recorded error).
 BARS = {
     # (mode, B, clip)            losses      embeddings  median      worst        downstream worst
-    ("bf16", 32, True): dict(loss=1e-4, emb=2e-3, med=0.05, worst=0.10, down=0.04),           # measured 4.8 % / 9.4 % / 2.0 %
-    ("bf16", 32, False): dict(loss=1e-4, emb=2e-3, med=0.015, worst=0.33, down=0.04),         # measured 0.6 % / 16.4 % (static conv biases) / 2.0 %
-    ("bf16", 2, True): dict(loss=1e-4, emb=2e-3, med=0.03, worst=0.19, down=0.12),            # measured 1.5 % / 9.3 % / 5.7 %
+    # (round 5, VERDICT r04 #7: the headline's embeddings are held to 1.2e-3 — measured 1.04e-3 (lang) / 0.93e-3 (vis) against north_star's
+    #  1e-3; the side rows' worst / downstream bars are the measured value x 1.5, no longer x 2)
+    ("bf16", 32, True): dict(loss=1e-4, emb=1.2e-3, med=0.05, worst=0.10, down=0.04),         # measured 4.8 % / 9.4 % / 2.0 %
+    ("bf16", 32, False): dict(loss=1e-4, emb=1.2e-3, med=0.015, worst=0.25, down=0.04),       # measured 0.6 % / 16.4 % (static conv biases) / 2.0 %
+    ("bf16", 2, True): dict(loss=1e-4, emb=2e-3, med=0.03, worst=0.14, down=0.09),            # measured 1.5 % / 9.3 % / 5.7 %
     ("bf16+sites", 32, True): dict(loss=1e-4, emb=2e-3, med=0.02, worst=0.20, down=0.04),     # measured 0.86 % / 10 % / 2.0 %
     ("mixed", 32, True): dict(loss=1e-4, emb=1e-5, med=0.013, worst=0.021, down=0.016),       # measured 0.65 % / 1.04 % / 0.8 %
     # fp32: north_star's 1e-3 holds for every tensor but two of the gripper conv1 / static conv2 weights (1.8e-3) — the reference's own fp32
@@ -412,12 +414,12 @@ BARS = {
 _ORACLE_CACHE = {}
 
 
-def _oracle_step(seed, B, S, clip, names):
+def _oracle_step(seed, B, S, clip, names, mods=("vis", "lang")):
     """the CPU oracle's training step on the seeded batch (gripper_control on): losses, embeddings and the gradient of every parameter — once per
     (seed, B, S, clip): at B = 32 it is about a minute on 8 host threads and several tests / modes compare against the same numbers"""
     from hulc2_amd import param_spec
     from oracle import hulc2_oracle as O
-    key = (seed, B, S, clip)
+    key = (seed, B, S, clip, tuple(mods))
     if key not in _ORACLE_CACHE:
         nthreads = torch.get_num_threads()
         torch.set_num_threads(min(8, nthreads))                   # the oracle oversubscribes badly on a 128-core host
@@ -426,7 +428,8 @@ def _oracle_step(seed, B, S, clip, names):
             syn.fill_state_dict_(sd, seed)
             for v in sd.values():
                 v.requires_grad_(True)
-            out = O.training_step(sd, _oracle_batch(syn.make_batch(seed, B, S)), dict(gripper_control=True, use_clip_auxiliary_loss=clip))
+            raw = syn.make_batch(seed, B, S)
+            out = O.training_step(sd, _oracle_batch({m: raw[m] for m in mods}), dict(gripper_control=True, use_clip_auxiliary_loss=clip))
             out["total_loss"].backward()
             out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         finally:
@@ -551,20 +554,17 @@ def test_training_step_arrangements_at_full_size(dev, variant, monkeypatch):
     torch.cuda.synchronize()
     P = dict(m.named_parameters())
     if variant == "vision_only":
-        # no oracle step of that shape is cached: the arrangement is held to the stacked default on the decoder / prior / visual-goal tensors' side
-        # by its own determinism and finiteness, and to the two-modality losses through the per-modality means (hulc2.py:239-241)
-        assert torch.isfinite(total) and all(p.grad is None or torch.isfinite(p.grad).all() for p in P.values())
+        # (round 5: its own oracle step — the vision modality alone, no contrastive term: hulc2.py:379-442 with a one-entry batch)
         assert P["language_goal.mlp.1.weight"].grad is None or float(P["language_goal.mlp.1.weight"].grad.abs().max()) == 0.0
         assert float(P["visual_goal.mlp.0.weight"].grad.abs().max()) > 0.0
-        return
-    out, sd = _oracle_step(seed, B, S, True, set(P))
-    bar = dict(BARS[("bf16", 32, True)])
+    out, sd = _oracle_step(seed, B, S, True, set(P), mods=("vis",) if variant == "vision_only" else ("vis", "lang"))
+    bar = dict(BARS[("bf16", 32, False) if variant == "vision_only" else ("bf16", 32, True)])
     if variant == "plain_goal_pair":
         bar.update(med=0.08, worst=0.30)              # measured 5.2 % / 21.8 %: the language goal encoder's bf16 forward alone costs 22 % on its own first layer
     assert abs(float(total) - float(out["total_loss"])) <= bar["loss"] * abs(float(out["total_loss"]))
     assert abs(float(m.logged["train/kl_loss"]) - float(out["kl_loss"])) <= bar["loss"] * abs(float(out["kl_loss"]))
     errs = sorted(((P[n].grad.double().cpu() - ref.grad.double()).norm() / (ref.grad.double().norm() + 1e-30)).item()
-                  for n, ref in sd.items() if ref.grad is not None and n != "logit_scale")
+                  for n, ref in sd.items() if ref.grad is not None and n != "logit_scale" and P[n].grad is not None and float(ref.grad.abs().max()) > 0.0)
     print(f"[{variant}] gradient error: median {errs[len(errs) // 2]:.4f}, worst {errs[-1]:.4f} over {len(errs)} tensors")
     assert errs[len(errs) // 2] <= bar["med"] and errs[-1] <= bar["worst"], (errs[len(errs) // 2], errs[-5:])
 

@@ -259,7 +259,7 @@ def test_external_optimizer_loop_keeps_weight_copies_fresh_with_a_shadows_only_t
     assert "_hulc_shadow_keeper" not in m_lazy.__dict__
     m, batch, got = run(True)
     keeper = m.__dict__.get("_hulc_shadow_keeper")
-    assert keeper is not None and keeper.shadows_only and keeper.flat_g.numel() == 0
+    assert keeper is not None and keeper.shadows_only and keeper.step_node and keeper.flat_g.numel() == keeper.total   # (round 5: the step node's gradient arena)
     assert got == want, (got, want)
     assert all(p.data_ptr() == keeper.flat_p.data_ptr() + 4 * off for p, off in zip(keeper.params, keeper.offsets))
     # one parameter nudged in place: the next step must run on the new value

@@ -33,7 +33,10 @@ for mb in (491, 1024, 2048):
     print(f"cast  {mb // 2:5d} MB  bf16->f32 {(mb / 2 + mb) / 1024 / t / 1e3 * 1.073741824:6.2f} TB/s (read + write)")
 
 import ctypes
-lib = ctypes.CDLL("tools/probe/read_probe.so")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _build  # noqa: E402  (builds the .so from the .hip next to it)
+lib = ctypes.CDLL(_build.ensure("read_probe.so"))
 out = torch.zeros(65536, device=dev)
 n = 1024 * 1024 * 1024 // 4
 x = torch.randn(n, device=dev)

@@ -1,6 +1,10 @@
 """what does ds_read_b64_tr_b16 return?  lds[i] = i; lane l = 16 g + i passes byte address base_g + (i // 4) * stride + (i % 4) * 8"""
-import ctypes, sys, torch
-lib = ctypes.CDLL("tools/probe/tr_probe.so")
+import ctypes
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+import _build  # noqa: E402  (builds the .so from the .hip next to it)
+lib = ctypes.CDLL(_build.ensure("tr_probe.so"))
 dev = torch.device("cuda")
 for stride in (32, 80, 144):
     addr = torch.tensor([(l // 16) * 1024 + ((l % 16) // 4) * stride + (l % 4) * 8 for l in range(64)], dtype=torch.int32, device=dev)

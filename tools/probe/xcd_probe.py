@@ -1,6 +1,10 @@
 """is workgroup -> XCD assignment round-robin on the linear workgroup id?"""
-import ctypes, torch
-lib = ctypes.CDLL("tools/probe/xcd_probe.so")
+import ctypes
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+import _build  # noqa: E402  (builds the .so from the .hip next to it)
+lib = ctypes.CDLL(_build.ensure("xcd_probe.so"))
 dev = torch.device("cuda")
 for (gx, gy, gz, thr) in ((1024, 1, 1, 256), (32, 16, 4, 256), (7, 5, 3, 512), (4096, 1, 1, 64)):
     n = gx * gy * gz
