@@ -8,7 +8,10 @@
 //
 //   variant 0  group = the 128 workgroups of an XCD parity (4 XCDs), 1 KB slice each, write-through (agent-scope) stores, one agent-scope
 //              counter per XCD, pollers wait for the group's four counters            [the shipped protocol]
-//   variant 1  group = the 32 workgroups of one XCD, 4 KB slice each, plain stores, one workgroup-scope (L2) counter, sc0 polling loads
+//   variant 1  group = the 32 workgroups of one XCD, 4 KB slice each, plain stores, one workgroup-scope (L2) counter, polled with a
+//              workgroup-scope fetch_add(0) (atomics execute in the XCD's L2; a workgroup-scope LOAD may be served by the CU's L1 for ever:
+//              measured — the first version of this probe polled with sc0 loads and timed out)
+//   variant 4  as 1, polled with buffer_inv sc0 (L1 invalidate) + an ordinary load
 //   variant 2  as 1 but with the agent-scope stores / counter / poll of variant 0     [placement alone]
 //   variant 3  as 0 but plain stores + L2 atomics (expected to FAIL its checksum or hang-guard: not coherent across XCDs) — skipped unless argv[1]=="3"
 // Every round writes a fresh region (addresses never cached before they are complete).  Output: us per round, checksum status.
@@ -23,6 +26,8 @@
 constexpr int REGION = 128 * 1024;        // bytes exchanged per group and round
 constexpr int CTR_STRIDE = 1024;          // words between counters (4 KB)
 
+__device__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }
+
 template <int V>
 __global__ __launch_bounds__(512) void probe(unsigned char* buf, unsigned* ctr, int rounds, unsigned long long* sums, int* fail) {
     const int tid = threadIdx.x, wg = blockIdx.x, xcd = wg & 7, slot = wg >> 3;
@@ -30,6 +35,7 @@ __global__ __launch_bounds__(512) void probe(unsigned char* buf, unsigned* ctr, 
     int grp, mem, nmem;
     if (V == 0 || V == 3) { grp = xcd & 1; mem = (xcd >> 1) * 32 + slot; nmem = 128; }
     else { grp = xcd; mem = slot; nmem = 32; }
+    if (tid == 0 && (int)xcc_id() != xcd) *fail = 100 + V;     // the placement assumption itself (workgroup -> XCD round-robin)
     const int slice = REGION / nmem;                           // bytes this workgroup publishes per round
     unsigned long long acc = 0;
     for (int r = 0; r < rounds; ++r) {
@@ -62,11 +68,13 @@ __global__ __launch_bounds__(512) void probe(unsigned char* buf, unsigned* ctr, 
             else { c = ctr + (24 + xcd) * CTR_STRIDE; want = 32u * (unsigned)(r + 1); }
             long spins = 0;
             while (true) {
-                const unsigned got = (V == 0 || V == 2) ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                        : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned got;
+                if (V == 0 || V == 2) got = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (V == 4) { asm volatile("buffer_inv sc0" ::: "memory"); got = *(volatile const unsigned*)c; }
+                else got = __hip_atomic_fetch_add((unsigned*)c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (got >= want) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1L << 20)) { *fail = 1 + V; break; }
+                if (++spins > (1L << 16)) { *fail = 1 + V; break; }
             }
         }
         __syncthreads();
@@ -126,14 +134,15 @@ static void run(const char* name, int rounds) {
         for (int i = 0; i < 256; ++i) ok = ok && h[i] == want;
         if (failed) break;
     }
-    printf("variant %d  %-62s %7.2f us per round   checksum %s%s\n", V, name, best * 1e3f / rounds, ok ? "ok" : "WRONG", failed ? "  (poll timed out)" : "");
+    printf("variant %d  %-62s %7.2f us per round   checksum %s%s\n", V, name, best * 1e3f / rounds, ok ? "ok" : "WRONG", failed >= 100 ? "  (workgroup -> XCD is NOT id % 8 here)" : (failed ? "  (poll timed out)" : ""));
     CK(hipFree(buf)); CK(hipFree(ctr)); CK(hipFree(sums)); CK(hipFree(fail));
 }
 
 int main(int argc, char** argv) {
     const int rounds = 64;
     run<0>("4 XCDs x 32 wgs, write-through stores, agent counters (shipped)", rounds);
-    run<1>("1 XCD x 32 wgs, plain stores, L2 counter, sc0 poll", rounds);
+    run<1>("1 XCD x 32 wgs, plain stores, L2 counter, fetch_add(0) poll", rounds);
+    run<4>("1 XCD x 32 wgs, plain stores, L2 counter, buffer_inv sc0 + load poll", rounds);
     run<2>("1 XCD x 32 wgs, write-through stores, agent counter", rounds);
     if (argc > 1 && !strcmp(argv[1], "3")) run<3>("4 XCDs, plain stores + L2 atomics (not coherent: expected wrong)", rounds);
     return 0;
