@@ -770,10 +770,13 @@ def main():
         # per image: frozen ResNet-18 trunk forward (1.82 GMAC at 224 x 224) + 3 x the trainable part (decoder convolutions 6 256 MMAC by closed
         # form over unet_decoder.py's ten 3 x 3 layers and the head, depth / text MLPs 21 MMAC)
         seq_flop = 2 * 1.82e9 + 3 * 2 * (6256.0 + 21.0) * 1e6
+        if args.trunk_mode == "reference":                 # + the trunk's data gradient (all layers but the stem) and the stem's weight gradient
+            seq_flop += 2 * (1.82e9 - 0.118e9) + 2 * 0.118e9
     workload = ("BASELINE configs[4] (secondary): affordance model PixelAffLangDetector.training_step, shipped r3m variant — frozen R3M ResNet-18 trunk "
                 + ("(random weights, trunk_mode=frozen: inference-mode BatchNorm folded into the convolutions)" if args.trunk_mode == "frozen" else
                    "(random weights, trunk_mode=reference: every trunk BatchNorm on BATCH statistics with running statistics updated, as the "
-                   "reference's train() leaves them — r3m_rn18.py:27-43; the stem stays frozen)")
+                   "reference's train() leaves them — r3m_rn18.py:27-43; STEM TRAINABLE as in the reference: conv1.weight / bn1 receive their gradient "
+                   "through the data gradient of the whole frozen ResNet-18, hulc2_amd/affordance/trunk.py)")
                 + ", language-fused U-Net decoder with BatchNorm on batch statistics, pixel cross-entropy + "
                 "Gaussian depth NLL, Adam lr 1e-4; 224 x 224 images, lang = random (B,384) embeddings"
                 if args.affordance else

@@ -69,7 +69,9 @@ class AffDecoderLossFn(torch.autograd.Function):
     """(p0, out_hw, running-stat buffers, g0, g1, g2, stem, l1, l2, l3, l4, 30 block parameters, head weight, head bias) -> (aff_loss, logits)
 
     g_i (N, C_in_i) fp32 = lang_proj_i(l_enc) for the three language-fused blocks (computed outside: its Linear is an ordinary MLP layer);
-    the trunk maps are NHWC bf16 and receive no gradient (frozen trunk).  BatchNorm runs on batch statistics and updates the running buffers."""
+    the trunk maps are NHWC bf16; they receive a gradient only when they ask for one (trunk_mode "reference": the trainable stem behind them,
+    affordance/trunk.py) — the skip connections' share is the data gradient of a block's first convolution over its skip channels, the
+    last map's the first block's upsampled input.  BatchNorm runs on batch statistics and updates the running buffers."""
 
     @staticmethod
     def forward(ctx, p0, out_hw, buffers, g0, g1, g2, f_stem, f1, f2, f3, f4, *params):
@@ -142,6 +144,9 @@ class AffDecoderLossFn(torch.autograd.Function):
             d_head_b = None
         dO2 = kn.head_conv_dgrad(g, head_w.detach().contiguous(), N, out_hw, out_hw, last.C)
         dgs = [None, None, None]
+        want_maps = ctx.needs_input_grad[6:11]                          # (f_stem, f1, f2, f3, f4)
+        dmaps = [None] * 5
+        skip_of = (3, 2, 1, 0, None)                                    # block i's skip connection is trunk map skip_of[i]
         for i in range(4, -1, -1):
             cin, cs, cout = chans[i]
             X, Y1, bn1, O1, Y2, bn2, O2, x_map, x_str, g, hi, s = saved[i]
@@ -157,15 +162,20 @@ class AffDecoderLossFn(torch.autograd.Function):
             DZ1 = kn.grid_bn_relu_bwd(dO1, O1, Y1, bn1, d_ga1, d_be1, accumulate=a1 or a2)
             grads_blocks[6 * i + 1], grads_blocks[6 * i + 2] = r1, r2
             grads_blocks[6 * i] = _conv_wgrad(DZ1, X, w1, cin + cs)
-            need_small = i > 0                                          # block 0's input is the frozen trunk's last map
+            need_small = i > 0 or want_maps[4]                          # block 0's input is the trunk's last map
             need_dg = i < 3
+            if skip_of[i] is not None and want_maps[skip_of[i]]:        # the skip channels' data gradient: the trunk map's share
+                dS, _ = kn.gridconv3x3(DZ1, _dgrad_w(w1)[cin:], cs, flip=True)
+                dmaps[skip_of[i]] = dS.interior().contiguous()
             if need_small or need_dg:
                 dX, _ = kn.gridconv3x3(DZ1, _dgrad_w(w1, cin), cin, flip=True)
                 dsmall, dg = kn.grid_upcat_bwd(dX, x_map, x_str, g, N, hi, hi, s, cin, want_dsmall=need_small, want_dg=need_dg)
                 if need_dg:
                     dgs[i] = dg
                 dO2 = dsmall
-        return (None, None, None, dgs[0], dgs[1], dgs[2], None, None, None, None, None, *grads_blocks, d_head_w, d_head_b)
+                if i == 0 and want_maps[4]:
+                    dmaps[4] = dsmall.interior().contiguous()
+        return (None, None, None, dgs[0], dgs[1], dgs[2], *dmaps, *grads_blocks, d_head_w, d_head_b)
 
 
 class DepthNllFn(torch.autograd.Function):

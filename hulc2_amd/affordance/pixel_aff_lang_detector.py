@@ -11,10 +11,12 @@ the same tensors, not repeated here).
 Trunk modes (`trunk_mode`): "frozen" (default) — the WHOLE trunk is a frozen inference-mode feature extractor (BatchNorm folded into the
 convolutions).  "reference" (round 4) — the BatchNorms of the trunk as the reference runs them: r3m_rn18.py:34-38 freezes the PARAMETERS of
 layer1..layer4 only and pixel_aff_lang_detector.py:51-53 leaves Lightning's train() on, so in training every BatchNorm2d of the ResNet
-normalises with the statistics of the batch and updates its running statistics (eval mode: running statistics, = "frozen").  Still a deviation
-in both modes, shared with the oracle: the reference's freeze leaves conv1 / bn1 of the STEM trainable by omission (a full ResNet-18 backward:
-not built); here no trunk parameter receives a gradient.  Third-party arithmetic (r3m weights, sentence-transformers) is absent: parity of
+normalises with the statistics of the batch and updates its running statistics (eval mode: running statistics, = "frozen"), and (round 5) the
+STEM trains: the reference's freeze leaves `conv1.weight`, `bn1.weight`, `bn1.bias` trainable by omission, their gradient is the data gradient
+through the whole frozen ResNet (affordance/trunk.py: one autograd node, hulc_nhwc_bn_train_bwd / zero-inserted data-gradient convolutions /
+hulc_maxpool_nhwc_bwd / a 7 x 7 weight gradient).  "frozen" stays what it says: no trunk parameter receives a gradient.  Third-party arithmetic (r3m weights, sentence-transformers) is absent: parity of
 the trunk and of SBERT is unpinned; everything behind them is pinned on the reference's own modules."""
+import os
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -107,15 +109,25 @@ class PixelAffLangDetector(nn.Module):
         self.img_size, self.normalize_depth, self.lr = img_size, normalize_depth, lr
         self.loss_weights = dict(loss_weights or LOSS_WEIGHTS)
         self.model = AffDepthLangFusionPixel(img_size, sbert)
+        if trunk_mode == "reference":                  # r3m_rn18.py:34-38 freezes layer1..layer4 only: the stem's three tensors train
+            net = self.model.aff_stream.r3m.convnet
+            for p in (net.conv1.weight, net.bn1.weight, net.bn1.bias):
+                p.requires_grad = True
         self.logged: Dict[str, torch.Tensor] = {}
 
     # ---- pieces ---------------------------------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def trunk_maps(self, img: torch.Tensor) -> List[torch.Tensor]:
         """R3M.r3m_resnet18 (r3m_rn18.py:71-76): the stem's and the four stages' outputs, NHWC bf16 — from the folded inference-mode trunk, or
-        (trunk_mode "reference", training) with every BatchNorm on the statistics of the batch"""
-        from ..models.perceptual_encoders.vision_r3m import trunk_feature_maps
-        return trunk_feature_maps(self.model.aff_stream.r3m, img, batch_stats=self.trunk_mode == "reference" and self.training)
+        (trunk_mode "reference", training) with every BatchNorm on the statistics of the batch and the stem's three tensors trainable"""
+        from ..models.perceptual_encoders.vision_r3m import _trunk_of, trunk_feature_maps
+        r3m = self.model.aff_stream.r3m
+        net = r3m.convnet
+        if (self.trunk_mode == "reference" and self.training and torch.is_grad_enabled() and net.conv1.weight.requires_grad
+                and not os.environ.get("HULC_AFF_FROZEN_STEM")):
+            from .trunk import TrunkStemFn
+            return list(TrunkStemFn.apply(img, net.conv1.weight, net.bn1.weight, net.bn1.bias, _trunk_of(r3m)))
+        with torch.no_grad():
+            return trunk_feature_maps(r3m, img, batch_stats=self.trunk_mode == "reference" and self.training)
 
     def text_enc(self, lang_goal) -> torch.Tensor:
         le = self.model.lang_encoder

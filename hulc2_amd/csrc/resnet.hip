@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void nhwc_bn_stats_kernel(const void* __restri
 // updated like nn.BatchNorm2d in training mode (momentum, unbiased variance); ss[c] = scale, ss[C + c] = shift
 __global__ __launch_bounds__(256) void nhwc_bn_finalize_kernel(const float* __restrict__ partial, int P, long M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
-                                                               float* __restrict__ run_var, float* __restrict__ ss) {
+                                                               float* __restrict__ run_var, float* __restrict__ ss, float* __restrict__ saved) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void nhwc_bn_finalize_kernel(const float* __re
     if (var < 0.0) var = 0.0;
     const float scale = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
     ss[c] = scale; ss[C + c] = beta[c] - (float)mean * scale;
+    if (saved) { saved[c] = (float)mean; saved[C + c] = (float)(1.0 / sqrt(var + (double)eps)); }      // what the backward needs: batch mean, rstd
     if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
     if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(M > 1 ? var * (double)M / (double)(M - 1) : var);
 }
@@ -153,6 +154,156 @@ __global__ __launch_bounds__(256) void nhwc_bn_apply_kernel(const void* __restri
     }
 }
 
+// ---- backward of the same BatchNorm (+ ReLU) in training mode (round 5: the affordance trunk's trainable stem needs the data gradient through
+// every frozen layer, r3m_rn18.py:34-38).  g = dy * (y > 0) (relu) or dy;  s1[c] = sum g, s2[c] = sum g * xhat, xhat = (z - mean) * rstd;
+// dz = gamma * rstd * (g - s1 / M - xhat * s2 / M);  dgamma = s2, dbeta = s1.  Same slicing and summation order as the forward statistics.
+__global__ __launch_bounds__(256) void nhwc_bn_bwd_stats_kernel(const void* __restrict__ dy, int dy_dtype, const void* __restrict__ y, int y_dtype,
+                                                                const float* __restrict__ z, long M, int C, long rows_per,
+                                                                const float* __restrict__ saved, float* __restrict__ partial) {
+    __shared__ float red[2][256];
+    const int RL = C >= 256 ? 1 : 256 / C;
+    const int rl = threadIdx.x / (C >= 256 ? 256 : C), c0 = threadIdx.x % (C >= 256 ? 256 : C);
+    const long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+    for (int c = c0; c < C; c += 256) {
+        const float mean = saved[c], rstd = saved[C + c];
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        long r = r0 + rl;
+        auto term = [&](long row, float& s, float& q) {
+            float g = load_elem(dy, dy_dtype, row * C + c);
+            if (y && !(load_elem(y, y_dtype, row * C + c) > 0.f)) g = 0.f;
+            s += g; q += g * ((z[row * C + c] - mean) * rstd);
+        };
+        for (; r + RL < r1; r += 2 * RL) { term(r, s0, q0); term(r + RL, s1, q1); }
+        if (r < r1) term(r, s0, q0);
+        float sv = s0 + s1, qv = q0 + q1;
+        if (RL > 1) {
+            red[0][threadIdx.x] = sv; red[1][threadIdx.x] = qv;
+            __syncthreads();
+            if (rl == 0) {
+                sv = 0.f; qv = 0.f;
+                for (int k = 0; k < RL; ++k) { sv += red[0][k * C + c0]; qv += red[1][k * C + c0]; }
+            }
+            __syncthreads();
+        }
+        if (rl == 0) { partial[((long)blockIdx.x * 2) * C + c] = sv; partial[((long)blockIdx.x * 2 + 1) * C + c] = qv; }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, long M, int C, float* __restrict__ sums,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < P; ++p) { s += (double)partial[((long)p * 2) * C + c]; q += (double)partial[((long)p * 2 + 1) * C + c]; }
+    sums[c] = (float)(s / (double)M); sums[C + c] = (float)(q / (double)M);
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+}
+
+// dz = gamma * rstd * (g - mean(g) - xhat * mean(g xhat)), and (optionally) g itself — the gradient the block's shortcut branch receives
+__global__ __launch_bounds__(256) void nhwc_bn_bwd_apply_kernel(const void* __restrict__ dy, int dy_dtype, const void* __restrict__ y, int y_dtype,
+                                                                const float* __restrict__ z, long total8, int C8, const float* __restrict__ gamma,
+                                                                const float* __restrict__ saved, const float* __restrict__ sums,
+                                                                void* __restrict__ dz, void* __restrict__ gout, int o_dtype) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int c = (int)(i % C8) * 8, C = C8 * 8;
+    Chunk8 g, yy;
+    chunk_load_contig(g, dy, dy_dtype, i * 8);
+    if (y) chunk_load_contig(yy, y, y_dtype, i * 8);
+    const float4 za = *(const float4*)(z + i * 8), zb = *(const float4*)(z + i * 8 + 4);
+    const float zv[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+    float o[8], gg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        gg[e] = (y && !(yy.v[e] > 0.f)) ? 0.f : g.v[e];
+        const float rstd = saved[C + c + e], xhat = (zv[e] - saved[c + e]) * rstd;
+        o[e] = gamma[c + e] * rstd * (gg[e] - sums[c + e] - xhat * sums[C + c + e]);
+    }
+    if (o_dtype == HULC_BF16) {
+        *(uint4*)((uint16_t*)dz + i * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        if (gout) *(uint4*)((uint16_t*)gout + i * 8) = make_uint4(pack_bf16x2(gg[0], gg[1]), pack_bf16x2(gg[2], gg[3]), pack_bf16x2(gg[4], gg[5]), pack_bf16x2(gg[6], gg[7]));
+    } else {
+        float4* q = (float4*)((float*)dz + i * 8);
+        q[0] = make_float4(o[0], o[1], o[2], o[3]); q[1] = make_float4(o[4], o[5], o[6], o[7]);
+        if (gout) { float4* h = (float4*)((float*)gout + i * 8); h[0] = make_float4(gg[0], gg[1], gg[2], gg[3]); h[1] = make_float4(gg[4], gg[5], gg[6], gg[7]); }
+    }
+}
+
+// max pool backward, NHWC, 8 channels per thread: dx[pixel] = sum of dy over the windows whose FIRST maximum (scan order kh, kw; strict >, as
+// nn.MaxPool2d records its indices) is this pixel.  A gather over the <= ceil(k/s)^2 windows that contain the pixel: no atomics, deterministic.
+__global__ __launch_bounds__(256) void maxpool_nhwc_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, int dtype, int H, int W, int C8,
+                                                               int OH, int OW, int k, int s, int pad, long total, void* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*H*W*C8
+    if (i >= total) return;
+    const int c8 = (int)(i % C8); long r = i / C8;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H); const long n = r / H;
+    Chunk8 me;
+    chunk_load_contig(me, x, dtype, i * 8);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // windows (oy, ox) with oy*s - pad <= iy < oy*s - pad + k
+    int oy_lo = iy + pad - k + 1; oy_lo = oy_lo <= 0 ? 0 : (oy_lo + s - 1) / s;
+    int oy_hi = (iy + pad) / s; if (oy_hi > OH - 1) oy_hi = OH - 1;
+    int ox_lo = ix + pad - k + 1; ox_lo = ox_lo <= 0 ? 0 : (ox_lo + s - 1) / s;
+    int ox_hi = (ix + pad) / s; if (ox_hi > OW - 1) ox_hi = OW - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            // is (iy, ix) the FIRST maximum of window (oy, ox)?  per channel: every element before it in scan order is strictly smaller (an equal
+            // earlier one would have kept the index), every element after it is not larger
+            bool win[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) win[e] = true;
+            for (int ky = 0; ky < k; ++ky) {
+                const int yy = oy * s - pad + ky;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int xx = ox * s - pad + kx;
+                    if (xx < 0 || xx >= W || (yy == iy && xx == ix)) continue;
+                    Chunk8 o;
+                    chunk_load_contig(o, x, dtype, ((n * H + yy) * W + xx) * (long)C8 * 8 + c8 * 8);
+                    const bool before = yy < iy || (yy == iy && xx < ix);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) win[e] = win[e] && (before ? o.v[e] < me.v[e] : o.v[e] <= me.v[e]);
+                }
+            }
+            Chunk8 d;
+            chunk_load_contig(d, dy, dtype, ((n * OH + oy) * OW + ox) * (long)C8 * 8 + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += win[e] ? d.v[e] : 0.f;
+        }
+    if (dtype == HULC_BF16) {
+        *(uint4*)((uint16_t*)dx + i * 8) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    } else {
+        float4* q = (float4*)((float*)dx + i * 8);
+        q[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); q[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// y [N][Hy][Wy][C] = x [N][H][W][C] placed at (oy + a * step, ox + a * step), zero elsewhere: step 2 / offset 0 = the zero-inserted gradient of a
+// stride-2 convolution (its data gradient is then a stride-1 convolution with the flipped taps); step 1 / offset p = zero padding
+__global__ __launch_bounds__(256) void nhwc_scatter_kernel(const void* __restrict__ x, int dtype, int H, int W, int C8, int Hy, int Wy, int step, int off,
+                                                           long total, void* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over N*Hy*Wy*C8
+    if (i >= total) return;
+    const int c8 = (int)(i % C8); long r = i / C8;
+    const int xo = (int)(r % Wy); r /= Wy;
+    const int yo = (int)(r % Hy); const long n = r / Hy;
+    const int ys = yo - off, xs = xo - off;
+    const bool live = ys >= 0 && xs >= 0 && ys % step == 0 && xs % step == 0 && ys / step < H && xs / step < W;
+    if (dtype == HULC_BF16) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (live) v = *(const uint4*)((const uint16_t*)x + (((n * H + ys / step) * W + xs / step) * (long)C8 + c8) * 8);
+        *(uint4*)((uint16_t*)y + i * 8) = v;
+    } else {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) { const float4* q = (const float4*)((const float*)x + (((n * H + ys / step) * W + xs / step) * (long)C8 + c8) * 8); a = q[0]; b = q[1]; }
+        float4* o = (float4*)((float*)y + i * 8); o[0] = a; o[1] = b;
+    }
+}
+
 }  // namespace
 
 // see include/hulc2_amd.h
@@ -164,6 +315,12 @@ extern "C" long hulc_nhwc_bn_train_workspace(long M, int C) {
 extern "C" int hulc_nhwc_bn_train_fwd(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
                                       float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype, void* ws,
                                       void* stream) {
+    return hulc_nhwc_bn_train_fwd_saved(z, z_dtype, M, C, gamma, beta, eps, momentum, run_mean, run_var, add, add_dtype, relu, y, y_dtype, nullptr, ws, stream);
+}
+
+extern "C" int hulc_nhwc_bn_train_fwd_saved(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                            float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype,
+                                            float* saved, void* ws, void* stream) {
     if (!z || !gamma || !beta || !y || !ws) return hulc_fail(-1, "hulc_nhwc_bn_train_fwd: null pointer");
     if (M < 1 || C < 8 || C % 8 || C > 2048 || (C < 256 && 256 % C)) return hulc_fail(-2, "hulc_nhwc_bn_train_fwd: C must be a multiple of 8 (a divisor of 256 below 256)");
     if (((uintptr_t)z | (uintptr_t)y | (uintptr_t)add) % 16) return hulc_fail(-4, "hulc_nhwc_bn_train_fwd: 16-byte aligned rows");
@@ -174,7 +331,7 @@ extern "C" int hulc_nhwc_bn_train_fwd(const void* z, int z_dtype, long M, int C,
     float* ss = partial + P * 2 * C;
     hipStream_t s = (hipStream_t)stream;
     nhwc_bn_stats_kernel<<<(unsigned)P, 256, 0, s>>>(z, z_dtype, M, C, rows_per, partial);
-    nhwc_bn_finalize_kernel<<<(unsigned)((C + 255) / 256), 256, 0, s>>>(partial, (int)P, M, C, gamma, beta, eps, momentum, run_mean, run_var, ss);
+    nhwc_bn_finalize_kernel<<<(unsigned)((C + 255) / 256), 256, 0, s>>>(partial, (int)P, M, C, gamma, beta, eps, momentum, run_mean, run_var, ss, saved);
     const long total8 = M * (C / 8);
     nhwc_bn_apply_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(z, z_dtype, total8, C / 8, ss, add, add_dtype, relu, y, y_dtype);
     return hulc_check_launch("hulc_nhwc_bn_train_fwd");
@@ -207,4 +364,42 @@ extern "C" int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, 
     const long total = (long)N * OH * OW * (C / 8);
     maxpool_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, dtype, H, W, C / 8, OH, OW, k, stride, pad, total, y);
     return hulc_check_launch("hulc_maxpool_nhwc");
+}
+
+extern "C" int hulc_nhwc_bn_train_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, const float* z, long M, int C, const float* gamma,
+                                      const float* saved, void* dz, void* g_out, int o_dtype, float* dgamma, float* dbeta, int accumulate_params,
+                                      void* ws, void* stream) {
+    if (!dy || !z || !gamma || !saved || !dz || !ws) return hulc_fail(-1, "hulc_nhwc_bn_train_bwd: null pointer");
+    if (M < 1 || C < 8 || C % 8 || C > 2048 || (C < 256 && 256 % C)) return hulc_fail(-2, "hulc_nhwc_bn_train_bwd: C must be a multiple of 8 (a divisor of 256 below 256)");
+    if (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)g_out) % 16) return hulc_fail(-4, "hulc_nhwc_bn_train_bwd: 16-byte aligned rows");
+    long P = (M + 255) / 256; if (P > 1024) P = 1024; if (P < 1) P = 1;
+    const long rows_per = (M + P - 1) / P;
+    P = (M + rows_per - 1) / rows_per;
+    float* partial = (float*)ws;
+    float* sums = partial + P * 2 * C;
+    hipStream_t s = (hipStream_t)stream;
+    nhwc_bn_bwd_stats_kernel<<<(unsigned)P, 256, 0, s>>>(dy, dy_dtype, y, y_dtype, z, M, C, rows_per, saved, partial);
+    nhwc_bn_bwd_finalize_kernel<<<(unsigned)((C + 255) / 256), 256, 0, s>>>(partial, (int)P, M, C, sums, dgamma, dbeta, accumulate_params);
+    const long total8 = M * (C / 8);
+    nhwc_bn_bwd_apply_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, s>>>(dy, dy_dtype, y, y_dtype, z, total8, C / 8, gamma, saved, sums, dz, g_out, o_dtype);
+    return hulc_check_launch("hulc_nhwc_bn_train_bwd");
+}
+
+extern "C" int hulc_maxpool_nhwc_bwd(const void* x, const void* dy, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* dx, void* stream) {
+    if (!x || !dy || !dx) return hulc_fail(-1, "hulc_maxpool_nhwc_bwd: null pointer");
+    if (N <= 0 || C <= 0 || C % 8 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k || H + 2 * pad < k || W + 2 * pad < k)
+        return hulc_fail(-2, "hulc_maxpool_nhwc_bwd: bad geometry (C must be a multiple of 8, 2 * pad <= k)");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    const long total = (long)N * H * W * (C / 8);
+    maxpool_nhwc_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, dy, dtype, H, W, C / 8, OH, OW, k, stride, pad, total, dx);
+    return hulc_check_launch("hulc_maxpool_nhwc_bwd");
+}
+
+extern "C" int hulc_nhwc_scatter(const void* x, int dtype, int N, int H, int W, int C, int Hy, int Wy, int step, int off, void* y, void* stream) {
+    if (!x || !y) return hulc_fail(-1, "hulc_nhwc_scatter: null pointer");
+    if (N <= 0 || C <= 0 || C % 8 || step < 1 || off < 0 || (long)(H - 1) * step + off >= Hy || (long)(W - 1) * step + off >= Wy)
+        return hulc_fail(-2, "hulc_nhwc_scatter: the placed map must fit the destination (C a multiple of 8)");
+    const long total = (long)N * Hy * Wy * (C / 8);
+    nhwc_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, dtype, H, W, C / 8, Hy, Wy, step, off, total, y);
+    return hulc_check_launch("hulc_nhwc_scatter");
 }

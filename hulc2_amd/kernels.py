@@ -453,13 +453,49 @@ def r3m_stem_fwd(xp, w, bias, y, N, H, W, Cout, relu=True):
     return y
 
 
-def nhwc_bn_train_fwd(z, M, C, gamma, beta, eps, momentum, run_mean, run_var, y, add=None, relu=False):
-    """nn.BatchNorm2d in training mode over NHWC rows z (M, C) -> y (+ add, ReLU); running statistics updated in place (may be None)"""
+def nhwc_bn_train_fwd(z, M, C, gamma, beta, eps, momentum, run_mean, run_var, y, add=None, relu=False, saved=None):
+    """nn.BatchNorm2d in training mode over NHWC rows z (M, C) -> y (+ add, ReLU); running statistics updated in place (may be None);
+    saved (2, C) fp32 (optional): the batch mean and rstd, what nhwc_bn_train_bwd needs"""
     lib = _L.load()
     lib.hulc_nhwc_bn_train_workspace.restype = ctypes.c_long
     ws = _ws(lib.hulc_nhwc_bn_train_workspace(_l(M), _i(C)), z.device)
-    _call("hulc_nhwc_bn_train_fwd", z, _i(_dt(z)), _l(M), _i(C), gamma, beta, _f(eps), _f(momentum), run_mean, run_var, add,
-          _i(_dt(add) if add is not None else F32), _i(int(relu)), y, _i(_dt(y)), ws)
+    _call("hulc_nhwc_bn_train_fwd_saved", z, _i(_dt(z)), _l(M), _i(C), gamma, beta, _f(eps), _f(momentum), run_mean, run_var, add,
+          _i(_dt(add) if add is not None else F32), _i(int(relu)), y, _i(_dt(y)), saved, ws)
+    return y
+
+
+def nhwc_bn_train_bwd(dy, y, z, M, C, gamma, saved, dz, g_out=None, dgamma=None, dbeta=None, accumulate_params=False):
+    """backward of nhwc_bn_train_fwd (+ its ReLU when y is given): dz (and g_out = the masked incoming gradient, the shortcut branch's share)
+    from dy, the saved fp32 convolution output z and the forward's (mean, rstd); dgamma / dbeta optional (hulc_nhwc_bn_train_bwd)"""
+    if z.dtype != torch.float32 or saved.dtype != torch.float32:
+        raise TypeError("nhwc_bn_train_bwd: z and saved are fp32")
+    if g_out is not None and g_out.dtype != dz.dtype:
+        raise TypeError("nhwc_bn_train_bwd: g_out shares dz's dtype")
+    _require_contiguous(dy=dy, y=y, z=z, dz=dz, g_out=g_out)
+    lib = _L.load()
+    lib.hulc_nhwc_bn_train_workspace.restype = ctypes.c_long
+    ws = _ws(lib.hulc_nhwc_bn_train_workspace(_l(M), _i(C)), z.device)
+    _call("hulc_nhwc_bn_train_bwd", dy, _i(_dt(dy)), y, _i(_dt(y) if y is not None else F32), z, _l(M), _i(C), gamma, saved, dz, g_out, _i(_dt(dz)),
+          dgamma, dbeta, _i(int(accumulate_params)), ws)
+    return dz
+
+
+def maxpool_nhwc_bwd(x, dy, dx, N, H, W, C, k, stride, pad):
+    """dx of maxpool_nhwc: the gradient goes to the first maximum of every window (nn.MaxPool2d's recorded index); x, dy, dx one dtype"""
+    if not (x.dtype == dy.dtype == dx.dtype):
+        raise TypeError("maxpool_nhwc_bwd: x, dy, dx share a dtype")
+    _require_contiguous(x=x, dy=dy, dx=dx)
+    _call("hulc_maxpool_nhwc_bwd", x, dy, _i(_dt(x)), _i(N), _i(H), _i(W), _i(C), _i(k), _i(stride), _i(pad), dx)
+    return dx
+
+
+def nhwc_scatter(x, y, step: int, off: int):
+    """y (N, Hy, Wy, C) = x (N, H, W, C) placed at (off + step * row, off + step * col), zeros elsewhere (zero insertion / zero padding)"""
+    if x.dtype != y.dtype or x.dim() != 4 or y.dim() != 4 or x.shape[0] != y.shape[0] or x.shape[3] != y.shape[3]:
+        raise TypeError("nhwc_scatter: x (N, H, W, C) and y (N, Hy, Wy, C) of one dtype")
+    _require_contiguous(x=x, y=y)
+    n, h, w, c = x.shape
+    _call("hulc_nhwc_scatter", x, _i(_dt(x)), _i(n), _i(h), _i(w), _i(c), _i(y.shape[1]), _i(y.shape[2]), _i(step), _i(off), y)
     return y
 
 

@@ -304,6 +304,14 @@ class _TrunkOnly(VisionR3M):
 _trunks = {}
 
 
+def _trunk_of(r3m: "R3M") -> "_TrunkOnly":
+    """the (cached) folded-trunk wrapper of an R3M module"""
+    t = _trunks.get(id(r3m))
+    if t is None or t.r3m is not r3m:
+        t = _trunks[id(r3m)] = _TrunkOnly(r3m)
+    return t
+
+
 def trunk_feature_maps(r3m: "R3M", img: torch.Tensor, batch_stats: bool = False):
     """the affordance encoder (hulc2/affordance/models/visual_lang_encoders/r3m_rn18.py:27-32,71-76 uses the ResNet's children directly: no
     / 255, no ImageNet normalisation inside — the dataset transforms did that): img (N, 3, H, W) fp32 -> [stem, layer1, layer2, layer3, layer4]

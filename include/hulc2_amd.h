@@ -279,6 +279,25 @@ int hulc_maxpool_nhwc(const void* x, int dtype, int N, int H, int W, int C, int 
 long hulc_nhwc_bn_train_workspace(long M, int C);
 int hulc_nhwc_bn_train_fwd(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
                            float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype, void* ws, void* stream);
+/* (ABI 5) The same launch, additionally leaving the batch mean and 1 / sqrt(var + eps) in saved[0..C) / saved[C..2C) for the backward. */
+int hulc_nhwc_bn_train_fwd_saved(const void* z, int z_dtype, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* run_mean, float* run_var, const void* add, int add_dtype, int relu, void* y, int y_dtype, float* saved, void* ws,
+                                 void* stream);
+/* (ABI 5) Backward of nn.BatchNorm2d in training mode (+ the ReLU behind it when y is given) over NHWC rows — the data gradient through the
+ * FROZEN layers of the affordance trunk, which the reference's trainable stem needs (r3m_rn18.py:34-38 freezes layer1..4 only; the modules stay
+ * in train mode, pixel_aff_lang_detector.py:51-53): g = dy * (y > 0), dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) with
+ * xhat = (z - mean) * rstd from the forward's `saved`; g_out (optional) receives g — the gradient of the block's shortcut branch;
+ * dgamma / dbeta (optional; accumulate_params: added to) = sum g * xhat / sum g (the stem's bn1).  z fp32 (the bias-free convolution's output),
+ * dz / g_out in o_dtype; ws = hulc_nhwc_bn_train_workspace(M, C) bytes.  Fixed summation order: bit-reproducible. */
+int hulc_nhwc_bn_train_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, const float* z, long M, int C, const float* gamma,
+                           const float* saved, void* dz, void* g_out, int o_dtype, float* dgamma, float* dbeta, int accumulate_params, void* ws,
+                           void* stream);
+/* (ABI 5) Backward of hulc_maxpool_nhwc: dx[pixel] = sum of dy over the windows whose first maximum (scan order kh, kw, strict >: the index
+ * nn.MaxPool2d records) is that pixel; x, dy, dx share `dtype`; a gather, no atomics. */
+int hulc_maxpool_nhwc_bwd(const void* x, const void* dy, int dtype, int N, int H, int W, int C, int k, int stride, int pad, void* dx, void* stream);
+/* (ABI 5) y [N][Hy][Wy][C] = x [N][H][W][C] placed at (off + step * row, off + step * col), zeros elsewhere: step 2 = the zero-inserted gradient
+ * of a stride-2 convolution (whose data gradient is then a stride-1 convolution with flipped taps), step 1 = zero padding by `off`. */
+int hulc_nhwc_scatter(const void* x, int dtype, int N, int H, int W, int C, int Hy, int Wy, int step, int off, void* y, void* stream);
 /* The stem (7x7, stride 2, padding 3, 3 -> Cout) on a packed input, bf16: hulc_r3m_normalize_packed writes xp [N][H+6][Wp][4] with
  * Wp = hulc_r3m_packed_width(W), pixel (y, x) at [y+3][x+3] = normalised (R, G, B, 0), zero border; hulc_r3m_stem_fwd computes
  * y NHWC [N][OH][OW][Cout] = [relu](conv + bias) from it with w [Cout][7][8][4] bf16 = the (BatchNorm-folded) stem weight as [o][kh][kw][c],

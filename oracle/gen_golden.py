@@ -657,18 +657,24 @@ def gen_r3m_trunk_trainmode():
     net.train()
     B, HW = 4, 64
     img = randn(SEED, "x.trunk.train", B, 3, HW, HW)
-    with torch.no_grad():
-        t = nn.functional.max_pool2d(torch.relu(net.bn1(net.conv1(img))), 3, 2, 1)
-        maps = [t]
-        for li in range(1, 5):
-            t = getattr(net, f"layer{li}")(t)
-            maps.append(t)
+    # (round 5) the same forward with autograd on: the gradients of the stem's three tensors — the ones r3m_rn18.py:34-38 leaves trainable —
+    # for seeded upstream gradients G_k of the five maps (what the decoder's skip connections and the depth head hand back), through every
+    # frozen layer's train-mode BatchNorm, the stride-2 convolutions and the max pool
+    t = nn.functional.max_pool2d(torch.relu(net.bn1(net.conv1(img))), 3, 2, 1)
+    maps = [t]
+    for li in range(1, 5):
+        t = getattr(net, f"layer{li}")(t)
+        maps.append(t)
+    ups = [randn(SEED, f"g.trunk.map{i}", *m.shape) * (0.5 ** i) for i, m in enumerate(maps)]
+    sum((m * u).sum() for m, u in zip(maps, ups)).backward()
+    stem_grads = {"d_conv1_weight": net.conv1.weight.grad.clone(), "d_bn1_weight": net.bn1.weight.grad.clone(), "d_bn1_bias": net.bn1.bias.grad.clone()}
+    maps = [m.detach() for m in maps]
     after = net.state_dict()
     names = sorted(k for k in after if k.endswith("running_mean") or k.endswith("running_var"))
     save("r3m_trunk_trainmode", seed=SEED, B=B, HW=HW, **{f"map{i}": m for i, m in enumerate(maps)},
          stat_names=np.array(names), stat_sums=np.array([float(after[k].double().sum()) for k in names]),
          bn1_running_mean=after["bn1.running_mean"], layer4_1_bn2_running_var=after["layer4.1.bn2.running_var"],
-         tracked=int(after["bn1.num_batches_tracked"]))
+         tracked=int(after["bn1.num_batches_tracked"]), **stem_grads)
 
 
 def transformers_version():

@@ -314,4 +314,7 @@ def test_torch_ddp_with_parked_comm_hook_keeps_the_cooperative_kernels():
     # buckets — nothing to park there)
     for log in res["logs"][2:]:
         assert log.count("release") == 1 and log.count("park") >= 2 and "send" not in log[:log.index("release")], log
-        assert log.count("send") > log.count("park"), log      # the encoders' bucket: sent after the release without parking
+        # (round 4's loop: the encoders' bucket becomes ready after the release and is sent without parking — send > park; with the step node
+        #  (round 5) every gradient of the pass reaches the reducer at once, behind the whole captured backward: all buckets are parked and
+        #  released at the last one — send == park)
+        assert log.count("send") >= log.count("park"), log

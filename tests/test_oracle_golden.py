@@ -525,6 +525,19 @@ def test_r3m_trunk_train_mode_oracle_matches_nn_layers():
     assert torch.allclose(sd["r3m.convnet.bn1.running_mean"], torch.as_tensor(g["bn1_running_mean"]), atol=1e-6)
     assert torch.allclose(sd["r3m.convnet.layer4.1.bn2.running_var"], torch.as_tensor(g["layer4_1_bn2_running_var"]), rtol=1e-5, atol=1e-7)
     assert int(sd["r3m.convnet.bn1.num_batches_tracked"]) == int(g["tracked"]) == 1
+    # (round 5) the trainable stem: the oracle's gradients of conv1.weight / bn1.weight / bn1.bias — autograd through its own functional ops —
+    # against the ones torch's nn layers produced for the same seeded upstream gradients of the five maps
+    sd3 = {k: torch.empty_like(v) for k, v in sd.items()}
+    syn.fill_state_dict_(sd3, seed)
+    stem = ["r3m.convnet.conv1.weight", "r3m.convnet.bn1.weight", "r3m.convnet.bn1.bias"]
+    for k in stem:
+        sd3[k].requires_grad_(True)
+    m3 = A.trunk_maps(sd3, img, bn_train=True)
+    ups = [torch.randn(m.shape, generator=syn._gen(seed, f"g.trunk.map{i}")) * (0.5 ** i) for i, m in enumerate(m3)]
+    sum((m * u).sum() for m, u in zip(m3, ups)).backward()
+    for k, name in zip(stem, ("d_conv1_weight", "d_bn1_weight", "d_bn1_bias")):
+        want = torch.as_tensor(g[name])
+        assert (sd3[k].grad - want).norm().item() <= 1e-4 * want.norm().item(), name
     # and train mode is NOT the frozen inference-mode trunk the default build runs: the maps differ by O(1)
     sd2 = {k: torch.empty_like(v) for k, v in sd.items()}
     syn.fill_state_dict_(sd2, seed)

@@ -171,7 +171,7 @@ def test_accumulation_validation_and_layout_changes_leave_the_graphs(dev):
     assert node.replays == 2
     for n, p in m.named_parameters():
         if n in g1:
-            assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-5, atol=1e-12), n
+            assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-4, atol=1e-12), n      # (one bias gradient comes from another kernel on the plain path: 2e-7)
     # another layout
     small = syn.make_batch(7, 2, 4, device=dev)
     for i in range(3):
@@ -202,23 +202,40 @@ def test_accumulation_validation_and_layout_changes_leave_the_graphs(dev):
 
 def test_drop_in_adam_reads_the_gradient_arena_and_takes_the_scaler_on_device(dev):
     """hulc2_amd.optim.Adam behind the node: gradients are the arena views (no copy), GradScaler hands its scale / found_inf over as device
-    scalars (`_step_supports_amp_scaling`: no found_inf.item() in the loop) — same parameters as torch.optim.Adam in the same loop to fp32
-    rounding of the two evaluation orders; a step with an inf gradient is skipped on the device and does not count."""
+    scalars (`_step_supports_amp_scaling`: no found_inf.item() in the loop).  Fed the SAME (scaled) gradients, torch.optim.Adam on clones —
+    stepped with the gradients unscaled by hand — lands on the same parameters to fp32 rounding of two evaluation orders; a step with an inf
+    gradient is skipped on the device and does not count."""
     from hulc2_amd.optim import Adam
+    lr = 2e-4
     with _env(HULC_NO_STEP_NODE=None, HULC_NO_STEP_GRAPH=None):
-        _, l_t, _, p_t, _ = _amp_loop(dev, 5)
-        m, l_h, _, p_h, opt = _amp_loop(dev, 5, opt_cls=Adam)
-    assert opt.fused_launches == 5
+        kn.reset_step_state(dev)
+        m = _model(dev, 31)
+        batch = _batch(dev, 31)
+        params = [p for p in m.parameters() if p.requires_grad]
+        opt = Adam(params, lr=lr)
+        clones = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        ref = torch.optim.Adam(clones, lr=lr)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+        for i in range(5):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = m.training_step(batch, i)
+            scaler.scale(loss).backward()
+            for c, p in zip(clones, params):
+                c.grad = None if p.grad is None else p.grad.detach() / 65536.0
+            scaler.step(opt)                                       # no unscale_ before it: the kernel divides by the scale itself
+            scaler.update()
+            ref.step()
+        torch.cuda.synchronize()
+        kn.check_faults(dev)
+    assert opt.fused_launches == 5 and scaler.get_scale() == 65536.0
     tr = m.__dict__["_hulc_shadow_keeper"]
+    assert m.__dict__["_hulc_step_node"].replays == 3
     assert opt._arena[1].data_ptr() == tr.flat_g.data_ptr(), "the optimizer reads the keeper's gradient arena in place"
-    for a, b in zip(l_t, l_h):                                      # (two trajectories: fp32 rounding of two evaluation orders, then bf16 operands)
-        assert abs(a - b) <= 2e-3 * abs(a), (l_t, l_h)
-    for n in p_t:
-        assert float((p_t[n] - p_h[n]).abs().max()) <= 1.5 * 2e-4, n
+    for (n, p), c in zip([(n, p) for n, p in m.named_parameters() if p.requires_grad], clones):
+        assert float((p - c).abs().max()) <= 2e-6 * max(float(c.abs().max()), 1.0) + 1e-3 * lr, n
     assert float(opt.state_dict()["state"][0]["step"]) == 5.0
     # an inf in one gradient: the scaler's found_inf reaches the kernel, nothing moves, the step count stays, the scale halves
-    batch = _batch(dev, 31)
-    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
     opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.float16):
