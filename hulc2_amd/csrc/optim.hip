@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const uint16_t* __
 HULC_DEVICE void repack_conv_job(const float* __restrict__ src, uint16_t* __restrict__ dst, const long* __restrict__ table, int entry, int sub, int nsub) {
     const long* q = table + (long)entry * 7;
     const long so = q[0], d0 = q[1];
-    const int Cout = (int)q[2], Cin = (int)q[3], KH = (int)q[4], KW = (int)q[5], mode = (int)q[6];
+    const int Cout = (int)q[2], Cin = (int)q[3], KH = (int)q[4], KW = (int)q[5], mode = (int)q[6] & 7;
+    const bool lo = ((int)q[6] & 8) != 0;                  // (round 5) + 8: the ROUNDING REMAINDER bf16(w - float(bf16(w))) in the same layout
     const int n = Cout * Cin * KH * KW, taps = KH * KW;
     for (int i = sub * blockDim.x + threadIdx.x; i < n; i += nsub * blockDim.x) {
         int o, c, t;                                      // destination index i -> (o, c, tap)
@@ -215,7 +216,9 @@ HULC_DEVICE void repack_conv_job(const float* __restrict__ src, uint16_t* __rest
         else if (mode == 1) { o = i / (taps * Cin); t = (i / Cin) % taps; c = i % Cin; }
         else if (mode == 2) { c = i / (taps * Cout); t = (i / Cout) % taps; o = i % Cout; }
         else { t = i / (Cin * Cout); c = (i / Cout) % Cin; o = i % Cout; }     // mode 3: [tap][c][o], the transposed flatten-linear operand
-        dst[d0 + i] = f32_to_bf16_bits(src[so + ((long)o * Cin + c) * taps + t]);
+        const float w = src[so + ((long)o * Cin + c) * taps + t];
+        const uint16_t hi = f32_to_bf16_bits(w);
+        dst[d0 + i] = lo ? f32_to_bf16_bits(w - bf16_bits_to_f32(hi)) : hi;
     }
 }
 

@@ -234,6 +234,20 @@ class FlattenLinearFn(torch.autograd.Function):
         K = a[0].numel()
         O = W.shape[0]
         ctx.a_dtype = a.dtype
+        chw = (a.shape[3], a.shape[1], a.shape[2])
+        if kn.exact_site_in_bf16_step() and a.dtype == torch.bfloat16 and not os.environ.get("HULC_FLATLIN_FP32"):
+            # the exact-forward site "encfc" behind a bf16 conv stack (round 5): the activation IS bf16 (nothing to split), so the fp32-class
+            # product is two bf16 MFMA GEMMs, a w_hi + a w_lo, on the trainer's layout shadows — instead of a cast copy of the activation, a
+            # per-step fp32 relayout of the weight and an fp32-MFMA GEMM (38 + 9 + 5 us per step)
+            x2 = _c(a).reshape(N, K)
+            out = _f32(N, O, like=x2)
+            with kn.compute_scope("bf16", fwd_only=True):
+                part = _f32(N, O, like=x2)
+                kn.gemm(x2, weight_operand(W, "hwc_lo", chw=chw), part, N, O, K, K, K, O)
+                kn.gemm(x2, weight_operand(W, "hwc", chw=chw), out, N, O, K, K, K, O, bias=b, add=part, ld_add=O, relu=True)
+            ctx.save_for_backward(x2, out, W, b)
+            ctx.ashape = a.shape
+            return out
         if kn.get_compute() != "bf16" and a.dtype == torch.bfloat16:
             # an exact-fp32 site behind a bf16 conv stack (HULC_FP32_SITES "encfc"): the fp32 GEMM takes fp32 operands
             a32 = torch.empty(a.shape, dtype=torch.float32, device=a.device)
@@ -241,7 +255,7 @@ class FlattenLinearFn(torch.autograd.Function):
             a = a32
         x2 = _c(a).reshape(N, K)
         out = _f32(N, O, like=x2)
-        kn.gemm(x2, weight_operand(W, "hwc", chw=(a.shape[3], a.shape[1], a.shape[2])), out, N, O, K, K, K, O, bias=b, relu=True)
+        kn.gemm(x2, weight_operand(W, "hwc", chw=chw), out, N, O, K, K, K, O, bias=b, relu=True)
         ctx.save_for_backward(x2, out, W, b)
         ctx.ashape = a.shape
         return out

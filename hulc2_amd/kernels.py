@@ -813,6 +813,13 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
         return True
     q = _wg_pending.setdefault(dev, [])
     q.append((A, B, C, rowsum, int(M), int(N), int(K), int(lda), int(ldb), int(ldc), bool(accumulate), bool(rowsum_accumulate), int(col_perm), int(col_mul), int(store_rows), int(conv_taps_wp)))
+    # the stream the operands were produced on (a backward node runs on the stream of its forward: the gripper camera's encoder lives on a side
+    # stream).  The grouped launch is issued on whatever stream is current at the end of the pass and must wait for every producer stream:
+    # autograd's own end-of-pass join only covers streams on which a LEAF received a defined gradient — with gradient sinks the Functions return
+    # None, and under the step node the parameters' AccumulateGrad nodes belong to the caller's stream (round 5: found as zero / NaN weight
+    # gradients of the gripper encoder's head when the grouped launch overtook the side stream)
+    with torch.cuda.device(dev):
+        _wg_streams.setdefault(dev, set()).add(_stream())
     if not defer:
         wgrad_flush(dev)
     elif dev not in _wg_armed:
@@ -827,6 +834,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
 def wgrad_reset(device) -> None:
     """drop products left behind by a backward pass that raised (start of a trainer step)"""
     _wg_pending.pop(device, None)
+    _wg_streams.pop(device, None)
     _wg_armed.discard(device)
     ent = _wg_side.get(device)
     if ent is not None and len(ent) > 2:
@@ -868,11 +876,33 @@ def wgrad_flush(device=None) -> None:
         _wgrad_issue(dev)
 
 
+_wg_streams = {}        # device -> raw handles of the streams that produced operands of the pending products
+
+
+def join_stream(dev, other) -> None:
+    """the current stream waits for everything `other` holds.  Inside a hipGraph capture only a stream that is part of the capture may be
+    joined (an event of an un-captured stream would cross the capture boundary); one that is not has no captured work to wait for."""
+    cur = torch.cuda.current_stream(dev)
+    if torch.cuda.is_current_stream_capturing():
+        with torch.cuda.stream(other):
+            inside = torch.cuda.is_current_stream_capturing()
+        if not inside:
+            return
+    cur.wait_stream(other)
+
+
 def _wgrad_issue(dev) -> None:
     if True:
         q = _wg_pending.pop(dev, None)
+        producers = _wg_streams.pop(dev, None)
         if not q:
             return
+        if producers:
+            with torch.cuda.device(dev):
+                here = _stream()
+                for h in producers:
+                    if h != here and h != 0:
+                        join_stream(dev, torch.cuda.ExternalStream(h, device=dev))
         n = len(q)
         items = (_L.WgradItem * n)()
         flops = nbytes = 0.0

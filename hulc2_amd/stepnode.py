@@ -125,6 +125,13 @@ class StepNode:
         with gradsink.active(tr):
             res = torch.autograd.grad(inner, tr.params if leaves is None else leaves, grad_outputs=g.reshape(inner.shape), allow_unused=True)
             kn.wgrad_flush(self.dev)                          # (autograd's end-of-pass callback already issued it: no-op unless the pass was cut short)
+        # the gripper camera's encoder runs forward AND backward on a side stream (concat_encoders.forward_multi); its weight-gradient kernels
+        # write the gradient arena from there.  autograd's end-of-pass join covers only streams on which a leaf received a gradient — here the
+        # leaves' AccumulateGrad nodes belong to the caller's stream and the Functions return None — so the join is made explicitly
+        from .models.perceptual_encoders.concat_encoders import _side_streams
+        side = _side_streams.get(self.dev)
+        if side is not None:
+            kn.join_stream(self.dev, side)
         tr._settle_sinks()
         outs = []
         for i, (p, v, r) in enumerate(zip(tr.params, self.views, res)):

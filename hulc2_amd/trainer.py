@@ -553,7 +553,9 @@ class ArenaTrainer:
                 chw = flat_lin.get(id(p))
                 if p.dim() == 2 and chw is not None:          # Linear behind nn.Flatten of a (C, H, W) map (gripper encoder): NHWC column order
                     co, (ci, kh, kw) = p.shape[0], chw
-                    modes = [("hwc", 1, (co, kh * kw * ci)), ("hwc_t", 3, (kh * kw * ci, co))]
+                    # (+ the rounding remainder in the forward layout: the exact-forward site of the flatten-linear is TWO bf16 products on
+                    #  the bf16 activation — a w_hi + a w_lo — instead of an fp32 GEMM on a cast copy; round 5)
+                    modes = [("hwc", 1, (co, kh * kw * ci)), ("hwc_t", 3, (kh * kw * ci, co)), ("hwc_lo", 1 | 8, (co, kh * kw * ci))]
                 elif p.dim() != 4:
                     continue
                 else:

@@ -647,7 +647,9 @@ int hulc_gather_chunks(const void* src0, const void* src1, void* dst, const unsi
 int hulc_residual_bf16(const float* p32, const void* hi, void* lo, const long* segments, int nseg, void* stream);
 /* All conv-weight repacks of a step in one launch: table[q] = {src offset (fp32 arena elements), dst offset (bf16 elements), Cout, Cin,
  * KH, KW, mode}; mode 0 = OIHW flat (conv1 forward), 1 = OHWI (NHWC forward, k = (kh,kw,c)), 2 = IHWO (data gradient,
- * rows = input channel, k = (kh,kw,cout)).  Replaces a permute copy + cast per layer and layout. */
+ * rows = input channel, k = (kh,kw,cout)), 3 = [tap][c][o] (the transposed flatten-linear operand); mode + 8 (ABI 5): the rounding remainder
+ * bf16(w - float(bf16(w))) in the same layout — the second operand of a two-product (fp32-class) forward on bf16 activations.  Replaces a
+ * permute copy + cast per layer and layout. */
 int hulc_repack_conv_weights(const float* src, void* dst, const long* table, int n, void* stream);
 /* (ABI 4) hulc_transpose_bf16_tiles and hulc_repack_conv_weights of a step as ONE launch (independent jobs on disjoint workgroup ranges);
  * either half may be empty (count 0). */

@@ -209,6 +209,7 @@ def test_real_world_training_step_matches_oracle(dev, B, S, cmode, monkeypatch):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         assert p.grad is not None, k
+        assert torch.isfinite(p.grad).all(), f"{k}: {int((~torch.isfinite(p.grad)).sum())} non-finite gradient entries of {p.grad.numel()}"
         errs[k] = ((p.grad.double().cpu() - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
         checked += 1
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
