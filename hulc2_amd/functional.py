@@ -235,10 +235,12 @@ class FlattenLinearFn(torch.autograd.Function):
         O = W.shape[0]
         ctx.a_dtype = a.dtype
         chw = (a.shape[3], a.shape[1], a.shape[2])
-        if kn.exact_site_in_bf16_step() and a.dtype == torch.bfloat16 and not os.environ.get("HULC_FLATLIN_FP32"):
-            # the exact-forward site "encfc" behind a bf16 conv stack (round 5): the activation IS bf16 (nothing to split), so the fp32-class
-            # product is two bf16 MFMA GEMMs, a w_hi + a w_lo, on the trainer's layout shadows — instead of a cast copy of the activation, a
-            # per-step fp32 relayout of the weight and an fp32-MFMA GEMM (38 + 9 + 5 us per step)
+        if kn.exact_site_in_bf16_step() and a.dtype == torch.bfloat16 and os.environ.get("HULC_FLATLIN_X2"):
+            # OPT-IN (HULC_FLATLIN_X2=1; round 5): the exact-forward site "encfc" behind a bf16 conv stack as two bf16 MFMA GEMMs, a w_hi + a w_lo
+            # (the activation IS bf16: nothing to split), on the trainer's layout shadows — instead of a cast copy of the activation, a per-step
+            # fp32 relayout of the weight and an fp32-MFMA GEMM (38 + 9 + 5 us per step).  Off by default: the 2^-17 weight remainder it drops
+            # moved one recorded gradient error of the B = 2 parity case past its 1.5 x ratchet (tests/golden/error_budget.json), and the
+            # recorded errors are not re-recorded for a 0.8 % step-time gain
             x2 = _c(a).reshape(N, K)
             out = _f32(N, O, like=x2)
             with kn.compute_scope("bf16", fwd_only=True):
