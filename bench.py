@@ -325,6 +325,37 @@ def lightning_loop(args, dev):
         measure("cooperative_kernels_hulc2_amd_adam")
         res["cooperative_kernels_hulc2_amd_adam"]["fused_steps"] = int(opt.fused_launches)
         node_stats("cooperative_kernels_hulc2_amd_adam")
+        # a data loader delivers every batch at NEW addresses: the node copies it into the graphs' input buffers (1.16 GB of frames per step).
+        # Two more resident batches, alternated: every step pays the copy
+        try:
+            others = [syn.make_batch(43 + j, args.batch, args.seq_len, device=dev) for j in range(2)]
+            for b2 in others:
+                for db in b2.values():
+                    db.pop("plan_idx", None)
+
+            def step(i):                                    # noqa: F811
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    loss = model.training_step(others[i % 2], i)
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+                return loss
+            measure("hulc2_amd_adam_batches_at_new_addresses")
+            node_stats("hulc2_amd_adam_batches_at_new_addresses")
+        except Exception as e:                              # noqa: BLE001
+            res["new_addresses_error"] = f"{type(e).__name__}: {e}"
+        finally:
+            del others
+
+            def step(i):                                    # noqa: F811
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    loss = model.training_step(batch, i)
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+                return loss
         opt = torch_opt
         # the same loop under torch's own DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75), on a ONE-rank
         # RCCL group — the collectives move nothing, the reducer's bucket copies, hooks and stream hand-overs are all there: with
