@@ -27,6 +27,7 @@ struct C1P {
     int dbg;
     int u8, pad; const int* shift; const int* fidx;   // uint8 NHWC source with the shift / scale / normalise transforms applied while staging
     const void* X2; int nsplit;                  // fp32 frames: frames n >= nsplit come from X2 (pre-offset by -nsplit frames); X2 == X when unused
+    const void* const* xs; const void* const* xs2;   // optional device slots holding the frame tensors' addresses (fp32 frames; xs2 un-offset): read at kernel start
 };
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes) — compile-time, so that the two load paths never join in front of the MFMA loop
@@ -40,6 +41,21 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
     const int r = lane & 31, h = lane >> 5;
     const int bands = (p.OH + p.R - 1) / p.R;
     const float inv_OW = fast_rcp(p.OW);
+    // (round 5, ABI 5: hulc_conv_desc.x_slot / x2_slot) the frame tensors' base addresses read from DEVICE slots at kernel start: a captured
+    // hipGraph then follows whatever batch the caller points the slots at — the step node updates two pointers instead of copying 1.16 GB of
+    // frames into the graph's input buffers.  One scalar-valued load per slot, once per workgroup, in front of the first band's loads.
+    const float* xbase = (const float*)p.X;
+    const float* xbase2 = (const float*)p.X2;
+    if (!U8 && p.xs) {
+        const unsigned long long a = (unsigned long long)*p.xs;
+        xbase = (const float*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+        xbase2 = xbase;
+        if (p.xs2) {
+            const unsigned long long b = (unsigned long long)*p.xs2;
+            xbase2 = (const float*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b))
+                     - (long)p.nsplit * 3 * p.H * p.W;
+        }
+    }
     // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
     // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
     // sweep order (HULC_CONV1_SWEEP=1, experiment): unit u of the launch = (frame u / bands, band u % bands), workgroup w takes w, w + grid, ...
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             const int c = j / (XF / C), id = tid + (j % (XF / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
-            const float* xb = (const float*)(n < p.nsplit ? p.X : p.X2);       // (n is uniform: a scalar select)
+            const float* xb = n < p.nsplit ? xbase : xbase2;                   // (n is uniform: a scalar select)
             xraw[U8 ? 0 : j][0] = *(const f32x4_t*)(xb + off);
             xraw[U8 ? 0 : j][1] = *(const f32x4_t*)(xb + (inb2 ? off + 4 : off));
         }
@@ -319,7 +335,7 @@ int launch_conv1(C1P& p, hipStream_t s) {
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
                              int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, const void* w_lo,
-                             const void* x2, int n_split, hipStream_t s) {
+                             const void* x2, int n_split, const void* x_slot, const void* x2_slot, hipStream_t s) {
     if (getenv("HULC_NO_BAND_CONV1") && !u8) return 1;
     if (w_dtype != HULC_BF16 || ((uintptr_t)w % 16) || ldw % 8) return u8 ? hulc_fail(-6, "conv1 band: bf16 weights, 16-byte aligned rows") : 1;
     if (W % 4 || ((uintptr_t)x % (u8 ? 4 : 16)) || (bias && ((uintptr_t)bias % 16)) || (H - 8) % 4 || (W - 8) % 4) return 1;
@@ -330,6 +346,9 @@ int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ld
     { static const char* e = getenv("HULC_C1_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.X = x; p.Wt = w; p.bias = bias; p.Y = y; p.w_dtype = w_dtype; p.y_dtype = y_dtype; p.relu = relu;
     p.X2 = x; p.nsplit = N;
+    p.xs = (const void* const*)x_slot; p.xs2 = (const void* const*)x2_slot;
+    if ((x_slot || x2_slot) && (u8 || !x_slot || (x2_slot && !x2) || ((uintptr_t)x_slot | (uintptr_t)x2_slot) % 8))
+        return hulc_fail(-6, "conv1 band: frame slots are for fp32 frames (x_slot with every launch, x2_slot next to x2), 8-byte aligned");
     if (x2) {
         if (n_split < 0 || n_split > N || ((uintptr_t)x2 % (u8 ? 4 : 16)) || (u8 && fidx))
             return hulc_fail(-6, "conv1 band: x2 needs 0 <= n_split <= N, 16-byte (uint8 frames: 4-byte) alignment and no frame_index");

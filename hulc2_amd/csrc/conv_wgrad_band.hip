@@ -418,6 +418,7 @@ struct W1P {
     int u8, pad; const int* shift; const int* fidx;
     int dbg;
     const void* X2; int nsplit;             // fp32 frames: frames n >= nsplit come from X2 (pre-offset by -nsplit frames); X2 == X when unused
+    const void* const* xs; const void* const* xs2;   // optional device slots holding the frame tensors' addresses (see conv1_band.hip)
 };
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes); dY is bf16 (other gradients dtypes take the generic kernel).  Both are compile-time so
@@ -430,6 +431,21 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
     const int r = lane & 31, h = lane >> 5;
     const int bands = (p.OH + p.R - 1) / p.R;
     const float inv_OW = fast_rcp(p.OW), inv_W = fast_rcp(p.W);
+    // (round 5, ABI 5: hulc_conv_desc.x_slot / x2_slot) the frame tensors' base addresses read from DEVICE slots at kernel start: a captured
+    // hipGraph then follows whatever batch the caller points the slots at — the step node updates two pointers instead of copying 1.16 GB of
+    // frames into the graph's input buffers.  One scalar-valued load per slot, once per workgroup, in front of the first band's loads.
+    const float* xbase = (const float*)p.X;
+    const float* xbase2 = (const float*)p.X2;
+    if (!U8 && p.xs) {
+        const unsigned long long a = (unsigned long long)*p.xs;
+        xbase = (const float*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+        xbase2 = xbase;
+        if (p.xs2) {
+            const unsigned long long b = (unsigned long long)*p.xs2;
+            xbase2 = (const float*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b))
+                     - (long)p.nsplit * 3 * p.H * p.W;
+        }
+    }
     // a workgroup walks whole frames (blockIdx, blockIdx + grid, ...), band after band: the 4 halo rows a band shares with its
     // predecessor were read by this CU a moment ago and come back from L2, so small bands (few staging registers) cost no HBM traffic
     const int nunits = ((p.Nimg - blockIdx.x + gridDim.x - 1) / gridDim.x) * bands;     // this workgroup's units
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
-            const float* xb = (const float*)(n < p.nsplit ? p.X : p.X2);       // (n is uniform: a scalar select)
+            const float* xb = n < p.nsplit ? xbase : xbase2;                   // (n is uniform: a scalar select)
             xraw[j][0] = *(const float4*)(xb + off);
             xraw[j][1] = *(const float4*)(xb + (inb2 ? off + 4 : off));
         }
@@ -774,7 +790,7 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
 // 0 = launched, 1 = geometry not covered (caller uses the gather kernel), < 0 = error.  dw is [Cout][K] fp32 in the forward k order.
 int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, int S, const void* x, int x_dtype, const void* dy, int dy_dtype,
                                   int N, int H, int W, float* dw, float* db, void* ws, long ws_bytes, int dw_oihw, int accumulate, int u8, int pad,
-                                  const int* shift, const int* fidx, const void* x2, int n_split, hipStream_t s) {
+                                  const int* shift, const int* fidx, const void* x2, int n_split, const void* x_slot, const void* x2_slot, hipStream_t s) {
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
@@ -794,6 +810,8 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     else if (nchw && Cin == 3 && Cout == 32 && KH == 8 && KW == 8 && S == 4 && (x_dtype == HULC_F32 || (u8 && W % 4 == 0 && (uintptr_t)x % 4 == 0))) {
         if (x2 && (dy_dtype != HULC_BF16 || n_split < 0 || n_split > N || ((uintptr_t)x2 % (u8 ? 4 : 16)) || (u8 && fidx) || getenv("HULC_CONV1_WGRAD_OLD")))
             return hulc_fail(-6, "conv1 weight gradient: x2 needs a bf16 gradient map, 0 <= n_split <= N, 16-byte (uint8 frames: 4-byte) alignment, no frame_index");
+        if ((x_slot || x2_slot) && (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16))
+            return hulc_fail(-6, "conv1 weight gradient: frame slots need the phase-plane kernel (bf16 gradient map)");
         if (getenv("HULC_CONV1_WGRAD_OLD") || dy_dtype != HULC_BF16) rc = launch_wband<3, 1, 8, 8, 4, true, 6, 4, 2>(p, dw, db, ws, ws_bytes, dw_oihw, accumulate, s);
         else {
             W1P q;
@@ -801,6 +819,9 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
             q.dy_sn = p.dy_sn; q.dy_sy = p.dy_sy; q.dy_sx = p.dy_sx;
             q.u8 = u8; q.pad = pad; q.shift = shift; q.fidx = fidx;
             q.X2 = x; q.nsplit = N;
+            q.xs = (const void* const*)x_slot; q.xs2 = (const void* const*)x2_slot;
+            if ((x_slot || x2_slot) && (u8 || !x_slot || (x2_slot && !x2) || ((uintptr_t)x_slot | (uintptr_t)x2_slot) % 8))
+                return hulc_fail(-6, "conv1 weight gradient: frame slots are for fp32 frames (x_slot with every launch, x2_slot next to x2), 8-byte aligned");
             if (x2) {
                 q.X2 = u8 ? (const float*)((const unsigned char*)x2 - (long)n_split * 3 * H * W) : (const float*)x2 - (long)n_split * 3 * H * W;
                 q.nsplit = n_split;
@@ -809,7 +830,7 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
             rc = launch_conv1_wgrad(q, dw, db, ws, ws_bytes, accumulate, s);
         }
     }
-    else return x2 ? hulc_fail(-6, "conv weight gradient: x2 is for conv1 only") : 1;
+    else return (x2 || x_slot) ? hulc_fail(-6, "conv weight gradient: x2 / frame slots are for conv1 only") : 1;
     if (rc == -1) return 1;
     if (rc < 0) return hulc_fail(-8, "conv wgrad band: could not raise the dynamic LDS limit");
     return 0;

@@ -370,6 +370,36 @@ def _second_frames(d, x, x2, N, Cin, H, W):
     d.x2, d.n_split = x2.data_ptr(), int(x.shape[0])
 
 
+# hulc_conv_desc.x_slot / x2_slot (ABI 5): while the step node captures its graphs, {address of a graph-input frame tensor: device address of the
+# slot that holds its current pointer}.  The conv1 band launches of the capture then read the frames through the slots, and a batch at new
+# addresses costs two pointer updates instead of a copy (hulc2_amd/stepnode.py).  None outside a capture: the launches take plain addresses.
+_frame_slots = None
+_frame_slots_used = set()
+_frame_slots_probe = False          # record which frame tensors WOULD be read through slots (the node's warm-up pass), change nothing
+
+
+def _slot_fields(d, x, x2, H, W, Cin, Cout, KH, stride, x_nchw) -> None:
+    if not _frame_slots or not x_nchw or x.dtype != torch.float32 or (Cin, Cout, KH, stride) != (3, 32, 8, 4):
+        return
+    if W % 4 or (H - 8) % 4 or (W - 8) % 4 or W < 72 or H < 72 or _compute_mode != BF16:      # (what the band kernels take; smaller frames keep plain addresses)
+        return
+    if _frame_slots_probe:
+        if x.data_ptr() in _frame_slots and (x2 is None or x2.data_ptr() in _frame_slots):
+            _frame_slots_used.add(x.data_ptr())
+            if x2 is not None:
+                _frame_slots_used.add(x2.data_ptr())
+        return
+    a = _frame_slots.get(x.data_ptr())
+    b = _frame_slots.get(x2.data_ptr()) if x2 is not None else None
+    if a is None or (x2 is not None and b is None):
+        return
+    d.x_slot = a
+    _frame_slots_used.add(x.data_ptr())
+    if x2 is not None:
+        d.x2_slot = b
+        _frame_slots_used.add(x2.data_ptr())
+
+
 def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
                frame_index=None, relu_bits=None, w_lo=None, x2=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
@@ -379,6 +409,8 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
     _u8_frames(d, x, aug_shift, aug_pad, frame_index)
     _second_frames(d, x, x2, N, Cin, H, W)
+    if compute is None and frame_index is None:
+        _slot_fields(d, x, x2, H, W, Cin, Cout, KH, stride, x_nchw)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)
     if relu_bits is not None:              # ReLU sign planes of y: int32 (N * OH * OW * Cout / 32,), written next to y (hulc_conv_desc.relu_bits)
         _require_cuda(relu_bits)
@@ -534,6 +566,8 @@ def conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, KH, KW, stride, x_nchw,
     d.dw_oihw, d.dw_accumulate = int(dw_oihw), int(accumulate)
     _u8_frames(d, x, aug_shift, aug_pad, frame_index)
     _second_frames(d, x, x2, N, Cin, H, W)
+    if compute is None and frame_index is None and dy.dtype == torch.bfloat16:
+        _slot_fields(d, x, x2, H, W, Cin, Cout, KH, stride, x_nchw)
     nbytes = lib.hulc_conv2d_bwd_weight_workspace(ctypes.byref(d))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     oh, ow = conv_out_hw(H, W, KH, KW, stride)

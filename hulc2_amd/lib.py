@@ -81,6 +81,7 @@ class ConvDesc(ctypes.Structure):
         ("relu_bits", ctypes.c_void_p),
         ("w_lo", ctypes.c_void_p),
         ("x2", ctypes.c_void_p), ("n_split", ctypes.c_int),
+        ("x_slot", ctypes.c_void_p), ("x2_slot", ctypes.c_void_p),
     ]
 
 

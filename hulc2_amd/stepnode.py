@@ -34,6 +34,17 @@ from . import kernels as kn
 from . import shadow
 
 
+def _rebuild(obj, it):
+    """the same nest of dicts / lists with its tensors taken, in _leaves' order, from the iterator `it`"""
+    if torch.is_tensor(obj):
+        return next(it)
+    if isinstance(obj, dict):
+        return {k: _rebuild(v, it) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_rebuild(v, it) for v in obj)
+    return obj
+
+
 def _leaves(obj, prefix: str, out: list) -> bool:
     """flatten a batch into (path, tensor) pairs in a fixed order; False when it holds anything a graph cannot take as an input"""
     if torch.is_tensor(obj):
@@ -103,6 +114,14 @@ class StepNode:
         self.static_logs = []
         self.disabled: Optional[str] = "HULC_NO_STEP_GRAPH" if os.environ.get("HULC_NO_STEP_GRAPH") else None
         self.replays = self.eager_steps = self.captures = self.input_copies = 0      # (tests / bench read these)
+        # frame slots (hulc_conv_desc.x_slot): the big frame tensors are read by conv1's captured launches through device pointer slots
+        self.slot_idx: List[int] = []          # leaves read through slots
+        self.slots_ok = False                  # ... verified by the self-check of _capture
+        self.slot_table = None                 # int64 [leaves]: the device slots
+        self.slot_ptrs: List[int] = []         # what the slots hold now
+        self.slot_updates = 0
+        self._ring, self._ring_pos = [], 0     # pinned staging buffers of the slot table + the events that guard their reuse
+        self._live_inputs = None               # the caller's current batch tensors: the backward graph reads the frames again
         self._logs = []
 
     def __deepcopy__(self, memo):
@@ -178,13 +197,25 @@ class StepNode:
                     warnings.warn(f"hulc2_amd step node: {self.disabled}; the step stays on the eager node")
             if self.graph_fwd is not None:
                 src, dst = [], []
-                for (_, t), st in zip(leaves, self.static_leaves):
-                    if t.data_ptr() != st.data_ptr():
+                moved = False
+                slot = set(self.slot_idx) if self.slots_ok else ()
+                for i, ((_, t), st) in enumerate(zip(leaves, self.static_leaves)):
+                    if i in slot and t.is_contiguous() and t.data_ptr() % 16 == 0:
+                        if self.slot_ptrs[i] != t.data_ptr():        # a frame tensor at a new address: its slot follows it, nothing is copied
+                            self.slot_ptrs[i] = t.data_ptr()
+                            moved = True
+                    elif t.data_ptr() != st.data_ptr():
                         src.append(t)
                         dst.append(st)
+                        if i in slot and self.slot_ptrs[i] != st.data_ptr():
+                            self.slot_ptrs[i] = st.data_ptr()
+                            moved = True
                 if src:
                     torch._foreach_copy_(dst, src)
                     self.input_copies += 1
+                if moved:
+                    self._write_slots()
+                self._live_inputs = [t for _, t in leaves]
                 self.replays += 1
                 loss = _GraphStepFn.apply(self, *tr.params)
                 return loss, self.static_logs
@@ -198,6 +229,24 @@ class StepNode:
         self.graph_fwd = self.graph_bwd = None
         self.static_loss = None
         self.static_outs, self.static_leaves, self.static_logs = [], [], []
+        self.slot_idx, self.slots_ok, self.slot_table, self.slot_ptrs, self._live_inputs = [], False, None, [], None
+
+    def _write_slots(self) -> None:
+        """slot_ptrs -> the device table, stream-ordered in front of the next replay: through a small ring of pinned buffers (an asynchronous
+        copy from pageable memory would synchronise the stream; a buffer is reused only once its copy has run)"""
+        if not self._ring:
+            self._ring = [(torch.empty(len(self.slot_ptrs), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        buf, ev = self._ring[self._ring_pos % len(self._ring)]
+        if buf.numel() != len(self.slot_ptrs):
+            self._ring = [(torch.empty(len(self.slot_ptrs), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            buf, ev = self._ring[self._ring_pos % len(self._ring)]
+        elif self._ring_pos >= len(self._ring):
+            ev.synchronize()
+        self._ring_pos += 1
+        buf.copy_(torch.tensor(self.slot_ptrs, dtype=torch.int64))
+        self.slot_table.copy_(buf, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.slot_updates += 1
 
     def _param_slots(self):
         """(module, attribute name, index into keeper.params) of every place a module holds one of the keeper's parameters"""
@@ -223,14 +272,30 @@ class StepNode:
         side = torch.cuda.Stream(device=dev)
         words = kn.step_state(dev).clone()
         one = torch.ones((), dtype=torch.float32, device=dev)
+        # frame slots: which of the batch's tensors would conv1's band launches read through device pointer slots?  (recorded by the warm-up)
+        want_slots = kn.base_mode() == "bf16" and not os.environ.get("HULC_NO_FRAME_SLOTS")
+        cand = {t.data_ptr(): i for i, t in enumerate(leaves)
+                if want_slots and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() >= 4 and t.numel() >= (1 << 18)
+                and t.data_ptr() % 16 == 0}
+        kn._frame_slots, kn._frame_slots_probe = (cand or None), True
+        kn._frame_slots_used = set()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            loss, _ = self._inner_forward(batch, batch_idx)
-            self._inner_backward(loss, one)
-            del loss
-            kn.step_state(dev).copy_(words)
+        try:
+            with torch.cuda.stream(side):
+                loss, _ = self._inner_forward(batch, batch_idx)
+                self._inner_backward(loss, one)
+                del loss
+                kn.step_state(dev).copy_(words)
+        finally:
+            kn._frame_slots, kn._frame_slots_probe = None, False
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
+        slot_idx = sorted(cand[p] for p in kn._frame_slots_used if p in cand)
+        # the graphs' input buffers: the caller's own tensors (a resident batch then costs nothing), except the slot-read frame tensors — private
+        # copies, so that the self-check below may poison them and a batch that cannot be read in place (not contiguous) has a place to go
+        statics = [t.clone() if i in set(slot_idx) else t for i, t in enumerate(leaves)]
+        cap_batch = _rebuild(batch, iter(statics)) if slot_idx else batch
+        table = torch.tensor([t.data_ptr() for t in statics], dtype=torch.int64, device=dev) if slot_idx else None
         self.static_g = torch.ones((), dtype=torch.float32, device=dev)
         g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # (a process group's watchdog thread may query events while this thread captures: only this thread's calls are policed then)
@@ -242,17 +307,56 @@ class StepNode:
             for mod, name, i in slots:
                 mod._parameters[name] = aliases[i]
             gradsink.set_aliases(aliases, self.keeper.params)
+            if slot_idx:
+                kn._frame_slots = {statics[i].data_ptr(): table.data_ptr() + 8 * i for i in slot_idx}
+                kn._frame_slots_used = set()
             with torch.cuda.graph(g_f, stream=side, **mode):
-                loss, logs = self._inner_forward(batch, batch_idx)
+                loss, logs = self._inner_forward(cap_batch, batch_idx)
             with torch.cuda.graph(g_b, pool=g_f.pool(), stream=side, **mode):
                 outs = self._inner_backward(loss, self.static_g, leaves=aliases)
         finally:
+            kn._frame_slots = None
             for mod, name, i in slots:
                 mod._parameters[name] = self.keeper.params[i]
             gradsink.clear_aliases()
         self.static_loss, self.static_logs, self.static_outs = loss.detach(), logs, outs
         del loss, aliases
-        self.static_leaves = list(leaves)
+        self.static_leaves = statics
         self.graph_fwd, self.graph_bwd = g_f, g_b
+        self.slot_idx, self.slot_table, self.slot_ptrs = slot_idx, table, [t.data_ptr() for t in statics]
+        self.slots_ok = bool(slot_idx) and self._slots_self_check()
         self.captures += 1
         torch.cuda.synchronize(dev)
+
+    def _slots_self_check(self) -> bool:
+        """Does EVERY captured reader of a slot-driven frame tensor go through its slot?  Replay both graphs twice from the same RNG word — once
+        as captured, once with the slots pointed at fresh copies of the frames and the graphs' own buffers filled with NaN: loss and the
+        checksums of the gradient arena must agree bit for bit.  If they do not (some kernel of the capture read a frame tensor at its baked-in
+        address: another arithmetic mode's forward, a model that hands the frames to more than conv1), the slots stay on the private buffers
+        and every batch is copied into them, as without slots."""
+        dev, tr = self.dev, self.keeper
+        words = kn.step_state(dev).clone()
+
+        def probe():
+            kn.step_state(dev).copy_(words)
+            self.static_g.fill_(1.0)
+            self.graph_fwd.replay()
+            self.graph_bwd.replay()
+            g = tr.flat_g.double()
+            return self.static_loss.clone(), g.sum(), (g * g).sum()
+        ref = probe()
+        alts = {i: self.static_leaves[i].clone() for i in self.slot_idx}
+        self.slot_table.copy_(torch.tensor([alts[i].data_ptr() if i in alts else p for i, p in enumerate(self.slot_ptrs)], dtype=torch.int64))
+        for i in self.slot_idx:
+            self.static_leaves[i].fill_(float("nan"))
+        got = probe()
+        for i in self.slot_idx:
+            self.static_leaves[i].copy_(alts[i])
+        self.slot_table.copy_(torch.tensor(self.slot_ptrs, dtype=torch.int64))
+        kn.step_state(dev).copy_(words)
+        torch.cuda.synchronize(dev)
+        ok = all(bool(torch.equal(a, b)) for a, b in zip(ref, got))
+        if not ok:
+            warnings.warn("hulc2_amd step node: a captured kernel reads a frame tensor at its baked-in address; frame slots are off, "
+                          "batches at new addresses are copied into the graphs' input buffers")
+        return ok

@@ -99,6 +99,14 @@ typedef struct {
      * modality (one prologue, one set of weight-gradient slabs, one reduce).  NULL = all N frames in x. */
     const void* x2;
     int n_split;
+    /* (ABI 5) conv1 on fp32 NCHW frames (LDS-band kernels, forward and weight gradient): DEVICE slots — each an 8-byte aligned device
+     * address holding one device pointer — from which the kernels read the base addresses of the frame tensors when they start, instead of
+     * taking them from x / x2 (which then only say "one tensor" / "two tensors" and are checked for alignment).  A captured hipGraph of a
+     * training step (hulc2_amd/stepnode.py: the reference's trainer loop, hulc2/training.py:79-82, with a data loader that delivers every
+     * batch at new addresses) follows the caller's current batch by updating two pointers instead of copying 1.16 GB of frames into the
+     * graph's input buffers.  x_slot NULL = the addresses in x / x2; x2_slot goes with x2 (its address un-offset). */
+    const void* x_slot;
+    const void* x2_slot;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

@@ -148,9 +148,16 @@ def test_batches_at_new_addresses_are_copied_into_the_graph_inputs(dev):
     with _env(HULC_NO_STEP_NODE=None, HULC_NO_STEP_GRAPH=None):
         m, l_g, _, p_g, _ = _amp_loop(dev, 5, fresh_batches=True)
     node = m.__dict__["_hulc_step_node"]
-    assert node.replays == 3 and node.input_copies >= 2            # (the capturing call's own batch IS the input buffer)
+    assert node.replays == 3 and node.input_copies >= 2            # (the small tensors of a batch are copied into the graphs' input buffers)
+    # ... the frame tensors are not: conv1's captured launches read them through device pointer slots (hulc_conv_desc.x_slot), verified by the
+    # capture's self-check (slots redirected to copies, the graphs' own buffers poisoned: same bits), and every step moved four pointers
+    assert node.slots_ok and len(node.slot_idx) == 4 and node.slot_updates >= 3, (node.slots_ok, node.slot_idx, node.slot_updates)
     assert l_g == l_e
     _same(p_g, p_e, "parameters")
+    with _env(HULC_NO_STEP_NODE=None, HULC_NO_STEP_GRAPH=None, HULC_NO_FRAME_SLOTS="1"):
+        m2, l_c, _, p_c, _ = _amp_loop(dev, 5, fresh_batches=True)
+    assert not m2.__dict__["_hulc_step_node"].slots_ok and l_c == l_e
+    _same(p_c, p_e, "parameters (frames copied)")
 
 
 def test_accumulation_validation_and_layout_changes_leave_the_graphs(dev):
