@@ -175,6 +175,13 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _stream_of(dev) -> int:
+    """the raw handle of `dev`'s current stream (no device-context switch, no Stream object)"""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else _raw_device())
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
 def _require_contiguous(**ts) -> None:
     for name, t in ts.items():
         if t is not None and not t.is_contiguous():
@@ -852,8 +859,7 @@ def wgrad(A, B, C, M, N, K, lda, ldb, ldc, accumulate=False, rowsum=None, rowsum
     # autograd's own end-of-pass join only covers streams on which a LEAF received a defined gradient — with gradient sinks the Functions return
     # None, and under the step node the parameters' AccumulateGrad nodes belong to the caller's stream (round 5: found as zero / NaN weight
     # gradients of the gripper encoder's head when the grouped launch overtook the side stream)
-    with torch.cuda.device(dev):
-        _wg_streams.setdefault(dev, set()).add(_stream())
+    _wg_streams.setdefault(dev, set()).add(_stream_of(dev))
     if not defer:
         wgrad_flush(dev)
     elif dev not in _wg_armed:
@@ -932,11 +938,10 @@ def _wgrad_issue(dev) -> None:
         if not q:
             return
         if producers:
-            with torch.cuda.device(dev):
-                here = _stream()
-                for h in producers:
-                    if h != here and h != 0:
-                        join_stream(dev, torch.cuda.ExternalStream(h, device=dev))
+            here = _stream_of(dev)
+            for h in producers:
+                if h != here and h != 0:
+                    join_stream(dev, torch.cuda.ExternalStream(h, device=dev))
         n = len(q)
         items = (_L.WgradItem * n)()
         flops = nbytes = 0.0
