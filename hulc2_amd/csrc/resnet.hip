@@ -86,29 +86,46 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const void* __restric
 // partial[p][0][c] = sum z, partial[p][1][c] = sum z^2 over the rows of slice p; rows per slice fixed, lanes walk channels (coalesced), the row
 // lanes of a workgroup are summed in a fixed order: bit-reproducible
 __global__ __launch_bounds__(256) void nhwc_bn_stats_kernel(const void* __restrict__ z, int dtype, long M, int C, long rows_per, float* __restrict__ partial) {
-    __shared__ float red[2][256];
-    const int RL = C >= 256 ? 1 : 256 / C;                  // row lanes
-    const int rl = threadIdx.x / (C >= 256 ? 256 : C), c0 = threadIdx.x % (C >= 256 ? 256 : C);
+    // (round 5: 8-channel chunks per thread — 16-byte / 2 x 16-byte loads — instead of one channel with scalar loads; same slices, the row
+    //  lanes of a chunk summed through LDS in lane order: bit-reproducible)
+    __shared__ float red[256][17];
+    const int C8 = C / 8;
+    const int RL = C8 >= 256 ? 1 : 256 / C8;
+    const int rl = threadIdx.x / (C8 >= 256 ? 256 : C8), c80 = threadIdx.x % (C8 >= 256 ? 256 : C8);
     const long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
-    for (int c = c0; c < C; c += 256) {
-        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;        // two independent chains per statistic (one load per trip would be a latency chain)
+    for (int c8 = c80; c8 < C8; c8 += 256) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        auto term = [&](long row) {
+            Chunk8 v;
+            chunk_load_contig(v, z, dtype, row * C + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += v.v[e]; q[e] += v.v[e] * v.v[e]; }
+        };
         long r = r0 + rl;
-        for (; r + RL < r1; r += 2 * RL) {
-            const float a = load_elem(z, dtype, r * C + c), b = load_elem(z, dtype, (r + RL) * C + c);
-            s0 += a; q0 += a * a; s1 += b; q1 += b * b;
-        }
-        if (r < r1) { const float a = load_elem(z, dtype, r * C + c); s0 += a; q0 += a * a; }
-        float s = s0 + s1, q = q0 + q1;
+        for (; r + RL < r1; r += 2 * RL) { term(r); term(r + RL); }
+        if (r < r1) term(r);
         if (RL > 1) {
-            red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][8 + e] = q[e]; }
             __syncthreads();
             if (rl == 0) {
-                s = 0.f; q = 0.f;
-                for (int k = 0; k < RL; ++k) { s += red[0][k * C + c0]; q += red[1][k * C + c0]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+                for (int k = 0; k < RL; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += red[k * C8 + c80][e]; q[e] += red[k * C8 + c80][8 + e]; }
             }
             __syncthreads();
         }
-        if (rl == 0) { partial[((long)blockIdx.x * 2) * C + c] = s; partial[((long)blockIdx.x * 2 + 1) * C + c] = q; }
+        if (rl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                partial[((long)blockIdx.x * 2) * C + c8 * 8 + e] = s[e];
+                partial[((long)blockIdx.x * 2 + 1) * C + c8 * 8 + e] = q[e];
+            }
+        }
     }
 }
 
