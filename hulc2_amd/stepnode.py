@@ -77,21 +77,23 @@ class _GraphStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, node, *params):
         node.graph_fwd.replay()
-        ctx.node = node
+        ctx.cap = (node.graph_bwd, node.static_g, node.static_outs)        # (the node may have switched to another batch layout's graphs by the time of backward)
         return node.static_loss.clone()                   # (the caller may keep the loss beyond the next replay)
 
     @staticmethod
     def backward(ctx, g):
-        node = ctx.node
-        node.static_g.copy_(g.reshape(node.static_g.shape))
-        node.graph_bwd.replay()
-        return (None, *[None if o is None else o.detach() for o in node.static_outs])
+        graph_bwd, static_g, static_outs = ctx.cap
+        static_g.copy_(g.reshape(static_g.shape))
+        graph_bwd.replay()
+        return (None, *[None if o is None else o.detach() for o in static_outs])
 
 
 class StepNode:
     """the step node of one Hulc2 module under its shadows-only keeper (`Hulc2._step_node`)"""
 
     EAGER_STEPS = 2                   # eager-node steps of a configuration before it is captured (the second one runs in sink-overwrite mode)
+    _STATE = ("eager_seen", "graph_fwd", "graph_bwd", "static_loss", "static_g", "static_outs", "static_leaves", "static_logs", "slot_idx", "slots_ok",
+              "slot_table", "slot_ptrs", "_ring", "_ring_pos")          # what belongs to ONE captured batch layout
 
     def __init__(self, model, keeper):
         import weakref
@@ -106,6 +108,7 @@ class StepNode:
                 if off <= o < off + gv.numel():
                     self.group_of[i] = pv
         self.sig = None
+        self._stash = {}                       # signature -> the captured state of a layout that is not the current one (at most one)
         self.eager_seen = 0
         self.graph_fwd = self.graph_bwd = None
         self.static_loss = self.static_g = None
@@ -186,8 +189,18 @@ class StepNode:
         if graphable:
             sig = self._signature(leaves)
             if sig != self.sig:
+                # another batch layout (the last, smaller batch of an epoch; validation-sized batches; another KL weight): its graphs are kept
+                # next to the current ones — the two most recent layouts stay captured
+                if self.sig is not None and self.graph_fwd is not None:
+                    self._stash[self.sig] = {k: getattr(self, k) for k in self._STATE}
+                    while len(self._stash) > 1:
+                        self._stash.pop(next(iter(self._stash)))
+                st = self._stash.pop(sig, None)
                 self._drop_graphs()
                 self.sig, self.eager_seen = sig, 0
+                if st is not None:
+                    for k, v in st.items():
+                        setattr(self, k, v)
             if self.graph_fwd is None and self.eager_seen >= self.EAGER_STEPS:
                 try:
                     self._capture(batch, batch_idx, [t for _, t in leaves])
@@ -230,6 +243,7 @@ class StepNode:
         self.static_loss = None
         self.static_outs, self.static_leaves, self.static_logs = [], [], []
         self.slot_idx, self.slots_ok, self.slot_table, self.slot_ptrs, self._live_inputs = [], False, None, [], None
+        self._ring, self._ring_pos = [], 0
 
     def _write_slots(self) -> None:
         """slot_ptrs -> the device table, stream-ordered in front of the next replay: through a small ring of pinned buffers (an asynchronous

@@ -185,6 +185,13 @@ def test_accumulation_validation_and_layout_changes_leave_the_graphs(dev):
         opt.zero_grad(set_to_none=True)
         m.training_step(small, i).backward()
     assert node.captures == 2 and node.replays == 3
+    # back to the first layout (the last, smaller batch of an epoch, then the next epoch's full batches): its graphs were kept — no new capture
+    opt.zero_grad(set_to_none=True)
+    m.training_step(batch, 7).backward()
+    assert node.captures == 2 and node.replays == 4
+    opt.zero_grad(set_to_none=True)
+    m.training_step(small, 8).backward()
+    assert node.captures == 2 and node.replays == 5
     # no_grad call of a training-mode model: plain path, no gradient
     with torch.no_grad():
         out = m.training_step(small, 0)
