@@ -191,11 +191,11 @@ class StepNode:
             if sig != self.sig:
                 # another batch layout (the last, smaller batch of an epoch; validation-sized batches; another KL weight): its graphs are kept
                 # next to the current ones — the two most recent layouts stay captured
+                st = self._stash.pop(sig, None)
                 if self.sig is not None and self.graph_fwd is not None:
                     self._stash[self.sig] = {k: getattr(self, k) for k in self._STATE}
                     while len(self._stash) > 1:
                         self._stash.pop(next(iter(self._stash)))
-                st = self._stash.pop(sig, None)
                 self._drop_graphs()
                 self.sig, self.eager_seen = sig, 0
                 if st is not None:
