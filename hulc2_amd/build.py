@@ -16,6 +16,7 @@ OBJ = CSRC / "_obj"
 LIB = HERE / "libhulc2_amd.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS += os.environ.get("HULC_BUILD_FLAGS", "").split()      # (A/B builds of compile-time switches, e.g. -DHULC_NT_FRAMES=0; part of the object digest)
 
 
 def _digest(src: Path) -> str:

@@ -5,6 +5,7 @@
 //   arena (params / grads / exp_avg / exp_avg_sq share offsets).  HBM-bound: 4 reads + 3 writes of
 //   4 bytes (+2 for the bf16 weight shadow the MFMA kernels consume) per parameter, float4-vectorised.
 #include <cmath>
+#include <cstdlib>
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 
@@ -15,6 +16,18 @@ namespace {
 // step: a read of p and of the shadow for 6 M elements through 2-byte stores).  Up to 8 element ranges, multiples of 4, kernel arguments.
 struct LoRanges { int n; long b[8], e[8]; };
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <bool NT> HULC_DEVICE float4 ld4(const float* a) {
+    if (NT) { const v4f_t t = __builtin_nontemporal_load((const v4f_t*)a); return make_float4(t.x, t.y, t.z, t.w); }
+    return *(const float4*)a;
+}
+template <bool NT> HULC_DEVICE void st4(float* a, float x, float y, float z, float w) {
+    if (NT) { v4f_t t = {x, y, z, w}; __builtin_nontemporal_store(t, (v4f_t*)a); }
+    else *(float4*)a = make_float4(x, y, z, w);
+}
+
+template <int NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
-            float4 pv = *(float4*)(p + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+            float4 pv = ld4<(NT & 2) != 0>(p + i), gv = ld4<(NT & 1) != 0>(g + i), mv = ld4<(NT & 2) != 0>(m + i), vv = ld4<(NT & 2) != 0>(v + i);
             float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
             float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -47,12 +60,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
                 pa[k] -= (lr / bc1) * (ma[k] / denom);
             }
-            *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-            *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
-            *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+            st4<(NT & 4) != 0>(p + i, pa[0], pa[1], pa[2], pa[3]);
+            st4<(NT & 4) != 0>(m + i, ma[0], ma[1], ma[2], ma[3]);
+            st4<(NT & 4) != 0>(v + i, va[0], va[1], va[2], va[3]);
             if (shadow) {
                 uint2 s; s.x = pack_bf16x2(pa[0], pa[1]); s.y = pack_bf16x2(pa[2], pa[3]);
-                *(uint2*)(shadow + i) = s;
+                if (NT & 8) { v2u_t t = {s.x, s.y}; __builtin_nontemporal_store(t, (v2u_t*)(shadow + i)); }
+                else *(uint2*)(shadow + i) = s;
                 if (lo) {
                     bool in = false;
 #pragma unroll
@@ -328,10 +342,22 @@ extern "C" int hulc_adam_step_amp(float* p, const float* g, float* m, float* v, 
     auto meant = [](float b) -> double { const double d = (double)b, r = std::round(d * 1e7) / 1e7; return std::fabs(r - d) <= 6e-8 * std::fabs(d) ? r : d; };
     const double b1d = meant(beta1), b2d = meant(beta2);
     const float bc1 = (float)(1.0 - std::pow(b1d, (double)step)), bc2s = (float)std::sqrt(1.0 - std::pow(b2d, (double)step));
-    long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay,
-                                                                   bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_,
-                                                                   (float)(1.0 - b1d), (float)(1.0 - b2d), b1d, b2d, loss_scale, found_inf);
+    // (round 5, tools/adam_sweep.py on two boxes) every operand of the pass is touched once per step and the arenas (753 MB) are three times the
+    // MALL: non-temporal loads of p / g / m / v and stores of p / m / v take the 47 M-element pass from 256-288 us to 241-251 us (5.5 -> 5.8 TB/s of
+    // its 30 B per element); the bf16 shadow keeps the default policy (derive_copies reads it next).  8192 workgroups instead of 4096: -3 %.
+    // HULC_ADAM_NT (bit 0: g loads, 1: p / m / v loads, 2: p / m / v stores, 3: shadow stores) / HULC_ADAM_BLOCKS: the sweep's knobs.
+    static const long cap = getenv("HULC_ADAM_BLOCKS") ? atol(getenv("HULC_ADAM_BLOCKS")) : 8192;
+    static const int nt = getenv("HULC_ADAM_NT") ? atoi(getenv("HULC_ADAM_NT")) : 7;
+    long blocks = (n / 4 + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
+#define ADAM_GO(NTV) adam_kernel<NTV><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (uint16_t*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, \
+                                                                   bc1, bc2s, grad_scale, step_state, skip_flag, (uint16_t*)lo_shadow, lr_, \
+                                                                   (float)(1.0 - b1d), (float)(1.0 - b2d), b1d, b2d, loss_scale, found_inf)
+    switch (nt) {
+        case 1: ADAM_GO(1); break; case 3: ADAM_GO(3); break; case 4: ADAM_GO(4); break; case 5: ADAM_GO(5); break;
+        case 0: ADAM_GO(0); break; case 15: ADAM_GO(15); break; case 12: ADAM_GO(12); break; case 13: ADAM_GO(13); break;
+        default: ADAM_GO(7);
+    }
+#undef ADAM_GO
     return hulc_check_launch("hulc_adam_step");
 }
 
