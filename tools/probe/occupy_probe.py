@@ -64,6 +64,36 @@ def run(n, regs, lds, ticks=120000, rep=5):
     return sorted(ts)[len(ts) // 2]
 
 
+so.stream_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+NP = 47_000_000 // 4
+arr = [torch.zeros(NP * 4, device=dev) for _ in range(4)]
+
+
+def run_stream(n, pace, rep=5):
+    """conv chain beside a paced streaming pass over 4 x 188 MB: -> (chain us, pass us)"""
+    tc, tp = [], []
+    for _ in range(rep):
+        torch.cuda.synchronize()
+        e0, e1, s0, s1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        occ.wait_stream(cur)
+        s0.record(occ)
+        rc = so.stream_launch(n, arr[0].data_ptr(), arr[1].data_ptr(), arr[2].data_ptr(), arr[3].data_ptr(), NP, pace, occ.cuda_stream)
+        assert rc == 0, rc
+        s1.record(occ)
+        e0.record(cur)
+        g.replay()
+        e1.record(cur)
+        torch.cuda.synchronize()
+        tc.append(e0.elapsed_time(e1) * 1e3); tp.append(s0.elapsed_time(s1) * 1e3)
+    return sorted(tc)[len(tc) // 2], sorted(tp)[len(tp) // 2]
+
+
 print(f"conv backward chain alone: {run(0, 0, 0):7.1f} us")
+for n, regs, lds in ((256, 32, 0), (512, 32, 0), (1024, 32, 0)):
+    print(f"beside {n:4d} resident workgroups ({regs} registers, {lds >> 10} KB LDS): {run(n, regs, lds):7.1f} us")
+for n, pace in ((256, 0), (256, 1), (256, 2), (256, 4), (128, 0), (128, 1), (128, 2), (64, 0), (512, 0), (512, 2), (512, 4)):
+    c, p_ = run_stream(n, pace)
+    print(f"beside a streaming pass of {n:4d} workgroups, pace {pace}: chain {c:7.1f} us, pass {p_:7.1f} us ({NP * 16 * 7 / p_ / 1e6:.2f} TB/s)")
+sys.exit(0)
 for n, regs, lds in ((8, 32, 0), (16, 32, 0), (32, 32, 0), (64, 32, 0), (16, 120, 0), (32, 120, 0), (16, 120, 32768), (32, 120, 32768), (64, 120, 32768)):
     print(f"beside {n:3d} resident workgroups ({regs} registers, {lds >> 10} KB LDS): {run(n, regs, lds):7.1f} us")
