@@ -309,7 +309,7 @@ def lightning_loop(args, dev):
             node = model.__dict__.get("_hulc_step_node")
             if node is not None:
                 res[name]["step_node"] = {"replays": node.replays, "eager_steps": node.eager_steps, "captures": node.captures,
-                                          "input_copies": node.input_copies, "disabled": node.disabled}
+                                          "input_copies": node.input_copies, "accum_steps": node.accum_steps, "disabled": node.disabled}
 
         for name, conc in (("cooperative_kernels", False), ("concurrent_streams", True)):
             kn.set_concurrent_streams(conc)
@@ -356,6 +356,43 @@ def lightning_loop(args, dev):
                 scaler.step(opt)
                 scaler.update()
                 return loss
+        # round 6: (a) the optimizer the UNCHANGED conf/model/optimizer/adam.yaml gets from Hulc2.configure_optimizers (`_target_: torch.optim.Adam`
+        # -> the drop-in subclass), (b) in the order pytorch-lightning 1.8's closure runs a step — training_step -> optimizer.zero_grad() -> backward —
+        # with the previous step's .grad still attached while training_step runs, set_to_none as torch 2.x defaults (True) and as the torch 1.12 the
+        # reference pins defaults (False: zeroed in place, still attached at backward time -> the node's add-back path, stepnode._take_live_grads)
+        try:
+            hulc_opt = opt
+            opt = model.configure_optimizers()["optimizer"]
+            res["configure_optimizers_class"] = f"{type(opt).__module__}.{type(opt).__name__}"
+            opt.load_state_dict(hulc_opt.state_dict())
+            for name, stn in (("default_yaml_lightning_closure_order", True), ("default_yaml_lightning_closure_order_zero_in_place", False)):
+                def step(i, stn=stn):                       # noqa: F811
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        loss = model.training_step(batch, i)
+                    opt.zero_grad(set_to_none=stn)
+                    scaler.scale(loss).backward()
+                    scaler.step(opt)
+                    scaler.update()
+                    return loss
+                node = model.__dict__.get("_hulc_step_node")
+                before = (node.replays, node.accum_steps) if node is not None else (0, 0)
+                measure(name)
+                node_stats(name)
+                if node is not None:
+                    res[name]["replays_in_this_leg"] = node.replays - before[0]
+                    res[name]["accum_steps_in_this_leg"] = node.accum_steps - before[1]
+                res[name]["fused_steps"] = int(getattr(opt, "fused_launches", -1))
+        except Exception as e:                              # noqa: BLE001
+            res["closure_order_error"] = f"{type(e).__name__}: {e}"
+        finally:
+            def step(i):                                    # noqa: F811
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    loss = model.training_step(batch, i)
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+                return loss
         opt = torch_opt
         # the same loop under torch's own DistributedDataParallel (what Lightning's DDPStrategy builds, hulc2/training.py:72-75), on a ONE-rank
         # RCCL group — the collectives move nothing, the reducer's bucket copies, hooks and stream hand-overs are all there: with
@@ -377,9 +414,20 @@ def lightning_loop(args, dev):
                 def forward(self, b, i):
                     return self.module.training_step(b, i)
 
-            for name, conc, parked in (("torch_ddp_parked_hook", False, True), ("torch_ddp_concurrent_streams", True, False)):
+            # (`_one_bucket`: gradient_as_bucket_view=True + one 200 MB bucket — the reducer copies every gradient into ONE buffer and hands the
+            #  views back as .grad: no per-bucket launches, no copy back; `_hulc2_amd_adam`: the optimizer configure_optimizers now returns)
+            for name, conc, parked, extra, hulc_adam in (("torch_ddp_parked_hook", False, True, {}, False),
+                                                         ("torch_ddp_parked_hook_one_bucket", False, True, dict(gradient_as_bucket_view=True, bucket_cap_mb=200), False),
+                                                         ("torch_ddp_parked_hook_one_bucket_hulc2_amd_adam", False, True, dict(gradient_as_bucket_view=True, bucket_cap_mb=200), True),
+                                                         ("torch_ddp_parked_hook_hulc2_amd_adam", False, True, {}, True),
+                                                         ("torch_ddp_concurrent_streams", True, False, {}, False)):
                 kn.set_concurrent_streams(conc)
-                ddp = DDP(_Step(model), device_ids=[dev.index or 0], static_graph=True, find_unused_parameters=False)
+                if hulc_adam:
+                    opt = HulcAdam([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+                    opt.load_state_dict(torch_opt.state_dict())
+                else:
+                    opt = torch_opt
+                ddp = DDP(_Step(model), device_ids=[dev.index or 0], static_graph=True, find_unused_parameters=False, **extra)
                 if parked:
                     register_parked_comm_hook(ddp)
                 inner_step = step
@@ -397,6 +445,7 @@ def lightning_loop(args, dev):
                     node_stats(name)
                 finally:
                     step = inner_step
+                    opt = torch_opt
                     del ddp
         except Exception as e:                              # noqa: BLE001
             res["torch_ddp_error"] = f"{type(e).__name__}: {e}"

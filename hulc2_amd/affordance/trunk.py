@@ -48,8 +48,10 @@ class TrunkStemFn(torch.autograd.Function):
         wdt = adt
         n, _, h, w = img.shape
         dev = img.device
-        dkey = (wdt, tuple(p._version for p in net.parameters()))
-        if getattr(trunk, "_dgrad_key", None) != dkey:          # the frozen layers' data-gradient weights: repacked once
+        frozen = [c.weight for b in net.blocks() for c in (b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ())]
+        dkey = (wdt, tuple(p._version for p in frozen), tuple(p.data_ptr() for p in frozen))
+        if getattr(trunk, "_dgrad_key", None) != dkey:          # the FROZEN layers' data-gradient weights: repacked once (the trainable
+                                                                # stem has no data gradient; its forward operand is live, vision_r3m._raw_trunk)
             trunk._dgrad_w = [(_dgrad_weight(b.conv1, wdt), _dgrad_weight(b.conv2, wdt),
                                _dgrad_weight(b.downsample[0], wdt) if b.downsample is not None else None) for b in net.blocks()]
             trunk._dgrad_key = dkey

@@ -91,8 +91,19 @@ class Hulc2(LightningModule):
 
     def configure_optimizers(self):
         """hulc2.py:185-198 (Adam lr 2e-4 + constant schedule).  The native trainer (hulc2_amd/trainer.py) replaces this
-        with the fused arena Adam; under Lightning any torch optimizer works (bf16 shadows refresh by version)."""
-        opt = instantiate(self.optimizer_config, params=self.parameters())
+        with the fused arena Adam; under Lightning any torch optimizer works (the keeper re-derives the weight copies)."""
+        cfg = self.optimizer_config
+        tgt = cfg.get("_target_") if hasattr(cfg, "get") else None
+        if tgt == "torch.optim.Adam" and not os.environ.get("HULC_TORCH_ADAM"):
+            # round 6: the unchanged conf/model/optimizer/adam.yaml gets the drop-in SUBCLASS (hulc2_amd/optim.py): same update rule, same
+            # hyper-parameters, same state_dict layout (checkpoints interchange), isinstance(opt, torch.optim.Adam) holds; its step is one
+            # launch of the arena kernel on the step node's gradient arena and takes a GradScaler's device scalars without a host
+            # synchronisation; any configuration it does not cover (amsgrad, several groups, CPU, ...) runs torch.optim.Adam.step() on the
+            # same state.  HULC_TORCH_ADAM=1 hands out torch's own class.
+            from ..optim import Adam
+            opt = Adam(self.parameters(), **{k: v for k, v in cfg.items() if not str(k).startswith("_")})
+        else:
+            opt = instantiate(cfg, params=self.parameters())
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda _: 1.0)
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
 

@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from hulc2_amd import functional as HF
 from hulc2_amd import kernels as kn
+from hulc2_amd import shadow
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -126,7 +127,10 @@ class VisionR3M(nn.Module):
     def _fold_trunk(self):
         ts = self._trunk_tensors()
         wdtype = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
-        key = (wdtype, ts[0].device, tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+        # a trainable trunk tensor (the affordance model's stem, r3m_rn18.py:34-38) may be moved by an optimizer that writes the parameter
+        # arena through raw pointers (no version bump): such optimizers bump shadow's epoch instead
+        live = shadow.epoch() if any(t.requires_grad for t in ts) else 0
+        key = (wdtype, ts[0].device, tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts), live)
         if key != self._folded_key:
             net = self.r3m.convnet
             with torch.no_grad():
@@ -145,25 +149,26 @@ class VisionR3M(nn.Module):
         return self._folded
 
     def _raw_trunk(self):
-        """the convolution weights alone (OHWI, compute dtype), no BatchNorm folded in: the operands of the batch-statistics path"""
-        ws = [p for n, p in self.r3m.convnet.named_parameters() if n.endswith("conv1.weight") or n.endswith("conv2.weight")
-              or n.endswith("downsample.0.weight")]
+        """the convolution weights alone (OHWI, compute dtype), no BatchNorm folded in: the operands of the batch-statistics path.  The FROZEN
+        layers' operands are cached on their own version counters; the stem's — trainable in the affordance model (r3m_rn18.py:34-38), moved
+        by arena optimizers without a version bump — is derived from the live parameter on every call through shadow.weight_operand, which
+        re-makes it once per step (inside a captured step too)."""
+        net = self.r3m.convnet
+        ws = [p for n, p in net.named_parameters() if n != "conv1.weight" and (n.endswith("conv1.weight") or n.endswith("conv2.weight")
+              or n.endswith("downsample.0.weight"))]
         wdtype = torch.bfloat16 if kn.get_compute() == "bf16" else torch.float32
         key = (wdtype, ws[0].device, tuple(t._version for t in ws), tuple(t.data_ptr() for t in ws))
         if key != getattr(self, "_raw_key", None):
-            def raw(conv, cin_pad=0):
-                w = conv.weight.float()
-                if cin_pad > w.shape[1]:
-                    w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
-                return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(wdtype)
-            net = self.r3m.convnet
+            def raw(conv):
+                return conv.weight.float().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).contiguous().to(wdtype)
             with torch.no_grad():
-                self._raw = {"stem": raw(net.conv1, 8),
-                             "blocks": [(raw(b.conv1), raw(b.conv2), raw(b.downsample[0]) if b.downsample is not None else None, b.stride)
+                self._raw = {"blocks": [(raw(b.conv1), raw(b.conv2), raw(b.downsample[0]) if b.downsample is not None else None, b.stride)
                                         for b in net.blocks()],
                              "zero": torch.zeros(512, dtype=torch.float32, device=ws[0].device)}
             self._raw_key = key
-        return self._raw
+        f = dict(self._raw)
+        f["stem"] = shadow.weight_operand(net.conv1.weight, "ohwi_c8")
+        return f
 
     @torch.no_grad()
     def _trunk_maps_batch_stats(self, x: torch.Tensor, mean, std):

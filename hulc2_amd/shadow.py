@@ -34,6 +34,11 @@ def bump_epoch() -> None:
     _epoch += 1
 
 
+def epoch() -> int:
+    """the counter bump_epoch() moves: part of the key of caches that hold copies of TRAINABLE tensors outside this module"""
+    return _epoch
+
+
 def register_arena_view(param: torch.Tensor, view_bf16: torch.Tensor) -> None:
     """The native trainer keeps one flat bf16 arena that the Adam kernel refreshes in place."""
     key = id(param)
@@ -74,6 +79,10 @@ def _layout(w: torch.Tensor, layout: Optional[str], chw=None) -> torch.Tensor:
         return w.reshape(w.shape[0], -1)
     if layout == "ohwi":               # NHWC forward: k = (kh, kw, c)
         return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    if layout == "ohwi_c8":            # the ResNet stem on NHWC-8 frames: input channels zero-padded to 8, k = (kh, kw, c)
+        w8 = w.new_zeros((w.shape[0], 8) + tuple(w.shape[2:]))
+        w8[:, :w.shape[1]] = w
+        return w8.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     if layout == "ihwo":               # data gradient: rows = input channel, k = (kh, kw, cout)
         return w.permute(1, 2, 3, 0)
     if layout == "t":                  # transposed 2-D weight: lets dX = dY W stream W k-major

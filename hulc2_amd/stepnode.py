@@ -70,27 +70,35 @@ class _EagerStepFn(torch.autograd.Function):
         inner, ctx.inner = ctx.inner, None
         if inner is None:
             raise RuntimeError("hulc2_amd step node: backward through one training step twice (the inner graph is freed by its first backward)")
-        return (None, None, None, *ctx.node._inner_backward(inner, g))
+        node = ctx.node
+        held = node._take_live_grads(node.views)
+        outs = node._inner_backward(inner, g)
+        node._give_back_live_grads(held, outs)
+        return (None, None, None, *outs)
 
 
 class _GraphStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, node, *params):
         node.graph_fwd.replay()
+        ctx.node = node
         ctx.cap = (node.graph_bwd, node.static_g, node.static_outs)        # (the node may have switched to another batch layout's graphs by the time of backward)
         return node.static_loss.clone()                   # (the caller may keep the loss beyond the next replay)
 
     @staticmethod
     def backward(ctx, g):
         graph_bwd, static_g, static_outs = ctx.cap
+        held = ctx.node._take_live_grads(static_outs)
         static_g.copy_(g.reshape(static_g.shape))
         graph_bwd.replay()
+        ctx.node._give_back_live_grads(held, static_outs)
         return (None, *[None if o is None else o.detach() for o in static_outs])
 
 
 class StepNode:
     """the step node of one Hulc2 module under its shadows-only keeper (`Hulc2._step_node`)"""
 
+    STASHED = 3                       # captured batch layouts kept beside the current one (least recently used goes first)
     EAGER_STEPS = 2                   # eager-node steps of a configuration before it is captured (the second one runs in sink-overwrite mode)
     _STATE = ("eager_seen", "graph_fwd", "graph_bwd", "static_loss", "static_g", "static_outs", "static_leaves", "static_logs", "slot_idx", "slots_ok",
               "slot_table", "slot_ptrs", "_ring", "_ring_pos")          # what belongs to ONE captured batch layout
@@ -116,7 +124,8 @@ class StepNode:
         self.static_leaves: List[torch.Tensor] = []
         self.static_logs = []
         self.disabled: Optional[str] = "HULC_NO_STEP_GRAPH" if os.environ.get("HULC_NO_STEP_GRAPH") else None
-        self.replays = self.eager_steps = self.captures = self.input_copies = 0      # (tests / bench read these)
+        self.replays = self.eager_steps = self.captures = self.input_copies = self.accum_steps = self.evictions = 0      # (tests / bench read these)
+        self._seen = {}                        # signature -> eager-node steps taken (a loop that alternates layouts still reaches its captures)
         # frame slots (hulc_conv_desc.x_slot): the big frame tensors are read by conv1's captured launches through device pointer slots
         self.slot_idx: List[int] = []          # leaves read through slots
         self.slots_ok = False                  # ... verified by the self-check of _capture
@@ -173,13 +182,68 @@ class StepNode:
                 float(m.clip_auxiliary_loss_beta), bool(m.use_clip_auxiliary_loss))
 
     def usable(self) -> bool:
-        """the keeper's parameter list is still the model's trainable set, and no gradient is being accumulated over several calls (a live
-        .grad may alias the arena the next backward overwrites: such steps take the plain path, where autograd adds into it)"""
+        """the keeper's parameter list is still the model's trainable set.  (A live `.grad` is NOT a reason to leave the node — round 6, ADVICE
+        r05: Lightning's closure runs training_step -> zero_grad -> backward, so from the second step on the previous step's gradients are
+        still attached when training_step runs; what they mean is decided when backward runs: _take_live_grads.)"""
+        return all(p.requires_grad for p in self.keeper.params)
+
+    # ---- gradients that are still attached when backward runs -----------------------------------------------------------------------------
+    def _take_live_grads(self, dests):
+        """Called in front of the inner backward.  `dests[i]` is the tensor the backward is about to OVERWRITE and hand to autograd as parameter
+        i's gradient (an arena view, or a buffer of the captured graph).  A parameter whose `.grad` is that very memory — the previous step's
+        gradient left attached: `optimizer.zero_grad(set_to_none=False)` (the default of the torch 1.12 the reference pins) zeroed it in
+        place, or nobody zeroed it because gradients are being accumulated over several calls — would see `grad += grad` from AccumulateGrad.
+        So: keep a copy of what is there (ONE copy of the arena), detach those `.grad`s, let the backward overwrite, add the copy back in
+        (_give_back_live_grads, one launch): autograd then installs the views again and `.grad` = old + new, bit for bit what the plain loop's
+        accumulation gives (zeros + new = new).  A `.grad` that lives elsewhere (DDP's bucket views, a user's tensor) is left alone:
+        AccumulateGrad adds into it as always.  ~0.2 ms per step on this path; `set_to_none=True` costs nothing."""
         tr = self.keeper
-        for p in tr.params:
-            if p.grad is not None or not p.requires_grad:
-                return False
-        return True
+        lo = tr.flat_g.data_ptr()
+        hi = lo + tr.flat_g.numel() * 4
+        taken, others = [], []
+        for i, (p, d) in enumerate(zip(tr.params, dests)):
+            g = p.grad
+            if g is None:
+                continue
+            if lo <= g.data_ptr() < hi:                          # an arena view: every backward of this node overwrites the arena
+                taken.append((i, g))
+            elif d is not None and g.data_ptr() == d.data_ptr():  # a buffer of the captured backward graph (a gradient autograd itself produced)
+                others.append((i, g, g.clone()))
+            else:
+                continue
+            p.grad = None
+        if not taken and not others:
+            return None
+        self.accum_steps += 1
+        return (tr.flat_g.clone() if taken else None, taken, others)
+
+    def _give_back_live_grads(self, held, outs) -> None:
+        if held is None:
+            return
+        prev, taken, others = held
+        tr = self.keeper
+        if prev is not None:
+            # the old values go back into the slices of the parameters they were taken from — and nowhere else: the slice of a parameter whose
+            # `.grad` lives outside the arena (AccumulateGrad cloned instead of adopting the view) is never zeroed by zero_grad, what a copy of
+            # the arena holds there is the previous step's gradient
+            dst, src = [], []
+            for i, g in taken:
+                o = outs[i]
+                off = tr.offsets[i]
+                if o is None:                                     # no gradient for this parameter in this pass: what was attached stays attached
+                    g.copy_(prev[off:off + g.numel()].view(g.shape))
+                    tr.params[i].grad = g
+                else:                                             # the arena view, or a sum autograd made next to it (view + its own term)
+                    dst.append(o)
+                    src.append(prev[off:off + o.numel()].view(o.shape))
+            if dst:
+                torch._foreach_add_(dst, src)
+        for i, g, old in others:
+            if outs[i] is None:
+                g.copy_(old)
+                tr.params[i].grad = g
+            else:
+                outs[i].add_(old)
 
     def __call__(self, batch, batch_idx) -> Tuple[torch.Tensor, list]:
         tr = self.keeper
@@ -192,12 +256,22 @@ class StepNode:
                 # another batch layout (the last, smaller batch of an epoch; validation-sized batches; another KL weight): its graphs are kept
                 # next to the current ones — the two most recent layouts stay captured
                 st = self._stash.pop(sig, None)
-                if self.sig is not None and self.graph_fwd is not None:
-                    self._stash[self.sig] = {k: getattr(self, k) for k in self._STATE}
-                    while len(self._stash) > 1:
-                        self._stash.pop(next(iter(self._stash)))
+                if self.sig is not None:
+                    self._seen[self.sig] = self.eager_seen       # (kept per layout: alternating layouts each reach EAGER_STEPS and are captured)
+                    if self.graph_fwd is not None:
+                        self._stash[self.sig] = {k: getattr(self, k) for k in self._STATE}
+                        while len(self._stash) > self.STASHED:
+                            old_sig = next(iter(self._stash))
+                            self._stash.pop(old_sig)
+                            self._seen.pop(old_sig, None)
+                            self.evictions += 1
+                            if self.evictions == 8:
+                                warnings.warn(f"hulc2_amd step node: more than {self.STASHED + 1} batch layouts / loss weights rotate through training_step; "
+                                              "their graphs are being re-captured (StepNode.STASHED raises the number kept)")
                 self._drop_graphs()
-                self.sig, self.eager_seen = sig, 0
+                self.sig, self.eager_seen = sig, self._seen.get(sig, 0)
+                while len(self._seen) > 16:
+                    self._seen.pop(next(iter(self._seen)))
                 if st is not None:
                     for k, v in st.items():
                         setattr(self, k, v)
@@ -231,12 +305,35 @@ class StepNode:
                 self._live_inputs = [t for _, t in leaves]
                 self.replays += 1
                 loss = _GraphStepFn.apply(self, *tr.params)
-                return loss, self.static_logs
+                return loss, self._logs_of_this_call()
         self.eager_seen += 1
         self.eager_steps += 1
         loss = _EagerStepFn.apply(self, batch, batch_idx, *tr.params)
         logs, self._logs = self._logs, []
         return loss, logs
+
+    def _logs_of_this_call(self) -> list:
+        """the captured graph's logged values are its static device tensors: the next replay overwrites them, and a logger keeps what it is
+        given (`self.log(..., on_step=True)`, `_MiniLightningModule.logged`) — ADVICE r05.  One stack launch copies the tensor-valued entries
+        (values and device-valued `batch_size` keywords) into a buffer of this call; the entries handed out are views of it."""
+        flat = []
+        for _, v, kw in self.static_logs:
+            if torch.is_tensor(v):
+                flat.append(v)
+            flat += [x for x in kw.values() if torch.is_tensor(x)]
+        fresh = [None] * len(flat)
+        by_dtype = {}
+        for i, t in enumerate(flat):
+            if t.dim() == 0:
+                by_dtype.setdefault(t.dtype, []).append(i)
+            else:
+                fresh[i] = t.clone()
+        for idx in by_dtype.values():                             # (losses: fp32 scalars; the contrastive head's row count: one more dtype)
+            for i, c in zip(idx, torch.stack([flat[i] for i in idx]).unbind(0)):
+                fresh[i] = c
+        it = iter(fresh)
+        return [(n, next(it) if torch.is_tensor(v) else v, {k: (next(it) if torch.is_tensor(x) else x) for k, x in kw.items()})
+                for n, v, kw in self.static_logs]
 
     def _drop_graphs(self) -> None:
         self.graph_fwd = self.graph_bwd = None

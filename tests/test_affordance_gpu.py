@@ -418,3 +418,51 @@ def test_whole_step_trains_the_stem_in_reference_mode():
     tr.optimizer_step()
     torch.cuda.synchronize()
     assert not torch.equal(net.conv1.weight, before)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_stem_operand_follows_the_parameter_over_several_steps(graph):
+    """the stem's kernel-side operand was cached on Parameter._version / data_ptr only, and the arena Adam moves
+    conv1.weight through raw pointers (no version bump): from the second step on the trunk convolved with the INITIAL stem weights.  After N
+    native-trainer steps (eager, and replayed as a graph) the stem map of a train-mode forward must equal the stem computed by torch from the
+    CURRENT conv1.weight / bn1 (batch statistics), and must differ from the one the initial weights give."""
+    dev = _dev()
+    from hulc2_amd.affordance import PixelAffLangDetector
+    from hulc2_amd.trainer import ArenaTrainer
+    B, HW = 4, 64
+    kn.set_compute("bf16")
+    m = PixelAffLangDetector(img_size=HW, trunk_mode="reference").to(dev)
+    syn.fill_affordance_state_dict_({k: v for k, v in m.state_dict().items() if ".r3m." not in k}, 5)
+    net = m.model.aff_stream.r3m.convnet
+    syn.fill_state_dict_({"r3m.convnet." + k: v for k, v in net.state_dict().items()}, 5)
+    m.train()
+    gen = torch.Generator().manual_seed(3)
+    img = torch.randn(B, 3, HW, HW, generator=gen).to(dev)
+    emb = (torch.randn(B, 384, generator=gen) * 0.5).to(dev)
+    p0 = torch.stack([torch.randint(0, HW, (B,), generator=gen), torch.randint(0, HW, (B,), generator=gen)], 1)
+    depth = torch.randn(B, generator=gen)
+    batch = ({"img": img, "lang_goal": emb}, {"p0": p0.to(dev), "normalized_depth": depth.to(dev)})
+    tr = ArenaTrainer(m, lr=3e-2, overlap=False)           # (a large step: the stem must move visibly within a few steps)
+    w0 = net.conv1.weight.detach().clone()
+    if graph:
+        tr.capture(batch)
+        for _ in range(4):
+            tr.replay()
+    else:
+        for i in range(4):
+            tr.step(batch, i)
+    torch.cuda.synchronize()
+    assert (net.conv1.weight - w0).abs().max().item() > 1e-2
+
+    def torch_stem(w):                                       # (train-mode BatchNorm removes whatever scale the trunk gives its input)
+        z = torch.nn.functional.conv2d(img, w, stride=2, padding=3)
+        mu, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+        y = (z - mu) / torch.sqrt(var + net.bn1.eps) * net.bn1.weight.view(1, -1, 1, 1) + net.bn1.bias.view(1, -1, 1, 1)
+        return torch.nn.functional.max_pool2d(torch.relu(y), 3, 2, 1)
+    with torch.no_grad():
+        got = m.trunk_maps(img)[0].float().permute(0, 3, 1, 2)
+        want_now, want_old = torch_stem(net.conv1.weight.detach()), torch_stem(w0)
+    e_now = (got - want_now).abs().max().item() / want_now.abs().max().item()
+    e_old = (got - want_old).abs().max().item() / want_old.abs().max().item()
+    print(f"stem map vs current weights {e_now:.3e}, vs initial weights {e_old:.3e}")
+    assert e_now <= 3e-2 and e_old > 3 * e_now, (e_now, e_old)
