@@ -18,4 +18,15 @@ int hulc_check_launch(const char* where) {
 }
 
 extern "C" const char* hulc_last_error(void) { return g_err; }
-extern "C" int hulc_abi_version(void) { return 5; }
+extern "C" int hulc_abi_version(void) { return 6; }
+
+// (ABI 6) How many cooperative launches share the device from now on (see include/hulc2_amd.h): a host-side setting read when a launch is
+// issued — a captured graph keeps the grids it was captured with.
+static int g_coop_share = 1;
+int hulc_coop_share(void) { return g_coop_share; }
+extern "C" int hulc_set_coop_share(int n) {
+    if (n != 1 && n != 2 && n != 4) return hulc_fail(-2, "hulc_set_coop_share: 1, 2 or 4");
+    const int old = g_coop_share;
+    g_coop_share = n;
+    return old;
+}

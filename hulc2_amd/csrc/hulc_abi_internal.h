@@ -5,6 +5,7 @@
 
 int hulc_fail(int code, const char* msg);          // records msg for hulc_last_error(), returns code
 int hulc_check_launch(const char* where);          // hipGetLastError() -> 0 / -100
+int hulc_coop_share(void);                         // hulc_set_coop_share's current value (1: a cooperative launch may take every CU)
 
 // wgrad_taps.hip: the conv_taps_wp items of hulc_wgrad_group that run as nine-tap tiles (one pass over the operands)
 int hulc_wgrad_taps_takes(const hulc_wgrad_item* d);

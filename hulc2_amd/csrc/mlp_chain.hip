@@ -344,14 +344,25 @@ static int chain_launch(const hulc_mlp_chain_desc* d, const hulc_mlp_chain_desc*
         p.xb_lo = p.xb + data;
         p.x0b_lo = p.xb_lo + ((off + 7) / 8) * 8;
     }
+    // grid: a layer of N columns keeps N / 16 workgroups busy — a chain no wider than 2048 runs on 128 workgroups (the others of a 256-grid only
+    // take part in the barriers), which leaves the other half of the device to a second cooperative launch (round 6: g_coop_share)
+    int widest = 0;
+    for (int l = 0; l < d->nl; ++l) widest = d->layers[l].N > widest ? d->layers[l].N : widest;
+    int grid = 256;
+    {
+        static const char* e = getenv("HULC_CHAIN_GRID");
+        const int want = e ? atoi(e) : (hulc_coop_share() > 1 ? 256 / hulc_coop_share() : 256);
+        if (want >= 8 && want < 256 && want % 8 == 0 && widest <= 16 * want) grid = want;
+        else if (hulc_coop_share() > 1) return hulc_fail(-9, "hulc_mlp_chain: the chain is wider than its share of the device (hulc_set_coop_share)");
+    }
     if (p.x3) {
         for (int l = 0; l < d->nl; ++l) {
             const int kk = d2 && l < d2->nl && p.L2[l].K > p.L[l].K ? p.L2[l].K : p.L[l].K;
             if (kk > 2048) return hulc_fail(-3, "hulc_mlp_chain: split operands take K <= 2048");
         }
-        mlp_chain_kernel<true><<<256, 256, 0, (hipStream_t)stream>>>(p);
+        mlp_chain_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     } else {
-        mlp_chain_kernel<false><<<256, 256, 0, (hipStream_t)stream>>>(p);
+        mlp_chain_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     }
     return hulc_check_launch("hulc_mlp_chain");
 }

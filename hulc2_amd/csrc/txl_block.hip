@@ -571,7 +571,7 @@ int block_share(const hulc_txl_block_desc* d) {
     if (!d->ws || d->exclusive == 0) return 1;
     const int ns = d->FF / 128, groups = (d->B + 7) / 8 * 8;
     for (int q = 4; q > 1; q >>= 1)
-        if ((forced == 0 || q <= forced) && ns % q == 0 && groups * q <= device_cus() && d->B <= SYNC_MAX_SEQ) return q;
+        if ((forced == 0 || q <= forced) && ns % q == 0 && groups * q <= device_cus() / hulc_coop_share() && d->B <= SYNC_MAX_SEQ) return q;
     return 1;
 }
 

@@ -95,6 +95,7 @@ class MLPFn(torch.autograd.Function):
         ctx.save_for_backward(x2, *acts[:-1], *params)
         ctx.meta = (relus, drops, seed, L, x.shape)
         ctx.chain = chain
+        ctx.share = kn.coop_share()                        # (a forked branch of the step: the backward's chain launch keeps to the same share of the device)
         return acts[-1].reshape(*x.shape[:-1], acts[-1].shape[-1])
 
     @staticmethod
@@ -106,7 +107,8 @@ class MLPFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         # (the data-gradient chain does not depend on how the forward ran: an exact-fp32 forward — selective precision, mixed mode — leaves the
         # same fp32 activations behind, and the backward products run in bf16 either way)
-        dx, grads = _mlp_backward(x2, acts, params, relus, drops, g, need_x, ctx.chain or not any(d > 0 for d in drops))
+        with kn.coop_share_scope(ctx.share):
+            dx, grads = _mlp_backward(x2, acts, params, relus, drops, g, need_x, ctx.chain or not any(d > 0 for d in drops))
         return (dx.reshape(xshape) if need_x else None, None, None, None, *grads)
 
 
@@ -190,10 +192,16 @@ class DualMLPFn(torch.autograd.Function):
                       xb, [(weight_operand(pb[2 * i]), pb[2 * i + 1], relus[i], None, 1.0, outs[1][i]) + lo[i] for i in range(L)], xb.shape[0])
         ctx.save_for_backward(xa, xb, *outs[0][:-1], *outs[1][:-1], *params)
         ctx.relus = relus
+        ctx.share = kn.coop_share()
         return outs[0][-1], outs[1][-1]
 
     @staticmethod
     def backward(ctx, dya, dyb):
+        with kn.coop_share_scope(ctx.share):
+            return DualMLPFn._backward(ctx, dya, dyb)
+
+    @staticmethod
+    def _backward(ctx, dya, dyb):
         relus = ctx.relus
         L = len(relus)
         saved = ctx.saved_tensors
@@ -1035,6 +1043,7 @@ class TxlBlockFn(torch.autograd.Function):
             ctx.save_for_backward(emb, pos, pos_ids, *flat, *params)
             ctx.meta = (B, S, E, H, FF, L, drop_p, seed)
             ctx.pos_identity = bool(getattr(pos_ids, "_hulc_arange", False)) and pos_ids.numel() == S
+            ctx.share = kn.coop_share()                    # (the posterior as a forked branch: the backward launch keeps to the same share of the device)
         return pooled
 
     @staticmethod
@@ -1066,7 +1075,7 @@ class TxlBlockFn(torch.autograd.Function):
             x = y2
         demb = _f32(B, S, E, like=like)
         d = kn.txl_block_desc(emb, pos, pos_ids, B, S, H, FF, drop_p, seed, 1e-5, recs, dpooled=dpooled, demb=demb)
-        kn.txl_block_bwd(d, B, S, H, E, FF, L)
+        kn.txl_block_bwd(d, B, S, H, E, FF, L, share=ctx.share)
         grads = []
         rets = []
         dgs, dbs, accs = [], [], []

@@ -716,17 +716,73 @@ def concurrent_streams() -> bool:
     return _concurrent_streams
 
 
+# ---- two cooperative launches side by side (round 6; include/hulc2_amd.h hulc_set_coop_share) -------------------------------------------------
+# The prior branch (goal encoders -> plan proposal: persistent MLP chains) and the posterior branch (the transformer trunk) of a step do not
+# depend on each other (hulc2/models/hulc2.py:228-233).  Both are cooperative launches that take one workgroup per CU — on two streams (two
+# branches of the captured graph) they fit the device only if each keeps to HALF of it.  `coop_share_scope(2)` is where the model forks; the
+# autograd Functions of the cooperative launches remember the share they ran under and launch their backward with it.
+_coop_share = 1
+_branch_streams = {}
+
+
+def coop_share() -> int:
+    return _coop_share
+
+
+class coop_share_scope:
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _coop_share
+        self.old, _coop_share = _coop_share, self.n
+
+    def __exit__(self, *exc):
+        global _coop_share
+        _coop_share = self.old
+
+
+def fork_branches() -> bool:
+    """run the prior and the posterior branch of a step on two streams (HULC_FORK=0: one after the other, as until round 5)"""
+    import os
+    return os.environ.get("HULC_FORK", "1") != "0" and not concurrent_streams() and _timing is None
+
+
+def branch_stream(device):
+    st = _branch_streams.get(device)
+    if st is None:
+        st = _branch_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _call_shared(share: int, name, *args, **kw):
+    """a cooperative launch issued for 1 / share of the device (host-side setting, read by the launcher; None: the scope's share)"""
+    share = _coop_share if share is None else share
+    if share <= 1:
+        return _call(name, *args, **kw)
+    lib = _L.load()
+    lib.hulc_set_coop_share(_i(share))
+    try:
+        _call(name, *args, **kw)
+    finally:
+        lib.hulc_set_coop_share(_i(1))
+
+
 def gemm_fuses_rowsum(M: int, a_kmajor: bool) -> bool:
     """hulc_gemm computes rowsum_a (the bias gradient of a weight-gradient GEMM) in the same launch on the tiled path"""
     return M > 64
 
 
-def mlp_chain_ok(M: int, K0: int, widths, device) -> bool:
-    """shapes hulc_mlp_chain takes (include/hulc2_amd.h) on a whole MI355X with nothing else sharing the GPU"""
+def mlp_chain_ok(M: int, K0: int, widths, device, share=None) -> bool:
+    """shapes hulc_mlp_chain takes (include/hulc2_amd.h) on a whole MI355X with nothing else sharing the GPU — or, under a coop share of n, on
+    1 / n of it: a layer of N columns needs N / 16 workgroups"""
     import os
     if os.environ.get("HULC_NO_MLP_CHAIN") or _compute_mode != BF16 or concurrent_streams() or device_cu_count(device) < 256:
         return False
     if not (1 <= M <= 64) or not (1 <= len(widths) <= 8):
+        return False
+    share = _coop_share if share is None else share
+    if share > 1 and max(widths) > 16 * (256 // share):
         return False
     k = K0
     for n in widths:
@@ -778,25 +834,25 @@ def _chain_workspace(device, need: int):
     return ws
 
 
-def mlp_chain(x0, layers, M):
+def mlp_chain(x0, layers, M, share=None):
     """layers: [(W bf16 [N][K] k-major, bias fp32 or None, relu flag, mask fp32 (M, N) or None, mask_scale, out fp32 (M, N))]; one persistent
     launch (csrc/mlp_chain.hip).  x0 fp32 (M, K0), unit inner stride."""
     d, flops, nbytes = _chain_desc(x0, layers, M)
     lib = _L.load()
     lib.hulc_mlp_chain_workspace.restype = _c.c_long
     ws = _chain_workspace(x0.device, int(lib.hulc_mlp_chain_workspace(_c.byref(d))))
-    _call("hulc_mlp_chain", _c.byref(d), ws, fault_word(x0.device), key=("mlp_chain", M, int(x0.shape[1])) + tuple(int(l[0].shape[0]) for l in layers),
-          flops=flops, nbytes=nbytes)
+    _call_shared(share, "hulc_mlp_chain", _c.byref(d), ws, fault_word(x0.device), key=("mlp_chain", M, int(x0.shape[1])) + tuple(int(l[0].shape[0]) for l in layers),
+                 flops=flops, nbytes=nbytes)
 
 
-def mlp_chain2_ok(Ma: int, K0a: int, widths_a, Mb: int, K0b: int, widths_b, device) -> bool:
+def mlp_chain2_ok(Ma: int, K0a: int, widths_a, Mb: int, K0b: int, widths_b, device, share=None) -> bool:
     """shapes hulc_mlp_chain2 takes: two chains of <= 32 rows, the second no deeper than the first and of its widths where both run"""
     widths_a, widths_b = list(widths_a), list(widths_b)
     return (Ma <= 32 and Mb <= 32 and 1 <= len(widths_b) <= len(widths_a) and widths_a[:len(widths_b)] == widths_b
-            and mlp_chain_ok(Ma, K0a, widths_a, device) and mlp_chain_ok(Mb, K0b, widths_b, device))
+            and mlp_chain_ok(Ma, K0a, widths_a, device, share) and mlp_chain_ok(Mb, K0b, widths_b, device, share))
 
 
-def mlp_chain2(xa, layers_a, Ma, xb, layers_b, Mb):
+def mlp_chain2(xa, layers_a, Ma, xb, layers_b, Mb, share=None):
     """two independent chains (mlp_chain's layer tuples) as ONE persistent launch — the visual and the language goal encoder, and their
     data-gradient chains (hulc_mlp_chain2, include/hulc2_amd.h)"""
     da, fa, na = _chain_desc(xa, layers_a, Ma)
@@ -804,7 +860,7 @@ def mlp_chain2(xa, layers_a, Ma, xb, layers_b, Mb):
     lib = _L.load()
     lib.hulc_mlp_chain_workspace.restype = _c.c_long
     ws = _chain_workspace(xa.device, int(lib.hulc_mlp_chain_workspace(_c.byref(da))) + int(lib.hulc_mlp_chain_workspace(_c.byref(db))))
-    _call("hulc_mlp_chain2", _c.byref(da), _c.byref(db), ws, fault_word(xa.device),
+    _call_shared(share, "hulc_mlp_chain2", _c.byref(da), _c.byref(db), ws, fault_word(xa.device),
           key=("mlp_chain2", Ma, Mb, int(xa.shape[1]), int(xb.shape[1])) + tuple(int(l[0].shape[0]) for l in layers_a), flops=fa + fb, nbytes=na + nb)
 
 
@@ -1138,13 +1194,13 @@ def _txl_block_flops(B, S, H, E, FF, L, bwd):
     return L * ((2.5 * attn + 2.5 * ffn) if bwd else (attn + ffn))
 
 
-def txl_block_fwd(d, B, S, H, E, FF, L):
+def txl_block_fwd(d, B, S, H, E, FF, L, share=None):
     """the whole posterior trunk (position embedding -> L transformer layers -> sequence mean) as one launch (csrc/txl_block.hip)"""
-    _call("hulc_txl_block_fwd", _c.byref(d), key=("txl_block_fwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, False))
+    _call_shared(share, "hulc_txl_block_fwd", _c.byref(d), key=("txl_block_fwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, False))
 
 
-def txl_block_bwd(d, B, S, H, E, FF, L):
-    _call("hulc_txl_block_bwd", _c.byref(d), key=("txl_block_bwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, True))
+def txl_block_bwd(d, B, S, H, E, FF, L, share=None):
+    _call_shared(share, "hulc_txl_block_bwd", _c.byref(d), key=("txl_block_bwd", B, S, L), flops=_txl_block_flops(B, S, H, E, FF, L, True))
 
 
 def residual_bf16(p32, hi, lo, segments):

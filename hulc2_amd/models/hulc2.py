@@ -224,45 +224,62 @@ class Hulc2(LightningModule):
             lo, hi = self.action_decoder.perceptual_emb_slice
             fan = vis_first and emb_all.is_cuda
             goal_all = None
+            # round 6: the posterior (transformer trunk + its head) does not depend on the goal encoders and the prior (hulc2.py:228-233): it runs as
+            # a second branch — a side stream eagerly, a branch of the captured graph in replay; autograd runs each branch's backward on the
+            # stream of its forward, so the backward forks the same way.  Both branches are cooperative launches that own a CU per workgroup:
+            # each keeps to half of the device (kernels.coop_share_scope, include/hulc2_amd.h hulc_set_coop_share).  HULC_FORK=0: one after the other.
+            fork = fan and kn.fork_branches()
             if fan:
                 emb0, emb_last, emb_rec, emb_dec_t = HF.EmbFanoutFn.apply(emb_all, B, lo, hi)
-                # selective precision: of the goal encoders only the LANGUAGE one is upstream of the contrastive head; inside a bf16
-                # step with site "goal" it alone runs its forward exactly, the visual one stays on its bf16 chain launch
-                lang_only_exact = kn.base_mode() == "bf16" and kn.get_compute() == "bf16" and "goal" in kn.fp32_sites() and len(mods) == 2
-                if lang_only_exact:
-                    # both encoders in ONE launch, the language one from split operands (three MFMAs per product: fp32-class values) ...
-                    pair = HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
-                                       self.language_goal.mlp_layers(), exact_b=True)
-                    if pair is None:        # ... or, where the pair does not fit the launch, on the exact-fp32 GEMMs
-                        pre_v = self.visual_goal(emb_last, pre_ln=True)
-                        with kn.site_scope("goal"):
-                            pre_l = self.language_goal(mods[1][1]["lang"], pre_ln=True)
-                        pair = (pre_v, pre_l)
-                    pre = list(pair)
-                with kn.site_scope("goal"):
-                    # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
-                    # directly (no concatenation, no strided gradient slices on the way back)
+            if fork:
+                cur, side = torch.cuda.current_stream(emb_all.device), kn.branch_stream(emb_all.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side), kn.coop_share_scope(2):
+                    pr_all, seq_all = self.plan_recognition(emb_rec)
+            with kn.coop_share_scope(2 if fork else 1):           # (the prior branch's chain launches: half of the device next to the posterior's)
+                if fan:
+                    # selective precision: of the goal encoders only the LANGUAGE one is upstream of the contrastive head; inside a bf16
+                    # step with site "goal" it alone runs its forward exactly, the visual one stays on its bf16 chain launch
+                    lang_only_exact = kn.base_mode() == "bf16" and kn.get_compute() == "bf16" and "goal" in kn.fp32_sites() and len(mods) == 2
                     if lang_only_exact:
-                        pass
-                    elif len(mods) == 2:    # the two goal MLPs (same hidden widths, their own weights) as one launch each way
-                        pre = list(HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
-                                               self.language_goal.mlp_layers()))
-                    else:
-                        pre = [self.language_goal(db["lang"], pre_ln=True) if "lang" in scope else self.visual_goal(emb_last, pre_ln=True) for scope, db in mods]
-                    goal_all = HF.layer_norm_cat(pre, [self.language_goal.ln if "lang" in scope else self.visual_goal.ln for scope, _ in mods], dim=0)
-                goals = [None] * len(mods)
+                        # both encoders in ONE launch, the language one from split operands (three MFMAs per product: fp32-class values) ...
+                        pair = HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
+                                           self.language_goal.mlp_layers(), exact_b=True)
+                        if pair is None:        # ... or, where the pair does not fit the launch, on the exact-fp32 GEMMs
+                            pre_v = self.visual_goal(emb_last, pre_ln=True)
+                            with kn.site_scope("goal"):
+                                pre_l = self.language_goal(mods[1][1]["lang"], pre_ln=True)
+                            pair = (pre_v, pre_l)
+                        pre = list(pair)
+                    with kn.site_scope("goal"):
+                        # the modalities' goal encoders stop in front of their LayerNorms, which then write the rows of the stacked goal tensor
+                        # directly (no concatenation, no strided gradient slices on the way back)
+                        if lang_only_exact:
+                            pass
+                        elif len(mods) == 2:    # the two goal MLPs (same hidden widths, their own weights) as one launch each way
+                            pre = list(HF.dual_mlp(emb_last, self.visual_goal.mlp_layers(), self.language_goal.embed(mods[1][1]["lang"]),
+                                                   self.language_goal.mlp_layers()))
+                        else:
+                            pre = [self.language_goal(db["lang"], pre_ln=True) if "lang" in scope else self.visual_goal(emb_last, pre_ln=True) for scope, db in mods]
+                        goal_all = HF.layer_norm_cat(pre, [self.language_goal.ln if "lang" in scope else self.visual_goal.ln for scope, _ in mods], dim=0)
+                    goals = [None] * len(mods)
+                else:
+                    embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
+                    emb0, emb_rec = emb_all[:, 0], emb_all
+                    goals = []
+                    for i, (scope, db) in enumerate(mods):
+                        with self._goal_site("lang" in scope):
+                            goals.append(self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]))
+                if goal_all is None:
+                    goal_all = torch.cat(goals, dim=0)
+                with kn.site_scope("prior"):
+                    pp_all = self.plan_proposal(emb0, goal_all)
+            if fork:
+                cur.wait_stream(side)                      # join: sample + KL consume both branches
+                for t_ in (pr_all.logit, seq_all):
+                    t_.record_stream(cur)
             else:
-                embs = [emb_all[i * B:(i + 1) * B] for i in range(len(mods))]
-                emb0, emb_rec = emb_all[:, 0], emb_all
-                goals = []
-                for i, (scope, db) in enumerate(mods):
-                    with self._goal_site("lang" in scope):
-                        goals.append(self.language_goal(db["lang"]) if "lang" in scope else self.visual_goal(embs[i][:, -1]))
-            if goal_all is None:
-                goal_all = torch.cat(goals, dim=0)
-            with kn.site_scope("prior"):
-                pp_all = self.plan_proposal(emb0, goal_all)
-            pr_all, seq_all = self.plan_recognition(emb_rec)
+                pr_all, seq_all = self.plan_recognition(emb_rec)
             # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality.  Sample + KL are ONE
             # autograd node (both consume the posterior's logits: their gradients meet inside the kernels, not in a fan-in add)
             idxs = [db.get("plan_idx") for _, db in mods]

@@ -178,7 +178,7 @@ class StepNode:
     def _signature(self, leaves) -> tuple:
         m = self._model()
         return (tuple((path, tuple(t.shape), t.dtype, t.device) for path, t in leaves), kn.base_mode(), kn.get_compute(),
-                os.environ.get("HULC_FP32_SITES"), kn.concurrent_streams(), float(m.kl_beta), float(m.kl_balancing_mix),
+                os.environ.get("HULC_FP32_SITES"), kn.concurrent_streams(), kn.fork_branches(), float(m.kl_beta), float(m.kl_balancing_mix),
                 float(m.clip_auxiliary_loss_beta), bool(m.use_clip_auxiliary_loss))
 
     def usable(self) -> bool:

@@ -26,6 +26,14 @@ extern "C" {
 
 const char* hulc_last_error(void);
 int hulc_abi_version(void);
+/* (ABI 6) Cooperative launches — the ones whose workgroups wait for each other inside the kernel and therefore must all be resident at once:
+ * hulc_mlp_chain / hulc_mlp_chain2, hulc_txl_block_fwd / _bwd with shared sequences, the recurrent sweeps — take one workgroup per CU.  Two of
+ * them on two streams (two branches of a captured graph) deadlock unless both fit the device TOGETHER: after hulc_set_coop_share(n), n = 2 or 4,
+ * the MLP chains run on 256 / n workgroups (error -9 for a chain wider than 16 x that) and the transformer trunk shares a sequence between as
+ * many workgroups as keep its grid within 256 / n; the recurrent sweeps are unaffected (never forked).  Read on the host when a launch is
+ * issued: a captured graph keeps what it was captured with.  Returns the previous value; n = 1 restores whole-device launches.
+ * reference: the prior and the posterior of hulc2/models/hulc2.py:228-233 do not depend on each other. */
+int hulc_set_coop_share(int n);
 
 /* ---- dense layers --------------------------------------------------------------------------- */
 /* C[M,N] = epi(alpha * A·B^T): A is [M][K] (a_kmajor) or stored [K][M]; B is [N][K] (b_kmajor, the
