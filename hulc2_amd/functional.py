@@ -1335,8 +1335,30 @@ class DecoderRNNFn(torch.autograd.Function):
             return (None if sink is not None else out), (None if bsink is not None else bout)
 
         b_ih0, b_hh0, b_ih1, b_hh1 = ctx.biases
+        # round 6, OPT-IN (HULC_WGRAD_FORK=1, native trainer only): the three 2048^3 recurrent weight gradients feed nothing downstream (they land in
+        # the gradient arena) while the chain behind them — sequence sums, skinny data-gradient GEMMs, KL / sample backward: ~0.1 ms of launches that
+        # leave the chip nearly idle — is the critical path: as a branch, joined by the end-of-pass weight-gradient launch.  Measured 3.177 -> 3.131 ms
+        # on one box and nothing on another (3.13 either way); on a THIRD cached stream of its own the branch made a later step-node capture's
+        # hipGraphLaunch segfault in every run of tests/test_trainer_gpu.py + tests/test_stepnode_gpu.py in that order (0 of 6 runs without it, 0 of 3
+        # on the encoder stream): off by default.
+        wg_fork = (kn.fork_branches() and kn.wgrad_branch_ok() and dev.type == "cuda" and ctx.persistent and not use_t
+                   and all(gradsink.get(t_) is not None for t_ in (w_ih1, b_ih1, w_hh1, b_hh1, w_hh0, b_hh0)))
+        if wg_fork:
+            # (on the gripper camera's encoder stream: idle between the encoders' forward and their backward at the end of the pass)
+            from .models.perceptual_encoders.concat_encoders import _encoder_side_stream
+            wg_s = _encoder_side_stream(dev)
+            cur_s = torch.cuda.current_stream(dev)
+            wg_s.wait_stream(cur_s)
+            with torch.cuda.stream(wg_s):
+                wgrad(d1w, zw[1:S + 1], Hd, w_ih1, b_ih1)
+                wgrad(d1w, zw[1:S + 1][:, :, Hd:], Hd, w_hh1, b_hh1)
+                wgrad(d0w, zw[0:S], Hd, w_hh0, b_hh0)
+            for t_ in (d1w, zw, d0w):
+                t_.record_stream(wg_s)
+            kn.note_producer_stream(dev, wg_s)
+            dw_ih1 = db_ih1 = dw_hh1 = db_hh1 = dw_hh0 = db_hh0 = None
         # layer 1: dW_ih1 = delta1^T h0_t, dW_hh1 = delta1^T h1_{t-1}   (zbuf[t+1] = [h0_t | h1_{t-1}]); both biases see delta1
-        if use_t:
+        elif use_t:
             dw_ih1, db_ih1 = wgrad_t(0, 1, 0, 1, Hd, w_ih1, b_ih1)                  # delta1 = d[1:S+1][:, :, :H], h0_t = z[1:S+1][:, :, :H]
             dw_hh1, db_hh1 = wgrad_t(0, 1, Hd, 1, Hd, w_hh1, b_hh1)                 # h1_{t-1} = z[1:S+1][:, :, H:]
             dw_hh0, db_hh0 = wgrad_t(Hd, 0, 0, 0, Hd, w_hh0, b_hh0)                 # delta0 = d[0:S][:, :, H:], h0_{t-1} = z[0:S][:, :, :H]

@@ -742,17 +742,79 @@ class coop_share_scope:
         _coop_share = self.old
 
 
+class no_gc:
+    """Around a hipGraph capture: cyclic garbage is collected BEFORE it and the collector stays off until it ends.  A collection that starts in
+    the middle of a capture (autograd's worker thread allocates Python objects all the time) finalises whatever garbage earlier steps left —
+    graphs, pooled tensors, events of other models — and a runtime call from such a finaliser while a capture is open aborts the process
+    (seen as `Fatal Python error: Aborted ... Garbage-collecting` inside a captured backward, once in a few runs)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 def fork_branches() -> bool:
     """run the prior and the posterior branch of a step on two streams (HULC_FORK=0: one after the other, as until round 5)"""
     import os
     return os.environ.get("HULC_FORK", "1") != "0" and not concurrent_streams() and _timing is None
 
 
-def branch_stream(device):
-    st = _branch_streams.get(device)
+_wgrad_branch = False
+
+
+class wgrad_branch_scope:
+    """ArenaTrainer's forward + backward: the recurrent weight gradients may run as a third branch (functional.DecoderRNNFn.backward)"""
+
+    def __enter__(self):
+        global _wgrad_branch
+        self.old, _wgrad_branch = _wgrad_branch, True
+
+    def __exit__(self, *exc):
+        global _wgrad_branch
+        _wgrad_branch = self.old
+
+
+def wgrad_branch_ok() -> bool:
+    import os
+    return _wgrad_branch and os.environ.get("HULC_WGRAD_FORK", "0") not in ("", "0")
+
+
+def branch_stream(device, which: int = 0):
+    """the stream of a forked branch of the step: 0 the posterior, 1 weight gradients that nothing downstream consumes"""
+    st = _branch_streams.get((device, which))
     if st is None:
-        st = _branch_streams[device] = torch.cuda.Stream(device=device)
+        st = _branch_streams[(device, which)] = capture_stream(device)      # (distinct from every other cached stream)
     return st
+
+
+def capture_stream(device):
+    """a stream to capture a graph on that is none of the cached branch / side streams.  torch.cuda.Stream() hands out the 32 streams of its pool
+    round-robin: after enough captures in one process the "new" stream IS one of the streams this module keeps for forked branches — a capture
+    whose origin stream doubles as one of its own branches (round 6: seen as a segfault in hipGraphLaunch of the graph captured that way)."""
+    taken = {st.cuda_stream for st in _branch_streams.values()}
+    try:
+        from .models.perceptual_encoders.concat_encoders import _side_streams
+        taken |= {st.cuda_stream for st in _side_streams.values()}
+    except Exception:                        # noqa: BLE001
+        pass
+    for _ in range(64):
+        st = torch.cuda.Stream(device=device)
+        if st.cuda_stream not in taken:
+            return st
+    return st
+
+
+def note_producer_stream(device, stream) -> None:
+    """work issued on `stream` writes gradients straight into the arena and feeds no autograd node: the end-of-pass weight-gradient launch
+    (wgrad_flush, before the optimizer / the end of a captured backward graph) joins it"""
+    _wg_streams.setdefault(device, set()).add(stream.cuda_stream)
 
 
 def _call_shared(share: int, name, *args, **kw):
@@ -782,7 +844,7 @@ def mlp_chain_ok(M: int, K0: int, widths, device, share=None) -> bool:
     if not (1 <= M <= 64) or not (1 <= len(widths) <= 8):
         return False
     share = _coop_share if share is None else share
-    if share > 1 and max(widths) > 16 * (256 // share):
+    if share == 0 or (share > 1 and max(widths) > 16 * (256 // share)):     # (0: a branch that runs beside a whole-device cooperative launch)
         return False
     k = K0
     for n in widths:
@@ -991,13 +1053,13 @@ def _wgrad_issue(dev) -> None:
     if True:
         q = _wg_pending.pop(dev, None)
         producers = _wg_streams.pop(dev, None)
-        if not q:
-            return
-        if producers:
+        if producers:                           # (also with nothing queued: a forked weight-gradient branch writes the arena by itself)
             here = _stream_of(dev)
             for h in producers:
                 if h != here and h != 0:
                     join_stream(dev, torch.cuda.ExternalStream(h, device=dev))
+        if not q:
+            return
         n = len(q)
         items = (_L.WgradItem * n)()
         flops = nbytes = 0.0

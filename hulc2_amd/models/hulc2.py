@@ -197,6 +197,7 @@ class Hulc2(LightningModule):
     def _training_step_impl(self, batch: Dict[str, Dict], batch_idx: int):
         """the arithmetic of training_step: -> (total loss, [(logged name, value, self.log keyword arguments)])"""
         kl_loss = action_loss = total_loss = lang_clip_loss = None
+        clip_forked = False
         batch_size: Dict[str, int] = {}
         total_bs = 0
 
@@ -280,15 +281,6 @@ class Hulc2(LightningModule):
                     t_.record_stream(cur)
             else:
                 pr_all, seq_all = self.plan_recognition(emb_rec)
-            # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality.  Sample + KL are ONE
-            # autograd node (both consume the posterior's logits: their gradients meet inside the kernels, not in a fan-in add)
-            idxs = [db.get("plan_idx") for _, db in mods]
-            idx_all = torch.cat(idxs, dim=0) if all(i is not None for i in idxs) else None
-            plan_all, _, kls = self.dist.rsample_plan_and_kl(pp_all, pr_all, 0xA11CE, idx_all, self.kl_beta, self.kl_balancing_mix, len(mods))
-            kl_stacked = kls
-            act_losses = self.action_decoder.loss_stacked(plan_all, emb_dec_t if fan else emb_all, goal_all,
-                                                          [db["actions"] for _, db in mods], [db["state_info"]["robot_obs"] for _, db in mods],
-                                                          len(mods), emb_tm=fan)
             # the contrastive head sees the stacked rows when the language modality is the last segment: rows below row0 are masked out inside the
             # loss kernel (their gradient is exactly zero) — no slice of the pooled features / goals, no gradient scatter on the way back
             lang_ix = [i for i, (sc, _) in enumerate(mods) if "lang" in sc]
@@ -299,6 +291,28 @@ class Hulc2(LightningModule):
                 else:
                     per.append((self.modality_scope, db, None, goals[i] if goals[i] is not None else goal_all[i * B:(i + 1) * B],
                                 seq_all[i * B:(i + 1) * B], None, None))
+            # round 6: the contrastive head (two projections + the loss, forward and backward ~0.15 ms of small launches) needs the pooled
+            # posterior features and the goals only — it runs as a branch beside sample / KL / the decoder's input projections, and its backward
+            # beside the start of the decoder's.  The recurrent sweeps take every CU while they run, so nothing in this branch may be a
+            # cooperative launch (coop_share_scope(0): the projections' chains fall back to GEMMs — a chain spinning on some CUs while the sweep
+            # waits for all of them would never finish).
+            if fork and self.use_clip_auxiliary_loss and any("lang" in p_[0] for p_ in per) and not os.environ.get("HULC_NO_CLIP_FORK"):
+                side.wait_stream(cur)
+                with torch.cuda.stream(side), kn.coop_share_scope(0):
+                    for (scope_, db_, _e, goal_, seqf_, plan_, _k) in per:
+                        if "lang" in scope_:
+                            lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seqf_, goal_, db_["use_for_aux_lang_loss"],
+                                                                                          row0=plan_ if isinstance(plan_, int) else 0))
+                clip_forked = True
+            # sample, KL and decoder once over the stacked rows; the KL / decoder kernels return one mean per modality.  Sample + KL are ONE
+            # autograd node (both consume the posterior's logits: their gradients meet inside the kernels, not in a fan-in add)
+            idxs = [db.get("plan_idx") for _, db in mods]
+            idx_all = torch.cat(idxs, dim=0) if all(i is not None for i in idxs) else None
+            plan_all, _, kls = self.dist.rsample_plan_and_kl(pp_all, pr_all, 0xA11CE, idx_all, self.kl_beta, self.kl_balancing_mix, len(mods))
+            kl_stacked = kls
+            act_losses = self.action_decoder.loss_stacked(plan_all, emb_dec_t if fan else emb_all, goal_all,
+                                                          [db["actions"] for _, db in mods], [db["state_info"]["robot_obs"] for _, db in mods],
+                                                          len(mods), emb_tm=fan)
         else:
             for self.modality_scope, db in mods:
                 with kn.site_scope("enc"):
@@ -320,8 +334,9 @@ class Hulc2(LightningModule):
             if "lang" in self.modality_scope:
                 batch_size["aux_lang"] = 1
                 if self.use_clip_auxiliary_loss:
-                    row0 = plan if (kl_stacked is not None and isinstance(plan, int)) else 0        # (stacked rows: see `stacked_head` above)
-                    lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"], row0=row0))
+                    if not clip_forked:
+                        row0 = plan if (kl_stacked is not None and isinstance(plan, int)) else 0    # (stacked rows: see `stacked_head` above)
+                        lang_clip_loss = acc(lang_clip_loss, self.clip_auxiliary_loss(seq_feat, latent_goal, db["use_for_aux_lang_loss"], row0=row0))
                     # hulc2.py:391-394: the epoch mean of train/lang_clip_loss is weighted by the number of masked-in rows (1 when there are
                     # none) — counted by the loss kernel, a device value (no torch.any / torch.sum host round trip)
                     batch_size["aux_lang"] = self._aux_lang_rows
@@ -329,6 +344,9 @@ class Hulc2(LightningModule):
             batch_size[self.modality_scope] = bs
             total_bs += bs
         n = len(batch)
+        if clip_forked:
+            cur.wait_stream(side)
+            lang_clip_loss.record_stream(cur)
         kl_vec = kl_stacked if kl_stacked is not None else torch.stack([p[6].reshape(()) for p in per])
         act_vec = act_losses if act_losses.dim() == 1 else act_losses.reshape(-1)
         clip_term = lang_clip_loss if (self.use_clip_auxiliary_loss and lang_clip_loss is not None) else None

@@ -19,7 +19,8 @@ _side_streams = {}
 def _encoder_side_stream(device):
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        from hulc2_amd import kernels as kn
+        st = _side_streams[device] = kn.capture_stream(device)       # (none of the other cached streams: kernels.capture_stream)
     return st
 
 

@@ -380,7 +380,7 @@ class StepNode:
         dev = self.dev
         torch.cuda.synchronize(dev)
         cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
+        side = kn.capture_stream(dev)
         words = kn.step_state(dev).clone()
         one = torch.ones((), dtype=torch.float32, device=dev)
         # frame slots: which of the batch's tensors would conv1's band launches read through device pointer slots?  (recorded by the warm-up)
@@ -421,10 +421,11 @@ class StepNode:
             if slot_idx:
                 kn._frame_slots = {statics[i].data_ptr(): table.data_ptr() + 8 * i for i in slot_idx}
                 kn._frame_slots_used = set()
-            with torch.cuda.graph(g_f, stream=side, **mode):
-                loss, logs = self._inner_forward(cap_batch, batch_idx)
-            with torch.cuda.graph(g_b, pool=g_f.pool(), stream=side, **mode):
-                outs = self._inner_backward(loss, self.static_g, leaves=aliases)
+            with kn.no_gc():
+                with torch.cuda.graph(g_f, stream=side, **mode):
+                    loss, logs = self._inner_forward(cap_batch, batch_idx)
+                with torch.cuda.graph(g_b, pool=g_f.pool(), stream=side, **mode):
+                    outs = self._inner_backward(loss, self.static_g, leaves=aliases)
         finally:
             kn._frame_slots = None
             for mod, name, i in slots:

@@ -932,8 +932,9 @@ class ArenaTrainer:
         kn.wgrad_reset(self.dev)
         self.zero_grad()
         loss = self.model.training_step(batch, batch_idx)
-        torch.autograd.backward(loss, grad_tensors=self._one_like(loss))
-        kn.wgrad_flush(self.dev)
+        with kn.wgrad_branch_scope():          # (the recurrent weight gradients as a third branch of this graph: functional.DecoderRNNFn.backward)
+            torch.autograd.backward(loss, grad_tensors=self._one_like(loss))
+            kn.wgrad_flush(self.dev)
         return loss.detach()
 
     def _one_like(self, loss: torch.Tensor) -> torch.Tensor:
@@ -1009,7 +1010,7 @@ class ArenaTrainer:
         self.comm.reserve()
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
+        side = kn.capture_stream(self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                # AccumulateGrad nodes must be born on the capture stream
             for i in range(2):
@@ -1019,19 +1020,20 @@ class ArenaTrainer:
         self.graph_fb = torch.cuda.CUDAGraph()
         # world > 1: the process group's watchdog thread may touch the runtime while this thread captures; only this thread's calls are policed
         mode = {"capture_error_mode": os.environ.get("HULC_CAPTURE_MODE", "thread_local")} if self.multi else {}
-        if self.multi and self.enc_hi > self.enc_lo and not os.environ.get("HULC_NO_SPLIT_GRAPH"):
-            # two graphs around the split point; replay() launches the big all-reduce between them on the comm stream
-            with torch.cuda.graph(self.graph_fb, stream=side, **mode):
-                self.static_loss = self._forward_backward_head(batch, 0)
-            self.graph_enc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_enc, pool=self.graph_fb.pool(), stream=side, **mode):
-                self._backward_encoder()
-        else:
-            with torch.cuda.graph(self.graph_fb, stream=side, **mode):
-                self.static_loss = self._forward_backward(batch, 0)
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), stream=side, **mode):
-            self.optimizer_step()
+        with kn.no_gc():                             # (no garbage collection inside a capture: see kernels.no_gc)
+            if self.multi and self.enc_hi > self.enc_lo and not os.environ.get("HULC_NO_SPLIT_GRAPH"):
+                # two graphs around the split point; replay() launches the big all-reduce between them on the comm stream
+                with torch.cuda.graph(self.graph_fb, stream=side, **mode):
+                    self.static_loss = self._forward_backward_head(batch, 0)
+                self.graph_enc = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_enc, pool=self.graph_fb.pool(), stream=side, **mode):
+                    self._backward_encoder()
+            else:
+                with torch.cuda.graph(self.graph_fb, stream=side, **mode):
+                    self.static_loss = self._forward_backward(batch, 0)
+            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), stream=side, **mode):
+                self.optimizer_step()
         torch.cuda.synchronize()
 
     def replay(self) -> torch.Tensor:
