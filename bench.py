@@ -877,6 +877,11 @@ def main():
         "config": {"workload": workload,
                    "sequences_per_gpu_step": (1 if args.affordance else 2) * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay (fwd+bwd graph, all-reduce, optimizer graph)" if use_graph else "eager launches",
+                   # round 6: independent branches of the step as branches of the captured graph (HULC_FORK=0: one chain, as until round 5)
+                   "graph_branches": ("camera encoders x 2; posterior (transformer trunk + head) || goal encoders + prior, forward and backward, each on half "
+                                      "of the device (hulc_set_coop_share 2); contrastive head || sample / KL / decoder projections"
+                                      + ("; recurrent weight gradients || data-gradient chain" if kn.wgrad_branch_ok() or os.environ.get("HULC_WGRAD_FORK", "0") not in ("", "0") else ""))
+                                     if kn.fork_branches() else "camera encoders x 2 only (HULC_FORK=0)",
                    "frames": "HBM-resident uint8 episode store, new play windows (20..32 steps, padded by repetition) every step, conv1 reads "
                              "the store through index rows" if args.episode_store
                              else "uint8 NHWC + RandomShiftsAug offsets, scaled/normalised while staging conv1" if args.uint8_frames

@@ -49,5 +49,7 @@ HULC_DEVICE uint4 band_load_x(const void* X, long off) {
 
 // conv_band4.hip: 0 = launched, -1 = geometry / options not covered (the caller tries the other kernels), -2 = LDS limit could not be raised
 int launch_band4(BandP& p, int C, int NSET, int TH, int TW, int S, hipStream_t s);
+// conv_band_planes.hip (direct-to-LDS loads into a chunk-major band, 64 input channels, the static camera's frame sizes): 0 = launched, -1 = not covered
+int launch_band_planes(BandP& p, int NSET, int TH, int TW, hipStream_t s);
 
 }  // namespace hulc_band

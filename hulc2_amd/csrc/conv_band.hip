@@ -626,6 +626,11 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
         // (conv_band_glds_kernel; HULC_BAND_GLDS=0: the register-staged kernel; small maps pack several frames into a unit there)
         static const char* ge = getenv("HULC_BAND_GLDS");
         rc = -1;
+        {   // round 6: the chunk-major direct-to-LDS band (conv_band_planes.hip): fragment reads without address arithmetic
+            const char* pe = getenv("HULC_BAND_PLANES");       // (read per launch: the tests switch inside one process)
+            if (pe && atoi(pe) && !(ge && !atoi(ge))) rc = launch_band_planes(p, NSET, TH, TW, s);
+        }
+        if (rc == -1) {
         const bool contiguous = x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && ((uintptr_t)x % 16) == 0;
         if (!(ge && !atoi(ge)) && !mask_only(mask, bits_in) && !add && !bits_out && x_dtype == HULC_BF16 && y_dtype == HULC_BF16 && contiguous &&
             (long)p.OHmax * p.OWmax >= 256 && !p.dbg) {
@@ -633,6 +638,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
             if (NSET == 2 && !padded && !bits_in) rc = launch_band_glds<2, 3, 3, 0, false>(p, s);
             else if (NSET == 2 && padded && bits_in) rc = launch_band_glds<2, 3, 3, 2, true>(p, s);
             else if (NSET == 4 && padded && bits_in) rc = launch_band_glds<4, 2, 2, 2, true>(p, s);
+        }
         }
         if (rc == -1) rc = NSET == 2 ? launch_band<64, 2, 3, 3, 1, 10, 2, 9>(p, s) : launch_band<64, 4, 2, 2, 1, 12, 2, 9>(p, s);
     }

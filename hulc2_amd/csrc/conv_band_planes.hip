@@ -1,0 +1,236 @@
+// conv_band_planes.hip — the direct-to-LDS band convolution with a CHUNK-MAJOR band (round 6).
+//
+// reference arithmetic: nn.Conv2d(+ReLU) of hulc2/models/perceptual_encoders/vision_network.py:41-46 (conv3 of the static camera) and
+// autograd's conv2d input gradient of conv3 / conv2.
+//
+// conv_band_glds_kernel (conv_band.hip) fills its band pixel-major (128-byte pixels, no padding possible: a direct load writes 1 KB of
+// consecutive LDS) and spreads the fragment reads over the banks with an XOR swizzle on the source address — which every fragment read
+// then has to undo: ~3 vector instructions per MFMA in a loop whose MFMAs and VALU share the SIMD's issue slot (252 MFMAs + ~1640 VALU per
+// SIMD and frame in conv3's forward: 4.4 + 3 us of the 8.8 us a unit takes).  tools/probe/mfma_lds_probe.hip: the LDS itself is not what
+// such a loop waits for.  Here the band is EIGHT PLANES, one per 16-byte channel chunk: plane c holds chunk c of every pixel, 16 bytes per
+// pixel, pixels in frame order.
+//   * a fragment read of 64 lanes = 64 (mostly consecutive) pixels of one plane = consecutive 16-byte slots: conflict-free without a swizzle;
+//   * with the frame width a template parameter the address of tap (ty, tx), chunk 2 kc + h is  lane base + IMMEDIATE: the MFMA loop is
+//     MFMA + ds_read_b128 + s_waitcnt, no VALU (conv_band4.hip's loop, kept at two 256-register waves per SIMD so that the phases of a unit
+//     still hide behind the other wave);
+//   * a direct load instruction takes 64 consecutive pixels of ONE chunk: 64 lanes x 16 bytes, 128 bytes apart in memory (64 cache lines per
+//     instruction instead of 8; the eight instructions of a pixel group hit the same lines back to back, wave w = chunk w);
+//   * zero padding (data gradients) stays the ONE zero pixel behind every plane; a tap outside the frame is redirected per TAP (one select per
+//     tap and lane instead of per k-step).
+// Everything else — two static LDS bands, one raw barrier per unit, weights parked through the band arrays in the prologue, sign planes fetched
+// a unit ahead, packed-word epilogue — is conv_band_glds_kernel's.  bf16 in / out, whole frames per unit, 64 input channels.
+#include "hulc_common.h"
+#include "hulc_abi_internal.h"
+#include "conv_band.h"
+#include <stdlib.h>
+
+using namespace hulc_band;
+
+namespace {
+
+constexpr int PL_BAND_BYTES = 69 * 1024;       // 8 planes x (23 x 23 + 1) pixels x 16 B = 67 840 B, rounded up
+
+// NSET weight sets (32 output channels each), TH x TW taps, HIN x WIN input frame (compile time), BITS = 2: sign-plane words mask the result,
+// PAD: taps may fall outside the frame (data gradients)
+template <int NSET, int TH, int TW, int HIN, int WIN, int BITS, bool PAD>
+__global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
+    constexpr int C = 64, CPP = 8;
+    constexpr int K = TH * TW * C, KSTEPS = K / 16, WPS = 8 / NSET;
+    constexpr int SPA = NSET / 2;                           // weight sets parked per band array in the prologue
+    constexpr int P = HIN * WIN;                            // pixels of a frame; pixel P of every plane is the zero pixel
+    constexpr int PLANE = (P + 1) * 16;                     // bytes of one chunk plane
+    constexpr int NG = (P + 63) / 64;                       // 64-pixel groups = direct-load instructions per plane
+    static_assert(CPP * PLANE <= PL_BAND_BYTES, "a frame fits a band");
+    __shared__ __attribute__((aligned(2048))) float sbias[BAND_MAXCLS * 32 + 384];
+    __shared__ __attribute__((aligned(256))) char bandA_[PL_BAND_BYTES];
+    __shared__ __attribute__((aligned(256))) char bandB_[PL_BAND_BYTES];
+    constexpr int MAXTW = BITS == 2 ? (NSET == 2 ? 6 : 12) : 1;             // tiles of one wave per unit that carry a sign-plane word
+    __shared__ unsigned smask[8][MAXTW][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int set = wave % NSET, part = wave / NSET;
+    const BandCls& cl = p.cls[set];
+    const int cl_OH = cl.OH, cl_OW = cl.OW, cl_co = cl.co_base;
+    const long cl_yoff = cl.y_off;
+    const float inv_OW = __builtin_amdgcn_rcpf((float)cl_OW);
+    const int nunits = p.Nimg;
+    const int npix = cl_OH * cl_OW, ntile = (npix + 31) / 32;
+
+    // ---- prologue: weights once through LDS (as conv_band_kernel), SPA sets per (still empty) band array
+    constexpr int RPI = 64 / CPP, WITEMS = (32 / RPI) * TH * TW, NW = (WITEMS + WPS - 1) / WPS, WS = K * 2 + 16;
+    static_assert((long)SPA * 32 * WS <= PL_BAND_BYTES, "the parked weights fit a band array");
+    char* const wpark = ((set / SPA) ? bandB_ : bandA_) + (set % SPA) * 32 * WS;
+    uint4 wtmp[NW];
+    {
+        const int wrow = lane / CPP, wc = lane % CPP;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS, itc = it < WITEMS ? it : WITEMS - 1;
+            const int rg = itc / (TH * TW), t = itc % (TH * TW);
+            wtmp[i] = band_load_bits(p.Wt, (cl.w_row0 + rg * RPI + wrow) * p.ldw + cl.w_tap_off[t] + wc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int it = part + i * WPS;
+            if (it < WITEMS) {
+                const int rg = it / (TH * TW), t = it % (TH * TW);
+                *(uint4*)(wpark + (rg * RPI + wrow) * WS + (t * C + wc * 8) * 2) = wtmp[i];
+            }
+        }
+    }
+    if (tid < NSET * 32) sbias[tid] = p.bias ? p.bias[p.cls[tid >> 5].co_base + (tid & 31)] : 0.f;
+    __syncthreads();
+    bf16x8_t wfrag[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)(wpark + r * WS + (ks * 16 + h * 8) * 2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+    __syncthreads();
+    if (PAD && tid < 16) *(uint4*)((tid < 8 ? bandA_ : bandB_) + (tid & 7) * PLANE + P * 16) = make_uint4(0u, 0u, 0u, 0u);   // the zero pixels (never written again)
+
+    // direct loads of one frame: wave w fills plane w (chunk w of every pixel), 64 consecutive pixels per instruction
+    auto glds_band = [&](int unit, char* band) {
+        const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn + wave * 8;
+        char* plane = band + wave * PLANE;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int q = g * 64 + lane;
+            if (q < P)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C),
+                                                 (void __attribute__((address_space(3)))*)(plane + g * 1024), 16, 0, 0);
+        }
+    };
+    unsigned mbn[MAXTW];
+    auto mask_park = [&]() {
+        if (BITS == 2 && lane < 32) {
+#pragma unroll
+            for (int i = 0; i < MAXTW; ++i) smask[wave][i][lane] = mbn[i];
+        }
+    };
+    auto mask_fetch = [&](int unit) {
+#pragma unroll
+        for (int i = 0; i < MAXTW; ++i) {
+            const int tile = part + i * WPS;
+            int q = tile * 32 + r;
+            q = q < npix ? q : npix - 1;
+            if (tile >= ntile) q = 0;
+            const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
+            const long pix_off = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx;
+            mbn[i] = p.bits_in[(long)(cl_co >> 5) * p.bplane + (pix_off >> p.bshift)];
+        }
+    };
+
+    int unit = blockIdx.x;
+    if (BITS == 2 && unit < nunits) mask_fetch(unit);
+    if (unit < nunits) glds_band(unit, bandA_);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) — the BUILTIN (the compiler's wait-count bookkeeping sees it)
+    mask_park();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the zero pixels are in LDS before anybody passes the (raw) barrier
+    __builtin_amdgcn_s_barrier();
+    auto do_unit = [&](int unit, const char* __restrict__ band, char* __restrict__ band_next) {
+        const int next = unit + gridDim.x;
+        if (BITS == 2 && next < nunits) mask_fetch(next);         // requested BEFORE the direct loads, parked behind the closing wait, used a unit later
+        if (next < nunits) glds_band(next, band_next);        // lands while this unit is multiplied
+
+        auto do_tile = [&](int tile, unsigned mb_in) {
+            int q = tile * 32 + r;
+            const bool live = q < npix;
+            if (!live) q = npix - 1;
+            const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
+            const char* lane_base = band + h * PLANE;         // (chunk 2 kc + h: the lane half picks the odd planes)
+            // band pixel of tap (ty, tx) = (oy + ty - pad_y) * WIN + (ox + tx - pad_x), or the zero pixel outside the frame
+            const int q0 = (oy - p.pad_y) * WIN + (ox - p.pad_x);
+            const char* tap_base[PAD ? TH * TW : 1];
+            if (PAD) {
+#pragma unroll
+                for (int ty = 0; ty < TH; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < TW; ++tx) {
+                        const int iy = oy + ty - p.pad_y, ix = ox + tx - p.pad_x;
+                        const bool in = iy >= 0 && iy < HIN && ix >= 0 && ix < WIN;
+                        tap_base[ty * TW + tx] = lane_base + (in ? q0 + ty * WIN + tx : P) * 16;
+                    }
+            } else {
+                tap_base[0] = lane_base + q0 * 16;
+            }
+            f32x16_t acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(sbias + set * 32 + 8 * g + 4 * h);
+                acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+            }
+            constexpr int RD = 8;
+            auto frag = [&](int ks) {
+                const int k0 = ks * 16, t = k0 / C, kc = (k0 % C) / 16;
+                const int ty = t / TW, tx = t % TW;
+                if (PAD) return *(const bf16x8_t*)(tap_base[t] + 2 * kc * PLANE);
+                return *(const bf16x8_t*)(tap_base[0] + (ty * WIN + tx) * 16 + 2 * kc * PLANE);
+            };
+            bf16x8_t pf[RD];
+#pragma unroll
+            for (int i = 0; i < RD; ++i) pf[i] = frag(i);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const bf16x8_t px = pf[ks % RD];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ks], px, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + RD < KSTEPS) pf[ks % RD] = frag(ks + RD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const long off0 = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
+            uint2 pk[4];
+            const uint32_t floor2 = p.relu ? 0u : 0x80008000u;  // (ReLU on the packed words: see conv_band_kernel's epilogue)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pk[g] = make_uint2(max_s16x2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), floor2), max_s16x2(pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]), floor2));
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * gp].x, pk[2 * gp + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * gp].y, pk[2 * gp + 1].y, false, false);
+                uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};                 // channels co_base + 16 gp + 8 h + {0..7}
+                if (BITS == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = keep_u16x2(o[e], (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u);
+                }
+                if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        };
+        int ti = 0;
+        for (int tile = part; tile < ntile; tile += WPS, ++ti) do_tile(tile, BITS == 2 ? smask[wave][ti][r] : 0u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the next band has landed (and this unit's stores are acknowledged)
+        if (next < nunits) mask_park();
+        __builtin_amdgcn_s_barrier();                          // every wave is done reading this band
+    };
+    for (; unit < nunits; unit += 2 * gridDim.x) {
+        do_unit(unit, bandA_, bandB_);
+        if (unit + (int)gridDim.x < nunits) do_unit(unit + gridDim.x, bandB_, bandA_);
+    }
+}
+
+template <int NSET, int TH, int TW, int HIN, int WIN, int BITS, bool PAD>
+int launch_planes(BandP& p, hipStream_t s) {
+    const long npix = (long)p.OHmax * p.OWmax;
+    if (BITS == 2 && (npix + 31) / 32 > (long)(NSET == 2 ? 6 : 12) * (8 / NSET)) return -1;      // the per-wave sign-word registers cover a unit's tiles
+    const int nunits = p.Nimg, per = (nunits + 255) / 256, grid = (nunits + per - 1) / per;
+    conv_band_planes_kernel<NSET, TH, TW, HIN, WIN, BITS, PAD><<<grid, 512, 0, s>>>(p);
+    return 0;
+}
+
+}  // namespace
+
+namespace hulc_band {
+
+// 0 = launched, -1 = not covered (the caller goes on to the other band kernels)
+int launch_band_planes(BandP& p, int NSET, int TH, int TW, hipStream_t s) {
+    if (p.x_dtype != HULC_BF16 || p.y_dtype != HULC_BF16 || p.w_dtype != HULC_BF16 || p.add || p.bits_out || (p.mask && !p.bits_in) || p.dbg) return -1;
+    if (p.x_sx != 64 || p.x_sy != (long)p.W * 64 || p.x_sn != (long)p.H * p.W * 64 || ((uintptr_t)p.X % 16) != 0) return -1;
+    const bool padded = p.pad_y != 0 || p.pad_x != 0;
+    if (NSET == 2 && TH == 3 && TW == 3 && !padded && !p.bits_in && p.H == 23 && p.W == 23)                          // conv3 forward
+        return launch_planes<2, 3, 3, 23, 23, 0, false>(p, s);
+    if (NSET == 2 && TH == 3 && TW == 3 && p.pad_y == 2 && p.pad_x == 2 && p.bits_in && p.H == 21 && p.W == 21)      // conv3 data gradient
+        return launch_planes<2, 3, 3, 21, 21, 2, true>(p, s);
+    if (NSET == 4 && TH == 2 && TW == 2 && p.pad_y == 1 && p.pad_x == 1 && p.bits_in && p.H == 23 && p.W == 23)      // conv2 data gradient
+        return launch_planes<4, 2, 2, 23, 23, 2, true>(p, s);
+    return -1;
+}
+
+}  // namespace hulc_band
