@@ -25,6 +25,7 @@
 // once per launch: the protocol of mlp_chain.hip) and summed in workgroup order by all Q, which then continue in lock step.  Tensors every
 // member computes are stored by every member (identical values).  Like mlp_chain this needs its workgroups co-resident: the launcher picks
 // Q > 1 only when the whole grid fits the device, and a member that waits too long sets bit 2 of the sticky fault word.
+#include <stdio.h>
 #include "hulc_common.h"
 #include "hulc_abi_internal.h"
 #include "txl_attn.h"

@@ -196,7 +196,7 @@ class StepNode:
         So: keep a copy of what is there (ONE copy of the arena), detach those `.grad`s, let the backward overwrite, add the copy back in
         (_give_back_live_grads, one launch): autograd then installs the views again and `.grad` = old + new, bit for bit what the plain loop's
         accumulation gives (zeros + new = new).  A `.grad` that lives elsewhere (DDP's bucket views, a user's tensor) is left alone:
-        AccumulateGrad adds into it as always.  ~0.2 ms per step on this path; `set_to_none=True` costs nothing."""
+        AccumulateGrad adds into it as always.  A copy and an add of the arena per step on this path; `set_to_none=True` costs nothing."""
         tr = self.keeper
         lo = tr.flat_g.data_ptr()
         hi = lo + tr.flat_g.numel() * 4
@@ -226,18 +226,42 @@ class StepNode:
             # the old values go back into the slices of the parameters they were taken from — and nowhere else: the slice of a parameter whose
             # `.grad` lives outside the arena (AccumulateGrad cloned instead of adopting the view) is never zeroed by zero_grad, what a copy of
             # the arena holds there is the previous step's gradient
-            dst, src = [], []
+            taken_idx = {i for i, _ in taken}
+            in_arena, dst, src = [], [], []
             for i, g in taken:
                 o = outs[i]
                 off = tr.offsets[i]
                 if o is None:                                     # no gradient for this parameter in this pass: what was attached stays attached
                     g.copy_(prev[off:off + g.numel()].view(g.shape))
                     tr.params[i].grad = g
-                else:                                             # the arena view, or a sum autograd made next to it (view + its own term)
+                elif o.data_ptr() == self.views[i].data_ptr():
+                    in_arena.append(i)                            # the arena view itself
+                else:                                             # a sum autograd made next to the arena (view + its own term)
                     dst.append(o)
                     src.append(prev[off:off + o.numel()].view(o.shape))
-            if dst:
-                torch._foreach_add_(dst, src)
+            # the arena views: ONE add over the whole arena once the copy is zero wherever it must not land (the slices of parameters that were
+            # not taken — a handful: per-tensor adds over ~100 views cost 0.6 ms of launches, this costs the two passes)
+            # (must be zero in the copy: slices the backward wrote for a parameter that was NOT taken, and the taken ones handled above;
+            #  a parameter without a gradient this step and without an attached one has an all-zero slice on both sides)
+            skip = [i for i in range(len(tr.params))
+                    if (i in taken_idx and (outs[i] is None or outs[i].data_ptr() != self.views[i].data_ptr()))
+                    or (i not in taken_idx and outs[i] is not None)]
+            if len(skip) <= 16:
+                for i in skip:
+                    off = tr.offsets[i]
+                    if not any(outs[i] is d_ for d_ in dst):      # (its copy is still needed by the per-tensor add below)
+                        prev[off:off + tr.params[i].numel()].zero_()
+                if dst:
+                    torch._foreach_add_(dst, src)
+                    for i in skip:
+                        off = tr.offsets[i]
+                        prev[off:off + tr.params[i].numel()].zero_()
+                tr.flat_g.add_(prev)
+            else:
+                dst += [self.views[i] for i in in_arena]
+                src += [prev[tr.offsets[i]:tr.offsets[i] + self.views[i].numel()].view(self.views[i].shape) for i in in_arena]
+                if dst:
+                    torch._foreach_add_(dst, src)
         for i, g, old in others:
             if outs[i] is None:
                 g.copy_(old)
