@@ -7,16 +7,16 @@
 // consecutive LDS) and spreads the fragment reads over the banks with an XOR swizzle on the source address — which every fragment read
 // then has to undo: ~3 vector instructions per MFMA in a loop whose MFMAs and VALU share the SIMD's issue slot (252 MFMAs + ~1640 VALU per
 // SIMD and frame in conv3's forward: 4.4 + 3 us of the 8.8 us a unit takes).  tools/probe/mfma_lds_probe.hip: the LDS itself is not what
-// such a loop waits for.  Here the band is EIGHT PLANES, one per 16-byte channel chunk: plane c holds chunk c of every pixel, 16 bytes per
-// pixel, pixels in frame order.
-//   * a fragment read of 64 lanes = 64 (mostly consecutive) pixels of one plane = consecutive 16-byte slots: conflict-free without a swizzle;
-//   * with the frame width a template parameter the address of tap (ty, tx), chunk 2 kc + h is  lane base + IMMEDIATE: the MFMA loop is
-//     MFMA + ds_read_b128 + s_waitcnt, no VALU (conv_band4.hip's loop, kept at two 256-register waves per SIMD so that the phases of a unit
-//     still hide behind the other wave);
-//   * a direct load instruction takes 64 consecutive pixels of ONE chunk: 64 lanes x 16 bytes, 128 bytes apart in memory (64 cache lines per
-//     instruction instead of 8; the eight instructions of a pixel group hit the same lines back to back, wave w = chunk w);
-//   * zero padding (data gradients) stays the ONE zero pixel behind every plane; a tap outside the frame is redirected per TAP (one select per
-//     tap and lane instead of per k-step).
+// such a loop waits for.  First attempt (eight whole-frame planes, one per 16-byte chunk: fragment reads = base + immediate, ZERO VALU in the
+// loop): no faster — a direct load then takes 64 pixels of one chunk, 64 cache lines per instruction, and the phase stamps (HULC_BAND_STAMPS)
+// showed the second wave of every SIMD spending 6 300 of a unit's 15 400 cycles ISSUING its nine loads (address processing, 64 lines each).
+// What ships in this file: blocks of 8 pixels, chunk-major INSIDE the 1 KB block —
+//   * a direct load = the 1 KB of 8 consecutive pixels, 8 cache lines, as in the pixel-major kernel;
+//   * slot s of block b holds chunk s ^ (b & 1) (picked on the source side): the 16 lanes of a read group — two blocks, one chunk — use both
+//     halves of the bank row: conflict-free;
+//   * the address of chunk 2 kc + h at tap (ty, tx) = per-lane TAP base + kc * 256 (immediate): ~6 VALU per tap and tile instead of ~5 per tap
+//     + 2 per k-step;
+//   * zero padding (data gradients) = ONE zero pixel behind the frame; a tap outside the frame is redirected when its base is formed.
 // Everything else — two static LDS bands, one raw barrier per unit, weights parked through the band arrays in the prologue, sign planes fetched
 // a unit ahead, packed-word epilogue — is conv_band_glds_kernel's.  bf16 in / out, whole frames per unit, 64 input channels.
 #include "hulc_common.h"
@@ -32,15 +32,14 @@ constexpr int PL_BAND_BYTES = 69 * 1024;       // 8 planes x (23 x 23 + 1) pixel
 
 // NSET weight sets (32 output channels each), TH x TW taps, HIN x WIN input frame (compile time), BITS = 2: sign-plane words mask the result,
 // PAD: taps may fall outside the frame (data gradients)
-template <int NSET, int TH, int TW, int HIN, int WIN, int BITS, bool PAD>
-__global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
+template <int NSET, int TH, int TW, int HIN, int WIN, int BITS, bool PAD, bool STAMP = false>
+__global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned long long* stamps = nullptr) {
     constexpr int C = 64, CPP = 8;
     constexpr int K = TH * TW * C, KSTEPS = K / 16, WPS = 8 / NSET;
     constexpr int SPA = NSET / 2;                           // weight sets parked per band array in the prologue
-    constexpr int P = HIN * WIN;                            // pixels of a frame; pixel P of every plane is the zero pixel
-    constexpr int PLANE = (P + 1) * 16;                     // bytes of one chunk plane
-    constexpr int NG = (P + 63) / 64;                       // 64-pixel groups = direct-load instructions per plane
-    static_assert(CPP * PLANE <= PL_BAND_BYTES, "a frame fits a band");
+    constexpr int P = HIN * WIN;                            // pixels of a frame; pixel P is the zero pixel
+    constexpr int NBLK = (P + 1 + 7) / 8;                   // 1 KB blocks of 8 pixels (the zero pixel included) = direct-load instructions per band
+    static_assert(NBLK * 1024 <= PL_BAND_BYTES, "a frame fits a band");
     __shared__ __attribute__((aligned(2048))) float sbias[BAND_MAXCLS * 32 + 384];
     __shared__ __attribute__((aligned(256))) char bandA_[PL_BAND_BYTES];
     __shared__ __attribute__((aligned(256))) char bandB_[PL_BAND_BYTES];
@@ -85,18 +84,24 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
     for (int ks = 0; ks < KSTEPS; ++ks) wfrag[ks] = *(const bf16x8_t*)(wpark + r * WS + (ks * 16 + h * 8) * 2);
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
     __syncthreads();
-    if (PAD && tid < 16) *(uint4*)((tid < 8 ? bandA_ : bandB_) + (tid & 7) * PLANE + P * 16) = make_uint4(0u, 0u, 0u, 0u);   // the zero pixels (never written again)
+    // band layout: blocks of 8 pixels, 1 KB each; inside a block CHUNK-major — slot s (128 bytes) holds, for the block's 8 pixels, 16-byte chunk
+    // s ^ (block & 1) — so that (a) one direct-load instruction = the 1 KB of 8 consecutive pixels in memory (fully coalesced: 8 cache lines) and
+    // (b) the 16 lanes of a fragment-read group (two blocks, same chunk) fall on the two different halves of the 256-byte bank row.
+    // chunk c = 2 kc + h of pixel q:  (q >> 3) * 1024 + ((c ^ ((q >> 3) & 1)) << 7) + (q & 7) * 16  =  tap base (per lane and tap) + kc * 256
+    if (PAD && tid < 16) {                                   // the zero pixels (never written again: the last block's load stops in front of them)
+        char* b = tid < 8 ? bandA_ : bandB_;
+        *(uint4*)(b + (P >> 3) * 1024 + ((tid & 7) << 7) + (P & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
 
-    // direct loads of one frame: wave w fills plane w (chunk w of every pixel), 64 consecutive pixels per instruction
+    // direct loads of one frame: block i by wave i % 8; lane = (slot, pixel of the block), the slot's chunk picked on the SOURCE side
     auto glds_band = [&](int unit, char* band) {
-        const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn + wave * 8;
-        char* plane = band + wave * PLANE;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int q = g * 64 + lane;
+        const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn;
+        const int slot = lane >> 3, pj = lane & 7;
+        for (int i = wave; i < NBLK; i += 8) {
+            const int q = i * 8 + pj;
             if (q < P)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C),
-                                                 (void __attribute__((address_space(3)))*)(plane + g * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C + ((slot ^ (i & 1)) << 3)),
+                                                 (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
         }
     };
     unsigned mbn[MAXTW];
@@ -106,7 +111,9 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
             for (int i = 0; i < MAXTW; ++i) smask[wave][i][lane] = mbn[i];
         }
     };
-    auto mask_fetch = [&](int unit) {
+    // sign-plane word of a tile's pixel: plane base + (pixel offset inside the frame, the same for every unit: formed ONCE) + the unit's frame offset
+    int moff[MAXTW];
+    if (BITS == 2) {
 #pragma unroll
         for (int i = 0; i < MAXTW; ++i) {
             const int tile = part + i * WPS;
@@ -114,9 +121,15 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
             q = q < npix ? q : npix - 1;
             if (tile >= ntile) q = 0;
             const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
-            const long pix_off = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx;
-            mbn[i] = p.bits_in[(long)(cl_co >> 5) * p.bplane + (pix_off >> p.bshift)];
+            moff[i] = (int)((cl_yoff + (long)oy * p.y_sy + (long)ox * p.y_sx) >> p.bshift);
         }
+    }
+    const unsigned* const mplane = BITS == 2 ? p.bits_in + (long)(cl_co >> 5) * p.bplane : nullptr;
+    const long unit_words = p.y_sn >> p.bshift;              // (the launcher's caller checked y_sn % channels == 0)
+    auto mask_fetch = [&](int unit) {
+        const unsigned* mp = mplane + (long)unit * unit_words;
+#pragma unroll
+        for (int i = 0; i < MAXTW; ++i) mbn[i] = mp[moff[i]];
     };
 
     int unit = blockIdx.x;
@@ -126,32 +139,35 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
     mask_park();
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the zero pixels are in LDS before anybody passes the (raw) barrier
     __builtin_amdgcn_s_barrier();
+    unsigned long long t_issue = 0, t_tiles = 0, t_wait = 0, t_bar = 0, t_units = 0;      // (STAMP: per-wave cycle sums of a unit's four phases)
     auto do_unit = [&](int unit, const char* __restrict__ band, char* __restrict__ band_next) {
         const int next = unit + gridDim.x;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (STAMP) c0 = __builtin_readcyclecounter();
         if (BITS == 2 && next < nunits) mask_fetch(next);         // requested BEFORE the direct loads, parked behind the closing wait, used a unit later
         if (next < nunits) glds_band(next, band_next);        // lands while this unit is multiplied
+        if (STAMP) c1 = __builtin_readcyclecounter();
 
         auto do_tile = [&](int tile, unsigned mb_in) {
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
             const int oy = fast_div(q, inv_OW), ox = q - oy * cl_OW;
-            const char* lane_base = band + h * PLANE;         // (chunk 2 kc + h: the lane half picks the odd planes)
-            // band pixel of tap (ty, tx) = (oy + ty - pad_y) * WIN + (ox + tx - pad_x), or the zero pixel outside the frame
+            // band position of tap (ty, tx): pixel (oy + ty - pad_y) * WIN + (ox + tx - pad_x), or the zero pixel outside the frame
             const int q0 = (oy - p.pad_y) * WIN + (ox - p.pad_x);
-            const char* tap_base[PAD ? TH * TW : 1];
-            if (PAD) {
+            const char* tap_base[TH * TW];
 #pragma unroll
-                for (int ty = 0; ty < TH; ++ty)
+            for (int ty = 0; ty < TH; ++ty)
 #pragma unroll
-                    for (int tx = 0; tx < TW; ++tx) {
+                for (int tx = 0; tx < TW; ++tx) {
+                    int qt = q0 + ty * WIN + tx;
+                    if (PAD) {
                         const int iy = oy + ty - p.pad_y, ix = ox + tx - p.pad_x;
-                        const bool in = iy >= 0 && iy < HIN && ix >= 0 && ix < WIN;
-                        tap_base[ty * TW + tx] = lane_base + (in ? q0 + ty * WIN + tx : P) * 16;
+                        qt = (iy >= 0 && iy < HIN && ix >= 0 && ix < WIN) ? qt : P;
                     }
-            } else {
-                tap_base[0] = lane_base + q0 * 16;
-            }
+                    const int blk = qt >> 3;
+                    tap_base[ty * TW + tx] = band + blk * 1024 + ((h ^ (blk & 1)) << 7) + ((qt & 7) << 4);
+                }
             f32x16_t acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -161,9 +177,7 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
             constexpr int RD = 8;
             auto frag = [&](int ks) {
                 const int k0 = ks * 16, t = k0 / C, kc = (k0 % C) / 16;
-                const int ty = t / TW, tx = t % TW;
-                if (PAD) return *(const bf16x8_t*)(tap_base[t] + 2 * kc * PLANE);
-                return *(const bf16x8_t*)(tap_base[0] + (ty * WIN + tx) * 16 + 2 * kc * PLANE);
+                return *(const bf16x8_t*)(tap_base[t] + kc * 256);
             };
             bf16x8_t pf[RD];
 #pragma unroll
@@ -196,13 +210,23 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p) {
         };
         int ti = 0;
         for (int tile = part; tile < ntile; tile += WPS, ++ti) do_tile(tile, BITS == 2 ? smask[wave][ti][r] : 0u);
+        if (STAMP) c2 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the next band has landed (and this unit's stores are acknowledged)
+        if (STAMP) c3 = __builtin_readcyclecounter();
         if (next < nunits) mask_park();
         __builtin_amdgcn_s_barrier();                          // every wave is done reading this band
+        if (STAMP) {
+            const unsigned long long c4 = __builtin_readcyclecounter();
+            t_issue += c1 - c0; t_tiles += c2 - c1; t_wait += c3 - c2; t_bar += c4 - c3; t_units += 1;
+        }
     };
     for (; unit < nunits; unit += 2 * gridDim.x) {
         do_unit(unit, bandA_, bandB_);
         if (unit + (int)gridDim.x < nunits) do_unit(unit + gridDim.x, bandB_, bandA_);
+    }
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 5;
+        o[0] = t_issue; o[1] = t_tiles; o[2] = t_wait; o[3] = t_bar; o[4] = t_units;
     }
 }
 
@@ -211,6 +235,13 @@ int launch_planes(BandP& p, hipStream_t s) {
     const long npix = (long)p.OHmax * p.OWmax;
     if (BITS == 2 && (npix + 31) / 32 > (long)(NSET == 2 ? 6 : 12) * (8 / NSET)) return -1;      // the per-wave sign-word registers cover a unit's tiles
     const int nunits = p.Nimg, per = (nunits + 255) / 256, grid = (nunits + per - 1) / per;
+    // HULC_BAND_STAMPS=<device address of 256 x 8 x 5 uint64>: the instrumented instance leaves, per workgroup and wave, the cycle sums of a
+    // unit's phases (issue of the next band's loads | tile loop | wait for loads + store acknowledgements | barrier) and the unit count
+    const char* se = getenv("HULC_BAND_STAMPS");
+    if (se && *se) {
+        conv_band_planes_kernel<NSET, TH, TW, HIN, WIN, BITS, PAD, true><<<grid, 512, 0, s>>>(p, (unsigned long long*)strtoull(se, nullptr, 0));
+        return 0;
+    }
     conv_band_planes_kernel<NSET, TH, TW, HIN, WIN, BITS, PAD><<<grid, 512, 0, s>>>(p);
     return 0;
 }
