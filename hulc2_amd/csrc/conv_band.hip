@@ -627,12 +627,12 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
         static const char* ge = getenv("HULC_BAND_GLDS");
         rc = -1;
         {   // round 6: the chunk-major direct-to-LDS band (conv_band_planes.hip): fragment reads without address arithmetic
-            // default: conv3's data gradient only (89 vs 97 us per 2048 frames; conv3's forward and conv2's data gradient measure the same on
-            // both kernels); HULC_BAND_PLANES=1: every geometry it covers, =0: none
+            // default: conv3's forward (70 vs 75 us per 2048 frames) and data gradient (89 vs 97); conv2's data gradient measures the same on
+            // both kernels and stays; HULC_BAND_PLANES=1: every geometry it covers, =0: none
             const char* pe = getenv("HULC_BAND_PLANES");       // (read per launch: the tests switch inside one process)
             const int want = pe ? atoi(pe) : -1;
-            const bool conv3_dgrad = NSET == 2 && TH == 3 && TW == 3 && (pad_y != 0 || pad_x != 0) && bits_in != nullptr;
-            if ((want == 1 || (want == -1 && conv3_dgrad)) && !(ge && !atoi(ge))) rc = launch_band_planes(p, NSET, TH, TW, s);
+            const bool conv3 = NSET == 2 && TH == 3 && TW == 3;    // (forward: 70 vs 75 us with its loads spread over the tile loop)
+            if ((want == 1 || (want == -1 && conv3)) && !(ge && !atoi(ge))) rc = launch_band_planes(p, NSET, TH, TW, s);
         }
         if (rc == -1) {
         const bool contiguous = x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && ((uintptr_t)x % 16) == 0;

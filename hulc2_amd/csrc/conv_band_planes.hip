@@ -104,6 +104,14 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned
                                                  (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
         }
     };
+    // one of them (block i) — for the variant that spreads a wave's loads over its tile loop (SPREAD)
+    auto glds_one = [&](int unit, char* band, int i) {
+        const uint16_t* frame = (const uint16_t*)p.X + (long)unit * p.x_sn;
+        const int slot = lane >> 3, pj = lane & 7, q = i * 8 + pj;
+        if (i < NBLK && q < P)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(frame + (long)q * C + ((slot ^ (i & 1)) << 3)),
+                                             (void __attribute__((address_space(3)))*)(band + i * 1024), 16, 0, 0);
+    };
     unsigned mbn[MAXTW];
     auto mask_park = [&]() {
         if (BITS == 2 && lane < 32) {
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned
         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (STAMP) c0 = __builtin_readcyclecounter();
         if (BITS == 2 && next < nunits) mask_fetch(next);         // requested BEFORE the direct loads, parked behind the closing wait, used a unit later
-        if (next < nunits) glds_band(next, band_next);        // lands while this unit is multiplied
+        const bool spread = (p.dbg & 256) != 0;               // (HULC_BAND_PLANES_SPREAD: a wave's direct loads between its tiles instead of up front)
+        if (next < nunits && !spread) glds_band(next, band_next);        // lands while this unit is multiplied
         if (STAMP) c1 = __builtin_readcyclecounter();
 
         auto do_tile = [&](int tile, unsigned mb_in) {
@@ -208,8 +217,17 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned
                 if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         };
-        int ti = 0;
-        for (int tile = part; tile < ntile; tile += WPS, ++ti) do_tile(tile, BITS == 2 ? smask[wave][ti][r] : 0u);
+        int ti = 0, li = wave;                                // li: this wave's next block to load
+        constexpr int PER_TILE = 2;                           // (a wave has ~NBLK / 8 = 7-9 blocks and 5-10 tiles per unit)
+        for (int tile = part; tile < ntile; tile += WPS, ++ti) {
+            if (spread && next < nunits) {
+#pragma unroll
+                for (int k = 0; k < PER_TILE; ++k, li += 8) glds_one(next, band_next, li);
+            }
+            do_tile(tile, BITS == 2 ? smask[wave][ti][r] : 0u);
+        }
+        if (spread && next < nunits)
+            for (; li < NBLK; li += 8) glds_one(next, band_next, li);
         if (STAMP) c2 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the next band has landed (and this unit's stores are acknowledged)
         if (STAMP) c3 = __builtin_readcyclecounter();
@@ -235,6 +253,9 @@ int launch_planes(BandP& p, hipStream_t s) {
     const long npix = (long)p.OHmax * p.OWmax;
     if (BITS == 2 && (npix + 31) / 32 > (long)(NSET == 2 ? 6 : 12) * (8 / NSET)) return -1;      // the per-wave sign-word registers cover a unit's tiles
     const int nunits = p.Nimg, per = (nunits + 255) / 256, grid = (nunits + per - 1) / per;
+    // a wave's direct loads between its tiles instead of up front: conv3's forward 70 vs 75 us (the ~250-cycle issue of each load then falls
+    // behind MFMAs that are in flight), conv3's data gradient the same either way, conv2's 180 vs 173: default for the unpadded geometry only
+    { const char* sp = getenv("HULC_BAND_PLANES_SPREAD"); p.dbg = (sp ? atoi(sp) != 0 : !PAD) ? 256 : 0; }
     // HULC_BAND_STAMPS=<device address of 256 x 8 x 5 uint64>: the instrumented instance leaves, per workgroup and wave, the cycle sums of a
     // unit's phases (issue of the next band's loads | tile loop | wait for loads + store acknowledgements | barrier) and the unit count
     const char* se = getenv("HULC_BAND_STAMPS");
