@@ -30,3 +30,12 @@ extern "C" int hulc_set_coop_share(int n) {
     g_coop_share = n;
     return old;
 }
+
+// (ABI 6) A brand-new non-blocking stream of the current device (never one a graph capture has used before: see include/hulc2_amd.h).
+extern "C" int hulc_stream_create(void** out) {
+    if (!out) return hulc_fail(-1, "hulc_stream_create: null pointer");
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { *out = nullptr; return hulc_fail(-100, "hulc_stream_create: hipStreamCreateWithFlags failed"); }
+    *out = (void*)s;
+    return 0;
+}

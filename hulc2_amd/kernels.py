@@ -794,10 +794,27 @@ def branch_stream(device, which: int = 0):
     return st
 
 
+_made_streams = []       # (kept alive: a stream wrapped by ExternalStream is never destroyed by torch)
+
+
 def capture_stream(device):
-    """a stream to capture a graph on that is none of the cached branch / side streams.  torch.cuda.Stream() hands out the 32 streams of its pool
-    round-robin: after enough captures in one process the "new" stream IS one of the streams this module keeps for forked branches — a capture
-    whose origin stream doubles as one of its own branches (round 6: seen as a segfault in hipGraphLaunch of the graph captured that way)."""
+    """A stream to capture a graph on that NO earlier capture has used: a brand-new HIP stream (hulc_stream_create: hipStreamCreateWithFlags,
+    non-blocking), not one of torch's pooled streams.  torch.cuda.Stream() hands out the 32 streams of its pool round-robin, so in a long
+    process the "new" stream of a capture is one an earlier capture ran on — and with forked branches inside the captures (round 6) that ended,
+    now and then, in a segfault inside hipGraphLaunch of a step-node backward graph captured later (seen with a cached third branch stream,
+    with a pool of four capture streams, and after ~390 tests of the full suite on torch's own pool).  Falls back to a pooled stream that is
+    none of the cached branch / side streams if the creation fails."""
+    import ctypes
+    try:
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = _L.load().hulc_stream_create(ctypes.byref(h))
+        if rc == 0 and h.value:
+            st = torch.cuda.ExternalStream(h.value, device=device)
+            _made_streams.append(st)
+            return st
+    except AttributeError:
+        pass
     taken = {st.cuda_stream for st in _branch_streams.values()}
     try:
         from .models.perceptual_encoders.concat_encoders import _side_streams

@@ -34,6 +34,11 @@ int hulc_abi_version(void);
  * issued: a captured graph keeps what it was captured with.  Returns the previous value; n = 1 restores whole-device launches.
  * reference: the prior and the posterior of hulc2/models/hulc2.py:228-233 do not depend on each other. */
 int hulc_set_coop_share(int n);
+/* (ABI 6) *out = a new non-blocking stream of the current device (hipStreamCreateWithFlags; the caller owns it and may keep it for the life of
+ * the process).  For hipGraph captures: a capture that forks onto side streams must start on a stream no earlier capture has used — a
+ * framework's pooled streams come round again (torch: 32 per device), and a later capture on such a stream crashed hipGraphLaunch on this
+ * runtime (round 6).  No reference counterpart (Lightning never captures graphs). */
+int hulc_stream_create(void** out);
 
 /* ---- dense layers --------------------------------------------------------------------------- */
 /* C[M,N] = epi(alpha * A·B^T): A is [M][K] (a_kmajor) or stored [K][M]; B is [N][K] (b_kmajor, the
