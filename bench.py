@@ -309,7 +309,8 @@ def lightning_loop(args, dev):
             node = model.__dict__.get("_hulc_step_node")
             if node is not None:
                 res[name]["step_node"] = {"replays": node.replays, "eager_steps": node.eager_steps, "captures": node.captures,
-                                          "input_copies": node.input_copies, "accum_steps": node.accum_steps, "disabled": node.disabled}
+                                          "input_copies": node.input_copies, "accum_steps": node.accum_steps, "zeroed_steps": node.zeroed_steps,
+                                         "disabled": node.disabled}
 
         for name, conc in (("cooperative_kernels", False), ("concurrent_streams", True)):
             kn.set_concurrent_streams(conc)
@@ -375,12 +376,13 @@ def lightning_loop(args, dev):
                     scaler.update()
                     return loss
                 node = model.__dict__.get("_hulc_step_node")
-                before = (node.replays, node.accum_steps) if node is not None else (0, 0)
+                before = (node.replays, node.accum_steps, node.zeroed_steps) if node is not None else (0, 0, 0)
                 measure(name)
                 node_stats(name)
                 if node is not None:
                     res[name]["replays_in_this_leg"] = node.replays - before[0]
                     res[name]["accum_steps_in_this_leg"] = node.accum_steps - before[1]
+                    res[name]["zeroed_steps_in_this_leg"] = node.zeroed_steps - before[2]   # (arena zeroed by optim.Adam.zero_grad: no add-back)
                 res[name]["fused_steps"] = int(getattr(opt, "fused_launches", -1))
         except Exception as e:                              # noqa: BLE001
             res["closure_order_error"] = f"{type(e).__name__}: {e}"

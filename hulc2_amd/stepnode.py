@@ -124,7 +124,7 @@ class StepNode:
         self.static_leaves: List[torch.Tensor] = []
         self.static_logs = []
         self.disabled: Optional[str] = "HULC_NO_STEP_GRAPH" if os.environ.get("HULC_NO_STEP_GRAPH") else None
-        self.replays = self.eager_steps = self.captures = self.input_copies = self.accum_steps = self.evictions = 0      # (tests / bench read these)
+        self.replays = self.eager_steps = self.captures = self.input_copies = self.accum_steps = self.zeroed_steps = self.evictions = 0      # (tests / bench read these)
         self._seen = {}                        # signature -> eager-node steps taken (a loop that alternates layouts still reaches its captures)
         # frame slots (hulc_conv_desc.x_slot): the big frame tensors are read by conv1's captured launches through device pointer slots
         self.slot_idx: List[int] = []          # leaves read through slots
@@ -200,6 +200,11 @@ class StepNode:
         tr = self.keeper
         lo = tr.flat_g.data_ptr()
         hi = lo + tr.flat_g.numel() * 4
+        # hulc2_amd.optim.Adam.zero_grad(set_to_none=False) filled the whole arena with zeros and no torch operation has written it since (the
+        # views share the arena's version counter; this node's own kernels are the only other writers, and every backward of it forgets the
+        # mark): nothing to keep, nothing to add back
+        known_zero = getattr(tr, "grads_zeroed_at", None) is not None and tr.grads_zeroed_at == tr.flat_g._version
+        tr.grads_zeroed_at = None
         taken, others = [], []
         for i, (p, d) in enumerate(zip(tr.params, dests)):
             g = p.grad
@@ -214,6 +219,9 @@ class StepNode:
             p.grad = None
         if not taken and not others:
             return None
+        if known_zero and not others:
+            self.zeroed_steps += 1
+            return (None, taken, others)
         self.accum_steps += 1
         return (tr.flat_g.clone() if taken else None, taken, others)
 
@@ -222,7 +230,12 @@ class StepNode:
             return
         prev, taken, others = held
         tr = self.keeper
-        if prev is not None:
+        if prev is None:
+            for i, g in taken:                                    # the arena was known to be zero: a parameter without a gradient in this pass gets its
+                if outs[i] is None:                               # (zero) gradient back, everything else is zero + new = new
+                    g.zero_()
+                    tr.params[i].grad = g
+        else:
             # the old values go back into the slices of the parameters they were taken from — and nowhere else: the slice of a parameter whose
             # `.grad` lives outside the arena (AccumulateGrad cloned instead of adopting the view) is never zeroed by zero_grad, what a copy of
             # the arena holds there is the previous step's gradient

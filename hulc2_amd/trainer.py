@@ -412,6 +412,7 @@ class ArenaTrainer:
         _ARENAS[self.flat_p.untyped_storage().data_ptr()] = self    # (hulc2_amd.optim.Adam finds the arena behind a parameter list here)
         n_state = 0 if self.shadows_only else total            # (gradients and Adam moments belong to the caller's optimizer then)
         self.flat_g = torch.zeros(total if self.step_node else n_state, dtype=torch.float32, device=dev)
+        self.grads_zeroed_at = None            # flat_g._version at which hulc2_amd.optim.Adam.zero_grad(set_to_none=False) left the arena all zeros
         self.exp_avg = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.flat_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
@@ -882,6 +883,7 @@ class ArenaTrainer:
     def zero_grad(self):
         if self.shadows_only:
             raise RuntimeError("ArenaTrainer(shadows_only=True) keeps the kernel-side weight copies only: gradients and the optimizer are the caller's")
+        self.grads_zeroed_at = None                        # (optim.Adam.zero_grad's mark: this pass writes the arena with kernels of its own)
         self._zero_arena()
         for p, off in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point at the arena
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:

@@ -252,6 +252,54 @@ def test_lightning_closure_order_stays_on_the_graphs(dev, set_to_none):
     _same(p_b, p_a, "parameters after six steps in Lightning's closure order")
 
 
+def test_arena_zero_grad_in_place_needs_no_add_back(dev):
+    """The reference's unchanged loop: `configure_optimizers()` (hulc2_amd.optim.Adam by default) + Lightning's closure order +
+    `zero_grad(set_to_none=False)` (torch 1.12's default).  The optimizer zeroes the gradient arena with one fill and marks it; the node's
+    backward finds the mark (and nothing written since) and neither copies nor adds: same bits as the plain order with the same optimizer.
+    A torch operation on a gradient between zero_grad and backward moves the arena's version: that step goes through the add-back and keeps
+    what was written."""
+    def loop(lightning_order, poke=False):
+        kn.reset_step_state(dev)
+        m = _model(dev, 19)
+        batch = _batch(dev, 19)
+        opt = m.configure_optimizers()["optimizer"]
+        from hulc2_amd.optim import Adam
+        assert isinstance(opt, Adam)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+        losses = []
+        for i in range(6):
+            if not lightning_order:
+                opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = m.training_step(batch, i)
+            if lightning_order:
+                opt.zero_grad(set_to_none=False)
+                if i >= 1:
+                    assert all(float(p.grad.abs().max()) == 0.0 for p in list(m.parameters())[:3] if p.grad is not None)
+                if poke and i == 3:
+                    fg = m.__dict__["_hulc_step_node"].keeper.flat_g
+                    lo, hi = fg.data_ptr(), fg.data_ptr() + 4 * fg.numel()
+                    next(p for p in m.parameters() if p.grad is not None and lo <= p.grad.data_ptr() < hi).grad.add_(0.0)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        kn.check_faults(dev)
+        assert opt.fused_launches == 6
+        return m, losses, {n: p.detach().clone() for n, p in m.named_parameters()}
+    with _env(HULC_NO_STEP_NODE=None, HULC_NO_STEP_GRAPH=None, HULC_TORCH_ADAM=None):
+        m_a, l_a, p_a = loop(False)
+        m_b, l_b, p_b = loop(True)
+        m_c, l_c, p_c = loop(True, poke=True)
+    nb, nc = m_b.__dict__["_hulc_step_node"], m_c.__dict__["_hulc_step_node"]
+    assert nb.replays == 4 and nb.zeroed_steps == 5 and nb.accum_steps == 0, (nb.replays, nb.zeroed_steps, nb.accum_steps)
+    assert nc.zeroed_steps == 4 and nc.accum_steps == 1, (nc.zeroed_steps, nc.accum_steps)
+    assert l_a == l_b == l_c, (l_a, l_b, l_c)
+    _same(p_b, p_a, "parameters after six steps, arena zero_grad in place")
+    _same(p_c, p_a, "parameters after six steps, one of them through the add-back")
+
+
 def test_logged_values_of_a_replayed_step_survive_the_next_replay(dev):
     """the graph path handed out the captured graph's static log tensors; a logger that keeps them saw step N+1's values"""
     kn.reset_step_state(dev)
