@@ -136,8 +136,11 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
             const float* xb = n < p.nsplit ? xbase : xbase2;                   // (n is uniform: a scalar select)
-            xraw[U8 ? 0 : j][0] = *(const f32x4_t*)(xb + off);
-            xraw[U8 ? 0 : j][1] = *(const f32x4_t*)(xb + (inb2 ? off + 4 : off));
+            // (global address space spelled out: a base address read from a device slot is an integer, and a pointer made of one is a FLAT
+            //  pointer — flat loads count against lgkmcnt as well, so every LDS wait of the tile loop waited for the frame prefetch too)
+            typedef const f32x4_t __attribute__((address_space(1))) * gvec;
+            xraw[U8 ? 0 : j][0] = *(gvec)(xb + off);
+            xraw[U8 ? 0 : j][1] = *(gvec)(xb + (inb2 ? off + 4 : off));
         }
     };
     auto stage_store = [&](int unit) {

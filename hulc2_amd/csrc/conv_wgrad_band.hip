@@ -407,9 +407,13 @@ __global__ __launch_bounds__(1024) void wband_reduce_kernel(const float* __restr
 // MFMA: the kernel was LDS-issue-bound at ~3 TB/s of frames.  Here the band is de-interleaved while it is staged: plane phi of a row
 // holds columns phi, phi + 4, phi + 8, ... so that 8 consecutive output pixels of tap kw are the 8 consecutive elements
 // j = ox + kw / 4 of plane kw % 4.  Output pixels are enumerated per row in blocks of 8 (row padded to OWP = 8 * ceil(OW / 8) slots, dY^T
-// zero in the padding), a block's fragment is ONE aligned ds_read_b128 plus one ds_read_b32, shifted by one element with
-// v_alignbit for the taps kw >= 4.  Plane stride PSTR (multiple of 16 B with an odd number of 16-byte slots) makes the 16 distinct
-// (kh, phi) addresses of a ds_read_b128 lane group fall on 16 different bank quads.
+// zero in the padding), a block's fragment is ONE aligned ds_read_b128.  The taps kw >= 4 read plane kw - 4 one element further:
+// dW[kw + 4] = sum_ox dY[ox] * P[ox + 1] = sum_ox' dY[ox' - 1] * P[ox'] — so instead of realigning the X fragment (round 4: one more
+// ds_read_b32 and four v_alignbit per MFMA) a wave holds 32 taps of ONE half (kw < 4 or kw >= 4) and the upper-half waves read their dY^T
+// fragment ONE SLOT EARLIER (the slot in front of a row's first pixel is the previous row's padding, or the guard slot in front of the
+// array: zero).  Plane stride PSTR (multiple of 16 B with an odd number of 16-byte slots) makes the 16 (kh, phi) addresses of a
+// ds_read_b128 lane group fall on 16 different bank quads.  The bias gradient is the seventh wave's MFMA chain: the same dY^T
+// fragments against a fragment of ones (wave 6 was idle in the loop; as per-thread sums in stage_store it cost 32 VALU per thread and unit).
 struct W1P {
     const void* X; const void* dY; int dy_dtype;
     int Nimg, H, W, OH, OW, OWP, R, PSTR, AT_ROW;
@@ -423,8 +427,8 @@ struct W1P {
 
 // U8: uint8 NHWC frames (else fp32 NCHW planes); dY is bf16 (other gradients dtypes take the generic kernel).  Both are compile-time so
 // that no join of two load paths makes the compiler wait for the prefetch early.
-template <int XCH, int YCH, bool U8>
-__global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
+template <int XCH, int YCH, bool U8, bool STAMP = false>
+__global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p, unsigned long long* stamps = nullptr) {
     constexpr int NT = 512, C = 3, S = 4, K = 192, KTN = 6, YCPP = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -457,21 +461,20 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
     const int nslots = p.R * p.OWP;
     char* xband = smem;                                     // [c][row][phi][PSTR bytes]
     const int xbytes = C * rows_max * 4 * p.PSTR;
-    char* at = smem + xbytes;                               // [nslots][DR1]
+    char* at = smem + xbytes + DR1;                         // [nslots][DR1] behind one guard slot (zero: the upper-half waves' slot -1)
+    const int ones_off = xbytes + (nslots + 9) * DR1;       // 32 bytes of bf16 1.0: the bias wave's "X fragment"
 
-    // this lane's tap inside the wave's k tile: k = (c, kh, kw) = wave * 32 + r
-    const bool live = wave < KTN;
-    const int k = (live ? wave : 0) * 32 + r, kc = k >> 6, kh = (k >> 3) & 7, kw = k & 7;
-    const int koff = ((kc * rows_max + kh) * 4 + (kw & 3)) * p.PSTR;
-    const unsigned ksh = (kw >> 2) * 16;                    // taps kw >= 4 read plane kw - 4 one element further
+    // this lane's tap: wave = (channel, half of kw), lane r = (kh, phi): k = (c, kh, kw = phi + 4 * half).  Wave 6 = the bias chain.
+    const bool live = wave < KTN, biasw = wave == KTN && p.partial_b != nullptr;
+    const int kc = (live ? wave : 0) >> 1, hi = live ? (wave & 1) : 0, kh = r >> 2, phi = r & 3;
+    const int k = kc * 64 + kh * 8 + phi + 4 * hi;
+    const int koff = biasw ? ones_off : ((kc * rows_max + kh) * 4 + phi) * p.PSTR;
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float bsum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    // zero once: the dY^T padding slots and the plane elements past W / 4 are read (times zero / as never-used taps) but never written
-    for (int o = tid * 16; o < xbytes + nslots * DR1; o += NT * 16) *(uint4*)(smem + o) = make_uint4(0, 0, 0, 0);
+    // zero once: the guard slot, the dY^T padding slots and the plane elements past W / 4 are read (times zero / as never-used taps) but never written
+    for (int o = tid * 16; o < xbytes + (nslots + 1) * DR1; o += NT * 16) *(uint4*)(smem + o) = make_uint4(0, 0, 0, 0);
+    if (tid < 2) *(uint4*)(smem + ones_off + tid * 16) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
 
     // prefetched data stays RAW in registers (fp32 frames: 8 floats per item; uint8 frames: the aligned dword windows) and is
     // converted in stage_store: any ALU use at load time would put the wait for the loads in front of the MFMA loop they overlap
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
     // (uint8 frames) per-frame parameters — augmentation shift, frame index — of this workgroup's first MAXU units, read once into LDS (see
     // conv1_band.hip: as global loads they were two dependent round trips to memory in front of every unit's prefetch)
     constexpr int MAXU = 256;
-    int4* ftab = (int4*)(smem + xbytes + (p.R * p.OWP + 8) * 96 + 64);
+    int4* ftab = (int4*)(smem + xbytes + (p.R * p.OWP + 9) * 96 + 64);
     auto frame_params = [&](int unit, int n, int& sx, int& sy, int& fi) {
         if (unit < MAXU) {
             const int4 e = ftab[unit];
@@ -500,8 +503,27 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
         }
         __syncthreads();
     }
-    auto stage_load = [&](int unit) {
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+    // thread-only parts of the load addresses: the item's float index inside the band of plane c, the gradient element of pixel q
+    unsigned xld[C], yld[YCH];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xld[c] = (unsigned)(c * p.H * p.W + tid * 8) * 4u;                       // (bytes)
+#pragma unroll
+    for (int j = 0; j < YCH; ++j) yld[j] = (unsigned)((tid / YCPP + j * (NT / YCPP)) * (int)p.dy_sx + (tid % YCPP) * 8) * 2u;
+    // a unit's geometry is carried from unit to unit (next band of the frame, or the first band of the workgroup's next frame): as
+    // unit / bands and unit % bands it was two scalar division sequences in front of every unit's loads
+    struct Geo { int n, r0, R, rows; };
+    auto geo_next = [&](const Geo& g) -> Geo {
+        const int b1 = g.r0 + p.R;
+        const bool wrapf = b1 >= p.OH;
+        Geo o;
+        o.n = wrapf ? g.n + (int)gridDim.x : g.n;
+        o.r0 = wrapf ? 0 : b1;
+        o.R = (o.r0 + p.R <= p.OH) ? p.R : p.OH - o.r0;
+        o.rows = (o.R - 1) * S + 8;
+        return o;
+    };
+    auto stage_load = [&](int unit, const Geo& g) {
+        const int n = g.n, r0 = g.r0, R = g.R, rows = g.rows;
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         if (U8) {                                          // uint8 NHWC frames: item = 8 elements of all three planes = 2 x (4 aligned dwords)
             int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
@@ -515,32 +537,76 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
                 xraw[i][0] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
                 xraw[i][1] = make_float4(__uint_as_float(raw[4]), __uint_as_float(raw[5]), __uint_as_float(raw[6]), __uint_as_float(raw[7]));
             }
+        } else if (XCH == C) {
+            // fp32 planes: the band rows of a channel are contiguous -> flat copy, 8 floats per item (rows * W is a multiple of 16: no partial
+            // item).  Address = uniform base of the band (scalar registers) + a 32-bit offset that depends on the thread only: one load
+            // instruction each, no vector address arithmetic (as 64-bit per-lane addresses the eight loads took ~100 instructions to issue)
+            const float* ub = (n < p.nsplit ? xbase : xbase2) + ((long)n * C * p.H * p.W + (long)(r0 * S) * p.W);
+            typedef float f32x4n __attribute__((ext_vector_type(4)));
+            typedef const f32x4n __attribute__((address_space(1))) * gvec;
+            const bool inb = tid < items;
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const unsigned o = inb ? xld[j] : (unsigned)(j * p.H * p.W) * 4u;     // BYTE offset (zero-extended: the scalar-base addressing form)
+                const f32x4n v0 = *(gvec)((const char*)ub + o), v1 = *(gvec)((const char*)ub + o + 16);
+                xraw[j][0] = make_float4(v0.x, v0.y, v0.z, v0.w);
+                xraw[j][1] = make_float4(v1.x, v1.y, v1.z, v1.w);
+            }
         } else
 #pragma unroll
-        for (int j = 0; j < XCH; ++j) {                    // fp32 planes: the band rows of a channel are contiguous -> flat copy, 8 floats per item
+        for (int j = 0; j < XCH; ++j) {
             const int c = j / (XCH / C), id = tid + (j % (XCH / C)) * NT;
             const bool inb = id < items, inb2 = inb && id * 8 + 8 <= nflt;
             const long off = ((long)n * C + c) * p.H * p.W + (long)(r0 * S) * p.W + (inb ? (long)id * 8 : 0);
             const float* xb = n < p.nsplit ? xbase : xbase2;                   // (n is uniform: a scalar select)
-            xraw[j][0] = *(const float4*)(xb + off);
-            xraw[j][1] = *(const float4*)(xb + (inb2 ? off + 4 : off));
+            // (global address space spelled out: a base address read from a device slot is an integer and a pointer made of one is a FLAT
+            //  pointer; flat loads count against lgkmcnt as well as vmcnt.  Measured: no difference here — the loads have landed by then)
+            typedef float f32x4n __attribute__((ext_vector_type(4)));
+            typedef const f32x4n __attribute__((address_space(1))) * gvec;
+            const f32x4n v0 = *(gvec)(xb + off), v1 = *(gvec)(xb + (inb2 ? off + 4 : off));
+            xraw[j][0] = make_float4(v0.x, v0.y, v0.z, v0.w);
+            xraw[j][1] = make_float4(v1.x, v1.y, v1.z, v1.w);
         }
-        const int npix = R * p.OW, ycc = tid % YCPP;
+        const int npix = R * p.OW;
+        // the output pixels of a band are contiguous in dY (dy_sy == OW * dy_sx): uniform base + the thread's element offset
+        const uint16_t* yb = (const uint16_t*)p.dY + ((long)n * p.dy_sn + (long)r0 * p.dy_sy);
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
+            typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+            typedef const u32x4n __attribute__((address_space(1))) * gvec;
             const int q = tid / YCPP + j * (NT / YCPP);
-            const bool inb = q < npix;
-            // the output pixels of a band are contiguous in dY (dy_sy == OW * dy_sx)
-            const long off = (long)n * p.dy_sn + (long)r0 * p.dy_sy + (long)(inb ? q : 0) * p.dy_sx + ycc * 8;
-            const uint4 v = *(const uint4*)((const uint16_t*)p.dY + off);   // (bias partial sums are taken in stage_store, off the load path)
-            ypre[j] = v;
+            const u32x4n v = *(gvec)((const char*)yb + (q < npix ? yld[j] : (unsigned)((tid % YCPP) * 16)));
+            ypre[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto stage_store = [&](int unit) {
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+    // thread-only parts of the staging addresses (fp32 frames, XCH == C: a thread's item is id == tid in every channel plane)
+    int xdst;
+    { const int e0 = tid * 8, row = fast_div(e0, inv_W), col = e0 - row * p.W; xdst = row * 4 * p.PSTR + (col >> 2) * 2; }
+    int ydst[YCH];
+#pragma unroll
+    for (int j = 0; j < YCH; ++j) {
+        const int q = tid / YCPP + j * (NT / YCPP), oy = fast_div(q, inv_OW);
+        ydst[j] = (oy * p.OWP + (q - oy * p.OW)) * DR1 + (tid % YCPP) * 16;
+    }
+    auto stage_store = [&](int unit, const Geo& g) {
+        const int n = g.n, r0 = g.r0, R = g.R, rows = g.rows;
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         const bool w8 = (p.W & 7) == 0;                    // chunks never straddle a row and start at an even plane index
         uint4 xpre[XCH];
+        if (!U8 && XCH == C && w8) {
+            // plane phi takes columns (col + phi, col + 4 + phi) as one dword: exactly v_cvt_pk_bf16_f32 of the item's floats phi and 4 + phi —
+            // four conversions and four 4-byte LDS stores per item, at an offset that depends on the thread only (xdst, taken once)
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                if (tid >= items) continue;
+                const float4 a = xraw[j][0], b = xraw[j][1];
+                char* dst = xband + j * rows_max * 4 * p.PSTR + xdst;
+                *(uint32_t*)(dst) = pack_bf16x2(a.x, b.x);
+                *(uint32_t*)(dst + p.PSTR) = pack_bf16x2(a.y, b.y);
+                *(uint32_t*)(dst + 2 * p.PSTR) = pack_bf16x2(a.z, b.z);
+                *(uint32_t*)(dst + 3 * p.PSTR) = pack_bf16x2(a.w, b.w);
+            }
+        } else {
         if (U8) {
             int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
 #pragma unroll
@@ -583,6 +649,7 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
                 }
             }
         }
+        }
         const int npix = R * p.OW, ycc = tid % YCPP;
         // an odd number of 8-slot blocks: the MFMA loop's last step pairs the last block with the 8 slots behind it — zeros (after a partial band
         // they would hold the previous band's next row; behind a full band they are the padding slots, zero anyway)
@@ -590,37 +657,41 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
             const int q = tid / YCPP + j * (NT / YCPP);
-            if (q < npix) {
-                const int oy = fast_div(q, inv_OW), slot = oy * p.OWP + (q - oy * p.OW);
-                const uint32_t w[4] = {ypre[j].x, ypre[j].y, ypre[j].z, ypre[j].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(w[e] << 16); bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
-                *(uint4*)(at + slot * DR1 + ycc * 16) = ypre[j];
-            }
+            if (q < npix) *(uint4*)(at + ydst[j]) = ypre[j];     // (slot offset of pixel q: a function of the thread, taken once)
         }
     };
 
     int unit = 0;
     __syncthreads();                                         // the zero fill precedes the first stage_store
-    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    Geo gc;
+    unit_geom(0, gc.n, gc.r0, gc.R, gc.rows);
+    if (unit < nunits) { stage_load(unit, gc); stage_store(unit, gc); }
     __syncthreads();
+    // (STAMP, HULC_W1_STAMPS: per-wave cycle sums of a unit's phases — issue of the next band's loads | MFMA loop | barrier | wait for the
+    //  loads | convert + LDS stores | barrier)
+    unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_units = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     for (; unit < nunits; ++unit) {
         const int next = unit + 1;
-        if (next < nunits && !(p.dbg & 8)) stage_load(next);
+        if (STAMP) c0 = __builtin_readcyclecounter();
+        const Geo gn = geo_next(gc);
+        if (next < nunits && !(p.dbg & 8)) stage_load(next, gn);
+        if (STAMP) c1 = __builtin_readcyclecounter();
 
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
-        if (live && !(p.dbg & 1)) {
+        const int R = gc.R;
+        if ((live || biasw) && !(p.dbg & 1)) {
             const int nblk = R * nbx, nsteps = (nblk + 1) / 2;
             // this lane half's pixel block b = 2 * s + h as (row, column bx) — only its X offset `xo` is kept: + 32 bytes per step, one row of
             // planes further when the column wraps.  An odd block count leaves the last step's second block empty: its dY^T slots are zero
             // (stage_store clears them), so its X fragment may be anything finite in LDS.  (The MFMA loop is bound by instruction issue: this
             // form spends ~11 VALU per MFMA where block validity selects and a multiply per address spent 21.)
+            // (the bias wave reads the 32 bytes of ones at every step: no walk)
             int bx = h, xo = koff + h * 16;
-            int xwrap = S * 4 * p.PSTR - nbx * 16;
-            asm volatile("" : "+v"(xwrap));                  // (kept in a vector register)
-            const char* ab = at + (h * 8 + ((lane & 15) >> 2)) * DR1 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
-            // one step = 16 pixel slots: dY^T fragment (two ds_read_b64_tr_b16), X fragment (ds_read_b128 + ds_read_b32, realigned), one MFMA
-            auto fetch = [&](int st, uint4& a, uint4& w, uint32_t& w4) {
+            int xwrap = biasw ? 0 : S * 4 * p.PSTR - nbx * 16, xstep = biasw ? 0 : 32;
+            asm volatile("" : "+v"(xwrap), "+v"(xstep));     // (kept in vector registers)
+            // the upper-half taps pair plane element ox' with dY slot ox' - 1: their dY^T fragment starts one slot earlier
+            const char* ab = at + (h * 8 + ((lane & 15) >> 2) - hi) * DR1 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+            // one step = 16 pixel slots: dY^T fragment (two ds_read_b64_tr_b16), X fragment (one ds_read_b128), one MFMA
+            auto fetch = [&](int st, uint4& a, uint4& w) {
                 {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     typedef v4s __attribute__((address_space(3))) * lds_v4s;
@@ -630,43 +701,55 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
                     a = f.u;
                     ab += 16 * DR1;
                 }
-                const char* src = xband + xo;
-                w = *(const uint4*)src;
-                w4 = *(const uint32_t*)(src + 16);
+                w = *(const uint4*)(xband + xo);
                 const int t = bx + 2 - nbx;                  // (selects between vector registers only: a select with a scalar operand next to the
                 const bool wrap = t >= 0;                    //  condition mask costs a move per step on this target)
                 bx = wrap ? t : bx + 2;
-                xo += 32 + (wrap ? xwrap : 0);
+                xo += xstep + (wrap ? xwrap : 0);
             };
-            auto mma = [&](f32x16_t& c, const uint4& a, const uint4& w, uint32_t w4) {
-                union { uint4 u; bf16x8_t b; } af; af.u = a;
-                union { uint32_t w[4]; bf16x8_t b; } x;
-                x.w[0] = __builtin_amdgcn_alignbit(w.y, w.x, ksh); x.w[1] = __builtin_amdgcn_alignbit(w.z, w.y, ksh);
-                x.w[2] = __builtin_amdgcn_alignbit(w.w, w.z, ksh); x.w[3] = __builtin_amdgcn_alignbit(w4, w.w, ksh);
+            auto mma = [&](f32x16_t& c, const uint4& a, const uint4& w) {
+                union { uint4 u; bf16x8_t b; } af, x; af.u = a; x.u = w;
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, x.b, c, 0, 0, 0);
             };
             // software-pipelined: the next step's fragments are in flight while this step's MFMA issues (one accumulator: a second
             // chain or deeper prefetch spills at the 128-VGPR budget of two workgroups per CU)
             if (nsteps > 0) {                                // (two steps per trip: the fragment registers alternate instead of being copied)
-                uint4 a0, w0, a1, w1; uint32_t e0, e1;
-                fetch(0, a0, w0, e0);
-                int st = 1;
-                for (; st + 1 < nsteps; st += 2) {
-                    fetch(st, a1, w1, e1);
-                    mma(acc, a0, w0, e0);
-                    fetch(st + 1, a0, w0, e0);
-                    mma(acc, a1, w1, e1);
+                // fragments TWO steps ahead (three register sets, three steps per trip): with one step of distance a step cost the LDS round
+                // trip (~140 cycles against the MFMA's 32).  Steps past the end read the zeroed slots behind the band / stay inside the
+                // band's planes (finite), and are not multiplied
+                uint4 a0, w0, a1, w1, a2, w2;
+                fetch(0, a0, w0);
+                fetch(1, a1, w1);
+                int st = 0;
+                for (; st + 3 <= nsteps; st += 3) {
+                    fetch(st + 2, a2, w2);
+                    mma(acc, a0, w0);
+                    fetch(st + 3, a0, w0);
+                    mma(acc, a1, w1);
+                    fetch(st + 4, a1, w1);
+                    mma(acc, a2, w2);
                 }
-                if (st < nsteps) {
-                    fetch(st, a1, w1, e1);
-                    mma(acc, a0, w0, e0);
-                    mma(acc, a1, w1, e1);
-                } else mma(acc, a0, w0, e0);
+                if (st < nsteps) mma(acc, a0, w0);
+                if (st + 1 < nsteps) mma(acc, a1, w1);
             }
         }
+        if (STAMP) c2 = __builtin_readcyclecounter();
         __syncthreads();
-        if (next < nunits) stage_store(next);
+        if (STAMP) { c3 = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c4 = __builtin_readcyclecounter(); }
+        if (next < nunits) stage_store(next, gn);
+        if (STAMP) c5 = __builtin_readcyclecounter();
         __syncthreads();
+        gc = gn;
+        if (STAMP) {
+            const unsigned long long c6 = __builtin_readcyclecounter();
+            t_ph[0] += c1 - c0; t_ph[1] += c2 - c1; t_ph[2] += c3 - c2; t_ph[3] += c4 - c3; t_ph[4] += c5 - c4; t_ph[5] += c6 - c5; t_units += 1;
+        }
+    }
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 7;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) o[e] = t_ph[e];
+        o[6] = t_units;
     }
 
     // ---- slabs: dW partial [32][K] (lane = k column, register = channel row) and the bias partial
@@ -675,18 +758,9 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) pw[(long)acc_row(e, lane) * K + k] = acc[e];
     }
-    if (p.partial_b) {
-        float* red = (float*)smem;                            // bands are dead: reuse LDS, [NT][8] floats = 16 KB
-        __syncthreads();
+    if (biasw && r == 0) {                                    // every column of the bias wave's tile holds the channel sums: lanes 0 and 32 cover the rows
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
-        __syncthreads();
-        if (tid < 32) {
-            const int ycc = tid / 8, e = tid % 8;
-            float sacc = 0.f;
-            for (int q = ycc; q < NT; q += YCPP) sacc += red[q * 8 + e];   // threads with tid % YCPP == ycc, fixed order
-            p.partial_b[(long)blockIdx.x * 32 + tid] = sacc;
-        }
+        for (int e = 0; e < 16; ++e) p.partial_b[(long)blockIdx.x * 32 + acc_row(e, lane)] = acc[e];
     }
 }
 
@@ -698,7 +772,7 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
     p.PSTR = ((p.OWP + 2) * 2 + 15) / 16 * 16;
     if (((p.PSTR / 16) & 1) == 0) p.PSTR += 16;
     auto at_row = [&](int R) -> int { int a = R * p.OWP * 2 + 16; if (((a / 16) & 1) == 0) a += 16; return a; };
-    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + (long)(R * p.OWP + 8) * 96 + 64 + (p.u8 ? 256 * 16 : 0); };
+    auto lds_of = [&](int R) -> long { return 3L * ((R - 1) * 4 + 8) * 4 * p.PSTR + (long)(R * p.OWP + 9) * 96 + 64 + (p.u8 ? 256 * 16 : 0); };
     auto fits = [&](int R) -> bool {
         const long rows = (R - 1) * 4 + 8;
         return lds_of(R) <= (160 * 1024 - 256) / 2 && (rows * p.W + 7) / 8 * 3 <= (long)XCH * 512 && (long)R * p.OW * 4 <= (long)YCH * 512;
@@ -723,6 +797,16 @@ int launch_conv1_wgrad(W1P& p, float* dw, float* db, void* ws, long ws_bytes, in
             hipFuncSetAttribute((const void*)conv1_wgrad_kernel<XCH, YCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
         attr_set = true;
     }
+    // HULC_W1_STAMPS=<device address of grid x 8 x 7 uint64>: the instrumented instance (tools/study/conv1_stamps.py)
+    const char* se = getenv("HULC_W1_STAMPS");
+    if (se && *se && !p.u8) {
+        static bool stamp_attr = false;
+        if (!stamp_attr) {
+            if (hipFuncSetAttribute((const void*)conv1_wgrad_kernel<XCH, YCH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -2;
+            stamp_attr = true;
+        }
+        conv1_wgrad_kernel<XCH, YCH, false, true><<<grid, 512, (size_t)lds_of(R), s>>>(p, (unsigned long long*)strtoull(se, nullptr, 0));
+    } else
     if (p.u8) conv1_wgrad_kernel<XCH, YCH, true><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     else conv1_wgrad_kernel<XCH, YCH, false><<<grid, 512, (size_t)lds_of(R), s>>>(p);
     const long Rw = 32L * K;
