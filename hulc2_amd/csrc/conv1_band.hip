@@ -113,8 +113,26 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
         }
         __syncthreads();
     }
-    auto stage_load = [&](int unit) {
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+    // a unit's geometry is carried from unit to unit (next band of the frame, or the first band of the workgroup's next frame): as
+    // unit / bands and unit % bands it was two scalar division sequences in front of every unit's loads (sweep order keeps the divisions)
+    struct Geo { int n, r0, R, rows; };
+    auto geo_next = [&](int unit_next, const Geo& g) -> Geo {
+        Geo o;
+        if (p.sweep) { unit_geom(unit_next, o.n, o.r0, o.R, o.rows); return o; }
+        const int b1 = g.r0 + p.R;
+        const bool wrapf = b1 >= p.OH;
+        o.n = wrapf ? g.n + (int)gridDim.x : g.n;
+        o.r0 = wrapf ? 0 : b1;
+        o.R = (o.r0 + p.R <= p.OH) ? p.R : p.OH - o.r0;
+        o.rows = (o.R - 1) * S + TH;
+        return o;
+    };
+    // thread-only part of the fp32 load addresses: the byte offset of the thread's item inside the band of plane c
+    unsigned xld[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xld[c] = (unsigned)(c * p.H * p.W + tid * 8) * 4u;
+    auto stage_load = [&](int unit, const Geo& g) {
+        const int n = g.n, r0 = g.r0, R = g.R, rows = g.rows;
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         if (U8) {                                          // uint8 NHWC frames: one item = 8 elements of all three planes
             int sx, sy, fi; frame_params(unit, n, sx, sy, fi);
@@ -127,6 +145,23 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
                 const int id = tid + i * NT;
                 const bool inb = id < items;
                 u8_band_chunk3_load(img, p.H, p.W, r0 * S, inb ? id * 8 : 0, inb ? nflt : 0, sx - p.pad, sy - p.pad, &uraw[(U8 ? i : 0) * 8]);
+            }
+            return;
+        }
+        if (XF == C) {
+            // the band rows of a channel plane are contiguous -> flat copy, 8 floats per item (rows * W is a multiple of 16: no partial item).
+            // Address = uniform base of the band (scalar registers) + a 32-bit byte offset that depends on the thread only: one load
+            // instruction each, no 64-bit vector address arithmetic
+            const char* ub = (const char*)((n < p.nsplit ? xbase : xbase2) + ((long)n * C * p.H * p.W + (long)(r0 * S) * p.W));
+            typedef const f32x4_t __attribute__((address_space(1))) * gvec;
+            // (measured: with the loads of the four halo rows a band shares with its predecessor — L2 hits, a fifth of the requests — switched
+            //  off, the kernel is 2 % faster: a row ring in LDS that keeps them is not worth building)
+            const bool inb = tid < items;
+#pragma unroll
+            for (int j = 0; j < XF; ++j) {
+                const unsigned o = inb ? xld[j] : (unsigned)(j * p.H * p.W) * 4u;
+                xraw[U8 ? 0 : j][0] = *(gvec)(ub + o);
+                xraw[U8 ? 0 : j][1] = *(gvec)(ub + o + 16);
             }
             return;
         }
@@ -143,8 +178,8 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             xraw[U8 ? 0 : j][1] = *(gvec)(xb + (inb2 ? off + 4 : off));
         }
     };
-    auto stage_store = [&](int unit) {
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+    auto stage_store = [&](int unit, const Geo& g) {
+        const int n = g.n, r0 = g.r0, R = g.R, rows = g.rows;
         const int nflt = rows * p.W, items = (nflt + 7) / 8;
         uint4 xpre[XF];
         if (U8) {
@@ -189,15 +224,20 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
     };
 
     int unit = 0;
-    if (unit < nunits) { stage_load(unit); stage_store(unit); }
+    Geo gc;
+    unit_geom(0, gc.n, gc.r0, gc.R, gc.rows);
+    if (unit < nunits) { stage_load(unit, gc); stage_store(unit, gc); }
     __syncthreads();
     for (; unit < nunits; ++unit) {
         const int next = unit + 1;
+        const Geo gn = geo_next(next, gc);
         // (uint8 frames: the prefetch is unconditional — after the last unit it re-reads that unit's band, from L2, into registers nobody uses.  With
         //  the previous unit's values flowing around a skipped prefetch the register allocator copied loaded dwords into the loop-carried registers
         //  right behind each load: a wait for the load where it was issued)
-        if (U8) { if (!(p.dbg & 2)) stage_load(next < nunits ? next : unit); }
-        else if (next < nunits && !(p.dbg & 2)) stage_load(next);
+        if (U8) { if (!(p.dbg & 2)) { if (next < nunits) stage_load(next, gn); else stage_load(unit, gc); } }
+        else if (next < nunits && !(p.dbg & 2)) stage_load(next, gn);
+        // this lane's A-operand fragments (output channel r, half h of every k-step) live in registers over the unit's tiles only: re-read per
+        // unit (12 LDS reads against 36+ fragment reads), they do not sit on the register budget while the next band is converted
         // this lane's A-operand fragments (output channel r, half h of every k-step) live in registers over the unit's tiles only: re-read per
         // unit (12 LDS reads against 36+ fragment reads), they do not sit on the register budget while the next band is converted
         bf16x8_t wreg[X3 ? 1 : KSTEPS];
@@ -205,8 +245,7 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) wreg[ks] = *(const bf16x8_t*)(wlds + r * WROW + h * 16 + ks * 32);
         }
-
-        int n, r0, R, rows; unit_geom(unit, n, r0, R, rows);
+        const int n = gc.n, r0 = gc.r0, R = gc.R;
         const int npix = R * p.OW, ntiles = (npix + 31) / 32;
         for (int t = wave; t < ((p.dbg & 1) ? 0 : ntiles); t += 8) {
             const int q = t * 32 + r;
@@ -224,6 +263,8 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             }
             // the band fragments of PF k-steps ahead are requested before each MFMA (left alone the compiler reads one fragment, waits for
             // it, multiplies: the LDS round trip twelve times per tile with four waves per SIMD to hide it)
+            // (round 6, measured: weight fragments read per k-step, two accumulator chains and fragments two k-steps ahead — 265 -> 262 us per
+            //  2048 fp32 frames, 206 -> 215 with uint8 frames: the tile phase is not what this kernel waits for; removed)
             constexpr int PF = X3 ? 1 : 1;
             auto frag = [&](int ks, int base) {
                 const int c = ks / 4, kh2 = (ks % 4) * 2;                         // patch row kh2 + h of channel c
@@ -293,8 +334,9 @@ __global__ __launch_bounds__(512, X3 ? 2 : 4) void conv1_band_kernel(C1P p) {   
             }
         }
         __syncthreads();
-        if (next < nunits && !(p.dbg & 2)) stage_store(next);
+        if (next < nunits && !(p.dbg & 2)) stage_store(next, gn);
         __syncthreads();
+        gc = gn;
     }
 }
 

@@ -32,12 +32,14 @@ struct WBandP {
     float* partial_w;                 // [grid][Cout][K]
     float* partial_b;                 // [grid][Cout]
     int u8, pad; const int* shift; const int* fidx;   // conv1 fed by uint8 NHWC frames: shift / scale / normalise applied while staging (see conv1_band.hip)
+    int burst;                        // bf16 NHWC layers: 1 = the next unit's loads as ONE burst in front of the MFMA loop (else staggered by wave)
+    int stag_num;                     // the bursts are spread over the first stag_num / 8 of the loop
 };
 
 // C: input channels, CT: Cout / 32, TH x TW taps, S stride, NCHW: conv1 layout (k = (c, kh, kw), fp32 planes)
 // PURE16: X and dY are bf16 (the benchmarked NHWC layers) — compile-time, so that no run-time dtype branch surrounds a prefetch load
-template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC, bool PURE16>
-__global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p) {
+template <int C, int CT, int TH, int TW, int S, bool NCHW, int XCH, int YCH, int BPC, bool PURE16, bool STAMP = false>
+__global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p, unsigned long long* stamps = nullptr) {
     constexpr int NT = 512;
     constexpr int COUT = CT * 32;
     constexpr int K = TH * TW * C, KTN = K / 32;          // 32-wide k tiles
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             ypre[j] = v;                                     // (pixels past npix are zeroed in stage_store, not here: see the note above)
         }
     };
+    int po_R = -1, po_npix = -1;                              // the shape the patch-origin table was built for
     auto stage_store = [&](int unit) {
         int n, r0, R, rows, npix; unit_geom(unit, n, r0, R, rows, npix);
         if (NCHW) {
@@ -215,23 +218,42 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                 }
             }
         }
-        for (int q = tid; q < npad; q += NT) {               // patch origin of every output pixel of the band
+        // patch origin of every output pixel of the band: a function of the unit's shape only — rebuilt when the shape changes (with an even
+        // grid a workgroup sees the same band of every frame: once per launch)
+        if (R != po_R || npix != po_npix)
+        for (int q = tid; q < npad; q += NT) {
             const int qc = q < npix ? q : npix - 1;
             const int ppf = R * p.OW, f = fast_div(qc, fast_rcp(ppf)), qq = qc - f * ppf;
             const int oy = fast_div(qq, inv_OW), ox = qq - oy * p.OW;
             pixoff[q] = NCHW ? ((oy * S) * Wp + ox * S) * 2 : ((f * p.H + oy * S) * Wb + ox * S) * PS;
         }
+        po_R = R; po_npix = npix;
     };
 
     int unit = blockIdx.x;
     if (unit < nunits) { stage_load(unit); stage_store(unit); }
     __syncthreads();
+    // (STAMP, HULC_WB_STAMPS: per-wave cycle sums of a unit's phases — issue of the next unit's loads | MFMA loop | barrier | wait for the
+    //  loads | LDS stores | barrier; tools/study/wband_stamps.py)
+    unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_units = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
-        if (next < nunits) stage_load(next);
-
+        if (STAMP) c0 = __builtin_readcyclecounter();
+        // (round 6, bf16 NHWC layers) the next unit's loads leave in two bursts: the second wave of every SIMD in front of the loop, the
+        // first wave half way through it.  A load instruction of a wave is a kilobyte through the CU's one vector-memory path (~35 cycles each,
+        // 120 of them per unit: tools/study/wband_stamps.py — 2300 cycles for the first wave of a SIMD, 4300 for the second, and the same
+        // total when the loads are spread between the steps), and a wave queueing there issues no MFMAs: with all eight waves in one burst the
+        // matrix pipes idle meanwhile (one workgroup per CU); staggered, the other wave of the SIMD has them.  HULC_WB_BURST=1: one burst.
+        const bool pre = next < nunits, stagger = TR && !p.burst;
         int n, r0, R, rows, npix; unit_geom(unit, n, r0, R, rows, npix);
         const int nsteps = (npix + 15) / 16;
+        // the step in front of which this wave issues its loads: every wave its own slot over the loop (the two waves of a SIMD half of it
+        // apart) — a wave then pays for its own 15 loads, not for its place in a queue of 120 (conv2, 2048 frames: 139 us as one burst, 129 in
+        // two half-workgroup bursts, 122 / 116 / 114 with the slots over 5/8, 7/8, all of the loop; the last wave's data still arrives in time)
+        const int bat = stagger ? ((wave * ((nsteps * p.stag_num) >> 3)) >> 3) & ~1 : 0;
+        if (pre && !stagger) stage_load(next);
+        if (STAMP) c1 = __builtin_readcyclecounter();
+
         if (TR) {
             typedef short v4s __attribute__((ext_vector_type(4)));
             typedef v4s __attribute__((address_space(3))) * lds_v4s;
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             // (conv2's geometry only: with conv3's three k tiles per wave the alternating sets cost registers and tail re-reads, measured 5 % slower)
             constexpr bool PIPE = (C == 32);
             if (!PIPE) {
-                for (int st = 0; st < nsteps; ++st) {
+                auto one_step = [&](int st) {
                     const int m0 = st * 16 + h * 8;                             // this lane half's 8 pixels
                     const int po0 = pixoff[m0 + prow], po1 = pixoff[m0 + 4 + prow];
                     bf16x8_t a[CT];
@@ -288,6 +310,10 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
 #pragma unroll
                         for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
                     }
+                };
+                for (int st = 0; st < nsteps; ++st) {
+                    if (pre && stagger && st == bat) stage_load(next);
+                    one_step(st);
                 }
             } else {
             const int last = nsteps - 1;
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
             bf16x8_t aA[CT], xA[MAXT], aB[CT], xB[MAXT];
             load_po(0, pa0, pa1); load_po(last < 1 ? last : 1, pb0, pb1);
             load_fr(0, pa0, pa1, aA, xA);
-            for (int st = 0; st < nsteps; st += 2) {
+            auto trip = [&](int st) {
                 load_po(st + 2 < last ? st + 2 : last, pa0, pa1);
                 load_fr(st + 1 < last ? st + 1 : last, pb0, pb1, aB, xB);
                 __builtin_amdgcn_sched_barrier(0);
@@ -308,6 +334,10 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                     mm(aB, xB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            for (int st = 0; st < nsteps; st += 2) {
+                if (pre && stagger && st == bat) stage_load(next);
+                trip(st);
             }
             }
         } else
@@ -332,9 +362,22 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p)
                 for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
             }
         }
+        if (STAMP) c2 = __builtin_readcyclecounter();
         __syncthreads();
+        if (STAMP) { c3 = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c4 = __builtin_readcyclecounter(); }
         if (next < nunits) stage_store(next);
+        if (STAMP) c5 = __builtin_readcyclecounter();
         __syncthreads();
+        if (STAMP) {
+            const unsigned long long c6 = __builtin_readcyclecounter();
+            t_ph[0] += c1 - c0; t_ph[1] += c2 - c1; t_ph[2] += c3 - c2; t_ph[3] += c4 - c3; t_ph[4] += c5 - c4; t_ph[5] += c6 - c5; t_units += 1;
+        }
+    }
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 7;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) o[e] = t_ph[e];
+        o[6] = t_units;
     }
 
     // ---- slabs: dW partial [COUT][K] (lane = k column, register = channel row) and the bias partial
@@ -544,6 +587,8 @@ __global__ __launch_bounds__(512, 4) void conv1_wgrad_kernel(W1P p, unsigned lon
             const float* ub = (n < p.nsplit ? xbase : xbase2) + ((long)n * C * p.H * p.W + (long)(r0 * S) * p.W);
             typedef float f32x4n __attribute__((ext_vector_type(4)));
             typedef const f32x4n __attribute__((address_space(1))) * gvec;
+            // (measured: with the loads of the four halo rows a band shares with its predecessor — L2 hits, a fifth of the requests — switched
+            //  off, the kernel is 2 % faster: a row ring in LDS that keeps them is not worth building)
             const bool inb = tid < items;
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
@@ -861,7 +906,17 @@ int launch_wband(WBandP& p, float* dw, float* db, void* ws, long ws_bytes, int d
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
         attr_set = true;
     }
-    kern<<<grid, 512, (size_t)lds_of(R, F), s>>>(p);
+    const char* se = getenv("HULC_WB_STAMPS");               // <device address of grid x 8 x 7 uint64>: the instrumented instance
+    if (se && *se && PURE16 && !NCHW) {
+        auto kst = conv_wgrad_band_kernel<C, CT, TH, TW, S, NCHW, XCH, YCH, BPC, PURE16, true>;
+        static bool st_attr = false;
+        if (!st_attr) {
+            if (hipFuncSetAttribute((const void*)kst, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            st_attr = true;
+        }
+        kst<<<grid, 512, (size_t)lds_of(R, F), s>>>(p, (unsigned long long*)strtoull(se, nullptr, 0));
+    } else
+    kern<<<grid, 512, (size_t)lds_of(R, F), s>>>(p, nullptr);
     const long Rw = (long)COUT * K;
     const int nbw = (int)((Rw + 63) / 64);
     wband_reduce_kernel<<<nbw + (db ? 1 : 0), 1024, 0, s>>>(p.partial_w, dw, grid, Rw, accumulate, (dw_oihw && !NCHW) ? C : 0, TH * TW, nbw, p.partial_b, db,
@@ -878,6 +933,8 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
+    { static const bool b = getenv("HULC_WB_BURST") && atoi(getenv("HULC_WB_BURST")); p.burst = b; }
+    { static const int sn = getenv("HULC_WB_STAG") ? atoi(getenv("HULC_WB_STAG")) : 8; p.stag_num = sn; }
     p.X = x; p.dY = dy; p.x_dtype = x_dtype; p.dy_dtype = dy_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - KH) / S + 1; p.OW = (W - KW) / S + 1; p.R = 1; p.F = 1;
     if (nchw) { p.x_sn = (long)Cin * H * W; p.x_sc = (long)H * W; p.x_sy = W; p.x_sx = 1; }
