@@ -155,7 +155,13 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
         const bool have_next = next < nunits && !(p.dbg & 4);
-        if (have_next) stage_load(next);                                     // in flight during the MFMA loop below
+        // (round 6, single band) the next band's loads leave WAVE BY WAVE over the tile loop, each wave in front of its own tile slot, instead
+        // of as one burst of 8 x MAXCH load instructions queueing at the CU's vector-memory path while no wave multiplies (the weight-gradient
+        // kernels' finding, tools/study/wband_stamps.py).  HULC_BAND_DBG bit 64: the burst.  With two bands the band is written early: burst.
+        // Measured: the gripper camera's small maps (several frames per unit) gain (conv2 forward 42 -> 35 us per 2048 frames, conv3 29 -> 25); the
+        // static camera's conv2 forward does not (probe 170 / 170 us, inside the step 143 -> 148): staggered for the packed-frame instances only.
+        const bool stagger = MULTI && !DB && BITS != 2 && !(p.dbg & 64);
+        if (have_next && !stagger) stage_load(next);                         // in flight during the MFMA loop below
         char* band_next = DB ? (band == band0 ? band0 + p.lds_band : band0) : band;
         bool staged = !DB || !have_next;
 
@@ -163,7 +169,12 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         const int Rc = r0 < cl_OH ? ((r0 + R <= cl_OH) ? R : cl_OH - r0) : 0;   // this class may have fewer rows/cols
         const int fpix = Rc * cl_OW, npix = fu * fpix;
         const int ntile = (npix + 31) / 32;
-        for (int tile = part; tile < ntile; tile += WPS) {
+        const int my_tiles = ntile > part ? (ntile - part + WPS - 1) / WPS : 0;
+        const int slot = (wave * my_tiles) >> 3;                             // (waves w and w + 4 share a SIMD: half the loop apart)
+        bool issued = !have_next || !stagger;
+        int it = 0;
+        for (int tile = part; tile < ntile; tile += WPS, ++it) {
+            if (!issued && it == slot) { stage_load(next); issued = true; }
             int q = tile * 32 + r;
             const bool live = q < npix;
             if (!live) q = npix - 1;
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
               }
             }
         }
+        if (!issued) stage_load(next);                       // (a wave without a tile in this unit)
         if (DB) {
             if (!staged) stage_store(next, band_next);       // (a wave with fewer than two tiles in this unit)
             __syncthreads();                                 // every wave is done reading this band and has written its part of the next
