@@ -33,21 +33,22 @@ PEAK_HBM = 8.0e12               # HBM3E bytes/s (MI355X_MICROARCH.md)
 
 # device kernel behind a timed (entry point, shape): kernel name prefix in the committed --pmc passes.  One kernel instance serves the
 # static and the gripper camera (told apart in the passes by LDS size / grid): "max" = its launches with the larger traffic (static frames)
+# (prefixes of the kernel names in profiles/*_pmc_traffic.json: round 6's instances carry one more template argument, the phase-stamp switch)
 PMC_KERNEL = {
-    ("conv2d_bwd_weight", 1024, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "max"),
-    ("conv2d_bwd_weight", 1024, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "min"),
+    ("conv2d_bwd_weight", 1024, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false", "max"),
+    ("conv2d_bwd_weight", 1024, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false", "min"),
     ("conv2d_fwd", 1024, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false, false>", "max"),
     ("conv2d_fwd", 1024, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false, false>", "min"),
     ("conv2d_bwd_data", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_glds_kernel<4, 2, 2, 2, true>", "max"),   # (round 4: the direct-to-LDS instance)
     ("conv2d_fwd", 2048, 49, 49, 32, 64, 4, 2): ("conv_band_kernel<32, 2, 4, 4, 2, 12, false, false,", "max"),
-    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1, true>", "max"),
+    ("conv2d_bwd_weight", 2048, 49, 49, 32, 64, 4, 2): ("conv_wgrad_band_kernel<32, 2, 4, 4, 2, false, 10, 5, 1, true", "max"),
     ("rnn_wavefront", 32, 64, 2048, 1): ("rnn_wavefront2_kernel<2048, true", "max"),
     ("rnn_wavefront", 32, 64, 2048, 0): ("rnn_wavefront2_kernel<2048, false", "max"),
     ("hulc_adam_step",): ("adam_kernel", "max"),
     ("hulc_adam_step_lo",): ("adam_kernel", "max"),
     # round 4: conv1 takes both modalities' frame tensors in one launch (hulc_conv_desc.x2): 2048 frames per launch
-    ("conv2d_bwd_weight", 2048, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "max"),
-    ("conv2d_bwd_weight", 2048, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false>", "min"),
+    ("conv2d_bwd_weight", 2048, 200, 200, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false", "max"),
+    ("conv2d_bwd_weight", 2048, 84, 84, 3, 32, 8, 4): ("conv1_wgrad_kernel<3, 2, false", "min"),
     ("conv2d_fwd", 2048, 200, 200, 3, 32, 8, 4): ("conv1_band_kernel<3, false, false>", "max"),
     ("conv2d_fwd", 2048, 84, 84, 3, 32, 8, 4): ("conv1_band_kernel<3, false, false>", "min"),
 }
