@@ -18,7 +18,7 @@ int hulc_check_launch(const char* where) {
 }
 
 extern "C" const char* hulc_last_error(void) { return g_err; }
-extern "C" int hulc_abi_version(void) { return 6; }
+extern "C" int hulc_abi_version(void) { return 7; }
 
 // (ABI 6) How many cooperative launches share the device from now on (see include/hulc2_amd.h): a host-side setting read when a launch is
 // issued — a captured graph keeps the grids it was captured with.

@@ -27,7 +27,8 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             long x_sn, long x_sy, long x_sx, void* y, int y_dtype, long y_sn, long y_sy, long y_sx, const void* wt,
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
-                            const long* cls_wtap, const void* add, unsigned* bits_out, const unsigned* bits_in, int bits_channels, hipStream_t s);
+                            const long* cls_wtap, const void* add, unsigned* bits_out, const unsigned* bits_in, int bits_channels, void* y16,
+                            hipStream_t s);
 // LDS-band conv1 forward (conv1_band.hip): NCHW fp32 frames, 3 -> 32 channels, 8x8 stride 4; same return convention
 int hulc_conv1_band_dispatch(const float* x, const void* w, int w_dtype, long ldw, const float* bias, void* y, int y_dtype, int relu,
                              int N, int H, int W, int u8, int pad, const int* shift, const int* fidx, unsigned* relu_bits, const void* w_lo,
@@ -683,6 +684,8 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     GatherP g; fill_gather(g, d);
     bool bits_pending = false;
     if (d->relu_bits && (d->Cout % 32 || !d->relu)) return hulc_fail(-4, "hulc_conv2d_fwd: relu_bits needs relu and Cout % 32 == 0");
+    if (d->y_bf16 && (d->y_dtype != HULC_F32 || d->relu_bits || ((uintptr_t)d->y_bf16 % 16)))
+        return hulc_fail(-4, "hulc_conv2d_fwd: y_bf16 goes with an fp32 output, no sign planes, 16-byte aligned");
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = nullptr; g.add_dtype = HULC_F32;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
@@ -696,11 +699,11 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
         rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                      y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
                                      cOH, cOW, cyo, cco, cw0, ctap, nullptr, (d->relu && d->y_dtype == HULC_BF16) ? (unsigned*)d->relu_bits : nullptr, nullptr,
-                                     d->Cout, (hipStream_t)stream);
+                                     d->Cout, (d->y_dtype == HULC_F32 ? d->y_bf16 : nullptr), (hipStream_t)stream);
         if (rc == 1 && d->relu_bits)            // (the planes' preconditions failed, not the geometry: the same launch without them)
             rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                          y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
-                                         cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, (hipStream_t)stream), bits_pending = d->relu_bits != nullptr;
+                                         cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, (d->y_dtype == HULC_F32 ? d->y_bf16 : nullptr), (hipStream_t)stream), bits_pending = d->relu_bits != nullptr;
         else bits_pending = false;
         if (rc < 0) return rc;
         if (rc == 0) { if (bits_pending) launch_relu_bits(d, y, (hipStream_t)stream); return hulc_check_launch("hulc_conv2d_fwd(band)"); }
@@ -721,6 +724,10 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     if (d->x_slot || d->x2_slot) return hulc_fail(-6, "hulc_conv2d_fwd: frame slots are taken by the conv1 band kernel only");
     if (d->compute == HULC_F32) launch_gather<float>(g, (hipStream_t)stream); else launch_gather<bf16_t>(g, (hipStream_t)stream);
     if (d->relu_bits) launch_relu_bits(d, y, (hipStream_t)stream);       // kernels without the epilogue: the planes from a second pass over y
+    if (d->y_bf16) {                                                     // (the band kernels store the copy themselves: here a cast launch follows)
+        rc = hulc_cast_f32_to_bf16((const float*)y, d->y_bf16, (long)d->N * g.OH * g.OW * d->Cout, stream);
+        if (rc) return rc;
+    }
     return hulc_check_launch("hulc_conv2d_fwd");
 }
 
@@ -762,7 +769,7 @@ extern "C" int hulc_conv2d_padded_fwd(const hulc_conv_desc* d, int pad, const vo
         }
         const int rc = hulc_conv_band_dispatch(64, 2, 3, 3, 1, x, d->x_dtype, d->N, d->H, d->W, pad, pad, g.x_sn, g.x_sy, g.x_sx, y, d->y_dtype, g.y_sn,
                                                g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_BF16, d->relu, 2, cOH, cOW, cyo, cco, cw0, ctap,
-                                               add, nullptr, nullptr, 0, (hipStream_t)stream);
+                                               add, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
         if (rc < 0) return rc;
         if (rc == 0) return hulc_check_launch("hulc_conv2d_padded_fwd(band)");
     }
@@ -828,13 +835,12 @@ extern "C" int hulc_conv2d_bwd_data(const hulc_conv_desc* d, const void* dy, con
                                                     (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
                                                     (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
                                                     nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr,
-                                                    (const unsigned*)d->relu_bits, d->Cin, (hipStream_t)stream);
+                                                    (const unsigned*)d->relu_bits, d->Cin, nullptr, (hipStream_t)stream);
             if (brc == 1 && d->relu_bits)       // the planes' preconditions failed: the same launch with the activation as the mask
                 brc = hulc_conv_band_dispatch(d->Cout, nset, U, V, 1, dy, d->y_dtype, d->N, OH, OW, U - 1, V - 1, (long)OH * OW * d->Cout,
                                               (long)OW * d->Cout, d->Cout, dx, d->x_dtype, (long)d->H * d->W * d->Cin,
                                               (long)s * d->W * d->Cin, (long)s * d->Cin, wt, d->w_dtype, (long)d->KH * d->KW * d->Cout,
-                                              nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0,
-                                              (hipStream_t)stream);
+                                              nullptr, relu_src, d->x_dtype, 0, nset, cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
             if (brc < 0) return brc;
             if (brc == 0) return hulc_check_launch("hulc_conv2d_bwd_data(band)");
         }

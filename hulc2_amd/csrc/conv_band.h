@@ -16,6 +16,7 @@ struct BandCls {
 struct BandP {
     const void* X; void* Y; const void* Wt; const float* bias; const void* mask;
     const void* add;                // optional residual (bf16, laid out like Y), summed before the ReLU: the ResNet trunk's block outputs
+    void* Y16;                      // optional (fp32 Y only): a bf16 copy of Y, same layout, from the same accumulators (hulc_conv_desc.y_bf16)
     int x_dtype, y_dtype, w_dtype, mask_dtype;
     int Nimg, H, W;                 // input tensor dims (NHWC, C = template)
     int OHmax, OWmax;               // largest class grid: defines the staged band

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
                         if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
                     }
                     *(float4*)((float*)p.Y + off + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                    // (hulc_conv_desc.y_bf16) the bf16 map a bf16-output launch would have stored, next to the exact one
+                    if (p.Y16) *(uint2*)((uint16_t*)p.Y16 + off + 8 * g) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
               }
             }
@@ -592,11 +594,12 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             int w_dtype, long ldw, const float* bias, const void* mask, int mask_dtype, int relu, int ncls,
                             const int* cls_OH, const int* cls_OW, const long* cls_yoff, const int* cls_cobase, const long* cls_wrow0,
                             const long* cls_wtap /* [ncls][16] */, const void* add, unsigned* bits_out, const unsigned* bits_in, int bits_channels,
-                            hipStream_t s) {
+                            void* y16, hipStream_t s) {
     if (getenv("HULC_NO_BAND")) return 1;
     if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
+    if (y16 && (y_dtype != HULC_F32 || mask || add || bits_out || bits_in)) return 1;      // (the copy rides on the plain fp32-output forward only)
     BandP p;
-    p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask; p.add = add;
+    p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask; p.add = add; p.Y16 = y16;
     p.bits_out = bits_out; p.bits_in = bits_in; p.bshift = 0; p.bplane = 0;
     if (bits_out || bits_in) {
         // planes exist for bf16 tensors of 32 / 64 / 128 channels whose pixels are whole multiples of the channel count apart
@@ -626,7 +629,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
     {   // round 6: four waves per workgroup, every weight set in every wave (conv_band4.hip); HULC_BAND4=0: the kernels below only
         const char* e4 = getenv("HULC_BAND4");              // (read per launch: the tests switch between the kernels inside one process)
         const int band4 = e4 ? atoi(e4) : 0;
-        if (band4) {
+        if (band4 && !y16) {
             const int rc4 = launch_band4(p, C, NSET, TH, TW, S, s);
             if (rc4 == 0) return 0;
             if (rc4 == -2) return hulc_fail(-8, "conv band4: could not raise the dynamic LDS limit");

@@ -237,7 +237,7 @@ class FlattenLinearFn(torch.autograd.Function):
     `a` (conv3's) is applied to the returned gradient in the data-gradient GEMM's epilogue: da is already masked by (a > 0)."""
 
     @staticmethod
-    def forward(ctx, a, W, b):
+    def forward(ctx, a, W, b, a_exact=None):
         N = a.shape[0]
         K = a[0].numel()
         O = W.shape[0]
@@ -259,10 +259,14 @@ class FlattenLinearFn(torch.autograd.Function):
             ctx.ashape = a.shape
             return out
         if kn.get_compute() != "bf16" and a.dtype == torch.bfloat16:
-            # an exact-fp32 site behind a bf16 conv stack (HULC_FP32_SITES "encfc"): the fp32 GEMM takes fp32 operands
-            a32 = torch.empty(a.shape, dtype=torch.float32, device=a.device)
-            kn.cast_bf16_to_f32(_c(a), a32, a.numel())
-            a = a32
+            # an exact-fp32 site behind a bf16 conv stack (HULC_FP32_SITES "encfc"): the fp32 GEMM takes fp32 operands — the stack's own
+            # exact map when it kept one (site "a3"), else a cast copy of the bf16 map
+            if a_exact is not None:
+                a = a_exact
+            else:
+                a32 = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+                kn.cast_bf16_to_f32(_c(a), a32, a.numel())
+                a = a32
         x2 = _c(a).reshape(N, K)
         out = _f32(N, O, like=x2)
         kn.gemm(x2, weight_operand(W, "hwc", chw=chw), out, N, O, K, K, K, O, bias=b, relu=True)
@@ -310,11 +314,11 @@ class FlattenLinearFn(torch.autograd.Function):
             da = torch.empty(N, K, dtype=ctx.a_dtype, device=g.device)
             kn.gemm(g, weight_operand(W, "hwc_t", chw=(C, ctx.ashape[1], ctx.ashape[2])), da, N, K, O, O, O, K, mask=x2, ld_mask=K, mask_scale=1.0)   # x (a > 0): conv3's ReLU
             da = da.view(ctx.ashape)
-        return da, dW, db
+        return da, dW, db, None
 
 
 def flatten_linear_relu(a_nhwc, W, b):
-    return FlattenLinearFn.apply(a_nhwc, W, b)
+    return FlattenLinearFn.apply(a_nhwc, W, b, exact_map(a_nhwc))
 
 
 def mlp(x, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, bool]], drops: Optional[Sequence[float]] = None, seed: int = 0, x3: bool = False):
@@ -451,6 +455,10 @@ class ConvStackFn(torch.autograd.Function):
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
             y = torch.empty(N, oh, ow, cout, dtype=torch.float32 if (a3_exact and li == 2) else _act_dtype(), device=xs[0].device)
+            # (site "a3", round 6) conv3 stores BOTH maps from its accumulators: the exact one for whoever consumes the values, the bf16 one the
+            # backward pass of a bf16 step works on (hulc_conv_desc.y_bf16) — the stack's differentiable output stays bf16, so neither autograd
+            # nor the stack casts the incoming gradient (returning the fp32 map cost two passes over it: 0.145 ms per step)
+            y16 = torch.empty(N, oh, ow, cout, dtype=torch.bfloat16, device=xs[0].device) if (a3_exact and li == 2) else None
             if want_bits and li < 2 and cout % 32 == 0 and (li > 0 or cout == 32):     # (conv1 writes per input tensor: one plane, pixel-major slices)
                 bits[li] = torch.empty(N * oh * ow * (cout // 32), dtype=torch.int32, device=xs[0].device)
             if li == 0:
@@ -479,10 +487,11 @@ class ConvStackFn(torch.autograd.Function):
                                       relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
                         off += n
             else:
-                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li])
+                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li], y_bf16=y16)
             dims.append((h, w_, cin, cout, k, s, nchw))
-            acts.append(y)
+            acts.append(y16 if y16 is not None else y)
             inp, h, w_, cin = y, oh, ow, cout
+        a3_f32 = y if a3_exact else None
         saved = acts
         if kn.backward_compute() == "bf16" and acts[0].dtype != torch.bfloat16:
             # exact-fp32 forward, bf16 backward ('mixed' mode): the backward kernels get what a bf16 step would have saved — bf16 maps — only
@@ -498,10 +507,13 @@ class ConvStackFn(torch.autograd.Function):
         ctx.relu_bits = bits
         ctx.aug = (pad, shifts, indices)
         ctx.meta = (dims, grad_premasked, Ns)
+        if a3_f32 is not None:
+            ctx.mark_non_differentiable(a3_f32)
+            return acts[2], a3_f32
         return acts[2]
 
     @staticmethod
-    def backward(ctx, da3):
+    def backward(ctx, da3, *unused):
         a1, a2, a3, w2, w3, *xs = ctx.saved_tensors
         dims, premasked, Ns = ctx.meta
         N = sum(Ns)
@@ -569,7 +581,17 @@ def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, fram
         ix = list(frame_index) if isinstance(frame_index, (list, tuple)) else [frame_index] * len(xs)
         aug = (int(aug_pad), [None if t is None else _c(t.reshape(-1, 2).to(torch.int32)) for t in sh],
                [None if t is None else _c(t.reshape(-1).to(torch.int32)) for t in ix])
-    return ConvStackFn.apply(grad_premasked, aug, *params, *xs)
+    out = ConvStackFn.apply(grad_premasked, aug, *params, *xs)
+    if isinstance(out, tuple):             # site "a3": the bf16 map carries its exact twin for the consumers that read values (exact_map())
+        out[0]._hulc_f32 = out[1]
+        return out[0]
+    return out
+
+
+def exact_map(a: torch.Tensor):
+    """the fp32 twin of a conv stack's output map when the stack kept one (precision site "a3"), else None"""
+    t = getattr(a, "_hulc_f32", None)
+    return t if (t is not None and t.shape == a.shape) else None
 
 
 @_scoped
@@ -577,11 +599,12 @@ class SpatialSoftmaxFn(torch.autograd.Function):
     """NHWC (N,H,W,C) -> (N,2C); backward also applies the ReLU mask of its input (vision_network.py:100-108)."""
 
     @staticmethod
-    def forward(ctx, a, xmap, ymap, temperature):
+    def forward(ctx, a, xmap, ymap, temperature, a_exact=None):
         N, H, W, C = a.shape
         out = _f32(N, 2 * C, like=a)
         stats = _f32(N, C, 2, like=a)
-        kn.spatial_softmax_fwd(a, N, H * W, C, xmap, ymap, temperature, out, stats)
+        # (site "a3": the expectation is taken over the exact map; the backward recomputes its softmax from the bf16 map, as a bf16 step does)
+        kn.spatial_softmax_fwd(a_exact if a_exact is not None else a, N, H * W, C, xmap, ymap, temperature, out, stats)
         ctx.save_for_backward(a, xmap, ymap, temperature, out, stats)
         return out
 
@@ -593,11 +616,11 @@ class SpatialSoftmaxFn(torch.autograd.Function):
         gdt = torch.bfloat16 if (a.dtype == torch.float32 and kn.base_mode() == "bf16" and kn.get_compute() == "bf16") else a.dtype
         dx = torch.empty(a.shape, dtype=gdt, device=a.device)
         kn.spatial_softmax_bwd(a, N, H * W, C, xmap, ymap, temperature, out, stats, _c(dout), dx, relu_mask=True)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 def spatial_softmax(a, xmap, ymap, temperature):
-    return SpatialSoftmaxFn.apply(a, xmap, ymap, temperature)
+    return SpatialSoftmaxFn.apply(a, xmap, ymap, temperature, exact_map(a))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -408,9 +408,10 @@ def _slot_fields(d, x, x2, H, W, Cin, Cout, KH, stride, x_nchw) -> None:
 
 
 def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu=True, compute=None, aug_shift=None, aug_pad=0,
-               frame_index=None, relu_bits=None, w_lo=None, x2=None):
+               frame_index=None, relu_bits=None, w_lo=None, x2=None, y_bf16=None):
     """y (NHWC) = relu(conv(x, w) + b); w2d is [Cout][K] in the layout's k order (see hulc_conv_desc).  x may be uint8 NHWC frames
-    for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad)."""
+    for conv1 (aug_shift (N, 2) int32 {sx, sy} or None, aug_pad: RandomShiftsAug's pad).  y_bf16 (fp32 y only): a bf16 copy of y from the
+    same accumulators (hulc_conv_desc.y_bf16)."""
     _require_cuda(x, w2d, bias, y, aug_shift, frame_index)
     _require_contiguous(x=x, w2d=w2d, y=y)
     d = _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, x_nchw, F32 if x.dtype == torch.uint8 else _dt(x), _dt(y), _dt(w2d), relu, compute)
@@ -429,8 +430,13 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
         if w_lo.dtype != torch.bfloat16 or w_lo.shape != w2d.shape or not w_lo.is_contiguous():
             raise TypeError("w_lo: the bf16 remainders of w2d, same shape")
         d.w_lo = w_lo.data_ptr()
+    if y_bf16 is not None:
+        _require_cuda(y_bf16)
+        if y.dtype != torch.float32 or y_bf16.dtype != torch.bfloat16 or y_bf16.shape != y.shape or not y_bf16.is_contiguous():
+            raise TypeError("y_bf16: a contiguous bf16 tensor shaped like the fp32 output y")
+        d.y_bf16 = y_bf16.data_ptr()
     macs = float(N) * oh * ow * Cout * Cin * KH * KW * (3 if w_lo is not None else 1)
-    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y) + (_nbytes(x2) if x2 is not None else 0)):
+    with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y, y_bf16) + (_nbytes(x2) if x2 is not None else 0)):
         _L.check(_L.load().hulc_conv2d_fwd(ctypes.byref(d), _p(x), _p(w2d), _p(bias), _p(y), ctypes.c_void_p(_stream())),
                  "hulc_conv2d_fwd")
     return y

@@ -82,6 +82,7 @@ class ConvDesc(ctypes.Structure):
         ("w_lo", ctypes.c_void_p),
         ("x2", ctypes.c_void_p), ("n_split", ctypes.c_int),
         ("x_slot", ctypes.c_void_p), ("x2_slot", ctypes.c_void_p),
+        ("y_bf16", ctypes.c_void_p),
     ]
 
 

@@ -120,6 +120,12 @@ typedef struct {
      * graph's input buffers.  x_slot NULL = the addresses in x / x2; x2_slot goes with x2 (its address un-offset). */
     const void* x_slot;
     const void* x2_slot;
+    /* (ABI 7) hulc_conv2d_fwd with an fp32 output (y_dtype = HULC_F32) inside a bf16 step: a bf16 copy of the output map, laid out like y,
+     * written from the same accumulators (rounded once, after the ReLU: bit for bit the map a bf16-output launch stores).  The selective-
+     * precision site "a3" (DESIGN §5): the consumer of the map's VALUES (the spatial softmax, vision_network.py:74-108; the gripper
+     * camera's flatten-linear) reads the fp32 map, the backward pass keeps working on the bf16 one — no second pass over the map and no
+     * cast of its gradient.  The LDS-band kernels store both from the epilogue; elsewhere a cast launch follows.  NULL = none. */
+    void* y_bf16;
 } hulc_conv_desc;
 int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream);
 /* dx (NHWC, dtype x_dtype) from dy (NHWC, dtype y_dtype); wt = the weight permuted to [Cin][KH][KW][Cout]

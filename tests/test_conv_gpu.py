@@ -251,3 +251,56 @@ def test_conv1_two_uint8_frame_tensors_in_one_launch(dev, name, Na, Nb, H, W, sh
     kn.conv2d_bwd_weight(xa, dy, dw2, db2, N, H, W, 3, 32, 8, 8, 4, True, compute=kn.BF16, x2=xb, aug_shift=sab, aug_pad=pad)
     torch.cuda.synchronize()
     assert float((dw1 - dw2).abs().max()) <= 1e-5 * float(dw1.abs().max()) and float((db1 - db2).abs().max()) <= 1e-5 * float(db1.abs().max())
+
+
+@pytest.mark.parametrize("name,N,H,W", [("static3", 300, 23, 23), ("static3-few", 3, 23, 23), ("grip3", 700, 9, 9), ("grip3-few", 5, 9, 9),
+                                        ("odd3", 2, 11, 13)])
+def test_conv3_stores_the_exact_map_and_the_bf16_map_from_one_launch(dev, name, N, H, W):
+    """hulc_conv_desc.y_bf16 (ABI 7; precision site "a3"): an fp32-output forward that also leaves the bf16 map.  The fp32 map equals the plain
+    fp32-output launch bit for bit, the bf16 map equals its rounding (= what a bf16-output launch of the same kernel family stores: ReLU and
+    round-to-nearest commute); covered on the LDS-band kernels (frame-sized and packed-frame units) and on the path that follows the generic
+    kernel with a cast launch (a map too small for a band unit)."""
+    from hulc2_amd import kernels as kn
+
+    kn.set_compute("bf16")
+    Cin, Cout, K, s = 64, 64, 3, 1
+    g = torch.Generator().manual_seed(17)
+    x = torch.relu(torch.randn(N, H, W, Cin, generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    w2d = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(dev)
+    b = (torch.rand(Cout, generator=g) * 0.2 - 0.1).to(dev)
+    OH, OW = kn.conv_out_hw(H, W, K, K, s)
+    y32 = torch.empty(N, OH, OW, Cout, device=dev)
+    kn.conv2d_fwd(x, w2d, b, y32, N, H, W, Cin, Cout, K, K, s, False)
+    y32b = torch.full_like(y32, float("nan"))
+    y16 = torch.full((N, OH, OW, Cout), float("nan"), device=dev, dtype=torch.bfloat16)
+    kn.conv2d_fwd(x, w2d, b, y32b, N, H, W, Cin, Cout, K, K, s, False, y_bf16=y16)
+    torch.cuda.synchronize()
+    assert torch.equal(y32b, y32)
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.to(torch.bfloat16).double().to(dev), b.double(), stride=s)).permute(0, 2, 3, 1)
+    assert (y32.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(Exception):                                           # the copy goes with an fp32 output only
+        kn.conv2d_fwd(x, w2d, b, y16, N, H, W, Cin, Cout, K, K, s, False, y_bf16=y16)
+
+
+def test_site_a3_keeps_the_stack_output_bf16_and_hands_out_its_exact_twin(dev, monkeypatch):
+    """site "a3": the conv stack's differentiable output is the bf16 map (its gradient is never cast), the consumers of the VALUES get the exact
+    map; without the site there is no twin"""
+    from hulc2_amd import functional as HF, kernels as kn
+
+    kn.set_compute("bf16")
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(4, 3, 200, 200, generator=g) * 2 - 1).to(dev)
+    ps = []
+    for co, ci, k in ((32, 3, 8), (64, 32, 4), (64, 64, 3)):
+        ps += [(torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev).requires_grad_(), torch.zeros(co, device=dev).requires_grad_()]
+    monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl,a3")
+    a = HF.conv_stack(x, ps, grad_premasked=True)
+    tw = HF.exact_map(a)
+    assert a.dtype == torch.bfloat16 and tw is not None and tw.dtype == torch.float32 and not tw.requires_grad
+    assert torch.equal(a, tw.to(torch.bfloat16))
+    a.backward(torch.ones_like(a))                                           # a bf16 gradient goes in as it is
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ps)
+    monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl")
+    assert HF.exact_map(HF.conv_stack(x, ps, grad_premasked=True)) is None

@@ -82,7 +82,7 @@ def test_abi_library_exports_every_declared_symbol():
     so = ctypes.CDLL(str(lib.lib_path()))
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, missing
-    assert so.hulc_abi_version() == 6
+    assert so.hulc_abi_version() == 7
 
 
 def test_product_never_imports_oracle():
