@@ -684,8 +684,9 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
     GatherP g; fill_gather(g, d);
     bool bits_pending = false;
     if (d->relu_bits && (d->Cout % 32 || !d->relu)) return hulc_fail(-4, "hulc_conv2d_fwd: relu_bits needs relu and Cout % 32 == 0");
-    if (d->y_bf16 && (d->y_dtype != HULC_F32 || d->relu_bits || ((uintptr_t)d->y_bf16 % 16)))
-        return hulc_fail(-4, "hulc_conv2d_fwd: y_bf16 goes with an fp32 output, no sign planes, 16-byte aligned");
+    if (d->y_bf16 && ((d->y_dtype != HULC_F32 && d->y_dtype != HULC_F16) || d->relu_bits || ((uintptr_t)d->y_bf16 % 16)))
+        return hulc_fail(-4, "hulc_conv2d_fwd: y_bf16 goes with an fp32 / fp16 output, no sign planes, 16-byte aligned");
+    if (d->y_dtype == HULC_F16 && !d->y_bf16) return hulc_fail(-4, "hulc_conv2d_fwd: an fp16 output is the twin of a bf16 map (y_bf16)");
     g.X = x; g.Wt = w; g.bias = bias; g.Y = y; g.mask = nullptr; g.mask_dtype = HULC_F32; g.mask_scale = 1.f; g.add = nullptr; g.add_dtype = HULC_F32;
     g.y_dtype = d->y_dtype; g.relu = d->relu;
     g.y_sn = (long)g.OH * g.OW * d->Cout; g.y_sy = (long)g.OW * d->Cout; g.y_sx = d->Cout;
@@ -699,16 +700,18 @@ extern "C" int hulc_conv2d_fwd(const hulc_conv_desc* d, const void* x, const voi
         rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                      y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
                                      cOH, cOW, cyo, cco, cw0, ctap, nullptr, (d->relu && d->y_dtype == HULC_BF16) ? (unsigned*)d->relu_bits : nullptr, nullptr,
-                                     d->Cout, (d->y_dtype == HULC_F32 ? d->y_bf16 : nullptr), (hipStream_t)stream);
+                                     d->Cout, (d->y_dtype != HULC_BF16 ? d->y_bf16 : nullptr), (hipStream_t)stream);
         if (rc == 1 && d->relu_bits)            // (the planes' preconditions failed, not the geometry: the same launch without them)
             rc = hulc_conv_band_dispatch(d->Cin, nset, d->KH, d->KW, d->stride, x, d->x_dtype, d->N, d->H, d->W, 0, 0, g.x_sn, g.x_sy, g.x_sx,
                                          y, d->y_dtype, g.y_sn, g.y_sy, g.y_sx, w, d->w_dtype, g.ldw, bias, nullptr, HULC_F32, d->relu, nset,
-                                         cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, (d->y_dtype == HULC_F32 ? d->y_bf16 : nullptr), (hipStream_t)stream), bits_pending = d->relu_bits != nullptr;
+                                         cOH, cOW, cyo, cco, cw0, ctap, nullptr, nullptr, nullptr, 0, (d->y_dtype != HULC_BF16 ? d->y_bf16 : nullptr), (hipStream_t)stream), bits_pending = d->relu_bits != nullptr;
         else bits_pending = false;
         if (rc < 0) return rc;
         if (rc == 0) { if (bits_pending) launch_relu_bits(d, y, (hipStream_t)stream); return hulc_check_launch("hulc_conv2d_fwd(band)"); }
         bits_pending = d->relu_bits != nullptr;
     }
+    if (d->y_dtype == HULC_F16)
+        return hulc_fail(-6, "hulc_conv2d_fwd: the fp16 twin is stored by the direct-to-LDS band kernel only (bf16 compute, NHWC 23 x 23 x 64 -> 64, 3 x 3)");
     if (d->compute == HULC_BF16 && d->x_nchw && (d->x_dtype == HULC_F32 || d->x_u8_nhwc) && d->Cin == 3 && d->Cout == 32 && d->KH == 8 && d->KW == 8 &&
         d->stride == 4) {
         unsigned* planes = (d->relu && d->y_dtype == HULC_BF16) ? (unsigned*)d->relu_bits : nullptr;

@@ -597,7 +597,8 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
                             void* y16, hipStream_t s) {
     if (getenv("HULC_NO_BAND")) return 1;
     if (ncls != NSET || ncls > BAND_MAXCLS || TH * TW > 16) return 1;
-    if (y16 && (y_dtype != HULC_F32 || mask || add || bits_out || bits_in)) return 1;      // (the copy rides on the plain fp32-output forward only)
+    if (y16 && ((y_dtype != HULC_F32 && y_dtype != HULC_F16) || mask || add || bits_out || bits_in)) return 1;      // (the copy rides on the plain forward only)
+    if (y_dtype == HULC_F16 && !y16) return 1;
     BandP p;
     p.X = x; p.Y = y; p.Wt = wt; p.bias = bias; p.mask = mask; p.add = add; p.Y16 = y16;
     p.bits_out = bits_out; p.bits_in = bits_in; p.bshift = 0; p.bplane = 0;
@@ -635,6 +636,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
             if (rc4 == -2) return hulc_fail(-8, "conv band4: could not raise the dynamic LDS limit");
         }
     }
+    if (y_dtype == HULC_F16 && !(C == 64 && S == 1 && NSET == 2 && TH == 3 && TW == 3)) return 1;
     if (C == 32 && NSET == 2 && TH == 4 && TW == 4 && S == 2) rc = launch_band<32, 2, 4, 4, 2, 12, 1, 7>(p, s);        // conv2 forward (writes sign planes)
     else if (C == 64 && S == 1 && ((NSET == 2 && TH == 3 && TW == 3) || (NSET == 4 && TH == 2 && TW == 2))) {
         // conv3 forward / data gradient, conv2 data gradient (4 parity classes).  Frame-sized maps take the direct-to-LDS instances
@@ -649,6 +651,7 @@ int hulc_conv_band_dispatch(int C, int NSET, int TH, int TW, int S, const void* 
             const bool conv3 = NSET == 2 && TH == 3 && TW == 3;    // (forward: 70 vs 75 us with its loads spread over the tile loop)
             if ((want == 1 || (want == -1 && conv3)) && !(ge && !atoi(ge))) rc = launch_band_planes(p, NSET, TH, TW, s);
         }
+        if (rc == -1 && y_dtype == HULC_F16) return 1;       // (the fp16 twin is stored by the direct-to-LDS kernel only)
         if (rc == -1) {
         const bool contiguous = x_sx == 64 && x_sy == (long)W * 64 && x_sn == (long)H * W * 64 && ((uintptr_t)x % 16) == 0;
         if (!(ge && !atoi(ge)) && !mask_only(mask, bits_in) && !add && !bits_out && x_dtype == HULC_BF16 && y_dtype == HULC_BF16 && contiguous &&

@@ -200,6 +200,34 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned
                 __builtin_amdgcn_sched_barrier(0);
             }
             const long off0 = cl_yoff + (long)unit * p.y_sn + (long)oy * p.y_sy + (long)ox * p.y_sx + cl_co;
+            if (BITS == 0 && p.Y16 && p.y_dtype == HULC_F32 && live) {
+                // (hulc_conv_desc.y_bf16, precision site "a3") the exact map next to the bf16 one: Y is the fp32 tensor, Y16 the bf16 one
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *(float4*)((float*)p.Y + off0 + 8 * g + 4 * h) = v;
+                }
+            }
+            if (BITS == 0 && p.Y16 && p.y_dtype == HULC_F16) {
+                // the fp16 twin (11 bits of mantissa at the bf16 map's two bytes: measured, the fp32 twin's 16-byte pieces at 256-byte pixel
+                // pitch cost this launch 48 us per 2048 frames): packed and exchanged between the lane halves exactly like the bf16 map below
+                auto pkh = [&](float a, float b) -> uint32_t {
+                    if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                    union { _Float16 hh[2]; uint32_t u; } r; r.hh[0] = (_Float16)a; r.hh[1] = (_Float16)b;
+                    return r.u;
+                };
+                uint2 ph[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ph[g] = make_uint2(pkh(acc[4 * g], acc[4 * g + 1]), pkh(acc[4 * g + 2], acc[4 * g + 3]));
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const auto sx = __builtin_amdgcn_permlane32_swap(ph[2 * gp].x, ph[2 * gp + 1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(ph[2 * gp].y, ph[2 * gp + 1].y, false, false);
+                    if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                }
+            }
+            uint16_t* const ybf = (uint16_t*)((BITS == 0 && p.Y16) ? p.Y16 : p.Y);
             uint2 pk[4];
             const uint32_t floor2 = p.relu ? 0u : 0x80008000u;  // (ReLU on the packed words: see conv_band_kernel's epilogue)
 #pragma unroll
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_band_planes_kernel(BandP p, unsigned
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = keep_u16x2(o[e], (mb_in >> (16 * gp + 8 * h + 2 * e)) & 3u);
                 }
-                if (live) *(uint4*)((uint16_t*)p.Y + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (live) *(uint4*)(ybf + off0 + 16 * gp + 8 * h) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         };
         int ti = 0, li = wave;                                // li: this wave's next block to load
@@ -273,7 +301,9 @@ namespace hulc_band {
 
 // 0 = launched, -1 = not covered (the caller goes on to the other band kernels)
 int launch_band_planes(BandP& p, int NSET, int TH, int TW, hipStream_t s) {
-    if (p.x_dtype != HULC_BF16 || p.y_dtype != HULC_BF16 || p.w_dtype != HULC_BF16 || p.add || p.bits_out || (p.mask && !p.bits_in) || p.dbg) return -1;
+    // (an fp32 Y goes with its bf16 twin Y16 — hulc_conv_desc.y_bf16 — on the forward instances)
+    const bool y_ok = (p.y_dtype == HULC_BF16 && !p.Y16) || ((p.y_dtype == HULC_F32 || p.y_dtype == HULC_F16) && p.Y16 && !p.bits_in);
+    if (p.x_dtype != HULC_BF16 || !y_ok || p.w_dtype != HULC_BF16 || p.add || p.bits_out || (p.mask && !p.bits_in) || p.dbg) return -1;
     if (p.x_sx != 64 || p.x_sy != (long)p.W * 64 || p.x_sn != (long)p.H * p.W * 64 || ((uintptr_t)p.X % 16) != 0) return -1;
     const bool padded = p.pad_y != 0 || p.pad_x != 0;
     if (NSET == 2 && TH == 3 && TW == 3 && !padded && !p.bits_in && p.H == 23 && p.W == 23)                          // conv3 forward

@@ -13,6 +13,7 @@
 
 #define HULC_F32 0
 #define HULC_BF16 1
+#define HULC_F16 2      // (ABI 7) the finer twin of a bf16 map: conv forward output next to y_bf16, spatial softmax input
 
 typedef __bf16 bf16_t;
 typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
@@ -98,6 +99,10 @@ HULC_DEVICE void chunk_load_contig(Chunk8& c, const void* base, int dtype, long 
         float4 a = p[0], b = p[1];
         c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
         c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
+    } else if (dtype == HULC_F16) {
+        union { uint4 u; _Float16 h[8]; } r; r.u = *(const uint4*)((const uint16_t*)base + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c.v[j] = (float)r.h[j];
     } else {
         uint4 r = *(const uint4*)((const uint16_t*)base + off);
         c.v[0] = __uint_as_float(r.x << 16); c.v[1] = __uint_as_float(r.x & 0xffff0000u);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void spatial_softmax_fwd64_kernel(const void* 
 }
 // HW <= 448 (the 21 x 21 map of the static camera): a lane's 14 positions fit in registers, so the maximum is taken first and every element
 // costs ONE exponential instead of the two of the online form above (which is VALU-bound: 2.6 TB/s).  Same partials, same merge tree.
-template <bool BF16>
+template <int DT>       // storage type of the map: HULC_F32 / HULC_BF16 / HULC_F16
 __global__ __launch_bounds__(256) void spatial_softmax_fwd64_regs_kernel(const void* __restrict__ x, int HW, const float* __restrict__ xmap,
                                                                          const float* __restrict__ ymap, const float* __restrict__ temperature,
                                                                          float* __restrict__ out, float* __restrict__ stats) {
@@ -152,11 +152,15 @@ __global__ __launch_bounds__(256) void spatial_softmax_fwd64_regs_kernel(const v
         const bool on = p < HW;
         const long off = base + (long)(on ? p : 0) * 64;
         float c[8];
-        if (BF16) {
+        if (DT == HULC_BF16) {
             const uint4 r = *(const uint4*)((const uint16_t*)x + off);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) { c[2 * j] = __uint_as_float(w[j] << 16); c[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        } else if (DT == HULC_F16) {
+            union { uint4 u; _Float16 hh[8]; } r; r.u = *(const uint4*)((const uint16_t*)x + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j] = (float)r.hh[j];
         } else {
             const float4* q = (const float4*)((const float*)x + off);
             const float4 a0 = q[0], a1 = q[1];
@@ -667,10 +671,12 @@ extern "C" int hulc_spatial_softmax_fwd(const void* x, int x_dtype, int N, int H
                                         const float* temperature, float* out, float* stats, void* stream) {
     if (!x || !xmap || !ymap || !temperature || !out || !stats) return hulc_fail(-1, "hulc_spatial_softmax_fwd: null pointer");
     if (C > 64 || C <= 0) return hulc_fail(-2, "hulc_spatial_softmax_fwd: C must be in 1..64 (lane = channel)");
+    if (x_dtype == HULC_F16 && (C != 64 || ((uintptr_t)x % 16))) return hulc_fail(-4, "hulc_spatial_softmax_fwd: an fp16 map has 64 channels, 16-byte aligned");
     const int esz = x_dtype == HULC_F32 ? 4 : 2;
     if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0 && HW >= 32 && HW <= 448 && !getenv("HULC_SSM_ONLINE")) {
-        if (x_dtype == HULC_BF16) spatial_softmax_fwd64_regs_kernel<true><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
-        else spatial_softmax_fwd64_regs_kernel<false><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
+        if (x_dtype == HULC_BF16) spatial_softmax_fwd64_regs_kernel<HULC_BF16><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
+        else if (x_dtype == HULC_F16) spatial_softmax_fwd64_regs_kernel<HULC_F16><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
+        else spatial_softmax_fwd64_regs_kernel<HULC_F32><<<N, 256, 0, (hipStream_t)stream>>>(x, HW, xmap, ymap, temperature, out, stats);
     } else if (C == 64 && ((uintptr_t)x % (8 * esz)) == 0)
         spatial_softmax_fwd64_kernel<<<N, 256, 0, (hipStream_t)stream>>>(x, x_dtype, HW, xmap, ymap, temperature, out, stats);
     else

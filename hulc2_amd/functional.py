@@ -261,8 +261,16 @@ class FlattenLinearFn(torch.autograd.Function):
         if kn.get_compute() != "bf16" and a.dtype == torch.bfloat16:
             # an exact-fp32 site behind a bf16 conv stack (HULC_FP32_SITES "encfc"): the fp32 GEMM takes fp32 operands — the stack's own
             # exact map when it kept one (site "a3"), else a cast copy of the bf16 map
-            if a_exact is not None:
-                a = a_exact
+            if a_exact is not None and a_exact.dtype == torch.float32:
+                # forward on the exact map; the backward's operand stays the bf16 map (what it was when a cast copy of it was saved: the
+                # weight-gradient and masked data-gradient products round their operands to bf16 anyway, and every path rounds a value that
+                # is already bf16 the same way)
+                x2 = _c(a_exact).reshape(N, K)
+                out = _f32(N, O, like=x2)
+                kn.gemm(x2, weight_operand(W, "hwc", chw=chw), out, N, O, K, K, K, O, bias=b, relu=True)
+                ctx.save_for_backward(_c(a).reshape(N, K), out, W, b)
+                ctx.ashape = a.shape
+                return out
             else:
                 a32 = torch.empty(a.shape, dtype=torch.float32, device=a.device)
                 kn.cast_bf16_to_f32(_c(a), a32, a.numel())
@@ -426,7 +434,7 @@ class ConvStackFn(torch.autograd.Function):
     GEOM = ((8, 4), (4, 2), (3, 1))   # (kernel, stride) of the three layers
 
     @staticmethod
-    def forward(ctx, grad_premasked: bool, aug, w1, b1, w2, b2, w3, b3, *xs):
+    def forward(ctx, grad_premasked, aug, w1, b1, w2, b2, w3, b3, *xs):
         """aug: None, or (pad, [shift_i or None per input], [index_i or None per input]) for uint8 NHWC frame tensors (N_i, H, W, 3):
         conv1 applies RandomShiftsAug / ScaleImageTensor / Normalize while staging.  With index_i the tensor is
         the HBM-resident episode store and the batch frames are store frames index_i (windows padded by repeating an index)."""
@@ -448,17 +456,27 @@ class ConvStackFn(torch.autograd.Function):
         bits = [None, None, None]
         # selective precision site "a3" (DESIGN §5): the stack's OUTPUT (conv3's ReLU map, the spatial softmax's / flatten-linear's input) is
         # kept in fp32 inside a bf16 step — its rounding to bf16 alone costs as much gradient fidelity as all of conv1's operand rounding
-        a3_exact = _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16" and "a3" in kn.fp32_sites()
+        # (round 6: `grad_premasked` may be the pair (grad_premasked, exact_out) — the consumer of the values asks for the twin: the gripper
+        #  camera's flatten-linear under site "encfc", every map under site "a3")
+        exact_out = False
+        if isinstance(grad_premasked, tuple):
+            grad_premasked, exact_out = grad_premasked
+        a3_exact = _act_dtype() == torch.bfloat16 and kn.base_mode() == "bf16" and (exact_out or "a3" in kn.fp32_sites())
         for li, (k, s) in enumerate(ConvStackFn.GEOM):
             cout = ws[li].shape[0]
             nchw = li == 0
             w2d = weight_operand(ws[li], "oihw_flat" if nchw else "ohwi")
             oh, ow = kn.conv_out_hw(h, w_, k, k, s)
-            y = torch.empty(N, oh, ow, cout, dtype=torch.float32 if (a3_exact and li == 2) else _act_dtype(), device=xs[0].device)
-            # (site "a3", round 6) conv3 stores BOTH maps from its accumulators: the exact one for whoever consumes the values, the bf16 one the
+            # (site "a3", round 6) conv3 stores TWO maps from its accumulators: a finer one for whoever consumes the values, the bf16 one the
             # backward pass of a bf16 step works on (hulc_conv_desc.y_bf16) — the stack's differentiable output stays bf16, so neither autograd
-            # nor the stack casts the incoming gradient (returning the fp32 map cost two passes over it: 0.145 ms per step)
-            y16 = torch.empty(N, oh, ow, cout, dtype=torch.bfloat16, device=xs[0].device) if (a3_exact and li == 2) else None
+            # nor the stack casts the incoming gradient (returning an fp32 map cost two passes over it: 0.145 ms per step).  The static
+            # camera's map (23 x 23 -> 21 x 21, the spatial softmax's input) gets an fp16 twin — 11 bits of mantissa at the bf16 map's two
+            # bytes: an fp32 twin's 16-byte pieces at 256-byte pixel pitch cost conv3's launch 48 us per 2048 frames and the softmax twice the
+            # bytes —, the gripper camera's small map (the exact-fp32 flatten-linear's operand) an fp32 one
+            twin = a3_exact and li == 2
+            f16_twin = twin and (h, w_, cin, cout, k, s) == (23, 23, 64, 64, 3, 1) and not os.environ.get("HULC_A3_F32_TWIN")
+            y = torch.empty(N, oh, ow, cout, dtype=(torch.float16 if f16_twin else torch.float32) if twin else _act_dtype(), device=xs[0].device)
+            y16 = torch.empty(N, oh, ow, cout, dtype=torch.bfloat16, device=xs[0].device) if twin else None
             if want_bits and li < 2 and cout % 32 == 0 and (li > 0 or cout == 32):     # (conv1 writes per input tensor: one plane, pixel-major slices)
                 bits[li] = torch.empty(N * oh * ow * (cout // 32), dtype=torch.int32, device=xs[0].device)
             if li == 0:
@@ -487,11 +505,18 @@ class ConvStackFn(torch.autograd.Function):
                                       relu_bits=None if bits[li] is None else bits[li][off * oh * ow * (cout // 32):(off + n) * oh * ow * (cout // 32)])
                         off += n
             else:
-                kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li], y_bf16=y16)
+                try:
+                    kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li], y_bf16=y16)
+                except kn._L.HulcKernelError:
+                    if not (twin and y.dtype == torch.float16):
+                        raise
+                    # (the fp16 twin is stored by the direct-to-LDS kernel only — e.g. HULC_BAND_PLANES=0 —: the fp32 twin is served everywhere)
+                    y = torch.empty(N, oh, ow, cout, dtype=torch.float32, device=xs[0].device)
+                    kn.conv2d_fwd(inp, w2d, bs[li], y, N, h, w_, cin, cout, k, k, s, nchw, relu=True, relu_bits=bits[li], y_bf16=y16)
             dims.append((h, w_, cin, cout, k, s, nchw))
             acts.append(y16 if y16 is not None else y)
             inp, h, w_, cin = y, oh, ow, cout
-        a3_f32 = y if a3_exact else None
+        a3_f32 = y if (a3_exact and y16 is not None) else None
         saved = acts
         if kn.backward_compute() == "bf16" and acts[0].dtype != torch.bfloat16:
             # exact-fp32 forward, bf16 backward ('mixed' mode): the backward kernels get what a bf16 step would have saved — bf16 maps — only
@@ -508,7 +533,10 @@ class ConvStackFn(torch.autograd.Function):
         ctx.aug = (pad, shifts, indices)
         ctx.meta = (dims, grad_premasked, Ns)
         if a3_f32 is not None:
+            # (the twin carries no gradient, and autograd must not make one up: with materialised gradients the engine filled a 231 MB fp32
+            #  zero tensor for it in front of every backward)
             ctx.mark_non_differentiable(a3_f32)
+            ctx.set_materialize_grads(False)
             return acts[2], a3_f32
         return acts[2]
 
@@ -516,6 +544,8 @@ class ConvStackFn(torch.autograd.Function):
     def backward(ctx, da3, *unused):
         a1, a2, a3, w2, w3, *xs = ctx.saved_tensors
         dims, premasked, Ns = ctx.meta
+        if da3 is None:                                   # (gradients are not materialised when the stack handed out its exact twin)
+            da3 = torch.zeros_like(a3)
         N = sum(Ns)
         g = _c(da3)
         if premasked and g.dtype != ctx.g_dtype:          # ('mixed' mode / site "a3": the consumer worked on the fp32 map) -> the saved maps' storage type
@@ -570,7 +600,7 @@ class ConvStackFn(torch.autograd.Function):
         return (None, None, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], *([None] * len(xs)))
 
 
-def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, frame_index=None):
+def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, frame_index=None, exact_out=False):
     """x: a frame tensor or a list of them (batched from conv1's output on); fp32 NCHW frames in [-1, 1], or uint8 NHWC frames as
     stored, with aug_shifts (per tensor: (N, 2) int32 or None) and aug_pad applied inside conv1; frame_index (per tensor: int32 store
     frame numbers or None) when x is the episode store itself."""
@@ -581,7 +611,7 @@ def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, fram
         ix = list(frame_index) if isinstance(frame_index, (list, tuple)) else [frame_index] * len(xs)
         aug = (int(aug_pad), [None if t is None else _c(t.reshape(-1, 2).to(torch.int32)) for t in sh],
                [None if t is None else _c(t.reshape(-1).to(torch.int32)) for t in ix])
-    out = ConvStackFn.apply(grad_premasked, aug, *params, *xs)
+    out = ConvStackFn.apply((bool(grad_premasked), True) if exact_out else grad_premasked, aug, *params, *xs)
     if isinstance(out, tuple):             # site "a3": the bf16 map carries its exact twin for the consumers that read values (exact_map())
         out[0]._hulc_f32 = out[1]
         return out[0]
@@ -589,7 +619,7 @@ def conv_stack(x, params, grad_premasked=False, aug_pad=0, aug_shifts=None, fram
 
 
 def exact_map(a: torch.Tensor):
-    """the fp32 twin of a conv stack's output map when the stack kept one (precision site "a3"), else None"""
+    """the finer twin (fp16 or fp32) of a conv stack's bf16 output map when the stack kept one (precision site "a3"), else None"""
     t = getattr(a, "_hulc_f32", None)
     return t if (t is not None and t.shape == a.shape) else None
 

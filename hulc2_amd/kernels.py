@@ -10,7 +10,7 @@ import torch
 
 from . import lib as _L
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 _COMPUTE = {"bf16": BF16, "fp32": F32, "f32": F32}
 _compute_mode = BF16
 
@@ -79,8 +79,12 @@ def fp32_sites() -> frozenset:
     `enc` = the whole camera encoders (exact-fp32 MFMA);  `prior`;  `none`.
     `txl` inside the whole-trunk launch (csrc/txl_block.hip) means split operands — three bf16 MFMAs per product, fp32-class values — not
     the fp32 matrix instruction.
-    Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.4 %,
-    median 4.7 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.06-0.10 ms per step (3.50 -> 3.58);
+    Default `head,goal,encfc,txl` (measured at the benchmark's size against the fp32 oracle): every gradient within 9.2 %,
+    median 4.8 % — closer than the reference's own fp16 autocast (26 % / 6.7 %) — for +0.06-0.10 ms per step over the head alone; round 6:
+    `encfc` also makes the gripper camera's conv3 store the EXACT map next to the bf16 one (hulc_conv_desc.y_bf16) for its exact-fp32
+    flatten-linear — that operand's bf16 rounding was what held the FORWARD perceptual embeddings at 1.06e-3; with it 9.0e-4, inside
+    north_star's 1e-3, at no cost (the cast launch it replaces was dearer);  `a3` adds the static camera's map (an fp16 twin for the spatial
+    softmax: + 0.01-0.03 ms per step, the embeddings' maximum error does not move);
     `head,goal,encfc`: 13 % / 8.0 % for +0.09 ms; `head` alone: 23 % / 13 % at no cost; `head,goal,encfc,txl,conv1,a3`: median
     0.84 % (worst 10 %: the conv stacks' own parameters) for +0.45 ms."""
     import os
@@ -160,6 +164,8 @@ def _dt(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:       # (ABI 7: the finer twin of a bf16 map — conv forward output next to y_bf16, spatial softmax input)
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
@@ -432,8 +438,8 @@ def conv2d_fwd(x, w2d, bias, y, N, H, W, Cin, Cout, KH, KW, stride, x_nchw, relu
         d.w_lo = w_lo.data_ptr()
     if y_bf16 is not None:
         _require_cuda(y_bf16)
-        if y.dtype != torch.float32 or y_bf16.dtype != torch.bfloat16 or y_bf16.shape != y.shape or not y_bf16.is_contiguous():
-            raise TypeError("y_bf16: a contiguous bf16 tensor shaped like the fp32 output y")
+        if y.dtype not in (torch.float32, torch.float16) or y_bf16.dtype != torch.bfloat16 or y_bf16.shape != y.shape or not y_bf16.is_contiguous():
+            raise TypeError("y_bf16: a contiguous bf16 tensor shaped like the fp32 / fp16 output y")
         d.y_bf16 = y_bf16.data_ptr()
     macs = float(N) * oh * ow * Cout * Cin * KH * KW * (3 if w_lo is not None else 1)
     with _Timed(("conv2d_fwd", N, H, W, Cin, Cout, KH, stride), 2 * macs, _nbytes(x, w2d, y, y_bf16) + (_nbytes(x2) if x2 is not None else 0)):

@@ -1,3 +1,4 @@
+import os
 """Gripper-camera encoder (nature-CNN) on MI355X kernels.
 
 Mirrors hulc2.models.perceptual_encoders.vision_network_gripper.VisionNetwork (reference
@@ -44,7 +45,9 @@ class VisionNetwork(nn.Module):
         return (c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias)
 
     def forward(self, x: torch.Tensor, aug_shift=None, aug_pad: int = 0, frame_index=None, pre_ln: bool = False) -> torch.Tensor:
-        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index)     # (N, 7, 7, 64) NHWC
+        # (site "encfc": the exact-fp32 flatten-linear below gets the EXACT map — conv3 stores it next to the bf16 one, hulc_conv_desc.y_bf16)
+        a3 = HF.conv_stack(x, self.conv_params(), grad_premasked=True, aug_pad=aug_pad, aug_shifts=aug_shift, frame_index=frame_index,
+                           exact_out="encfc" in kn.fp32_sites() and not os.environ.get("HULC_A3_NOTWIN"))                                                                               # (N, 7, 7, 64) NHWC
         # nn.Flatten + Linear(3136, 128) + ReLU on the NHWC activation in place: the weight's columns are reordered, not the activations
         c = self.conv_model
         with kn.site_scope("encfc"):         # (selective precision)

@@ -23,6 +23,9 @@ extern "C" {
 
 #define HULC_F32 0
 #define HULC_BF16 1
+/* (ABI 7) IEEE half precision — accepted in two places only: as hulc_conv2d_fwd's y_dtype next to hulc_conv_desc.y_bf16 (the finer twin of the
+ * bf16 output map: 11 bits of mantissa at bf16's two bytes), and as hulc_spatial_softmax_fwd's x_dtype (the consumer of that twin). */
+#define HULC_F16 2
 
 const char* hulc_last_error(void);
 int hulc_abi_version(void);
@@ -120,7 +123,8 @@ typedef struct {
      * graph's input buffers.  x_slot NULL = the addresses in x / x2; x2_slot goes with x2 (its address un-offset). */
     const void* x_slot;
     const void* x2_slot;
-    /* (ABI 7) hulc_conv2d_fwd with an fp32 output (y_dtype = HULC_F32) inside a bf16 step: a bf16 copy of the output map, laid out like y,
+    /* (ABI 7) hulc_conv2d_fwd with an fp32 or fp16 output (y_dtype = HULC_F32 / HULC_F16; fp16: the direct-to-LDS 64-channel 3 x 3 forward
+     * of 23 x 23 frames only — conv3 of the static camera) inside a bf16 step: a bf16 copy of the output map, laid out like y,
      * written from the same accumulators (rounded once, after the ReLU: bit for bit the map a bf16-output launch stores).  The selective-
      * precision site "a3" (DESIGN §5): the consumer of the map's VALUES (the spatial softmax, vision_network.py:74-108; the gripper
      * camera's flatten-linear) reads the fp32 map, the backward pass keeps working on the bf16 one — no second pass over the map and no

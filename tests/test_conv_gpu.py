@@ -280,8 +280,19 @@ def test_conv3_stores_the_exact_map_and_the_bf16_map_from_one_launch(dev, name, 
     assert torch.equal(y16, y32.to(torch.bfloat16))
     ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.to(torch.bfloat16).double().to(dev), b.double(), stride=s)).permute(0, 2, 3, 1)
     assert (y32.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    with pytest.raises(Exception):                                           # the copy goes with an fp32 output only
+    with pytest.raises(Exception):                                           # the copy goes with an fp32 / fp16 output only
         kn.conv2d_fwd(x, w2d, b, y16, N, H, W, Cin, Cout, K, K, s, False, y_bf16=y16)
+    # the fp16 twin (HULC_F16): served by the direct-to-LDS kernel for the static camera's conv3 only — the same accumulators rounded to half
+    # precision next to the same bf16 map; refused (loudly) everywhere else
+    yh = torch.full((N, OH, OW, Cout), float("nan"), device=dev, dtype=torch.float16)
+    y16b = torch.full_like(y16, float("nan"))
+    if (H, W) == (23, 23):
+        kn.conv2d_fwd(x, w2d, b, yh, N, H, W, Cin, Cout, K, K, s, False, y_bf16=y16b)
+        torch.cuda.synchronize()
+        assert torch.equal(yh, y32.to(torch.float16)) and torch.equal(y16b, y16)
+    else:
+        with pytest.raises(Exception):
+            kn.conv2d_fwd(x, w2d, b, yh, N, H, W, Cin, Cout, K, K, s, False, y_bf16=y16b)
 
 
 def test_site_a3_keeps_the_stack_output_bf16_and_hands_out_its_exact_twin(dev, monkeypatch):
@@ -298,9 +309,14 @@ def test_site_a3_keeps_the_stack_output_bf16_and_hands_out_its_exact_twin(dev, m
     monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl,a3")
     a = HF.conv_stack(x, ps, grad_premasked=True)
     tw = HF.exact_map(a)
-    assert a.dtype == torch.bfloat16 and tw is not None and tw.dtype == torch.float32 and not tw.requires_grad
-    assert torch.equal(a, tw.to(torch.bfloat16))
+    assert a.dtype == torch.bfloat16 and tw is not None and tw.dtype == torch.float16 and not tw.requires_grad      # (the static camera's map: fp16 twin)
+    assert float((a.float() - tw.float()).abs().max()) <= 2.0 ** -8 * float(tw.float().abs().max())                # both are roundings of one fp32 map
     a.backward(torch.ones_like(a))                                           # a bf16 gradient goes in as it is
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ps)
     monkeypatch.setenv("HULC_FP32_SITES", "head,goal,encfc,txl")
     assert HF.exact_map(HF.conv_stack(x, ps, grad_premasked=True)) is None
+    # a consumer that asks for the twin gets one whatever the sites say (the gripper camera's flatten-linear under "encfc"): fp32 for a small map
+    xg = (torch.rand(6, 3, 84, 84, generator=g) * 2 - 1).to(dev)
+    ag = HF.conv_stack(xg, ps, grad_premasked=True, exact_out=True)
+    twg = HF.exact_map(ag)
+    assert ag.dtype == torch.bfloat16 and twg is not None and twg.dtype == torch.float32 and torch.equal(ag, twg.to(torch.bfloat16))

@@ -81,7 +81,13 @@ def test_forked_step_equals_the_one_chain_step(dev):
     for a, b in zip(l1, l0):
         assert abs(a - b) <= 2e-4 * abs(b), (l1, l0)
     assert (g1 - g0).norm().item() <= 2e-2 * g0.norm().item()
-    assert (p1 - p0).abs().max().item() <= 2e-3 * 4 * 2e-4 * 100          # (at most a few Adam steps of lr 2e-4 apart, in a handful of elements)
+    # parameters: Adam moves an element by ~lr per step whatever the size of its gradient, so an element whose near-zero gradient changes sign
+    # walks up to 4 steps x lr = 8e-4 away.  Whether that happens within four steps is a matter of the seed and of the arithmetic elsewhere
+    # (tools/study/_fork_seeds.py: the two arrangements stay within 4e-9 of each other for most seeds and part ways — in the 52 tensors upstream
+    # of the contrastive head, whose gradient is the small remainder of a sum that cancels — for some, with either flatten-linear operand);
+    # asserted: nothing moves further than Adam can, and the parameters stay within 5 % of a step of each other on average
+    d = (p1 - p0).abs()
+    assert d.max().item() <= 4 * 2e-4 * 1.01 and d.mean().item() <= 0.05 * 2e-4, (d.max().item(), d.mean().item())
 
 
 def test_forked_graph_replay_equals_forked_eager_steps(dev):

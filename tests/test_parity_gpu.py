@@ -398,10 +398,11 @@ def _oracle_batch(raw):
 # ratchet (every tensor also within 1.5x of its recorded error).
 BARS = {
     # (mode, B, clip)            losses      embeddings  median      worst        downstream worst
-    # (round 5, VERDICT r04 #7: the headline's embeddings are held to 1.2e-3 — measured 1.04e-3 (lang) / 0.93e-3 (vis) against north_star's
-    #  1e-3; the side rows' worst / downstream bars are the measured value x 1.5, no longer x 2)
-    ("bf16", 32, True): dict(loss=1e-4, emb=1.2e-3, med=0.05, worst=0.10, down=0.04),         # measured 4.8 % / 9.4 % / 2.0 %
-    ("bf16", 32, False): dict(loss=1e-4, emb=1.2e-3, med=0.015, worst=0.25, down=0.04),       # measured 0.6 % / 16.4 % (static conv biases) / 2.0 %
+    # (round 6, VERDICT r05 #8: the headline's embeddings are held to north_star's 1e-3 — measured 9.0e-4 (vis) / 9.0e-4 (lang) now that the
+    #  gripper camera's exact-fp32 flatten-linear reads the EXACT conv3 map (site "encfc" + hulc_conv_desc.y_bf16); 1.06e-3 when it read the
+    #  bf16 map.  The side rows' worst / downstream bars are the measured value x 1.5)
+    ("bf16", 32, True): dict(loss=1e-4, emb=1e-3, med=0.05, worst=0.10, down=0.04),           # measured 4.8 % / 9.2 % / 2.0 %
+    ("bf16", 32, False): dict(loss=1e-4, emb=1e-3, med=0.015, worst=0.25, down=0.04),         # measured 0.7 % / 15.6 % (static conv biases) / 2.0 %
     ("bf16", 2, True): dict(loss=1e-4, emb=2e-3, med=0.03, worst=0.14, down=0.09),            # measured 1.5 % / 9.3 % / 5.7 %
     ("bf16+sites", 32, True): dict(loss=1e-4, emb=2e-3, med=0.02, worst=0.20, down=0.04),     # measured 0.86 % / 10 % / 2.0 %
     ("mixed", 32, True): dict(loss=1e-4, emb=1e-5, med=0.013, worst=0.021, down=0.016),       # measured 0.65 % / 1.04 % / 0.8 %
