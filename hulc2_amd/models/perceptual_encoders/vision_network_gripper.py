@@ -1,10 +1,10 @@
-import os
 """Gripper-camera encoder (nature-CNN) on MI355X kernels.
 
 Mirrors hulc2.models.perceptual_encoders.vision_network_gripper.VisionNetwork (reference
 vision_network_gripper.py:11-26,57-89): keys conv_model.{0,2,4,7}, fc1.0, fc2, ln.  The reference's Flatten
 runs over NCHW, so the NHWC conv output is re-ordered (a 3136-float copy per frame) before the first Linear.
 """
+import os
 from typing import Tuple
 
 import torch
