@@ -933,8 +933,9 @@ int hulc_conv_wgrad_band_dispatch(int nchw, int Cin, int Cout, int KH, int KW, i
     if (getenv("HULC_NO_BAND_WGRAD") && !u8) return 1;
     WBandP p;
     p.u8 = u8; p.pad = pad; p.shift = shift; p.fidx = fidx;
-    { static const bool b = getenv("HULC_WB_BURST") && atoi(getenv("HULC_WB_BURST")); p.burst = b; }
-    { static const int sn = getenv("HULC_WB_STAG") ? atoi(getenv("HULC_WB_STAG")) : 8; p.stag_num = sn; }
+    // (read per launch: the tests switch between the arrangements inside one process)
+    { const char* e = getenv("HULC_WB_BURST"); p.burst = e && atoi(e); }
+    { const char* e = getenv("HULC_WB_STAG"); p.stag_num = e ? atoi(e) : 8; }
     p.X = x; p.dY = dy; p.x_dtype = x_dtype; p.dy_dtype = dy_dtype;
     p.Nimg = N; p.H = H; p.W = W; p.OH = (H - KH) / S + 1; p.OW = (W - KW) / S + 1; p.R = 1; p.F = 1;
     if (nchw) { p.x_sn = (long)Cin * H * W; p.x_sc = (long)H * W; p.x_sy = W; p.x_sx = 1; }

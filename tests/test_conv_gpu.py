@@ -320,3 +320,31 @@ def test_site_a3_keeps_the_stack_output_bf16_and_hands_out_its_exact_twin(dev, m
     ag = HF.conv_stack(xg, ps, grad_premasked=True, exact_out=True)
     twg = HF.exact_map(ag)
     assert ag.dtype == torch.bfloat16 and twg is not None and twg.dtype == torch.float32 and torch.equal(ag, twg.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("name,N,H,W,Cin,Cout,K,stride", [("static2", 300, 49, 49, 32, 64, 4, 2), ("static3", 300, 23, 23, 64, 64, 3, 1),
+                                                          ("grip2", 700, 20, 20, 32, 64, 4, 2), ("grip3", 700, 9, 9, 64, 64, 3, 1)])
+def test_weight_gradient_load_arrangements_give_the_same_bits(dev, name, N, H, W, Cin, Cout, K, stride, monkeypatch):
+    """round 6: the next unit's loads leave wave by wave over the MFMA loop (default), as one burst in front of it (HULC_WB_BURST=1, round 5), or
+    over a part of the loop (HULC_WB_STAG): WHEN a load is issued changes nothing about what is multiplied — dW and db bit for bit"""
+    from hulc2_amd import kernels as kn
+
+    kn.set_compute("bf16")
+    g = torch.Generator().manual_seed(23)
+    x = torch.relu(torch.randn(N, H, W, Cin, generator=g)).to(torch.bfloat16).to(dev)
+    OH, OW = kn.conv_out_hw(H, W, K, K, stride)
+    dy = torch.randn(N, OH, OW, Cout, generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for env in ({}, {"HULC_WB_BURST": "1"}, {"HULC_WB_STAG": "3"}):
+        for k_ in ("HULC_WB_BURST", "HULC_WB_STAG"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        dw = torch.full((Cout, Cin * K * K), float("nan"), device=dev)
+        db = torch.full((Cout,), float("nan"), device=dev)
+        kn.conv2d_bwd_weight(x, dy, dw, db, N, H, W, Cin, Cout, K, K, stride, False)
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    for dw, db in outs[1:]:
+        assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+    assert torch.isfinite(outs[0][0]).all()
