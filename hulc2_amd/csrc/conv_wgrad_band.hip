@@ -72,11 +72,22 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p,
     int* pixoff = (int*)(at + (TR ? npix_max * DROW : COUT * AT_ROW));   // [npix_max] byte offset of each output pixel's patch origin
 
     // ---- per-lane byte offset of this lane's k index inside a patch, for each k tile the wave owns
+    // k tiles of a wave.  KTN = 16 (conv2): tiles wave and wave + 8, both output-channel tiles of each.  KTN = 18 (conv3, round 6): with
+    // "wave + 8 t" waves 0 and 1 carried THREE k tiles x 2 channel tiles = 6 accumulator tiles against the others' 4, and the workgroup
+    // waited for them (MFMA loop 7 970 vs 6 260 cycles, tools/study/wband_stamps.py); now every wave has k tiles 2 wave, 2 wave + 1 and
+    // tiles 16 / 17 are shared out by channel tile among waves 0-3: five accumulator tiles there, four in waves 4-7
+    constexpr bool SPLIT18 = KTN == 18 && CT == 2;
     int koff[MAXT]; bool kt_live[MAXT];
+    int kts[MAXT];
+    bool ct_live[MAXT][CT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        const int kt = wave + 8 * t;
-        kt_live[t] = kt < KTN;
+        int kt = wave + 8 * t;
+        if (SPLIT18) kt = t < 2 ? 2 * wave + t : 16 + (wave >> 1);
+        kts[t] = kt;
+        kt_live[t] = SPLIT18 ? (t < 2 || wave < 4) : kt < KTN;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) ct_live[t][i] = kt_live[t] && (!SPLIT18 || t < 2 || i == (wave & 1));
         const int k = (kt_live[t] ? kt : 0) * 32 + r;
         if (NCHW) { const int c = k / (TH * TW), kh = (k / TW) % TH, kw = k % TW; koff[t] = (c * PP + kh * Wp + kw) * 2; }
         else if (TR) {   // transpose read: this lane hands in channels cb + 4 (i % 4) .. + 3 of its group's 16, for pixel row i / 4
@@ -286,7 +297,8 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p,
                 for (int t = 0; t < MAXT; ++t) {
                     if (!kt_live[t]) continue;
 #pragma unroll
-                    for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x[t], acc[t][i], 0, 0, 0);
+                    for (int i = 0; i < CT; ++i)
+                        if (ct_live[t][i]) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x[t], acc[t][i], 0, 0, 0);
                 }
             };
             // (conv2's geometry only: with conv3's three k tiles per wave the alternating sets cost registers and tail re-reads, measured 5 % slower)
@@ -308,7 +320,8 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p,
                         union { v4s v[2]; bf16x8_t b; } x;
                         x.v[0] = tr(xband + po0 + koff[t]); x.v[1] = tr(xband + po1 + koff[t]);
 #pragma unroll
-                        for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
+                        for (int i = 0; i < CT; ++i)
+                            if (ct_live[t][i]) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
                     }
                 };
                 for (int st = 0; st < nsteps; ++st) {
@@ -359,7 +372,8 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p,
                     x.w[e] = lo | (hi << 16);
                 }
 #pragma unroll
-                for (int i = 0; i < CT; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
+                for (int i = 0; i < CT; ++i)
+                    if (ct_live[t][i]) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], x.b, acc[t][i], 0, 0, 0);
             }
         }
         if (STAMP) c2 = __builtin_readcyclecounter();
@@ -385,11 +399,13 @@ __global__ __launch_bounds__(512, 2 * BPC) void conv_wgrad_band_kernel(WBandP p,
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         if (!kt_live[t]) continue;
-        const int k = (wave + 8 * t) * 32 + r;
+        const int k = kts[t] * 32 + r;
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CT; ++i) {
+            if (!ct_live[t][i]) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) pw[(long)(i * 32 + acc_row(e, lane)) * K + k] = acc[t][i][e];
+        }
     }
     if (p.partial_b) {
         float* red = (float*)smem;                            // bands are dead: reuse LDS, [NT][8] floats = 16 KB
