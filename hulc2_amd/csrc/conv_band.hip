@@ -31,8 +31,8 @@ namespace {
 // vector memory returns in order and the stores of the tile loop are counted with the loads) then covers the prefetch and stores that are a
 // tile old, not the write acknowledgements of the stores just issued (single band: +1.4 us per unit, HULC_BAND_DBG=2) — and one workgroup
 // barrier per unit instead of two.
-template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32, int BITS, bool DB>
-__global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
+template <int C, int NSET, int TH, int TW, int S, int MAXCH, bool MULTI, bool XF32, int BITS, bool DB, bool STAMP = false>
+__global__ __launch_bounds__(512) void conv_band_kernel(BandP p, unsigned long long* stamps = nullptr) {
     constexpr int NT = 512;
     constexpr int K = TH * TW * C, KSTEPS = K / 16;
     constexpr int PS = C * 2 + 16;          // band pixel stride (bytes): +16 B keeps ds_read_b128 conflict-free
@@ -152,9 +152,12 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
     char* band = band0;
     if (unit < nunits) stage_store(unit, band);
     __syncthreads();
+    // (STAMP, HULC_BANDK_STAMPS: per-wave cycle sums of a unit's phases — issue of the next band's loads | tile loop | barrier | LDS stores + barrier)
+    unsigned long long t_ph[4] = {0, 0, 0, 0}, t_units = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     for (; unit < nunits; unit += gridDim.x) {
         const int next = unit + gridDim.x;
         const bool have_next = next < nunits && !(p.dbg & 4);
+        if (STAMP) c0 = __builtin_readcyclecounter();
         // (round 6, single band) the next band's loads leave WAVE BY WAVE over the tile loop, each wave in front of its own tile slot, instead
         // of as one burst of 8 x MAXCH load instructions queueing at the CU's vector-memory path while no wave multiplies (the weight-gradient
         // kernels' finding, tools/study/wband_stamps.py).  HULC_BAND_DBG bit 64: the burst.  With two bands the band is written early: burst.
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
         const int slot = (wave * my_tiles) >> 3;                             // (waves w and w + 4 share a SIMD: half the loop apart)
         bool issued = !have_next || !stagger;
         int it = 0;
+        if (STAMP) c1 = __builtin_readcyclecounter();
         for (int tile = part; tile < ntile; tile += WPS, ++it) {
             if (!issued && it == slot) { stage_load(next); issued = true; }
             int q = tile * 32 + r;
@@ -299,15 +303,27 @@ __global__ __launch_bounds__(512) void conv_band_kernel(BandP p) {
             }
         }
         if (!issued) stage_load(next);                       // (a wave without a tile in this unit)
+        if (STAMP) c2 = __builtin_readcyclecounter();
         if (DB) {
             if (!staged) stage_store(next, band_next);       // (a wave with fewer than two tiles in this unit)
             __syncthreads();                                 // every wave is done reading this band and has written its part of the next
             band = band_next;
         } else {
             __syncthreads();                                 // every wave is done reading this band
+            if (STAMP) c3 = __builtin_readcyclecounter();
             if (have_next) stage_store(next, band);
             __syncthreads();
         }
+        if (STAMP) {
+            const unsigned long long c4 = __builtin_readcyclecounter();
+            t_ph[0] += c1 - c0; t_ph[1] += c2 - c1; t_ph[2] += c3 - c2; t_ph[3] += c4 - c3; t_units += 1;
+        }
+    }
+    if (STAMP && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 5;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = t_ph[e];
+        o[4] = t_units;
     }
 }
 
@@ -345,7 +361,7 @@ int launch_band_x(BandP& p, hipStream_t s) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
             attr_set = true;
         }
-        kern<<<grid, 512, lds, s>>>(p);
+        kern<<<grid, 512, lds, s>>>(p, nullptr);
     } else {
         auto kern = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32, BITS, DB>;
         static bool attr_set = false;
@@ -353,7 +369,17 @@ int launch_band_x(BandP& p, hipStream_t s) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
             attr_set = true;
         }
-        kern<<<grid, 512, lds, s>>>(p);
+        const char* se = getenv("HULC_BANDK_STAMPS");          // <device address of grid x 8 x 5 uint64>: the instrumented instance (conv2 forward)
+        if (se && *se && C == 32 && !XF32 && !DB && BITS == 1) {
+            auto kst = conv_band_kernel<C, NSET, TH, TW, S, MAXCH, false, XF32, BITS, DB, true>;
+            static bool st_attr = false;
+            if (!st_attr) {
+                if (hipFuncSetAttribute((const void*)kst, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -2;
+                st_attr = true;
+            }
+            kst<<<grid, 512, lds, s>>>(p, (unsigned long long*)strtoull(se, nullptr, 0));
+        } else
+        kern<<<grid, 512, lds, s>>>(p, nullptr);
     }
     return 0;
 }
